@@ -1,0 +1,215 @@
+/* akz.h — C ABI of the MI355X-native AKAZE + brute-force Hamming front-end.
+ *
+ * This is the drop-in boundary for the reference's data-parallel hot path.
+ * Every entry point names the reference interface it replaces (paths relative to the rust-cv/cv
+ * checkout).  Plain pointers and sizes only: no C++/torch/HIP types appear in a signature
+ * (device pointers and streams travel as void*).
+ *
+ * Conventions
+ *   - every function returns an int32_t status: AKZ_OK (0) or a negative akz_status;
+ *     nothing throws, nothing aborts, akz_strerror() names the code;
+ *   - the library never retains a caller pointer after the call returns;
+ *   - a context is bound to one HIP device and one internal stream; use one context per host
+ *     thread.  Contexts on different devices are independent;
+ *   - "capacity" arguments are in elements.  When an output does not fit, the call returns
+ *     AKZ_E_CAPACITY and *n_out holds the required element count;
+ *   - there is NO CPU fallback: if no HIP device is usable akz_create() fails with AKZ_E_NO_DEVICE.
+ */
+#ifndef AKZ_H
+#define AKZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum akz_status {
+    AKZ_OK = 0,
+    AKZ_E_INVALID = -1,    /* null pointer, bad dimension, unsupported config value */
+    AKZ_E_NO_DEVICE = -2,  /* no usable HIP device / device index out of range */
+    AKZ_E_OOM = -3,        /* hipMalloc failed */
+    AKZ_E_CAPACITY = -4,   /* caller buffer too small; *n_out = required */
+    AKZ_E_HIP = -5,        /* a HIP runtime call failed (akz_last_hip_error()) */
+    AKZ_E_TOO_LARGE = -6,  /* image or batch exceeds what the context was created for */
+    AKZ_E_INTERNAL = -7    /* device-side overflow of an internal work list */
+} akz_status;
+
+/* akaze::Akaze — akaze/src/lib.rs:109-142 (fields), :169-185 (Default), :147-166 (new/sparse/dense).
+ * Field-for-field; usize -> uint64_t. */
+typedef struct akz_config {
+    uint64_t maximum_features;        /* usize::MAX by default */
+    uint32_t num_sublevels;           /* 4 */
+    uint32_t max_octave_evolution;    /* 4 */
+    double base_scale_offset;         /* 1.6 */
+    double initial_contrast;          /* 0.001 (unused by the reference as well) */
+    double contrast_percentile;       /* 0.7 */
+    uint64_t contrast_factor_num_bins; /* 300 */
+    double derivative_factor;         /* 1.5 */
+    double detector_threshold;        /* 0.001; sparse 0.01; dense 0.0001 */
+    uint64_t descriptor_channels;     /* 3 */
+    uint64_t descriptor_pattern_size; /* 10 */
+} akz_config;
+
+/* akaze::KeyPoint — akaze/src/lib.rs:69-93. point=(x,y). 28 bytes, no padding. */
+typedef struct akz_keypoint {
+    float x, y;
+    float response;
+    float size;
+    float angle;
+    uint32_t octave;
+    uint32_t class_id;
+} akz_keypoint;
+
+/* bitarray::BitArray<64> as filled by akaze/src/descriptors.rs:181-202: bit i lives in
+ * bytes[i >> 3] at position (i & 7); 486 bits used, bits 486..511 are zero. */
+typedef struct akz_descriptor {
+    uint8_t bytes[64];
+} akz_descriptor;
+
+/* space::Neighbor<u32> — what LinearKnn::knn returns (call sites akaze/tests/estimate_pose.rs:82-88,
+ * tutorial-code/chapter5-geometric-verification/src/main.rs:155-161). */
+typedef struct akz_neighbor {
+    uint32_t index;
+    uint32_t distance;
+} akz_neighbor;
+
+typedef struct akz_ctx akz_ctx;
+
+/* Akaze::default() (akaze/src/lib.rs:169-185). */
+void akz_config_default(akz_config* cfg);
+
+/* Context = the pre-allocated per-device pyramid for up to max_batch frames of up to
+ * max_w x max_h pixels (what Akaze::allocate_evolutions, akaze/src/evolution.rs:80-126, allocates
+ * per call in the reference).  max_keypoints bounds the per-frame candidate/keypoint lists
+ * (0 = default 16384). */
+int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h,
+                   int32_t max_batch, uint32_t max_keypoints, akz_ctx** out);
+int32_t akz_destroy(akz_ctx* ctx);
+
+/* Akaze::extract on a DynamicImage::ImageLuma8 (akaze/src/lib.rs:295, image.rs:47-56):
+ * img is host memory, h rows of w bytes, `stride` bytes apart.  Outputs are index-aligned,
+ * ordered by response descending, exactly as the reference returns them. */
+int32_t akz_extract_gray_u8(akz_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                            akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
+
+/* Akaze::extract_from_gray_float_image (akaze/src/lib.rs:309): f32 pixels in [0,1], stride in
+ * elements. */
+int32_t akz_extract_gray_f32(akz_ctx* ctx, const float* img, int32_t w, int32_t h, int32_t stride,
+                             akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
+
+/* Batched extract: n host images of identical size (what a caller looping Akaze::extract over
+ * frames does, cv-sfm/src/lib.rs:2200-2204).  fmt: 0 = u8, 1 = f32.  kps/descs hold
+ * n * cap_per_img entries, frame i at offset i*cap_per_img; n_out[i] = count of frame i. */
+int32_t akz_extract_batch(akz_ctx* ctx, const void* const* imgs, int32_t fmt, int32_t n, int32_t w,
+                          int32_t h, int32_t stride, akz_keypoint* kps, akz_descriptor* descs,
+                          uint32_t cap_per_img, uint32_t* n_out);
+
+/* Zero-copy batched extract for a device-resident pipeline: d_imgs is ONE device buffer of n
+ * frames (frame-major, tightly packed w*h elements each), outputs are device buffers laid out
+ * as in akz_extract_batch; d_n_out is a device array of n counts.  Work is enqueued on the
+ * context's stream; `stream_to_wait` (a hipStream_t passed as void*, may be NULL) is the stream
+ * that produced d_imgs.  The call returns after enqueueing; akz_sync() waits. */
+int32_t akz_extract_batch_device(akz_ctx* ctx, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
+                                 int32_t h, void* d_kps, void* d_descs, uint32_t cap_per_img,
+                                 void* d_n_out, void* stream_to_wait);
+int32_t akz_sync(akz_ctx* ctx);
+/* The context's hipStream_t, as void*, so callers can order their own work after ours. */
+void* akz_stream(akz_ctx* ctx);
+
+/* Scale-space only (BASELINE.json configs[1] "scale-space kernels only"): runs A1..A11 of
+ * SURVEY.md §8a — create_nonlinear_scale_space (akaze/src/lib.rs:193-258) + detector_response
+ * (akaze/src/detector_response.rs:33-57) — on n device-resident frames and leaves Lt/Lx/Ly/Ldet
+ * of every level in the context. */
+int32_t akz_scale_space_device(akz_ctx* ctx, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
+                               int32_t h, void* stream_to_wait);
+
+/* ---- pyramid introspection / parity taps (what Akaze::allocate_evolutions returns) ---- */
+typedef struct akz_level_info {
+    int32_t width, height;
+    uint32_t octave, sublevel;
+    double esigma, etime;
+    uint32_t n_fed_steps;
+    uint32_t deriv_sigma; /* round(esigma*derivative_factor/2^octave), detector_response.rs:11-13 */
+} akz_level_info;
+int32_t akz_num_levels(akz_ctx* ctx, int32_t w, int32_t h, int32_t* n_levels);
+int32_t akz_level(akz_ctx* ctx, int32_t w, int32_t h, int32_t level, akz_level_info* out);
+int32_t akz_fed_tau(akz_ctx* ctx, int32_t w, int32_t h, int32_t level, double* tau, uint32_t cap,
+                    uint32_t* n_out);
+enum { AKZ_BUF_LT = 0, AKZ_BUF_LSMOOTH = 1, AKZ_BUF_LX = 2, AKZ_BUF_LY = 3, AKZ_BUF_LDET = 4,
+       AKZ_BUF_LFLOW = 5 };
+/* Copy one level buffer of frame `img` of the most recent batch to host `out` (w*h floats). */
+int32_t akz_debug_get_level(akz_ctx* ctx, int32_t img, int32_t level, int32_t which, float* out);
+/* Contrast factor (compute_contrast_factor, akaze/src/contrast_factor.rs:16-64) of frame img. */
+int32_t akz_debug_get_contrast(akz_ctx* ctx, int32_t img, double* out);
+/* Keypoint list after a named stage of frame img of the most recent batch:
+ * 0 = find_scale_space_extrema output (scale_space_extrema.rs:14-143),
+ * 1 = after do_subpixel_refinement + orientation (:297-362), 2 = after sort+truncate (lib.rs:326-327). */
+int32_t akz_debug_get_keypoints(akz_ctx* ctx, int32_t img, int32_t stage, akz_keypoint* out,
+                                uint32_t cap, uint32_t* n_out);
+
+/* ---- stand-alone image ops (akaze::image public API, akaze/src/image.rs:202-389) ---- */
+/* gaussian_kernel(r, kernel_size) — image.rs:360-374.  Host-only scalar math. */
+int32_t akz_gaussian_kernel(float r, uint32_t kernel_size, float* out);
+/* horizontal_filter / vertical_filter / separable_filter — image.rs:202-340: clamp-border
+ * correlation with the reference's 4-lane accumulation order.  Host buffers in and out. */
+int32_t akz_horizontal_filter(akz_ctx* ctx, const float* img, int32_t w, int32_t h,
+                              const float* kernel, uint32_t ksize, float* out);
+int32_t akz_vertical_filter(akz_ctx* ctx, const float* img, int32_t w, int32_t h,
+                            const float* kernel, uint32_t ksize, float* out);
+/* GrayFloatImage::half_size — image.rs:154-199. out is (w/2)*(h/2). */
+int32_t akz_half_size(akz_ctx* ctx, const float* img, int32_t w, int32_t h, float* out);
+
+/* ---- brute-force Hamming matcher (space::LinearKnn{metric: Hamming} + bitarray::BitArray<64>) ---- */
+typedef struct hm_ctx hm_ctx;
+int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out);
+int32_t hm_destroy(hm_ctx* ctx);
+/* LinearKnn::knn(q, 2) for every query (akaze/tests/estimate_pose.rs:82-88): out[2*i+0/1] are the
+ * nearest and second-nearest targets of query i under Hamming distance over all 64 bytes, ordered
+ * by (distance, index) ascending — the lowest index wins ties.  nt < 2 is AKZ_E_INVALID (the
+ * reference asserts two neighbours, estimate_pose.rs:89). Host buffers. */
+int32_t hm_knn2(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t,
+                uint32_t nt, akz_neighbor* out);
+/* matching()/symmetric_matching() of tutorial ch5 main.rs:154-200 and cv-sfm/src/lib.rs:3097-3133,
+ * and match_descriptors() of akaze/tests/estimate_pose.rs:78-97.
+ *   rule 0: accept iff d0 + param_u <  d1   (tutorial, param_u = 24)
+ *   rule 1: accept iff d0 + param_u <= d1   (cv-sfm better_by = 24); returns no matches when either
+ *           side has fewer than 2 descriptors (cv-sfm/src/lib.rs:3099-3101)
+ *   rule 2: accept iff (f32)d0 < (f32)d1 * param_f   (Lowe ratio, estimate_pose.rs:91-93)
+ * symmetric != 0 keeps [a,b] only when the reverse match of b is a.  pairs = [a0,b0,a1,b1,...],
+ * ascending a. */
+enum { HM_RULE_BETTER_BY_STRICT = 0, HM_RULE_BETTER_BY = 1, HM_RULE_LOWE = 2 };
+int32_t hm_match(hm_ctx* ctx, const akz_descriptor* a, uint32_t na, const akz_descriptor* b,
+                 uint32_t nb, int32_t rule, uint32_t param_u, float param_f, int32_t symmetric,
+                 uint32_t* pairs, uint32_t cap, uint32_t* n_out);
+/* Device-resident batched form: `n_pairs` independent (a,b) problems.  d_a/d_b are frame-major
+ * descriptor blocks of cap_per_img entries each; d_na/d_nb the per-frame counts (device).
+ * Problem p matches block ia[p] of d_a against block ib[p] of d_b (host index arrays).
+ * d_pairs holds n_pairs*cap_per_img [a,b] pairs; d_n_out n_pairs counts.  Enqueued on the hm
+ * context's stream after `stream_to_wait`. */
+int32_t hm_match_batch_device(hm_ctx* ctx, const void* d_a, const void* d_na, const void* d_b,
+                              const void* d_nb, uint32_t cap_per_img, const uint32_t* ia,
+                              const uint32_t* ib, uint32_t n_pairs, int32_t rule, uint32_t param_u,
+                              float param_f, int32_t symmetric, void* d_pairs, void* d_n_out,
+                              void* stream_to_wait);
+int32_t hm_sync(hm_ctx* ctx);
+void* hm_stream(hm_ctx* ctx);
+
+/* ---- misc ---- */
+const char* akz_strerror(int32_t status);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text. */
+int32_t akz_last_hip_error(void);
+const char* akz_last_hip_error_string(void);
+const char* akz_version(void);
+
+/* HIP-event timing of the dominant kernels of the last batch (for bench.py's roofline object):
+ * which: 0 = FED diffusion steps (calculate_step), 1 = whole scale space, 2 = whole extract.
+ * Returns accumulated milliseconds and launch count since akz_timing_reset(). */
+int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
+int32_t akz_timing_reset(akz_ctx* ctx);
+int32_t akz_timing_get(akz_ctx* ctx, int32_t which, double* ms, uint64_t* launches, uint64_t* units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKZ_H */

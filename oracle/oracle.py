@@ -1,0 +1,308 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never by anything under cv_amd/.  See akaze_oracle.c / match_oracle.c for what each function
+restates and which reference file:line it follows.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class Config(C.Structure):
+    """akz_config == akaze::Akaze (akaze/src/lib.rs:109-142)."""
+    _fields_ = [
+        ("maximum_features", C.c_uint64),
+        ("num_sublevels", C.c_uint32),
+        ("max_octave_evolution", C.c_uint32),
+        ("base_scale_offset", C.c_double),
+        ("initial_contrast", C.c_double),
+        ("contrast_percentile", C.c_double),
+        ("contrast_factor_num_bins", C.c_uint64),
+        ("derivative_factor", C.c_double),
+        ("detector_threshold", C.c_double),
+        ("descriptor_channels", C.c_uint64),
+        ("descriptor_pattern_size", C.c_uint64),
+    ]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("octave", C.c_uint32), ("sublevel", C.c_uint32),
+        ("esigma", C.c_double), ("etime", C.c_double),
+        ("n_fed_steps", C.c_uint32), ("deriv_sigma", C.c_uint32),
+    ]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                     ("angle", "<f4"), ("octave", "<u4"), ("class_id", "<u4")])
+assert KP_DTYPE.itemsize == 28
+NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
+
+OPT_REDUCE, OPT_FMA, OPT_HALFSUM, OPT_TRIG = 0, 1, 2, 3
+BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6, "Lyy": 7, "Lxy": 8}
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_num_levels.argtypes = [C.c_void_p]
+        L.orc_level.argtypes = [C.c_void_p, C.c_int, C.POINTER(LevelInfo)]
+        L.orc_fed_tau.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.orc_extract_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_extract_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_scale_space_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_level_buffer.restype = fp
+        L.orc_level_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_contrast.restype = C.c_double
+        L.orc_contrast.argtypes = [C.c_void_p]
+        L.orc_num_candidates.restype = C.c_uint32
+        L.orc_num_candidates.argtypes = [C.c_void_p]
+        L.orc_keypoints.restype = C.c_uint32
+        L.orc_keypoints.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.orc_descriptors.restype = C.c_void_p
+        L.orc_descriptors.argtypes = [C.c_void_p]
+        L.orc_config_default.argtypes = [C.POINTER(Config)]
+        L.orc_gaussian_kernel.argtypes = [C.c_float, C.c_int, C.c_void_p]
+        L.orc_horizontal_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_vertical_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_gaussian_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_half_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_scharr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_scharr_kernel.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_contrast_factor.restype = C.c_double
+        L.orc_contrast_factor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint64]
+        L.orc_pm_g2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+        L.orc_fed_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.orc_fed_tau_by_process_time.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]
+        L.orc_u8_to_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_set_option.argtypes = [C.c_int, C.c_int]
+        L.orc_get_option.argtypes = [C.c_int]
+        L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
+                                C.c_float, C.c_int, C.c_void_p, C.c_uint32]
+        L.orc_pm_atan2f_v.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_pm_sincosf_v.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def set_option(which, value):
+    lib().orc_set_option(which, value)
+
+
+def default_config(threshold=None, maximum_features=None):
+    cfg = Config()
+    lib().orc_config_default(C.byref(cfg))
+    if threshold is not None:
+        cfg.detector_threshold = threshold
+    if maximum_features is not None:
+        cfg.maximum_features = maximum_features
+    return cfg
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def gaussian_kernel(r, ksize):
+    out = np.empty(ksize, np.float32)
+    lib().orc_gaussian_kernel(r, ksize, out.ctypes.data)
+    return out
+
+
+def horizontal_filter(img, kernel):
+    img = _f32(img); k = _f32(kernel); out = np.empty_like(img)
+    lib().orc_horizontal_filter(img.ctypes.data, img.shape[1], img.shape[0], k.ctypes.data, len(k), out.ctypes.data)
+    return out
+
+
+def vertical_filter(img, kernel):
+    img = _f32(img); k = _f32(kernel); out = np.empty_like(img)
+    lib().orc_vertical_filter(img.ctypes.data, img.shape[1], img.shape[0], k.ctypes.data, len(k), out.ctypes.data)
+    return out
+
+
+def gaussian_blur(img, r):
+    img = _f32(img); out = np.empty_like(img)
+    lib().orc_gaussian_blur(img.ctypes.data, img.shape[1], img.shape[0], r, out.ctypes.data)
+    return out
+
+
+def half_size(img):
+    img = _f32(img)
+    out = np.empty((img.shape[0] // 2, img.shape[1] // 2), np.float32)
+    lib().orc_half_size(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data)
+    return out
+
+
+def scharr(img, sigma, vertical):
+    img = _f32(img); out = np.empty_like(img)
+    lib().orc_scharr(img.ctypes.data, img.shape[1], img.shape[0], sigma, int(vertical), out.ctypes.data)
+    return out
+
+
+def contrast_factor(img, percentile=0.7, scale=1.0, nbins=300):
+    img = _f32(img)
+    return lib().orc_contrast_factor(img.ctypes.data, img.shape[1], img.shape[0], percentile, scale, nbins)
+
+
+def pm_g2(lx, ly, k):
+    lx = _f32(lx); ly = _f32(ly); out = np.empty_like(lx)
+    lib().orc_pm_g2(lx.ctypes.data, ly.ctypes.data, lx.size, k, out.ctypes.data)
+    return out
+
+
+def fed_step(L, c, tau):
+    L = _f32(L).copy(); c = _f32(c)
+    lib().orc_fed_step(L.ctypes.data, c.ctypes.data, L.shape[1], L.shape[0], np.float32(tau))
+    return L
+
+
+def u8_to_f32(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty(img.shape, np.float32)
+    lib().orc_u8_to_f32(img.ctypes.data, img.shape[1], img.shape[0], img.shape[1], out.ctypes.data)
+    return out
+
+
+class Akaze:
+    """CPU oracle of akaze::Akaze::extract for one image size."""
+
+    def __init__(self, w, h, cfg=None):
+        self.cfg = cfg if cfg is not None else default_config()
+        self.w, self.h = w, h
+        self._c = lib().orc_create(C.byref(self.cfg), w, h)
+
+    def close(self):
+        if self._c:
+            lib().orc_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_levels(self):
+        return lib().orc_num_levels(self._c)
+
+    def level(self, i):
+        info = LevelInfo()
+        assert lib().orc_level(self._c, i, C.byref(info)) == 0
+        return info
+
+    def fed_tau(self, i):
+        buf = (C.c_double * 256)()
+        n = lib().orc_fed_tau(self._c, i, buf, 256)
+        return np.array(buf[:n], np.float64)
+
+    def extract(self, img):
+        """img: HxW uint8 or float32. Returns (keypoints structured array, descriptors [n,64] u8)."""
+        img = np.ascontiguousarray(img)
+        assert img.shape == (self.h, self.w), (img.shape, self.h, self.w)
+        if img.dtype == np.uint8:
+            n = lib().orc_extract_u8(self._c, img.ctypes.data, self.w)
+        else:
+            img = _f32(img)
+            n = lib().orc_extract_f32(self._c, img.ctypes.data)
+        return self.keypoints(3), self.descriptors()
+
+    def scale_space(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        lib().orc_scale_space_u8(self._c, img.ctypes.data, self.w)
+
+    def keypoints(self, stage):
+        p = C.c_void_p()
+        n = lib().orc_keypoints(self._c, stage, C.byref(p))
+        if n == 0:
+            return np.empty(0, KP_DTYPE)
+        buf = (C.c_char * (n * 28)).from_address(p.value)
+        return np.frombuffer(buf, KP_DTYPE, n).copy()
+
+    def descriptors(self):
+        p = C.c_void_p()
+        n = lib().orc_keypoints(self._c, 3, C.byref(p))
+        d = lib().orc_descriptors(self._c)
+        if n == 0:
+            return np.empty((0, 64), np.uint8)
+        buf = (C.c_char * (n * 64)).from_address(d)
+        return np.frombuffer(buf, np.uint8, n * 64).reshape(n, 64).copy()
+
+    def buffer(self, level, name):
+        w = C.c_int(); h = C.c_int()
+        p = lib().orc_level_buffer(self._c, level, BUF[name], C.byref(w), C.byref(h))
+        if not p or w.value == 0:
+            return None
+        return np.ctypeslib.as_array(p, (h.value, w.value)).copy()
+
+    @property
+    def contrast(self):
+        return lib().orc_contrast(self._c)
+
+    @property
+    def num_candidates(self):
+        return lib().orc_num_candidates(self._c)
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 64)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 64)
+    out = np.empty((len(q), 2), NB_DTYPE)
+    r = lib().orc_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data)
+    if r != 0:
+        raise ValueError("knn2 needs at least two targets")
+    return out
+
+
+RULE_STRICT, RULE_BETTER_BY, RULE_LOWE = 0, 1, 2
+
+
+def match(a, b, rule=RULE_STRICT, param_u=24, param_f=0.5, symmetric=True):
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 64)
+    b = np.ascontiguousarray(b, np.uint8).reshape(-1, 64)
+    cap = max(len(a), 1)
+    pairs = np.empty((cap, 2), np.uint32)
+    n = lib().orc_match(a.ctypes.data, len(a), b.ctypes.data, len(b), rule, param_u, param_f,
+                        int(symmetric), pairs.ctypes.data, cap)
+    if n < 0:
+        raise ValueError("match: fewer than two descriptors on a side")
+    return pairs[:n].copy()
+
+
+def pm_atan2f(y, x):
+    y = _f32(y); x = _f32(x); out = np.empty_like(y)
+    lib().orc_pm_atan2f_v(y.ctypes.data, x.ctypes.data, y.size, out.ctypes.data)
+    return out
+
+
+def pm_sincosf(a):
+    a = _f32(a); s = np.empty_like(a); c = np.empty_like(a)
+    lib().orc_pm_sincosf_v(a.ctypes.data, a.size, s.ctypes.data, c.ctypes.data)
+    return s, c
