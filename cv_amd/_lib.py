@@ -1,0 +1,122 @@
+"""ctypes loader for cv_amd/lib/libakz.so (the C ABI of include/akz.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, every entry point
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libakz.so")
+
+
+class AkzError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib().akz_strerror(status).decode()
+        hip = lib().akz_last_hip_error()
+        if status == -5 and hip:
+            msg += f" (hip {hip}: {lib().akz_last_hip_error_string().decode()})"
+        super().__init__(f"{what}: {msg}" if what else msg)
+
+
+class Config(C.Structure):
+    """akz_config == akaze::Akaze (akaze/src/lib.rs:109-142)."""
+    _fields_ = [
+        ("maximum_features", C.c_uint64),
+        ("num_sublevels", C.c_uint32),
+        ("max_octave_evolution", C.c_uint32),
+        ("base_scale_offset", C.c_double),
+        ("initial_contrast", C.c_double),
+        ("contrast_percentile", C.c_double),
+        ("contrast_factor_num_bins", C.c_uint64),
+        ("derivative_factor", C.c_double),
+        ("detector_threshold", C.c_double),
+        ("descriptor_channels", C.c_uint64),
+        ("descriptor_pattern_size", C.c_uint64),
+    ]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("octave", C.c_uint32), ("sublevel", C.c_uint32),
+        ("esigma", C.c_double), ("etime", C.c_double),
+        ("n_fed_steps", C.c_uint32), ("deriv_sigma", C.c_uint32),
+    ]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                     ("angle", "<f4"), ("octave", "<u4"), ("class_id", "<u4")])
+NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
+assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
+
+# every symbol include/akz.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "akz_config_default", "akz_create", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_f32",
+    "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
+    "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
+    "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
+    "akz_half_size", "hm_create", "hm_destroy", "hm_knn2", "hm_match", "hm_match_batch_device", "hm_sync",
+    "hm_stream", "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
+    "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m cv_amd.build` (hipcc, gfx950). "
+            "cv_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+    L.akz_strerror.restype = C.c_char_p
+    L.akz_strerror.argtypes = [i32]
+    L.akz_last_hip_error_string.restype = C.c_char_p
+    L.akz_version.restype = C.c_char_p
+    L.akz_config_default.argtypes = [C.POINTER(Config)]
+    L.akz_create.argtypes = [C.POINTER(Config), i32, i32, i32, i32, u32, C.POINTER(vp)]
+    L.akz_destroy.argtypes = [vp]
+    L.akz_extract_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
+    L.akz_extract_gray_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
+    L.akz_extract_batch.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, vp, u32, vp]
+    L.akz_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, u32, vp, vp]
+    L.akz_scale_space_device.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.akz_sync.argtypes = [vp]
+    L.akz_stream.restype = vp
+    L.akz_stream.argtypes = [vp]
+    L.akz_num_levels.argtypes = [vp, i32, i32, C.POINTER(i32)]
+    L.akz_level.argtypes = [vp, i32, i32, i32, C.POINTER(LevelInfo)]
+    L.akz_fed_tau.argtypes = [vp, i32, i32, i32, vp, u32, C.POINTER(u32)]
+    L.akz_debug_get_level.argtypes = [vp, i32, i32, i32, vp]
+    L.akz_debug_get_contrast.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    L.akz_debug_get_keypoints.argtypes = [vp, i32, i32, vp, u32, C.POINTER(u32)]
+    L.akz_gaussian_kernel.argtypes = [C.c_float, u32, vp]
+    L.akz_horizontal_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]
+    L.akz_vertical_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]
+    L.akz_half_size.argtypes = [vp, vp, i32, i32, vp]
+    L.hm_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
+    L.hm_destroy.argtypes = [vp]
+    L.hm_knn2.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
+    L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]
+    L.hm_sync.argtypes = [vp]
+    L.hm_stream.restype = vp
+    L.hm_stream.argtypes = [vp]
+    L.akz_timing_enable.argtypes = [vp, i32]
+    L.akz_timing_reset.argtypes = [vp]
+    L.akz_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status != 0:
+        raise AkzError(status, what)

@@ -1,0 +1,64 @@
+"""Builds cv_amd/lib/libakz.so (the C-ABI library of include/akz.h) with hipcc for gfx950.
+
+The flags are part of the parity contract: -ffp-contract=off (rustc never contracts to FMA),
+no fast-math, IEEE-correct f32 divide/sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libakz.so")
+SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "akz_plan.cpp"]
+HEADERS = ["akz_common.h", "akz_ctx.h", "../../include/akz.h", "../../include/akz_portable_math.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, "lib", s.replace(".", "_") + ".o")
+        cmd = [hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if out and (verbose or p.returncode != 0):
+            sys.stderr.write(out.decode(errors="replace"))
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"hipcc failed on {s}\n")
+    if failed:
+        raise RuntimeError("libakz build failed")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,589 @@
+// akz_api.hip — the extern "C" boundary declared in include/akz.h: context lifetime, arena
+// carving, host/device entry points, parity taps, timing.  Host-side glue only; the kernels live in
+// akz_scale_space.hip / akz_keypoints.hip / hm_match.hip.
+#include <math.h>
+#include <stdio.h>
+
+#include <new>
+
+#include "akz_ctx.h"
+
+thread_local int g_akz_last_hip = 0;
+
+extern "C" const char* akz_version(void) { return "cv_amd-akz 0.1 (gfx950)"; }
+
+extern "C" const char* akz_strerror(int32_t s)
+{
+    switch (s) {
+    case AKZ_OK: return "ok";
+    case AKZ_E_INVALID: return "invalid argument or unsupported configuration";
+    case AKZ_E_NO_DEVICE: return "no usable HIP device";
+    case AKZ_E_OOM: return "out of device memory";
+    case AKZ_E_CAPACITY: return "output buffer too small";
+    case AKZ_E_HIP: return "HIP runtime error";
+    case AKZ_E_TOO_LARGE: return "image or batch larger than the context was created for";
+    case AKZ_E_INTERNAL: return "internal work list overflow (raise max_keypoints)";
+    default: return "unknown status";
+    }
+}
+extern "C" int32_t akz_last_hip_error(void) { return g_akz_last_hip; }
+extern "C" const char* akz_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_akz_last_hip); }
+
+extern "C" void akz_config_default(akz_config* c)
+{
+    if (!c) return;
+    // Akaze::default(), akaze/src/lib.rs:169-185
+    c->maximum_features = UINT64_MAX;
+    c->num_sublevels = 4;
+    c->max_octave_evolution = 4;
+    c->base_scale_offset = 1.6;
+    c->initial_contrast = 0.001;
+    c->contrast_percentile = 0.7;
+    c->contrast_factor_num_bins = 300;
+    c->derivative_factor = 1.5;
+    c->detector_threshold = 0.001;
+    c->descriptor_channels = 3;
+    c->descriptor_pattern_size = 10;
+}
+
+// ---- timers ---------------------------------------------------------------------------------
+static hipEvent_t timer_event(AkzTimer* t)
+{
+    if (!t->pool.empty()) {
+        hipEvent_t e = t->pool.back();
+        t->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void akz_timer_begin(akz_ctx* c, AkzTimer* t)
+{
+    if (!c->timing) return;
+    t->cur_start = timer_event(t);
+    if (t->cur_start) hipEventRecord(t->cur_start, c->stream);
+}
+void akz_timer_end(akz_ctx* c, AkzTimer* t, uint64_t launches, uint64_t units)
+{
+    if (!c->timing || !t->cur_start) return;
+    hipEvent_t stop = timer_event(t);
+    if (!stop) return;
+    hipEventRecord(stop, c->stream);
+    t->pending.emplace_back(t->cur_start, stop);
+    t->cur_start = nullptr;
+    t->launches += launches;
+    t->units += units;
+}
+static void timer_resolve(AkzTimer* t)
+{
+    for (auto& pr : t->pending) {
+        float ms = 0.0f;
+        hipEventSynchronize(pr.second);
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) t->ms += (double)ms;
+        t->pool.push_back(pr.first);
+        t->pool.push_back(pr.second);
+    }
+    t->pending.clear();
+}
+static void timer_free(AkzTimer* t)
+{
+    timer_resolve(t);
+    for (auto e : t->pool) hipEventDestroy(e);
+    t->pool.clear();
+}
+
+// ---- context ---------------------------------------------------------------------------------
+static int32_t validate_config(const akz_config* cfg)
+{
+    if (cfg->num_sublevels == 0 || cfg->num_sublevels > 8) return AKZ_E_INVALID;
+    if (cfg->max_octave_evolution == 0 || cfg->max_octave_evolution > 8) return AKZ_E_INVALID;
+    if (!(cfg->base_scale_offset > 0.0) || !(cfg->derivative_factor > 0.0)) return AKZ_E_INVALID;
+    if (cfg->contrast_factor_num_bins == 0 || cfg->contrast_factor_num_bins > 510) return AKZ_E_INVALID;
+    if (cfg->descriptor_channels < 1 || cfg->descriptor_channels > 3) return AKZ_E_INVALID;
+    if (cfg->descriptor_pattern_size < 1 || cfg->descriptor_pattern_size > 100) return AKZ_E_INVALID;
+    // the fused Gaussian tile kernel is instantiated for the radii of sigma = base_scale_offset in
+    // (1.5, 2.0] (9 taps) — the reference default 1.6 — and the fixed sigma 1.0 (5 taps)
+    if (akz_gaussian_radius((float)cfg->base_scale_offset) != 4) return AKZ_E_INVALID;
+    return AKZ_OK;
+}
+
+extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h, int32_t max_batch,
+                              uint32_t max_keypoints, akz_ctx** out)
+{
+    if (!cfg || !out || max_w < 3 || max_h < 3 || max_batch < 1 || max_w > 65535 || max_h > 65535) return AKZ_E_INVALID;
+    AKZ_TRY(validate_config(cfg));
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_akz_last_hip = (int)e;
+        return AKZ_E_NO_DEVICE;  // no CPU fallback, by design
+    }
+    AKZ_HIP(hipSetDevice(device));
+    akz_ctx* c = new (std::nothrow) akz_ctx();
+    if (!c) return AKZ_E_OOM;
+    c->cfg = *cfg;
+    c->device = device;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->max_batch = max_batch;
+    c->max_kp = max_keypoints ? max_keypoints : 16384u;
+    if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
+    c->max_cand = c->max_kp * 4u;
+    const char* keep = getenv("AKZ_KEEP_ALL");
+    c->keep_all = keep && keep[0] == '1';
+    int32_t st = AKZ_OK;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) st = AKZ_E_HIP;
+    if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
+    if (st != AKZ_OK) {
+        akz_destroy(c);
+        return st;
+    }
+    *out = c;
+    return AKZ_OK;
+}
+
+extern "C" int32_t akz_destroy(akz_ctx* c)
+{
+    if (!c) return AKZ_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    timer_free(&c->t_fed);
+    timer_free(&c->t_ss);
+    timer_free(&c->t_all);
+    if (c->arena) hipFree(c->arena);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return AKZ_OK;
+}
+
+namespace {
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t count)
+    {
+        off = akz_align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += sizeof(T) * count;
+        return p;
+    }
+};
+}  // namespace
+
+static void carve(akz_ctx* c, char* base, size_t* total)
+{
+    const AkzPlan& P = c->plan;
+    const size_t B = (size_t)c->max_batch;
+    const size_t P0 = (size_t)c->max_w * c->max_h;  // sized for the largest frame the context accepts
+    const int nlev = (int)P.levels.size();
+    Carver cv{base};
+    c->Lt.assign(nlev, nullptr);
+    c->Lsm.assign(nlev, nullptr);
+    c->Lx.assign(nlev, nullptr);
+    c->Ly.assign(nlev, nullptr);
+    c->Ldet.assign(nlev, nullptr);
+    c->Lflow.assign(nlev, nullptr);
+    // persistent per-level planes: Lt, Lx, Ly (descriptors), Ldet (extrema, sub-pixel)
+    size_t max_level_px = 0;
+    for (int i = 0; i < nlev; ++i) {
+        size_t px = P.levels[i].pixels() * B;
+        c->Lt[i] = cv.take<float>(px);
+        c->Lx[i] = cv.take<float>(px);
+        c->Ly[i] = cv.take<float>(px);
+        c->Ldet[i] = cv.take<float>(px);
+        if (px > max_level_px) max_level_px = px;
+    }
+    // transient planes: Lsmooth / Lflow only live while their level is being built
+    float* sm_scratch = c->keep_all ? nullptr : cv.take<float>(max_level_px);
+    float* fl_scratch = c->keep_all ? nullptr : cv.take<float>(max_level_px);
+    for (int i = 0; i < nlev; ++i) {
+        size_t px = P.levels[i].pixels() * B;
+        if (i == 0) {
+            c->Lsm[0] = c->Lt[0];  // lib.rs:201
+            c->Lflow[0] = nullptr;
+            continue;
+        }
+        c->Lsm[i] = c->keep_all ? cv.take<float>(px) : sm_scratch;
+        c->Lflow[i] = c->keep_all ? cv.take<float>(px) : fl_scratch;
+    }
+    c->tmp = cv.take<float>(P0 * B);
+    c->d_in = cv.take<float>(P0 * B);
+    c->d_cmax = cv.take<unsigned long long>(B);
+    c->d_hist = cv.take<uint32_t>(B * 512);
+    c->d_npoints = cv.take<uint32_t>(B);
+    c->d_contrast = cv.take<double>(B);
+    c->d_invk = cv.take<float>(B * 8);
+    size_t rows = P.total_rows + 1;
+    // the row table is sized for the tallest pyramid the context can see
+    size_t max_rows = (size_t)c->max_h * 2 * (size_t)c->cfg.num_sublevels + 64;
+    if (rows > max_rows) max_rows = rows;
+    c->d_rowcount = cv.take<uint32_t>(B * max_rows);
+    c->d_ncand = cv.take<uint32_t>(B);
+    c->d_cand = cv.take<uint2>(B * c->max_cand);
+    const size_t K = c->max_kp;
+    c->d_cache = cv.take<DevKp>(B * K);
+    c->d_ncache = cv.take<uint32_t>(B);
+    c->d_kp_a = cv.take<DevKp>(B * K);
+    c->d_n_a = cv.take<uint32_t>(B);
+    c->d_kp_b = cv.take<DevKp>(B * K);
+    c->d_flag_b = cv.take<uint32_t>(B * K);
+    c->d_kp_c = cv.take<DevKp>(B * K);
+    c->d_n_c = cv.take<uint32_t>(B);
+    c->d_kp_d = cv.take<DevKp>(B * K);
+    c->d_n_d = cv.take<uint32_t>(B);
+    c->d_desc_tmp = cv.take<akz_descriptor>(B * K);
+    c->d_flag_d = cv.take<uint32_t>(B * K);
+    c->d_kp_out = cv.take<DevKp>(B * K);
+    c->d_desc_out = cv.take<akz_descriptor>(B * K);
+    c->d_n_out = cv.take<uint32_t>(B);
+    c->d_err = cv.take<uint32_t>(4);
+    c->d_ori = cv.take<char>(akz_ori_table_bytes());
+    c->d_desc = cv.take<char>(akz_desc_table_bytes());
+    *total = akz_align_up(cv.off, 256);
+}
+
+int32_t akz_ctx_prepare(akz_ctx* c, int w, int h)
+{
+    if (w > c->max_w || h > c->max_h) return AKZ_E_TOO_LARGE;
+    if (w < 3 || h < 3) return AKZ_E_INVALID;
+    if (c->arena && c->cur_w == w && c->cur_h == h) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    // The arena is sized once for (max_w, max_h); smaller frames re-carve the same arena.
+    if (!c->arena) {
+        akz_build_plan(c->cfg, c->max_w, c->max_h, &c->plan);
+        size_t total = 0;
+        carve(c, nullptr, &total);
+        AKZ_HIP(hipMalloc(&c->arena, total));
+        c->arena_bytes = total;
+    } else {
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+    }
+    akz_build_plan(c->cfg, w, h, &c->plan);
+    size_t total = 0;
+    carve(c, (char*)c->arena, &total);
+    if (total > c->arena_bytes) return AKZ_E_INTERNAL;
+    c->cur_w = w;
+    c->cur_h = h;
+    AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t) * 4, c->stream));
+    AKZ_TRY(akz_upload_tables(c));
+    return AKZ_OK;
+}
+
+static int32_t check_device_err(akz_ctx* c)
+{
+    uint32_t err = 0;
+    AKZ_HIP(hipMemcpyAsync(&err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    if (err & ~4u) {
+        AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+        return AKZ_E_INTERNAL;
+    }
+    return AKZ_OK;
+}
+
+static int32_t wait_for(akz_ctx* c, void* stream_to_wait)
+{
+    if (!stream_to_wait) return AKZ_OK;
+    hipEvent_t ev;
+    AKZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    AKZ_HIP(hipEventRecord(ev, (hipStream_t)stream_to_wait));
+    AKZ_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+    AKZ_HIP(hipEventDestroy(ev));
+    return AKZ_OK;
+}
+
+extern "C" void* akz_stream(akz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int32_t akz_sync(akz_ctx* c)
+{
+    if (!c) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    return check_device_err(c);
+}
+
+extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
+                                          void* stream_to_wait)
+{
+    if (!c || !d_imgs || n < 1 || (fmt != 0 && fmt != 1)) return AKZ_E_INVALID;
+    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(akz_ctx_prepare(c, w, h));
+    AKZ_TRY(wait_for(c, stream_to_wait));
+    c->cur_n = n;
+    return akz_run_scale_space(c, d_imgs, fmt, n);
+}
+
+extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
+                                            int32_t h, void* d_kps, void* d_descs, uint32_t cap_per_img,
+                                            void* d_n_out, void* stream_to_wait)
+{
+    if (!c || !d_imgs || !d_kps || !d_descs || !d_n_out || n < 1 || (fmt != 0 && fmt != 1) || cap_per_img == 0)
+        return AKZ_E_INVALID;
+    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(akz_ctx_prepare(c, w, h));
+    AKZ_TRY(wait_for(c, stream_to_wait));
+    c->cur_n = n;
+    akz_timer_begin(c, &c->t_all);
+    AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
+    AKZ_TRY(akz_run_keypoints(c, n, (DevKp*)d_kps, (akz_descriptor*)d_descs, cap_per_img, (uint32_t*)d_n_out));
+    akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+    return AKZ_OK;
+}
+
+extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
+                                     int32_t stride, akz_keypoint* kps, akz_descriptor* descs, uint32_t cap_per_img,
+                                     uint32_t* n_out)
+{
+    if (!c || !imgs || !n_out || n < 1 || (fmt != 0 && fmt != 1) || stride < w) return AKZ_E_INVALID;
+    if (cap_per_img && (!kps || !descs)) return AKZ_E_INVALID;
+    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(akz_ctx_prepare(c, w, h));
+    const size_t esz = fmt == 0 ? 1 : 4;
+    const size_t P0 = (size_t)w * h;
+    for (int i = 0; i < n; ++i) {
+        if (!imgs[i]) return AKZ_E_INVALID;
+        AKZ_HIP(hipMemcpy2DAsync((char*)c->d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
+                                 (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    }
+    c->cur_n = n;
+    akz_timer_begin(c, &c->t_all);
+    AKZ_TRY(akz_run_scale_space(c, c->d_in, fmt, n));
+    AKZ_TRY(akz_run_keypoints(c, n, c->d_kp_out, c->d_desc_out, c->max_kp, c->d_n_out));
+    akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+    std::vector<uint32_t> cnt(n);
+    AKZ_HIP(hipMemcpyAsync(cnt.data(), c->d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    AKZ_TRY(check_device_err(c));  // synchronises
+    int32_t status = AKZ_OK;
+    for (int i = 0; i < n; ++i) {
+        n_out[i] = cnt[i];
+        if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;
+        if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
+        uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
+        if (m) {
+            AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
+                              hipMemcpyDeviceToHost));
+            AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->d_desc_out + (size_t)i * c->max_kp,
+                              sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
+        }
+    }
+    return status;
+}
+
+extern "C" int32_t akz_extract_gray_u8(akz_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                                       akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
+{
+    const void* p = img;
+    return akz_extract_batch(c, &p, 0, 1, w, h, stride, kps, descs, cap, n_out);
+}
+extern "C" int32_t akz_extract_gray_f32(akz_ctx* c, const float* img, int32_t w, int32_t h, int32_t stride,
+                                        akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
+{
+    const void* p = img;
+    return akz_extract_batch(c, &p, 1, 1, w, h, stride, kps, descs, cap, n_out);
+}
+
+// ---- introspection -----------------------------------------------------------------------------
+static int32_t plan_for(akz_ctx* c, int w, int h, AkzPlan* tmp, const AkzPlan** out)
+{
+    if (!c) return AKZ_E_INVALID;
+    if (w == c->cur_w && h == c->cur_h) {
+        *out = &c->plan;
+        return AKZ_OK;
+    }
+    if (w < 1 || h < 1) return AKZ_E_INVALID;
+    akz_build_plan(c->cfg, w, h, tmp);
+    *out = tmp;
+    return AKZ_OK;
+}
+extern "C" int32_t akz_num_levels(akz_ctx* c, int32_t w, int32_t h, int32_t* n_levels)
+{
+    AkzPlan tmp;
+    const AkzPlan* P;
+    if (!n_levels) return AKZ_E_INVALID;
+    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+    *n_levels = (int32_t)P->levels.size();
+    return AKZ_OK;
+}
+extern "C" int32_t akz_level(akz_ctx* c, int32_t w, int32_t h, int32_t level, akz_level_info* out)
+{
+    AkzPlan tmp;
+    const AkzPlan* P;
+    if (!out) return AKZ_E_INVALID;
+    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+    if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
+    const AkzLevel& L = P->levels[level];
+    out->width = L.w;
+    out->height = L.h;
+    out->octave = L.octave;
+    out->sublevel = L.sublevel;
+    out->esigma = L.esigma;
+    out->etime = L.etime;
+    out->n_fed_steps = (uint32_t)L.tau.size();
+    out->deriv_sigma = L.deriv_sigma;
+    return AKZ_OK;
+}
+extern "C" int32_t akz_fed_tau(akz_ctx* c, int32_t w, int32_t h, int32_t level, double* tau, uint32_t cap,
+                               uint32_t* n_out)
+{
+    AkzPlan tmp;
+    const AkzPlan* P;
+    if (!n_out) return AKZ_E_INVALID;
+    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+    if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
+    const auto& t = P->levels[level].tau;
+    *n_out = (uint32_t)t.size();
+    if (t.size() > cap) return AKZ_E_CAPACITY;
+    for (size_t i = 0; i < t.size(); ++i) tau[i] = t[i];
+    return AKZ_OK;
+}
+
+extern "C" int32_t akz_debug_get_level(akz_ctx* c, int32_t img, int32_t level, int32_t which, float* out)
+{
+    if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+    if (level < 0 || level >= (int)c->plan.levels.size()) return AKZ_E_INVALID;
+    const float* src = nullptr;
+    switch (which) {
+    case AKZ_BUF_LT: src = c->Lt[level]; break;
+    case AKZ_BUF_LSMOOTH: src = c->Lsm[level]; break;
+    case AKZ_BUF_LX: src = c->Lx[level]; break;
+    case AKZ_BUF_LY: src = c->Ly[level]; break;
+    case AKZ_BUF_LDET: src = c->Ldet[level]; break;
+    case AKZ_BUF_LFLOW: src = c->Lflow[level]; break;
+    default: return AKZ_E_INVALID;
+    }
+    if (!src) return AKZ_E_INVALID;
+    // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
+    if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    size_t px = c->plan.levels[level].pixels();
+    AKZ_HIP(hipMemcpy(out, src + (size_t)img * px, sizeof(float) * px, hipMemcpyDeviceToHost));
+    return AKZ_OK;
+}
+extern "C" int32_t akz_debug_get_contrast(akz_ctx* c, int32_t img, double* out)
+{
+    if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    AKZ_HIP(hipMemcpy(out, c->d_contrast + img, sizeof(double), hipMemcpyDeviceToHost));
+    return AKZ_OK;
+}
+extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stage, akz_keypoint* out, uint32_t cap,
+                                           uint32_t* n_out)
+{
+    if (!c || !n_out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+    const DevKp* src;
+    const uint32_t* cnt;
+    switch (stage) {
+    case 0: src = c->d_kp_a; cnt = c->d_n_a; break;
+    case 1: src = c->d_kp_c; cnt = c->d_n_c; break;
+    case 2: src = c->d_kp_d; cnt = c->d_n_d; break;
+    default: return AKZ_E_INVALID;
+    }
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    uint32_t n = 0;
+    AKZ_HIP(hipMemcpy(&n, cnt + img, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > c->max_kp) return AKZ_E_INTERNAL;
+    uint32_t m = n < cap ? n : cap;
+    if (m && !out) return AKZ_E_INVALID;
+    if (m) AKZ_HIP(hipMemcpy(out, src + (size_t)img * c->max_kp, sizeof(akz_keypoint) * m, hipMemcpyDeviceToHost));
+    return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+}
+
+// ---- akaze::image stand-alone ops ----------------------------------------------------------------
+extern "C" int32_t akz_gaussian_kernel(float r, uint32_t kernel_size, float* out)
+{
+    if (!out || kernel_size % 2 != 1 || !(r > 0.0f)) return AKZ_E_INVALID;  // image.rs:361 asserts odd
+    akz_host_gaussian_kernel(r, (int)kernel_size, out);
+    return AKZ_OK;
+}
+
+static int32_t filter_host(akz_ctx* c, const float* img, int w, int h, const float* kernel, uint32_t ksize,
+                           float* out, int vertical)
+{
+    if (!c || !img || !kernel || !out || w < 1 || h < 1 || ksize % 2 != 1 || ksize > 4095) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    float *d_in = nullptr, *d_out = nullptr, *d_k = nullptr;
+    size_t px = (size_t)w * h;
+    int32_t st = AKZ_OK;
+    hipError_t e;
+    if ((e = hipMalloc(&d_in, px * 4)) != hipSuccess || (e = hipMalloc(&d_out, px * 4)) != hipSuccess ||
+        (e = hipMalloc(&d_k, ksize * 4)) != hipSuccess) {
+        g_akz_last_hip = (int)e;
+        st = AKZ_E_OOM;
+    }
+    if (st == AKZ_OK) {
+        hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
+        hipMemcpyAsync(d_k, kernel, ksize * 4, hipMemcpyHostToDevice, c->stream);
+        st = akz_dev_filter1d(c->stream, d_in, d_out, w, h, d_k, (int)ksize, vertical);
+        if (st == AKZ_OK && hipMemcpyAsync(out, d_out, px * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
+    }
+    hipFree(d_in);
+    hipFree(d_out);
+    hipFree(d_k);
+    return st;
+}
+extern "C" int32_t akz_horizontal_filter(akz_ctx* c, const float* img, int32_t w, int32_t h, const float* kernel,
+                                         uint32_t ksize, float* out)
+{
+    return filter_host(c, img, w, h, kernel, ksize, out, 0);
+}
+extern "C" int32_t akz_vertical_filter(akz_ctx* c, const float* img, int32_t w, int32_t h, const float* kernel,
+                                       uint32_t ksize, float* out)
+{
+    return filter_host(c, img, w, h, kernel, ksize, out, 1);
+}
+extern "C" int32_t akz_half_size(akz_ctx* c, const float* img, int32_t w, int32_t h, float* out)
+{
+    if (!c || !img || !out || w < 2 || h < 2) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    size_t px = (size_t)w * h, opx = (size_t)(w / 2) * (h / 2);
+    int32_t st = AKZ_OK;
+    if (hipMalloc(&d_in, px * 4) != hipSuccess || hipMalloc(&d_out, opx * 4) != hipSuccess) st = AKZ_E_OOM;
+    if (st == AKZ_OK) {
+        hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
+        st = akz_dev_half_size(c->stream, d_in, d_out, w, h, 1, px, opx);
+        if (st == AKZ_OK && hipMemcpyAsync(out, d_out, opx * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
+    }
+    hipFree(d_in);
+    hipFree(d_out);
+    return st;
+}
+
+// ---- timing -----------------------------------------------------------------------------------
+extern "C" int32_t akz_timing_enable(akz_ctx* c, int32_t on)
+{
+    if (!c) return AKZ_E_INVALID;
+    c->timing = on != 0;
+    return AKZ_OK;
+}
+extern "C" int32_t akz_timing_reset(akz_ctx* c)
+{
+    if (!c) return AKZ_E_INVALID;
+    for (AkzTimer* t : {&c->t_fed, &c->t_ss, &c->t_all}) {
+        timer_resolve(t);
+        t->ms = 0.0;
+        t->launches = t->units = 0;
+    }
+    return AKZ_OK;
+}
+extern "C" int32_t akz_timing_get(akz_ctx* c, int32_t which, double* ms, uint64_t* launches, uint64_t* units)
+{
+    if (!c || which < 0 || which > 2) return AKZ_E_INVALID;
+    AkzTimer* t = which == 0 ? &c->t_fed : (which == 1 ? &c->t_ss : &c->t_all);
+    AKZ_HIP(hipSetDevice(c->device));
+    timer_resolve(t);
+    if (ms) *ms = t->ms;
+    if (launches) *launches = t->launches;
+    if (units) *units = t->units;
+    return AKZ_OK;
+}

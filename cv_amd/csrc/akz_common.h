@@ -1,0 +1,70 @@
+// akz_common.h — internal declarations shared by the HIP translation units of libakz.
+// Nothing here is part of the ABI (that is include/akz.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/akz.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+extern thread_local int g_akz_last_hip;
+#define AKZ_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_akz_last_hip = (int)e_;                                                            \
+            return (e_ == hipErrorOutOfMemory) ? AKZ_E_OOM : AKZ_E_HIP;                          \
+        }                                                                                        \
+    } while (0)
+#define AKZ_TRY(expr)                                                                            \
+    do {                                                                                         \
+        int32_t s_ = (expr);                                                                     \
+        if (s_ != AKZ_OK) return s_;                                                             \
+    } while (0)
+#define AKZ_LAUNCH_CHECK() AKZ_HIP(hipGetLastError())
+
+// ---- host-side plan: what Akaze::allocate_evolutions computes (akaze/src/evolution.rs:80-126) ---
+struct AkzLevel {
+    int w, h;
+    uint32_t octave, sublevel;
+    double esigma, etime;
+    uint32_t deriv_sigma;       // round(esigma*derivative_factor/2^octave), detector_response.rs:11-13
+    float sigma_quat;           // (deriv_sigma^4) as f32, detector_response.rs:38
+    float kp_size;              // (esigma*derivative_factor) as f32, scale_space_extrema.rs:63
+    std::vector<double> tau;    // fed_tau_steps (f64); each step uses tau as f32 (lib.rs:254)
+    bool new_octave;            // octave > previous level's octave (lib.rs:219)
+    size_t pixels() const { return (size_t)w * (size_t)h; }
+};
+struct AkzPlan {
+    int w = 0, h = 0;
+    std::vector<AkzLevel> levels;
+    int n_octaves = 0;
+    size_t sum_pixels = 0;
+    size_t total_rows = 0;
+};
+// Host scalar math (no device work): evolution.rs:46-126 + fed_tau.rs:26-93.
+void akz_build_plan(const akz_config& cfg, int w, int h, AkzPlan* plan);
+// gaussian_kernel — image.rs:360-374 (host libm expf, as the reference).
+void akz_host_gaussian_kernel(float r, int ksize, float* out);
+// kernel radius of gaussian_blur(sigma) — image.rs:385.
+int akz_gaussian_radius(float r);
+
+// ---- small POD passed by value to kernels ---------------------------------------------------
+struct GaussTaps {
+    float k[12];  // up to 9 taps used on the AKAZE path (sigma 1.6 -> 9, sigma 1.0 -> 5)
+    int n;
+};
+
+struct ScharrW {   // computer_scharr_kernel, derivatives.rs:57-79
+    float norm;    // side weight
+    float middle;  // centre weight
+    int sigma;
+};
+ScharrW akz_scharr_weights(uint32_t sigma);
+
+static inline int akz_div_up(int a, int b) { return (a + b - 1) / b; }
+static inline size_t akz_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,89 @@
+// akz_ctx.h — the context object behind akz_ctx* (internal).
+#pragma once
+#include <utility>
+
+#include "akz_common.h"
+
+// One keypoint work record on the device; identical to akz_keypoint (28 B).
+typedef akz_keypoint DevKp;
+
+struct AkzTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // recorded, not yet resolved
+    std::vector<hipEvent_t> pool;                            // recycled events
+    hipEvent_t cur_start = nullptr;
+    double ms = 0.0;
+    uint64_t launches = 0, units = 0;
+};
+
+struct akz_ctx {
+    akz_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
+    uint32_t max_cand = 0;    // capacity of the per-frame raw candidate list
+    bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
+
+    AkzPlan plan;             // for (cur_w, cur_h)
+    int cur_w = 0, cur_h = 0, cur_n = 0;
+
+    // ---- device memory (one arena, carved in akz_ctx_prepare) ----
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<float*> Lt, Lsm, Lx, Ly, Ldet, Lflow;  // [level] -> frame-major planes
+    float* tmp = nullptr;       // ping-pong partner for FED steps, max_batch * P0
+    void* d_in = nullptr;       // staged input frames (u8 or f32), max_batch * P0 * 4 bytes
+    // contrast factor (contrast_factor.rs)
+    unsigned long long* d_cmax = nullptr;  // [B] bit pattern of max f64 gradient magnitude^2
+    uint32_t* d_hist = nullptr;            // [B][nbins]
+    uint32_t* d_npoints = nullptr;         // [B]
+    double* d_contrast = nullptr;          // [B]
+    float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
+    // keypoint stage
+    uint32_t* d_rowcount = nullptr;        // [B][total_rows+1] candidate count per pyramid row, then offsets
+    uint32_t* d_ncand = nullptr;           // [B]
+    uint2* d_cand = nullptr;               // [B][max_cand] {packed x|y|level, response bits}
+    DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
+    uint32_t* d_ncache = nullptr;          // [B]
+    DevKp* d_kp_a = nullptr;               // [B][max_kp]  stage-0 list (find_scale_space_extrema output)
+    uint32_t* d_n_a = nullptr;
+    DevKp* d_kp_b = nullptr;               // [B][max_kp]  stage-1 list (refined + orientation), pre-compaction slots
+    uint32_t* d_flag_b = nullptr;          // [B][max_kp]  keep flags
+    DevKp* d_kp_c = nullptr;               // [B][max_kp]  stage-1 compacted
+    uint32_t* d_n_c = nullptr;
+    DevKp* d_kp_d = nullptr;               // [B][max_kp]  stage-2 sorted + truncated
+    uint32_t* d_n_d = nullptr;
+    akz_descriptor* d_desc_tmp = nullptr;  // [B][max_kp]  descriptors before dropping out-of-bounds keypoints
+    uint32_t* d_flag_d = nullptr;          // [B][max_kp]
+    DevKp* d_kp_out = nullptr;             // [B][max_kp]  final (internal copy used by the host-buffer API)
+    akz_descriptor* d_desc_out = nullptr;  // [B][max_kp]
+    uint32_t* d_n_out = nullptr;           // [B]
+    uint32_t* d_err = nullptr;             // [1] sticky device-side overflow flag
+    void* d_ori = nullptr;                 // OriTables (orientation sample/window tables)
+    void* d_desc = nullptr;                // DescTables (M-LDB cell + comparison tables)
+
+    // timing (akz_timing_*)
+    bool timing = false;
+    AkzTimer t_fed, t_ss, t_all;
+};
+
+// (Re)build plan + carve the arena for images of w x h. Allocates lazily.
+int32_t akz_ctx_prepare(akz_ctx* c, int w, int h);
+
+// Stage launchers (enqueue on c->stream).
+int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n);
+int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
+                          uint32_t* d_n_out);
+
+// stand-alone image ops on device buffers (used by akz_horizontal_filter & co)
+int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel,
+                         int ksize, int vertical);
+int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
+                          size_t out_fs);
+
+int32_t akz_upload_tables(akz_ctx* c);
+size_t akz_ori_table_bytes();
+size_t akz_desc_table_bytes();
+
+void akz_timer_begin(akz_ctx* c, AkzTimer* t);
+void akz_timer_end(akz_ctx* c, AkzTimer* t, uint64_t launches, uint64_t units);

@@ -1,0 +1,855 @@
+// akz_keypoints.hip — gfx950 kernels for keypoint detection and description (SURVEY.md §8a rows
+// A12a..A17).  -ffp-contract=off; every f32 expression follows the reference's order.
+//
+// Reference functions implemented here (paths relative to the rust-cv/cv checkout):
+//   find_scale_space_extrema  candidate test   akaze/src/scale_space_extrema.rs:34-60    k_cand_count / k_cand_scatter
+//   find_scale_space_extrema  serial pass      akaze/src/scale_space_extrema.rs:61-118   k_suppress
+//   find_scale_space_extrema  upper-scale pass akaze/src/scale_space_extrema.rs:121-140  k_filter_upper
+//   do_subpixel_refinement                     akaze/src/scale_space_extrema.rs:297-362  k_refine
+//   compute_main_orientation + GAUSS25         akaze/src/scale_space_extrema.rs:162-288  k_refine
+//   sort_unstable_by_key + truncate            akaze/src/lib.rs:326-327                  k_sort
+//   extract_descriptors / get_mldb_descriptor  akaze/src/descriptors.rs:16-98            k_describe
+//   mldb_fill_values / mldb_binary_comparisons akaze/src/descriptors.rs:102-202          k_describe
+//
+// Order-dependent parts keep the reference's order: candidates are compacted in (level, raster)
+// order; the suppression cache is processed strictly sequentially per frame (parallel across the
+// frames of the batch and, inside a frame, across the cache entries tested for one candidate);
+// list compactions preserve order; the response sort is (response desc, index asc).
+#include "akz_ctx.h"
+#include "../../include/akz_portable_math.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Rust `f32 as usize`: truncate toward zero, negatives and NaN saturate to 0.
+__device__ __forceinline__ unsigned sat_u32(float v) { return v > 0.0f ? (v >= 4294967040.0f ? 0xFFFFFFFFu : (unsigned)v) : 0u; }
+// Rust `f32 as isize` (saturating); the values on this path are far inside the i32 range.
+__device__ __forceinline__ int sat_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483520.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int)0x80000000;
+    return (int)v;
+}
+
+struct LevelDesc {  // per-level constants for the keypoint kernels
+    const float* Ldet;
+    const float* Lt;
+    const float* Lx;
+    const float* Ly;
+    int w, h;
+    size_t fs;        // frame stride (pixels)
+    uint32_t octave;
+    float kp_size;    // (esigma * derivative_factor) as f32
+    uint32_t row_base;  // index of this level's row 0 in the per-frame row table
+};
+constexpr int kMaxLevels = 32;
+struct LevelTable {
+    LevelDesc L[kMaxLevels];
+    int n;
+    uint32_t total_rows;
+};
+
+// ---------------------------------------------------------------------------------------------
+// A12a: candidate = interior pixel with Ldet > threshold and strictly greater than its 8 neighbours
+// (scale_space_extrema.rs:50-59).
+__device__ __forceinline__ bool is_candidate(const float* D, int w, int x, int y, float thr, float* val)
+{
+    const float* p = D + (size_t)y * w + x;
+    float v = p[0];
+    *val = v;
+    return v > thr && v > p[-w - 1] && v > p[-w] && v > p[-w + 1] && v > p[-1] && v > p[1] && v > p[w - 1] &&
+           v > p[w] && v > p[w + 1];
+}
+
+// one block per (row, frame): count candidates of the row
+__global__ __launch_bounds__(256) void k_cand_count(LevelDesc L, float thr, uint32_t* __restrict__ rowcount,
+                                                    uint32_t rows_stride)
+{
+    __shared__ uint32_t s_cnt;
+    int y = blockIdx.x + 1;  // rows 1..h-2
+    int frame = blockIdx.y;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const float* D = L.Ldet + (size_t)frame * L.fs;
+    uint32_t local = 0;
+    for (int x = 1 + threadIdx.x; x < L.w - 1; x += 256) {
+        float v;
+        if (is_candidate(D, L.w, x, y, thr, &v)) local++;
+    }
+    unsigned long long b = __ballot(local != 0);
+    if (b) {  // rare
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+        if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s_cnt, local);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rowcount[(size_t)frame * rows_stride + L.row_base + y] = s_cnt;
+}
+
+// exclusive scan over the per-frame row table (all levels, level-major): one block per frame.
+__global__ __launch_bounds__(1024) void k_row_scan(uint32_t* __restrict__ rowcount, uint32_t rows_stride,
+                                                   uint32_t total_rows, uint32_t* __restrict__ ncand)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    uint32_t* rc = rowcount + (size_t)blockIdx.x * rows_stride;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total_rows; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < total_rows ? rc[i] : 0;
+        uint32_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off);
+            if ((int)(threadIdx.x & 63) >= off) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) wave_off += s_wave[wv];
+        uint32_t carry = s_carry;
+        if (i < total_rows) rc[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rc[total_rows] = s_carry;
+        ncand[blockIdx.x] = s_carry;
+    }
+}
+
+// one block per (row, frame): write the row's candidates at their raster-ordered slots.
+__global__ __launch_bounds__(256) void k_cand_scatter(LevelDesc L, float thr, const uint32_t* __restrict__ rowoff,
+                                                      uint32_t rows_stride, uint2* __restrict__ cand,
+                                                      uint32_t max_cand, uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t s_wave[4];
+    int y = blockIdx.x + 1;
+    int frame = blockIdx.y;
+    const uint32_t* ro = rowoff + (size_t)frame * rows_stride + L.row_base + y;
+    uint32_t base = ro[0];
+    if (ro[1] == base) return;  // empty row (uniform for the block)
+    const float* D = L.Ldet + (size_t)frame * L.fs;
+    uint2* out = cand + (size_t)frame * max_cand;
+    for (int x0 = 1; x0 < L.w - 1; x0 += 256) {
+        int x = x0 + threadIdx.x;
+        float v = 0.0f;
+        bool hit = x < L.w - 1 && is_candidate(D, L.w, x, y, thr, &v);
+        unsigned long long b = __ballot(hit);
+        int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i < wv) woff += s_wave[i];
+            tot += s_wave[i];
+        }
+        if (hit) {
+            uint32_t slot = base + woff + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            if (slot < max_cand)
+                out[slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
+            else
+                *err = 1u;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A12b: the order-dependent suppression pass (scale_space_extrema.rs:61-118).  One block per frame.
+// The reference scans the whole cache for the FIRST entry (in cache order) whose class_id is the
+// candidate's level or the one below and that lies within the candidate's size.  Only entries of
+// those two classes can match, so the block keeps them — in cache order — in an LDS "active list"
+// (rebuilt at each level change) and scans that; pushes append to it, in-place replacements
+// update it in place, so its order always equals cache order.  The full cache goes to HBM in slot
+// order for the second pass.
+constexpr int kActCap = 8192;
+struct ActEntry {   // 16 B
+    float x, y;     // full-resolution coordinates (with the +0.5(ratio-1) offset, as cached)
+    float resp;
+    uint32_t slot_cls;  // slot (24 bits) | class (8 bits)
+};
+
+__global__ __launch_bounds__(256) void k_suppress(LevelTable T, const uint32_t* __restrict__ rowoff,
+                                                  uint32_t rows_stride, const uint2* __restrict__ cand,
+                                                  uint32_t max_cand, DevKp* __restrict__ cache, uint32_t max_kp,
+                                                  uint32_t* __restrict__ ncache, uint32_t* __restrict__ err)
+{
+    // all LDS lives in the dynamic region so the 16-byte ActEntry accesses stay aligned
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ActEntry* act = reinterpret_cast<ActEntry*>(smem);
+    uint32_t* s_vars = reinterpret_cast<uint32_t*>(smem + sizeof(ActEntry) * kActCap);
+    uint32_t* s_first = s_vars;       // [4]
+    uint32_t* s_scan = s_vars + 4;    // [4]
+    uint32_t& s_nact = s_vars[8];
+    uint32_t& s_ncache = s_vars[9];
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t* ro = rowoff + (size_t)frame * rows_stride;
+    const uint2* cd = cand + (size_t)frame * max_cand;
+    DevKp* ch = cache + (size_t)frame * max_kp;
+    const float smax = 10.0f * sqrtf(2.0f);
+    if (tid == 0) {
+        s_nact = 0;
+        s_ncache = 0;
+    }
+    __syncthreads();
+    uint32_t total = ro[T.total_rows];
+    if (total > max_cand) total = max_cand;  // overflow already flagged by k_cand_scatter
+    for (int e = 0; e < T.n; ++e) {
+        const LevelDesc& L = T.L[e];
+        // ---- level change: keep only class e-1 entries (class e-2 can no longer match), in order ----
+        {
+            uint32_t n = s_nact;
+            __syncthreads();
+            uint32_t kept_base = 0;
+            for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+                uint32_t i = b0 + tid;
+                ActEntry en;
+                bool keep = false;
+                if (i < n) {
+                    en = act[i];
+                    keep = (int)(en.slot_cls & 0xFFu) == e - 1;
+                }
+                unsigned long long bal = __ballot(keep);
+                if (lane == 0) s_scan[wv] = (uint32_t)__popcll(bal);
+                __syncthreads();  // also: every read of act[b0..b0+255] is done before any write below
+                uint32_t woff = 0, tot = 0;
+                for (int q = 0; q < 4; ++q) {
+                    if (q < wv) woff += s_scan[q];
+                    tot += s_scan[q];
+                }
+                if (keep) act[kept_base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = en;
+                kept_base += tot;
+                __syncthreads();
+            }
+            if (tid == 0) s_nact = kept_base;
+            __syncthreads();
+        }
+        const float ratio = ldexpf(1.0f, (int)L.octave);
+        const float size = L.kp_size;
+        const float size2 = size * size;
+        const float sigma_size = roundf(size / ratio);
+        uint32_t c_begin = ro[L.row_base], c_end = ro[L.row_base + L.h];
+        if (c_begin > total) c_begin = total;
+        if (c_end > total) c_end = total;
+        for (uint32_t ci = c_begin; ci < c_end; ++ci) {
+            uint2 cv = cd[ci];  // uniform
+            float px = (float)(cv.x & 0xFFFFu), py = (float)(cv.x >> 16);
+            float resp = fabsf(__uint_as_float(cv.y));
+            float fx = px * ratio, fy = py * ratio;
+            // scan the active list for the first hit
+            uint32_t nact = s_nact;
+            uint32_t first = 0xFFFFFFFFu;
+            for (uint32_t b0 = 0; b0 < nact; b0 += 256) {
+                uint32_t i = b0 + tid;
+                bool hit = false;
+                if (i < nact) {
+                    ActEntry en = act[i];
+                    float dx = fx - en.x, dy = fy - en.y;
+                    float dist = dx * dx + dy * dy;
+                    hit = dist <= size2;  // class filter is implied by list membership
+                }
+                unsigned long long bal = __ballot(hit);
+                if (lane == 0) s_first[wv] = bal ? (b0 + wv * 64 + (uint32_t)__ffsll((long long)bal) - 1u) : 0xFFFFFFFFu;
+                __syncthreads();
+                uint32_t f = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+                __syncthreads();
+                if (f != 0xFFFFFFFFu) {
+                    first = f;
+                    break;
+                }
+            }
+            // decision (uniform): scale_space_extrema.rs:72-116
+            if (tid == 0) {
+                bool is_repeated = false, is_extremum = true;
+                if (first != 0xFFFFFFFFu) {
+                    if (resp > act[first].resp) is_repeated = true;
+                    else is_extremum = false;
+                }
+                if (is_extremum) {
+                    float left_x = roundf(px - smax * sigma_size) - 1.0f;
+                    float right_x = roundf(px + smax * sigma_size) + 1.0f;
+                    float up_y = roundf(py - smax * sigma_size) - 1.0f;
+                    float down_y = roundf(py + smax * sigma_size) + 1.0f;
+                    bool is_out = left_x < 0.0f || right_x >= (float)L.w || up_y < 0.0f || down_y >= (float)L.h;
+                    if (!is_out) {
+                        DevKp kp;
+                        kp.x = px * ratio + 0.5f * (ratio - 1.0f);
+                        kp.y = py * ratio + 0.5f * (ratio - 1.0f);
+                        kp.response = resp;
+                        kp.size = size;
+                        kp.angle = 0.0f;
+                        kp.octave = L.octave;
+                        kp.class_id = (uint32_t)e;
+                        if (!is_repeated) {
+                            uint32_t slot = s_ncache, ai = s_nact;
+                            if (slot < max_kp && ai < (uint32_t)kActCap && slot < (1u << 24)) {
+                                ch[slot] = kp;
+                                ActEntry en = {kp.x, kp.y, resp, (slot << 8) | (uint32_t)e};
+                                act[ai] = en;
+                                s_ncache = slot + 1;
+                                s_nact = ai + 1;
+                            } else {
+                                *err = 2u;
+                            }
+                        } else {
+                            uint32_t slot = act[first].slot_cls >> 8;
+                            ch[slot] = kp;
+                            ActEntry en = {kp.x, kp.y, resp, (slot << 8) | (uint32_t)e};
+                            act[first] = en;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) ncache[frame] = s_ncache;
+}
+
+// second pass (scale_space_extrema.rs:121-140): drop i if a LATER cache entry of class i+1 lies within
+// size_i and has response >= response_i.  Block per (chunk of i, frame); j streamed through LDS.
+__global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ cache, uint32_t max_kp,
+                                                      const uint32_t* __restrict__ ncache,
+                                                      uint32_t* __restrict__ flag)
+{
+    __shared__ float4 s_j[256];  // x, y, resp, class
+    const int frame = blockIdx.y;
+    const uint32_t n = min(ncache[frame], max_kp);
+    const uint32_t i0 = blockIdx.x * 256;
+    if (i0 >= n) return;
+    const DevKp* ch = cache + (size_t)frame * max_kp;
+    const uint32_t i = i0 + threadIdx.x;
+    DevKp ki;
+    bool valid = i < n;
+    if (valid) ki = ch[i];
+    bool rep = false;
+    for (uint32_t j0 = i0; j0 < n; j0 += 256) {
+        uint32_t j = j0 + threadIdx.x;
+        if (j < n) {
+            DevKp kj = ch[j];
+            s_j[threadIdx.x] = make_float4(kj.x, kj.y, kj.response, __uint_as_float(kj.class_id));
+        }
+        __syncthreads();
+        if (valid && !rep) {
+            uint32_t cnt = min(256u, n - j0);
+            for (uint32_t t = 0; t < cnt; ++t) {
+                uint32_t jj = j0 + t;
+                if (jj <= i) continue;
+                float4 q = s_j[t];
+                if (ki.class_id + 1u == __float_as_uint(q.w)) {
+                    float dx = ki.x - q.x, dy = ki.y - q.y;
+                    float dist = dx * dx + dy * dy;
+                    if (dist <= ki.size * ki.size && ki.response <= q.z) {
+                        rep = true;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
+}
+
+// ordered compaction of a per-frame keypoint list (and optionally its descriptors): block per frame.
+template <bool WITH_DESC>
+__global__ __launch_bounds__(1024) void k_compact(const DevKp* __restrict__ in, const akz_descriptor* __restrict__ din,
+                                                  const uint32_t* __restrict__ flag, const uint32_t* __restrict__ n_in,
+                                                  uint32_t in_stride, DevKp* __restrict__ out,
+                                                  akz_descriptor* __restrict__ dout, uint32_t out_stride,
+                                                  uint32_t* __restrict__ n_out, uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t s_wave[16];
+    const int frame = blockIdx.x;
+    const uint32_t n = min(n_in[frame], in_stride);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t base = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+        uint32_t i = b0 + threadIdx.x;
+        bool keep = i < n && flag[(size_t)frame * in_stride + i] != 0;
+        unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (keep) {
+            uint32_t o = base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (o < out_stride) {
+                out[(size_t)frame * out_stride + o] = in[(size_t)frame * in_stride + i];
+                if (WITH_DESC) {
+                    const uint4* s = reinterpret_cast<const uint4*>(&din[(size_t)frame * in_stride + i]);
+                    uint4* d = reinterpret_cast<uint4*>(&dout[(size_t)frame * out_stride + o]);
+                    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+                }
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        n_out[frame] = base;  // required count (may exceed out_stride -> AKZ_E_CAPACITY on the host side)
+        if (base > out_stride && err) atomicOr(err, 4u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A13 + A14: sub-pixel refinement and main orientation, one wave per keypoint.
+struct OriTables {
+    signed char di[109], dj[109];  // sample offsets in the reference's (j outer, i inner) order
+    float gw[109];                 // GAUSS25[id[j+6]][id[i+6]]
+    float ang1[48];                // window starts: f32 accumulation of 0.15 (scale_space_extrema.rs:259-287)
+    int n_win;
+};
+
+__device__ __forceinline__ float fast_atan2_equiv(float y, float x)
+{
+    // (y.atan2(x) + 2*PI).rem_euclid(2*PI) in f32 (scale_space_extrema.rs:242); the sum lies in
+    // [pi, 3pi] so fmod is one exact conditional subtraction.
+    const float two_pi = 2.0f * 3.14159274101257324219f;
+    float a = akz_pm_atan2f(y, x) + two_pi;
+    return a >= two_pi ? a - two_pi : a;
+}
+
+__global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* __restrict__ ori_p,
+                                                const DevKp* __restrict__ in,
+                                                const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                DevKp* __restrict__ out, uint32_t* __restrict__ flag,
+                                                uint32_t* __restrict__ err)
+{
+    __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112];
+    const OriTables& c_ori = *ori_p;
+    const int frame = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t ki = blockIdx.x * 4 + wv;
+    const bool active = ki < n;  // wave-uniform; inactive waves still join the block barriers
+    const float PI_F = 3.14159274101257324219f;
+    DevKp kp;
+    bool keep = false;
+    const LevelDesc* Lp = &T.L[0];
+    float ratio = 1.0f;
+    if (active) {
+        kp = in[(size_t)frame * stride + ki];
+        Lp = &T.L[kp.class_id];
+        // do_subpixel_refinement, :301-347 (every lane computes the same scalars)
+        ratio = ldexpf(1.0f, (int)kp.octave);
+        int x = (int)sat_u32(roundf(kp.x / ratio));
+        int y = (int)sat_u32(roundf(kp.y / ratio));
+        const float* D = Lp->Ldet + (size_t)frame * Lp->fs;
+        const int w = Lp->w;
+        // the suppression pass guarantees a >= 15 px margin (scale_space_extrema.rs:97-104)
+        x = clampi(x, 1, w - 2);
+        y = clampi(y, 1, Lp->h - 2);
+        const float* p = D + (size_t)y * w + x;
+        float x_i = p[0], x_p = p[1], x_m = p[-1], y_p = p[w], y_m = p[-w];
+        float x_p_y_p = p[w + 1], x_p_y_m = p[-w + 1], x_m_y_p = p[w - 1], x_m_y_m = p[-w - 1];
+        float d_x = 0.5f * (x_p - x_m);
+        float d_y = 0.5f * (y_p - y_m);
+        float d_xx = x_p + x_m - 2.0f * x_i;
+        float d_yy = y_p + y_m - 2.0f * x_i;
+        float d_xy = 0.25f * (x_p_y_p + x_m_y_m) - 0.25f * (x_p_y_m + x_m_y_p);
+        float inv_det_a = 1.0f / (d_xx * d_yy - d_xy * d_xy);
+        float inv_a0 = inv_det_a * d_yy;
+        float inv_a1 = inv_det_a * -d_xy;
+        float inv_a2 = inv_det_a * -d_xy;
+        float inv_a3 = inv_det_a * d_xx;
+        float dst0 = -d_x * inv_a0 + -d_y * inv_a1;
+        float dst1 = -d_x * inv_a2 + -d_y * inv_a3;
+        keep = fabsf(dst0) <= 1.0f && fabsf(dst1) <= 1.0f;
+        if (keep) {
+            float nx = (float)x + dst0, ny = (float)y + dst1;
+            float power = ldexpf(1.0f, (int)Lp->octave);
+            kp.x = nx * power + 0.5f * (power - 1.0f);
+            kp.y = ny * power + 0.5f * (power - 1.0f);
+            kp.size = kp.size * 2.0f;
+        }
+    }
+    // compute_main_orientation, :229-288
+    if (active && keep) {
+        const float oratio = (float)(1u << Lp->octave);
+        const float s = roundf(0.5f * kp.size / oratio);
+        const float xf = kp.x / oratio, yf = kp.y / oratio;
+        const float* LX = Lp->Lx + (size_t)frame * Lp->fs;
+        const float* LY = Lp->Ly + (size_t)frame * Lp->fs;
+        for (int idx = lane; idx < 109; idx += 64) {
+            unsigned iy = sat_u32(roundf(yf + (float)c_ori.dj[idx] * s));
+            unsigned ix = sat_u32(roundf(xf + (float)c_ori.di[idx] * s));
+            if (ix >= (unsigned)Lp->w || iy >= (unsigned)Lp->h) {  // the reference would panic here
+                atomicOr(err, 8u);
+                ix = min(ix, (unsigned)Lp->w - 1u);
+                iy = min(iy, (unsigned)Lp->h - 1u);
+            }
+            float g = c_ori.gw[idx];
+            float rx = g * LX[(size_t)iy * Lp->w + ix];
+            float ry = g * LY[(size_t)iy * Lp->w + ix];
+            s_rx[wv][idx] = rx;
+            s_ry[wv][idx] = ry;
+            s_ang[wv][idx] = fast_atan2_equiv(ry, rx);
+        }
+    }
+    __syncthreads();
+    if (active && keep) {
+        float val = -1.0f, sum_x = 0.0f, sum_y = 0.0f;
+        if (lane < c_ori.n_win) {
+            float ang1 = c_ori.ang1[lane];
+            float ang2 = (ang1 + PI_F / 3.0f > 2.0f * PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+            for (int k = 0; k < 109; ++k) {
+                float ang = s_ang[wv][k];
+                if ((ang1 < ang2 && ang1 < ang && ang < ang2) ||
+                    (ang2 < ang1 && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * PI_F)))) {
+                    sum_x += s_rx[wv][k];
+                    sum_y += s_ry[wv][k];
+                }
+            }
+            val = sum_x * sum_x + sum_y * sum_y;
+        }
+        // the serial loop keeps the FIRST window whose val exceeds every earlier one: the earliest
+        // window holding the overall maximum, provided that maximum is > 0.
+        float m = val;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        unsigned long long bal = __ballot(val == m && lane < c_ori.n_win);
+        int win = __ffsll((long long)bal) - 1;
+        float best_sx = __shfl(sum_x, win), best_sy = __shfl(sum_y, win);
+        kp.angle = (m > 0.0f) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
+    }
+    if (active && lane == 0) {
+        out[(size_t)frame * stride + ki] = kp;
+        flag[(size_t)frame * stride + ki] = keep ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A15: sort by response descending (ties: lower pre-sort index first), truncate to maximum_features.
+// Bitonic sort of 64-bit keys (~response_bits << 32 | index) in LDS, one block per frame.
+__global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
+                                               uint32_t stride, uint32_t max_features, DevKp* __restrict__ out,
+                                               uint32_t* __restrict__ n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    const int frame = blockIdx.x;
+    const uint32_t n = min(n_in[frame], stride);
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const DevKp* src = in + (size_t)frame * stride;
+    for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            // responses are |Ldet| > 0: the IEEE bit pattern is monotone in the value
+            uint32_t rb = __float_as_uint(src[i].response);
+            k = ((unsigned long long)(~rb) << 32) | (unsigned long long)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = key[i], b = key[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t m = n < max_features ? n : max_features;
+    for (uint32_t i = threadIdx.x; i < m; i += 1024) out[(size_t)frame * stride + i] = src[(uint32_t)(key[i] & 0xFFFFFFFFull)];
+    if (threadIdx.x == 0) n_out[frame] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A16 + A17: M-LDB descriptor, one wave per keypoint.  Lane c (< n_cells) accumulates cell c of the
+// three sampling grids sequentially in the reference's (k outer, l inner) order; the comparisons
+// are then spread over the lanes one output byte each.
+struct DescTables {
+    // per cell: grid-local origin (i, j) and sample step of its grid; value slot base
+    signed char ci[32], cj[32];
+    unsigned char step[32];
+    unsigned char vbase[32];        // index of the cell's first value in the per-keypoint value array
+    int n_cells;                    // 4 + 9 + 16 = 29
+    int nch;                        // descriptor_channels
+    int n_bits;                     // nch * (6 + 36 + 120)
+    unsigned char cmp_a[512], cmp_b[512];  // value indices compared for bit b: bit = v[a] > v[b]
+};
+
+__global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables* __restrict__ desc_p,
+                                                  const DevKp* __restrict__ in,
+                                                  const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                  akz_descriptor* __restrict__ out, uint32_t* __restrict__ flag)
+{
+    __shared__ float s_val[4][96];
+    const DescTables& c_desc = *desc_p;
+    const int frame = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t ki = blockIdx.x * 4 + wv;
+    const bool active = ki < n;
+    bool oob = false;
+    if (active) {
+        const DevKp kp = in[(size_t)frame * stride + ki];
+        const LevelDesc& L = T.L[kp.class_id];
+        // get_mldb_descriptor, descriptors.rs:66-72
+        const float ratio = (float)(1u << kp.octave);
+        const float scale = roundf(0.5f * kp.size / ratio);
+        const float xf = kp.x / ratio, yf = kp.y / ratio;
+        const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
+        if (lane < c_desc.n_cells) {
+            const float* LT = L.Lt + (size_t)frame * L.fs;
+            const float* LX = L.Lx + (size_t)frame * L.fs;
+            const float* LY = L.Ly + (size_t)frame * L.fs;
+            const int i0 = c_desc.ci[lane], j0 = c_desc.cj[lane], st = c_desc.step[lane];
+            const int nch = c_desc.nch;
+            float di = 0.0f, dx = 0.0f, dy = 0.0f;
+            uint32_t nsamples = 0;
+            // mldb_fill_values, descriptors.rs:123-159
+            for (int k = i0; k < i0 + st && !oob; ++k) {
+                for (int l = j0; l < j0 + st; ++l) {
+                    float lf = (float)l, kf = (float)k;
+                    float sample_y = yf + (lf * co * scale + kf * si * scale);
+                    float sample_x = xf + (-lf * si * scale + kf * co * scale);
+                    int y1 = sat_i32(roundf(sample_y));
+                    int x1 = sat_i32(roundf(sample_x));
+                    if (x1 < 0 || x1 >= L.w || y1 < 0 || y1 >= L.h) {
+                        oob = true;  // Error::SampleOutOfBounds -> the keypoint is dropped (descriptors.rs:28)
+                        break;
+                    }
+                    size_t p = (size_t)y1 * L.w + x1;
+                    float ri = LT[p];
+                    di += ri;
+                    if (nch > 1) {
+                        float rx = LX[p], ry = LY[p];
+                        if (nch == 2) {
+                            dx += sqrtf(rx * rx + ry * ry);
+                        } else {
+                            float rry = rx * co + ry * si;
+                            float rrx = -rx * si + ry * co;
+                            dx += rrx;
+                            dy += rry;
+                        }
+                    }
+                    nsamples += 1;
+                }
+            }
+            if (!oob) {
+                float ns = (float)nsamples;
+                di /= ns;
+                dx /= ns;
+                dy /= ns;
+                int vb = c_desc.vbase[lane];
+                s_val[wv][vb] = di;
+                if (nch > 1) s_val[wv][vb + 1] = dx;
+                if (nch > 2) s_val[wv][vb + 2] = dy;
+            }
+        }
+        oob = __any(oob);
+    }
+    __syncthreads();
+    if (active) {
+        // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
+        uint32_t byte = 0;
+        if (!oob) {
+            for (int t = 0; t < 8; ++t) {
+                int b = lane * 8 + t;
+                if (b < c_desc.n_bits) {
+                    float va = s_val[wv][c_desc.cmp_a[b]], vb = s_val[wv][c_desc.cmp_b[b]];
+                    byte |= (va > vb ? 1u : 0u) << t;
+                }
+            }
+        }
+        out[(size_t)frame * stride + ki].bytes[lane] = (uint8_t)byte;
+        if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
+    }
+}
+
+void build_level_table(const akz_ctx* c, LevelTable* T)
+{
+    const AkzPlan& P = c->plan;
+    T->n = (int)P.levels.size();
+    uint32_t rb = 0;
+    for (int i = 0; i < T->n; ++i) {
+        const AkzLevel& L = P.levels[i];
+        LevelDesc& d = T->L[i];
+        d.Ldet = c->Ldet[i];
+        d.Lt = c->Lt[i];
+        d.Lx = c->Lx[i];
+        d.Ly = c->Ly[i];
+        d.w = L.w;
+        d.h = L.h;
+        d.fs = L.pixels();
+        d.octave = L.octave;
+        d.kp_size = L.kp_size;
+        d.row_base = rb;
+        rb += (uint32_t)L.h;
+    }
+    T->total_rows = rb;
+}
+
+}  // namespace
+
+size_t akz_ori_table_bytes() { return sizeof(OriTables); }
+size_t akz_desc_table_bytes() { return sizeof(DescTables); }
+
+// ---------------------------------------------------------------------------------------------
+// host-side constant tables
+int32_t akz_upload_tables(akz_ctx* c)
+{
+    const akz_config& cfg = c->cfg;
+    static const float GAUSS25[7][7] = {
+        {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+        {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+        {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+        {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+        {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+        {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+        {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f},
+    };
+    static const int id[13] = {6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6};
+    OriTables ot;
+    memset(&ot, 0, sizeof(ot));
+    int idx = 0;
+    for (int j = -6; j <= 6; ++j)
+        for (int i = -6; i <= 6; ++i)
+            if (i * i + j * j < 36) {
+                ot.di[idx] = (signed char)i;
+                ot.dj[idx] = (signed char)j;
+                ot.gw[idx] = GAUSS25[id[j + 6]][id[i + 6]];
+                idx++;
+            }
+    if (idx != 109) return AKZ_E_INTERNAL;
+    {
+        const float PI_F = 3.14159274101257324219f;
+        volatile float ang1 = 0.0f;  // volatile: keep the f32 accumulation literal
+        int nw = 0;
+        while (ang1 < 2.0f * PI_F && nw < 48) {
+            ot.ang1[nw++] = ang1;
+            ang1 = ang1 + 0.15f;
+        }
+        if (nw >= 48) return AKZ_E_INTERNAL;
+        ot.n_win = nw;
+    }
+    AKZ_HIP(hipMemcpy(c->d_ori, &ot, sizeof(ot), hipMemcpyHostToDevice));
+
+    DescTables dt;
+    memset(&dt, 0, sizeof(dt));
+    const int pattern = (int)cfg.descriptor_pattern_size;
+    const int nch = (int)cfg.descriptor_channels;
+    if (nch < 1 || nch > 3 || pattern < 1 || pattern > 100) return AKZ_E_INVALID;
+    const float size_mult[3] = {1.0f, 2.0f / 3.0f, 1.0f / 2.0f};
+    int cell = 0, vpos_total = 0, bit = 0;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        int val_count = (lvl + 2) * (lvl + 2);
+        float fs = ceilf((float)pattern * size_mult[lvl]);
+        int step = (int)fs;
+        if (step < 1) return AKZ_E_INVALID;
+        int cells_here = 0;
+        // the value array is REUSED per grid in the reference (values[valuepos] restarts at 0); we keep one
+        // private segment per grid instead, which the comparison table indexes accordingly.
+        for (int i = -pattern; i < pattern; i += step)
+            for (int j = -pattern; j < pattern; j += step) {
+                if (cell >= 32) return AKZ_E_INVALID;
+                dt.ci[cell] = (signed char)i;
+                dt.cj[cell] = (signed char)j;
+                dt.step[cell] = (unsigned char)step;
+                dt.vbase[cell] = (unsigned char)(vpos_total + cells_here * nch);
+                cell++;
+                cells_here++;
+            }
+        if (cells_here != val_count) return AKZ_E_INVALID;  // the reference assumes (lvl+2)^2 cells
+        for (int pos = 0; pos < nch; ++pos)
+            for (int i = 0; i < val_count; ++i)
+                for (int j = i + 1; j < val_count; ++j) {
+                    if (bit >= 512) return AKZ_E_INVALID;
+                    dt.cmp_a[bit] = (unsigned char)(vpos_total + nch * i + pos);
+                    dt.cmp_b[bit] = (unsigned char)(vpos_total + nch * j + pos);
+                    bit++;
+                }
+        vpos_total += val_count * nch;
+    }
+    dt.n_cells = cell;
+    dt.nch = nch;
+    dt.n_bits = bit;
+    if (vpos_total > 96) return AKZ_E_INVALID;
+    AKZ_HIP(hipMemcpy(c->d_desc, &dt, sizeof(dt), hipMemcpyHostToDevice));
+    return AKZ_OK;
+}
+
+int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
+                          uint32_t* d_n_out)
+{
+    const AkzPlan& P = c->plan;
+    hipStream_t s = c->stream;
+    LevelTable T;
+    if ((int)P.levels.size() > kMaxLevels) return AKZ_E_INVALID;
+    build_level_table(c, &T);
+    const uint32_t rows_stride = (uint32_t)P.total_rows + 1;
+    const float thr = (float)c->cfg.detector_threshold;
+    if (T.n == 0) {
+        AKZ_HIP(hipMemsetAsync(d_n_out, 0, sizeof(uint32_t) * n, s));
+        return AKZ_OK;
+    }
+    // A12a: ordered candidate lists
+    AKZ_HIP(hipMemsetAsync(c->d_rowcount, 0, sizeof(uint32_t) * (size_t)rows_stride * n, s));
+    for (int i = 0; i < T.n; ++i) {
+        if (T.L[i].h < 3 || T.L[i].w < 3) continue;
+        hipLaunchKernelGGL(k_cand_count, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, c->d_rowcount,
+                           rows_stride);
+        AKZ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_row_scan, dim3(n), dim3(1024), 0, s, c->d_rowcount, rows_stride, T.total_rows, c->d_ncand);
+    AKZ_LAUNCH_CHECK();
+    for (int i = 0; i < T.n; ++i) {
+        if (T.L[i].h < 3 || T.L[i].w < 3) continue;
+        hipLaunchKernelGGL(k_cand_scatter, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, c->d_rowcount,
+                           rows_stride, c->d_cand, c->max_cand, c->d_err);
+        AKZ_LAUNCH_CHECK();
+    }
+    // A12b
+    hipLaunchKernelGGL(k_suppress, dim3(n), dim3(256), sizeof(ActEntry) * kActCap + 64, s, T, c->d_rowcount, rows_stride,
+                       c->d_cand, c->max_cand, c->d_cache, c->max_kp, c->d_ncache, c->d_err);
+    AKZ_LAUNCH_CHECK();
+    const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
+    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, c->d_cache, c->max_kp, c->d_ncache, c->d_flag_b);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, c->d_cache, (const akz_descriptor*)nullptr,
+                       c->d_flag_b, c->d_ncache, c->max_kp, c->d_kp_a, (akz_descriptor*)nullptr, c->max_kp, c->d_n_a,
+                       c->d_err);
+    AKZ_LAUNCH_CHECK();
+    // A13 + A14
+    const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
+    hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, c->d_kp_a, c->d_n_a, c->max_kp, c->d_kp_b,
+                       c->d_flag_b, c->d_err);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, c->d_kp_b, (const akz_descriptor*)nullptr,
+                       c->d_flag_b, c->d_n_a, c->max_kp, c->d_kp_c, (akz_descriptor*)nullptr, c->max_kp, c->d_n_c,
+                       c->d_err);
+    AKZ_LAUNCH_CHECK();
+    // A15
+    uint32_t np2 = 1;
+    while (np2 < c->max_kp) np2 <<= 1;
+    uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, c->d_kp_c, c->d_n_c,
+                       c->max_kp, maxf, c->d_kp_d, c->d_n_d);
+    AKZ_LAUNCH_CHECK();
+    // A16 + A17
+    hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d, c->d_n_d, c->max_kp, c->d_desc_tmp,
+                       c->d_flag_d);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, c->d_kp_d, c->d_desc_tmp, c->d_flag_d, c->d_n_d,
+                       c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}

@@ -1,0 +1,573 @@
+// akz_scale_space.hip — gfx950 kernels for the nonlinear scale space and the Hessian response
+// (SURVEY.md §8a rows A1..A11).  Compiled with -ffp-contract=off: every f32 expression below is
+// evaluated in exactly the order the reference evaluates it, one rounding per operation.
+//
+// Reference functions implemented here (paths relative to the rust-cv/cv checkout):
+//   GrayFloatImage::from_dynamic (Luma8 arm)      akaze/src/image.rs:47-56          k_blur_tile<.., uint8_t, ..>
+//   horizontal_filter / vertical_filter           akaze/src/image.rs:202-331        lane4_dot(), k_filter1d
+//   gaussian_blur                                 akaze/src/image.rs:383-389        k_blur_tile
+//   GrayFloatImage::half_size                     akaze/src/image.rs:154-199        k_half_size
+//   simple_scharr_horizontal / _vertical          akaze/src/derivatives.rs:3-11     k_blur_tile epilogues
+//   compute_contrast_factor                       akaze/src/contrast_factor.rs:16-64  EPI_CMAX / EPI_CHIST / k_contrast_finish
+//   pm_g2                                         akaze/src/nonlinear_diffusion.rs:70-83  EPI_FLOW
+//   calculate_step                                akaze/src/nonlinear_diffusion.rs:14-58  k_fed_step*
+//   scharr_horizontal / scharr_vertical           akaze/src/derivatives.rs:23-79    k_deriv_first / k_deriv_second
+//   Akaze::detector_response                      akaze/src/detector_response.rs:33-57   k_deriv_second
+//   Akaze::create_nonlinear_scale_space           akaze/src/lib.rs:193-258          akz_run_scale_space
+//
+// Layout: every pyramid buffer is a dense row-major f32 plane per frame, frames back to back
+// (frame stride = level pixels), so consecutive lanes touch consecutive addresses of one row and
+// blockIdx.z selects the frame: one launch covers the whole batch.
+//
+// Clamp-border rule used by every fused stage: an on-chip tile position holds the value of the
+// image at the CLAMPED coordinate of that position, and a stage evaluated at a position outside
+// the image is evaluated at its clamped coordinate.  That is exactly what the reference's
+// edge-replicated scratch rows/columns produce stage by stage.
+#include "akz_ctx.h"
+
+namespace {
+
+constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
+constexpr int kTH = 32;  // output tile height
+
+enum { EPI_BLUR = 0, EPI_FLOW = 1, EPI_CMAX = 2, EPI_CHIST = 3 };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float load_px(const float* p, size_t i) { return p[i]; }
+// image.rs:54 — f32::from(v) / 255f32: a true IEEE division per pixel.
+__device__ __forceinline__ float load_px(const uint8_t* p, size_t i) { return (float)p[i] / 255.0f; }
+
+// wide::f32x4 accumulate + reduce_add as used by horizontal_filter/vertical_filter
+// (image.rs:242-247, :320-325): tap i goes to lane i&3, lanes accumulate in chunk order with an
+// unfused multiply-then-add starting from +0, lanes are summed ((a0+a1)+a2)+a3.
+template <int N>
+__device__ __forceinline__ float lane4_dot(const float* s, int stride, const float* k)
+{
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float p = s[i * stride] * k[i];
+        if ((i & 3) == 0) a0 = p + a0;
+        else if ((i & 3) == 1) a1 = p + a1;
+        else if ((i & 3) == 2) a2 = p + a2;
+        else a3 = p + a3;
+    }
+    return ((a0 + a1) + a2) + a3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused Gaussian tile kernel: [u8->f32] -> H pass -> V pass -> epilogue, all intermediates
+// materialised as rounded f32 in LDS exactly like the reference's intermediate images.
+//   R = Gaussian radius (4 for sigma 1.6, 2 for sigma 1.0), E = extra halo the epilogue needs.
+template <int R, int E, typename InT, int EPI>
+__global__ __launch_bounds__(256) void k_blur_tile(const InT* __restrict__ in, int w, int h, size_t in_fs,
+                                                   GaussTaps taps, float* __restrict__ out_g,
+                                                   float* __restrict__ out_flow, size_t out_fs,
+                                                   const float* __restrict__ invk, int invk_off,
+                                                   unsigned long long* __restrict__ cmax,
+                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ npoints,
+                                                   int nbins)
+{
+    constexpr int N = 2 * R + 1;
+    constexpr int GW = kTW + 2 * E, GH = kTH + 2 * E;  // blurred region
+    constexpr int IW = GW + 2 * R, IH = GH + 2 * R;    // input region
+    __shared__ float s_in[IH * IW];
+    __shared__ float s_h[IH * GW];
+    __shared__ float s_g[GH * GW];
+    __shared__ uint32_t s_hist[(EPI == EPI_CHIST) ? 512 : 1];
+    __shared__ double s_red[(EPI == EPI_CMAX) ? 4 : 1];
+
+    const int frame = blockIdx.z;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+    const int tid = threadIdx.x;
+    const InT* src = in + (size_t)frame * in_fs;
+
+    for (int idx = tid; idx < IH * IW; idx += 256) {
+        int iy = idx / IW, ix = idx - iy * IW;
+        int cx = clampi(tx0 - E - R + ix, 0, w - 1);
+        int cy = clampi(ty0 - E - R + iy, 0, h - 1);
+        s_in[idx] = load_px(src, (size_t)cy * w + cx);
+    }
+    if (EPI == EPI_CHIST)
+        for (int i = tid; i < 512; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    // horizontal pass at the clamped column of each position
+    for (int idx = tid; idx < IH * GW; idx += 256) {
+        int j = idx / GW, p = idx - j * GW;
+        int cc = clampi(tx0 - E + p, 0, w - 1);
+        s_h[idx] = lane4_dot<N>(&s_in[j * IW + (cc - tx0 + E)], 1, taps.k);
+    }
+    __syncthreads();
+    // vertical pass at the clamped row of each position
+    for (int idx = tid; idx < GH * GW; idx += 256) {
+        int q = idx / GW, p = idx - q * GW;
+        int rc = clampi(ty0 - E + q, 0, h - 1);
+        s_g[idx] = lane4_dot<N>(&s_h[(rc - ty0 + E) * GW + p], GW, taps.k);
+    }
+    __syncthreads();
+
+    if (EPI == EPI_BLUR) {
+        float* dst = out_g + (size_t)frame * out_fs;
+        for (int idx = tid; idx < kTH * kTW; idx += 256) {
+            int q = idx / kTW, p = idx - q * kTW;
+            int x = tx0 + p, y = ty0 + q;
+            if (x < w && y < h) dst[(size_t)y * w + x] = s_g[(q + E) * GW + (p + E)];
+        }
+        return;
+    }
+
+    // simple Scharr on the blurred tile (derivatives.rs:3-11) in the reference's lane order:
+    //   Lx = V[3,10,3](H[-1,0,1] g):  hx = g(x+1) - g(x-1);  Lx = (3*hx(y-1) + 10*hx(y)) + 3*hx(y+1)
+    //   Ly = V[-1,0,1](H[3,10,3] g):  hy = (3*g(x-1) + 10*g(x)) + 3*g(x+1);  Ly = hy(y+1) - hy(y-1)
+    double lmax = -1.0;
+    float inverse_k = 0.0f;
+    double hmax = 0.0;
+    if (EPI == EPI_FLOW) inverse_k = invk[(size_t)frame * 8 + invk_off];
+    if (EPI == EPI_CHIST) hmax = sqrt(__longlong_as_double((long long)cmax[frame]));
+    for (int idx = tid; idx < kTH * kTW; idx += 256) {
+        int q = idx / kTW, p = idx - q * kTW;
+        int x = tx0 + p, y = ty0 + q;
+        if (x >= w || y >= h) continue;
+        const float* g = &s_g[(q + E) * GW + (p + E)];
+        float hx_m = g[-GW + 1] - g[-GW - 1];
+        float hx_0 = g[1] - g[-1];
+        float hx_p = g[GW + 1] - g[GW - 1];
+        float lx = (3.0f * hx_m + 10.0f * hx_0) + 3.0f * hx_p;
+        float hy_m = (3.0f * g[-GW - 1] + 10.0f * g[-GW]) + 3.0f * g[-GW + 1];
+        float hy_p = (3.0f * g[GW - 1] + 10.0f * g[GW]) + 3.0f * g[GW + 1];
+        float ly = hy_p - hy_m;
+        if (EPI == EPI_FLOW) {
+            out_g[(size_t)frame * out_fs + (size_t)y * w + x] = g[0];
+            // pm_g2, nonlinear_diffusion.rs:80
+            out_flow[(size_t)frame * out_fs + (size_t)y * w + x] =
+                1.0f / (1.0f + inverse_k * (lx * lx + ly * ly));
+        } else {
+            // contrast_factor.rs:27-37: interior pixels only; squares in f32, sum in f64
+            if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) {
+                double v = (double)(lx * lx) + (double)(ly * ly);
+                if (EPI == EPI_CMAX) {
+                    lmax = v > lmax ? v : lmax;
+                } else {
+                    double modg = sqrt(v);
+                    if (modg != 0.0) {
+                        double b = floor((double)nbins * (modg / hmax));
+                        int bin = b >= (double)nbins ? nbins - 1 : (int)b;
+                        atomicAdd(&s_hist[bin], 1u);
+                        atomicAdd(&s_hist[511], 1u);  // num_points
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == EPI_CMAX) {
+        // non-negative doubles order like their bit patterns: wave max by shuffles, one atomic per block
+        for (int off = 32; off > 0; off >>= 1) {
+            double o = __shfl_down(lmax, off);
+            lmax = o > lmax ? o : lmax;
+        }
+        if ((tid & 63) == 0) s_red[tid >> 6] = lmax;
+        __syncthreads();
+        if (tid == 0) {
+            double m = s_red[0];
+            for (int i = 1; i < 4; ++i) m = s_red[i] > m ? s_red[i] : m;
+            if (m >= 0.0) atomicMax(&cmax[frame], (unsigned long long)__double_as_longlong(m));
+        }
+    }
+    if (EPI == EPI_CHIST) {
+        __syncthreads();
+        for (int i = tid; i < nbins; i += 256)
+            if (s_hist[i]) atomicAdd(&hist[(size_t)frame * nbins + i], s_hist[i]);
+        if (tid == 0 && s_hist[511]) atomicAdd(&npoints[frame], s_hist[511]);
+    }
+}
+
+// contrast_factor.rs:48-63 + the per-octave `contrast_factor *= 0.75` of lib.rs:222 and the
+// inverse_k of nonlinear_diffusion.rs:73.  One thread per frame (scalar f64 work).
+__global__ void k_contrast_finish(const unsigned long long* __restrict__ cmax, const uint32_t* __restrict__ hist,
+                                  const uint32_t* __restrict__ npoints, int nbins, double percentile, int n,
+                                  int n_octaves, double* __restrict__ contrast, float* __restrict__ invk)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    double hmax = sqrt(__longlong_as_double((long long)cmax[f]));
+    double num_points = (double)npoints[f];
+    double t = num_points * percentile;
+    unsigned long long threshold = t > 0.0 ? (unsigned long long)t : 0ull;
+    unsigned long long num_elements = 0;
+    int k = 0;
+    while (num_elements < threshold && k < nbins) {
+        num_elements += hist[(size_t)f * nbins + k];
+        k += 1;
+    }
+    double cf = (num_elements >= threshold) ? hmax * (double)k / (double)nbins : 0.03;
+    contrast[f] = cf;
+    for (int o = 0; o < 8; ++o) {
+        if (o > 0) cf *= 0.75;
+        invk[(size_t)f * 8 + o] = (o < n_octaves) ? (float)(1.0 / (cf * cf)) : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// half_size — image.rs:154-199.  2x2 window sum is (a+b)+(c+d) (ndarray row-wise fold), odd edges
+// take the 1x2 / 2x1 / 1x1 rule from the LAST input row/column.
+__global__ __launch_bounds__(256) void k_half_size(const float* __restrict__ in, float* __restrict__ out, int w,
+                                                   int h, size_t in_fs, size_t out_fs)
+{
+    int ow = w >> 1, oh = h >> 1;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const float* src = in + (size_t)blockIdx.z * in_fs;
+    bool last_row = (oh * 2 != h) && (y == oh - 1);
+    bool last_col = (ow * 2 != w) && (x == ow - 1);
+    float v;
+    if (last_row && last_col) {
+        v = src[(size_t)(h - 1) * w + (w - 1)];
+    } else if (last_col) {
+        v = (src[(size_t)(2 * y) * w + (w - 1)] + src[(size_t)(2 * y + 1) * w + (w - 1)]) * 0.5f;
+    } else if (last_row) {
+        v = (src[(size_t)(h - 1) * w + 2 * x] + src[(size_t)(h - 1) * w + 2 * x + 1]) * 0.5f;
+    } else {
+        const float* p = src + (size_t)(2 * y) * w + 2 * x;
+        v = ((p[0] + p[1]) + (p[w] + p[w + 1])) * 0.25f;
+    }
+    out[(size_t)blockIdx.z * out_fs + (size_t)y * ow + x] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// calculate_step — nonlinear_diffusion.rs:14-58.  Jacobi: flows from the pre-update image `src`,
+//   hf(x) = ((0.5*tau)*(c(x)+c(x+1)))*(L(x+1)-L(x)),  vf likewise in y,
+//   dst = (((L + hf(x)) - hf(x-1)) + vf(y)) - vf(y-1), terms that cross the border are skipped.
+// HBM traffic per pixel-step: 4 B (L) + 4 B (c) read, 4 B write = 12 B.
+__device__ __forceinline__ float fed_flow(float ht, float ca, float cb, float a, float b)
+{
+    return (ht * (ca + cb)) * (b - a);
+}
+
+// scalar variant (any width)
+__global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src, const float* __restrict__ c,
+                                                  float* __restrict__ dst, int w, int h, size_t fs, float half_tau)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    size_t base = (size_t)blockIdx.z * fs + (size_t)y * w + x;
+    const float* L = src + base;
+    const float* C = c + base;
+    float l0 = L[0], c0 = C[0];
+    float v = l0;
+    if (x < w - 1) v = v + fed_flow(half_tau, c0, C[1], l0, L[1]);
+    if (x > 0) v = v - fed_flow(half_tau, C[-1], c0, L[-1], l0);
+    if (y < h - 1) v = v + fed_flow(half_tau, c0, C[w], l0, L[w]);
+    if (y > 0) v = v - fed_flow(half_tau, C[-w], c0, L[-w], l0);
+    dst[base] = v;
+}
+
+// 4 pixels per lane (w % 4 == 0): row segments move as dwordx4, a wave covers 256 contiguous pixels.
+__global__ __launch_bounds__(256) void k_fed_step_x4(const float* __restrict__ src, const float* __restrict__ c,
+                                                     float* __restrict__ dst, int w, int h, size_t fs,
+                                                     float half_tau)
+{
+    int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    size_t base = (size_t)blockIdx.z * fs + (size_t)y * w + x;
+    const float* L = src + base;
+    const float* C = c + base;
+    float4 l = *reinterpret_cast<const float4*>(L);
+    float4 cc = *reinterpret_cast<const float4*>(C);
+    float lv[6], cv[6];
+    lv[1] = l.x; lv[2] = l.y; lv[3] = l.z; lv[4] = l.w;
+    cv[1] = cc.x; cv[2] = cc.y; cv[3] = cc.z; cv[4] = cc.w;
+    bool has_l = x > 0, has_r = x + 4 < w;
+    lv[0] = has_l ? L[-1] : 0.0f;
+    cv[0] = has_l ? C[-1] : 0.0f;
+    lv[5] = has_r ? L[4] : 0.0f;
+    cv[5] = has_r ? C[4] : 0.0f;
+    float hf[5];  // hf[i] = flow between pixel (x-1+i) and (x+i)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) hf[i] = fed_flow(half_tau, cv[i], cv[i + 1], lv[i], lv[i + 1]);
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = lv[i + 1];
+        if (i < 3 || has_r) v = v + hf[i + 1];
+        if (i > 0 || has_l) v = v - hf[i];
+        r[i] = v;
+    }
+    if (y < h - 1) {
+        float4 ld = *reinterpret_cast<const float4*>(L + w);
+        float4 cd = *reinterpret_cast<const float4*>(C + w);
+        r[0] = r[0] + fed_flow(half_tau, cc.x, cd.x, l.x, ld.x);
+        r[1] = r[1] + fed_flow(half_tau, cc.y, cd.y, l.y, ld.y);
+        r[2] = r[2] + fed_flow(half_tau, cc.z, cd.z, l.z, ld.z);
+        r[3] = r[3] + fed_flow(half_tau, cc.w, cd.w, l.w, ld.w);
+    }
+    if (y > 0) {
+        float4 lu = *reinterpret_cast<const float4*>(L - w);
+        float4 cu = *reinterpret_cast<const float4*>(C - w);
+        r[0] = r[0] - fed_flow(half_tau, cu.x, cc.x, lu.x, l.x);
+        r[1] = r[1] - fed_flow(half_tau, cu.y, cc.y, lu.y, l.y);
+        r[2] = r[2] - fed_flow(half_tau, cu.z, cc.z, lu.z, l.z);
+        r[3] = r[3] - fed_flow(half_tau, cu.w, cc.w, lu.w, l.w);
+    }
+    *reinterpret_cast<float4*>(dst + base) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
+// {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
+// {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
+//   main kernel [-1,0..0,1]:      v(+s) - v(-s)                          (every sigma)
+//   off  kernel [n,0..,m,..0,n]:  (v(-s)*n + v(+s)*n) + v(0)*m           (sigma with 2*sigma % 4 != 0 ... see below)
+//                                 (v(-s)*n + v(0)*m) + v(+s)*n           (sigma % 4 == 0: all three taps share lane 0)
+// sigma == 2: taps 0,2,4 -> lanes 0,2,0: lane0 = v(+s)n + v(-s)n, lane2 = v(0)m -> (lane0 + lane2)
+// sigma == 3: taps 0,3,6 -> lanes 0,3,2: ((v(-s)n + 0) + v(+s)n) + v(0)m
+// sigma == 1 is the unnormalised simple Scharr [3,10,3]: (3 v(-1) + 10 v(0)) + 3 v(+1).
+struct OffK {
+    float n, m;
+    int mode;  // 0: (a*n + c*n) + b*m   1: (a*n + b*m) + c*n    (a = v(-s), b = v(0), c = v(+s))
+};
+__device__ __forceinline__ float off_combine(const OffK k, float a, float b, float c)
+{
+    float pa = a * k.n, pb = b * k.m, pc = c * k.n;
+    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+}
+
+// Lx = V_off(H_main(Lsmooth)), Ly = V_main(H_off(Lsmooth)) — detector_response.rs:63-64.
+__global__ __launch_bounds__(256) void k_deriv_first(const float* __restrict__ sm, float* __restrict__ Lx,
+                                                     float* __restrict__ Ly, int w, int h, size_t fs, int s, OffK k)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* S = sm + (size_t)blockIdx.z * fs;
+    int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
+    size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
+    float mm = S[rm + xm], m0 = S[rm + x], mp = S[rm + xp];
+    float zm = S[r0 + xm], zp = S[r0 + xp];
+    float pm = S[rp + xm], p0 = S[rp + x], pp = S[rp + xp];
+    // H_main rows
+    float hm_m = mp - mm, hm_0 = zp - zm, hm_p = pp - pm;
+    float lx = off_combine(k, hm_m, hm_0, hm_p);
+    // H_off rows y-s and y+s
+    float ho_m = off_combine(k, mm, m0, mp);
+    float ho_p = off_combine(k, pm, p0, pp);
+    float ly = ho_p - ho_m;
+    size_t o = (size_t)blockIdx.z * fs + r0 + x;
+    Lx[o] = lx;
+    Ly[o] = ly;
+}
+
+// Lxx = scharr_h(Lx) = V_off(H_main Lx); Lyy = scharr_v(Ly) = V_main(H_off Ly); Lxy = scharr_v(Lx) =
+// V_main(H_off Lx) — detector_response.rs:65-67; Ldet = (Lxx*Lyy - Lxy*Lxy) * sigma^4 — :46.
+__global__ __launch_bounds__(256) void k_deriv_second(const float* __restrict__ Lx, const float* __restrict__ Ly,
+                                                      float* __restrict__ Ldet, int w, int h, size_t fs, int s,
+                                                      OffK k, float sigma_quat)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* X = Lx + (size_t)blockIdx.z * fs;
+    const float* Y = Ly + (size_t)blockIdx.z * fs;
+    int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
+    size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
+    float xmm = X[rm + xm], xm0 = X[rm + x], xmp = X[rm + xp];
+    float xzm = X[r0 + xm], xzp = X[r0 + xp];
+    float xpm = X[rp + xm], xp0 = X[rp + x], xpp = X[rp + xp];
+    float lxx = off_combine(k, xmp - xmm, xzp - xzm, xpp - xpm);
+    float lxy = off_combine(k, xpm, xp0, xpp) - off_combine(k, xmm, xm0, xmp);
+    float lyy = off_combine(k, Y[rp + xm], Y[rp + x], Y[rp + xp]) - off_combine(k, Y[rm + xm], Y[rm + x], Y[rm + xp]);
+    Ldet[(size_t)blockIdx.z * fs + r0 + x] = (lxx * lyy - lxy * lxy) * sigma_quat;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic dense 1-D filter for the stand-alone akaze::image API (image.rs:202-331), any odd ksize.
+__global__ __launch_bounds__(256) void k_filter1d(const float* __restrict__ in, float* __restrict__ out, int w, int h,
+                                                  const float* __restrict__ kern, int ksize, int vertical)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    int half = ksize / 2;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < ksize; ++i) {
+        float s = vertical ? in[(size_t)clampi(y + i - half, 0, h - 1) * w + x]
+                           : in[(size_t)y * w + clampi(x + i - half, 0, w - 1)];
+        float p = s * kern[i];
+        int l = i & 3;
+        // (branch-free lane select keeps a[] in registers)
+        a[0] = l == 0 ? p + a[0] : a[0];
+        a[1] = l == 1 ? p + a[1] : a[1];
+        a[2] = l == 2 ? p + a[2] : a[2];
+        a[3] = l == 3 ? p + a[3] : a[3];
+    }
+    out[(size_t)y * w + x] = ((a[0] + a[1]) + a[2]) + a[3];
+}
+
+OffK make_offk(uint32_t sigma)
+{
+    ScharrW sw = akz_scharr_weights(sigma);
+    OffK k;
+    if (sigma == 1) {  // simple_scharr: [3,10,3], taps in lanes 0,1,2 -> (a*3 + b*10) + c*3
+        k.n = 3.0f;
+        k.m = 10.0f;
+        k.mode = 1;
+    } else {
+        k.n = sw.norm;
+        k.m = sw.middle;
+        // tap indices 0, sigma, 2*sigma -> lanes 0, sigma&3, (2*sigma)&3, chunks idx>>2.
+        int lb = sigma & 3, lc = (2 * sigma) & 3;
+        if (lc == 0 && lb != 0) {
+            k.mode = 0;  // a and c share lane 0: lane0 = c*n + a*n; then + lane(lb) = b*m
+        } else if (lb == 0) {
+            k.mode = 1;  // all three in lane 0, chunk order a, b, c: (a*n + b*m) + c*n
+        } else {
+            // three distinct lanes 0, lb, lc summed in lane order 0,1,2,3
+            k.mode = (lb < lc) ? 1 : 0;
+        }
+    }
+    return k;
+}
+
+inline dim3 grid_px(int w, int h, int n) { return dim3(akz_div_up(w, 64), akz_div_up(h, 4), n); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel, int ksize,
+                         int vertical)
+{
+    hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, in, out, w, h, d_kernel, ksize, vertical);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
+                          size_t out_fs)
+{
+    if (w / 2 <= 0 || h / 2 <= 0) return AKZ_E_INVALID;
+    hipLaunchKernelGGL(k_half_size, grid_px(w / 2, h / 2, n), dim3(256), 0, s, in, out, w, h, in_fs, out_fs);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+template <int R, int E, typename InT, int EPI>
+static int32_t launch_blur(akz_ctx* c, const InT* in, int w, int h, size_t in_fs, const GaussTaps& taps, float* out_g,
+                           float* out_flow, size_t out_fs, int invk_off, int n)
+{
+    dim3 grid(akz_div_up(w, kTW), akz_div_up(h, kTH), n);
+    hipLaunchKernelGGL((k_blur_tile<R, E, InT, EPI>), grid, dim3(256), 0, c->stream, in, w, h, in_fs, taps, out_g,
+                       out_flow, out_fs, c->d_invk, invk_off, c->d_cmax, c->d_hist, c->d_npoints,
+                       (int)c->cfg.contrast_factor_num_bins);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+static GaussTaps make_taps(float sigma)
+{
+    GaussTaps t;
+    int r = akz_gaussian_radius(sigma);
+    t.n = 2 * r + 1;
+    for (int i = 0; i < 12; ++i) t.k[i] = 0.0f;
+    akz_host_gaussian_kernel(sigma, t.n, t.k);
+    return t;
+}
+
+template <typename InT>
+static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
+{
+    const AkzPlan& P = c->plan;
+    const int w = P.w, h = P.h;
+    const size_t P0 = (size_t)w * h;
+    const int nlev = (int)P.levels.size();
+    if (nlev == 0) return AKZ_OK;
+    hipStream_t s = c->stream;
+    const int nbins = (int)c->cfg.contrast_factor_num_bins;
+
+    // base_scale_offset and the gradient-histogram scale are config values; the fused tile kernel is
+    // instantiated for the radii the AKAZE path uses (sigma 1.6 -> 4, sigma 1.0 -> 2).
+    GaussTaps t0 = make_taps((float)c->cfg.base_scale_offset);
+    GaussTaps t1 = make_taps(1.0f);
+    if (t0.n != 9 || t1.n != 5) return AKZ_E_INVALID;
+
+    akz_timer_begin(c, &c->t_ss);
+    // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
+    AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, c->Lt[0], nullptr, P0, 0, n)));
+    // lib.rs:206-211 — contrast factor on the ORIGINAL image
+    AKZ_HIP(hipMemsetAsync(c->d_cmax, 0, sizeof(unsigned long long) * n, s));
+    AKZ_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
+    AKZ_HIP(hipMemsetAsync(c->d_npoints, 0, sizeof(uint32_t) * n, s));
+    AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
+    AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
+    hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, c->d_cmax, c->d_hist,
+                       c->d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, c->d_contrast, c->d_invk);
+    AKZ_LAUNCH_CHECK();
+
+    uint64_t fed_launches = 0, fed_units = 0;
+    for (int i = 0; i < nlev; ++i) {
+        const AkzLevel& L = P.levels[i];
+        const size_t fs = L.pixels();
+        const float* smooth = c->Lt[0];
+        if (i > 0) {
+            const int nsteps = (int)L.tau.size();
+            // Ping-pong so the last FED step lands in Lt[i]; `init` is where the un-diffused Lt[i] lives.
+            float* bufA = c->Lt[i];
+            float* bufB = c->tmp;
+            const float* init;
+            if (L.new_octave) {
+                const AkzLevel& Lp = P.levels[i - 1];
+                float* half_dst = (nsteps % 2 == 0) ? bufA : bufB;  // step 0 must not write where it reads
+                if (nsteps == 0) half_dst = bufA;
+                AKZ_TRY(akz_dev_half_size(s, c->Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
+                init = half_dst;
+            } else {
+                init = c->Lt[i - 1];  // lib.rs:230 clone(): read in place, never modified again
+            }
+            // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
+            AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, c->Lsm[i], c->Lflow[i], fs,
+                                                       (int)L.octave, n)));
+            // lib.rs:251-256 — FED cycle
+            akz_timer_begin(c, &c->t_fed);
+            const float* src = init;
+            for (int j = 0; j < nsteps; ++j) {
+                float* dst = ((nsteps - 1 - j) % 2 == 0) ? bufA : bufB;
+                float half_tau = 0.5f * (float)L.tau[j];
+                if ((L.w & 3) == 0) {
+                    hipLaunchKernelGGL(k_fed_step_x4, dim3(akz_div_up(L.w, 256), akz_div_up(L.h, 4), n), dim3(256), 0,
+                                       s, src, c->Lflow[i], dst, L.w, L.h, fs, half_tau);
+                } else {
+                    hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, c->Lflow[i], dst, L.w,
+                                       L.h, fs, half_tau);
+                }
+                AKZ_LAUNCH_CHECK();
+                src = dst;
+            }
+            akz_timer_end(c, &c->t_fed, (uint64_t)nsteps, (uint64_t)nsteps * fs * n);
+            fed_launches += nsteps;
+            fed_units += (uint64_t)nsteps * fs * n;
+            if (nsteps == 0 && init != bufA)
+                AKZ_HIP(hipMemcpyAsync(bufA, init, sizeof(float) * fs * n, hipMemcpyDeviceToDevice, s));
+            smooth = c->Lsm[i];
+        }
+        // detector_response.rs:60-67 + :33-57
+        OffK k = make_offk(L.deriv_sigma);
+        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, c->Lx[i], c->Ly[i], L.w, L.h,
+                           fs, (int)L.deriv_sigma, k);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, c->Lx[i], c->Ly[i], c->Ldet[i], L.w,
+                           L.h, fs, (int)L.deriv_sigma, k, L.sigma_quat);
+        AKZ_LAUNCH_CHECK();
+    }
+    akz_timer_end(c, &c->t_ss, 0, (uint64_t)n);
+    (void)fed_launches;
+    (void)fed_units;
+    return AKZ_OK;
+}
+
+int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n)
+{
+    if (fmt == 0) return scale_space_impl<uint8_t>(c, (const uint8_t*)d_imgs, n);
+    return scale_space_impl<float>(c, (const float*)d_imgs, n);
+}

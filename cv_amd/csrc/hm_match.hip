@@ -1,0 +1,389 @@
+// hm_match.hip — brute-force Hamming 2-NN matcher for 512-bit descriptors on gfx950
+// (SURVEY.md §8a rows M1, M2).
+//
+// Replaces, for BitArray<64> descriptors (paths relative to the rust-cv/cv checkout):
+//   space::LinearKnn{metric: Hamming, iter}.knn(q, 2)   call sites akaze/tests/estimate_pose.rs:82-88,
+//                                                        tutorial-code/chapter5-…/src/main.rs:155-161
+//   matching / symmetric_matching                       tutorial ch5 main.rs:154-200, cv-sfm/src/lib.rs:3097-3133
+//   match_descriptors (Lowe ratio)                      akaze/tests/estimate_pose.rs:78-97
+//
+// Kernel shape: integer VALU work, not a GEMM.  A lane owns kQPT query descriptors in VGPRs
+// (16 dwords each); a workgroup stages a tile of targets in LDS and every lane walks the tile with
+// broadcast ds_read_b128, 16 x (v_xor_b32 + v_bcnt_u32_b32 accumulate) per distance.  The running
+// (nearest, second) pair per query is two packed keys  distance << 22 | target_index  updated with
+// v_min_u32 / v_med3_u32: smaller key == smaller (distance, index), which is exactly LinearKnn's
+// "lowest index wins ties" order (space 0.17: partition_point(d <= new) insertion).
+#include "akz_common.h"
+
+namespace {
+
+constexpr int kQPT = 2;          // queries per lane
+constexpr int kBlock = 256;
+constexpr int kQPB = kQPT * kBlock;  // queries per workgroup
+constexpr int kTile = 256;       // targets per LDS tile (16 KB)
+constexpr uint32_t kIdxBits = 22;
+
+struct HmProb {            // one (queries -> targets) problem
+    const uint4* q;        // query descriptors (4 x uint4 each)
+    const uint32_t* nq;    // device count
+    uint32_t q_cap;
+    const uint4* t;
+    const uint32_t* nt;
+    uint32_t t_cap;
+    akz_neighbor* out;     // [q_cap][2]
+};
+
+__global__ __launch_bounds__(kBlock) void k_knn2(const HmProb* __restrict__ probs)
+{
+    __shared__ uint4 s_t[kTile * 4];
+    const HmProb P = probs[blockIdx.y];
+    uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
+    const uint32_t q0 = blockIdx.x * kQPB;
+    if (q0 >= nq) return;
+    uint32_t qv[kQPT][16];
+    uint32_t k0[kQPT], k1[kQPT];
+#pragma unroll
+    for (int r = 0; r < kQPT; ++r) {
+        uint32_t qi = q0 + r * kBlock + threadIdx.x;
+        uint32_t qc = qi < nq ? qi : nq - 1;  // clamp: idle lanes redo the last query, results discarded
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            uint4 x = P.q[(size_t)qc * 4 + v];
+            qv[r][4 * v + 0] = x.x;
+            qv[r][4 * v + 1] = x.y;
+            qv[r][4 * v + 2] = x.z;
+            qv[r][4 * v + 3] = x.w;
+        }
+        k0[r] = 0xFFFFFFFFu;
+        k1[r] = 0xFFFFFFFFu;
+    }
+    for (uint32_t t0 = 0; t0 < nt; t0 += kTile) {
+        uint32_t cnt = min((uint32_t)kTile, nt - t0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt * 4; i += kBlock) s_t[i] = P.t[(size_t)t0 * 4 + i];
+        __syncthreads();
+        for (uint32_t j = 0; j < cnt; ++j) {
+            uint4 a = s_t[j * 4 + 0], b = s_t[j * 4 + 1], c = s_t[j * 4 + 2], d = s_t[j * 4 + 3];
+            uint32_t tv[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int r = 0; r < kQPT; ++r) {
+                uint32_t dist = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dist += __popc(qv[r][v] ^ tv[v]);
+                uint32_t key = (dist << kIdxBits) | (t0 + j);
+                // sorted pair (k0 <= k1): new k1 = median(k0, k1, key), new k0 = min(k0, key)
+                uint32_t lo = min(k0[r], key);
+                uint32_t hi = max(k0[r], key);
+                k1[r] = min(k1[r], hi);
+                k0[r] = lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kQPT; ++r) {
+        uint32_t qi = q0 + r * kBlock + threadIdx.x;
+        if (qi < nq) {
+            akz_neighbor n0 = {k0[r] & ((1u << kIdxBits) - 1u), k0[r] >> kIdxBits};
+            akz_neighbor n1 = {k1[r] & ((1u << kIdxBits) - 1u), k1[r] >> kIdxBits};
+            P.out[(size_t)qi * 2 + 0] = n0;
+            P.out[(size_t)qi * 2 + 1] = n1;
+        }
+    }
+}
+
+struct HmPairProb {
+    const akz_neighbor* fwd;  // [na][2]  a -> b
+    const akz_neighbor* rev;  // [nb][2]  b -> a (symmetric only)
+    const uint32_t* na;
+    const uint32_t* nb;
+    uint32_t a_cap, b_cap;
+    uint32_t* pairs;          // [cap][2]
+    uint32_t cap;
+    uint32_t* n_out;
+};
+
+__device__ __forceinline__ bool accept(int rule, uint32_t d0, uint32_t d1, uint32_t pu, float pf)
+{
+    if (rule == HM_RULE_BETTER_BY_STRICT) return d0 + pu < d1;   // ch5 main.rs:162
+    if (rule == HM_RULE_BETTER_BY) return d0 + pu <= d1;         // cv-sfm/src/lib.rs:3107
+    return (float)d0 < (float)d1 * pf;                           // akaze/tests/estimate_pose.rs:92
+}
+
+// matching() + symmetric_matching(): accept rule, reverse check, ordered (ascending a) compaction.
+__global__ __launch_bounds__(1024) void k_pairs(const HmPairProb* __restrict__ probs, int rule, uint32_t pu, float pf,
+                                                int symmetric)
+{
+    __shared__ uint32_t s_wave[16];
+    const HmPairProb P = probs[blockIdx.x];
+    uint32_t na = min(*P.na, P.a_cap), nb = min(*P.nb, P.b_cap);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t base = 0;
+    if (na < 2 || nb < 2) na = 0;  // cv-sfm/src/lib.rs:3099-3101 (the other call sites would panic)
+    for (uint32_t a0 = 0; a0 < na; a0 += 1024) {
+        uint32_t a = a0 + threadIdx.x;
+        bool keep = false;
+        uint32_t bidx = 0;
+        if (a < na) {
+            akz_neighbor n0 = P.fwd[(size_t)a * 2], n1 = P.fwd[(size_t)a * 2 + 1];
+            if (accept(rule, n0.distance, n1.distance, pu, pf)) {
+                bidx = n0.index;
+                keep = true;
+                if (symmetric) {
+                    akz_neighbor r0 = P.rev[(size_t)bidx * 2], r1 = P.rev[(size_t)bidx * 2 + 1];
+                    keep = accept(rule, r0.distance, r1.distance, pu, pf) && r0.index == a;
+                }
+            }
+        }
+        unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (keep) {
+            uint32_t o = base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (o < P.cap) {
+                P.pairs[(size_t)o * 2] = a;
+                P.pairs[(size_t)o * 2 + 1] = bidx;
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *P.n_out = base;
+}
+
+}  // namespace
+
+struct hm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t max_q = 0, max_t = 0;
+    // staging for the host-buffer API
+    uint4* d_a = nullptr;
+    uint4* d_b = nullptr;
+    uint32_t* d_na = nullptr;  // [2]: na, nb
+    akz_neighbor* d_fwd = nullptr;
+    akz_neighbor* d_rev = nullptr;
+    uint32_t* d_pairs = nullptr;
+    uint32_t* d_npairs = nullptr;
+    // problem descriptor ring (device) for batched calls
+    void* d_probs = nullptr;
+    void* h_probs = nullptr;   // pinned staging twin of d_probs
+    size_t probs_bytes = 0;
+    hipEvent_t ev_copy = nullptr;  // recorded after the last staging -> device descriptor copy
+    bool copy_pending = false;
+    // scratch knn results for batched device calls
+    akz_neighbor* d_bfwd = nullptr;
+    akz_neighbor* d_brev = nullptr;
+    size_t bscratch_elems = 0;
+    hipEvent_t ev = nullptr;
+};
+
+// Problem descriptors are built in pinned host memory and copied stream-ordered; the staging
+// buffer is reused only after the previous copy has completed.
+static int32_t hm_ensure_probs(hm_ctx* c, size_t bytes)
+{
+    if (c->copy_pending) {
+        AKZ_HIP(hipEventSynchronize(c->ev_copy));
+        c->copy_pending = false;
+    }
+    if (bytes <= c->probs_bytes) return AKZ_OK;
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_probs) AKZ_HIP(hipFree(c->d_probs));
+    if (c->h_probs) AKZ_HIP(hipHostFree(c->h_probs));
+    c->d_probs = c->h_probs = nullptr;
+    size_t nb = akz_align_up(bytes * 2, 4096);
+    AKZ_HIP(hipMalloc(&c->d_probs, nb));
+    AKZ_HIP(hipHostMalloc(&c->h_probs, nb, hipHostMallocDefault));
+    c->probs_bytes = nb;
+    return AKZ_OK;
+}
+static int32_t hm_push_probs(hm_ctx* c, size_t off, const void* src, size_t bytes)
+{
+    memcpy((char*)c->h_probs + off, src, bytes);
+    AKZ_HIP(hipMemcpyAsync((char*)c->d_probs + off, (char*)c->h_probs + off, bytes, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipEventRecord(c->ev_copy, c->stream));
+    c->copy_pending = true;
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out)
+{
+    if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << kIdxBits)) return AKZ_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
+    AKZ_HIP(hipSetDevice(device));
+    hm_ctx* c = new hm_ctx();
+    c->device = device;
+    c->max_q = max_queries;
+    c->max_t = max_targets;
+    uint32_t m = max_queries > max_targets ? max_queries : max_targets;
+    c->max_q = c->max_t = m;  // symmetric matching swaps the roles
+    AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    AKZ_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
+    AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
+    AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
+    AKZ_HIP(hipMalloc(&c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)m));
+    AKZ_HIP(hipMalloc(&c->d_rev, sizeof(akz_neighbor) * 2 * (size_t)m));
+    AKZ_HIP(hipMalloc(&c->d_pairs, sizeof(uint32_t) * 2 * (size_t)m));
+    AKZ_HIP(hipMalloc(&c->d_npairs, sizeof(uint32_t) * 4));
+    *out = c;
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_destroy(hm_ctx* c)
+{
+    if (!c) return AKZ_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_a);
+    hipFree(c->d_b);
+    hipFree(c->d_na);
+    hipFree(c->d_fwd);
+    hipFree(c->d_rev);
+    hipFree(c->d_pairs);
+    hipFree(c->d_npairs);
+    hipFree(c->d_probs);
+    if (c->h_probs) hipHostFree(c->h_probs);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    hipFree(c->d_bfwd);
+    hipFree(c->d_brev);
+    if (c->ev) hipEventDestroy(c->ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return AKZ_OK;
+}
+
+extern "C" void* hm_stream(hm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int32_t hm_sync(hm_ctx* c)
+{
+    if (!c) return AKZ_E_INVALID;
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+
+static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, uint32_t max_nq, size_t probs_off)
+{
+    if (n_probs == 0) return AKZ_OK;
+    HmProb* dp = reinterpret_cast<HmProb*>((char*)c->d_probs + probs_off);
+    AKZ_TRY(hm_push_probs(c, probs_off, h_probs, sizeof(HmProb) * n_probs));
+    dim3 grid((max_nq + kQPB - 1) / kQPB, n_probs);
+    hipLaunchKernelGGL(k_knn2, grid, dim3(kBlock), 0, c->stream, dp);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
+                           akz_neighbor* out)
+{
+    if (!c || !q || !t || !out) return AKZ_E_INVALID;
+    if (nt < 2) return AKZ_E_INVALID;  // the reference asserts two neighbours (estimate_pose.rs:89)
+    if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
+    if (nq == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(hm_ensure_probs(c, sizeof(HmProb) * 4));
+    uint32_t cnt[2] = {nq, nt};
+    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+    HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt, c->d_fwd};
+    AKZ_TRY(launch_knn2(c, &p, 1, nq, 0));
+    AKZ_HIP(hipMemcpyAsync(out, c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uint32_t nb,
+                            int32_t rule, uint32_t param_u, float param_f, int32_t symmetric, uint32_t* pairs,
+                            uint32_t cap, uint32_t* n_out)
+{
+    if (!c || !n_out || (na && !a) || (nb && !b) || (cap && !pairs)) return AKZ_E_INVALID;
+    if (rule < 0 || rule > 2) return AKZ_E_INVALID;
+    if (na > c->max_q || nb > c->max_t) return AKZ_E_TOO_LARGE;
+    *n_out = 0;
+    if (na < 2 || nb < 2) {
+        // cv-sfm returns no matches (cv-sfm/src/lib.rs:3099-3101); the tutorial/test call sites would
+        // panic indexing knn[1] — reported as an invalid argument instead of aborting.
+        return rule == HM_RULE_BETTER_BY ? AKZ_OK : AKZ_E_INVALID;
+    }
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(hm_ensure_probs(c, sizeof(HmProb) * 2 + sizeof(HmPairProb) + 256));
+    uint32_t cnt[2] = {na, nb};
+    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_a, a, (size_t)na * 64, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, b, (size_t)nb * 64, hipMemcpyHostToDevice, c->stream));
+    HmProb p[2] = {{c->d_a, c->d_na, na, c->d_b, c->d_na + 1, nb, c->d_fwd},
+                   {c->d_b, c->d_na + 1, nb, c->d_a, c->d_na, na, c->d_rev}};
+    AKZ_TRY(launch_knn2(c, p, symmetric ? 2 : 1, na > nb ? na : nb, 0));
+    uint32_t kcap = cap < na ? cap : na;
+    HmPairProb pp = {c->d_fwd, c->d_rev, c->d_na, c->d_na + 1, na, nb, c->d_pairs, kcap, c->d_npairs};
+    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + 256);
+    AKZ_TRY(hm_push_probs(c, 256, &pp, sizeof(pp)));
+    hipLaunchKernelGGL(k_pairs, dim3(1), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f, (int)symmetric);
+    AKZ_LAUNCH_CHECK();
+    uint32_t n = 0;
+    AKZ_HIP(hipMemcpyAsync(&n, c->d_npairs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    *n_out = n;
+    uint32_t ncopy = n < kcap ? n : kcap;
+    if (ncopy) AKZ_HIP(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * (size_t)ncopy, hipMemcpyDeviceToHost));
+    return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+}
+
+extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void* d_na, const void* d_b,
+                                         const void* d_nb, uint32_t cap_per_img, const uint32_t* ia,
+                                         const uint32_t* ib, uint32_t n_pairs, int32_t rule, uint32_t param_u,
+                                         float param_f, int32_t symmetric, void* d_pairs, void* d_n_out,
+                                         void* stream_to_wait)
+{
+    if (!c || !d_a || !d_na || !d_b || !d_nb || !ia || !ib || !d_pairs || !d_n_out) return AKZ_E_INVALID;
+    if (rule < 0 || rule > 2 || cap_per_img == 0 || cap_per_img >= (1u << kIdxBits)) return AKZ_E_INVALID;
+    if (n_pairs == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    if (stream_to_wait) {
+        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    }
+    const uint32_t ndir = symmetric ? 2u : 1u;
+    size_t need = (size_t)n_pairs * cap_per_img * 2;
+    if (need > c->bscratch_elems) {
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
+        if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
+        c->d_bfwd = c->d_brev = nullptr;
+        AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
+        AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
+        c->bscratch_elems = need;
+    }
+    size_t knn_bytes = akz_align_up(sizeof(HmProb) * n_pairs * ndir, 256);
+    AKZ_TRY(hm_ensure_probs(c, knn_bytes + sizeof(HmPairProb) * n_pairs));
+    std::vector<HmProb> hp(n_pairs * ndir);
+    std::vector<HmPairProb> hpp(n_pairs);
+    const uint4* A = (const uint4*)d_a;
+    const uint4* B = (const uint4*)d_b;
+    const uint32_t* NA = (const uint32_t*)d_na;
+    const uint32_t* NB = (const uint32_t*)d_nb;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const uint4* qa = A + (size_t)ia[p] * cap_per_img * 4;
+        const uint4* tb = B + (size_t)ib[p] * cap_per_img * 4;
+        akz_neighbor* fwd = c->d_bfwd + (size_t)p * cap_per_img * 2;
+        akz_neighbor* rev = c->d_brev + (size_t)p * cap_per_img * 2;
+        hp[p] = HmProb{qa, NA + ia[p], cap_per_img, tb, NB + ib[p], cap_per_img, fwd};
+        if (symmetric) hp[n_pairs + p] = HmProb{tb, NB + ib[p], cap_per_img, qa, NA + ia[p], cap_per_img, rev};
+        hpp[p] = HmPairProb{fwd, rev, NA + ia[p], NB + ib[p], cap_per_img, cap_per_img,
+                            (uint32_t*)d_pairs + (size_t)p * cap_per_img * 2, cap_per_img,
+                            (uint32_t*)d_n_out + p};
+    }
+    AKZ_TRY(launch_knn2(c, hp.data(), n_pairs * ndir, cap_per_img, 0));
+    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + knn_bytes);
+    AKZ_TRY(hm_push_probs(c, knn_bytes, hpp.data(), sizeof(HmPairProb) * n_pairs));
+    hipLaunchKernelGGL(k_pairs, dim3(n_pairs), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f,
+                       (int)symmetric);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}

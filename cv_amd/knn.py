@@ -1,0 +1,137 @@
+"""Host-side mirror of the brute-force matcher the reference builds from `space` + `bitarray`.
+
+  space::LinearKnn { metric: Hamming, iter }.knn(query, num)   akaze/tests/estimate_pose.rs:82-88
+  matching / symmetric_matching (better-by-24, strict)         tutorial-code/chapter5-…/src/main.rs:154-200
+  matching / symmetric_matching (better_by, <=, <2 guard)      cv-sfm/src/lib.rs:3097-3133
+  match_descriptors (Lowe ratio 0.5, f32)                      akaze/tests/estimate_pose.rs:78-97
+Descriptors are [n,64] uint8 arrays (rows = BitArray<64>).  Everything runs on the MI355X through
+hm_* of include/akz.h; there is no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import NB_DTYPE, check
+
+RULE_STRICT, RULE_BETTER_BY, RULE_LOWE = 0, 1, 2
+
+
+class Hamming:
+    """bitarray::Hamming metric marker."""
+
+
+@dataclass
+class Neighbor:
+    """space::Neighbor<u32>."""
+    index: int
+    distance: int
+
+
+class Matcher:
+    """Owns one hm_ctx."""
+
+    def __init__(self, max_descriptors=16384, device=0):
+        self._h = C.c_void_p()
+        self.cap = max_descriptors
+        check(_lib.lib().hm_create(device, max_descriptors, max_descriptors, C.byref(self._h)), "hm_create")
+
+    def close(self):
+        if self._h:
+            _lib.lib().hm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def knn2(self, q, t):
+        q = _desc(q); t = _desc(t)
+        out = np.zeros((len(q), 2), NB_DTYPE)
+        check(_lib.lib().hm_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data), "hm_knn2")
+        return out
+
+    def match(self, a, b, rule=RULE_STRICT, param_u=24, param_f=0.5, symmetric=True):
+        a = _desc(a); b = _desc(b)
+        cap = max(len(a), 1)
+        pairs = np.zeros((cap, 2), np.uint32)
+        n = C.c_uint32()
+        check(_lib.lib().hm_match(self._h, a.ctypes.data, len(a), b.ctypes.data, len(b), rule, param_u, param_f,
+                                  int(symmetric), pairs.ctypes.data, cap, C.byref(n)), "hm_match")
+        return pairs[:n.value].copy()
+
+
+def _desc(d):
+    d = np.ascontiguousarray(d, np.uint8)
+    return d.reshape(-1, 64)
+
+
+_default = {}
+
+
+def default_matcher(n=16384, device=0):
+    m = _default.get(device)
+    if m is None or m.cap < n:
+        if m is not None:
+            m.close()
+        m = Matcher(max(n, 16384), device)
+        _default[device] = m
+    return m
+
+
+class LinearKnn:
+    """space::LinearKnn { metric, iter }: exact k-NN by scanning `iter` (the target descriptors)."""
+
+    def __init__(self, metric=Hamming, iter=None, device=0):
+        self.metric = metric
+        self.iter = _desc(iter if iter is not None else np.zeros((0, 64), np.uint8))
+        self.device = device
+
+    def knn(self, query, num):
+        """Knn::knn(&self, query, num) -> Vec<Neighbor>, sorted by (distance, index).  The device path
+        implements num == 2 (every reference call site); other values raise."""
+        if num != 2:
+            raise NotImplementedError("the MI355X matcher implements knn(query, 2), the reference's only use")
+        nn = default_matcher(max(len(self.iter), 1), self.device).knn2(_desc(query)[:1], self.iter)
+        return [Neighbor(int(nn[0, 0]["index"]), int(nn[0, 0]["distance"])),
+                Neighbor(int(nn[0, 1]["index"]), int(nn[0, 1]["distance"]))]
+
+    def knn_batch(self, queries):
+        """knn(q, 2) for every row of `queries` in one launch: [nq,2] structured (index, distance)."""
+        return default_matcher(max(len(self.iter), len(queries), 1), self.device).knn2(queries, self.iter)
+
+
+def matching(a_descriptors, b_descriptors, better_by=24, strict=True, device=0):
+    """matching() of tutorial ch5 (strict: d0 + 24 < d1, main.rs:162) or of cv-sfm (strict=False:
+    d0 + better_by <= d1, lib.rs:3107).  Returns a list of Optional[int] like the reference."""
+    a = _desc(a_descriptors); b = _desc(b_descriptors)
+    if not strict and (len(a) < 2 or len(b) < 2):
+        return []                                   # cv-sfm/src/lib.rs:3099-3101
+    m = default_matcher(max(len(a), len(b), 1), device)
+    pairs = m.match(a, b, RULE_STRICT if strict else RULE_BETTER_BY, better_by, 0.0, symmetric=False)
+    out = [None] * len(a)
+    for ai, bi in pairs:
+        out[int(ai)] = int(bi)
+    return out
+
+
+def symmetric_matching(a, b, better_by=24, strict=True, device=0):
+    """symmetric_matching() (ch5 main.rs:183-200 / cv-sfm lib.rs:3116-3133): list of [a, b]."""
+    a = _desc(a); b = _desc(b)
+    if not strict and (len(a) < 2 or len(b) < 2):
+        return []
+    m = default_matcher(max(len(a), len(b), 1), device)
+    return m.match(a, b, RULE_STRICT if strict else RULE_BETTER_BY, better_by, 0.0, symmetric=True).tolist()
+
+
+def match_descriptors(ds1, ds2, lowes_ratio=0.5, device=0):
+    """match_descriptors() of akaze/tests/estimate_pose.rs:78-97: a->b only, Lowe ratio in f32."""
+    m = default_matcher(max(len(ds1), len(ds2), 1), device)
+    return [tuple(p) for p in m.match(ds1, ds2, RULE_LOWE, 0, lowes_ratio, symmetric=False).tolist()]

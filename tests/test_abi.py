@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/akz.h declares; the host-side schedule math matches the oracle.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cv_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from cv_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "akz.h")).read()
+    declared = set(re.findall(r"\b((?:akz|hm)_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"akz_status"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libakz.so does not export {name}"
+
+
+def test_pod_layouts_match_the_reference_types(lib):
+    from cv_amd import _lib
+    assert C.sizeof(_lib.Config) == 80
+    cfg = _lib.Config()
+    lib.akz_config_default(C.byref(cfg))
+    # Akaze::default(), akaze/src/lib.rs:169-185
+    assert cfg.maximum_features == 2 ** 64 - 1 and cfg.num_sublevels == 4 and cfg.max_octave_evolution == 4
+    assert cfg.base_scale_offset == 1.6 and cfg.initial_contrast == 0.001 and cfg.contrast_percentile == 0.7
+    assert cfg.contrast_factor_num_bins == 300 and cfg.derivative_factor == 1.5
+    assert cfg.detector_threshold == 0.001 and cfg.descriptor_channels == 3 and cfg.descriptor_pattern_size == 10
+    assert _lib.KP_DTYPE.itemsize == 28
+
+
+def test_error_strings_and_no_cpu_fallback(lib):
+    from cv_amd import _lib
+    assert lib.akz_strerror(0) == b"ok"
+    for code in range(-7, 0):
+        assert lib.akz_strerror(code) not in (b"ok", b"unknown status")
+    import torch
+    if not torch.cuda.is_available():
+        cfg = _lib.Config()
+        lib.akz_config_default(C.byref(cfg))
+        h = C.c_void_p()
+        assert lib.akz_create(C.byref(cfg), 0, 64, 64, 1, 0, C.byref(h)) == -2  # AKZ_E_NO_DEVICE, no fallback
+        hm = C.c_void_p()
+        assert lib.hm_create(0, 16, 16, C.byref(hm)) == -2
+        from cv_amd.akaze import Akaze
+        with pytest.raises(_lib.AkzError):
+            Akaze.sparse().extract(np.zeros((64, 64), np.uint8))
+
+
+def test_host_mirror_surface():
+    """The Python mirror keeps the reference's names (akaze/src/lib.rs:109-185, 295-366)."""
+    from cv_amd.akaze import Akaze, KeyPoint
+    a = Akaze.default()
+    assert a.detector_threshold == 0.001 and Akaze.sparse().detector_threshold == 0.01
+    assert Akaze.dense().detector_threshold == 0.0001 and Akaze.new(0.5).detector_threshold == 0.5
+    for name in ("extract", "extract_from_gray_float_image", "extract_path"):
+        assert callable(getattr(a, name))
+    kp = KeyPoint((1.0, 2.0), 0.5, 4.8, 0, 0, 0.0)
+    assert kp.image_point() == (1.0, 2.0)
+    from cv_amd import knn
+    for name in ("LinearKnn", "Hamming", "matching", "symmetric_matching", "match_descriptors"):
+        assert hasattr(knn, name)
+
+
+def test_gaussian_kernel_host_entry(lib):
+    """akz_gaussian_kernel is host-only scalar math (image.rs:360-374): usable without a GPU."""
+    out = np.empty(7, np.float32)
+    assert lib.akz_gaussian_kernel(3.0, 7, out.ctypes.data) == 0
+    known = [0.10628852, 0.14032133, 0.16577007, 0.17524014, 0.16577007, 0.14032133, 0.10628852]
+    assert np.all(np.abs(out - np.array(known, np.float32)) < 1e-4)
+    assert lib.akz_gaussian_kernel(3.0, 6, out.ctypes.data) == -1  # even size: the reference asserts
