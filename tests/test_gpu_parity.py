@@ -27,8 +27,10 @@ def gpu():
 def _eq(a, b, what):
     a = np.asarray(a); b = np.asarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    if a.dtype.kind == "f":
-        same = (a.view(np.uint32) == b.view(np.uint32)) | (a == b)
+    if a.dtype == np.float32:
+        same = a.view(np.uint32) == b.view(np.uint32)      # bit-exact, sign of zero and NaN payload included
+    elif a.dtype == np.float64:
+        same = a.view(np.uint64) == b.view(np.uint64)
     else:
         same = a == b
     if not same.all():
