@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of AKAZE detect + describe + brute-force Hamming match on 1080p (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of 256 synthetic 1920x1080 frames per GPU
+(BASELINE.json configs[1], plus the consecutive-frame symmetric better-by-24 match of configs[2]'s
+matcher): Akaze::default() extract of every frame, then frame g is matched against frame g-1.
+Inputs are resident in HBM before the timed region.  Multi-GPU: one process per GPU, frames sharded
+frame g -> rank g mod N; the only exchange is an RCCL all-gather of the fixed-capacity
+descriptor blocks so that the owner of frame g holds frame g-1's descriptors.  Weak scaling: every rank
+processes its own 256 frames per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      — the FED diffusion step kernel (calculate_step, the dominant kernel): algorithmic bytes per
+                  launch (12 B per pixel-step x pixels x frames) / HIP-event time on the library's
+                  stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline  — the CPU oracle (a restatement of the reference, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+FRAMES_PER_STEP = 256
+CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FED_BYTES_PER_PIXEL_STEP = 12.0
+
+
+def make_world(seed, w, h):
+    """Deterministic synthetic 'world' canvas (value noise + rectangles + discs), uint8, numpy."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 96.0, np.float32)
+    for cell, amp in ((64, 48), (32, 24), (16, 12), (8, 6)):
+        gh, gw = h // cell + 2, w // cell + 2
+        g = rng.uniform(-amp, amp, (gh, gw)).astype(np.float32)
+        ys = np.arange(h, dtype=np.float32) / cell
+        xs = np.arange(w, dtype=np.float32) / cell
+        y0 = ys.astype(int); x0 = xs.astype(int)
+        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        img += ((1 - fy) * (1 - fx) * g[y0][:, x0] + (1 - fy) * fx * g[y0][:, x0 + 1]
+                + fy * (1 - fx) * g[y0 + 1][:, x0] + fy * fx * g[y0 + 1][:, x0 + 1])
+    density = (w * h) / (1920.0 * 1080.0)
+    n_shapes = int(200 * density)
+    for _ in range(n_shapes):
+        sw, sh = rng.integers(8, 97, 2)
+        x, y = rng.integers(0, w), rng.integers(0, h)
+        img[y:y + sh, x:x + sw] = rng.integers(0, 256)
+    yy, xx = np.mgrid[0:97, 0:97]
+    for _ in range(n_shapes):
+        r = int(rng.integers(4, 49))
+        x, y = int(rng.integers(r, w - r)), int(rng.integers(r, h - r))
+        m = (yy[:2 * r + 1, :2 * r + 1] - r) ** 2 + (xx[:2 * r + 1, :2 * r + 1] - r) ** 2 <= r * r
+        img[y - r:y + r + 1, x - r:x + r + 1][m] = rng.integers(0, 256)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def make_frames(torch, device, rank, n_frames, world_size):
+    """n_frames 1080p frames for this rank: a camera panning over the world canvas (4 px right, 2 px down
+    per GLOBAL frame) plus +-2 sensor noise.  Global frame g = j*world_size + rank."""
+    total = n_frames * world_size
+    world = make_world(0xA4A2E, W + 4 * total + 64, H + 2 * total + 64)
+    wt = torch.from_numpy(world).to(device)
+    frames = torch.empty((n_frames, H, W), dtype=torch.uint8, device=device)
+    gen = torch.Generator(device=device)
+    for j in range(n_frames):
+        g = j * world_size + rank
+        gen.manual_seed(1000 + g)
+        crop = wt[2 * g:2 * g + H, 4 * g:4 * g + W].to(torch.int16)
+        noise = torch.randint(-2, 3, (H, W), generator=gen, device=device, dtype=torch.int16)
+        frames[j] = (crop + noise).clamp_(0, 255).to(torch.uint8)
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
+    ap.add_argument("--micro-batch", type=int, default=32, help="frames per kernel launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from cv_amd import build
+    build.build()
+    from cv_amd import _lib
+    from cv_amd.akaze import Akaze
+    from cv_amd.knn import Matcher, RULE_STRICT
+    L = _lib.lib()
+
+    NF, MB = args.frames, min(args.micro_batch, args.frames)
+    assert NF % MB == 0
+    frames = make_frames(torch, dev, rank, NF, world)
+
+    ak = Akaze.default()
+    ak.device = local_rank
+    ak.max_keypoints = CAP
+    ctx = ak.context(W, H, MB)
+    matcher = Matcher(CAP, device=local_rank)
+    akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
+    hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
+
+    kps = torch.zeros((NF, CAP, 28), dtype=torch.uint8, device=dev)
+    descs = torch.zeros((NF, CAP, 64), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((NF,), dtype=torch.int32, device=dev)
+    # predecessor descriptor blocks: prev[j] = descriptors of global frame g-1 for local frame j
+    prev_descs = torch.zeros((NF, CAP, 64), dtype=torch.uint8, device=dev) if world > 1 else None
+    prev_counts = torch.zeros((NF,), dtype=torch.int32, device=dev) if world > 1 else None
+    pairs = torch.zeros((NF, CAP, 2), dtype=torch.int32, device=dev)
+    npairs = torch.zeros((NF,), dtype=torch.int32, device=dev)
+    if world > 1:
+        gath_d = torch.zeros((world, MB, CAP, 64), dtype=torch.uint8, device=dev)
+        gath_n = torch.zeros((world, MB), dtype=torch.int32, device=dev)
+    ia = (C.c_uint32 * NF)(*range(NF))
+    if world == 1:
+        ib = (C.c_uint32 * NF)(*[(j - 1) % NF for j in range(NF)])   # frame 0 pairs with the batch's last frame
+    else:
+        ib = (C.c_uint32 * NF)(*range(NF))
+
+    def step():
+        cur = torch.cuda.current_stream()
+        for m0 in range(0, NF, MB):
+            _lib.check(L.akz_extract_batch_device(
+                ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps[m0:m0 + MB].data_ptr(),
+                descs[m0:m0 + MB].data_ptr(), CAP, counts[m0:m0 + MB].data_ptr(), cur.cuda_stream), "extract")
+            if world > 1:
+                cur.wait_stream(akz_stream)
+                dist.all_gather_into_tensor(gath_d.view(-1), descs[m0:m0 + MB].reshape(-1))
+                dist.all_gather_into_tensor(gath_n.view(-1), counts[m0:m0 + MB])
+                if rank > 0:
+                    prev_descs[m0:m0 + MB].copy_(gath_d[rank - 1])
+                    prev_counts[m0:m0 + MB].copy_(gath_n[rank - 1])
+                else:  # predecessor of global frame j*world is local frame j-1 of the last rank
+                    prev_descs[m0 + 1:m0 + MB].copy_(gath_d[world - 1, :MB - 1])
+                    prev_counts[m0 + 1:m0 + MB].copy_(gath_n[world - 1, :MB - 1])
+                    if m0 + MB < NF:
+                        prev_descs[m0 + MB].copy_(gath_d[world - 1, MB - 1])
+                        prev_counts[m0 + MB].copy_(gath_n[world - 1, MB - 1])
+                    else:   # wrap: the step's first frame pairs with the step's last global frame
+                        prev_descs[0].copy_(gath_d[world - 1, MB - 1])
+                        prev_counts[0].copy_(gath_n[world - 1, MB - 1])
+        if world == 1:
+            tb, nb, wait = descs, counts, akz_stream
+        else:
+            tb, nb, wait = prev_descs, prev_counts, cur
+        _lib.check(L.hm_match_batch_device(
+            matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib, NF,
+            RULE_STRICT, 24, 0.0, 1, pairs.data_ptr(), npairs.data_ptr(), wait.cuda_stream), "match")
+        cur.wait_stream(hm_stream)
+        cur.wait_stream(akz_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.check(L.akz_sync(ctx.handle), "akz_sync")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fed_ms, fed_launches, fed_units = ctx.timing_get(0)
+    ss_ms, _, _ = ctx.timing_get(1)
+    all_ms, _, _ = ctx.timing_get(2)
+    ctx.timing_enable(False)
+
+    n_kp = counts.float().mean().item()
+    n_match = npairs.float().mean().item()
+    if rank == 0:
+        total_frames = NF * world * args.steps
+        fps = total_frames / elapsed
+        fed_bytes = FED_BYTES_PER_PIXEL_STEP * fed_units
+        achieved = fed_bytes / (fed_ms * 1e-3) / 1e9 if fed_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec AKAZE detect+describe+BF-Hamming-match, 1080p",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch of 256 synthetic 1920x1080 frames per GPU, "
+                                   "Akaze::default() detect+describe, + symmetric better-by-24 BF Hamming match "
+                                   "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
+                       "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
+                       "mean_matches_per_pair": round(n_match, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_fed_step_x4 (calculate_step)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": int(fed_launches),
+                         "avg_launch_us": round(fed_ms * 1e3 / max(1, fed_launches), 2),
+                         "algorithmic_bytes_per_launch": round(fed_bytes / max(1, fed_launches), 0)},
+            "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
+                                  "extract": round(all_ms / args.steps, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames, n):
+    """The CPU oracle (a C restatement of the reference's akaze crate + BF matcher; kind 'port') on the
+    first n frames of the same workload, single thread, on this box's host cores."""
+    from oracle import oracle as O
+    n = max(2, min(n, frames.shape[0]))
+    host = frames[:n].cpu().numpy()
+    orc = O.Akaze(W, H, O.default_config())
+    t0 = time.perf_counter()
+    prev = None
+    nk = 0
+    for i in range(n):
+        kp, d = orc.extract(host[i])
+        nk += len(d)
+        if prev is not None:
+            O.match(d, prev, rule=O.RULE_STRICT, param_u=24, symmetric=True)
+        prev = d
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": f"first {n} frames of the bench batch: Akaze::default() extract + symmetric match vs previous "
+                      f"frame, single thread, {dt:.1f} s, {nk // n} keypoints/frame"}
+
+
+if __name__ == "__main__":
+    main()
