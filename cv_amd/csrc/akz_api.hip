@@ -181,8 +181,7 @@ static void carve(akz_ctx* c, char* base, size_t* total)
     Carver cv{base};
     c->Lt.assign(nlev, nullptr);
     c->Lsm.assign(nlev, nullptr);
-    c->Lx.assign(nlev, nullptr);
-    c->Ly.assign(nlev, nullptr);
+    c->Lxy.assign(nlev, nullptr);
     c->Ldet.assign(nlev, nullptr);
     c->Lflow.assign(nlev, nullptr);
     // persistent per-level planes: Lt, Lx, Ly (descriptors), Ldet (extrema, sub-pixel)
@@ -190,8 +189,7 @@ static void carve(akz_ctx* c, char* base, size_t* total)
     for (int i = 0; i < nlev; ++i) {
         size_t px = P.levels[i].pixels() * B;
         c->Lt[i] = cv.take<float>(px);
-        c->Lx[i] = cv.take<float>(px);
-        c->Ly[i] = cv.take<float>(px);
+        c->Lxy[i] = cv.take<float2>(px);
         c->Ldet[i] = cv.take<float>(px);
         if (px > max_level_px) max_level_px = px;
     }
@@ -446,21 +444,29 @@ extern "C" int32_t akz_debug_get_level(akz_ctx* c, int32_t img, int32_t level, i
     if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
     if (level < 0 || level >= (int)c->plan.levels.size()) return AKZ_E_INVALID;
     const float* src = nullptr;
+    int comp = -1;
     switch (which) {
     case AKZ_BUF_LT: src = c->Lt[level]; break;
     case AKZ_BUF_LSMOOTH: src = c->Lsm[level]; break;
-    case AKZ_BUF_LX: src = c->Lx[level]; break;
-    case AKZ_BUF_LY: src = c->Ly[level]; break;
+    case AKZ_BUF_LX: comp = 0; break;
+    case AKZ_BUF_LY: comp = 1; break;
     case AKZ_BUF_LDET: src = c->Ldet[level]; break;
     case AKZ_BUF_LFLOW: src = c->Lflow[level]; break;
     default: return AKZ_E_INVALID;
     }
-    if (!src) return AKZ_E_INVALID;
+    if (!src && comp < 0) return AKZ_E_INVALID;
     // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
     if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_HIP(hipStreamSynchronize(c->stream));
     size_t px = c->plan.levels[level].pixels();
+    if (comp >= 0) {  // Lx / Ly live interleaved; split one component into the (idle) FED scratch plane
+        AKZ_TRY(akz_dev_deinterleave(c->stream, c->Lxy[level] + (size_t)img * px, c->tmp, px, comp));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        src = c->tmp;
+        AKZ_HIP(hipMemcpy(out, src, sizeof(float) * px, hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    }
     AKZ_HIP(hipMemcpy(out, src + (size_t)img * px, sizeof(float) * px, hipMemcpyDeviceToHost));
     return AKZ_OK;
 }

@@ -30,7 +30,9 @@ struct akz_ctx {
     // ---- device memory (one arena, carved in akz_ctx_prepare) ----
     void* arena = nullptr;
     size_t arena_bytes = 0;
-    std::vector<float*> Lt, Lsm, Lx, Ly, Ldet, Lflow;  // [level] -> frame-major planes
+    std::vector<float*> Lt, Lsm, Ldet, Lflow;  // [level] -> frame-major f32 planes
+    std::vector<float2*> Lxy;                  // [level] -> frame-major {Lx, Ly} planes (interleaved: every consumer
+                                               // reads both derivatives at the same pixel)
     float* tmp = nullptr;       // ping-pong partner for FED steps, max_batch * P0
     void* d_in = nullptr;       // staged input frames (u8 or f32), max_batch * P0 * 4 bytes
     // contrast factor (contrast_factor.rs)
@@ -78,6 +80,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
 // stand-alone image ops on device buffers (used by akz_horizontal_filter & co)
 int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel,
                          int ksize, int vertical);
+int32_t akz_dev_deinterleave(hipStream_t s, const float2* in, float* out, size_t n, int component);
 int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
                           size_t out_fs);
 

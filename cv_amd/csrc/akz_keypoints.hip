@@ -36,8 +36,7 @@ __device__ __forceinline__ int sat_i32(float v)
 struct LevelDesc {  // per-level constants for the keypoint kernels
     const float* Ldet;
     const float* Lt;
-    const float* Lx;
-    const float* Ly;
+    const float2* Lxy;  // {Lx, Ly} interleaved
     int w, h;
     size_t fs;        // frame stride (pixels)
     uint32_t octave;
@@ -63,6 +62,23 @@ __device__ __forceinline__ bool is_candidate(const float* D, int w, int x, int y
            v > p[w] && v > p[w + 1];
 }
 
+// Border test of scale_space_extrema.rs:96-104.  In the reference it runs after the cache scan, but a
+// candidate that fails it neither pushes nor replaces anything (:105), whatever the scan found, so it
+// can be discarded before the serial pass without changing any result.
+__device__ __forceinline__ bool border_ok(const LevelDesc& L, int x, int y)
+{
+    const float smax = 10.0f * sqrtf(2.0f);
+    const float ratio = ldexpf(1.0f, (int)L.octave);
+    const float sigma_size = roundf(L.kp_size / ratio);
+    const float px = (float)x, py = (float)y;
+    float left_x = roundf(px - smax * sigma_size) - 1.0f;
+    float right_x = roundf(px + smax * sigma_size) + 1.0f;
+    float up_y = roundf(py - smax * sigma_size) - 1.0f;
+    float down_y = roundf(py + smax * sigma_size) + 1.0f;
+    bool is_out = left_x < 0.0f || right_x >= (float)L.w || up_y < 0.0f || down_y >= (float)L.h;
+    return !is_out;
+}
+
 // one block per (row, frame): count candidates of the row
 __global__ __launch_bounds__(256) void k_cand_count(LevelDesc L, float thr, uint32_t* __restrict__ rowcount,
                                                     uint32_t rows_stride)
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(256) void k_cand_count(LevelDesc L, float thr, uint
     uint32_t local = 0;
     for (int x = 1 + threadIdx.x; x < L.w - 1; x += 256) {
         float v;
-        if (is_candidate(D, L.w, x, y, thr, &v)) local++;
+        if (is_candidate(D, L.w, x, y, thr, &v) && border_ok(L, x, y)) local++;
     }
     unsigned long long b = __ballot(local != 0);
     if (b) {  // rare
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void k_cand_scatter(LevelDesc L, float thr, co
     for (int x0 = 1; x0 < L.w - 1; x0 += 256) {
         int x = x0 + threadIdx.x;
         float v = 0.0f;
-        bool hit = x < L.w - 1 && is_candidate(D, L.w, x, y, thr, &v);
+        bool hit = x < L.w - 1 && is_candidate(D, L.w, x, y, thr, &v) && border_ok(L, x, y);
         unsigned long long b = __ballot(hit);
         int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
@@ -159,156 +175,180 @@ __global__ __launch_bounds__(256) void k_cand_scatter(LevelDesc L, float thr, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// A12b: the order-dependent suppression pass (scale_space_extrema.rs:61-118).  One block per frame.
+// A12b: the order-dependent suppression pass (scale_space_extrema.rs:61-118).  ONE WAVE per frame, no
+// workgroup barriers: the pass is a strict sequence over the frame's candidates, so the parallelism is
+// (a) across the frames of the batch and (b) across the cache entries tested for one candidate.
+//
 // The reference scans the whole cache for the FIRST entry (in cache order) whose class_id is the
-// candidate's level or the one below and that lies within the candidate's size.  Only entries of
-// those two classes can match, so the block keeps them — in cache order — in an LDS "active list"
-// (rebuilt at each level change) and scans that; pushes append to it, in-place replacements
-// update it in place, so its order always equals cache order.  The full cache goes to HBM in slot
-// order for the second pass.
-constexpr int kActCap = 8192;
+// candidate's level or the one below and that lies within the candidate's size.  Only entries of those
+// two classes can match, so the wave keeps them — in cache order — in an LDS "active list" (rebuilt at
+// each level change); pushes append to it and in-place replacements update it in place, so its order
+// always equals cache order.  The list is cut into chunks of 64 entries (one per lane) and every chunk
+// carries a conservative [ymin, ymax] of its entries (held in registers, only ever widened between rebuilds).  Candidates
+// arrive in raster order, so the entries that can lie within `size` of one are confined to a few chunks:
+// lane l tests chunk l's bounds, the ballot lists the chunks worth scanning, and they are scanned in
+// ascending order until the first hit — the same entry the reference's linear scan finds.  The full
+// cache goes to HBM in slot order for the second pass.
+constexpr int kActCap = 8192;            // active-list capacity (entries of two adjacent classes)
+static_assert(kActCap / 64 == 128, "chunk bounds are held two per lane");
 struct ActEntry {   // 16 B
     float x, y;     // full-resolution coordinates (with the +0.5(ratio-1) offset, as cached)
     float resp;
     uint32_t slot_cls;  // slot (24 bits) | class (8 bits)
 };
 
-__global__ __launch_bounds__(256) void k_suppress(LevelTable T, const uint32_t* __restrict__ rowoff,
-                                                  uint32_t rows_stride, const uint2* __restrict__ cand,
-                                                  uint32_t max_cand, DevKp* __restrict__ cache, uint32_t max_kp,
-                                                  uint32_t* __restrict__ ncache, uint32_t* __restrict__ err)
+__device__ __forceinline__ float rl_f(float v, uint32_t l)
 {
-    // all LDS lives in the dynamic region so the 16-byte ActEntry accesses stay aligned
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)l));
+}
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+__global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* __restrict__ rowoff,
+                                                 uint32_t rows_stride, const uint2* __restrict__ cand,
+                                                 uint32_t max_cand, DevKp* __restrict__ cache, uint32_t max_kp,
+                                                 uint32_t* __restrict__ ncache, uint32_t* __restrict__ err)
+{
+    // LDS: the active list only.  A single wave executes its DS instructions in order, so a ds_write by
+    // lane 0 is seen by every later ds_read of the wave without any barrier.  The wave is issue-bound
+    // (one dependent instruction stream), so the per-candidate path is kept as short as possible:
+    // everything that does not depend on the cache (the border test) was done in k_cand_scatter.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ActEntry* act = reinterpret_cast<ActEntry*>(smem);
-    uint32_t* s_vars = reinterpret_cast<uint32_t*>(smem + sizeof(ActEntry) * kActCap);
-    uint32_t* s_first = s_vars;       // [4]
-    uint32_t* s_scan = s_vars + 4;    // [4]
-    uint32_t& s_nact = s_vars[8];
-    uint32_t& s_ncache = s_vars[9];
     const int frame = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t lane = threadIdx.x;
     const uint32_t* ro = rowoff + (size_t)frame * rows_stride;
     const uint2* cd = cand + (size_t)frame * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
-    const float smax = 10.0f * sqrtf(2.0f);
-    if (tid == 0) {
-        s_nact = 0;
-        s_ncache = 0;
-    }
-    __syncthreads();
+    uint32_t nact = 0, nslots = 0;  // wave-uniform
+    // chunk bounds live in registers: lane l holds [ymin, ymax] of chunks l and l + 64
+    float bmin0 = 3.0e38f, bmax0 = -3.0e38f, bmin1 = 3.0e38f, bmax1 = -3.0e38f;
     uint32_t total = ro[T.total_rows];
     if (total > max_cand) total = max_cand;  // overflow already flagged by k_cand_scatter
     for (int e = 0; e < T.n; ++e) {
         const LevelDesc& L = T.L[e];
         // ---- level change: keep only class e-1 entries (class e-2 can no longer match), in order ----
         {
-            uint32_t n = s_nact;
-            __syncthreads();
-            uint32_t kept_base = 0;
-            for (uint32_t b0 = 0; b0 < n; b0 += 256) {
-                uint32_t i = b0 + tid;
-                ActEntry en;
+            uint32_t kept = 0;
+            for (uint32_t b0 = 0; b0 < nact; b0 += 64) {
+                uint32_t i = b0 + lane;
+                float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 bool keep = false;
-                if (i < n) {
-                    en = act[i];
-                    keep = (int)(en.slot_cls & 0xFFu) == e - 1;
+                if (i < nact) {
+                    en = *reinterpret_cast<const float4*>(&act[i]);
+                    keep = (int)(__float_as_uint(en.w) & 0xFFu) == e - 1;
                 }
                 unsigned long long bal = __ballot(keep);
-                if (lane == 0) s_scan[wv] = (uint32_t)__popcll(bal);
-                __syncthreads();  // also: every read of act[b0..b0+255] is done before any write below
-                uint32_t woff = 0, tot = 0;
-                for (int q = 0; q < 4; ++q) {
-                    if (q < wv) woff += s_scan[q];
-                    tot += s_scan[q];
-                }
-                if (keep) act[kept_base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = en;
-                kept_base += tot;
-                __syncthreads();
+                // reads of chunk b0 are complete (values are in registers) before the in-order writes below
+                if (keep) *reinterpret_cast<float4*>(&act[kept + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))]) = en;
+                kept += (uint32_t)__popcll(bal);
             }
-            if (tid == 0) s_nact = kept_base;
-            __syncthreads();
+            nact = kept;
+            bmin0 = bmin1 = 3.0e38f;
+            bmax0 = bmax1 = -3.0e38f;
+            for (uint32_t b0 = 0; b0 < nact; b0 += 64) {
+                uint32_t i = b0 + lane;
+                float y = i < nact ? act[i].y : 0.0f;
+                float lo = i < nact ? y : 3.0e38f, hi = i < nact ? y : -3.0e38f;
+                for (int off = 32; off > 0; off >>= 1) {
+                    lo = fminf(lo, __shfl_xor(lo, off));
+                    hi = fmaxf(hi, __shfl_xor(hi, off));
+                }
+                uint32_t ck = b0 >> 6;
+                if (lane == (ck & 63u)) {
+                    if (ck < 64u) { bmin0 = lo; bmax0 = hi; }
+                    else { bmin1 = lo; bmax1 = hi; }
+                }
+            }
         }
         const float ratio = ldexpf(1.0f, (int)L.octave);
+        const float half_off = 0.5f * (ratio - 1.0f);
         const float size = L.kp_size;
         const float size2 = size * size;
-        const float sigma_size = roundf(size / ratio);
+        const float margin = size * 1.001f + 0.01f;  // conservative: |dy| > margin  =>  dist > size^2
         uint32_t c_begin = ro[L.row_base], c_end = ro[L.row_base + L.h];
         if (c_begin > total) c_begin = total;
         if (c_end > total) c_end = total;
-        for (uint32_t ci = c_begin; ci < c_end; ++ci) {
-            uint2 cv = cd[ci];  // uniform
-            float px = (float)(cv.x & 0xFFFFu), py = (float)(cv.x >> 16);
-            float resp = fabsf(__uint_as_float(cv.y));
-            float fx = px * ratio, fy = py * ratio;
-            // scan the active list for the first hit
-            uint32_t nact = s_nact;
-            uint32_t first = 0xFFFFFFFFu;
-            for (uint32_t b0 = 0; b0 < nact; b0 += 256) {
-                uint32_t i = b0 + tid;
-                bool hit = false;
-                if (i < nact) {
-                    ActEntry en = act[i];
-                    float dx = fx - en.x, dy = fy - en.y;
-                    float dist = dx * dx + dy * dy;
-                    hit = dist <= size2;  // class filter is implied by list membership
-                }
-                unsigned long long bal = __ballot(hit);
-                if (lane == 0) s_first[wv] = bal ? (b0 + wv * 64 + (uint32_t)__ffsll((long long)bal) - 1u) : 0xFFFFFFFFu;
-                __syncthreads();
-                uint32_t f = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
-                __syncthreads();
-                if (f != 0xFFFFFFFFu) {
-                    first = f;
-                    break;
-                }
-            }
-            // decision (uniform): scale_space_extrema.rs:72-116
-            if (tid == 0) {
-                bool is_repeated = false, is_extremum = true;
-                if (first != 0xFFFFFFFFu) {
-                    if (resp > act[first].resp) is_repeated = true;
-                    else is_extremum = false;
-                }
-                if (is_extremum) {
-                    float left_x = roundf(px - smax * sigma_size) - 1.0f;
-                    float right_x = roundf(px + smax * sigma_size) + 1.0f;
-                    float up_y = roundf(py - smax * sigma_size) - 1.0f;
-                    float down_y = roundf(py + smax * sigma_size) + 1.0f;
-                    bool is_out = left_x < 0.0f || right_x >= (float)L.w || up_y < 0.0f || down_y >= (float)L.h;
-                    if (!is_out) {
-                        DevKp kp;
-                        kp.x = px * ratio + 0.5f * (ratio - 1.0f);
-                        kp.y = py * ratio + 0.5f * (ratio - 1.0f);
-                        kp.response = resp;
-                        kp.size = size;
-                        kp.angle = 0.0f;
-                        kp.octave = L.octave;
-                        kp.class_id = (uint32_t)e;
-                        if (!is_repeated) {
-                            uint32_t slot = s_ncache, ai = s_nact;
-                            if (slot < max_kp && ai < (uint32_t)kActCap && slot < (1u << 24)) {
-                                ch[slot] = kp;
-                                ActEntry en = {kp.x, kp.y, resp, (slot << 8) | (uint32_t)e};
-                                act[ai] = en;
-                                s_ncache = slot + 1;
-                                s_nact = ai + 1;
-                            } else {
-                                *err = 2u;
-                            }
-                        } else {
-                            uint32_t slot = act[first].slot_cls >> 8;
-                            ch[slot] = kp;
-                            ActEntry en = {kp.x, kp.y, resp, (slot << 8) | (uint32_t)e};
-                            act[first] = en;
+        for (uint32_t cb = c_begin; cb < c_end; cb += 64) {
+            // one coalesced load of the next 64 candidates, then broadcast lane by lane
+            uint2 mine = (cb + lane < c_end) ? cd[cb + lane] : make_uint2(0u, 0u);
+            const uint32_t cnt = min(64u, c_end - cb);
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t cxy = rl_u(mine.x, t);
+                const float resp = fabsf(__uint_as_float(rl_u(mine.y, t)));
+                const float px = (float)(cxy & 0xFFFFu), py = (float)(cxy >> 16);
+                const float fx = px * ratio, fy = py * ratio;
+                // which chunks can hold an entry within `size` of the candidate?
+                unsigned long long qm = __ballot(fy >= bmin0 - margin && fy <= bmax0 + margin);
+                unsigned long long q1 = 0ull;
+                if (nact > 4096u) q1 = __ballot(fy >= bmin1 - margin && fy <= bmax1 + margin);  // rare: > 64 chunks
+                bool found = false;
+                uint32_t first = 0u;
+                float first_resp = 0.f;
+                uint32_t first_sc = 0u;
+                uint32_t kbase = 0u;
+                for (;;) {
+                    while (qm) {
+                        uint32_t kk = kbase + (uint32_t)__ffsll((long long)qm) - 1u;
+                        qm &= qm - 1ull;
+                        uint32_t i = kk * 64u + lane;
+                        ActEntry en = act[i < nact ? i : 0u];
+                        float dx = fx - en.x, dy = fy - en.y;
+                        unsigned long long hb = __ballot(i < nact && dx * dx + dy * dy <= size2);
+                        if (hb) {
+                            uint32_t hl = (uint32_t)__ffsll((long long)hb) - 1u;
+                            found = true;
+                            first = kk * 64u + hl;
+                            first_resp = rl_f(en.resp, hl);
+                            first_sc = rl_u(en.slot_cls, hl);
+                            break;
                         }
+                    }
+                    if (found || q1 == 0ull) break;
+                    qm = q1;  // the chunks 64..127, visited only when chunks 0..63 had no hit
+                    q1 = 0ull;
+                    kbase = 64u;
+                }
+                // decision (wave-uniform values): scale_space_extrema.rs:72-116; the border test already passed
+                bool is_repeated = found && resp > first_resp;
+                if (found && !is_repeated) continue;  // is_extremum = false
+                uint32_t ai, slot;
+                if (!is_repeated) {
+                    ai = nact;
+                    slot = nslots;
+                    if (!(slot < max_kp && ai < (uint32_t)kActCap && slot < (1u << 24))) {
+                        if (lane == 0) *err = 2u;
+                        continue;
+                    }
+                    nact = ai + 1;
+                    nslots = slot + 1;
+                } else {
+                    ai = first;
+                    slot = first_sc >> 8;
+                }
+                // keypoint.point = p * ratio + 0.5 * (ratio - 1)  (:106-109)
+                const float kx = fx + half_off, ky = fy + half_off;
+                if (lane == 0) {
+                    DevKp kp = {kx, ky, resp, size, 0.0f, L.octave, (uint32_t)e};
+                    ch[slot] = kp;
+                    ActEntry w = {kx, ky, resp, (slot << 8) | (uint32_t)e};
+                    act[ai] = w;
+                }
+                // widen (or start) the bounds of chunk ai/64 in the lane that owns it
+                const uint32_t ck = ai >> 6;
+                const bool fresh = !is_repeated && (ai & 63u) == 0u;
+                if (lane == (ck & 63u)) {
+                    if (ck < 64u) {
+                        bmin0 = fresh ? ky : fminf(bmin0, ky);
+                        bmax0 = fresh ? ky : fmaxf(bmax0, ky);
+                    } else {
+                        bmin1 = fresh ? ky : fminf(bmin1, ky);
+                        bmax1 = fresh ? ky : fmaxf(bmax1, ky);
                     }
                 }
             }
-            __syncthreads();
         }
     }
-    if (tid == 0) ncache[frame] = s_ncache;
+    if (lane == 0) ncache[frame] = nslots;
 }
 
 // second pass (scale_space_extrema.rs:121-140): drop i if a LATER cache entry of class i+1 lies within
@@ -477,8 +517,7 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
         const float oratio = (float)(1u << Lp->octave);
         const float s = roundf(0.5f * kp.size / oratio);
         const float xf = kp.x / oratio, yf = kp.y / oratio;
-        const float* LX = Lp->Lx + (size_t)frame * Lp->fs;
-        const float* LY = Lp->Ly + (size_t)frame * Lp->fs;
+        const float2* LXY = Lp->Lxy + (size_t)frame * Lp->fs;
         for (int idx = lane; idx < 109; idx += 64) {
             unsigned iy = sat_u32(roundf(yf + (float)c_ori.dj[idx] * s));
             unsigned ix = sat_u32(roundf(xf + (float)c_ori.di[idx] * s));
@@ -488,8 +527,9 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
                 iy = min(iy, (unsigned)Lp->h - 1u);
             }
             float g = c_ori.gw[idx];
-            float rx = g * LX[(size_t)iy * Lp->w + ix];
-            float ry = g * LY[(size_t)iy * Lp->w + ix];
+            float2 dxy = LXY[(size_t)iy * Lp->w + ix];
+            float rx = g * dxy.x;
+            float ry = g * dxy.y;
             s_rx[wv][idx] = rx;
             s_ry[wv][idx] = ry;
             s_ang[wv][idx] = fast_atan2_equiv(ry, rx);
@@ -609,8 +649,7 @@ __global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables
         const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
         if (lane < c_desc.n_cells) {
             const float* LT = L.Lt + (size_t)frame * L.fs;
-            const float* LX = L.Lx + (size_t)frame * L.fs;
-            const float* LY = L.Ly + (size_t)frame * L.fs;
+            const float2* LXY = L.Lxy + (size_t)frame * L.fs;
             const int i0 = c_desc.ci[lane], j0 = c_desc.cj[lane], st = c_desc.step[lane];
             const int nch = c_desc.nch;
             float di = 0.0f, dx = 0.0f, dy = 0.0f;
@@ -631,7 +670,8 @@ __global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables
                     float ri = LT[p];
                     di += ri;
                     if (nch > 1) {
-                        float rx = LX[p], ry = LY[p];
+                        float2 dxy = LXY[p];
+                        float rx = dxy.x, ry = dxy.y;
                         if (nch == 2) {
                             dx += sqrtf(rx * rx + ry * ry);
                         } else {
@@ -675,6 +715,113 @@ __global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path of A16 + A17 for the reference's default pattern (descriptor_pattern_size 10, 3 channels:
+// grids of 2x2 / 3x3 / 4x4 cells with sample steps 10 / 7 / 5).  One wave per keypoint, grid by grid:
+//   gather   lane <-> sample, consecutive lanes = consecutive samples of a cell row, i.e. neighbouring
+//            pixels: the wave's loads fall on a few cache lines instead of 64, and {Lx,Ly} is one 8-byte
+//            load.  Each sample's (Lt, rotated dx, rotated dy) goes to the wave's LDS segment.
+//   reduce   lane <-> cell: the cell's samples are summed from LDS sequentially in the reference's
+//            (k outer, l inner) order (descriptors.rs:123-159) — the order is what makes the f32 sums
+//            bit-exact, so there is no tree reduction.
+// A wave's DS instructions execute in order, so the reduce phase sees the gather phase's writes without
+// a barrier; waves never share LDS here.
+template <int ST, int SIDE, int VBASE>
+__device__ __forceinline__ bool desc_grid(const float* __restrict__ LT, const float2* __restrict__ LXY, int W, int Hh,
+                                          float xf, float yf, float co, float si, float scale, float* s_ri,
+                                          float* s_dx, float* s_dy, float* s_val, int lane)
+{
+    constexpr int CS = ST * ST;             // samples per cell
+    constexpr int NS = SIDE * SIDE * CS;    // samples of the grid
+    bool oob = false;
+#pragma unroll 2
+    for (int s0 = 0; s0 < NS; s0 += 64) {
+        const int s = s0 + lane;
+        const bool on = s < NS;
+        const int cell = s / CS, rem = s - cell * CS;
+        const int kk = rem / ST, ll = rem - kk * ST;
+        // cell origins step from -pattern_size: i outer (k), j inner (l) — descriptors.rs:117-118
+        const float kf = (float)(-10 + (cell / SIDE) * ST + kk);
+        const float lf = (float)(-10 + (cell % SIDE) * ST + ll);
+        // descriptors.rs:127-128, exact expression order
+        float sample_y = yf + (lf * co * scale + kf * si * scale);
+        float sample_x = xf + (-lf * si * scale + kf * co * scale);
+        int y1 = sat_i32(roundf(sample_y));
+        int x1 = sat_i32(roundf(sample_x));
+        bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
+        oob |= on && bad;
+        int idx = (on && !bad) ? y1 * W + x1 : 0;
+        float ri = LT[idx];
+        float2 d = LXY[idx];
+        float rry = d.x * co + d.y * si;     // descriptors.rs:151-152
+        float rrx = -d.x * si + d.y * co;
+        if (on) {
+            s_ri[s] = ri;
+            s_dx[s] = rrx;
+            s_dy[s] = rry;
+        }
+    }
+    if (__any(oob)) return true;  // Error::SampleOutOfBounds: the keypoint is dropped (descriptors.rs:28)
+    if (lane < SIDE * SIDE) {
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        const int b = lane * CS;
+#pragma unroll 5
+        for (int t = 0; t < CS; ++t) {
+            di += s_ri[b + t];
+            dx += s_dx[b + t];
+            dy += s_dy[b + t];
+        }
+        const float ns = (float)CS;
+        s_val[VBASE + lane * 3 + 0] = di / ns;
+        s_val[VBASE + lane * 3 + 1] = dx / ns;
+        s_val[VBASE + lane * 3 + 2] = dy / ns;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescTables* __restrict__ desc_p,
+                                                       const DevKp* __restrict__ in,
+                                                       const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                       akz_descriptor* __restrict__ out, uint32_t* __restrict__ flag)
+{
+    constexpr int SMAX = 448;  // >= 441 samples of the largest grid
+    __shared__ float s_ri[4][SMAX], s_dx[4][SMAX], s_dy[4][SMAX];
+    __shared__ float s_val[4][96];
+    const DescTables& c_desc = *desc_p;
+    const int frame = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t ki = blockIdx.x * 4 + wv;
+    if (ki >= n) return;  // whole wave; no block-level barrier below
+    const DevKp kp = in[(size_t)frame * stride + ki];
+    const LevelDesc& L = T.L[kp.class_id];
+    // get_mldb_descriptor, descriptors.rs:66-72
+    const float ratio = (float)(1u << kp.octave);
+    const float scale = roundf(0.5f * kp.size / ratio);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
+    const float* LT = L.Lt + (size_t)frame * L.fs;
+    const float2* LXY = L.Lxy + (size_t)frame * L.fs;
+    bool oob = desc_grid<10, 2, 0>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+    if (!oob)
+        oob = desc_grid<7, 3, 12>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+    if (!oob)
+        oob = desc_grid<5, 4, 39>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+    // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
+    uint32_t byte = 0;
+    if (!oob) {
+        for (int t = 0; t < 8; ++t) {
+            int b = lane * 8 + t;
+            if (b < c_desc.n_bits) {
+                float va = s_val[wv][c_desc.cmp_a[b]], vb = s_val[wv][c_desc.cmp_b[b]];
+                byte |= (va > vb ? 1u : 0u) << t;
+            }
+        }
+    }
+    out[(size_t)frame * stride + ki].bytes[lane] = (uint8_t)byte;
+    if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
+}
+
 void build_level_table(const akz_ctx* c, LevelTable* T)
 {
     const AkzPlan& P = c->plan;
@@ -685,8 +832,7 @@ void build_level_table(const akz_ctx* c, LevelTable* T)
         LevelDesc& d = T->L[i];
         d.Ldet = c->Ldet[i];
         d.Lt = c->Lt[i];
-        d.Lx = c->Lx[i];
-        d.Ly = c->Ly[i];
+        d.Lxy = c->Lxy[i];
         d.w = L.w;
         d.h = L.h;
         d.fs = L.pixels();
@@ -702,6 +848,7 @@ void build_level_table(const akz_ctx* c, LevelTable* T)
 
 size_t akz_ori_table_bytes() { return sizeof(OriTables); }
 size_t akz_desc_table_bytes() { return sizeof(DescTables); }
+
 
 // ---------------------------------------------------------------------------------------------
 // host-side constant tables
@@ -818,7 +965,8 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         AKZ_LAUNCH_CHECK();
     }
     // A12b
-    hipLaunchKernelGGL(k_suppress, dim3(n), dim3(256), sizeof(ActEntry) * kActCap + 64, s, T, c->d_rowcount, rows_stride,
+    hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T,
+                       c->d_rowcount, rows_stride,
                        c->d_cand, c->max_cand, c->d_cache, c->max_kp, c->d_ncache, c->d_err);
     AKZ_LAUNCH_CHECK();
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
@@ -845,8 +993,13 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                        c->max_kp, maxf, c->d_kp_d, c->d_n_d);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
-    hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d, c->d_n_d, c->max_kp, c->d_desc_tmp,
-                       c->d_flag_d);
+    if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
+        hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d,
+                           c->d_n_d, c->max_kp, c->d_desc_tmp, c->d_flag_d);
+    } else {
+        hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d,
+                           c->d_n_d, c->max_kp, c->d_desc_tmp, c->d_flag_d);
+    }
     AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, c->d_kp_d, c->d_desc_tmp, c->d_flag_d, c->d_n_d,
                        c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr);

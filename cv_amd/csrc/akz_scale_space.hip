@@ -331,13 +331,15 @@ struct OffK {
 };
 __device__ __forceinline__ float off_combine(const OffK k, float a, float b, float c)
 {
-    float pa = a * k.n, pb = b * k.m, pc = c * k.n;
+    // the first tap of lane 0 is accumulated onto the +0 the reference's fold starts from (a product that
+    // underflows to -0 becomes +0); after that no partial sum can be -0, so no other tap needs it
+    float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
     return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
 }
 
 // Lx = V_off(H_main(Lsmooth)), Ly = V_main(H_off(Lsmooth)) — detector_response.rs:63-64.
-__global__ __launch_bounds__(256) void k_deriv_first(const float* __restrict__ sm, float* __restrict__ Lx,
-                                                     float* __restrict__ Ly, int w, int h, size_t fs, int s, OffK k)
+__global__ __launch_bounds__(256) void k_deriv_first(const float* __restrict__ sm, float2* __restrict__ Lxy, int w,
+                                                     int h, size_t fs, int s, OffK k)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -355,31 +357,35 @@ __global__ __launch_bounds__(256) void k_deriv_first(const float* __restrict__ s
     float ho_m = off_combine(k, mm, m0, mp);
     float ho_p = off_combine(k, pm, p0, pp);
     float ly = ho_p - ho_m;
-    size_t o = (size_t)blockIdx.z * fs + r0 + x;
-    Lx[o] = lx;
-    Ly[o] = ly;
+    Lxy[(size_t)blockIdx.z * fs + r0 + x] = make_float2(lx, ly);
 }
 
 // Lxx = scharr_h(Lx) = V_off(H_main Lx); Lyy = scharr_v(Ly) = V_main(H_off Ly); Lxy = scharr_v(Lx) =
 // V_main(H_off Lx) — detector_response.rs:65-67; Ldet = (Lxx*Lyy - Lxy*Lxy) * sigma^4 — :46.
-__global__ __launch_bounds__(256) void k_deriv_second(const float* __restrict__ Lx, const float* __restrict__ Ly,
-                                                      float* __restrict__ Ldet, int w, int h, size_t fs, int s,
-                                                      OffK k, float sigma_quat)
+__global__ __launch_bounds__(256) void k_deriv_second(const float2* __restrict__ Lxy, float* __restrict__ Ldet, int w,
+                                                      int h, size_t fs, int s, OffK k, float sigma_quat)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const float* X = Lx + (size_t)blockIdx.z * fs;
-    const float* Y = Ly + (size_t)blockIdx.z * fs;
+    const float2* D = Lxy + (size_t)blockIdx.z * fs;
     int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
     size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
-    float xmm = X[rm + xm], xm0 = X[rm + x], xmp = X[rm + xp];
-    float xzm = X[r0 + xm], xzp = X[r0 + xp];
-    float xpm = X[rp + xm], xp0 = X[rp + x], xpp = X[rp + xp];
-    float lxx = off_combine(k, xmp - xmm, xzp - xzm, xpp - xpm);
-    float lxy = off_combine(k, xpm, xp0, xpp) - off_combine(k, xmm, xm0, xmp);
-    float lyy = off_combine(k, Y[rp + xm], Y[rp + x], Y[rp + xp]) - off_combine(k, Y[rm + xm], Y[rm + x], Y[rm + xp]);
+    // the 3x3 stencil (spacing s) minus its centre; .x = Lx, .y = Ly
+    float2 mm = D[rm + xm], m0 = D[rm + x], mp = D[rm + xp];
+    float2 zm = D[r0 + xm], zp = D[r0 + xp];
+    float2 pm = D[rp + xm], p0 = D[rp + x], pp = D[rp + xp];
+    float lxx = off_combine(k, mp.x - mm.x, zp.x - zm.x, pp.x - pm.x);
+    float lxy = off_combine(k, pm.x, p0.x, pp.x) - off_combine(k, mm.x, m0.x, mp.x);
+    float lyy = off_combine(k, pm.y, p0.y, pp.y) - off_combine(k, mm.y, m0.y, mp.y);
     Ldet[(size_t)blockIdx.z * fs + r0 + x] = (lxx * lyy - lxy * lxy) * sigma_quat;
+}
+
+__global__ __launch_bounds__(256) void k_deinterleave(const float2* __restrict__ in, float* __restrict__ out, size_t n,
+                                                      int component)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = component ? in[i].y : in[i].x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,6 +446,13 @@ int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int 
                          int vertical)
 {
     hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, in, out, w, h, d_kernel, ksize, vertical);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+int32_t akz_dev_deinterleave(hipStream_t s, const float2* in, float* out, size_t n, int component)
+{
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, component);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
@@ -553,11 +566,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         }
         // detector_response.rs:60-67 + :33-57
         OffK k = make_offk(L.deriv_sigma);
-        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, c->Lx[i], c->Ly[i], L.w, L.h,
-                           fs, (int)L.deriv_sigma, k);
+        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, c->Lxy[i], L.w, L.h, fs,
+                           (int)L.deriv_sigma, k);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, c->Lx[i], c->Ly[i], c->Ldet[i], L.w,
-                           L.h, fs, (int)L.deriv_sigma, k, L.sigma_quat);
+        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, c->Lxy[i], c->Ldet[i], L.w, L.h, fs,
+                           (int)L.deriv_sigma, k, L.sigma_quat);
         AKZ_LAUNCH_CHECK();
     }
     akz_timer_end(c, &c->t_ss, 0, (uint64_t)n);

@@ -157,6 +157,22 @@ def test_full_hd_frame(gpu, oracle):
     assert len(kp) > 500
 
 
+@pytest.mark.parametrize("nch", [1, 2, 3])
+def test_descriptor_channels(gpu, oracle, nch):
+    """descriptor_channels 1 / 2 / 3 (descriptors.rs:145-156, :188): 1 and 2 run the generic kernel."""
+    akaze, _ = gpu
+    img = synth_frame(400, 300, 77)
+    ak = akaze.Akaze(descriptor_channels=nch)
+    kp, desc = ak.extract_arrays(img)
+    cfg = oracle.default_config()
+    cfg.descriptor_channels = nch
+    okp, odesc = oracle.Akaze(400, 300, cfg).extract(img)
+    _kp_eq(kp, okp, f"nch={nch}")
+    _eq(desc, odesc, f"nch={nch} desc")
+    used_bits = nch * 162
+    assert not np.unpackbits(desc, axis=1, bitorder="little")[:, used_bits:].any()
+
+
 def test_maximum_features_and_capacity(gpu, oracle, kitti):
     """lib.rs:326-327 truncation; AKZ_E_CAPACITY reports the required count."""
     akaze, _ = gpu
