@@ -69,7 +69,8 @@ void akz_timer_end(akz_ctx* c, AkzTimer* t, uint64_t launches, uint64_t units)
     if (!c->timing || !t->cur_start) return;
     hipEvent_t stop = timer_event(t);
     if (!stop) return;
-    hipEventRecord(stop, c->stream);
+    // the whole-extract timer closes where the outputs complete: on the keypoint stream
+    hipEventRecord(stop, t == &c->t_all ? c->stream_kp : c->stream);
     t->pending.emplace_back(t->cur_start, stop);
     t->cur_start = nullptr;
     t->launches += launches;
@@ -134,6 +135,13 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     c->keep_all = keep && keep[0] == '1';
     int32_t st = AKZ_OK;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) st = AKZ_E_HIP;
+    if (st == AKZ_OK && hipStreamCreateWithFlags(&c->stream_kp, hipStreamNonBlocking) != hipSuccess) st = AKZ_E_HIP;
+    for (int b = 0; b < 2 && st == AKZ_OK; ++b) {
+        if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+        if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+    }
+    const char* pipe = getenv("AKZ_PIPELINE");
+    c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
     if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
     if (st != AKZ_OK) {
         akz_destroy(c);
@@ -148,11 +156,17 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
     if (!c) return AKZ_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream_kp) hipStreamSynchronize(c->stream_kp);
     timer_free(&c->t_fed);
     timer_free(&c->t_ss);
     timer_free(&c->t_all);
     if (c->arena) hipFree(c->arena);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream_kp) hipStreamDestroy(c->stream_kp);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_ss_done[b]) hipEventDestroy(c->ev_ss_done[b]);
+        if (c->ev_kp_done[b]) hipEventDestroy(c->ev_kp_done[b]);
+    }
     delete c;
     return AKZ_OK;
 }
@@ -172,25 +186,24 @@ struct Carver {
 };
 }  // namespace
 
-static void carve(akz_ctx* c, char* base, size_t* total)
+static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
 {
     const AkzPlan& P = c->plan;
     const size_t B = (size_t)c->max_batch;
     const size_t P0 = (size_t)c->max_w * c->max_h;  // sized for the largest frame the context accepts
     const int nlev = (int)P.levels.size();
-    Carver cv{base};
-    c->Lt.assign(nlev, nullptr);
-    c->Lsm.assign(nlev, nullptr);
-    c->Lxy.assign(nlev, nullptr);
-    c->Ldet.assign(nlev, nullptr);
-    c->Lflow.assign(nlev, nullptr);
+    S.Lt.assign(nlev, nullptr);
+    S.Lsm.assign(nlev, nullptr);
+    S.Lxy.assign(nlev, nullptr);
+    S.Ldet.assign(nlev, nullptr);
+    S.Lflow.assign(nlev, nullptr);
     // persistent per-level planes: Lt, Lx, Ly (descriptors), Ldet (extrema, sub-pixel)
     size_t max_level_px = 0;
     for (int i = 0; i < nlev; ++i) {
         size_t px = P.levels[i].pixels() * B;
-        c->Lt[i] = cv.take<float>(px);
-        c->Lxy[i] = cv.take<float2>(px);
-        c->Ldet[i] = cv.take<float>(px);
+        S.Lt[i] = cv.take<float>(px);
+        S.Lxy[i] = cv.take<float2>(px);
+        S.Ldet[i] = cv.take<float>(px);
         if (px > max_level_px) max_level_px = px;
     }
     // transient planes: Lsmooth / Lflow only live while their level is being built
@@ -199,48 +212,56 @@ static void carve(akz_ctx* c, char* base, size_t* total)
     for (int i = 0; i < nlev; ++i) {
         size_t px = P.levels[i].pixels() * B;
         if (i == 0) {
-            c->Lsm[0] = c->Lt[0];  // lib.rs:201
-            c->Lflow[0] = nullptr;
+            S.Lsm[0] = S.Lt[0];  // lib.rs:201
+            S.Lflow[0] = nullptr;
             continue;
         }
-        c->Lsm[i] = c->keep_all ? cv.take<float>(px) : sm_scratch;
-        c->Lflow[i] = c->keep_all ? cv.take<float>(px) : fl_scratch;
+        S.Lsm[i] = c->keep_all ? cv.take<float>(px) : sm_scratch;
+        S.Lflow[i] = c->keep_all ? cv.take<float>(px) : fl_scratch;
     }
-    c->tmp = cv.take<float>(P0 * B);
-    c->d_in = cv.take<float>(P0 * B);
-    c->d_cmax = cv.take<unsigned long long>(B);
-    c->d_hist = cv.take<uint32_t>(B * 512);
-    c->d_npoints = cv.take<uint32_t>(B);
-    c->d_contrast = cv.take<double>(B);
-    c->d_invk = cv.take<float>(B * 8);
+    S.tmp = cv.take<float>(P0 * B);
+    S.d_in = cv.take<float>(P0 * B);
+    S.d_cmax = cv.take<unsigned long long>(B);
+    S.d_hist = cv.take<uint32_t>(B * 512);
+    S.d_npoints = cv.take<uint32_t>(B);
+    S.d_contrast = cv.take<double>(B);
+    S.d_invk = cv.take<float>(B * 8);
     size_t rows = P.total_rows + 1;
     // the row table is sized for the tallest pyramid the context can see
     size_t max_rows = (size_t)c->max_h * 2 * (size_t)c->cfg.num_sublevels + 64;
     if (rows > max_rows) max_rows = rows;
-    c->d_rowcount = cv.take<uint32_t>(B * max_rows);
-    c->d_ncand = cv.take<uint32_t>(B);
-    c->d_cand = cv.take<uint2>(B * c->max_cand);
+    S.d_rowcount = cv.take<uint32_t>(B * max_rows);
+    S.d_ncand = cv.take<uint32_t>(B);
+    S.d_cand = cv.take<uint2>(B * c->max_cand);
     const size_t K = c->max_kp;
-    c->d_cache = cv.take<DevKp>(B * K);
-    c->d_ncache = cv.take<uint32_t>(B);
-    c->d_kp_a = cv.take<DevKp>(B * K);
-    c->d_n_a = cv.take<uint32_t>(B);
-    c->d_kp_b = cv.take<DevKp>(B * K);
-    c->d_flag_b = cv.take<uint32_t>(B * K);
-    c->d_kp_c = cv.take<DevKp>(B * K);
-    c->d_n_c = cv.take<uint32_t>(B);
-    c->d_kp_d = cv.take<DevKp>(B * K);
-    c->d_n_d = cv.take<uint32_t>(B);
-    c->d_desc_tmp = cv.take<akz_descriptor>(B * K);
-    c->d_flag_d = cv.take<uint32_t>(B * K);
-    c->d_kp_out = cv.take<DevKp>(B * K);
-    c->d_desc_out = cv.take<akz_descriptor>(B * K);
-    c->d_n_out = cv.take<uint32_t>(B);
+    S.d_cache = cv.take<DevKp>(B * K);
+    S.d_ncache = cv.take<uint32_t>(B);
+    S.d_kp_a = cv.take<DevKp>(B * K);
+    S.d_n_a = cv.take<uint32_t>(B);
+    S.d_kp_b = cv.take<DevKp>(B * K);
+    S.d_flag_b = cv.take<uint32_t>(B * K);
+    S.d_kp_c = cv.take<DevKp>(B * K);
+    S.d_n_c = cv.take<uint32_t>(B);
+    S.d_kp_d = cv.take<DevKp>(B * K);
+    S.d_n_d = cv.take<uint32_t>(B);
+    S.d_desc_tmp = cv.take<akz_descriptor>(B * K);
+    S.d_flag_d = cv.take<uint32_t>(B * K);
+    S.d_kp_out = cv.take<DevKp>(B * K);
+    S.d_desc_out = cv.take<akz_descriptor>(B * K);
+    S.d_n_out = cv.take<uint32_t>(B);
+}
+
+static void carve(akz_ctx* c, char* base, size_t* total)
+{
+    Carver cv{base};
+    for (int b = 0; b < c->nsets; ++b) carve_set(c, c->sets[b], cv);
     c->d_err = cv.take<uint32_t>(4);
     c->d_ori = cv.take<char>(akz_ori_table_bytes());
     c->d_desc = cv.take<char>(akz_desc_table_bytes());
     *total = akz_align_up(cv.off, 256);
 }
+
+static int32_t sync_all(akz_ctx* c);
 
 int32_t akz_ctx_prepare(akz_ctx* c, int w, int h)
 {
@@ -256,7 +277,7 @@ int32_t akz_ctx_prepare(akz_ctx* c, int w, int h)
         AKZ_HIP(hipMalloc(&c->arena, total));
         c->arena_bytes = total;
     } else {
-        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_TRY(sync_all(c));
     }
     akz_build_plan(c->cfg, w, h, &c->plan);
     size_t total = 0;
@@ -272,12 +293,29 @@ int32_t akz_ctx_prepare(akz_ctx* c, int w, int h)
 static int32_t check_device_err(akz_ctx* c)
 {
     uint32_t err = 0;
-    AKZ_HIP(hipMemcpyAsync(&err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
+    AKZ_TRY(sync_all(c));
+    AKZ_HIP(hipMemcpy(&err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (err & ~4u) {
         AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
         return AKZ_E_INTERNAL;
     }
+    return AKZ_OK;
+}
+
+// Start of a batch call: pick the buffer set and make the scale-space stream wait until the keypoint
+// stage that last used this set has finished reading its pyramid.
+static int32_t begin_call(akz_ctx* c)
+{
+    c->cur = (int)(c->calls % (uint64_t)c->nsets);
+    c->calls++;
+    if (c->kp_pending[c->cur]) AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev_kp_done[c->cur], 0));
+    return AKZ_OK;
+}
+static int32_t sync_all(akz_ctx* c)
+{
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream_kp));
+    c->kp_pending[0] = c->kp_pending[1] = false;
     return AKZ_OK;
 }
 
@@ -292,13 +330,13 @@ static int32_t wait_for(akz_ctx* c, void* stream_to_wait)
     return AKZ_OK;
 }
 
-extern "C" void* akz_stream(akz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+// The stream on which a call's outputs complete (the keypoint stream).
+extern "C" void* akz_stream(akz_ctx* c) { return c ? (void*)c->stream_kp : nullptr; }
 extern "C" int32_t akz_sync(akz_ctx* c)
 {
     if (!c) return AKZ_E_INVALID;
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    return check_device_err(c);
+    return check_device_err(c);  // synchronises both streams
 }
 
 extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
@@ -308,9 +346,16 @@ extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_
     if (n > c->max_batch) return AKZ_E_TOO_LARGE;
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_TRY(akz_ctx_prepare(c, w, h));
+    AKZ_TRY(begin_call(c));
     AKZ_TRY(wait_for(c, stream_to_wait));
     c->cur_n = n;
-    return akz_run_scale_space(c, d_imgs, fmt, n);
+    AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
+    // completion is observable on akz_stream() like every other call
+    AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
+    AKZ_HIP(hipStreamWaitEvent(c->stream_kp, c->ev_ss_done[c->cur], 0));
+    AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
+    c->kp_pending[c->cur] = true;
+    return AKZ_OK;
 }
 
 extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
@@ -322,6 +367,7 @@ extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int3
     if (n > c->max_batch) return AKZ_E_TOO_LARGE;
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_TRY(akz_ctx_prepare(c, w, h));
+    AKZ_TRY(begin_call(c));
     AKZ_TRY(wait_for(c, stream_to_wait));
     c->cur_n = n;
     akz_timer_begin(c, &c->t_all);
@@ -340,21 +386,22 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
     if (n > c->max_batch) return AKZ_E_TOO_LARGE;
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_TRY(akz_ctx_prepare(c, w, h));
+    AKZ_TRY(begin_call(c));
     const size_t esz = fmt == 0 ? 1 : 4;
     const size_t P0 = (size_t)w * h;
     for (int i = 0; i < n; ++i) {
         if (!imgs[i]) return AKZ_E_INVALID;
-        AKZ_HIP(hipMemcpy2DAsync((char*)c->d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
+        AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
                                  (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
     }
     c->cur_n = n;
     akz_timer_begin(c, &c->t_all);
-    AKZ_TRY(akz_run_scale_space(c, c->d_in, fmt, n));
-    AKZ_TRY(akz_run_keypoints(c, n, c->d_kp_out, c->d_desc_out, c->max_kp, c->d_n_out));
+    AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
+    AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
     akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
     std::vector<uint32_t> cnt(n);
-    AKZ_HIP(hipMemcpyAsync(cnt.data(), c->d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    AKZ_TRY(check_device_err(c));  // synchronises
+    AKZ_TRY(check_device_err(c));  // synchronises both streams
+    AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     int32_t status = AKZ_OK;
     for (int i = 0; i < n; ++i) {
         n_out[i] = cnt[i];
@@ -362,9 +409,9 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
         if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
         uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
         if (m) {
-            AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
+            AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->S().d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
                               hipMemcpyDeviceToHost));
-            AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->d_desc_out + (size_t)i * c->max_kp,
+            AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->S().d_desc_out + (size_t)i * c->max_kp,
                               sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
         }
     }
@@ -446,24 +493,24 @@ extern "C" int32_t akz_debug_get_level(akz_ctx* c, int32_t img, int32_t level, i
     const float* src = nullptr;
     int comp = -1;
     switch (which) {
-    case AKZ_BUF_LT: src = c->Lt[level]; break;
-    case AKZ_BUF_LSMOOTH: src = c->Lsm[level]; break;
+    case AKZ_BUF_LT: src = c->S().Lt[level]; break;
+    case AKZ_BUF_LSMOOTH: src = c->S().Lsm[level]; break;
     case AKZ_BUF_LX: comp = 0; break;
     case AKZ_BUF_LY: comp = 1; break;
-    case AKZ_BUF_LDET: src = c->Ldet[level]; break;
-    case AKZ_BUF_LFLOW: src = c->Lflow[level]; break;
+    case AKZ_BUF_LDET: src = c->S().Ldet[level]; break;
+    case AKZ_BUF_LFLOW: src = c->S().Lflow[level]; break;
     default: return AKZ_E_INVALID;
     }
     if (!src && comp < 0) return AKZ_E_INVALID;
     // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
     if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
+    AKZ_TRY(sync_all(c));
     size_t px = c->plan.levels[level].pixels();
     if (comp >= 0) {  // Lx / Ly live interleaved; split one component into the (idle) FED scratch plane
-        AKZ_TRY(akz_dev_deinterleave(c->stream, c->Lxy[level] + (size_t)img * px, c->tmp, px, comp));
+        AKZ_TRY(akz_dev_deinterleave(c->stream, c->S().Lxy[level] + (size_t)img * px, c->S().tmp, px, comp));
         AKZ_HIP(hipStreamSynchronize(c->stream));
-        src = c->tmp;
+        src = c->S().tmp;
         AKZ_HIP(hipMemcpy(out, src, sizeof(float) * px, hipMemcpyDeviceToHost));
         return AKZ_OK;
     }
@@ -474,8 +521,8 @@ extern "C" int32_t akz_debug_get_contrast(akz_ctx* c, int32_t img, double* out)
 {
     if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    AKZ_HIP(hipMemcpy(out, c->d_contrast + img, sizeof(double), hipMemcpyDeviceToHost));
+    AKZ_TRY(sync_all(c));
+    AKZ_HIP(hipMemcpy(out, c->S().d_contrast + img, sizeof(double), hipMemcpyDeviceToHost));
     return AKZ_OK;
 }
 extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stage, akz_keypoint* out, uint32_t cap,
@@ -485,13 +532,13 @@ extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stag
     const DevKp* src;
     const uint32_t* cnt;
     switch (stage) {
-    case 0: src = c->d_kp_a; cnt = c->d_n_a; break;
-    case 1: src = c->d_kp_c; cnt = c->d_n_c; break;
-    case 2: src = c->d_kp_d; cnt = c->d_n_d; break;
+    case 0: src = c->S().d_kp_a; cnt = c->S().d_n_a; break;
+    case 1: src = c->S().d_kp_c; cnt = c->S().d_n_c; break;
+    case 2: src = c->S().d_kp_d; cnt = c->S().d_n_d; break;
     default: return AKZ_E_INVALID;
     }
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
+    AKZ_TRY(sync_all(c));
     uint32_t n = 0;
     AKZ_HIP(hipMemcpy(&n, cnt + img, sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_out = n;

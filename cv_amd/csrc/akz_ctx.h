@@ -15,21 +15,8 @@ struct AkzTimer {
     uint64_t launches = 0, units = 0;
 };
 
-struct akz_ctx {
-    akz_config cfg;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int max_w = 0, max_h = 0, max_batch = 0;
-    uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
-    uint32_t max_cand = 0;    // capacity of the per-frame raw candidate list
-    bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
-
-    AkzPlan plan;             // for (cur_w, cur_h)
-    int cur_w = 0, cur_h = 0, cur_n = 0;
-
-    // ---- device memory (one arena, carved in akz_ctx_prepare) ----
-    void* arena = nullptr;
-    size_t arena_bytes = 0;
+// Every per-batch device buffer (pyramid, work lists, outputs).
+struct AkzSet {
     std::vector<float*> Lt, Lsm, Ldet, Lflow;  // [level] -> frame-major f32 planes
     std::vector<float2*> Lxy;                  // [level] -> frame-major {Lx, Ly} planes (interleaved: every consumer
                                                // reads both derivatives at the same pixel)
@@ -60,6 +47,34 @@ struct akz_ctx {
     DevKp* d_kp_out = nullptr;             // [B][max_kp]  final (internal copy used by the host-buffer API)
     akz_descriptor* d_desc_out = nullptr;  // [B][max_kp]
     uint32_t* d_n_out = nullptr;           // [B]
+};
+
+struct akz_ctx {
+    akz_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
+    uint32_t max_cand = 0;    // capacity of the per-frame raw candidate list
+    bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
+
+    AkzPlan plan;             // for (cur_w, cur_h)
+    int cur_w = 0, cur_h = 0, cur_n = 0;
+
+    // ---- device memory (one arena, carved in akz_ctx_prepare) ----
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    // Two complete buffer sets: call k works in set k&1, so the scale space of micro-batch k+1 (stream
+    // `stream`, HBM-bound) overlaps the keypoint stage of micro-batch k (stream `stream_kp`, latency-bound).
+    AkzSet sets[2];
+    int nsets = 2;
+    int cur = 0;               // set used by the most recent call
+    uint64_t calls = 0;
+    hipStream_t stream_kp = nullptr;
+    hipEvent_t ev_ss_done[2] = {nullptr, nullptr};  // pyramid + candidates of set b ready
+    hipEvent_t ev_kp_done[2] = {nullptr, nullptr};  // keypoint stage of set b finished (pyramid reusable)
+    bool kp_pending[2] = {false, false};
+    AkzSet& S() { return sets[cur]; }
     uint32_t* d_err = nullptr;             // [1] sticky device-side overflow flag
     void* d_ori = nullptr;                 // OriTables (orientation sample/window tables)
     void* d_desc = nullptr;                // DescTables (M-LDB cell + comparison tables)

@@ -822,17 +822,18 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
     if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
 }
 
-void build_level_table(const akz_ctx* c, LevelTable* T)
+void build_level_table(akz_ctx* c, LevelTable* T)
 {
     const AkzPlan& P = c->plan;
+    AkzSet& S = c->S();
     T->n = (int)P.levels.size();
     uint32_t rb = 0;
     for (int i = 0; i < T->n; ++i) {
         const AkzLevel& L = P.levels[i];
         LevelDesc& d = T->L[i];
-        d.Ldet = c->Ldet[i];
-        d.Lt = c->Lt[i];
-        d.Lxy = c->Lxy[i];
+        d.Ldet = S.Ldet[i];
+        d.Lt = S.Lt[i];
+        d.Lxy = S.Lxy[i];
         d.w = L.w;
         d.h = L.h;
         d.fs = L.pixels();
@@ -938,7 +939,8 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                           uint32_t* d_n_out)
 {
     const AkzPlan& P = c->plan;
-    hipStream_t s = c->stream;
+    AkzSet& S = c->S();
+    hipStream_t s = c->stream;  // candidate detection streams Ldet: it stays on the scale-space stream
     LevelTable T;
     if ((int)P.levels.size() > kMaxLevels) return AKZ_E_INVALID;
     build_level_table(c, &T);
@@ -946,63 +948,74 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     const float thr = (float)c->cfg.detector_threshold;
     if (T.n == 0) {
         AKZ_HIP(hipMemsetAsync(d_n_out, 0, sizeof(uint32_t) * n, s));
+        AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
+        AKZ_HIP(hipStreamWaitEvent(c->stream_kp, c->ev_ss_done[c->cur], 0));
+        AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
+        c->kp_pending[c->cur] = true;
         return AKZ_OK;
     }
     // A12a: ordered candidate lists
-    AKZ_HIP(hipMemsetAsync(c->d_rowcount, 0, sizeof(uint32_t) * (size_t)rows_stride * n, s));
+    AKZ_HIP(hipMemsetAsync(S.d_rowcount, 0, sizeof(uint32_t) * (size_t)rows_stride * n, s));
     for (int i = 0; i < T.n; ++i) {
         if (T.L[i].h < 3 || T.L[i].w < 3) continue;
-        hipLaunchKernelGGL(k_cand_count, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, c->d_rowcount,
+        hipLaunchKernelGGL(k_cand_count, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, S.d_rowcount,
                            rows_stride);
         AKZ_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_row_scan, dim3(n), dim3(1024), 0, s, c->d_rowcount, rows_stride, T.total_rows, c->d_ncand);
+    hipLaunchKernelGGL(k_row_scan, dim3(n), dim3(1024), 0, s, S.d_rowcount, rows_stride, T.total_rows, S.d_ncand);
     AKZ_LAUNCH_CHECK();
     for (int i = 0; i < T.n; ++i) {
         if (T.L[i].h < 3 || T.L[i].w < 3) continue;
-        hipLaunchKernelGGL(k_cand_scatter, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, c->d_rowcount,
-                           rows_stride, c->d_cand, c->max_cand, c->d_err);
+        hipLaunchKernelGGL(k_cand_scatter, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, S.d_rowcount,
+                           rows_stride, S.d_cand, c->max_cand, c->d_err);
         AKZ_LAUNCH_CHECK();
     }
+    // ---- hand over to the keypoint stream: everything below is latency-bound per-frame work that overlaps
+    // the next micro-batch's scale space ----
+    AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
+    s = c->stream_kp;
+    AKZ_HIP(hipStreamWaitEvent(s, c->ev_ss_done[c->cur], 0));
     // A12b
     hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T,
-                       c->d_rowcount, rows_stride,
-                       c->d_cand, c->max_cand, c->d_cache, c->max_kp, c->d_ncache, c->d_err);
+                       S.d_rowcount, rows_stride,
+                       S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err);
     AKZ_LAUNCH_CHECK();
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
-    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, c->d_cache, c->max_kp, c->d_ncache, c->d_flag_b);
+    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache, S.d_flag_b);
     AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, c->d_cache, (const akz_descriptor*)nullptr,
-                       c->d_flag_b, c->d_ncache, c->max_kp, c->d_kp_a, (akz_descriptor*)nullptr, c->max_kp, c->d_n_a,
+    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_cache, (const akz_descriptor*)nullptr,
+                       S.d_flag_b, S.d_ncache, c->max_kp, S.d_kp_a, (akz_descriptor*)nullptr, c->max_kp, S.d_n_a,
                        c->d_err);
     AKZ_LAUNCH_CHECK();
     // A13 + A14
     const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
-    hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, c->d_kp_a, c->d_n_a, c->max_kp, c->d_kp_b,
-                       c->d_flag_b, c->d_err);
+    hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, S.d_kp_a, S.d_n_a, c->max_kp, S.d_kp_b,
+                       S.d_flag_b, c->d_err);
     AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, c->d_kp_b, (const akz_descriptor*)nullptr,
-                       c->d_flag_b, c->d_n_a, c->max_kp, c->d_kp_c, (akz_descriptor*)nullptr, c->max_kp, c->d_n_c,
+    hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_kp_b, (const akz_descriptor*)nullptr,
+                       S.d_flag_b, S.d_n_a, c->max_kp, S.d_kp_c, (akz_descriptor*)nullptr, c->max_kp, S.d_n_c,
                        c->d_err);
     AKZ_LAUNCH_CHECK();
     // A15
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
     uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
-    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, c->d_kp_c, c->d_n_c,
-                       c->max_kp, maxf, c->d_kp_d, c->d_n_d);
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, S.d_kp_c, S.d_n_c,
+                       c->max_kp, maxf, S.d_kp_d, S.d_n_d);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
-        hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d,
-                           c->d_n_d, c->max_kp, c->d_desc_tmp, c->d_flag_d);
+        hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
+                           S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
     } else {
-        hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, c->d_kp_d,
-                           c->d_n_d, c->max_kp, c->d_desc_tmp, c->d_flag_d);
+        hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
+                           S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
     }
     AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, c->d_kp_d, c->d_desc_tmp, c->d_flag_d, c->d_n_d,
+    hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, S.d_kp_d, S.d_desc_tmp, S.d_flag_d, S.d_n_d,
                        c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
+    AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
+    c->kp_pending[c->cur] = true;
     return AKZ_OK;
 }

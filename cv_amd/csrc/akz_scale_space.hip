@@ -470,9 +470,10 @@ template <int R, int E, typename InT, int EPI>
 static int32_t launch_blur(akz_ctx* c, const InT* in, int w, int h, size_t in_fs, const GaussTaps& taps, float* out_g,
                            float* out_flow, size_t out_fs, int invk_off, int n)
 {
+    AkzSet& S = c->S();
     dim3 grid(akz_div_up(w, kTW), akz_div_up(h, kTH), n);
     hipLaunchKernelGGL((k_blur_tile<R, E, InT, EPI>), grid, dim3(256), 0, c->stream, in, w, h, in_fs, taps, out_g,
-                       out_flow, out_fs, c->d_invk, invk_off, c->d_cmax, c->d_hist, c->d_npoints,
+                       out_flow, out_fs, S.d_invk, invk_off, S.d_cmax, S.d_hist, S.d_npoints,
                        (int)c->cfg.contrast_factor_num_bins);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
@@ -492,6 +493,7 @@ template <typename InT>
 static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 {
     const AkzPlan& P = c->plan;
+    AkzSet& S = c->S();
     const int w = P.w, h = P.h;
     const size_t P0 = (size_t)w * h;
     const int nlev = (int)P.levels.size();
@@ -507,39 +509,39 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 
     akz_timer_begin(c, &c->t_ss);
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
-    AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, c->Lt[0], nullptr, P0, 0, n)));
+    AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, S.Lt[0], nullptr, P0, 0, n)));
     // lib.rs:206-211 — contrast factor on the ORIGINAL image
-    AKZ_HIP(hipMemsetAsync(c->d_cmax, 0, sizeof(unsigned long long) * n, s));
-    AKZ_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
-    AKZ_HIP(hipMemsetAsync(c->d_npoints, 0, sizeof(uint32_t) * n, s));
+    AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
+    AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
+    AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
     AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
     AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
-    hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, c->d_cmax, c->d_hist,
-                       c->d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, c->d_contrast, c->d_invk);
+    hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
+                       S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk);
     AKZ_LAUNCH_CHECK();
 
     uint64_t fed_launches = 0, fed_units = 0;
     for (int i = 0; i < nlev; ++i) {
         const AkzLevel& L = P.levels[i];
         const size_t fs = L.pixels();
-        const float* smooth = c->Lt[0];
+        const float* smooth = S.Lt[0];
         if (i > 0) {
             const int nsteps = (int)L.tau.size();
             // Ping-pong so the last FED step lands in Lt[i]; `init` is where the un-diffused Lt[i] lives.
-            float* bufA = c->Lt[i];
-            float* bufB = c->tmp;
+            float* bufA = S.Lt[i];
+            float* bufB = S.tmp;
             const float* init;
             if (L.new_octave) {
                 const AkzLevel& Lp = P.levels[i - 1];
                 float* half_dst = (nsteps % 2 == 0) ? bufA : bufB;  // step 0 must not write where it reads
                 if (nsteps == 0) half_dst = bufA;
-                AKZ_TRY(akz_dev_half_size(s, c->Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
+                AKZ_TRY(akz_dev_half_size(s, S.Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
                 init = half_dst;
             } else {
-                init = c->Lt[i - 1];  // lib.rs:230 clone(): read in place, never modified again
+                init = S.Lt[i - 1];  // lib.rs:230 clone(): read in place, never modified again
             }
             // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
-            AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, c->Lsm[i], c->Lflow[i], fs,
+            AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,
                                                        (int)L.octave, n)));
             // lib.rs:251-256 — FED cycle
             akz_timer_begin(c, &c->t_fed);
@@ -549,9 +551,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 float half_tau = 0.5f * (float)L.tau[j];
                 if ((L.w & 3) == 0) {
                     hipLaunchKernelGGL(k_fed_step_x4, dim3(akz_div_up(L.w, 256), akz_div_up(L.h, 4), n), dim3(256), 0,
-                                       s, src, c->Lflow[i], dst, L.w, L.h, fs, half_tau);
+                                       s, src, S.Lflow[i], dst, L.w, L.h, fs, half_tau);
                 } else {
-                    hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, c->Lflow[i], dst, L.w,
+                    hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, S.Lflow[i], dst, L.w,
                                        L.h, fs, half_tau);
                 }
                 AKZ_LAUNCH_CHECK();
@@ -562,14 +564,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             fed_units += (uint64_t)nsteps * fs * n;
             if (nsteps == 0 && init != bufA)
                 AKZ_HIP(hipMemcpyAsync(bufA, init, sizeof(float) * fs * n, hipMemcpyDeviceToDevice, s));
-            smooth = c->Lsm[i];
+            smooth = S.Lsm[i];
         }
         // detector_response.rs:60-67 + :33-57
         OffK k = make_offk(L.deriv_sigma);
-        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, c->Lxy[i], L.w, L.h, fs,
+        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
                            (int)L.deriv_sigma, k);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, c->Lxy[i], c->Ldet[i], L.w, L.h, fs,
+        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,
                            (int)L.deriv_sigma, k, L.sigma_quat);
         AKZ_LAUNCH_CHECK();
     }
