@@ -111,6 +111,7 @@ def main():
     from cv_amd import _lib
     from cv_amd.akaze import Akaze
     from cv_amd.knn import Matcher, RULE_STRICT
+    from cv_amd.sharding import exchange_predecessors
     L = _lib.lib()
 
     NF, MB = args.frames, min(args.micro_batch, args.frames)
@@ -131,16 +132,16 @@ def main():
     # predecessor descriptor blocks: prev[j] = descriptors of global frame g-1 for local frame j
     prev_descs = torch.zeros((NF, CAP, 64), dtype=torch.uint8, device=dev) if world > 1 else None
     prev_counts = torch.zeros((NF,), dtype=torch.int32, device=dev) if world > 1 else None
-    pairs = torch.zeros((NF, CAP, 2), dtype=torch.int32, device=dev)
-    npairs = torch.zeros((NF,), dtype=torch.int32, device=dev)
+    pairs = torch.zeros((NF + 2, CAP, 2), dtype=torch.int32, device=dev)   # +2: a micro-batch can carry mb+1 pairs
+    npairs = torch.zeros((NF + 2,), dtype=torch.int32, device=dev)
     if world > 1:
         gath_d = torch.zeros((world, MB, CAP, 64), dtype=torch.uint8, device=dev)
         gath_n = torch.zeros((world, MB), dtype=torch.int32, device=dev)
-    ia = (C.c_uint32 * NF)(*range(NF))
-    if world == 1:
-        ib = (C.c_uint32 * NF)(*[(j - 1) % NF for j in range(NF)])   # frame 0 pairs with the batch's last frame
-    else:
-        ib = (C.c_uint32 * NF)(*range(NF))
+    # match problems are issued per micro-batch so the VALU-bound matcher of micro-batch m overlaps the
+    # HBM-bound scale space of micro-batch m+1: frame j pairs with frame j-1; frame 0 pairs with the step's
+    # last frame once that exists.
+    def idx(vals):
+        return (C.c_uint32 * len(vals))(*vals)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -148,29 +149,21 @@ def main():
             _lib.check(L.akz_extract_batch_device(
                 ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps[m0:m0 + MB].data_ptr(),
                 descs[m0:m0 + MB].data_ptr(), CAP, counts[m0:m0 + MB].data_ptr(), cur.cuda_stream), "extract")
+            js = [j for j in range(m0, m0 + MB) if j > 0]
+            if m0 + MB == NF:
+                js.append(0)
             if world > 1:
                 cur.wait_stream(akz_stream)
-                dist.all_gather_into_tensor(gath_d.view(-1), descs[m0:m0 + MB].reshape(-1))
-                dist.all_gather_into_tensor(gath_n.view(-1), counts[m0:m0 + MB])
-                if rank > 0:
-                    prev_descs[m0:m0 + MB].copy_(gath_d[rank - 1])
-                    prev_counts[m0:m0 + MB].copy_(gath_n[rank - 1])
-                else:  # predecessor of global frame j*world is local frame j-1 of the last rank
-                    prev_descs[m0 + 1:m0 + MB].copy_(gath_d[world - 1, :MB - 1])
-                    prev_counts[m0 + 1:m0 + MB].copy_(gath_n[world - 1, :MB - 1])
-                    if m0 + MB < NF:
-                        prev_descs[m0 + MB].copy_(gath_d[world - 1, MB - 1])
-                        prev_counts[m0 + MB].copy_(gath_n[world - 1, MB - 1])
-                    else:   # wrap: the step's first frame pairs with the step's last global frame
-                        prev_descs[0].copy_(gath_d[world - 1, MB - 1])
-                        prev_counts[0].copy_(gath_n[world - 1, MB - 1])
-        if world == 1:
-            tb, nb, wait = descs, counts, akz_stream
-        else:
-            tb, nb, wait = prev_descs, prev_counts, cur
-        _lib.check(L.hm_match_batch_device(
-            matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib, NF,
-            RULE_STRICT, 24, 0.0, 1, pairs.data_ptr(), npairs.data_ptr(), wait.cuda_stream), "match")
+                js = exchange_predecessors(dist, rank, world, m0, MB, NF, descs[m0:m0 + MB], counts[m0:m0 + MB],
+                                           gath_d, gath_n, prev_descs, prev_counts)
+                ia, ib, tb, nb, wait = idx(js), idx(js), prev_descs, prev_counts, cur
+            else:
+                ia, ib, tb, nb, wait = idx(js), idx([(j - 1) % NF for j in js]), descs, counts, akz_stream
+            # problem p writes pairs/npairs block p of the view starting at js[0]'s slot; keep them per frame
+            _lib.check(L.hm_match_batch_device(
+                matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib,
+                len(js), RULE_STRICT, 24, 0.0, 1, pairs[m0:].data_ptr(), npairs[m0:].data_ptr(), wait.cuda_stream),
+                "match")
         cur.wait_stream(hm_stream)
         cur.wait_stream(akz_stream)
 
@@ -200,7 +193,7 @@ def main():
     ctx.timing_enable(False)
 
     n_kp = counts.float().mean().item()
-    n_match = npairs.float().mean().item()
+    n_match = npairs[:NF].float().mean().item()
     if rank == 0:
         total_frames = NF * world * args.steps
         fps = total_frames / elapsed

@@ -130,7 +130,7 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     c->max_batch = max_batch;
     c->max_kp = max_keypoints ? max_keypoints : 16384u;
     if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
-    c->max_cand = c->max_kp * 4u;
+    c->max_cand = c->max_kp;  // per (frame, level) candidate capacity; k_cand_sort keeps one list in LDS
     const char* keep = getenv("AKZ_KEEP_ALL");
     c->keep_all = keep && keep[0] == '1';
     int32_t st = AKZ_OK;
@@ -231,8 +231,8 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     size_t max_rows = (size_t)c->max_h * 2 * (size_t)c->cfg.num_sublevels + 64;
     if (rows > max_rows) max_rows = rows;
     S.d_rowcount = cv.take<uint32_t>(B * max_rows);
-    S.d_ncand = cv.take<uint32_t>(B);
-    S.d_cand = cv.take<uint2>(B * c->max_cand);
+    S.d_ncand = cv.take<uint32_t>(B * 32);
+    S.d_cand = cv.take<uint2>(B * 32 * (size_t)c->max_cand);
     const size_t K = c->max_kp;
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);

@@ -30,8 +30,8 @@ struct AkzSet {
     float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
     // keypoint stage
     uint32_t* d_rowcount = nullptr;        // [B][total_rows+1] candidate count per pyramid row, then offsets
-    uint32_t* d_ncand = nullptr;           // [B]
-    uint2* d_cand = nullptr;               // [B][max_cand] {packed x|y|level, response bits}
+    uint32_t* d_ncand = nullptr;           // [B][32] candidates per (frame, level)
+    uint2* d_cand = nullptr;               // [B][32][max_cand] {x | y << 16, response bits}, raster-sorted per level
     DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
     uint32_t* d_ncache = nullptr;          // [B]
     DevKp* d_kp_a = nullptr;               // [B][max_kp]  stage-0 list (find_scale_space_extrema output)
@@ -55,7 +55,7 @@ struct akz_ctx {
     hipStream_t stream = nullptr;
     int max_w = 0, max_h = 0, max_batch = 0;
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
-    uint32_t max_cand = 0;    // capacity of the per-frame raw candidate list
+    uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
 
     AkzPlan plan;             // for (cur_w, cur_h)

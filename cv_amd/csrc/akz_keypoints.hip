@@ -50,129 +50,8 @@ struct LevelTable {
     uint32_t total_rows;
 };
 
-// ---------------------------------------------------------------------------------------------
-// A12a: candidate = interior pixel with Ldet > threshold and strictly greater than its 8 neighbours
-// (scale_space_extrema.rs:50-59).
-__device__ __forceinline__ bool is_candidate(const float* D, int w, int x, int y, float thr, float* val)
-{
-    const float* p = D + (size_t)y * w + x;
-    float v = p[0];
-    *val = v;
-    return v > thr && v > p[-w - 1] && v > p[-w] && v > p[-w + 1] && v > p[-1] && v > p[1] && v > p[w - 1] &&
-           v > p[w] && v > p[w + 1];
-}
-
-// Border test of scale_space_extrema.rs:96-104.  In the reference it runs after the cache scan, but a
-// candidate that fails it neither pushes nor replaces anything (:105), whatever the scan found, so it
-// can be discarded before the serial pass without changing any result.
-__device__ __forceinline__ bool border_ok(const LevelDesc& L, int x, int y)
-{
-    const float smax = 10.0f * sqrtf(2.0f);
-    const float ratio = ldexpf(1.0f, (int)L.octave);
-    const float sigma_size = roundf(L.kp_size / ratio);
-    const float px = (float)x, py = (float)y;
-    float left_x = roundf(px - smax * sigma_size) - 1.0f;
-    float right_x = roundf(px + smax * sigma_size) + 1.0f;
-    float up_y = roundf(py - smax * sigma_size) - 1.0f;
-    float down_y = roundf(py + smax * sigma_size) + 1.0f;
-    bool is_out = left_x < 0.0f || right_x >= (float)L.w || up_y < 0.0f || down_y >= (float)L.h;
-    return !is_out;
-}
-
-// one block per (row, frame): count candidates of the row
-__global__ __launch_bounds__(256) void k_cand_count(LevelDesc L, float thr, uint32_t* __restrict__ rowcount,
-                                                    uint32_t rows_stride)
-{
-    __shared__ uint32_t s_cnt;
-    int y = blockIdx.x + 1;  // rows 1..h-2
-    int frame = blockIdx.y;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const float* D = L.Ldet + (size_t)frame * L.fs;
-    uint32_t local = 0;
-    for (int x = 1 + threadIdx.x; x < L.w - 1; x += 256) {
-        float v;
-        if (is_candidate(D, L.w, x, y, thr, &v) && border_ok(L, x, y)) local++;
-    }
-    unsigned long long b = __ballot(local != 0);
-    if (b) {  // rare
-        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-        if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s_cnt, local);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) rowcount[(size_t)frame * rows_stride + L.row_base + y] = s_cnt;
-}
-
-// exclusive scan over the per-frame row table (all levels, level-major): one block per frame.
-__global__ __launch_bounds__(1024) void k_row_scan(uint32_t* __restrict__ rowcount, uint32_t rows_stride,
-                                                   uint32_t total_rows, uint32_t* __restrict__ ncand)
-{
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    uint32_t* rc = rowcount + (size_t)blockIdx.x * rows_stride;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < total_rows; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < total_rows ? rc[i] : 0;
-        uint32_t incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(incl, off);
-            if ((int)(threadIdx.x & 63) >= off) incl += t;
-        }
-        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) wave_off += s_wave[wv];
-        uint32_t carry = s_carry;
-        if (i < total_rows) rc[i] = carry + wave_off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        rc[total_rows] = s_carry;
-        ncand[blockIdx.x] = s_carry;
-    }
-}
-
-// one block per (row, frame): write the row's candidates at their raster-ordered slots.
-__global__ __launch_bounds__(256) void k_cand_scatter(LevelDesc L, float thr, const uint32_t* __restrict__ rowoff,
-                                                      uint32_t rows_stride, uint2* __restrict__ cand,
-                                                      uint32_t max_cand, uint32_t* __restrict__ err)
-{
-    __shared__ uint32_t s_wave[4];
-    int y = blockIdx.x + 1;
-    int frame = blockIdx.y;
-    const uint32_t* ro = rowoff + (size_t)frame * rows_stride + L.row_base + y;
-    uint32_t base = ro[0];
-    if (ro[1] == base) return;  // empty row (uniform for the block)
-    const float* D = L.Ldet + (size_t)frame * L.fs;
-    uint2* out = cand + (size_t)frame * max_cand;
-    for (int x0 = 1; x0 < L.w - 1; x0 += 256) {
-        int x = x0 + threadIdx.x;
-        float v = 0.0f;
-        bool hit = x < L.w - 1 && is_candidate(D, L.w, x, y, thr, &v) && border_ok(L, x, y);
-        unsigned long long b = __ballot(hit);
-        int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(b);
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (int i = 0; i < 4; ++i) {
-            if (i < wv) woff += s_wave[i];
-            tot += s_wave[i];
-        }
-        if (hit) {
-            uint32_t slot = base + woff + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-            if (slot < max_cand)
-                out[slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
-            else
-                *err = 1u;
-        }
-        base += tot;
-        __syncthreads();
-    }
-}
+// A12a (candidate test + border test) is fused into the second-order derivative kernel and followed by a
+// per-level raster sort: k_deriv_second_cand / k_cand_sort in akz_scale_space.hip.
 
 // ---------------------------------------------------------------------------------------------
 // A12b: the order-dependent suppression pass (scale_space_extrema.rs:61-118).  ONE WAVE per frame, no
@@ -203,9 +82,9 @@ __device__ __forceinline__ float rl_f(float v, uint32_t l)
 }
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
-__global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* __restrict__ rowoff,
-                                                 uint32_t rows_stride, const uint2* __restrict__ cand,
-                                                 uint32_t max_cand, DevKp* __restrict__ cache, uint32_t max_kp,
+__global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* __restrict__ ncand,
+                                                 const uint2* __restrict__ cand, uint32_t max_cand,
+                                                 DevKp* __restrict__ cache, uint32_t max_kp,
                                                  uint32_t* __restrict__ ncache, uint32_t* __restrict__ err)
 {
     // LDS: the active list only.  A single wave executes its DS instructions in order, so a ds_write by
@@ -216,14 +95,11 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
     ActEntry* act = reinterpret_cast<ActEntry*>(smem);
     const int frame = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    const uint32_t* ro = rowoff + (size_t)frame * rows_stride;
-    const uint2* cd = cand + (size_t)frame * max_cand;
+    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
     uint32_t nact = 0, nslots = 0;  // wave-uniform
     // chunk bounds live in registers: lane l holds [ymin, ymax] of chunks l and l + 64
     float bmin0 = 3.0e38f, bmax0 = -3.0e38f, bmin1 = 3.0e38f, bmax1 = -3.0e38f;
-    uint32_t total = ro[T.total_rows];
-    if (total > max_cand) total = max_cand;  // overflow already flagged by k_cand_scatter
     for (int e = 0; e < T.n; ++e) {
         const LevelDesc& L = T.L[e];
         // ---- level change: keep only class e-1 entries (class e-2 can no longer match), in order ----
@@ -265,9 +141,9 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
         const float size = L.kp_size;
         const float size2 = size * size;
         const float margin = size * 1.001f + 0.01f;  // conservative: |dy| > margin  =>  dist > size^2
-        uint32_t c_begin = ro[L.row_base], c_end = ro[L.row_base + L.h];
-        if (c_begin > total) c_begin = total;
-        if (c_end > total) c_end = total;
+        // this level's raster-sorted candidates (overflow beyond the capacity was flagged by the producer)
+        const uint32_t c_begin = (uint32_t)e * max_cand;
+        const uint32_t c_end = c_begin + min(ncand[(size_t)frame * 32 + e], max_cand);
         for (uint32_t cb = c_begin; cb < c_end; cb += 64) {
             // one coalesced load of the next 64 candidates, then broadcast lane by lane
             uint2 mine = (cb + lane < c_end) ? cd[cb + lane] : make_uint2(0u, 0u);
@@ -352,48 +228,53 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
 }
 
 // second pass (scale_space_extrema.rs:121-140): drop i if a LATER cache entry of class i+1 lies within
-// size_i and has response >= response_i.  Block per (chunk of i, frame); j streamed through LDS.
+// size_i and has response >= response_i.  Thread per entry i.  Entries of one class sit (apart from
+// slots replaced in place) in one contiguous run of the cache, so every block first finds, per class,
+// the [first, last] slot holding that class and thread i only walks max(i+1, first[c+1]) .. last[c+1]:
+// about two levels' worth of slots instead of the whole tail.  Neighbouring threads walk nearly the
+// same range, so their loads coalesce into broadcasts.
 __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ cache, uint32_t max_kp,
                                                       const uint32_t* __restrict__ ncache,
                                                       uint32_t* __restrict__ flag)
 {
-    __shared__ float4 s_j[256];  // x, y, resp, class
+    __shared__ uint32_t s_lo[kMaxLevels + 1], s_hi[kMaxLevels + 1];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
     const uint32_t i0 = blockIdx.x * 256;
     if (i0 >= n) return;
     const DevKp* ch = cache + (size_t)frame * max_kp;
+    if (threadIdx.x <= kMaxLevels) {
+        s_lo[threadIdx.x] = 0xFFFFFFFFu;
+        s_hi[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t j = i0 + threadIdx.x; j < n; j += 256) {  // only slots > i0 matter to this block
+        uint32_t c = min(ch[j].class_id, (uint32_t)kMaxLevels);
+        atomicMin(&s_lo[c], j);
+        atomicMax(&s_hi[c], j);
+    }
+    __syncthreads();
     const uint32_t i = i0 + threadIdx.x;
-    DevKp ki;
-    bool valid = i < n;
-    if (valid) ki = ch[i];
+    if (i >= n) return;
+    const DevKp ki = ch[i];
+    const uint32_t cn = min(ki.class_id + 1u, (uint32_t)kMaxLevels);
     bool rep = false;
-    for (uint32_t j0 = i0; j0 < n; j0 += 256) {
-        uint32_t j = j0 + threadIdx.x;
-        if (j < n) {
-            DevKp kj = ch[j];
-            s_j[threadIdx.x] = make_float4(kj.x, kj.y, kj.response, __uint_as_float(kj.class_id));
-        }
-        __syncthreads();
-        if (valid && !rep) {
-            uint32_t cnt = min(256u, n - j0);
-            for (uint32_t t = 0; t < cnt; ++t) {
-                uint32_t jj = j0 + t;
-                if (jj <= i) continue;
-                float4 q = s_j[t];
-                if (ki.class_id + 1u == __float_as_uint(q.w)) {
-                    float dx = ki.x - q.x, dy = ki.y - q.y;
-                    float dist = dx * dx + dy * dy;
-                    if (dist <= ki.size * ki.size && ki.response <= q.z) {
-                        rep = true;
-                        break;
-                    }
+    if (s_lo[cn] != 0xFFFFFFFFu) {
+        const uint32_t jb = max(i + 1u, s_lo[cn]), je = s_hi[cn];
+        const float size2 = ki.size * ki.size;
+        for (uint32_t j = jb; j <= je; ++j) {
+            const DevKp kj = ch[j];
+            if (kj.class_id == ki.class_id + 1u) {
+                float dx = ki.x - kj.x, dy = ki.y - kj.y;
+                float dist = dx * dx + dy * dy;
+                if (dist <= size2 && ki.response <= kj.response) {
+                    rep = true;
+                    break;
                 }
             }
         }
-        __syncthreads();
     }
-    if (valid) flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
+    flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
 }
 
 // ordered compaction of a per-frame keypoint list (and optionally its descriptors): block per frame.
@@ -944,8 +825,6 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     LevelTable T;
     if ((int)P.levels.size() > kMaxLevels) return AKZ_E_INVALID;
     build_level_table(c, &T);
-    const uint32_t rows_stride = (uint32_t)P.total_rows + 1;
-    const float thr = (float)c->cfg.detector_threshold;
     if (T.n == 0) {
         AKZ_HIP(hipMemsetAsync(d_n_out, 0, sizeof(uint32_t) * n, s));
         AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
@@ -954,30 +833,13 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         c->kp_pending[c->cur] = true;
         return AKZ_OK;
     }
-    // A12a: ordered candidate lists
-    AKZ_HIP(hipMemsetAsync(S.d_rowcount, 0, sizeof(uint32_t) * (size_t)rows_stride * n, s));
-    for (int i = 0; i < T.n; ++i) {
-        if (T.L[i].h < 3 || T.L[i].w < 3) continue;
-        hipLaunchKernelGGL(k_cand_count, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, S.d_rowcount,
-                           rows_stride);
-        AKZ_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_row_scan, dim3(n), dim3(1024), 0, s, S.d_rowcount, rows_stride, T.total_rows, S.d_ncand);
-    AKZ_LAUNCH_CHECK();
-    for (int i = 0; i < T.n; ++i) {
-        if (T.L[i].h < 3 || T.L[i].w < 3) continue;
-        hipLaunchKernelGGL(k_cand_scatter, dim3(T.L[i].h - 2, n), dim3(256), 0, s, T.L[i], thr, S.d_rowcount,
-                           rows_stride, S.d_cand, c->max_cand, c->d_err);
-        AKZ_LAUNCH_CHECK();
-    }
     // ---- hand over to the keypoint stream: everything below is latency-bound per-frame work that overlaps
     // the next micro-batch's scale space ----
     AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
     s = c->stream_kp;
     AKZ_HIP(hipStreamWaitEvent(s, c->ev_ss_done[c->cur], 0));
     // A12b
-    hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T,
-                       S.d_rowcount, rows_stride,
+    hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T, S.d_ncand,
                        S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err);
     AKZ_LAUNCH_CHECK();
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);

@@ -381,6 +381,118 @@ __global__ __launch_bounds__(256) void k_deriv_second(const float2* __restrict__
     Ldet[(size_t)blockIdx.z * fs + r0 + x] = (lxx * lyy - lxy * lxy) * sigma_quat;
 }
 
+// Fused second-order pass + extrema candidates (detector_response.rs:65-67,:46 and
+// scale_space_extrema.rs:34-60,96-104).  A block produces a 64x16 tile of Ldet plus a one-pixel ring
+// (kept in LDS only), writes the tile, and tests every interior pixel against the threshold and its 8
+// neighbours straight from LDS — Ldet is never re-read from HBM for detection.  Candidates that also pass
+// the border test are appended to the frame's per-level list in arbitrary order; k_cand_sort restores
+// the reference's raster order afterwards.
+struct CandParams {
+    float thr;         // detector_threshold as f32
+    float border;      // smax * sigma_size  (scale_space_extrema.rs:97-100)
+    uint32_t level;
+    uint32_t cap;      // per-level capacity of the candidate list
+};
+
+__global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
+                                                           int w, int h, size_t fs, int s, OffK k, float sigma_quat,
+                                                           CandParams cp, uint2* __restrict__ cand,
+                                                           uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
+{
+    constexpr int TW = 64, TH = 16, GW = TW + 2, GH = TH + 2;
+    __shared__ float s_d[GH * GW];
+    const int frame = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const float2* D = Lxy + (size_t)frame * fs;
+    for (int idx = threadIdx.x; idx < GH * GW; idx += 256) {
+        int q = idx / GW, p = idx - q * GW;
+        int x = tx0 - 1 + p, y = ty0 - 1 + q;
+        float v = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+            int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
+            size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
+            float2 mm = D[rm + xm], m0 = D[rm + x], mp = D[rm + xp];
+            float2 zm = D[r0 + xm], zp = D[r0 + xp];
+            float2 pm = D[rp + xm], p0 = D[rp + x], pp = D[rp + xp];
+            float lxx = off_combine(k, mp.x - mm.x, zp.x - zm.x, pp.x - pm.x);
+            float lxy = off_combine(k, pm.x, p0.x, pp.x) - off_combine(k, mm.x, m0.x, mp.x);
+            float lyy = off_combine(k, pm.y, p0.y, pp.y) - off_combine(k, mm.y, m0.y, mp.y);
+            v = (lxx * lyy - lxy * lxy) * sigma_quat;
+            if (p >= 1 && p <= TW && q >= 1 && q <= TH) Ldet[(size_t)frame * fs + r0 + x] = v;
+        }
+        s_d[idx] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TH * TW; idx += 256) {
+        int q = idx / TW, p = idx - q * TW;
+        int x = tx0 + p, y = ty0 + q;
+        if (x < 1 || x > w - 2 || y < 1 || y > h - 2) continue;  // interior pixels only (:50)
+        const float* c = &s_d[(q + 1) * GW + (p + 1)];
+        float v = c[0];
+        bool is_cand = v > cp.thr && v > c[-GW - 1] && v > c[-GW] && v > c[-GW + 1] && v > c[-1] && v > c[1] &&
+                       v > c[GW - 1] && v > c[GW] && v > c[GW + 1];
+        if (!is_cand) continue;
+        // border test (:96-104); a candidate failing it can neither push nor replace (:105)
+        const float px = (float)x, py = (float)y;
+        float left_x = roundf(px - cp.border) - 1.0f;
+        float right_x = roundf(px + cp.border) + 1.0f;
+        float up_y = roundf(py - cp.border) - 1.0f;
+        float down_y = roundf(py + cp.border) + 1.0f;
+        bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
+        if (is_out) continue;
+        uint32_t slot = atomicAdd(&ncand[(size_t)frame * 32 + cp.level], 1u);
+        if (slot < cp.cap)
+            cand[((size_t)frame * 32 + cp.level) * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
+        else
+            *err = 1u;
+    }
+}
+
+// Restore raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
+// (y << 48 | x << 32 | response bits) in LDS; (x, y) is unique so the order is total.
+__global__ __launch_bounds__(1024) void k_cand_sort(uint2* __restrict__ cand, const uint32_t* __restrict__ ncand,
+                                                    uint32_t cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    const uint32_t level = blockIdx.x, frame = blockIdx.y;
+    const uint32_t n = min(ncand[(size_t)frame * 32 + level], cap);
+    if (n < 2) return;
+    uint2* seg = cand + ((size_t)frame * 32 + level) * cap;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+        unsigned long long kk = ~0ull;
+        if (i < n) {
+            uint2 c = seg[i];
+            uint32_t yx = ((c.x >> 16) << 16) | (c.x & 0xFFFFu);  // y in the high half: raster order
+            kk = ((unsigned long long)yx << 32) | (unsigned long long)c.y;
+        }
+        key[i] = kk;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = key[i], b = key[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        unsigned long long kk = key[i];
+        seg[i] = make_uint2((uint32_t)(kk >> 32), (uint32_t)kk);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_deinterleave(const float2* __restrict__ in, float* __restrict__ out, size_t n,
                                                       int component)
 {
@@ -514,6 +626,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
     AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
+    AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * 32 * (size_t)n, s));
     AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
     AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
     hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
@@ -571,8 +684,27 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
                            (int)L.deriv_sigma, k);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_deriv_second, grid_px(L.w, L.h, n), dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,
-                           (int)L.deriv_sigma, k, L.sigma_quat);
+        {
+            // sigma_size = round(size / ratio) in f32 and smax = 10*sqrt(2) in f32 (scale_space_extrema.rs:16,69-70)
+            const float ratio = ldexpf(1.0f, (int)L.octave);
+            const float sigma_size = roundf(L.kp_size / ratio);
+            const float smax = 10.0f * sqrtf(2.0f);
+            CandParams cp;
+            cp.thr = (float)c->cfg.detector_threshold;
+            cp.border = smax * sigma_size;
+            cp.level = (uint32_t)i;
+            cp.cap = c->max_cand;
+            hipLaunchKernelGGL(k_deriv_second_cand, dim3(akz_div_up(L.w, 64), akz_div_up(L.h, 16), n), dim3(256), 0, s,
+                               S.Lxy[i], S.Ldet[i], L.w, L.h, fs, (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand,
+                               S.d_ncand, c->d_err);
+            AKZ_LAUNCH_CHECK();
+        }
+    }
+    {
+        uint32_t np2 = 1;
+        while (np2 < c->max_cand) np2 <<= 1;
+        hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * np2, s, S.d_cand,
+                           S.d_ncand, c->max_cand);
         AKZ_LAUNCH_CHECK();
     }
     akz_timer_end(c, &c->t_ss, 0, (uint64_t)n);
