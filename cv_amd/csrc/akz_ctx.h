@@ -56,6 +56,7 @@ struct akz_ctx {
     int max_w = 0, max_h = 0, max_batch = 0;
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
     uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
+    int fed_block = 4;        // FED steps fused per launch (1 = one launch per step); env AKZ_FED_BLOCK
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
 
     AkzPlan plan;             // for (cur_w, cur_h)

@@ -316,6 +316,108 @@ __global__ __launch_bounds__(256) void k_fed_step_x4(const float* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Temporally blocked FED: T (<= 4) consecutive calculate_step()s per launch.  A block owns a 64x32 output
+// tile; it stages the tile plus a halo (4 columns, T rows each side) of L and c in LDS once, runs the T
+// Jacobi steps LDS -> LDS (ping-pong), and writes the tile once.  Per pixel the arithmetic of every step is
+// exactly that of k_fed_step (same expression order, same border rules by GLOBAL coordinates); halo pixels
+// are recomputed redundantly by neighbouring blocks, and a value at distance d from the staged region's
+// edge is exact after step t whenever d >= t, which holds for the tile itself at t = T.
+// HBM traffic per pixel for T steps: ~1.4 x 8 B read + 4 B write, instead of T x 12 B.
+struct FedTaus {
+    float half_tau[4];
+};
+
+template <int T>
+__global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src, const float* __restrict__ cnd,
+                                                   float* __restrict__ dst, int w, int h, size_t fs, FedTaus taus)
+{
+    constexpr int TW = 64, TH = 32, HX = 4;
+    constexpr int LW = TW + 2 * HX;   // 72 floats per LDS row (16-byte aligned segments)
+    constexpr int ROWS = TH + 2 * T;
+    constexpr int SEGS = LW / 4;      // 18
+    __shared__ __attribute__((aligned(16))) float sL[2][ROWS * LW];
+    __shared__ __attribute__((aligned(16))) float sC[ROWS * LW];
+    const int frame = blockIdx.z;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const float* L = src + (size_t)frame * fs;
+    const float* C = cnd + (size_t)frame * fs;
+    // stage (w % 4 == 0 and tx0 % 4 == 0: a 4-pixel segment is entirely inside or outside the image)
+    for (int sidx = threadIdx.x; sidx < ROWS * SEGS; sidx += 256) {
+        int row = sidx / SEGS, c4 = (sidx - row * SEGS) * 4;
+        int gx = tx0 - HX + c4, gy = ty0 - T + row;
+        float4 l = make_float4(0.f, 0.f, 0.f, 0.f), c = l;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+            l = *reinterpret_cast<const float4*>(L + (size_t)gy * w + gx);
+            c = *reinterpret_cast<const float4*>(C + (size_t)gy * w + gx);
+        }
+        *reinterpret_cast<float4*>(&sL[0][row * LW + c4]) = l;
+        *reinterpret_cast<float4*>(&sC[row * LW + c4]) = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float half_tau = taus.half_tau[t];
+        const float* in = sL[t & 1];
+        float* out = sL[(t + 1) & 1];
+        for (int sidx = threadIdx.x; sidx < (ROWS - 2) * SEGS; sidx += 256) {
+            int row = sidx / SEGS + 1, c4 = (sidx - (row - 1) * SEGS) * 4;
+            int gx = tx0 - HX + c4, gy = ty0 - T + row;
+            if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+            const float* lp = in + row * LW + c4;
+            const float* cp = sC + row * LW + c4;
+            float4 l = *reinterpret_cast<const float4*>(lp);
+            float4 cc = *reinterpret_cast<const float4*>(cp);
+            float lv[6], cv[6];
+            lv[1] = l.x; lv[2] = l.y; lv[3] = l.z; lv[4] = l.w;
+            cv[1] = cc.x; cv[2] = cc.y; cv[3] = cc.z; cv[4] = cc.w;
+            const bool has_l = gx > 0, has_r = gx + 4 < w;
+            lv[0] = (c4 > 0) ? lp[-1] : 0.0f;
+            cv[0] = (c4 > 0) ? cp[-1] : 0.0f;
+            lv[5] = (c4 + 4 < LW) ? lp[4] : 0.0f;
+            cv[5] = (c4 + 4 < LW) ? cp[4] : 0.0f;
+            float hf[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) hf[i] = fed_flow(half_tau, cv[i], cv[i + 1], lv[i], lv[i + 1]);
+            float r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = lv[i + 1];
+                if (i < 3 || has_r) v = v + hf[i + 1];
+                if (i > 0 || has_l) v = v - hf[i];
+                r[i] = v;
+            }
+            if (gy < h - 1) {
+                float4 ld = *reinterpret_cast<const float4*>(lp + LW);
+                float4 cd = *reinterpret_cast<const float4*>(cp + LW);
+                r[0] = r[0] + fed_flow(half_tau, cc.x, cd.x, l.x, ld.x);
+                r[1] = r[1] + fed_flow(half_tau, cc.y, cd.y, l.y, ld.y);
+                r[2] = r[2] + fed_flow(half_tau, cc.z, cd.z, l.z, ld.z);
+                r[3] = r[3] + fed_flow(half_tau, cc.w, cd.w, l.w, ld.w);
+            }
+            if (gy > 0) {
+                float4 lu = *reinterpret_cast<const float4*>(lp - LW);
+                float4 cu = *reinterpret_cast<const float4*>(cp - LW);
+                r[0] = r[0] - fed_flow(half_tau, cu.x, cc.x, lu.x, l.x);
+                r[1] = r[1] - fed_flow(half_tau, cu.y, cc.y, lu.y, l.y);
+                r[2] = r[2] - fed_flow(half_tau, cu.z, cc.z, lu.z, l.z);
+                r[3] = r[3] - fed_flow(half_tau, cu.w, cc.w, lu.w, l.w);
+            }
+            *reinterpret_cast<float4*>(out + row * LW + c4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+    }
+    const float* fin = sL[T & 1];
+    float* D = dst + (size_t)frame * fs;
+    for (int sidx = threadIdx.x; sidx < TH * (TW / 4); sidx += 256) {
+        int q = sidx / (TW / 4), p4 = (sidx - q * (TW / 4)) * 4;
+        int gx = tx0 + p4, gy = ty0 + q;
+        if (gx < w && gy < h)
+            *reinterpret_cast<float4*>(D + (size_t)gy * w + gx) =
+                *reinterpret_cast<const float4*>(fin + (q + T) * LW + HX + p4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
 // {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
 // {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
@@ -643,11 +745,15 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // Ping-pong so the last FED step lands in Lt[i]; `init` is where the un-diffused Lt[i] lives.
             float* bufA = S.Lt[i];
             float* bufB = S.tmp;
+            const bool blocked = (L.w & 3) == 0 && c->fed_block > 1;
+            const int nwrites = blocked ? (nsteps + c->fed_block - 1) / c->fed_block : nsteps;  // FED launches
             const float* init;
             if (L.new_octave) {
                 const AkzLevel& Lp = P.levels[i - 1];
-                float* half_dst = (nsteps % 2 == 0) ? bufA : bufB;  // step 0 must not write where it reads
-                if (nsteps == 0) half_dst = bufA;
+                // the first FED launch must not write where it reads: with an odd number of launches the
+                // first one writes Lt[i], so the half-sized image goes to the scratch plane, and vice versa
+                float* half_dst = (nwrites % 2 == 0) ? bufA : bufB;
+                if (nwrites == 0) half_dst = bufA;
                 AKZ_TRY(akz_dev_half_size(s, S.Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
                 init = half_dst;
             } else {
@@ -659,6 +765,34 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // lib.rs:251-256 — FED cycle
             akz_timer_begin(c, &c->t_fed);
             const float* src = init;
+            if (blocked) {
+                // temporally blocked: groups of up to fed_block steps per launch; the ping-pong parity is
+                // chosen per GROUP so that the last group lands in Lt[i]
+                std::vector<int> groups;
+                for (int left = nsteps; left > 0;) {
+                    int ngr = (left + c->fed_block - 1) / c->fed_block;  // groups still to emit
+                    int g = (left + ngr - 1) / ngr;                      // balanced sizes, e.g. 5 -> 3+2
+                    groups.push_back(g);
+                    left -= g;
+                }
+                const int ng = (int)groups.size();  // == nwrites
+                int j = 0;
+                for (int gi = 0; gi < ng; ++gi) {
+                    float* dstb = ((ng - 1 - gi) % 2 == 0) ? bufA : bufB;
+                    FedTaus ft;
+                    for (int q = 0; q < 4; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
+                    dim3 grid(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
+                    switch (groups[gi]) {
+                    case 1: hipLaunchKernelGGL((k_fed_multi<1>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
+                    case 2: hipLaunchKernelGGL((k_fed_multi<2>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
+                    case 3: hipLaunchKernelGGL((k_fed_multi<3>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
+                    default: hipLaunchKernelGGL((k_fed_multi<4>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
+                    }
+                    AKZ_LAUNCH_CHECK();
+                    j += groups[gi];
+                    src = dstb;
+                }
+            } else
             for (int j = 0; j < nsteps; ++j) {
                 float* dst = ((nsteps - 1 - j) % 2 == 0) ? bufA : bufB;
                 float half_tau = 0.5f * (float)L.tau[j];
@@ -672,7 +806,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 AKZ_LAUNCH_CHECK();
                 src = dst;
             }
-            akz_timer_end(c, &c->t_fed, (uint64_t)nsteps, (uint64_t)nsteps * fs * n);
+            akz_timer_end(c, &c->t_fed, (uint64_t)nwrites, (uint64_t)nsteps * fs * n);
             fed_launches += nsteps;
             fed_units += (uint64_t)nsteps * fs * n;
             if (nsteps == 0 && init != bufA)
