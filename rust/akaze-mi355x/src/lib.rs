@@ -1,0 +1,218 @@
+//! `akaze`-compatible front-end over the MI355X library (C ABI declared in `include/akz.h`).
+//!
+//! NOT BUILT in this repository (no Rust toolchain in the build image); kept as the reference-side
+//! binding of INTEGRATION.md.  The public surface is the one rust-cv callers use
+//! (`akaze/src/lib.rs:69-185,295-366` of rust-cv/cv): `Akaze` with its 11 public fields,
+//! `Akaze::{new, sparse, dense, extract, extract_from_gray_float_image, extract_path}` and `KeyPoint`.
+use bitarray::BitArray;
+use cv_core::{nalgebra::Point2, ImagePoint};
+use image::{DynamicImage, ImageResult};
+use std::{os::raw::c_void, path::Path, ptr};
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+struct AkzConfig {
+    maximum_features: u64,
+    num_sublevels: u32,
+    max_octave_evolution: u32,
+    base_scale_offset: f64,
+    initial_contrast: f64,
+    contrast_percentile: f64,
+    contrast_factor_num_bins: u64,
+    derivative_factor: f64,
+    detector_threshold: f64,
+    descriptor_channels: u64,
+    descriptor_pattern_size: u64,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct AkzKeypoint {
+    x: f32,
+    y: f32,
+    response: f32,
+    size: f32,
+    angle: f32,
+    octave: u32,
+    class_id: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AkzNeighbor {
+    pub index: u32,
+    pub distance: u32,
+}
+
+extern "C" {
+    fn akz_create(cfg: *const AkzConfig, device: i32, max_w: i32, max_h: i32, max_batch: i32, max_kp: u32,
+                  out: *mut *mut c_void) -> i32;
+    fn akz_destroy(ctx: *mut c_void) -> i32;
+    fn akz_extract_gray_u8(ctx: *mut c_void, img: *const u8, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
+                           descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
+    fn akz_extract_gray_f32(ctx: *mut c_void, img: *const f32, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
+                            descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
+    fn hm_create(device: i32, max_q: u32, max_t: u32, out: *mut *mut c_void) -> i32;
+    fn hm_destroy(ctx: *mut c_void) -> i32;
+    fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
+}
+
+/// `akaze::KeyPoint` (akaze/src/lib.rs:69-93).
+#[derive(Debug, Clone, Copy)]
+pub struct KeyPoint {
+    pub point: (f32, f32),
+    pub response: f32,
+    pub size: f32,
+    pub octave: usize,
+    pub class_id: usize,
+    pub angle: f32,
+}
+impl ImagePoint for KeyPoint {
+    fn image_point(&self) -> Point2<f64> {
+        Point2::new(self.point.0 as f64, self.point.1 as f64)
+    }
+}
+
+/// `akaze::Akaze` (akaze/src/lib.rs:109-185): same fields, same defaults.
+#[derive(Debug, Copy, Clone)]
+pub struct Akaze {
+    pub maximum_features: usize,
+    pub num_sublevels: u32,
+    pub max_octave_evolution: u32,
+    pub base_scale_offset: f64,
+    pub initial_contrast: f64,
+    pub contrast_percentile: f64,
+    pub contrast_factor_num_bins: usize,
+    pub derivative_factor: f64,
+    pub detector_threshold: f64,
+    pub descriptor_channels: usize,
+    pub descriptor_pattern_size: usize,
+}
+impl Default for Akaze {
+    fn default() -> Akaze {
+        Akaze {
+            maximum_features: usize::MAX,
+            num_sublevels: 4,
+            max_octave_evolution: 4,
+            base_scale_offset: 1.6,
+            initial_contrast: 0.001,
+            contrast_percentile: 0.7,
+            contrast_factor_num_bins: 300,
+            derivative_factor: 1.5,
+            detector_threshold: 0.001,
+            descriptor_channels: 3,
+            descriptor_pattern_size: 10,
+        }
+    }
+}
+
+const MAX_KP: u32 = 16384;
+
+impl Akaze {
+    pub fn new(threshold: f64) -> Self {
+        Self { detector_threshold: threshold, ..Default::default() }
+    }
+    pub fn sparse() -> Self {
+        Self::new(0.01)
+    }
+    pub fn dense() -> Self {
+        Self::new(0.0001)
+    }
+
+    fn config(&self) -> AkzConfig {
+        AkzConfig {
+            maximum_features: self.maximum_features as u64,
+            num_sublevels: self.num_sublevels,
+            max_octave_evolution: self.max_octave_evolution,
+            base_scale_offset: self.base_scale_offset,
+            initial_contrast: self.initial_contrast,
+            contrast_percentile: self.contrast_percentile,
+            contrast_factor_num_bins: self.contrast_factor_num_bins as u64,
+            derivative_factor: self.derivative_factor,
+            detector_threshold: self.detector_threshold,
+            descriptor_channels: self.descriptor_channels as u64,
+            descriptor_pattern_size: self.descriptor_pattern_size as u64,
+        }
+    }
+
+    fn run<F: FnOnce(*mut c_void, *mut AkzKeypoint, *mut [u8; 64], *mut u32) -> i32>(
+        &self, w: u32, h: u32, f: F,
+    ) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
+        // `Akaze` is Copy and stateless in the reference, so the device context is created per call here;
+        // a production shim would cache one context per (config, size) in a thread-local.
+        let cfg = self.config();
+        let mut ctx: *mut c_void = ptr::null_mut();
+        let st = unsafe { akz_create(&cfg, 0, w as i32, h as i32, 1, MAX_KP, &mut ctx) };
+        assert_eq!(st, 0, "akz_create failed with status {st} (there is no CPU fallback)");
+        let mut kps = vec![AkzKeypoint::default(); MAX_KP as usize];
+        let mut descs = vec![[0u8; 64]; MAX_KP as usize];
+        let mut n = 0u32;
+        let st = f(ctx, kps.as_mut_ptr(), descs.as_mut_ptr(), &mut n);
+        unsafe { akz_destroy(ctx) };
+        assert_eq!(st, 0, "akz_extract failed with status {st}");
+        let n = n as usize;
+        let keypoints = kps[..n]
+            .iter()
+            .map(|k| KeyPoint {
+                point: (k.x, k.y),
+                response: k.response,
+                size: k.size,
+                octave: k.octave as usize,
+                class_id: k.class_id as usize,
+                angle: k.angle,
+            })
+            .collect();
+        let descriptors = descs[..n].iter().map(|d| BitArray::new(*d)).collect();
+        (keypoints, descriptors)
+    }
+
+    /// `Akaze::extract` (akaze/src/lib.rs:295).
+    pub fn extract(&self, image: &DynamicImage) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
+        match image.grayscale() {
+            DynamicImage::ImageLuma8(g) => {
+                let (w, h) = (g.width(), g.height());
+                self.run(w, h, |ctx, k, d, n| unsafe {
+                    akz_extract_gray_u8(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
+                })
+            }
+            other => {
+                // remaining arms of GrayFloatImage::from_dynamic (image.rs:57-106): convert on the host
+                let f = other.to_luma32f();
+                let (w, h) = (f.width(), f.height());
+                self.run(w, h, |ctx, k, d, n| unsafe {
+                    akz_extract_gray_f32(ctx, f.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
+                })
+            }
+        }
+    }
+
+    /// `Akaze::extract_path` (akaze/src/lib.rs:361).
+    pub fn extract_path(&self, path: impl AsRef<Path>) -> ImageResult<(Vec<KeyPoint>, Vec<BitArray<64>>)> {
+        Ok(self.extract(&image::open(path)?))
+    }
+}
+
+/// A `space::Knn` implementor with `LinearKnn { metric: Hamming, iter }` semantics for `BitArray<64>`.
+pub struct Mi355xLinearKnn<'a> {
+    pub targets: &'a [BitArray<64>],
+}
+impl<'a> space::Knn for Mi355xLinearKnn<'a> {
+    type Ix = usize;
+    type Metric = bitarray::Hamming;
+    type Point = BitArray<64>;
+    type KnnIter = Vec<space::Neighbor<u32, usize>>;
+    fn knn(&self, query: &BitArray<64>, num: usize) -> Self::KnnIter {
+        assert_eq!(num, 2, "the MI355X matcher implements knn(query, 2)");
+        let mut ctx: *mut c_void = ptr::null_mut();
+        let n = self.targets.len() as u32;
+        assert_eq!(unsafe { hm_create(0, 1, n.max(2), &mut ctx) }, 0);
+        let mut out = [AkzNeighbor { index: 0, distance: 0 }; 2];
+        let st = unsafe {
+            hm_knn2(ctx, query.bytes() as *const [u8; 64], 1, self.targets.as_ptr() as *const [u8; 64], n, out.as_mut_ptr())
+        };
+        unsafe { hm_destroy(ctx) };
+        assert_eq!(st, 0);
+        out.iter().map(|o| space::Neighbor { index: o.index as usize, distance: o.distance }).collect()
+    }
+    fn nn(&self, query: &BitArray<64>) -> Option<space::Neighbor<u32, usize>> {
+        self.knn(query, 2).into_iter().next()
+    }
+}

@@ -1,0 +1,76 @@
+// estimate_pose.cpp — the reference's integration test akaze/tests/estimate_pose.rs:24-59 restated
+// against the C++ host-side mirror (include/akaze.hpp), i.e. through the C ABI of libakz.so:
+//   Akaze::sparse().extract x2 on the two KITTI frames -> exactly 399 and 343 descriptors,
+//   space::LinearKnn{Hamming}.knn(d, 2) + Lowe ratio 0.5 -> exactly 11 matches.
+// (The ARRSAC + eight-point stage of the reference test is the second-phase path, see DESIGN.md.)
+// usage: estimate_pose frame0.raw frame14.raw width height
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "akaze.hpp"
+
+static const float LOWES_RATIO = 0.5f;
+
+static std::vector<uint8_t> read_raw(const char* path, size_t n)
+{
+    std::vector<uint8_t> v(n);
+    FILE* f = fopen(path, "rb");
+    if (!f || fread(v.data(), 1, n, f) != n) {
+        fprintf(stderr, "cannot read %s\n", path);
+        exit(2);
+    }
+    fclose(f);
+    return v;
+}
+
+static std::pair<std::vector<akaze::KeyPoint>, std::vector<akaze::BitArray64>> image_to_kps(const std::vector<uint8_t>& px,
+                                                                                           int w, int h)
+{
+    akaze::Akaze a = akaze::Akaze::sparse();
+    return a.extract(akaze::GrayImageU8{px.data(), w, h, w});
+}
+
+// match_descriptors, estimate_pose.rs:78-97, written against the Knn trait surface
+static std::vector<std::pair<size_t, size_t>> match_descriptors_knn(space::Matcher& m, const std::vector<akaze::BitArray64>& ds1,
+                                                                const std::vector<akaze::BitArray64>& ds2)
+{
+    std::vector<std::pair<size_t, size_t>> out;
+    space::LinearKnn knn(space::Hamming{}, ds2, m);
+    for (size_t ix1 = 0; ix1 < ds1.size(); ++ix1) {
+        auto neighbors = knn.knn(ds1[ix1], 2);
+        if ((float)neighbors[0].distance < (float)neighbors[1].distance * LOWES_RATIO)
+            out.push_back({ix1, neighbors[0].index});
+    }
+    return out;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 5) return 2;
+    int w = atoi(argv[3]), h = atoi(argv[4]);
+    auto f0 = read_raw(argv[1], (size_t)w * h), f1 = read_raw(argv[2], (size_t)w * h);
+    try {
+        auto r1 = image_to_kps(f0, w, h);
+        auto r2 = image_to_kps(f1, w, h);
+        printf("descriptors %zu %zu\n", r1.second.size(), r2.second.size());
+        if (r1.second.size() != 399 || r2.second.size() != 343) return 1;  // estimate_pose.rs:41-42
+        if (r1.first.size() != r1.second.size()) return 1;
+        for (size_t i = 1; i < r1.first.size(); ++i)
+            if (r1.first[i].response > r1.first[i - 1].response) return 1;  // ordered by response (lib.rs:326)
+        space::Matcher m(4096);
+        auto matches = match_descriptors_knn(m, r1.second, r2.second);
+        auto batched = space::match_descriptors(m, r1.second, r2.second, LOWES_RATIO);
+        printf("matches %zu (batched %zu)\n", matches.size(), batched.size());
+        if (matches.size() != 11 || batched.size() != 11) return 1;  // estimate_pose.rs:59
+        for (size_t i = 0; i < 11; ++i)
+            if (matches[i].first != batched[i][0] || matches[i].second != batched[i][1]) return 1;
+        auto sym = space::symmetric_matching(m, r1.second, r2.second);
+        printf("symmetric better-by-24 matches %zu\n", sym.size());
+    } catch (const akaze::Error& e) {
+        fprintf(stderr, "akaze error: %s\n", e.what());
+        return 3;
+    }
+    printf("estimate_pose ok\n");
+    return 0;
+}

@@ -270,3 +270,21 @@ def test_tutorial_ch5_symmetric_matching(gpu, oracle, kitti, kitti_golden):
     assert knn.symmetric_matching(da[:1], db, strict=False) == []
     got_le = knn.symmetric_matching(da, db, strict=False)
     assert got_le == oracle.match(da, db, rule=1, param_u=24, symmetric=True).tolist()
+
+
+def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
+    """The reference's integration test (akaze/tests/estimate_pose.rs:24-59) restated in C++ against
+    include/akaze.hpp and run as a separate native process linked to libakz.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "estimate_pose"
+    lib_dir = os.path.join(root, "cv_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "estimate_pose.cpp"), "-o", str(exe),
+                           "-L", lib_dir, "-lakz", f"-Wl,-rpath,{lib_dir}"])
+    f0, f1 = tmp_path / "f0.raw", tmp_path / "f14.raw"
+    kitti[0].tofile(f0); kitti[1].tofile(f1)
+    h, w = kitti[0].shape
+    r = subprocess.run([str(exe), str(f0), str(f1), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "descriptors 399 343" in r.stdout and "matches 11" in r.stdout
