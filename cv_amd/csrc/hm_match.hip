@@ -224,7 +224,13 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
     c->max_t = max_targets;
     uint32_t m = max_queries > max_targets ? max_queries : max_targets;
     c->max_q = c->max_t = m;  // symmetric matching swaps the roles
-    AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const char* pr = getenv("AKZ_STREAM_PRIORITY");
+        // the matcher is VALU-bound filler work: least urgent, so it yields to the scale-space stream
+        AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (pr && pr[0] == '1') ? prio_lo : 0));
+    }
     AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
     AKZ_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
