@@ -1,0 +1,410 @@
+// rs_ransac.hip — batched two-view geometric verification on gfx950 (SURVEY.md §8a rows R1-R4,
+// BASELINE.json configs[3]): eight-point essential matrices for a batch of minimal samples, the four
+// candidate poses of each, the triangulation residual of every (pose, match) pair, consensus by inlier
+// count.  All f64 VALU work, -ffp-contract=off, the same operation sequence as oracle/ransac_oracle.c.
+//
+// Reference code implemented here (paths relative to rust-cv/cv):
+//   CameraIntrinsics::calibrate (+K1)                     cv-pinhole/src/lib.rs:108-117,191-202   rs_calibrate (host)
+//   encode_epipolar_equation, EightPoint::from_matches    eight-point/src/lib.rs:11-58            k_rs_hypotheses
+//   EssentialMatrix::possible_unscaled_poses              cv-pinhole/src/essential.rs:114-162,217-231  k_rs_hypotheses
+//   CameraToCamera::residual                              cv-core/src/pose.rs:249-295             k_rs_score, k_rs_inliers
+//   Consensus::model_inliers                              call sites akaze/tests/estimate_pose.rs:63-67,
+//                                                         tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1406
+// nalgebra's eigen/SVD and the arrsac sampler are un-vendored: the eigen-solver is the shared cyclic Jacobi
+// of include/akz_ransac_math.h, the minimal samples are supplied by the caller, and every hypothesis is
+// scored against every match (parity: oracle == HIP, bit for bit).
+#include <math.h>
+
+#include "akz_common.h"
+#include "../../include/akz_ransac_math.h"
+
+namespace {
+
+constexpr double kEpsHyp = 1e-12;   // EightPoint::default epsilon (eight-point/src/lib.rs:60-67)
+constexpr int kItersHyp = 1000;     // EightPoint::default iterations
+constexpr double kEpsRes = 1e-12;   // try_symmetric_eigen(1e-12, 1024), cv-core/src/pose.rs:272
+constexpr int kItersRes = 1024;
+
+__device__ __forceinline__ bool finite_d(double v) { return v == v && fabs(v) != INFINITY; }
+
+// one lane per hypothesis; the 9x9 normal matrix and its eigenvectors live in LDS, interleaved across the
+// 64 lanes (element e of lane t at [e*64 + t]) so every access is conflict-free.
+__global__ __launch_bounds__(64) void k_rs_hypotheses(const double* __restrict__ ba, const double* __restrict__ bb,
+                                                      const uint32_t* __restrict__ sample_idx, uint32_t n_hyp,
+                                                      double* __restrict__ poses, uint32_t* __restrict__ ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sM = reinterpret_cast<double*>(smem) + threadIdx.x;        // [81][64]
+    double* sV = reinterpret_cast<double*>(smem) + 81 * 64 + threadIdx.x;
+    const uint32_t hh = blockIdx.x * 64 + threadIdx.x;
+    if (hh >= n_hyp) return;
+    double A[8][9];
+    for (int i = 0; i < 8; ++i) {
+        uint32_t m = sample_idx[(size_t)hh * 8 + i];
+        const double* a = ba + (size_t)3 * m;
+        const double* b = bb + (size_t)3 * m;
+        double az = a[2];
+        double ap[3] = {a[0] / az, a[1] / az, a[2] / az};
+        double bp[3] = {b[0] / az, b[1] / az, b[2] / az};  // sic: divided by a.z (eight-point/src/lib.rs:16)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) A[i][3 * j + k] = ap[j] * bp[k];
+    }
+    for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 9; ++c) {
+            double s = 0.0;
+            for (int i = 0; i < 8; ++i) s += A[i][r] * A[i][c];
+            sM[(r * 9 + c) * 64] = s;
+        }
+    akz_rm_jacobi9(sM, sV, 64, kEpsHyp, kItersHyp);
+    int best = 0;
+    for (int i = 1; i < 9; ++i)
+        if (sM[(i * 9 + i) * 64] < sM[(best * 9 + best) * 64]) best = i;
+    double E[9];
+    bool good = true;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            E[r * 3 + c] = sV[((c * 3 + r) * 9 + best) * 64];  // Matrix3::from_iterator is column-major
+            good = good && finite_d(E[r * 3 + c]);
+        }
+    // possible_unscaled_poses: SVD of E through the eigen-decomposition of E^T E
+    double M[9], V[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += E[k * 3 + r] * E[k * 3 + c];
+            M[r * 3 + c] = s;
+        }
+    akz_rm_jacobi3(M, V, 1, kEpsHyp, kItersHyp);
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (M[ord[j] * 3 + ord[j]] > M[ord[i] * 3 + ord[i]]) {
+                int t = ord[i];
+                ord[i] = ord[j];
+                ord[j] = t;
+            }
+    double Vs[9], U[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) Vs[r * 3 + c] = V[r * 3 + ord[c]];
+    for (int c = 0; c < 2; ++c) {
+        double lam = M[ord[c] * 3 + ord[c]];
+        double s = AKZ_RM_SQRT(lam > 0.0 ? lam : 0.0);
+        if (!(s > 0.0)) good = false;
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += E[r * 3 + k] * Vs[k * 3 + c];
+            U[r * 3 + c] = acc / s;
+        }
+    }
+    U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+    U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+    U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    double detV = Vs[0] * (Vs[4] * Vs[8] - Vs[5] * Vs[7]) - Vs[1] * (Vs[3] * Vs[8] - Vs[5] * Vs[6]) +
+                  Vs[2] * (Vs[3] * Vs[7] - Vs[4] * Vs[6]);
+    if (detV < 0.0)
+        for (int r = 0; r < 3; ++r) Vs[r * 3 + 2] = -Vs[r * 3 + 2];
+    // R1 = U W V^T, R2 = U W^T V^T with W = [[0,-1,0],[1,0,0],[0,0,1]]; the products are written out with
+    // the same term order as the oracle's generic 3x3 multiply (k = 0,1,2, zeros included)
+    const double W[9] = {0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+    const double Wt[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+    double R[2][9];
+    for (int which = 0; which < 2; ++which) {
+        const double* Wm = which ? Wt : W;
+        double UW[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += U[r * 3 + k] * Wm[k * 3 + c];
+                UW[r * 3 + c] = s;
+            }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += UW[r * 3 + k] * Vs[c * 3 + k];  // V^T(k,c) = Vs(c,k)
+                R[which][r * 3 + c] = s;
+            }
+    }
+    const double t[3] = {U[2], U[5], U[8]};
+    double* out = poses + (size_t)hh * 48;
+    for (int p = 0; p < 4; ++p) {
+        const double* Rm = R[p & 1];
+        double sg = (p & 2) ? -1.0 : 1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                out[p * 12 + r * 4 + c] = Rm[r * 3 + c];
+                good = good && finite_d(Rm[r * 3 + c]);
+            }
+            out[p * 12 + r * 4 + 3] = sg * t[r];
+            good = good && finite_d(t[r]);
+        }
+    }
+    ok[hh] = good ? 1u : 0u;
+}
+
+// CameraToCamera::residual for one (pose, match) — cv-core/src/pose.rs:249-295.
+__device__ double rs_residual(const double* __restrict__ pose, const double* a, const double* b)
+{
+    double design[16], V[16];
+    for (int i = 0; i < 16; ++i) design[i] = 0.0;
+    for (int view = 0; view < 2; ++view) {
+        double P[12];
+        for (int i = 0; i < 12; ++i) P[i] = view == 0 ? ((i == 0 || i == 5 || i == 10) ? 1.0 : 0.0) : pose[i];
+        const double* br = view == 0 ? a : b;
+        double term[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += (br[r] * br[k]) * P[k * 4 + c];
+                term[r * 4 + c] = P[r * 4 + c] - s;
+            }
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 3; ++k) s += term[k * 4 + r] * term[k * 4 + c];
+                design[r * 4 + c] += s;
+            }
+    }
+    akz_rm_jacobi4(design, V, 1, kEpsRes, kItersRes);
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (fabs(design[i * 4 + i]) < fabs(design[best * 4 + best])) best = i;
+    double p[4] = {V[0 * 4 + best], V[1 * 4 + best], V[2 * 4 + best], V[3 * 4 + best]};
+    if (__builtin_signbit(p[3]))
+        for (int i = 0; i < 4; ++i) p[i] = -p[i];
+    double nrm = AKZ_RM_SQRT(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    for (int i = 0; i < 4; ++i) p[i] = p[i] / nrm;
+    for (int i = 0; i < 4; ++i)
+        if (!finite_d(p[i])) return 2.0;
+    double q[4];
+    for (int r = 0; r < 3; ++r)
+        q[r] = ((pose[r * 4 + 0] * p[0] + pose[r * 4 + 1] * p[1]) + pose[r * 4 + 2] * p[2]) + pose[r * 4 + 3] * p[3];
+    q[3] = p[3];
+    if (__builtin_signbit(q[3]))
+        for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    double qn = AKZ_RM_SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    for (int i = 0; i < 4; ++i) q[i] = q[i] / qn;
+    double ad = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
+    double bd = (b[0] * q[0] + b[1] * q[1]) + b[2] * q[2];
+    double res = 0.5 * (1.0 - ad + 1.0 - bd);
+    return res == res ? res : 2.0;
+}
+
+// grid: (match blocks, pose id = hyp*4 + p).  Inlier count per pose by ballot + one atomic per wave.
+__global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba, const double* __restrict__ bb,
+                                                  uint32_t n, const double* __restrict__ poses,
+                                                  const uint32_t* __restrict__ ok, double thresh,
+                                                  uint32_t* __restrict__ counts)
+{
+    const uint32_t pid = blockIdx.y;
+    if (!ok[pid >> 2]) return;
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    bool inl = false;
+    if (m < n) {
+        double pose[12];
+        for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+        double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+        double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+        inl = rs_residual(pose, a, b) < thresh;
+    }
+    unsigned long long bal = __ballot(inl);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
+}
+
+// argmax of (count, -id): the pose with the most inliers, lowest id on ties (= the oracle's first-maximum scan)
+__global__ __launch_bounds__(1024) void k_rs_best(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ok,
+                                                  uint32_t n_pose, uint32_t* __restrict__ best)
+{
+    __shared__ unsigned long long s_key[16];
+    unsigned long long key = 0ull;  // 0 = nothing valid
+    for (uint32_t i = threadIdx.x; i < n_pose; i += 1024)
+        if (ok[i >> 2]) {
+            unsigned long long k = ((unsigned long long)(counts[i] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+            key = k > key ? k : key;
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(key, off);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
+        best[0] = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
+        best[1] = key ? (uint32_t)(key >> 32) - 1u : 0u;
+    }
+}
+
+// inlier indices of the best pose in ascending match order (ordered compaction, one block)
+__global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ ba, const double* __restrict__ bb,
+                                                     uint32_t n, const double* __restrict__ poses,
+                                                     const uint32_t* __restrict__ best, double thresh,
+                                                     uint32_t* __restrict__ inlier_idx, uint32_t cap,
+                                                     uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t pid = best[0];
+    if (pid == 0xFFFFFFFFu) {
+        if (threadIdx.x == 0) *n_inliers = 0;
+        return;
+    }
+    double pose[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t base = 0;
+    for (uint32_t m0 = 0; m0 < n; m0 += 1024) {
+        uint32_t m = m0 + threadIdx.x;
+        bool inl = false;
+        if (m < n) {
+            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+            inl = rs_residual(pose, a, b) < thresh;
+        }
+        unsigned long long bal = __ballot(inl);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (inl) {
+            uint32_t o = base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) inlier_idx[o] = m;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_inliers = base;
+}
+
+}  // namespace
+
+struct rs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t max_matches = 0, max_hyp = 0;
+    double *d_a = nullptr, *d_b = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
+    uint32_t *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_best = nullptr, *d_inl = nullptr,
+             *d_ninl = nullptr;
+    uint32_t last_hyp = 0;
+};
+
+extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_hyp, rs_ctx** out)
+{
+    if (!out || max_matches < 8 || max_hyp == 0 || max_hyp > (1u << 28)) return AKZ_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
+    AKZ_HIP(hipSetDevice(device));
+    rs_ctx* c = new rs_ctx();
+    c->device = device;
+    c->max_matches = max_matches;
+    c->max_hyp = max_hyp;
+    AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * (size_t)max_matches));
+    AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 3 * (size_t)max_matches));
+    AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12));
+    AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
+    AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
+    AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * 4));
+    *out = c;
+    return AKZ_OK;
+}
+
+extern "C" int32_t rs_destroy(rs_ctx* c)
+{
+    if (!c) return AKZ_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
+    hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return AKZ_OK;
+}
+
+// cv_pinhole::CameraIntrinsics::calibrate / CameraIntrinsicsK1Distortion::calibrate: host scalar math.
+extern "C" int32_t rs_calibrate(const double* intr, int32_t use_k1, double k1, const akz_keypoint* kps, uint32_t n,
+                                double* out)
+{
+    if (!intr || (n && (!kps || !out))) return AKZ_E_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        double cx = (double)kps[i].x - intr[2], cy = (double)kps[i].y - intr[3];
+        double y = cy / intr[1];
+        double x = (cx - intr[4] * y) / intr[0];
+        if (use_k1) {
+            double r2 = x * x + y * y;
+            double d = 1.0 + k1 * r2;
+            x = x / d;
+            y = y / d;
+        }
+        double nrm = sqrt(x * x + y * y + 1.0 * 1.0);
+        out[3 * i + 0] = x / nrm;
+        out[3 * i + 1] = y / nrm;
+        out[3 * i + 2] = 1.0 / nrm;
+    }
+    return AKZ_OK;
+}
+
+extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
+                                      const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
+                                      uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
+{
+    if (!c || !bearings_a || !bearings_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
+        return AKZ_E_INVALID;
+    if (n < 8 || n_hyp == 0) return AKZ_E_INVALID;  // EightPoint::MIN_SAMPLES (eight-point/src/lib.rs:73)
+    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+    for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
+        if (sample_idx[i] >= n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+    hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
+                       c->d_samples, n_hyp, c->d_poses, c->d_ok);
+    AKZ_LAUNCH_CHECK();
+    // grid.y is limited to 65535: score the poses in slabs
+    const uint32_t n_pose = n_hyp * 4;
+    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+        hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
+                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0 / 4, thresh, c->d_counts + p0);
+        AKZ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
+                       c->d_inl, n, c->d_ninl, c->d_best_pose);
+    AKZ_LAUNCH_CHECK();
+    uint32_t best[2] = {0, 0}, ninl = 0;
+    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipStreamSynchronize(s));
+    c->last_hyp = n_hyp;
+    *best_id = best[0];
+    *n_inliers = ninl;
+    if (best[0] == 0xFFFFFFFFu) {
+        *n_inliers = 0;
+        return AKZ_OK;  // Consensus::model_inliers returned None: no hypothesis produced a model
+    }
+    uint32_t ncopy = ninl < cap ? ninl : cap;
+    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+}
+
+// parity tap: inlier count of every (hypothesis, pose) of the last rs_essential_batch call
+extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
+{
+    if (!c || !counts) return AKZ_E_INVALID;
+    if (cap < c->last_hyp * 4) return AKZ_E_CAPACITY;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_HIP(hipMemcpy(counts, c->d_counts, sizeof(uint32_t) * 4 * (size_t)c->last_hyp, hipMemcpyDeviceToHost));
+    return AKZ_OK;
+}

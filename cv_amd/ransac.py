@@ -1,0 +1,72 @@
+"""Host-side mirror of the two-view geometric-verification call sites over rs_* of include/akz.h.
+
+  camera.calibrate(keypoint)                      cv-pinhole/src/lib.rs:108-117 (plain), :191-202 (K1 distortion)
+  consensus.model_inliers(&EightPoint::new(), matches)   akaze/tests/estimate_pose.rs:63-67, tutorial ch5 main.rs:70-72
+The reference's `arrsac` sampler is an un-vendored crate; here the minimal samples are an explicit argument
+(`sample_idx`, 8 match indices per hypothesis) and every hypothesis is scored on the MI355X.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, check
+
+
+@dataclass
+class CameraIntrinsics:
+    """cv_pinhole::CameraIntrinsics (focals, principal_point, skew)."""
+    focals: tuple
+    principal_point: tuple
+    skew: float = 0.0
+    k1: float = None      # set -> CameraIntrinsicsK1Distortion
+
+    def calibrate(self, keypoints):
+        """Pixel keypoints (structured array with x, y) -> [n,3] unit bearings."""
+        kps = np.ascontiguousarray(keypoints, dtype=KP_DTYPE)
+        intr = np.array([self.focals[0], self.focals[1], self.principal_point[0], self.principal_point[1], self.skew],
+                        np.float64)
+        out = np.empty((len(kps), 3), np.float64)
+        check(_lib.lib().rs_calibrate(intr.ctypes.data, int(self.k1 is not None), float(self.k1 or 0.0),
+                                      kps.ctypes.data, len(kps), out.ctypes.data), "rs_calibrate")
+        return out
+
+
+class EssentialConsensus:
+    """Owns one rs_ctx.  model_inliers() is the batched Consensus::model_inliers for EightPoint."""
+
+    def __init__(self, max_matches=8192, max_hypotheses=16384, device=0):
+        self._h = C.c_void_p()
+        self.max_hyp = max_hypotheses
+        check(_lib.lib().rs_create(device, max_matches, max_hypotheses, C.byref(self._h)), "rs_create")
+
+    def close(self):
+        if self._h:
+            _lib.lib().rs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def model_inliers(self, bearings_a, bearings_b, sample_idx, threshold):
+        """Returns (pose [3,4] = [R | t], inlier indices, best_id) or None when no sample gave a model."""
+        a = np.ascontiguousarray(bearings_a, np.float64); b = np.ascontiguousarray(bearings_b, np.float64)
+        si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 8)
+        n = len(a)
+        pose = np.empty((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
+        inl = np.empty(max(n, 1), np.uint32)
+        check(_lib.lib().rs_essential_batch(self._h, a.ctypes.data, b.ctypes.data, n, si.ctypes.data, len(si),
+                                            float(threshold), pose.ctypes.data, C.byref(best), inl.ctypes.data, n,
+                                            C.byref(ninl)), "rs_essential_batch")
+        if best.value == 0xFFFFFFFF:
+            return None
+        return pose, inl[:ninl.value].copy(), best.value
+
+    def counts(self, n_hyp):
+        out = np.zeros((n_hyp, 4), np.uint32)
+        check(_lib.lib().rs_debug_counts(self._h, out.ctypes.data, out.size), "rs_debug_counts")
+        return out

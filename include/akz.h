@@ -195,6 +195,30 @@ int32_t hm_match_batch_device(hm_ctx* ctx, const void* d_a, const void* d_na, co
 int32_t hm_sync(hm_ctx* ctx);
 void* hm_stream(hm_ctx* ctx);
 
+/* ---- two-view geometric verification (second phase) ---- */
+typedef struct rs_ctx rs_ctx;
+int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_hypotheses, rs_ctx** out);
+int32_t rs_destroy(rs_ctx* ctx);
+/* cv_pinhole::CameraIntrinsics::calibrate (cv-pinhole/src/lib.rs:108-117) and, with use_k1 != 0,
+ * CameraIntrinsicsK1Distortion::calibrate (:191-202): pixel keypoints -> unit bearings [n][3].
+ * intrinsics = {focal_x, focal_y, principal_x, principal_y, skew}.  Host-only scalar math. */
+int32_t rs_calibrate(const double* intrinsics, int32_t use_k1, double k1, const akz_keypoint* kps, uint32_t n,
+                     double* bearings);
+/* Consensus::model_inliers(&EightPoint::new(), matches) (call sites akaze/tests/estimate_pose.rs:63-67,
+ * tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1406) with the sampler factored out: the caller
+ * provides n_hyp minimal samples (8 match indices each, what arrsac draws from its RNG); every sample is
+ * turned into an essential matrix (eight-point/src/lib.rs:43-58) and its four poses
+ * (cv-pinhole/src/essential.rs:217-231), every pose is scored against all n matches with
+ * CameraToCamera::residual (cv-core/src/pose.rs:249-295) < thresh, and the pose with the most inliers wins
+ * (ties: lowest hypothesis, then lowest pose index).  best_pose = row-major 3x4 [R | t];
+ * best_id = hypothesis*4 + pose, 0xFFFFFFFF if no sample produced a model (the reference returns None);
+ * inlier_idx ascending. */
+int32_t rs_essential_batch(rs_ctx* ctx, const double* bearings_a, const double* bearings_b, uint32_t n,
+                           const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
+                           uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers);
+/* parity tap: inlier counts [n_hyp][4] of the last rs_essential_batch call */
+int32_t rs_debug_counts(rs_ctx* ctx, uint32_t* counts, uint32_t cap);
+
 /* ---- misc ---- */
 const char* akz_strerror(int32_t status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none) and its text. */

@@ -1,0 +1,82 @@
+/* akz_ransac_math.h — the dense f64 eigen-solver used by the two-view geometric-verification path
+ * (SURVEY.md §8a rows R1-R3), written as plain IEEE double arithmetic so that gcc (CPU oracle) and
+ * hipcc (gfx950 kernels) execute the same operation sequence (build: -ffp-contract=off, no fast-math).
+ *
+ * Why shared: the reference takes its eigen-decompositions and its SVD from nalgebra 0.30
+ * (`try_symmetric_eigen(eps, max_iter)` at eight-point/src/lib.rs:49 and cv-core/src/pose.rs:272,
+ * `SVD::try_new` at cv-pinhole/src/essential.rs:128), which is not vendored in the reference tree and
+ * cannot be built here.  Its iteration (tridiagonalisation + implicit QR) is not restated; both sides use
+ * this cyclic Jacobi iteration instead, so RANSAC parity is "oracle == HIP", bit for bit, while agreement
+ * with the reference is at the level its own tests pin: residual < 1e-4 on exact data
+ * (eight-point/tests/random.rs), pose recovery (cv-pinhole doc-tests).
+ */
+#ifndef AKZ_RANSAC_MATH_H
+#define AKZ_RANSAC_MATH_H
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define AKZ_RM_FN __host__ __device__ static inline
+#else
+#define AKZ_RM_FN static inline
+#endif
+
+/* Babylonian-free: sqrt is the one non-arithmetic primitive; it is correctly rounded on both sides. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AKZ_RM_SQRT(x) __dsqrt_rn(x)
+#else
+#include <math.h>
+#define AKZ_RM_SQRT(x) sqrt(x)
+#endif
+
+/* Cyclic Jacobi for a symmetric N x N matrix stored row-major in a[N*N] (destroyed: ends diagonal);
+ * v[N*N] receives the eigenvectors as COLUMNS (v[r*N + c] = component r of eigenvector c).
+ * Stops when the off-diagonal sum of squares is <= eps^2 * (sum of squares of the diagonal) or after
+ * max_sweeps.  Returns the number of sweeps used. */
+#define AKZ_RM_DEFINE_JACOBI(NAME, N)                                                              \
+    AKZ_RM_FN int NAME(double* a, double* v, int S, double eps, int max_sweeps)                           \
+    {                                                                                              \
+        for (int i = 0; i < (N); ++i)                                                              \
+            for (int j = 0; j < (N); ++j) v[(i * (N) + j) * S] = (i == j) ? 1.0 : 0.0;                   \
+        int sweep = 0;                                                                             \
+        for (; sweep < max_sweeps; ++sweep) {                                                      \
+            double off = 0.0, diag = 0.0;                                                          \
+            for (int p = 0; p < (N); ++p) {                                                        \
+                diag += a[(p * (N) + p) * S] * a[(p * (N) + p) * S];                                           \
+                for (int q = p + 1; q < (N); ++q) off += a[(p * (N) + q) * S] * a[(p * (N) + q) * S];          \
+            }                                                                                      \
+            if (off <= eps * eps * diag || off == 0.0) break;                                      \
+            for (int p = 0; p < (N)-1; ++p)                                                        \
+                for (int q = p + 1; q < (N); ++q) {                                                \
+                    double apq = a[(p * (N) + q) * S];                                                   \
+                    if (apq == 0.0) continue;                                                      \
+                    double app = a[(p * (N) + p) * S], aqq = a[(q * (N) + q) * S];                             \
+                    double theta = (aqq - app) / (2.0 * apq);                                      \
+                    double at = theta < 0.0 ? -theta : theta;                                      \
+                    double t = 1.0 / (at + AKZ_RM_SQRT(theta * theta + 1.0));                      \
+                    if (theta < 0.0) t = -t;                                                       \
+                    double c = 1.0 / AKZ_RM_SQRT(t * t + 1.0);                                     \
+                    double s = t * c;                                                              \
+                    for (int k = 0; k < (N); ++k) { /* columns p and q */                          \
+                        double akp = a[(k * (N) + p) * S], akq = a[(k * (N) + q) * S];                         \
+                        a[(k * (N) + p) * S] = c * akp - s * akq;                                        \
+                        a[(k * (N) + q) * S] = s * akp + c * akq;                                        \
+                    }                                                                              \
+                    for (int k = 0; k < (N); ++k) { /* rows p and q */                             \
+                        double apk = a[(p * (N) + k) * S], aqk = a[(q * (N) + k) * S];                         \
+                        a[(p * (N) + k) * S] = c * apk - s * aqk;                                        \
+                        a[(q * (N) + k) * S] = s * apk + c * aqk;                                        \
+                    }                                                                              \
+                    for (int k = 0; k < (N); ++k) {                                                \
+                        double vkp = v[(k * (N) + p) * S], vkq = v[(k * (N) + q) * S];                         \
+                        v[(k * (N) + p) * S] = c * vkp - s * vkq;                                        \
+                        v[(k * (N) + q) * S] = s * vkp + c * vkq;                                        \
+                    }                                                                              \
+                }                                                                                  \
+        }                                                                                          \
+        return sweep;                                                                              \
+    }
+
+AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi9, 9)
+AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi4, 4)
+AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi3, 3)
+
+#endif /* AKZ_RANSAC_MATH_H */

@@ -50,7 +50,7 @@ BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6,
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -105,6 +105,14 @@ def lib():
         L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
                                 C.c_float, C.c_int, C.c_void_p, C.c_uint32]
+        L.orc_calibrate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_eight_point.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.orc_essential_poses.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.orc_residual.restype = C.c_double
+        L.orc_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        L.orc_essential_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double,
+                                          C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
         L.orc_pm_atan2f_v.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_pm_sincosf_v.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         _lib = L
@@ -306,3 +314,54 @@ def pm_sincosf(a):
     a = _f32(a); s = np.empty_like(a); c = np.empty_like(a)
     lib().orc_pm_sincosf_v(a.ctypes.data, a.size, s.ctypes.data, c.ctypes.data)
     return s, c
+
+
+# ---- two-view geometric verification (ransac_oracle.c) ------------------------------------------------
+RS_EPS, RS_ITERS = 1e-12, 1000   # EightPoint::default (eight-point/src/lib.rs:60-67)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def calibrate(kps, fx, fy, cx, cy, skew=0.0, k1=None):
+    """CameraIntrinsics::calibrate / CameraIntrinsicsK1Distortion::calibrate -> [n,3] unit bearings."""
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    intr = _f64([fx, fy, cx, cy, skew])
+    out = np.empty((len(kps), 3), np.float64)
+    lib().orc_calibrate(intr.ctypes.data, int(k1 is not None), float(k1 or 0.0), kps.ctypes.data, len(kps),
+                        out.ctypes.data)
+    return out
+
+
+def eight_point(a8, b8):
+    a8 = _f64(a8); b8 = _f64(b8); E = np.empty((3, 3), np.float64)
+    if lib().orc_eight_point(a8.ctypes.data, b8.ctypes.data, RS_EPS, RS_ITERS, E.ctypes.data) != 0:
+        return None
+    return E
+
+
+def essential_poses(E):
+    E = _f64(E); P = np.empty((4, 3, 4), np.float64)
+    if lib().orc_essential_poses(E.ctypes.data, RS_EPS, RS_ITERS, P.ctypes.data) != 0:
+        return None
+    return P
+
+
+def pose_residual(pose, a, b):
+    pose = _f64(pose); a = _f64(a); b = _f64(b)
+    return lib().orc_residual(pose.ctypes.data, a.ctypes.data, b.ctypes.data, 1e-12, 1024)
+
+
+def essential_batch(ba, bb, sample_idx, thresh):
+    """Exhaustive consensus. Returns (pose[3,4], best_id (= hyp*4 + pose), inlier indices, counts[n_hyp,4])."""
+    ba = _f64(ba); bb = _f64(bb)
+    si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 8)
+    n = len(ba)
+    pose = np.empty((3, 4), np.float64); best = C.c_uint32(); inl = np.empty(max(n, 1), np.uint32); ninl = C.c_uint32()
+    counts = np.zeros((len(si), 4), np.uint32)
+    r = lib().orc_essential_batch(ba.ctypes.data, bb.ctypes.data, n, si.ctypes.data, len(si), thresh, 1e-12, 1000,
+                                  pose.ctypes.data, C.byref(best), inl.ctypes.data, C.byref(ninl), counts.ctypes.data)
+    if r != 0:
+        return None
+    return pose, best.value, inl[:ninl.value].copy(), counts

@@ -20,7 +20,7 @@ def lib():
 def test_library_exports_every_declared_symbol(lib):
     from cv_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "akz.h")).read()
-    declared = set(re.findall(r"\b((?:akz|hm)_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:akz|hm|rs)_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"akz_status"}
     assert declared, "no declarations parsed"
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)

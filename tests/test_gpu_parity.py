@@ -288,3 +288,66 @@ def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
     r = subprocess.run([str(exe), str(f0), str(f1), str(w), str(h)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "descriptors 399 343" in r.stdout and "matches 11" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------
+def _two_view_scene(rng, n, outlier_frac):
+    """the scene of eight-point/tests/random.rs:38-75 with uniformly random outlier
+    bearings mixed in."""
+    from test_oracle_ransac import _rot
+    R = _rot(rng.random(3) * np.pi * 2 * 0.2)
+    t = rng.random(3)
+    pts = rng.random((n, 3)) * 2.0
+    pts[:, 0] -= 1.0; pts[:, 1] -= 1.0; pts[:, 2] += 3.0
+    pb = pts @ R.T + t
+    a = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    b = pb / np.linalg.norm(pb, axis=1, keepdims=True)
+    bad = rng.random(n) < outlier_frac
+    rb = rng.standard_normal((n, 3)); rb[:, 2] = np.abs(rb[:, 2]) + 0.5
+    b[bad] = (rb / np.linalg.norm(rb, axis=1, keepdims=True))[bad]
+    return a, b
+
+
+def test_ransac_bit_exact(gpu, oracle):
+    """R1-R4: per-(hypothesis, pose) inlier counts, the winning pose (all 12 f64 bit patterns), its id and
+    its inlier index set equal the oracle's."""
+    from cv_amd.ransac import EssentialConsensus
+    rng = np.random.default_rng(0x5AC)
+    cons = EssentialConsensus(2048, 4096)
+    for n, n_hyp, frac, thr in ((200, 300, 0.3, 1e-7), (64, 500, 0.0, 1e-7), (1000, 64, 0.3, 1e-4), (8, 1, 0.0, 0.1)):
+        a, b = _two_view_scene(rng, n, frac)
+        samples = np.stack([rng.choice(n, 8, replace=False) for _ in range(n_hyp)]).astype(np.uint32)
+        got = cons.model_inliers(a, b, samples, thr)
+        want = oracle.essential_batch(a, b, samples, thr)
+        assert (got is None) == (want is None)
+        if want is None:
+            continue
+        wpose, wbest, winl, wcounts = want
+        _eq(cons.counts(n_hyp), wcounts, f"ransac counts n={n} hyp={n_hyp}")
+        pose, inl, best = got
+        assert best == wbest
+        _eq(pose, wpose, "ransac best pose")
+        _eq(inl, winl, "ransac inliers")
+        if frac > 0 and thr < 1e-5 and n >= 200:
+            assert len(inl) > 0.5 * n
+
+
+def test_ransac_estimate_pose_pin(gpu, kitti, oracle):
+    """akaze/tests/estimate_pose.rs:24-76 end to end on the device: 399/343 descriptors -> 11 matches ->
+    calibrate with K_00 -> consensus at 0.1 -> 11 inliers."""
+    import itertools
+    akaze, knn = gpu
+    from cv_amd.ransac import CameraIntrinsics, EssentialConsensus
+    kp1, ds1 = akaze.Akaze.sparse().extract_arrays(kitti[0])
+    kp2, ds2 = akaze.Akaze.sparse().extract_arrays(kitti[1])
+    m = np.array(knn.match_descriptors(ds1, ds2, 0.5))
+    assert len(m) == 11
+    cam = CameraIntrinsics((9.842439e2, 9.808141e2), (6.9e2, 2.331966e2), 0.0)
+    a = cam.calibrate(kp1[m[:, 0]]); b = cam.calibrate(kp2[m[:, 1]])
+    _eq(a, oracle.calibrate(kp1[m[:, 0]], 984.2439, 980.8141, 690.0, 233.1966), "calibrate")
+    samples = np.array(list(itertools.combinations(range(11), 8)), np.uint32)
+    pose, inl, best = EssentialConsensus(64, 256).model_inliers(a, b, samples, 0.1)
+    assert len(inl) == 11
+    wpose, wbest, winl, _ = oracle.essential_batch(a, b, samples, 0.1)
+    assert best == wbest
+    _eq(pose, wpose, "kitti pose")
