@@ -56,6 +56,92 @@ __device__ __forceinline__ float lane4_dot(const float* s, int stride, const flo
     return ((a0 + a1) + a2) + a3;
 }
 
+struct OffK {
+    float n, m;
+    int mode;  // 0: (a*n + c*n) + b*m   1: (a*n + b*m) + c*n    (a = v(-s), b = v(0), c = v(+s))
+};
+__device__ __forceinline__ float off_combine(const OffK k, float a, float b, float c)
+{
+    // the first tap of lane 0 is accumulated onto the +0 the reference's fold starts from (a product that
+    // underflows to -0 becomes +0); after that no partial sum can be -0, so no other tap needs it
+    float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
+    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level front-end: everything a level needs before its diffusion, in one pass over the input tile.
+//   levels >= 1 (R = 2, FLOW):  Lsmooth = blur(Lt, 1.0) -> simple Scharr -> Lflow = g2   (lib.rs:232-248)
+//                               and the multiscale first derivatives {Lx, Ly} of Lsmooth (detector_response.rs:63-64)
+//   level 0     (R = 4, !FLOW): Lt[0] = Lsmooth[0] = blur(image, 1.6) (lib.rs:199-201) and its {Lx, Ly}
+// Lsmooth itself never goes to HBM (unless the parity taps ask for it): the blurred tile plus an SG-pixel
+// ring lives in LDS and both derivative families read it there.  Same exact-arithmetic rules as
+// k_blur_tile: every intermediate is a rounded f32 in LDS, positions hold values at clamped coordinates.
+template <int R, int SG, typename InT, bool FLOW>
+__global__ __launch_bounds__(256) void k_level_front(const InT* __restrict__ in, int w, int h, size_t fs,
+                                                     GaussTaps taps, OffK k, float* __restrict__ out_g,
+                                                     float* __restrict__ out_flow, float2* __restrict__ out_xy,
+                                                     const float* __restrict__ invk, int invk_off)
+{
+    constexpr int N = 2 * R + 1;
+    constexpr int GW = kTW + 2 * SG, GH = kTH + 2 * SG;
+    constexpr int IW = GW + 2 * R, IH = GH + 2 * R;
+    __shared__ float s_a[IH * IW];   // input tile, later reused for the blurred tile
+    __shared__ float s_h[IH * GW];
+    float* s_in = s_a;
+    float* s_g = s_a;
+    const int frame = blockIdx.z;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+    const int tid = threadIdx.x;
+    const InT* src = in + (size_t)frame * fs;
+    for (int idx = tid; idx < IH * IW; idx += 256) {
+        int iy = idx / IW, ix = idx - iy * IW;
+        int cx = clampi(tx0 - SG - R + ix, 0, w - 1);
+        int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
+        s_in[idx] = load_px(src, (size_t)cy * w + cx);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < IH * GW; idx += 256) {
+        int j = idx / GW, p = idx - j * GW;
+        int cc = clampi(tx0 - SG + p, 0, w - 1);
+        s_h[idx] = lane4_dot<N>(&s_in[j * IW + (cc - tx0 + SG)], 1, taps.k);
+    }
+    __syncthreads();  // s_in is dead from here on: s_g overwrites it
+    for (int idx = tid; idx < GH * GW; idx += 256) {
+        int q = idx / GW, p = idx - q * GW;
+        int rc = clampi(ty0 - SG + q, 0, h - 1);
+        s_g[idx] = lane4_dot<N>(&s_h[(rc - ty0 + SG) * GW + p], GW, taps.k);
+    }
+    __syncthreads();
+    float inverse_k = 0.0f;
+    if (FLOW) inverse_k = invk[(size_t)frame * 8 + invk_off];
+    for (int idx = tid; idx < kTH * kTW; idx += 256) {
+        int q = idx / kTW, p = idx - q * kTW;
+        int x = tx0 + p, y = ty0 + q;
+        if (x >= w || y >= h) continue;
+        const float* g = &s_g[(q + SG) * GW + (p + SG)];
+        const size_t o = (size_t)frame * fs + (size_t)y * w + x;
+        if (out_g) out_g[o] = g[0];
+        if (FLOW) {
+            // simple Scharr (derivatives.rs:3-11) + pm_g2 (nonlinear_diffusion.rs:80)
+            float hx_m = g[-GW + 1] - g[-GW - 1];
+            float hx_0 = g[1] - g[-1];
+            float hx_p = g[GW + 1] - g[GW - 1];
+            float lx = (3.0f * hx_m + 10.0f * hx_0) + 3.0f * hx_p;
+            float hy_m = (3.0f * g[-GW - 1] + 10.0f * g[-GW]) + 3.0f * g[-GW + 1];
+            float hy_p = (3.0f * g[GW - 1] + 10.0f * g[GW]) + 3.0f * g[GW + 1];
+            float ly = hy_p - hy_m;
+            out_flow[o] = 1.0f / (1.0f + inverse_k * (lx * lx + ly * ly));
+        }
+        // multiscale Scharr first derivatives (derivatives.rs:23-49), taps at -SG, 0, +SG
+        float mm = g[-SG * GW - SG], m0 = g[-SG * GW], mp = g[-SG * GW + SG];
+        float zm = g[-SG], zp = g[SG];
+        float pm = g[SG * GW - SG], p0 = g[SG * GW], pp = g[SG * GW + SG];
+        float mlx = off_combine(k, mp - mm, zp - zm, pp - pm);
+        float mly = off_combine(k, pm, p0, pp) - off_combine(k, mm, m0, mp);
+        out_xy[o] = make_float2(mlx, mly);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused Gaussian tile kernel: [u8->f32] -> H pass -> V pass -> epilogue, all intermediates
 // materialised as rounded f32 in LDS exactly like the reference's intermediate images.
@@ -427,18 +513,6 @@ __global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src
 // sigma == 2: taps 0,2,4 -> lanes 0,2,0: lane0 = v(+s)n + v(-s)n, lane2 = v(0)m -> (lane0 + lane2)
 // sigma == 3: taps 0,3,6 -> lanes 0,3,2: ((v(-s)n + 0) + v(+s)n) + v(0)m
 // sigma == 1 is the unnormalised simple Scharr [3,10,3]: (3 v(-1) + 10 v(0)) + 3 v(+1).
-struct OffK {
-    float n, m;
-    int mode;  // 0: (a*n + c*n) + b*m   1: (a*n + b*m) + c*n    (a = v(-s), b = v(0), c = v(+s))
-};
-__device__ __forceinline__ float off_combine(const OffK k, float a, float b, float c)
-{
-    // the first tap of lane 0 is accumulated onto the +0 the reference's fold starts from (a product that
-    // underflows to -0 becomes +0); after that no partial sum can be -0, so no other tap needs it
-    float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
-    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
-}
-
 // Lx = V_off(H_main(Lsmooth)), Ly = V_main(H_off(Lsmooth)) — detector_response.rs:63-64.
 __global__ __launch_bounds__(256) void k_deriv_first(const float* __restrict__ sm, float2* __restrict__ Lxy, int w,
                                                      int h, size_t fs, int s, OffK k)
@@ -484,9 +558,11 @@ __global__ __launch_bounds__(256) void k_deriv_second(const float2* __restrict__
 }
 
 // Fused second-order pass + extrema candidates (detector_response.rs:65-67,:46 and
-// scale_space_extrema.rs:34-60,96-104).  A block produces a 64x16 tile of Ldet plus a one-pixel ring
+// scale_space_extrema.rs:34-60,96-104).  A block produces a 64x32 tile of Ldet plus a one-pixel ring
 // (kept in LDS only), writes the tile, and tests every interior pixel against the threshold and its 8
-// neighbours straight from LDS — Ldet is never re-read from HBM for detection.  Candidates that also pass
+// neighbours straight from LDS — Ldet is never re-read from HBM for detection.  For the derivative scales the
+// AKAZE path uses (sigma 2..4) the {Lx,Ly} tile and its halo are staged in LDS with coalesced 8-byte row reads
+// first, so each input pixel crosses the L1 once instead of eight times.  Candidates that also pass
 // the border test are appended to the frame's per-level list in arbitrary order; k_cand_sort restores
 // the reference's raster order afterwards.
 struct CandParams {
@@ -496,31 +572,55 @@ struct CandParams {
     uint32_t cap;      // per-level capacity of the candidate list
 };
 
+template <int SG>  // SG = deriv_sigma (2, 3 or 4); 0 = generic (direct global gathers)
 __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
                                                            int w, int h, size_t fs, int s, OffK k, float sigma_quat,
                                                            CandParams cp, uint2* __restrict__ cand,
                                                            uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
 {
-    constexpr int TW = 64, TH = 16, GW = TW + 2, GH = TH + 2;
+    constexpr int TW = 64, TH = 32, GW = TW + 2, GH = TH + 2;
+    constexpr int HL = (SG > 0 ? SG : 1) + 1;            // halo of the staged {Lx,Ly} tile
+    constexpr int SW = TW + 2 * HL, SH = TH + 2 * HL;
     __shared__ float s_d[GH * GW];
+    __shared__ float2 s_xy[SG > 0 ? SH * SW : 1];
     const int frame = blockIdx.z;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const float2* D = Lxy + (size_t)frame * fs;
+    if (SG > 0) {
+        // stage {Lx,Ly} at CLAMPED coordinates: consecutive lanes read consecutive 8-byte pixels of a row
+        for (int idx = threadIdx.x; idx < SH * SW; idx += 256) {
+            int q = idx / SW, p = idx - q * SW;
+            int cx = clampi(tx0 - HL + p, 0, w - 1), cy = clampi(ty0 - HL + q, 0, h - 1);
+            s_xy[idx] = D[(size_t)cy * w + cx];
+        }
+        __syncthreads();
+    }
     for (int idx = threadIdx.x; idx < GH * GW; idx += 256) {
         int q = idx / GW, p = idx - q * GW;
         int x = tx0 - 1 + p, y = ty0 - 1 + q;
         float v = 0.0f;
         if (x >= 0 && x < w && y >= 0 && y < h) {
-            int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
-            size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
-            float2 mm = D[rm + xm], m0 = D[rm + x], mp = D[rm + xp];
-            float2 zm = D[r0 + xm], zp = D[r0 + xp];
-            float2 pm = D[rp + xm], p0 = D[rp + x], pp = D[rp + xp];
+            float2 mm, m0, mp, zm, zp, pm, p0, pp;
+            if (SG > 0) {
+                // the +-s taps at clamped coordinates; a staged position holds the value of its clamped coordinate
+                int lxm = clampi(x - SG, 0, w - 1) - (tx0 - HL), lx0 = x - (tx0 - HL), lxp = clampi(x + SG, 0, w - 1) - (tx0 - HL);
+                int lym = (clampi(y - SG, 0, h - 1) - (ty0 - HL)) * SW, ly0 = (y - (ty0 - HL)) * SW,
+                    lyp = (clampi(y + SG, 0, h - 1) - (ty0 - HL)) * SW;
+                mm = s_xy[lym + lxm]; m0 = s_xy[lym + lx0]; mp = s_xy[lym + lxp];
+                zm = s_xy[ly0 + lxm]; zp = s_xy[ly0 + lxp];
+                pm = s_xy[lyp + lxm]; p0 = s_xy[lyp + lx0]; pp = s_xy[lyp + lxp];
+            } else {
+                int xm = clampi(x - s, 0, w - 1), xp = clampi(x + s, 0, w - 1);
+                size_t rm = (size_t)clampi(y - s, 0, h - 1) * w, r0 = (size_t)y * w, rp = (size_t)clampi(y + s, 0, h - 1) * w;
+                mm = D[rm + xm]; m0 = D[rm + x]; mp = D[rm + xp];
+                zm = D[r0 + xm]; zp = D[r0 + xp];
+                pm = D[rp + xm]; p0 = D[rp + x]; pp = D[rp + xp];
+            }
             float lxx = off_combine(k, mp.x - mm.x, zp.x - zm.x, pp.x - pm.x);
             float lxy = off_combine(k, pm.x, p0.x, pp.x) - off_combine(k, mm.x, m0.x, mp.x);
             float lyy = off_combine(k, pm.y, p0.y, pp.y) - off_combine(k, mm.y, m0.y, mp.y);
             v = (lxx * lyy - lxy * lxy) * sigma_quat;
-            if (p >= 1 && p <= TW && q >= 1 && q <= TH) Ldet[(size_t)frame * fs + r0 + x] = v;
+            if (p >= 1 && p <= TW && q >= 1 && q <= TH) Ldet[(size_t)frame * fs + (size_t)y * w + x] = v;
         }
         s_d[idx] = v;
     }
@@ -723,7 +823,15 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 
     akz_timer_begin(c, &c->t_ss);
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
-    AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, S.Lt[0], nullptr, P0, 0, n)));
+    const bool fused0 = P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
+    if (fused0) {
+        hipLaunchKernelGGL((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
+                           s, d_imgs, w, h, P0, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
+                           (const float*)nullptr, 0);
+        AKZ_LAUNCH_CHECK();
+    } else {
+        AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, S.Lt[0], nullptr, P0, 0, n)));
+    }
     // lib.rs:206-211 — contrast factor on the ORIGINAL image
     AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
@@ -740,6 +848,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         const AkzLevel& L = P.levels[i];
         const size_t fs = L.pixels();
         const float* smooth = S.Lt[0];
+        bool fused_front = false;
         if (i > 0) {
             const int nsteps = (int)L.tau.size();
             // Ping-pong so the last FED step lands in Lt[i]; `init` is where the un-diffused Lt[i] lives.
@@ -760,8 +869,25 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 init = S.Lt[i - 1];  // lib.rs:230 clone(): read in place, never modified again
             }
             // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
-            AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,
-                                                       (int)L.octave, n)));
+            fused_front = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
+            if (fused_front) {
+                float* lsm_out = c->keep_all ? S.Lsm[i] : nullptr;  // Lsmooth stays on chip unless the taps want it
+                dim3 gridf(akz_div_up(L.w, kTW), akz_div_up(L.h, kTH), n);
+                OffK kk = make_offk(L.deriv_sigma);
+#define AKZ_FRONT(SGV)                                                                                               \
+    hipLaunchKernelGGL((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
+                       lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+                switch (L.deriv_sigma) {
+                case 2: AKZ_FRONT(2); break;
+                case 3: AKZ_FRONT(3); break;
+                default: AKZ_FRONT(4); break;
+                }
+#undef AKZ_FRONT
+                AKZ_LAUNCH_CHECK();
+            } else {
+                AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,
+                                                           (int)L.octave, n)));
+            }
             // lib.rs:251-256 — FED cycle
             akz_timer_begin(c, &c->t_fed);
             const float* src = init;
@@ -815,9 +941,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         }
         // detector_response.rs:60-67 + :33-57
         OffK k = make_offk(L.deriv_sigma);
-        hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
-                           (int)L.deriv_sigma, k);
-        AKZ_LAUNCH_CHECK();
+        if (!(i == 0 ? fused0 : fused_front)) {
+            hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
+                               (int)L.deriv_sigma, k);
+            AKZ_LAUNCH_CHECK();
+        }
         {
             // sigma_size = round(size / ratio) in f32 and smax = 10*sqrt(2) in f32 (scale_space_extrema.rs:16,69-70)
             const float ratio = ldexpf(1.0f, (int)L.octave);
@@ -828,9 +956,17 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             cp.border = smax * sigma_size;
             cp.level = (uint32_t)i;
             cp.cap = c->max_cand;
-            hipLaunchKernelGGL(k_deriv_second_cand, dim3(akz_div_up(L.w, 64), akz_div_up(L.h, 16), n), dim3(256), 0, s,
-                               S.Lxy[i], S.Ldet[i], L.w, L.h, fs, (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand,
-                               S.d_ncand, c->d_err);
+            dim3 grid2(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
+#define AKZ_D2(SGV)                                                                                                  \
+    hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,          \
+                       (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+            switch (L.deriv_sigma) {
+            case 2: AKZ_D2(2); break;
+            case 3: AKZ_D2(3); break;
+            case 4: AKZ_D2(4); break;
+            default: AKZ_D2(0); break;
+            }
+#undef AKZ_D2
             AKZ_LAUNCH_CHECK();
         }
     }
