@@ -15,6 +15,8 @@
 // (nearest, second) pair per query is two packed keys  distance << 22 | target_index  updated with
 // v_min_u32 / v_med3_u32: smaller key == smaller (distance, index), which is exactly LinearKnn's
 // "lowest index wins ties" order (space 0.17: partition_point(d <= new) insertion).
+#include <algorithm>
+
 #include "akz_common.h"
 
 namespace {
@@ -90,6 +92,143 @@ __global__ __launch_bounds__(kBlock) void k_knn2(const HmProb* __restrict__ prob
             P.out[(size_t)qi * 2 + 0] = n0;
             P.out[(size_t)qi * 2 + 1] = n1;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA formulation of the same 2-NN search.  With the descriptor bits recoded as int8 +1 / -1,
+//   sum_k q_k * t_k = 512 - 2 * hamming(q, t),
+// so all distances between 32 queries and 32 targets are one 32x32x512 int8 contraction: sixteen
+// v_mfma_i32_32x32x32_i8 (exact integer accumulate).  Queries are the B operand (output COLUMNS): lane l
+// then holds, for query (l & 31), sixteen different targets per tile, and the running (nearest, second)
+// keys are reduced inside the lane; the two half-waves are merged once at the end.  Per distance the VALU
+// does ~6 operations (key build + min/max) instead of 36, the xor/popcount work moves to the matrix pipe.
+// k_expand writes the +-1 recoding (512 B per descriptor) once per descriptor block.
+// Measured (rocprof, 128 problems of ~5070 x 5070, profiles/): VALU kernel k_knn2 5.0 ms; this kernel with
+// fragment-shaped global loads 6.9 ms (TA-bound); with LDS-staged 32-row tiles and 8 waves per block 2.7 ms;
+// 64-row tiles with two accumulator chains 3.4 ms (slower: LDS footprint halves the resident blocks).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+struct HmExpandJob {
+    const uint32_t* src;   // [cap][16] descriptor words
+    const uint32_t* count; // device count
+    uint32_t cap;
+    uint32_t* dst;         // [cap][128] words of +-1 bytes
+};
+
+__global__ __launch_bounds__(256) void k_expand(const HmExpandJob* __restrict__ jobs)
+{
+    const HmExpandJob J = jobs[blockIdx.y];
+    const uint32_t n = min(*J.count, J.cap);
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;  // one thread per (descriptor, 32-bit word)
+    const uint32_t d = t >> 4, wd = t & 15u;
+    if (d >= n) return;
+    const uint32_t bits = J.src[(size_t)d * 16 + wd];
+    uint4 o[2];
+    uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        uint32_t nib = (bits >> (4 * g)) & 0xFu;
+        // spread 4 bits to 4 bytes (bit i -> byte i), then map 0 -> 0xFF (-1), 1 -> 0x01 (+1)
+        uint32_t sp = (nib * 0x00204081u) & 0x01010101u;
+        ow[g] = ((sp ^ 0x01010101u) * 0xFFu) | sp;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(J.dst + ((size_t)d * 128 + (size_t)wd * 8));
+    dst[0] = o[0];
+    dst[1] = o[1];
+}
+
+struct HmProbX {           // like HmProb, on the +-1 recoded descriptors
+    const uint32_t* q;     // [q_cap][128] words
+    const uint32_t* nq;
+    uint32_t q_cap;
+    const uint32_t* t;
+    const uint32_t* nt;
+    uint32_t t_cap;
+    akz_neighbor* out;
+};
+
+constexpr int kMfmaBlock = 512;   // 8 waves x 32 queries
+__global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restrict__ probs)
+{
+    // target tile: 32 descriptors x 512 B, rows padded to 33 x 16 B so the 16-byte fragment reads of the
+    // 32 rows fall on distinct bank groups; double-buffered, filled with full 512-B-row coalesced loads
+    constexpr int RS = 33;
+    __shared__ uint4 s_t[2][32 * RS];
+    const HmProbX P = probs[blockIdx.y];
+    const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t qblk = blockIdx.x * 256u;
+    if (qblk >= nq) return;                             // whole block
+    const uint32_t q0 = qblk + wv * 32u;                // 32 queries (one column block) per wave
+    const bool wave_on = q0 < nq;                       // idle waves still help staging and hit the barriers
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    // B fragments: query (q0 + col), bytes [32k + 16*half, +16) of its 512 -> 16 x v4i32, resident
+    v4i32 qb[16];
+    {
+        uint32_t qi = min(q0 + col, nq - 1u);
+        const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 128) + half;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) qb[k] = qp[2 * k];
+    }
+    const uint4* tg = reinterpret_cast<const uint4*>(P.t);  // 32 uint4 per descriptor
+    // staging map: thread -> 2 x (row, 16-byte column): idx = tid + 512 i, row = idx >> 5, c = idx & 31
+    const uint32_t srow0 = threadIdx.x >> 5, srow1 = (threadIdx.x + 512u) >> 5, scol = threadIdx.x & 31u;
+    uint4 st0, st1;
+    st0 = tg[(size_t)min(srow0, nt - 1u) * 32 + scol];
+    st1 = tg[(size_t)min(srow1, nt - 1u) * 32 + scol];
+    s_t[0][srow0 * RS + scol] = st0;
+    s_t[0][srow1 * RS + scol] = st1;
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    int buf = 0;
+    for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
+        __syncthreads();                                 // tile `buf` is complete; tile `buf^1` is free
+        const bool more = t0 + 32u < nt;
+        if (more) {                                      // global loads in flight during the MFMAs
+            st0 = tg[(size_t)min(t0 + 32u + srow0, nt - 1u) * 32 + scol];
+            st1 = tg[(size_t)min(t0 + 32u + srow1, nt - 1u) * 32 + scol];
+        }
+        if (wave_on) {
+            const uint4* tp = &s_t[buf][col * RS + half];
+            v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint4 av = tp[2 * k];
+                v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[k], acc, 0, 0, 0);
+            }
+            // D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
+            // key = hamming << 22 | target = ((512 - acc) << 21) | target = (512 << 21 | target) - (acc << 21)
+            const uint32_t base = (512u << 21) | (t0 + 4u * half);
+            const bool full = t0 + 32u <= nt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t off = (uint32_t)((r & 3) + 8 * (r >> 2));
+                uint32_t key = (base + off) - ((uint32_t)acc[r] << 21);
+                if (!full) key = (t0 + 4u * half + off) < nt ? key : 0xFFFFFFFFu;  // last, partial tile
+                uint32_t hi = max(k0, key);
+                k0 = min(k0, key);
+                k1 = min(k1, hi);
+            }
+        }
+        if (more) {
+            s_t[buf ^ 1][srow0 * RS + scol] = st0;
+            s_t[buf ^ 1][srow1 * RS + scol] = st1;
+        }
+        buf ^= 1;
+    }
+    if (!wave_on) return;
+    // merge the two half-waves' sorted pairs
+    uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+    uint32_t m0 = min(k0, o0);
+    uint32_t m1 = min(max(k0, o0), min(k1, o1));
+    uint32_t qi = q0 + col;
+    if (half == 0 && qi < nq) {
+        akz_neighbor n0 = {m0 & ((1u << kIdxBits) - 1u), m0 >> kIdxBits};
+        akz_neighbor n1 = {m1 & ((1u << kIdxBits) - 1u), m1 >> kIdxBits};
+        P.out[(size_t)qi * 2 + 0] = n0;
+        P.out[(size_t)qi * 2 + 1] = n1;
     }
 }
 
@@ -178,6 +317,10 @@ struct hm_ctx {
     hipEvent_t ev_copy = nullptr;  // recorded after the last staging -> device descriptor copy
     bool copy_pending = false;
     // scratch knn results for batched device calls
+    // MFMA path: +-1 recoded descriptor blocks
+    uint32_t* d_exp = nullptr;
+    size_t exp_words = 0;
+    bool use_mfma = true;
     akz_neighbor* d_bfwd = nullptr;
     akz_neighbor* d_brev = nullptr;
     size_t bscratch_elems = 0;
@@ -233,6 +376,10 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
     }
     AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
     AKZ_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    {
+        const char* mf = getenv("AKZ_MATCH_MFMA");
+        c->use_mfma = !(mf && mf[0] == '0');
+    }
     AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
     AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
     AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
@@ -259,6 +406,7 @@ extern "C" int32_t hm_destroy(hm_ctx* c)
     hipFree(c->d_probs);
     if (c->h_probs) hipHostFree(c->h_probs);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    hipFree(c->d_exp);
     hipFree(c->d_bfwd);
     hipFree(c->d_brev);
     if (c->ev) hipEventDestroy(c->ev);
@@ -278,12 +426,62 @@ extern "C" int32_t hm_sync(hm_ctx* c)
 static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, uint32_t max_nq, size_t probs_off)
 {
     if (n_probs == 0) return AKZ_OK;
-    HmProb* dp = reinterpret_cast<HmProb*>((char*)c->d_probs + probs_off);
-    AKZ_TRY(hm_push_probs(c, probs_off, h_probs, sizeof(HmProb) * n_probs));
-    dim3 grid((max_nq + kQPB - 1) / kQPB, n_probs);
-    hipLaunchKernelGGL(k_knn2, grid, dim3(kBlock), 0, c->stream, dp);
+    if (!c->use_mfma) {
+        HmProb* dp = reinterpret_cast<HmProb*>((char*)c->d_probs + probs_off);
+        AKZ_TRY(hm_push_probs(c, probs_off, h_probs, sizeof(HmProb) * n_probs));
+        dim3 grid((max_nq + kQPB - 1) / kQPB, n_probs);
+        hipLaunchKernelGGL(k_knn2, grid, dim3(kBlock), 0, c->stream, dp);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    }
+    // unique descriptor blocks referenced by the problems -> one +-1 recoding each
+    std::vector<HmExpandJob> jobs;
+    std::vector<size_t> job_off;   // word offset of each job's output inside d_exp
+    std::vector<HmProbX> px(n_probs);
+    size_t words = 0;
+    auto expanded = [&](const uint4* src, const uint32_t* cnt, uint32_t cap) -> size_t {
+        for (size_t i = 0; i < jobs.size(); ++i)
+            if (jobs[i].src == (const uint32_t*)src) return job_off[i];
+        jobs.push_back(HmExpandJob{(const uint32_t*)src, cnt, cap, nullptr});
+        job_off.push_back(words);
+        words += (size_t)cap * 128;
+        return job_off.back();
+    };
+    std::vector<size_t> qoff(n_probs), toff(n_probs);
+    uint32_t max_cap = 0;
+    for (uint32_t i = 0; i < n_probs; ++i) {
+        qoff[i] = expanded(h_probs[i].q, h_probs[i].nq, h_probs[i].q_cap);
+        toff[i] = expanded(h_probs[i].t, h_probs[i].nt, h_probs[i].t_cap);
+        max_cap = std::max(max_cap, std::max(h_probs[i].q_cap, h_probs[i].t_cap));
+    }
+    if (words > c->exp_words) {
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_exp) AKZ_HIP(hipFree(c->d_exp));
+        c->d_exp = nullptr;
+        AKZ_HIP(hipMalloc(&c->d_exp, sizeof(uint32_t) * words));
+        c->exp_words = words;
+    }
+    for (size_t i = 0; i < jobs.size(); ++i) jobs[i].dst = c->d_exp + job_off[i];
+    for (uint32_t i = 0; i < n_probs; ++i)
+        px[i] = HmProbX{c->d_exp + qoff[i], h_probs[i].nq, h_probs[i].q_cap, c->d_exp + toff[i], h_probs[i].nt,
+                        h_probs[i].t_cap, h_probs[i].out};
+    // descriptors for this call: [HmProbX x n_probs][HmExpandJob x jobs] inside the knn region of the staging buffer
+    const size_t jobs_off = probs_off + akz_align_up(sizeof(HmProbX) * n_probs, 64);
+    AKZ_TRY(hm_push_probs(c, probs_off, px.data(), sizeof(HmProbX) * n_probs));
+    AKZ_TRY(hm_push_probs(c, jobs_off, jobs.data(), sizeof(HmExpandJob) * jobs.size()));
+    hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
+                       reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + 255) / 256, n_probs), dim3(kMfmaBlock), 0, c->stream,
+                       reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off));
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
+}
+
+// bytes of staging the knn stage of a call needs
+static size_t knn_stage_bytes(uint32_t n_probs)
+{
+    return akz_align_up(sizeof(HmProbX) * n_probs, 64) + akz_align_up(sizeof(HmExpandJob) * 2 * n_probs, 64) + 256;
 }
 
 extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
@@ -294,7 +492,7 @@ extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, cons
     if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
     if (nq == 0) return AKZ_OK;
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(hm_ensure_probs(c, sizeof(HmProb) * 4));
+    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
     uint32_t cnt[2] = {nq, nt};
     AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
     AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
@@ -320,7 +518,8 @@ extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, con
         return rule == HM_RULE_BETTER_BY ? AKZ_OK : AKZ_E_INVALID;
     }
     AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(hm_ensure_probs(c, sizeof(HmProb) * 2 + sizeof(HmPairProb) + 256));
+    const size_t pair_off = akz_align_up(knn_stage_bytes(2), 256);
+    AKZ_TRY(hm_ensure_probs(c, pair_off + sizeof(HmPairProb) + 256));
     uint32_t cnt[2] = {na, nb};
     AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
     AKZ_HIP(hipMemcpyAsync(c->d_a, a, (size_t)na * 64, hipMemcpyHostToDevice, c->stream));
@@ -330,8 +529,8 @@ extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, con
     AKZ_TRY(launch_knn2(c, p, symmetric ? 2 : 1, na > nb ? na : nb, 0));
     uint32_t kcap = cap < na ? cap : na;
     HmPairProb pp = {c->d_fwd, c->d_rev, c->d_na, c->d_na + 1, na, nb, c->d_pairs, kcap, c->d_npairs};
-    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + 256);
-    AKZ_TRY(hm_push_probs(c, 256, &pp, sizeof(pp)));
+    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + pair_off);
+    AKZ_TRY(hm_push_probs(c, pair_off, &pp, sizeof(pp)));
     hipLaunchKernelGGL(k_pairs, dim3(1), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f, (int)symmetric);
     AKZ_LAUNCH_CHECK();
     uint32_t n = 0;
@@ -368,7 +567,7 @@ extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void*
         AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
         c->bscratch_elems = need;
     }
-    size_t knn_bytes = akz_align_up(sizeof(HmProb) * n_pairs * ndir, 256);
+    size_t knn_bytes = akz_align_up(knn_stage_bytes(n_pairs * ndir), 256);
     AKZ_TRY(hm_ensure_probs(c, knn_bytes + sizeof(HmPairProb) * n_pairs));
     std::vector<HmProb> hp(n_pairs * ndir);
     std::vector<HmPairProb> hpp(n_pairs);
