@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
-    ap.add_argument("--micro-batch", type=int, default=64, help="frames per kernel launch")
+    ap.add_argument("--micro-batch", type=int, default=128, help="frames per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     args = ap.parse_args()

@@ -255,6 +255,7 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_n_d = cv.take<uint32_t>(B);
     S.d_desc_tmp = cv.take<akz_descriptor>(B * K);
     S.d_flag_d = cv.take<uint32_t>(B * K);
+    S.d_perm = cv.take<uint32_t>(B * K);
     S.d_kp_out = cv.take<DevKp>(B * K);
     S.d_desc_out = cv.take<akz_descriptor>(B * K);
     S.d_n_out = cv.take<uint32_t>(B);

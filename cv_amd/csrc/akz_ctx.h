@@ -44,6 +44,7 @@ struct AkzSet {
     uint32_t* d_n_d = nullptr;
     akz_descriptor* d_desc_tmp = nullptr;  // [B][max_kp]  descriptors before dropping out-of-bounds keypoints
     uint32_t* d_flag_d = nullptr;          // [B][max_kp]
+    uint32_t* d_perm = nullptr;            // [B][max_kp] spatially coherent visiting order for the descriptor stage
     DevKp* d_kp_out = nullptr;             // [B][max_kp]  final (internal copy used by the host-buffer API)
     akz_descriptor* d_desc_out = nullptr;  // [B][max_kp]
     uint32_t* d_n_out = nullptr;           // [B]

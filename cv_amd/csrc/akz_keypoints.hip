@@ -492,6 +492,53 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
     if (threadIdx.x == 0) n_out[frame] = m;
 }
 
+// Visiting order for the descriptor stage.  The response-sorted list is spatially random, so four
+// consecutive keypoints (one workgroup) sample four unrelated 40-80 px patches and thrash the 32 KB L1.
+// This kernel sorts the keypoint INDICES by (level, 32-px tile row, 32-px tile column); k_describe_fast
+// walks that permutation and still writes each descriptor to its keypoint's own slot, so the output order
+// (response descending) is untouched.
+__global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevKp* __restrict__ in,
+                                                        const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                        uint32_t* __restrict__ perm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    const int frame = blockIdx.x;
+    const uint32_t n = min(n_in[frame], stride);
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const DevKp* src = in + (size_t)frame * stride;
+    for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            const DevKp kp = src[i];
+            const float ratio = (float)(1u << kp.octave);
+            uint32_t tx = (uint32_t)max(kp.x / ratio, 0.0f) >> 5, ty = (uint32_t)max(kp.y / ratio, 0.0f) >> 5;
+            uint32_t sk = (min(kp.class_id, 63u) << 24) | (min(ty, 4095u) << 12) | min(tx, 4095u);
+            k = ((unsigned long long)sk << 32) | (unsigned long long)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = key[i], b = key[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) perm[(size_t)frame * stride + i] = (uint32_t)(key[i] & 0xFFFFFFFFull);
+}
+
 // ---------------------------------------------------------------------------------------------
 // A16 + A17: M-LDB descriptor, one wave per keypoint.  Lane c (< n_cells) accumulates cell c of the
 // three sampling grids sequentially in the reference's (k outer, l inner) order; the comparisons
@@ -663,6 +710,7 @@ __device__ __forceinline__ bool desc_grid(const float* __restrict__ LT, const fl
 __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescTables* __restrict__ desc_p,
                                                        const DevKp* __restrict__ in,
                                                        const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                       const uint32_t* __restrict__ perm,
                                                        akz_descriptor* __restrict__ out, uint32_t* __restrict__ flag)
 {
     constexpr int SMAX = 448;  // >= 441 samples of the largest grid
@@ -672,8 +720,9 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
     const int frame = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n = min(n_in[frame], stride);
-    const uint32_t ki = blockIdx.x * 4 + wv;
-    if (ki >= n) return;  // whole wave; no block-level barrier below
+    const uint32_t vi = blockIdx.x * 4 + wv;
+    if (vi >= n) return;  // whole wave; no block-level barrier below
+    const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
     const DevKp kp = in[(size_t)frame * stride + ki];
     const LevelDesc& L = T.L[kp.class_id];
     // get_mldb_descriptor, descriptors.rs:66-72
@@ -867,8 +916,11 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     AKZ_LAUNCH_CHECK();
     // A16 + A17
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
+        hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, T, S.d_kp_d,
+                           S.d_n_d, c->max_kp, S.d_perm);
+        AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
-                           S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
+                           S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);
     } else {
         hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
