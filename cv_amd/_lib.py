@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
     "akz_half_size", "hm_create", "hm_destroy", "hm_knn2", "hm_match", "hm_match_batch_device", "hm_sync",
-    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_debug_counts",
+    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
 ]
@@ -115,6 +115,7 @@ def lib():
     L.rs_destroy.argtypes = [vp]
     L.rs_calibrate.argtypes = [vp, i32, C.c_double, vp, u32, vp]
     L.rs_essential_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
+    L.rs_p3p_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
     L.rs_debug_counts.argtypes = [vp, vp, u32]
     L.akz_timing_enable.argtypes = [vp, i32]
     L.akz_timing_reset.argtypes = [vp]

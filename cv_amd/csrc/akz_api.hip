@@ -147,6 +147,8 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
         if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
     }
+    const char* dts = getenv("AKZ_DESC_TILE_SHIFT");
+    if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
     const char* fb = getenv("AKZ_FED_BLOCK");
     if (fb && fb[0] >= '1' && fb[0] <= '4') c->fed_block = fb[0] - '0';
     const char* pipe = getenv("AKZ_PIPELINE");

@@ -57,6 +57,7 @@ struct akz_ctx {
     int max_w = 0, max_h = 0, max_batch = 0;
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
     uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
+    int desc_tile_shift = 5;  // log2 of the tile edge of the descriptor visiting order; env AKZ_DESC_TILE_SHIFT
     int fed_block = 4;        // FED steps fused per launch (1 = one launch per step); env AKZ_FED_BLOCK
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
 

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
 // (response descending) is untouched.
 __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevKp* __restrict__ in,
                                                         const uint32_t* __restrict__ n_in, uint32_t stride,
-                                                        uint32_t* __restrict__ perm)
+                                                        uint32_t* __restrict__ perm, int tile_shift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevK
         if (i < n) {
             const DevKp kp = src[i];
             const float ratio = (float)(1u << kp.octave);
-            uint32_t tx = (uint32_t)max(kp.x / ratio, 0.0f) >> 5, ty = (uint32_t)max(kp.y / ratio, 0.0f) >> 5;
+            uint32_t tx = (uint32_t)max(kp.x / ratio, 0.0f) >> tile_shift, ty = (uint32_t)max(kp.y / ratio, 0.0f) >> tile_shift;
             uint32_t sk = (min(kp.class_id, 63u) << 24) | (min(ty, 4095u) << 12) | min(tx, 4095u);
             k = ((unsigned long long)sk << 32) | (unsigned long long)i;
         }
@@ -917,7 +917,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A16 + A17
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
         hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, T, S.d_kp_d,
-                           S.d_n_d, c->max_kp, S.d_perm);
+                           S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);

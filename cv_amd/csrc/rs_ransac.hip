@@ -17,6 +17,7 @@
 
 #include "akz_common.h"
 #include "../../include/akz_ransac_math.h"
+#include "../../include/akz_p3p_math.h"
 
 namespace {
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64) void k_rs_hypotheses(const double* __restrict__
             good = good && finite_d(t[r]);
         }
     }
-    ok[hh] = good ? 1u : 0u;
+    for (int p = 0; p < 4; ++p) ok[(size_t)hh * 4 + p] = good ? 1u : 0u;  // validity per pose
 }
 
 // CameraToCamera::residual for one (pose, match) — cv-core/src/pose.rs:249-295.
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba,
                                                   uint32_t* __restrict__ counts)
 {
     const uint32_t pid = blockIdx.y;
-    if (!ok[pid >> 2]) return;
+    if (!ok[pid]) return;
     const uint32_t m = blockIdx.x * 256 + threadIdx.x;
     bool inl = false;
     if (m < n) {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_rs_best(const uint32_t* __restrict__ c
     __shared__ unsigned long long s_key[16];
     unsigned long long key = 0ull;  // 0 = nothing valid
     for (uint32_t i = threadIdx.x; i < n_pose; i += 1024)
-        if (ok[i >> 2]) {
+        if (ok[i]) {
             unsigned long long k = ((unsigned long long)(counts[i] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
             key = k > key ? k : key;
         }
@@ -278,13 +279,97 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
     if (threadIdx.x == 0) *n_inliers = base;
 }
 
+// ---- PnP: Lambda Twist hypotheses + WorldToCamera residual (row R5) ----------------------------------
+__global__ __launch_bounds__(64) void k_p3p_hypotheses(const double* __restrict__ bearings, const double* __restrict__ world,
+                                                       const uint32_t* __restrict__ sample_idx, uint32_t n_hyp,
+                                                       double* __restrict__ poses, uint32_t* __restrict__ ok)
+{
+    const uint32_t hh = blockIdx.x * 64 + threadIdx.x;
+    if (hh >= n_hyp) return;
+    double b3[9], w3[12], P[48];
+    for (int i = 0; i < 3; ++i) {
+        uint32_t m = sample_idx[(size_t)hh * 3 + i];
+        for (int k = 0; k < 3; ++k) b3[3 * i + k] = bearings[(size_t)3 * m + k];
+        for (int k = 0; k < 4; ++k) w3[4 * i + k] = world[(size_t)4 * m + k];
+    }
+    int np = akz_p3p_poses(b3, w3, 5, P);  // LambdaTwist::default(): 5 Gauss-Newton iterations
+    for (int p = 0; p < 4; ++p) {
+        ok[(size_t)hh * 4 + p] = p < np ? 1u : 0u;
+        if (p < np)
+            for (int i = 0; i < 12; ++i) poses[(size_t)hh * 48 + p * 12 + i] = P[p * 12 + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ bearings, const double* __restrict__ world,
+                                                   uint32_t n, const double* __restrict__ poses,
+                                                   const uint32_t* __restrict__ ok, double thresh,
+                                                   uint32_t* __restrict__ counts)
+{
+    const uint32_t pid = blockIdx.y;
+    if (!ok[pid]) return;
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    bool inl = false;
+    if (m < n) {
+        double pose[12];
+        for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+        double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
+        double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
+        inl = akz_w2c_residual(pose, b, w) < thresh;
+    }
+    unsigned long long bal = __ballot(inl);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
+}
+
+__global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__ bearings, const double* __restrict__ world,
+                                                      uint32_t n, const double* __restrict__ poses,
+                                                      const uint32_t* __restrict__ best, double thresh,
+                                                      uint32_t* __restrict__ inlier_idx, uint32_t cap,
+                                                      uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t pid = best[0];
+    if (pid == 0xFFFFFFFFu) {
+        if (threadIdx.x == 0) *n_inliers = 0;
+        return;
+    }
+    double pose[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t base = 0;
+    for (uint32_t m0 = 0; m0 < n; m0 += 1024) {
+        uint32_t m = m0 + threadIdx.x;
+        bool inl = false;
+        if (m < n) {
+            double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
+            double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
+            inl = akz_w2c_residual(pose, b, w) < thresh;
+        }
+        unsigned long long bal = __ballot(inl);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (inl) {
+            uint32_t o = base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) inlier_idx[o] = m;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_inliers = base;
+}
+
 }  // namespace
 
 struct rs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t max_matches = 0, max_hyp = 0;
-    double *d_a = nullptr, *d_b = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
+    double *d_a = nullptr, *d_b = nullptr, *d_w = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
     uint32_t *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_best = nullptr, *d_inl = nullptr,
              *d_ninl = nullptr;
     uint32_t last_hyp = 0;
@@ -306,7 +391,8 @@ extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_
     AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * (size_t)max_hyp));
     AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12));
     AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * (size_t)max_hyp));
-    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * (size_t)max_hyp));
+    AKZ_HIP(hipMalloc(&c->d_w, sizeof(double) * 4 * (size_t)max_matches));
     AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * (size_t)max_hyp));
     AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
     AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
@@ -320,7 +406,7 @@ extern "C" int32_t rs_destroy(rs_ctx* c)
     if (!c) return AKZ_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
+    hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
     hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -374,7 +460,7 @@ extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const
     for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
         uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
         hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
-                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0 / 4, thresh, c->d_counts + p0);
+                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
         AKZ_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
@@ -407,4 +493,54 @@ extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_HIP(hipMemcpy(counts, c->d_counts, sizeof(uint32_t) * 4 * (size_t)c->last_hyp, hipMemcpyDeviceToHost));
     return AKZ_OK;
+}
+
+// Consensus::model_inliers(&LambdaTwist::new(), world_matches) with the sampler factored out
+// (cv-sfm/src/lib.rs:1619-1622; lambda-twist/tests/consensus.rs:59-61): n_hyp sample triples.
+extern "C" int32_t rs_p3p_batch(rs_ctx* c, const double* bearings, const double* world, uint32_t n,
+                                const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
+                                uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
+{
+    if (!c || !bearings || !world || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
+        return AKZ_E_INVALID;
+    if (n < 3 || n_hyp == 0) return AKZ_E_INVALID;  // LambdaTwist::MIN_SAMPLES (lambda-twist/src/lib.rs:333)
+    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+    for (size_t i = 0; i < (size_t)n_hyp * 3; ++i)
+        if (sample_idx[i] >= n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    AKZ_HIP(hipMemcpyAsync(c->d_a, bearings, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_w, world, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 3 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+    hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
+                       c->d_poses, c->d_ok);
+    AKZ_LAUNCH_CHECK();
+    const uint32_t n_pose = n_hyp * 4;
+    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+        hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_w, n,
+                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+        AKZ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, thresh,
+                       c->d_inl, n, c->d_ninl, c->d_best_pose);
+    AKZ_LAUNCH_CHECK();
+    uint32_t best[2] = {0, 0}, ninl = 0;
+    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipStreamSynchronize(s));
+    c->last_hyp = n_hyp;
+    *best_id = best[0];
+    *n_inliers = ninl;
+    if (best[0] == 0xFFFFFFFFu) {
+        *n_inliers = 0;
+        return AKZ_OK;
+    }
+    uint32_t ncopy = ninl < cap ? ninl : cap;
+    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
 }

@@ -66,6 +66,20 @@ class EssentialConsensus:
             return None
         return pose, inl[:ninl.value].copy(), best.value
 
+    def p3p_model_inliers(self, bearings, world, sample_idx, threshold):
+        """Consensus::model_inliers(&LambdaTwist::new(), ...): bearings [n,3], world [n,4] homogeneous
+        (Projective form), sample_idx [n_hyp,3].  Returns (pose [3,4], inliers, best_id) or None."""
+        b = np.ascontiguousarray(bearings, np.float64); w = np.ascontiguousarray(world, np.float64)
+        si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 3)
+        n = len(b)
+        pose = np.empty((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
+        inl = np.empty(max(n, 1), np.uint32)
+        check(_lib.lib().rs_p3p_batch(self._h, b.ctypes.data, w.ctypes.data, n, si.ctypes.data, len(si), float(threshold),
+                                      pose.ctypes.data, C.byref(best), inl.ctypes.data, n, C.byref(ninl)), "rs_p3p_batch")
+        if best.value == 0xFFFFFFFF:
+            return None
+        return pose, inl[:ninl.value].copy(), best.value
+
     def counts(self, n_hyp):
         out = np.zeros((n_hyp, 4), np.uint32)
         check(_lib.lib().rs_debug_counts(self._h, out.ctypes.data, out.size), "rs_debug_counts")

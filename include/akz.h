@@ -216,7 +216,15 @@ int32_t rs_calibrate(const double* intrinsics, int32_t use_k1, double k1, const 
 int32_t rs_essential_batch(rs_ctx* ctx, const double* bearings_a, const double* bearings_b, uint32_t n,
                            const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
                            uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers);
-/* parity tap: inlier counts [n_hyp][4] of the last rs_essential_batch call */
+/* Consensus::model_inliers(&LambdaTwist::new(), matches) for 3D-2D registration (cv-sfm/src/lib.rs:1619-1622,
+ * lambda-twist/tests/consensus.rs:59-61), sampler factored out as above: n_hyp sample triples; each gives up
+ * to four WorldToCamera poses (lambda-twist/src/lib.rs:107-318), scored with WorldToCamera::residual
+ * (cv-core/src/pose.rs:194-201) < thresh.  bearings [n][3] unit vectors, world [n][4] homogeneous points in the
+ * reference's Projective form (xyz normalised, w = 1/distance). */
+int32_t rs_p3p_batch(rs_ctx* ctx, const double* bearings, const double* world, uint32_t n,
+                     const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
+                     uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers);
+/* parity tap: inlier counts [n_hyp][4] of the last rs_essential_batch / rs_p3p_batch call */
 int32_t rs_debug_counts(rs_ctx* ctx, uint32_t* counts, uint32_t cap);
 
 /* ---- misc ---- */

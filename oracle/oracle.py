@@ -50,7 +50,7 @@ BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6,
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -113,6 +113,11 @@ def lib():
         L.orc_essential_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double,
                                           C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
+        L.orc_p3p_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_w2c_residual.restype = C.c_double
+        L.orc_w2c_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_p3p_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_pm_atan2f_v.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_pm_sincosf_v.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         _lib = L
@@ -362,6 +367,33 @@ def essential_batch(ba, bb, sample_idx, thresh):
     counts = np.zeros((len(si), 4), np.uint32)
     r = lib().orc_essential_batch(ba.ctypes.data, bb.ctypes.data, n, si.ctypes.data, len(si), thresh, 1e-12, 1000,
                                   pose.ctypes.data, C.byref(best), inl.ctypes.data, C.byref(ninl), counts.ctypes.data)
+    if r != 0:
+        return None
+    return pose, best.value, inl[:ninl.value].copy(), counts
+
+
+# ---- PnP: Lambda Twist + WorldToCamera residual (p3p_oracle.c) -----------------------------------------
+def p3p_poses(bearings3, world3):
+    """LambdaTwist::estimate on 3 (bearing [3], homogeneous world point [4]) samples -> [k,3,4] poses."""
+    b = _f64(bearings3).reshape(3, 3); w = _f64(world3).reshape(3, 4)
+    out = np.empty((4, 3, 4), np.float64)
+    k = lib().orc_p3p_poses(b.ctypes.data, w.ctypes.data, out.ctypes.data)
+    return out[:k].copy()
+
+
+def w2c_residual(pose, bearing, world):
+    pose = _f64(pose); bearing = _f64(bearing); world = _f64(world)
+    return lib().orc_w2c_residual(pose.ctypes.data, bearing.ctypes.data, world.ctypes.data)
+
+
+def p3p_batch(bearings, world, sample_idx, thresh):
+    b = _f64(bearings); w = _f64(world)
+    si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 3)
+    n = len(b)
+    pose = np.empty((3, 4), np.float64); best = C.c_uint32(); inl = np.empty(max(n, 1), np.uint32); ninl = C.c_uint32()
+    counts = np.zeros((len(si), 4), np.uint32)
+    r = lib().orc_p3p_batch(b.ctypes.data, w.ctypes.data, n, si.ctypes.data, len(si), thresh, pose.ctypes.data,
+                            C.byref(best), inl.ctypes.data, C.byref(ninl), counts.ctypes.data)
     if r != 0:
         return None
     return pose, best.value, inl[:ninl.value].copy(), counts

@@ -351,3 +351,38 @@ def test_ransac_estimate_pose_pin(gpu, kitti, oracle):
     wpose, wbest, winl, _ = oracle.essential_batch(a, b, samples, 0.1)
     assert best == wbest
     _eq(pose, wpose, "kitti pose")
+
+
+def test_p3p_bit_exact(gpu, oracle):
+    """R5: Lambda Twist hypotheses + WorldToCamera residual consensus: counts, winning pose bits, id and inlier
+    set equal the oracle's, on the reference's two consensus scenes and on a random scene with outliers."""
+    import itertools
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import arrsac_manual_scene, endless_loop_scene, _projective, _rot
+    cons = EssentialConsensus(2048, 4096)
+    R, t, b, w = arrsac_manual_scene()
+    scenes = [(b, w, np.array(list(itertools.permutations(range(5), 3)), np.uint32), 0.01)]
+    b2, w2 = endless_loop_scene()
+    scenes.append((b2, w2, np.array(list(itertools.combinations(range(9), 3)), np.uint32), 0.01))
+    rng = np.random.default_rng(77)
+    n = 500
+    Rr = _rot(rng.random(3) * 0.8); tr = rng.random(3)
+    pts = rng.random((n, 3)) * 4.0 - 2.0
+    pts[:, 2] += 6.0
+    cam = pts @ Rr.T + tr
+    bb = cam / np.linalg.norm(cam, axis=1, keepdims=True)
+    bad = rng.random(n) < 0.3
+    rb = rng.standard_normal((n, 3)); rb[:, 2] = np.abs(rb[:, 2]) + 0.5
+    bb[bad] = (rb / np.linalg.norm(rb, axis=1, keepdims=True))[bad]
+    scenes.append((bb, _projective(pts), np.stack([rng.choice(n, 3, replace=False) for _ in range(1000)]).astype(np.uint32), 1e-6))
+    for b, w, samples, thr in scenes:
+        got = cons.p3p_model_inliers(b, w, samples, thr)
+        want = oracle.p3p_batch(b, w, samples, thr)
+        assert (got is None) == (want is None)
+        wpose, wbest, winl, wcounts = want
+        _eq(cons.counts(len(samples)), wcounts, "p3p counts")
+        pose, inl, best = got
+        assert best == wbest
+        _eq(pose, wpose, "p3p pose")
+        _eq(inl, winl, "p3p inliers")
+    assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6

@@ -97,3 +97,65 @@ def test_calibrate_k1(oracle):
     s = plain[:, :2] / plain[:, 2:3]
     n = d[:, :2] / d[:, 2:3]
     assert np.allclose(n, s / (1 + k1 * (s ** 2).sum(1, keepdims=True)), atol=1e-12)
+
+
+# ---- PnP: Lambda Twist (lambda-twist/tests/consensus.rs) --------------------------------------------------
+def _euler(r, p, y):
+    """Rotation3::from_euler_angles(roll, pitch, yaw) = Rz(yaw) Ry(pitch) Rx(roll)."""
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]]); Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _projective(points):
+    """Projective::from_point: homogeneous [x, y, z, 1] with xyz normalised (cv-core/src/point.rs:20-25,44-46)."""
+    h = np.concatenate([points, np.ones((len(points), 1))], 1)
+    return h / np.linalg.norm(h[:, :3], axis=1, keepdims=True)
+
+
+def _bearings(xy):
+    b = np.concatenate([xy, np.ones((len(xy), 1))], 1)
+    return b / np.linalg.norm(b, axis=1, keepdims=True)
+
+
+def arrsac_manual_scene():
+    """lambda-twist/tests/consensus.rs:20-57."""
+    cam = np.array([[-0.228125, -0.061458334, 1.0], [0.41875, -0.58125, 2.0], [1.128125, 0.878125, 3.0],
+                    [-0.528125, 0.178125, 2.5], [-0.923424, -0.235125, 2.8]])
+    R = _euler(0.1, 0.2, 0.3); t = np.array([0.1, 0.2, 0.3])
+    world = (cam - t) @ R                       # pose.inverse() * p
+    return R, t, _bearings(cam[:, :2] / cam[:, 2:3]), _projective(world)
+
+
+def endless_loop_scene():
+    """lambda-twist/tests/consensus.rs:72-127."""
+    a = (0.3070512144698557, 0.19317668016026052); b = (0.3208462966353674, 0.20741702947913013)
+    xy = np.array([a, b, a, b, b, a, (0.26619553978146293, 0.15033756455213498),
+                   (0.3494806979265859, 0.18264329458710366), (0.32132193890323213, 0.15408143785084824)])
+    pts = np.array([[1, 1, 0], [1, 1.5, 0], [3, 1, 0], [1, 2, 0], [2, 2, 0], [3, 2, 0], [1, 3, 0], [2, 3, 0], [3, 3, 0]], float)
+    return _bearings(xy), _projective(pts)
+
+
+def test_p3p_arrsac_manual_pose(oracle):
+    """lambda-twist/tests/consensus.rs:17-67: the pose is recovered within 1e-6 (threshold 0.01)."""
+    R, t, b, w = arrsac_manual_scene()
+    samples = np.array(list(itertools.permutations(range(5), 3)), np.uint32)
+    pose, best, inl, counts = oracle.p3p_batch(b, w, samples, 0.01)
+    assert len(inl) == 5
+    assert np.abs(pose[:, :3] - R).max() < 1e-6 and np.abs(pose[:, 3] - t).max() < 1e-6
+    # every minimal sample yields between 1 and 4 candidate poses, the true one among them
+    for s in samples[:10]:
+        P = oracle.p3p_poses(b[s], w[s])
+        assert 1 <= len(P) <= 4
+        assert min(np.abs(p[:, :3] - R).max() for p in P) < 1e-6
+        for p in P:
+            assert max(oracle.w2c_residual(p, b[i], w[i]) for i in s) < 1e-9   # each pose explains its own sample
+
+
+def test_p3p_endless_loop_case_terminates(oracle):
+    """lambda-twist/tests/consensus.rs:69-134: a degenerate 9-sample case must terminate and give a model."""
+    b, w = endless_loop_scene()
+    samples = np.array(list(itertools.combinations(range(9), 3)), np.uint32)
+    out = oracle.p3p_batch(b, w, samples, 0.01)
+    assert out is not None and len(out[2]) >= 3
