@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=128, help="frames per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "single-GPU smoke test of the multi-rank path)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
+    ap.add_argument("--dump-matches", default=None, help="write per-global-frame keypoint/match counts to this .npy")
     args = ap.parse_args()
 
     import torch
@@ -100,11 +104,16 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from cv_amd import build
     if world > 1:               # one rank builds (normally a no-op: the .so travels with the tree), the rest wait
@@ -218,6 +227,31 @@ def main():
             iso["frac"] = round(iso["achieved"] / HBM_PEAK_GBS, 4)
     if world > 1:
         dist.barrier()
+
+    if args.dump_matches:
+        # per GLOBAL frame g = j*world + rank: [keypoints, matches of (g, g-1)]; problem order follows `js`
+        # within each micro-batch, so the match count of local frame j is looked up through the same schedule
+        per_frame = torch.zeros((NF, 2), dtype=torch.int32, device=dev)
+        per_frame[:, 0] = counts
+        slot = 0
+        for m0 in range(0, NF, MB):
+            if world > 1:
+                if rank > 0:
+                    js = list(range(m0, m0 + MB))
+                else:
+                    js = list(range(m0 + 1, m0 + MB)) + ([m0] if m0 > 0 else []) + ([0] if m0 + MB == NF else [])
+            else:
+                js = [j for j in range(m0, m0 + MB) if j > 0] + ([0] if m0 + MB == NF else [])
+            for q, j in enumerate(js):
+                per_frame[j, 1] = npairs[m0 + q]
+        allf = [torch.zeros_like(per_frame) for _ in range(world)] if world > 1 else [per_frame]
+        if world > 1:
+            dist.all_gather(allf, per_frame)
+        if rank == 0:
+            glob = np.zeros((NF * world, 2), np.int32)
+            for r in range(world):
+                glob[r::world] = allf[r].cpu().numpy()
+            np.save(args.dump_matches, glob)
 
     n_kp = counts.float().mean().item()
     n_match = npairs[:NF].float().mean().item()

@@ -17,6 +17,16 @@ def global_index(rank, j, world):
     return j * world + rank
 
 
+def _all_gather(dist, out, inp):
+    """out[r] <- rank r's inp.  One collective; RCCL (backend "nccl") takes the fused single-buffer form, the
+    list form is the fallback for backends without it (gloo on device tensors, used only by the 1-GPU smoke
+    test of the multi-rank path)."""
+    try:
+        dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1))
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather(list(out.unbind(0)), inp.contiguous())
+
+
 def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, gath_d, gath_n, prev_descs,
                           prev_counts):
     """After the local frames [m0, m0+mb) of every rank have been extracted, all-gather their descriptor
@@ -26,8 +36,8 @@ def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, ga
     Returns the local frames whose predecessor block became available with this call (and can be
     matched now).  Tensors: descs_mb [mb,cap,64] u8, counts_mb [mb] i32, gath_d [world,mb,cap,64],
     gath_n [world,mb], prev_descs [nf,cap,64], prev_counts [nf]."""
-    dist.all_gather_into_tensor(gath_d.view(-1), descs_mb.reshape(-1))
-    dist.all_gather_into_tensor(gath_n.view(-1), counts_mb)
+    _all_gather(dist, gath_d, descs_mb)
+    _all_gather(dist, gath_n, counts_mb)
     if rank > 0:
         # predecessor of (rank, j) is (rank-1, j): same micro-batch
         prev_descs[m0:m0 + mb].copy_(gath_d[rank - 1])

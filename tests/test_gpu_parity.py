@@ -386,3 +386,28 @@ def test_p3p_bit_exact(gpu, oracle):
         _eq(pose, wpose, "p3p pose")
         _eq(inl, winl, "p3p inliers")
     assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6
+
+
+def test_two_rank_path_matches_single_rank(gpu, tmp_path):
+    """The N>1 path of bench.py end to end on ONE GPU: two ranks (gloo, both on cuda:0) shard 32 global frames
+    g -> rank g % 2, all-gather the descriptor blocks and match every frame against its predecessor; the
+    per-global-frame keypoint and match counts must equal the single-rank run over the same 32 frames."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m1, m2 = tmp_path / "m1.npy", tmp_path / "m2.npy"
+    common = ["--micro-batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = dict(os.environ); env.pop("AKZ_KEEP_ALL", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "32", "--dump-matches", str(m1)] + common,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--frames", "16", "--backend", "gloo", "--share-device",
+                        "--dump-matches", str(m2)] + common,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = np.load(m1), np.load(m2)
+    assert a.shape == b.shape == (32, 2)
+    assert np.array_equal(a, b), (a.T, b.T)
+    assert a[:, 0].min() > 1000 and a[:, 1].min() > 500
