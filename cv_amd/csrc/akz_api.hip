@@ -143,6 +143,7 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
     if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
         st = AKZ_E_HIP;
+    if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_input, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
     for (int b = 0; b < 2 && st == AKZ_OK; ++b) {
         if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
@@ -174,6 +175,7 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
     if (c->arena) hipFree(c->arena);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_kp) hipStreamDestroy(c->stream_kp);
+    if (c->ev_input) hipEventDestroy(c->ev_input);
     for (int b = 0; b < 2; ++b) {
         if (c->ev_ss_done[b]) hipEventDestroy(c->ev_ss_done[b]);
         if (c->ev_kp_done[b]) hipEventDestroy(c->ev_kp_done[b]);
@@ -237,11 +239,6 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_npoints = cv.take<uint32_t>(B);
     S.d_contrast = cv.take<double>(B);
     S.d_invk = cv.take<float>(B * 8);
-    size_t rows = P.total_rows + 1;
-    // the row table is sized for the tallest pyramid the context can see
-    size_t max_rows = (size_t)c->max_h * 2 * (size_t)c->cfg.num_sublevels + 64;
-    if (rows > max_rows) max_rows = rows;
-    S.d_rowcount = cv.take<uint32_t>(B * max_rows);
     S.d_ncand = cv.take<uint32_t>(B * 32);
     S.d_cand = cv.take<uint2>(B * 32 * (size_t)c->max_cand);
     const size_t K = c->max_kp;
@@ -334,11 +331,8 @@ static int32_t sync_all(akz_ctx* c)
 static int32_t wait_for(akz_ctx* c, void* stream_to_wait)
 {
     if (!stream_to_wait) return AKZ_OK;
-    hipEvent_t ev;
-    AKZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    AKZ_HIP(hipEventRecord(ev, (hipStream_t)stream_to_wait));
-    AKZ_HIP(hipStreamWaitEvent(c->stream, ev, 0));
-    AKZ_HIP(hipEventDestroy(ev));
+    AKZ_HIP(hipEventRecord(c->ev_input, (hipStream_t)stream_to_wait));
+    AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev_input, 0));
     return AKZ_OK;
 }
 

@@ -44,7 +44,6 @@ struct AkzPlan {
     std::vector<AkzLevel> levels;
     int n_octaves = 0;
     size_t sum_pixels = 0;
-    size_t total_rows = 0;
 };
 // Host scalar math (no device work): evolution.rs:46-126 + fed_tau.rs:26-93.
 void akz_build_plan(const akz_config& cfg, int w, int h, AkzPlan* plan);

@@ -29,7 +29,6 @@ struct AkzSet {
     double* d_contrast = nullptr;          // [B]
     float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
     // keypoint stage
-    uint32_t* d_rowcount = nullptr;        // [B][total_rows+1] candidate count per pyramid row, then offsets
     uint32_t* d_ncand = nullptr;           // [B][32] candidates per (frame, level)
     uint2* d_cand = nullptr;               // [B][32][max_cand] {x | y << 16, response bits}, raster-sorted per level
     DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
@@ -77,6 +76,7 @@ struct akz_ctx {
     hipEvent_t ev_ss_done[2] = {nullptr, nullptr};  // pyramid + candidates of set b ready
     hipEvent_t ev_kp_done[2] = {nullptr, nullptr};  // keypoint stage of set b finished (pyramid reusable)
     bool kp_pending[2] = {false, false};
+    hipEvent_t ev_input = nullptr;                  // orders the caller's producer stream before our scale-space stream
     AkzSet& S() { return sets[cur]; }
     uint32_t* d_err = nullptr;             // [1] sticky device-side overflow flag
     void* d_ori = nullptr;                 // OriTables (orientation sample/window tables)

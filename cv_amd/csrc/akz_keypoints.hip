@@ -41,13 +41,11 @@ struct LevelDesc {  // per-level constants for the keypoint kernels
     size_t fs;        // frame stride (pixels)
     uint32_t octave;
     float kp_size;    // (esigma * derivative_factor) as f32
-    uint32_t row_base;  // index of this level's row 0 in the per-frame row table
 };
 constexpr int kMaxLevels = 32;
 struct LevelTable {
     LevelDesc L[kMaxLevels];
     int n;
-    uint32_t total_rows;
 };
 
 // A12a (candidate test + border test) is fused into the second-order derivative kernel and followed by a
@@ -757,7 +755,6 @@ void build_level_table(akz_ctx* c, LevelTable* T)
     const AkzPlan& P = c->plan;
     AkzSet& S = c->S();
     T->n = (int)P.levels.size();
-    uint32_t rb = 0;
     for (int i = 0; i < T->n; ++i) {
         const AkzLevel& L = P.levels[i];
         LevelDesc& d = T->L[i];
@@ -769,10 +766,7 @@ void build_level_table(akz_ctx* c, LevelTable* T)
         d.fs = L.pixels();
         d.octave = L.octave;
         d.kp_size = L.kp_size;
-        d.row_base = rb;
-        rb += (uint32_t)L.h;
     }
-    T->total_rows = rb;
 }
 
 }  // namespace

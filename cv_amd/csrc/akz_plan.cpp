@@ -101,10 +101,8 @@ void akz_build_plan(const akz_config& cfg, int w, int h, AkzPlan* plan)
         plan->levels[i].tau = fed_tau_cycle(ttime / 1.0, 0.25);
     }
     plan->sum_pixels = 0;
-    plan->total_rows = 0;
     for (auto& L : plan->levels) {
         plan->sum_pixels += L.pixels();
-        plan->total_rows += (size_t)L.h;
         if ((int)L.octave + 1 > plan->n_octaves) plan->n_octaves = (int)L.octave + 1;
     }
 }
