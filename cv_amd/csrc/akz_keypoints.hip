@@ -236,6 +236,8 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
                                                       uint32_t* __restrict__ flag)
 {
     __shared__ uint32_t s_lo[kMaxLevels + 1], s_hi[kMaxLevels + 1];
+    __shared__ float4 s_j[256];  // x, y, response, class bits of a tile of later entries
+    __shared__ uint32_t s_range[2];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
     const uint32_t i0 = blockIdx.x * 256;
@@ -245,6 +247,10 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
         s_lo[threadIdx.x] = 0xFFFFFFFFu;
         s_hi[threadIdx.x] = 0u;
     }
+    if (threadIdx.x == 0) {
+        s_range[0] = 0xFFFFFFFFu;
+        s_range[1] = 0u;
+    }
     __syncthreads();
     for (uint32_t j = i0 + threadIdx.x; j < n; j += 256) {  // only slots > i0 matter to this block
         uint32_t c = min(ch[j].class_id, (uint32_t)kMaxLevels);
@@ -253,26 +259,54 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
     }
     __syncthreads();
     const uint32_t i = i0 + threadIdx.x;
-    if (i >= n) return;
-    const DevKp ki = ch[i];
-    const uint32_t cn = min(ki.class_id + 1u, (uint32_t)kMaxLevels);
-    bool rep = false;
-    if (s_lo[cn] != 0xFFFFFFFFu) {
-        const uint32_t jb = max(i + 1u, s_lo[cn]), je = s_hi[cn];
-        const float size2 = ki.size * ki.size;
-        for (uint32_t j = jb; j <= je; ++j) {
-            const DevKp kj = ch[j];
-            if (kj.class_id == ki.class_id + 1u) {
-                float dx = ki.x - kj.x, dy = ki.y - kj.y;
-                float dist = dx * dx + dy * dy;
-                if (dist <= size2 && ki.response <= kj.response) {
-                    rep = true;
-                    break;
-                }
-            }
+    const bool valid = i < n;
+    DevKp ki;
+    ki.x = ki.y = ki.response = ki.size = 0.0f;
+    ki.class_id = kMaxLevels;
+    uint32_t jb = 1, je = 0;  // empty
+    if (valid) {
+        ki = ch[i];
+        const uint32_t cn = min(ki.class_id + 1u, (uint32_t)kMaxLevels);
+        if (s_lo[cn] != 0xFFFFFFFFu) {
+            jb = max(i + 1u, s_lo[cn]);
+            je = s_hi[cn];
+        }
+        if (jb <= je) {  // the union of the threads' ranges is what the block streams through LDS
+            atomicMin(&s_range[0], jb);
+            atomicMax(&s_range[1], je);
         }
     }
-    flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
+    __syncthreads();
+    const uint32_t rb = s_range[0], re = s_range[1];
+    bool rep = false;
+    const float size2 = ki.size * ki.size;
+    const uint32_t want = ki.class_id + 1u;
+    if (rb != 0xFFFFFFFFu) {
+        for (uint32_t t0 = rb; t0 <= re; t0 += 256) {
+            uint32_t j = t0 + threadIdx.x;
+            if (j <= re) {
+                const DevKp kj = ch[j];
+                s_j[threadIdx.x] = make_float4(kj.x, kj.y, kj.response, __uint_as_float(kj.class_id));
+            }
+            __syncthreads();
+            if (!rep && jb <= je) {
+                const uint32_t lo = max(jb, t0), hi = min(je, min(re, t0 + 255u));
+                for (uint32_t jj = lo; jj <= hi && lo <= hi; ++jj) {
+                    const float4 q = s_j[jj - t0];
+                    if (__float_as_uint(q.w) == want) {
+                        float dx = ki.x - q.x, dy = ki.y - q.y;
+                        float dist = dx * dx + dy * dy;
+                        if (dist <= size2 && ki.response <= q.z) {
+                            rep = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (valid) flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
 }
 
 // ordered compaction of a per-frame keypoint list (and optionally its descriptors): block per frame.
