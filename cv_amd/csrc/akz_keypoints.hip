@@ -693,10 +693,14 @@ __device__ __forceinline__ bool desc_grid(const float* __restrict__ LT, const fl
 {
     constexpr int CS = ST * ST;             // samples per cell
     constexpr int NS = SIDE * SIDE * CS;    // samples of the grid
+    constexpr int NIT = (NS + 63) / 64;     // gather rounds (7 for every grid of the default pattern)
     bool oob = false;
-#pragma unroll 2
-    for (int s0 = 0; s0 < NS; s0 += 64) {
-        const int s = s0 + lane;
+    // round 1: all sample addresses, then ALL gathers back to back (2 * NIT loads in flight per lane: the
+    // kernel is bound by gather latency, not by issue), round 2: rotate and park in LDS
+    int idx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
         const bool on = s < NS;
         const int cell = s / CS, rem = s - cell * CS;
         const int kk = rem / ST, ll = rem - kk * ST;
@@ -710,13 +714,22 @@ __device__ __forceinline__ bool desc_grid(const float* __restrict__ LT, const fl
         int x1 = sat_i32(roundf(sample_x));
         bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
         oob |= on && bad;
-        int idx = (on && !bad) ? y1 * W + x1 : 0;
-        float ri = LT[idx];
-        float2 d = LXY[idx];
-        float rry = d.x * co + d.y * si;     // descriptors.rs:151-152
-        float rrx = -d.x * si + d.y * co;
-        if (on) {
-            s_ri[s] = ri;
+        idx[it] = (on && !bad) ? y1 * W + x1 : 0;
+    }
+    float ri[NIT];
+    float2 dd[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        ri[it] = LT[idx[it]];
+        dd[it] = LXY[idx[it]];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
+        float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
+        float rrx = -dd[it].x * si + dd[it].y * co;
+        if (s < NS) {
+            s_ri[s] = ri[it];
             s_dx[s] = rrx;
             s_dy[s] = rry;
         }
