@@ -150,7 +150,68 @@ struct HmProbX {           // like HmProb, on the +-1 recoded descriptors
 };
 
 constexpr int kMfmaBlock = 512;   // 8 waves x 32 queries
-__global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restrict__ probs)
+
+// One 32-target x 32-query tile: 16 chained MFMAs (K = 512 = 16 x 32) with the LDS fragment reads kept
+// four deep in flight, then the (distance, row) keys and the tile's two smallest, merged into (k0, k1).
+// D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
+// key = hamming << 22 | target = ((512 - acc) << 21) | target = acc * -(1 << 21) + (512 << 21 | target):
+// one v_mad_i32_i24 per accumulator register.  TAIL (the last, partial tile) masks rows >= nt.
+template <bool TAIL>
+__device__ __forceinline__ void knn2_keys(const v16i32& nacc, uint32_t t0, uint32_t half, uint32_t nt, int& k0, int& k1)
+{
+    // nacc = -dot (the resident query fragments are negated).  The unsigned key (512 - dot) << 21 | row is
+    // carried as the signed value key - (512 << 21) = (nacc << 21) | row: one v_lshl_or_b32 per accumulator
+    // register with inline constants only; the lane's row offset (t0 + 4 * half) is added to the tile's two
+    // smallest afterwards (row bits never carry: row < 2^21).
+    const int row0 = (int)(t0 + 4u * half);
+    int l0 = 0x7FFFFFFF, l1 = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int off = (r & 3) + 8 * (r >> 2);
+        int key = (int)(((uint32_t)nacc[r] << 21) | (uint32_t)off);
+        if (TAIL) key = (uint32_t)(row0 + off) < nt ? key : 0x7FFFFFFF - row0;
+        if (r == 0) {
+            l0 = key;
+        } else {
+            int hi = max(l0, key);
+            l0 = min(l0, key);
+            l1 = min(l1, hi);
+        }
+    }
+    l0 += row0;            // masked keys become INT_MAX again
+    l1 += row0;
+    int hi = max(k0, l0);
+    k0 = min(k0, l0);
+    k1 = min(hi, min(k1, l1));
+}
+
+__device__ __forceinline__ void knn2_tile(const uint4* __restrict__ tp, const v4i32 (&qb)[16], uint32_t t0,
+                                          uint32_t half, uint32_t nt, int& k0, int& k1)
+{
+    v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint4 f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f[k] = tp[2 * k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint4 av = f[k & 3];
+        v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+        if (k + 4 < 16) f[k & 3] = tp[2 * (k + 4)];
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[k], acc, 0, 0, 0);
+    }
+    // keep the fragment reads four deep ahead of the dependent MFMA chain
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (t0 + 32u <= nt) knn2_keys<false>(acc, t0, half, nt, k0, k1);
+    else knn2_keys<true>(acc, t0, half, nt, k0, k1);
+}
+
+__global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __restrict__ probs)
 {
     // target tile: 32 descriptors x 512 B, rows padded to 33 x 16 B so the 16-byte fragment reads of the
     // 32 rows fall on distinct bank groups; double-buffered, filled with full 512-B-row coalesced loads
@@ -170,7 +231,7 @@ __global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restr
         uint32_t qi = min(q0 + col, nq - 1u);
         const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 128) + half;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) qb[k] = qp[2 * k];
+        for (int k = 0; k < 16; ++k) qb[k] = qp[2 * k] ^ (int)0xFEFEFEFE;   // +-1 bytes negated (see knn2_keys)
     }
     const uint4* tg = reinterpret_cast<const uint4*>(P.t);  // 32 uint4 per descriptor
     // staging map: thread -> 2 x (row, 16-byte column): idx = tid + 512 i, row = idx >> 5, c = idx & 31
@@ -180,7 +241,7 @@ __global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restr
     st1 = tg[(size_t)min(srow1, nt - 1u) * 32 + scol];
     s_t[0][srow0 * RS + scol] = st0;
     s_t[0][srow1 * RS + scol] = st1;
-    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    int k0 = 0x7FFFFFFF, k1 = 0x7FFFFFFF;                // signed keys, see knn2_keys
     int buf = 0;
     for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
         __syncthreads();                                 // tile `buf` is complete; tile `buf^1` is free
@@ -191,26 +252,7 @@ __global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restr
         }
         if (wave_on) {
             const uint4* tp = &s_t[buf][col * RS + half];
-            v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                uint4 av = tp[2 * k];
-                v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[k], acc, 0, 0, 0);
-            }
-            // D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
-            // key = hamming << 22 | target = ((512 - acc) << 21) | target = (512 << 21 | target) - (acc << 21)
-            const uint32_t base = (512u << 21) | (t0 + 4u * half);
-            const bool full = t0 + 32u <= nt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t off = (uint32_t)((r & 3) + 8 * (r >> 2));
-                uint32_t key = (base + off) - ((uint32_t)acc[r] << 21);
-                if (!full) key = (t0 + 4u * half + off) < nt ? key : 0xFFFFFFFFu;  // last, partial tile
-                uint32_t hi = max(k0, key);
-                k0 = min(k0, key);
-                k1 = min(k1, hi);
-            }
+            knn2_tile(tp, qb, t0, half, nt, k0, k1);
         }
         if (more) {
             s_t[buf ^ 1][srow0 * RS + scol] = st0;
@@ -219,10 +261,12 @@ __global__ __launch_bounds__(kMfmaBlock) void k_knn2_mfma(const HmProbX* __restr
         buf ^= 1;
     }
     if (!wave_on) return;
-    // merge the two half-waves' sorted pairs
-    uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
-    uint32_t m0 = min(k0, o0);
-    uint32_t m1 = min(max(k0, o0), min(k1, o1));
+    // merge the two half-waves' sorted pairs, back to the unsigned key (INT_MAX = no neighbour -> all ones)
+    int o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+    int s0 = min(k0, o0);
+    int s1 = min(max(k0, o0), min(k1, o1));
+    uint32_t m0 = s0 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s0 + (512u << 21);
+    uint32_t m1 = s1 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s1 + (512u << 21);
     uint32_t qi = q0 + col;
     if (half == 0 && qi < nq) {
         akz_neighbor n0 = {m0 & ((1u << kIdxBits) - 1u), m0 >> kIdxBits};
