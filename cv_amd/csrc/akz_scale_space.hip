@@ -29,6 +29,8 @@ namespace {
 
 constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
 constexpr int kTH = 32;  // output tile height
+constexpr int kFTH = 24; // output tile height of the two-frame front kernel (LDS: 2 x 22 KB -> 3 blocks per CU)
+constexpr int kFNT = 512; // its block size: 3 blocks x 8 waves per CU
 
 enum { EPI_BLUR = 0, EPI_FLOW = 1, EPI_CMAX = 2, EPI_CHIST = 3 };
 
@@ -66,6 +68,231 @@ __device__ __forceinline__ float off_combine(const OffK k, float a, float b, flo
     // underflows to -0 becomes +0); after that no partial sum can be -0, so no other tap needs it
     float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
     return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-frame packed arithmetic.  The reference's filters are unfused multiply-then-add chains, so the VALU
+// count is what bounds the fused tile kernels (rocprof: 88 % VALU-busy).  gfx950 issues v_pk_mul_f32 /
+// v_pk_add_f32 at twice the element rate of the scalar forms, and they round each half exactly like the
+// scalar instruction, so a block processes the SAME tile of two consecutive frames with every on-chip
+// value stored as a {frame a, frame b} pair: same operation order per frame, half the instructions.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+// On-chip tile layout for the two-frame kernels.  A row of C columns (C % 4 == 0) is stored as two planes:
+// plane 0 holds the column pairs {4c, 4c+1}, plane 1 the pairs {4c+2, 4c+3}, each pair being 16 bytes
+// ({col, frame a}, {col, frame b}, {col+1, a}, {col+1, b}).  A thread works on a 4-column strip c and reads
+// it as 16-byte chunks plane0[c + j], plane1[c + j]: consecutive lanes touch consecutive 16-byte chunks, so
+// a ds_read_b128 covers all 64 banks once (with the strip stored contiguously, lanes L and L+8 of a
+// 16-lane group collide and the read takes twice the LDS cycles).
+template <int C>
+__device__ __forceinline__ int tile_col(int col) { return ((col & 2) ? C / 2 : 0) + ((col >> 2) << 1) + (col & 1); }
+
+// columns [4c + LO, 4c + HI] of 12 consecutive columns starting at strip c; v[j] = column 4c + j
+template <int C, int LO, int HI>
+__device__ __forceinline__ void lds_read12(const v2f* __restrict__ row, int c, v2f (&v)[12])
+{
+    const float4* p0 = reinterpret_cast<const float4*>(row) + c;
+    const float4* p1 = reinterpret_cast<const float4*>(row + C / 2) + c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (4 * j + 1 >= LO && 4 * j <= HI) {
+            float4 t = p0[j];
+            v[4 * j] = (v2f){t.x, t.y};
+            v[4 * j + 1] = (v2f){t.z, t.w};
+        }
+        if (4 * j + 3 >= LO && 4 * j + 2 <= HI) {
+            float4 t = p1[j];
+            v[4 * j + 2] = (v2f){t.x, t.y};
+            v[4 * j + 3] = (v2f){t.z, t.w};
+        }
+    }
+}
+template <int C>
+__device__ __forceinline__ void lds_write4(v2f* __restrict__ row, int c, v2f a, v2f b, v2f cc, v2f d)
+{
+    reinterpret_cast<float4*>(row)[c] = make_float4(a.x, a.y, b.x, b.y);
+    reinterpret_cast<float4*>(row + C / 2)[c] = make_float4(cc.x, cc.y, d.x, d.y);
+}
+
+// lane4_dot on register operands (see lane4_dot): taps v[0..N-1]
+template <int N>
+__device__ __forceinline__ v2f lane4_dot_v(const v2f* v, const float* k)
+{
+    v2f a0 = splat(0.0f), a1 = splat(0.0f), a2 = splat(0.0f), a3 = splat(0.0f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        v2f p = v[i] * splat(k[i]);
+        if ((i & 3) == 0) a0 = p + a0;
+        else if ((i & 3) == 1) a1 = p + a1;
+        else if ((i & 3) == 2) a2 = p + a2;
+        else a3 = p + a3;
+    }
+    return ((a0 + a1) + a2) + a3;
+}
+
+__device__ __forceinline__ v2f off_combine(const OffK k, v2f a, v2f b, v2f c)
+{
+    v2f pa = a * splat(k.n) + splat(0.0f), pb = b * splat(k.m), pc = c * splat(k.n);
+    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+}
+
+__device__ __forceinline__ float4 load4_px(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
+{
+    uint32_t u = *reinterpret_cast<const uint32_t*>(p + i);
+    return make_float4((float)(u & 0xFFu) / 255.0f, (float)((u >> 8) & 0xFFu) / 255.0f,
+                       (float)((u >> 16) & 0xFFu) / 255.0f, (float)(u >> 24) / 255.0f);
+}
+
+// k_level_front for two frames per block (requires w % 4 == 0 so that every 4-column strip is 16-byte
+// aligned in HBM and either fully inside or fully outside the image).  Column bookkeeping: s_in column ix
+// is image x = tx0 - 8 + ix (80 columns), s_h / s_g column p is image x = tx0 - 4 + p (72 columns), so an
+// output strip, the blur windows and the +-SG derivative taps all start on 4-column boundaries.
+// Every thread computes strips of 4 consecutive columns from registers: no per-pixel index arithmetic, one
+// LDS read per ~1.3 multiply-adds instead of one per multiply.  The H and V passes run with plain
+// (unclamped) windows over positions that hold values at clamped coordinates; positions of the blurred tile
+// that lie outside the image are then overwritten with the value at their clamped coordinate (border tiles
+// only), which is what the reference's edge replication produces stage by stage.
+template <int R, int SG, int TH, typename InT, bool FLOW>
+__global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
+                                                       GaussTaps taps, OffK k, float* __restrict__ out_g,
+                                                       float* __restrict__ out_flow, float2* __restrict__ out_xy,
+                                                       const float* __restrict__ invk, int invk_off)
+{
+    constexpr int N = 2 * R + 1;
+    constexpr int CI = kTW + 16, CG = kTW + 8;
+    constexpr int GH = TH + 2 * SG, IH = GH + 2 * R;
+    __shared__ __attribute__((aligned(16))) v2f s_a[IH * CI];   // input tile, later the blurred tile (GH x CG)
+    __shared__ __attribute__((aligned(16))) v2f s_h[IH * CG];
+    v2f* s_in = s_a;
+    v2f* s_g = s_a;
+    const int fa = 2 * blockIdx.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    const InT* srca = in + (size_t)fa * fs;
+    const InT* srcb = in + (size_t)fb * fs;
+    const bool x_inside = tx0 >= 8 && tx0 + kTW + 8 <= w;
+    if (x_inside) {
+        for (int idx = tid; idx < IH * (CI / 4); idx += kFNT) {
+            int iy = idx / (CI / 4), c4 = idx - iy * (CI / 4);
+            int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
+            size_t o = (size_t)cy * w + (tx0 - 8 + 4 * c4);
+            float4 a = load4_px(srca, o), b = load4_px(srcb, o);
+            lds_write4<CI>(&s_in[iy * CI], c4, (v2f){a.x, b.x}, (v2f){a.y, b.y}, (v2f){a.z, b.z}, (v2f){a.w, b.w});
+        }
+    } else {
+        for (int idx = tid; idx < IH * CI; idx += kFNT) {
+            int iy = idx / CI, ix = idx - iy * CI;
+            int cx = clampi(tx0 - 8 + ix, 0, w - 1);
+            int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
+            size_t o = (size_t)cy * w + cx;
+            s_in[iy * CI + tile_col<CI>(ix)] = (v2f){load_px(srca, o), load_px(srcb, o)};
+        }
+    }
+    __syncthreads();
+    // horizontal pass: s_h[iy][p] = sum_i s_in[iy][p + 4 - R + i] * k[i]
+    for (int idx = tid; idx < IH * (CG / 4); idx += kFNT) {
+        int iy = idx / (CG / 4), c = idx - iy * (CG / 4);
+        v2f v[12];
+        lds_read12<CI, 4 - R, 7 - R + N - 1>(&s_in[iy * CI], c, v);
+        lds_write4<CG>(&s_h[iy * CG], c, lane4_dot_v<N>(v + 4 - R, taps.k), lane4_dot_v<N>(v + 5 - R, taps.k),
+                       lane4_dot_v<N>(v + 6 - R, taps.k), lane4_dot_v<N>(v + 7 - R, taps.k));
+    }
+    __syncthreads();  // s_in is dead from here on: s_g overwrites it
+    // vertical pass: s_g[q][p] = sum_i s_h[q + i][p] * k[i]
+    for (int idx = tid; idx < GH * (CG / 4); idx += kFNT) {
+        int q = idx / (CG / 4), c = idx - q * (CG / 4);
+        v2f col[4][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const v2f* row = &s_h[(q + i) * CG];
+            float4 t0 = reinterpret_cast<const float4*>(row)[c];
+            float4 t1 = reinterpret_cast<const float4*>(row + CG / 2)[c];
+            col[0][i] = (v2f){t0.x, t0.y};
+            col[1][i] = (v2f){t0.z, t0.w};
+            col[2][i] = (v2f){t1.x, t1.y};
+            col[3][i] = (v2f){t1.z, t1.w};
+        }
+        lds_write4<CG>(&s_g[q * CG], c, lane4_dot_v<N>(col[0], taps.k), lane4_dot_v<N>(col[1], taps.k),
+                       lane4_dot_v<N>(col[2], taps.k), lane4_dot_v<N>(col[3], taps.k));
+    }
+    __syncthreads();
+    // positions outside the image take the value at their clamped coordinate (reads touch in-image
+    // positions only, writes out-of-image positions only)
+    if (tx0 < SG || tx0 + kTW + SG > w || ty0 < SG || ty0 + TH + SG > h) {
+        for (int idx = tid; idx < GH * CG; idx += kFNT) {
+            int q = idx / CG, p = idx - q * CG;
+            int x = tx0 - 4 + p, y = ty0 - SG + q;
+            int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
+            if (xc != x || yc != y)
+                s_g[q * CG + tile_col<CG>(p)] = s_g[(yc - (ty0 - SG)) * CG + tile_col<CG>(xc - (tx0 - 4))];
+        }
+        __syncthreads();
+    }
+    v2f inverse_k = splat(0.0f);
+    if (FLOW) inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
+    for (int idx = tid; idx < TH * (kTW / 4); idx += kFNT) {
+        const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
+        const int x0 = tx0 + 4 * c, y = ty0 + q;
+        if (x0 >= w || y >= h) continue;
+        const v2f* g0 = &s_g[(q + SG) * CG];   // v[4 + o] is output pixel o of the strip
+        v2f z[12], res_x[4], res_y[4], res_f[4];
+        lds_read12<CG, (SG > 1 ? 4 - SG : 3), (SG > 1 ? 7 + SG : 8)>(g0, c, z);
+        if (FLOW) {
+            // simple Scharr (derivatives.rs:3-11) + pm_g2 (nonlinear_diffusion.rs:80)
+            v2f m[12], pz[12];
+            lds_read12<CG, 3, 8>(g0 - CG, c, m);
+            lds_read12<CG, 3, 8>(g0 + CG, c, pz);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                v2f hx_m = m[5 + o] - m[3 + o];
+                v2f hx_0 = z[5 + o] - z[3 + o];
+                v2f hx_p = pz[5 + o] - pz[3 + o];
+                v2f lx = (splat(3.0f) * hx_m + splat(10.0f) * hx_0) + splat(3.0f) * hx_p;
+                v2f hy_m = (splat(3.0f) * m[3 + o] + splat(10.0f) * m[4 + o]) + splat(3.0f) * m[5 + o];
+                v2f hy_p = (splat(3.0f) * pz[3 + o] + splat(10.0f) * pz[4 + o]) + splat(3.0f) * pz[5 + o];
+                v2f ly = hy_p - hy_m;
+                res_f[o] = splat(1.0f) / (splat(1.0f) + inverse_k * (lx * lx + ly * ly));
+            }
+        }
+        {
+            // multiscale Scharr first derivatives (derivatives.rs:23-49), taps at -SG, 0, +SG
+            v2f m[12], pz[12];
+            lds_read12<CG, 4 - SG, 7 + SG>(g0 - SG * CG, c, m);
+            lds_read12<CG, 4 - SG, 7 + SG>(g0 + SG * CG, c, pz);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                v2f mm = m[4 + o - SG], m0 = m[4 + o], mp = m[4 + o + SG];
+                v2f zm = z[4 + o - SG], zp = z[4 + o + SG];
+                v2f pm = pz[4 + o - SG], p0 = pz[4 + o], pp = pz[4 + o + SG];
+                res_x[o] = off_combine(k, mp - mm, zp - zm, pp - pm);
+                res_y[o] = off_combine(k, pm, p0, pp) - off_combine(k, mm, m0, mp);
+            }
+        }
+        const size_t pix = (size_t)y * w + x0;
+        {
+            const size_t o = (size_t)fa * fs + pix;
+            if (out_g) *reinterpret_cast<float4*>(out_g + o) = make_float4(z[4].x, z[5].x, z[6].x, z[7].x);
+            if (FLOW)
+                *reinterpret_cast<float4*>(out_flow + o) = make_float4(res_f[0].x, res_f[1].x, res_f[2].x, res_f[3].x);
+            float4* xy = reinterpret_cast<float4*>(out_xy + o);
+            xy[0] = make_float4(res_x[0].x, res_y[0].x, res_x[1].x, res_y[1].x);
+            xy[1] = make_float4(res_x[2].x, res_y[2].x, res_x[3].x, res_y[3].x);
+        }
+        if (has_b) {
+            const size_t o = (size_t)fb * fs + pix;
+            if (out_g) *reinterpret_cast<float4*>(out_g + o) = make_float4(z[4].y, z[5].y, z[6].y, z[7].y);
+            if (FLOW)
+                *reinterpret_cast<float4*>(out_flow + o) = make_float4(res_f[0].y, res_f[1].y, res_f[2].y, res_f[3].y);
+            float4* xy = reinterpret_cast<float4*>(out_xy + o);
+            xy[0] = make_float4(res_x[0].y, res_y[0].y, res_x[1].y, res_y[1].y);
+            xy[1] = make_float4(res_x[2].y, res_y[2].y, res_x[3].y, res_y[3].y);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,7 +1051,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     akz_timer_begin(c, &c->t_ss);
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
     const bool fused0 = P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
-    if (fused0) {
+    if (fused0 && (w & 3) == 0 && c->front_pair) {
+        hipLaunchKernelGGL((k_level_front2<4, 2, kFTH, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kFTH), (n + 1) / 2),
+                           dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
+                           (const float*)nullptr, 0);
+        AKZ_LAUNCH_CHECK();
+    } else if (fused0) {
         hipLaunchKernelGGL((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
                            s, d_imgs, w, h, P0, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
                            (const float*)nullptr, 0);
@@ -877,12 +1109,18 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_FRONT(SGV)                                                                                               \
     hipLaunchKernelGGL((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
                        lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+                dim3 gridp(akz_div_up(L.w, kTW), akz_div_up(L.h, kFTH), (n + 1) / 2);
+#define AKZ_FRONT2(SGV)                                                                                              \
+    hipLaunchKernelGGL((k_level_front2<2, SGV, kFTH, float, true>), gridp, dim3(kFNT), 0, s, init, L.w, L.h, fs, n, t1, \
+                       kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+                const bool pair = (L.w & 3) == 0 && c->front_pair;
                 switch (L.deriv_sigma) {
-                case 2: AKZ_FRONT(2); break;
-                case 3: AKZ_FRONT(3); break;
-                default: AKZ_FRONT(4); break;
+                case 2: if (pair) AKZ_FRONT2(2); else AKZ_FRONT(2); break;
+                case 3: if (pair) AKZ_FRONT2(3); else AKZ_FRONT(3); break;
+                default: if (pair) AKZ_FRONT2(4); else AKZ_FRONT(4); break;
                 }
 #undef AKZ_FRONT
+#undef AKZ_FRONT2
                 AKZ_LAUNCH_CHECK();
             } else {
                 AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,

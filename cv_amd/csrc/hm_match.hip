@@ -211,6 +211,41 @@ __device__ __forceinline__ void knn2_tile(const uint4* __restrict__ tp, const v4
     else knn2_keys<true>(acc, t0, half, nt, k0, k1);
 }
 
+
+// Two column blocks (64 queries) per wave: every target fragment read from LDS feeds two MFMAs on two
+// independent accumulator chains, halving the LDS read traffic per MAC.
+__device__ __forceinline__ void knn2_tile2(const uint4* __restrict__ tp, const v4i32 (&qa)[16], const v4i32 (&qc)[16],
+                                           uint32_t t0, uint32_t half, uint32_t nt, int (&k)[4])
+{
+    v16i32 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16i32 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint4 f[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = tp[2 * i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint4 av = f[i & 3];
+        v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+        if (i + 4 < 16) f[i & 3] = tp[2 * (i + 4)];
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qa[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qc[i], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    if (t0 + 32u <= nt) {
+        knn2_keys<false>(acc0, t0, half, nt, k[0], k[1]);
+        knn2_keys<false>(acc1, t0, half, nt, k[2], k[3]);
+    } else {
+        knn2_keys<true>(acc0, t0, half, nt, k[0], k[1]);
+        knn2_keys<true>(acc1, t0, half, nt, k[2], k[3]);
+    }
+}
+
 __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __restrict__ probs)
 {
     // target tile: 32 descriptors x 512 B, rows padded to 33 x 16 B so the 16-byte fragment reads of the
@@ -273,6 +308,72 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __re
         akz_neighbor n1 = {m1 & ((1u << kIdxBits) - 1u), m1 >> kIdxBits};
         P.out[(size_t)qi * 2 + 0] = n0;
         P.out[(size_t)qi * 2 + 1] = n1;
+    }
+}
+
+constexpr int kMfma2Block = 512;  // 8 waves x 64 queries
+constexpr int kMfma2QPB = 512;
+__global__ __launch_bounds__(kMfma2Block, 2) void k_knn2_mfma2(const HmProbX* __restrict__ probs)
+{
+    constexpr int RS = 33;
+    __shared__ uint4 s_t[2][32 * RS];
+    const HmProbX P = probs[blockIdx.y];
+    const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t qblk = blockIdx.x * (uint32_t)kMfma2QPB;
+    if (qblk >= nq) return;                             // whole block
+    const uint32_t q0 = qblk + wv * 64u;                // 64 queries (two column blocks) per wave
+    const bool wave_on = q0 < nq;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    v4i32 qa[16], qc[16];
+    {
+        const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)min(q0 + col, nq - 1u) * 128) + half;
+        const v4i32* qr = reinterpret_cast<const v4i32*>(P.q + (size_t)min(q0 + 32u + col, nq - 1u) * 128) + half;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            qa[i] = qp[2 * i] ^ (int)0xFEFEFEFE;        // +-1 bytes negated (see knn2_keys)
+            qc[i] = qr[2 * i] ^ (int)0xFEFEFEFE;
+        }
+    }
+    const uint4* tg = reinterpret_cast<const uint4*>(P.t);
+    // staging map: thread -> 2 x (row, 16-byte column): row = (tid >> 5) + 16 i, c = tid & 31
+    const uint32_t srow = threadIdx.x >> 5, scol = threadIdx.x & 31u;
+    uint4 st0 = tg[(size_t)min(srow, nt - 1u) * 32 + scol];
+    uint4 st1 = tg[(size_t)min(srow + 16u, nt - 1u) * 32 + scol];
+    s_t[0][srow * RS + scol] = st0;
+    s_t[0][(srow + 16u) * RS + scol] = st1;
+    int k[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+    int buf = 0;
+    for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
+        __syncthreads();
+        const bool more = t0 + 32u < nt;
+        if (more) {
+            st0 = tg[(size_t)min(t0 + 32u + srow, nt - 1u) * 32 + scol];
+            st1 = tg[(size_t)min(t0 + 48u + srow, nt - 1u) * 32 + scol];
+        }
+        if (wave_on) knn2_tile2(&s_t[buf][col * RS + half], qa, qc, t0, half, nt, k);
+        if (more) {
+            s_t[buf ^ 1][srow * RS + scol] = st0;
+            s_t[buf ^ 1][(srow + 16u) * RS + scol] = st1;
+        }
+        buf ^= 1;
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int k0 = k[2 * c], k1 = k[2 * c + 1];
+        int o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+        int s0 = min(k0, o0);
+        int s1 = min(max(k0, o0), min(k1, o1));
+        uint32_t m0 = s0 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s0 + (512u << 21);
+        uint32_t m1 = s1 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s1 + (512u << 21);
+        uint32_t qi = q0 + 32u * c + col;
+        if (half == 0 && qi < nq) {
+            akz_neighbor n0 = {m0 & ((1u << kIdxBits) - 1u), m0 >> kIdxBits};
+            akz_neighbor n1 = {m1 & ((1u << kIdxBits) - 1u), m1 >> kIdxBits};
+            P.out[(size_t)qi * 2 + 0] = n0;
+            P.out[(size_t)qi * 2 + 1] = n1;
+        }
     }
 }
 
@@ -365,6 +466,7 @@ struct hm_ctx {
     uint32_t* d_exp = nullptr;
     size_t exp_words = 0;
     bool use_mfma = true;
+    int mfma_variant = 1;   // AKZ_MATCH_MFMA: 1 = 32 queries per wave, 2 = 64 queries per wave
     akz_neighbor* d_bfwd = nullptr;
     akz_neighbor* d_brev = nullptr;
     size_t bscratch_elems = 0;
@@ -423,6 +525,7 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
     {
         const char* mf = getenv("AKZ_MATCH_MFMA");
         c->use_mfma = !(mf && mf[0] == '0');
+        if (mf && mf[0] == '2') c->mfma_variant = 2;
     }
     AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
     AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
@@ -516,7 +619,11 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
                        reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
     AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + 255) / 256, n_probs), dim3(kMfmaBlock), 0, c->stream,
+    if (c->mfma_variant == 2)
+        hipLaunchKernelGGL(k_knn2_mfma2, dim3((max_nq + kMfma2QPB - 1) / kMfma2QPB, n_probs), dim3(kMfma2Block), 0, c->stream,
+                       reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off));
+    else
+        hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + 255) / 256, n_probs), dim3(kMfmaBlock), 0, c->stream,
                        reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off));
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
