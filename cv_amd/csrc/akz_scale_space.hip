@@ -90,20 +90,31 @@ template <int C>
 __device__ __forceinline__ int tile_col(int col) { return ((col & 2) ? C / 2 : 0) + ((col >> 2) << 1) + (col & 1); }
 
 // columns [4c + LO, 4c + HI] of 12 consecutive columns starting at strip c; v[j] = column 4c + j
-template <int C, int LO, int HI>
-__device__ __forceinline__ void lds_read12(const v2f* __restrict__ row, int c, v2f (&v)[12])
+typedef float f4v __attribute__((ext_vector_type(4)));
+// A full 16-byte LDS read.  The empty asm keeps the compiler from narrowing it to the 8-byte halves a
+// caller happens to use (it then pairs the halves into ds_read2_b64, which runs at half the ds_read_b128 rate
+// and on 32 instead of 64 banks).
+__device__ __forceinline__ f4v lds_chunk(const float4* p)
 {
-    const float4* p0 = reinterpret_cast<const float4*>(row) + c;
-    const float4* p1 = reinterpret_cast<const float4*>(row + C / 2) + c;
+    f4v t = *reinterpret_cast<const f4v*>(p);
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+template <int C, int LO, int HI>
+__device__ __forceinline__ void lds_read12(const float4* __restrict__ tile, int row, int c, v2f (&v)[12])
+{
+    const float4* p0 = tile + (row * (C / 2) + c);       // C / 2 chunks of 16 bytes per row
+    const float4* p1 = p0 + C / 4;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (4 * j + 1 >= LO && 4 * j <= HI) {
-            float4 t = p0[j];
+            f4v t = lds_chunk(p0 + j);
             v[4 * j] = (v2f){t.x, t.y};
             v[4 * j + 1] = (v2f){t.z, t.w};
         }
         if (4 * j + 3 >= LO && 4 * j + 2 <= HI) {
-            float4 t = p1[j];
+            f4v t = lds_chunk(p1 + j);
             v[4 * j + 2] = (v2f){t.x, t.y};
             v[4 * j + 3] = (v2f){t.z, t.w};
         }
@@ -155,8 +166,8 @@ __device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
 // (unclamped) windows over positions that hold values at clamped coordinates; positions of the blurred tile
 // that lie outside the image are then overwritten with the value at their clamped coordinate (border tiles
 // only), which is what the reference's edge replication produces stage by stage.
-template <int R, int SG, int TH, typename InT, bool FLOW>
-__global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
+template <int R, int SG, int TH, int NT, typename InT, bool FLOW>
+__global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
                                                        GaussTaps taps, OffK k, float* __restrict__ out_g,
                                                        float* __restrict__ out_flow, float2* __restrict__ out_xy,
                                                        const float* __restrict__ invk, int invk_off)
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
     const InT* srcb = in + (size_t)fb * fs;
     const bool x_inside = tx0 >= 8 && tx0 + kTW + 8 <= w;
     if (x_inside) {
-        for (int idx = tid; idx < IH * (CI / 4); idx += kFNT) {
+        for (int idx = tid; idx < IH * (CI / 4); idx += NT) {
             int iy = idx / (CI / 4), c4 = idx - iy * (CI / 4);
             int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
             size_t o = (size_t)cy * w + (tx0 - 8 + 4 * c4);
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
             lds_write4<CI>(&s_in[iy * CI], c4, (v2f){a.x, b.x}, (v2f){a.y, b.y}, (v2f){a.z, b.z}, (v2f){a.w, b.w});
         }
     } else {
-        for (int idx = tid; idx < IH * CI; idx += kFNT) {
+        for (int idx = tid; idx < IH * CI; idx += NT) {
             int iy = idx / CI, ix = idx - iy * CI;
             int cx = clampi(tx0 - 8 + ix, 0, w - 1);
             int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
@@ -195,23 +206,23 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
     }
     __syncthreads();
     // horizontal pass: s_h[iy][p] = sum_i s_in[iy][p + 4 - R + i] * k[i]
-    for (int idx = tid; idx < IH * (CG / 4); idx += kFNT) {
+    for (int idx = tid; idx < IH * (CG / 4); idx += NT) {
         int iy = idx / (CG / 4), c = idx - iy * (CG / 4);
         v2f v[12];
-        lds_read12<CI, 4 - R, 7 - R + N - 1>(&s_in[iy * CI], c, v);
+        lds_read12<CI, 4 - R, 7 - R + N - 1>(reinterpret_cast<const float4*>(s_in), iy, c, v);
         lds_write4<CG>(&s_h[iy * CG], c, lane4_dot_v<N>(v + 4 - R, taps.k), lane4_dot_v<N>(v + 5 - R, taps.k),
                        lane4_dot_v<N>(v + 6 - R, taps.k), lane4_dot_v<N>(v + 7 - R, taps.k));
     }
     __syncthreads();  // s_in is dead from here on: s_g overwrites it
     // vertical pass: s_g[q][p] = sum_i s_h[q + i][p] * k[i]
-    for (int idx = tid; idx < GH * (CG / 4); idx += kFNT) {
+    for (int idx = tid; idx < GH * (CG / 4); idx += NT) {
         int q = idx / (CG / 4), c = idx - q * (CG / 4);
         v2f col[4][N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const v2f* row = &s_h[(q + i) * CG];
-            float4 t0 = reinterpret_cast<const float4*>(row)[c];
-            float4 t1 = reinterpret_cast<const float4*>(row + CG / 2)[c];
+            const float4* rowp = reinterpret_cast<const float4*>(s_h) + ((q + i) * (CG / 2) + c);
+            f4v t0 = lds_chunk(rowp);
+            f4v t1 = lds_chunk(rowp + CG / 4);
             col[0][i] = (v2f){t0.x, t0.y};
             col[1][i] = (v2f){t0.z, t0.w};
             col[2][i] = (v2f){t1.x, t1.y};
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
     // positions outside the image take the value at their clamped coordinate (reads touch in-image
     // positions only, writes out-of-image positions only)
     if (tx0 < SG || tx0 + kTW + SG > w || ty0 < SG || ty0 + TH + SG > h) {
-        for (int idx = tid; idx < GH * CG; idx += kFNT) {
+        for (int idx = tid; idx < GH * CG; idx += NT) {
             int q = idx / CG, p = idx - q * CG;
             int x = tx0 - 4 + p, y = ty0 - SG + q;
             int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
@@ -235,18 +246,19 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
     }
     v2f inverse_k = splat(0.0f);
     if (FLOW) inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
-    for (int idx = tid; idx < TH * (kTW / 4); idx += kFNT) {
+    for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
         const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
         const int x0 = tx0 + 4 * c, y = ty0 + q;
         if (x0 >= w || y >= h) continue;
-        const v2f* g0 = &s_g[(q + SG) * CG];   // v[4 + o] is output pixel o of the strip
+        const float4* g4 = reinterpret_cast<const float4*>(s_g);
+        const int r0 = q + SG;                  // v[4 + o] is output pixel o of the strip
         v2f z[12], res_x[4], res_y[4], res_f[4];
-        lds_read12<CG, (SG > 1 ? 4 - SG : 3), (SG > 1 ? 7 + SG : 8)>(g0, c, z);
+        lds_read12<CG, (SG > 1 ? 4 - SG : 3), (SG > 1 ? 7 + SG : 8)>(g4, r0, c, z);
         if (FLOW) {
             // simple Scharr (derivatives.rs:3-11) + pm_g2 (nonlinear_diffusion.rs:80)
             v2f m[12], pz[12];
-            lds_read12<CG, 3, 8>(g0 - CG, c, m);
-            lds_read12<CG, 3, 8>(g0 + CG, c, pz);
+            lds_read12<CG, 3, 8>(g4, r0 - 1, c, m);
+            lds_read12<CG, 3, 8>(g4, r0 + 1, c, pz);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 v2f hx_m = m[5 + o] - m[3 + o];
@@ -262,8 +274,8 @@ __global__ __launch_bounds__(kFNT) void k_level_front2(const InT* __restrict__ i
         {
             // multiscale Scharr first derivatives (derivatives.rs:23-49), taps at -SG, 0, +SG
             v2f m[12], pz[12];
-            lds_read12<CG, 4 - SG, 7 + SG>(g0 - SG * CG, c, m);
-            lds_read12<CG, 4 - SG, 7 + SG>(g0 + SG * CG, c, pz);
+            lds_read12<CG, 4 - SG, 7 + SG>(g4, r0 - SG, c, m);
+            lds_read12<CG, 4 - SG, 7 + SG>(g4, r0 + SG, c, pz);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 v2f mm = m[4 + o - SG], m0 = m[4 + o], mp = m[4 + o + SG];
@@ -1052,9 +1064,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
     const bool fused0 = P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
     if (fused0 && (w & 3) == 0 && c->front_pair) {
-        hipLaunchKernelGGL((k_level_front2<4, 2, kFTH, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kFTH), (n + 1) / 2),
-                           dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
-                           (const float*)nullptr, 0);
+        if (c->front_cfg == 1)
+            hipLaunchKernelGGL((k_level_front2<4, 2, 32, 256, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, 32), (n + 1) / 2),
+                               dim3(256), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
+                               (const float*)nullptr, 0);
+        else
+            hipLaunchKernelGGL((k_level_front2<4, 2, kFTH, kFNT, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kFTH), (n + 1) / 2),
+                               dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
+                               (const float*)nullptr, 0);
         AKZ_LAUNCH_CHECK();
     } else if (fused0) {
         hipLaunchKernelGGL((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
@@ -1110,14 +1127,19 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     hipLaunchKernelGGL((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
                        lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
                 dim3 gridp(akz_div_up(L.w, kTW), akz_div_up(L.h, kFTH), (n + 1) / 2);
+                dim3 gridq(akz_div_up(L.w, kTW), akz_div_up(L.h, 32), (n + 1) / 2);
 #define AKZ_FRONT2(SGV)                                                                                              \
-    hipLaunchKernelGGL((k_level_front2<2, SGV, kFTH, float, true>), gridp, dim3(kFNT), 0, s, init, L.w, L.h, fs, n, t1, \
-                       kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+    if (c->front_cfg == 1)                                                                                           \
+        hipLaunchKernelGGL((k_level_front2<2, SGV, 32, 256, float, true>), gridq, dim3(256), 0, s, init, L.w, L.h, fs, \
+                           n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave);         \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_level_front2<2, SGV, kFTH, kFNT, float, true>), gridp, dim3(kFNT), 0, s, init, L.w, L.h, \
+                           fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
                 const bool pair = (L.w & 3) == 0 && c->front_pair;
                 switch (L.deriv_sigma) {
-                case 2: if (pair) AKZ_FRONT2(2); else AKZ_FRONT(2); break;
-                case 3: if (pair) AKZ_FRONT2(3); else AKZ_FRONT(3); break;
-                default: if (pair) AKZ_FRONT2(4); else AKZ_FRONT(4); break;
+                case 2: if (pair) { AKZ_FRONT2(2); } else AKZ_FRONT(2); break;
+                case 3: if (pair) { AKZ_FRONT2(3); } else AKZ_FRONT(3); break;
+                default: if (pair) { AKZ_FRONT2(4); } else AKZ_FRONT(4); break;
                 }
 #undef AKZ_FRONT
 #undef AKZ_FRONT2
