@@ -30,6 +30,7 @@ namespace {
 constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
 constexpr int kTH = 32;  // output tile height
 constexpr int kFTH = 24; // output tile height of the two-frame front kernel (LDS: 2 x 22 KB -> 3 blocks per CU)
+constexpr int kDTH = 12; // output tile height of the two-frame determinant kernel
 constexpr int kFNT = 512; // its block size: 3 blocks x 8 waves per CU
 
 enum { EPI_BLUR = 0, EPI_FLOW = 1, EPI_CMAX = 2, EPI_CHIST = 3 };
@@ -889,6 +890,120 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
     }
 }
 
+// k_deriv_second_cand for two frames per block (w % 4 == 0), same organisation as k_level_front2: the
+// {Lx, Ly} tiles of both frames are staged as two split-plane v2f tiles (X and Y), every thread produces
+// 4-column strips of the determinant from registers with packed arithmetic, and the candidate test reads the
+// determinant tile (plus its one-pixel ring) from LDS.  Staged positions hold the value at their clamped
+// coordinate, so the +-SG taps need no clamping of their own.  12 output rows per block: 18 strips x 14 ring
+// rows = 252 strips for 256 threads.
+template <int SG>
+__global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
+                                                            int w, int h, size_t fs, int n, OffK k, float sigma_quat,
+                                                            CandParams cp, uint2* __restrict__ cand,
+                                                            uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
+{
+    constexpr int TW = 64, TH = kDTH;
+    constexpr int CS = TW + 16, RS = TH + 2 + 2 * SG;    // staged tiles: x = tx0 - 8 + col, y = ty0 - 1 - SG + row
+    constexpr int CG = TW + 8, RG = TH + 2;              // determinant tile: x = tx0 - 4 + col, y = ty0 - 1 + row
+    __shared__ __attribute__((aligned(16))) v2f s_x[RS * CS];
+    __shared__ __attribute__((aligned(16))) v2f s_y[RS * CS];
+    __shared__ __attribute__((aligned(16))) v2f s_d[RG * CG];
+    const int fa = 2 * blockIdx.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    const float2* Da = Lxy + (size_t)fa * fs;
+    const float2* Db = Lxy + (size_t)fb * fs;
+    if (tx0 >= 8 && tx0 + TW + 8 <= w) {
+        // item = (row, pixel pair j): one 16-byte load per frame, one 16-byte chunk per plane
+        for (int idx = tid; idx < RS * (CS / 2); idx += 256) {
+            int r = idx / (CS / 2), j = idx - r * (CS / 2);
+            int cy = clampi(ty0 - 1 - SG + r, 0, h - 1);
+            size_t o = (size_t)cy * w + (tx0 - 8 + 2 * j);
+            float4 a = *reinterpret_cast<const float4*>(Da + o), b = *reinterpret_cast<const float4*>(Db + o);
+            const int chunk = r * (CS / 2) + (j >> 1) + ((j & 1) ? CS / 4 : 0);
+            reinterpret_cast<float4*>(s_x)[chunk] = make_float4(a.x, b.x, a.z, b.z);
+            reinterpret_cast<float4*>(s_y)[chunk] = make_float4(a.y, b.y, a.w, b.w);
+        }
+    } else {
+        for (int idx = tid; idx < RS * CS; idx += 256) {
+            int r = idx / CS, p = idx - r * CS;
+            int cx = clampi(tx0 - 8 + p, 0, w - 1), cy = clampi(ty0 - 1 - SG + r, 0, h - 1);
+            size_t o = (size_t)cy * w + cx;
+            float2 a = Da[o], b = Db[o];
+            s_x[r * CS + tile_col<CS>(p)] = (v2f){a.x, b.x};
+            s_y[r * CS + tile_col<CS>(p)] = (v2f){a.y, b.y};
+        }
+    }
+    __syncthreads();
+    const float4* x4 = reinterpret_cast<const float4*>(s_x);
+    const float4* y4 = reinterpret_cast<const float4*>(s_y);
+    for (int idx = tid; idx < RG * (CG / 4); idx += 256) {
+        const int q = idx / (CG / 4), c = idx - q * (CG / 4);
+        v2f xm[12], xz[12], xp[12], ym[12], yp[12], det[4];
+        lds_read12<CS, 4 - SG, 7 + SG>(x4, q, c, xm);
+        lds_read12<CS, 4 - SG, 7 + SG>(x4, q + SG, c, xz);
+        lds_read12<CS, 4 - SG, 7 + SG>(x4, q + 2 * SG, c, xp);
+        lds_read12<CS, 4 - SG, 7 + SG>(y4, q, c, ym);
+        lds_read12<CS, 4 - SG, 7 + SG>(y4, q + 2 * SG, c, yp);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int jm = 4 + o - SG, j0 = 4 + o, jp = 4 + o + SG;
+            v2f lxx = off_combine(k, xm[jp] - xm[jm], xz[jp] - xz[jm], xp[jp] - xp[jm]);
+            v2f lxy = off_combine(k, xp[jm], xp[j0], xp[jp]) - off_combine(k, xm[jm], xm[j0], xm[jp]);
+            v2f lyy = off_combine(k, yp[jm], yp[j0], yp[jp]) - off_combine(k, ym[jm], ym[j0], ym[jp]);
+            det[o] = (lxx * lyy - lxy * lxy) * splat(sigma_quat);
+        }
+        lds_write4<CG>(&s_d[q * CG], c, det[0], det[1], det[2], det[3]);
+        const int x0 = tx0 - 4 + 4 * c, y = ty0 - 1 + q;
+        if (c >= 1 && c <= TW / 4 && q >= 1 && q <= TH && x0 < w && y < h) {
+            const size_t pix = (size_t)y * w + x0;
+            *reinterpret_cast<float4*>(Ldet + (size_t)fa * fs + pix) = make_float4(det[0].x, det[1].x, det[2].x, det[3].x);
+            if (has_b)
+                *reinterpret_cast<float4*>(Ldet + (size_t)fb * fs + pix) =
+                    make_float4(det[0].y, det[1].y, det[2].y, det[3].y);
+        }
+    }
+    __syncthreads();
+    const float4* d4 = reinterpret_cast<const float4*>(s_d);
+    for (int idx = tid; idx < TH * (TW / 4); idx += 256) {
+        const int q = idx / (TW / 4), c = idx - q * (TW / 4);
+        const int x0 = tx0 + 4 * c, y = ty0 + q;
+        if (x0 >= w || y < 1 || y > h - 2) continue;          // interior pixels only (:50)
+        v2f m[12], z[12], p[12];
+        lds_read12<CG, 3, 8>(d4, q, c, m);                    // v[4 + o] is pixel o of the strip (ring tile x = tx0 - 4 + col)
+        lds_read12<CG, 3, 8>(d4, q + 1, c, z);
+        lds_read12<CG, 3, 8>(d4, q + 2, c, p);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int x = x0 + o;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const float v = z[4 + o][f];
+                const float nb = fmaxf(fmaxf(fmaxf(m[3 + o][f], m[4 + o][f]), fmaxf(m[5 + o][f], z[3 + o][f])),
+                                       fmaxf(fmaxf(z[5 + o][f], p[3 + o][f]), fmaxf(p[4 + o][f], p[5 + o][f])));
+                if (!(v > cp.thr && v > nb)) continue;
+                if (x < 1 || x > w - 2 || (f == 1 && !has_b)) continue;
+                // border test (:96-104); a candidate failing it can neither push nor replace (:105)
+                const float px = (float)x, py = (float)y;
+                float left_x = roundf(px - cp.border) - 1.0f;
+                float right_x = roundf(px + cp.border) + 1.0f;
+                float up_y = roundf(py - cp.border) - 1.0f;
+                float down_y = roundf(py + cp.border) + 1.0f;
+                bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
+                if (is_out) continue;
+                const size_t list = (size_t)(f ? fb : fa) * 32 + cp.level;
+                uint32_t slot = atomicAdd(&ncand[list], 1u);
+                if (slot < cp.cap)
+                    cand[list * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
+                else
+                    *err = 1u;
+            }
+        }
+    }
+}
+
 // Restore raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
 // (y << 48 | x << 32 | response bits) in LDS; (x, y) is unique so the order is total.
 __global__ __launch_bounds__(1024) void k_cand_sort(uint2* __restrict__ cand, const uint32_t* __restrict__ ncand,
@@ -1220,13 +1335,19 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_D2(SGV)                                                                                                  \
     hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,          \
                        (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+            dim3 grid2p(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2);
+#define AKZ_D2P(SGV)                                                                                                 \
+    hipLaunchKernelGGL((k_deriv_second_cand2<SGV>), grid2p, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs, n, k,  \
+                       L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+            const bool pair2 = (L.w & 3) == 0 && c->front_pair;
             switch (L.deriv_sigma) {
-            case 2: AKZ_D2(2); break;
-            case 3: AKZ_D2(3); break;
-            case 4: AKZ_D2(4); break;
+            case 2: if (pair2) AKZ_D2P(2); else AKZ_D2(2); break;
+            case 3: if (pair2) AKZ_D2P(3); else AKZ_D2(3); break;
+            case 4: if (pair2) AKZ_D2P(4); else AKZ_D2(4); break;
             default: AKZ_D2(0); break;
             }
 #undef AKZ_D2
+#undef AKZ_D2P
             AKZ_LAUNCH_CHECK();
         }
     }
