@@ -738,6 +738,137 @@ __global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------
+// calculate_step for two frames per block with the image held in REGISTERS across the T steps of a launch.
+// A thread owns a 4x4 pixel patch of both frames ({a, b} pairs, packed arithmetic); a block is 16x16 patches
+// = a 64x64 window whose outer patch ring is the halo (valid region shrinks by one pixel per step, T <= 4),
+// so it produces a 56x56 tile.  Per step a thread needs only the neighbouring patches' facing edges:
+// left/right columns come from the adjacent lanes with DPP row shifts (a 16-lane DPP row is one patch row),
+// top/bottom rows go through a small double-buffered LDS exchange (one barrier per step).  Every flow is
+// evaluated once (the reference's Jacobi update needs each twice, as +flow for one pixel and -flow for the
+// other).  A flow across the image border is replaced by +0: L is never -0 (it starts from sums of
+// non-negative products and x + (-0) = x, (+0) - (+0) = +0), so adding or subtracting +0 leaves every value
+// bit-identical to skipping the term as nonlinear_diffusion.rs:31-52 does.
+constexpr int kFedU = 56;   // output tile edge of k_fed_pair
+
+__device__ __forceinline__ v2f fed_flow2(v2f ht, v2f ca, v2f cb, v2f a, v2f b) { return (ht * (ca + cb)) * (b - a); }
+
+template <int CTRL>
+__device__ __forceinline__ v2f dpp_row(v2f v)   // value of the lane CTRL selects within the 16-lane row; 0 outside it
+{
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), CTRL, 0xF, 0xF, true);
+    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xF, 0xF, true);
+    return (v2f){__int_as_float(x), __int_as_float(y)};
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src, const float* __restrict__ cnd,
+                                                  float* __restrict__ dst, int w, int h, size_t fs, int n, FedTaus taus)
+{
+    __shared__ __attribute__((aligned(16))) float4 s_top[2][256 * 2];   // [parity][patch][4 px x 2 frames]
+    __shared__ __attribute__((aligned(16))) float4 s_bot[2][256 * 2];
+    const int fa = 2 * blockIdx.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
+    const int x0 = (int)blockIdx.x * kFedU - 4 + 4 * pc, y0 = (int)blockIdx.y * kFedU - 4 + 4 * pr;
+    const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
+    v2f L[4][4], C[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + r;
+        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la, ca = la, cb = la;
+        if (col_in && y >= 0 && y < h) {
+            const size_t o = (size_t)y * w + x0;
+            la = *reinterpret_cast<const float4*>(src + (size_t)fa * fs + o);
+            lb = *reinterpret_cast<const float4*>(src + (size_t)fb * fs + o);
+            ca = *reinterpret_cast<const float4*>(cnd + (size_t)fa * fs + o);
+            cb = *reinterpret_cast<const float4*>(cnd + (size_t)fb * fs + o);
+        }
+        L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
+        C[r][0] = (v2f){ca.x, cb.x}; C[r][1] = (v2f){ca.y, cb.y}; C[r][2] = (v2f){ca.z, cb.z}; C[r][3] = (v2f){ca.w, cb.w};
+    }
+    // conductivity of the facing edges: fixed for the whole launch
+    v2f Cl[4], Cr[4], Ct[4], Cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Cl[r] = dpp_row<0x111>(C[r][3]);   // row_shr:1 -> left neighbour's right column
+        Cr[r] = dpp_row<0x101>(C[r][0]);   // row_shl:1 -> right neighbour's left column
+    }
+    s_top[1][tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_top[1][tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+    s_bot[1][tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
+    s_bot[1][tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
+    __syncthreads();
+    const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
+    {
+        float4 a = s_bot[1][up * 2], b = s_bot[1][up * 2 + 1], c = s_top[1][dn * 2], d = s_top[1][dn * 2 + 1];
+        Ct[0] = (v2f){a.x, a.y}; Ct[1] = (v2f){a.z, a.w}; Ct[2] = (v2f){b.x, b.y}; Ct[3] = (v2f){b.z, b.w};
+        Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
+    }
+    // flows that cross the image border are +0 (see above)
+    const bool z_left = x0 <= 0, z_right = x0 + 4 >= w, z_top = y0 <= 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const v2f ht = splat(taus.half_tau[t]);
+        const int par = t & 1;
+        s_top[par][tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
+        s_top[par][tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
+        s_bot[par][tid * 2] = make_float4(L[3][0].x, L[3][0].y, L[3][1].x, L[3][1].y);
+        s_bot[par][tid * 2 + 1] = make_float4(L[3][2].x, L[3][2].y, L[3][3].x, L[3][3].y);
+        __syncthreads();   // also orders this step's reads after the previous-but-one step's (same parity) writes
+        v2f Lt[4], Lb[4];
+        {
+            float4 a = s_bot[par][up * 2], b = s_bot[par][up * 2 + 1], c = s_top[par][dn * 2], d = s_top[par][dn * 2 + 1];
+            Lt[0] = (v2f){a.x, a.y}; Lt[1] = (v2f){a.z, a.w}; Lt[2] = (v2f){b.x, b.y}; Lt[3] = (v2f){b.z, b.w};
+            Lb[0] = (v2f){c.x, c.y}; Lb[1] = (v2f){c.z, c.w}; Lb[2] = (v2f){d.x, d.y}; Lb[3] = (v2f){d.z, d.w};
+        }
+        v2f vu[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vu[c] = fed_flow2(ht, Ct[c], C[0][c], Lt[c], L[0][c]);
+            if (z_top) vu[c] = splat(0.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const v2f Ll = dpp_row<0x111>(L[r][3]), Lr = dpp_row<0x101>(L[r][0]);
+            v2f hf[5];
+            hf[0] = fed_flow2(ht, Cl[r], C[r][0], Ll, L[r][0]);
+            if (z_left) hf[0] = splat(0.0f);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
+            hf[4] = fed_flow2(ht, C[r][3], Cr[r], L[r][3], Lr);
+            if (z_right) hf[4] = splat(0.0f);
+            const bool z_down = y0 + r >= h - 1;
+            v2f vd[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vd[c] = r < 3 ? fed_flow2(ht, C[r][c], C[r + 1][c], L[r][c], L[r + 1][c])
+                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);
+                if (z_down) vd[c] = splat(0.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
+                vu[c] = vd[c];
+            }
+        }
+    }
+    if (pc >= 1 && pc <= 14 && pr >= 1 && pr <= 14 && col_in) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + r;
+            if (y >= h) break;
+            const size_t o = (size_t)y * w + x0;
+            *reinterpret_cast<float4*>(dst + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
+            if (has_b)
+                *reinterpret_cast<float4*>(dst + (size_t)fb * fs + o) =
+                    make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
 // {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
 // {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
@@ -1277,6 +1408,15 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                     FedTaus ft;
                     for (int q = 0; q < 4; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
                     dim3 grid(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
+                    dim3 gridp(akz_div_up(L.w, kFedU), akz_div_up(L.h, kFedU), (n + 1) / 2);
+                    if (c->front_pair) {
+                        switch (groups[gi]) {
+                        case 1: hipLaunchKernelGGL((k_fed_pair<1>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                        case 2: hipLaunchKernelGGL((k_fed_pair<2>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                        case 3: hipLaunchKernelGGL((k_fed_pair<3>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                        default: hipLaunchKernelGGL((k_fed_pair<4>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                        }
+                    } else
                     switch (groups[gi]) {
                     case 1: hipLaunchKernelGGL((k_fed_multi<1>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
                     case 2: hipLaunchKernelGGL((k_fed_multi<2>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
