@@ -241,6 +241,7 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_cmax = cv.take<unsigned long long>(B);
     S.d_hist = cv.take<uint32_t>(B * 512);
     S.d_npoints = cv.take<uint32_t>(B);
+    S.d_cthr = cv.take<double>(B * 512);
     S.d_contrast = cv.take<double>(B);
     S.d_invk = cv.take<float>(B * 8);
     S.d_ncand = cv.take<uint32_t>(B * 32);

@@ -26,6 +26,7 @@ struct AkzSet {
     unsigned long long* d_cmax = nullptr;  // [B] bit pattern of max f64 gradient magnitude^2
     uint32_t* d_hist = nullptr;            // [B][nbins]
     uint32_t* d_npoints = nullptr;         // [B]
+    double* d_cthr = nullptr;              // [B][512] histogram bin thresholds in magnitude^2 space
     double* d_contrast = nullptr;          // [B]
     float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
     // keypoint stage

@@ -161,23 +161,19 @@ __device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
 // (unclamped) windows over positions that hold values at clamped coordinates; positions of the blurred tile
 // that lie outside the image are then overwritten with the value at their clamped coordinate (border tiles
 // only), which is what the reference's edge replication produces stage by stage.
-template <int R, int SG, int TH, int NT, typename InT, bool FLOW>
-__global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
-                                                       GaussTaps taps, OffK k, float* __restrict__ out_g,
-                                                       float* __restrict__ out_flow, float2* __restrict__ out_xy,
-                                                       const float* __restrict__ invk, int invk_off)
+// Blurred two-frame tile: loads the input tile of frames fa / fb, runs the separable blur and leaves the
+// blurred tile (GH x CG, split-plane layout) in s_a; s_h is scratch.  Shared by the level front-end and the
+// contrast-factor passes.
+template <int R, int SG, int TH, int NT, typename InT>
+__device__ __forceinline__ void pair_blur_tile(const InT* __restrict__ in, int w, int h, size_t fs, int fa, int fb,
+                                               int tx0, int ty0, const GaussTaps& taps, v2f* __restrict__ s_a,
+                                               v2f* __restrict__ s_h)
 {
     constexpr int N = 2 * R + 1;
     constexpr int CI = kTW + 16, CG = kTW + 8;
     constexpr int GH = TH + 2 * SG, IH = GH + 2 * R;
-    __shared__ __attribute__((aligned(16))) v2f s_a[IH * CI];   // input tile, later the blurred tile (GH x CG)
-    __shared__ __attribute__((aligned(16))) v2f s_h[IH * CG];
     v2f* s_in = s_a;
     v2f* s_g = s_a;
-    const int fa = 2 * blockIdx.z;
-    const bool has_b = fa + 1 < n;
-    const int fb = has_b ? fa + 1 : fa;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const InT* srca = in + (size_t)fa * fs;
     const InT* srcb = in + (size_t)fb * fs;
@@ -239,6 +235,25 @@ __global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in,
         }
         __syncthreads();
     }
+}
+
+template <int R, int SG, int TH, int NT, typename InT, bool FLOW>
+__global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
+                                                       GaussTaps taps, OffK k, float* __restrict__ out_g,
+                                                       float* __restrict__ out_flow, float2* __restrict__ out_xy,
+                                                       const float* __restrict__ invk, int invk_off)
+{
+    constexpr int CI = kTW + 16, CG = kTW + 8;
+    constexpr int GH = TH + 2 * SG, IH = GH + 2 * R;
+    __shared__ __attribute__((aligned(16))) v2f s_a[IH * CI];   // input tile, later the blurred tile (GH x CG)
+    __shared__ __attribute__((aligned(16))) v2f s_h[IH * CG];
+    v2f* s_g = s_a;
+    const int fa = 2 * blockIdx.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, taps, s_a, s_h);
     v2f inverse_k = splat(0.0f);
     if (FLOW) inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
     for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
@@ -298,6 +313,147 @@ __global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in,
             float4* xy = reinterpret_cast<float4*>(out_xy + o);
             xy[0] = make_float4(res_x[0].y, res_y[0].y, res_x[1].y, res_y[1].y);
             xy[1] = make_float4(res_x[2].y, res_y[2].y, res_x[3].y, res_y[3].y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrast factor on two frames per block (contrast_factor.rs:16-64): the same blurred two-frame tile as the
+// level front-end (sigma 1.0, one-pixel ring), then the simple Scharr gradient and
+//   pass CMAX : the per-frame maximum of v = f64(lx*lx) + f64(ly*ly) over interior pixels,
+//   pass CHIST: the histogram of floor(nbins * (sqrt(v) / hmax)).
+// The histogram pass does not evaluate the f64 square root and division per pixel.  The bin index is a
+// non-decreasing function of v (sqrt, division by a positive constant, multiplication and floor are all
+// monotone under round-to-nearest), so bin k is exactly the v-interval [T[k], T[k+1]) where T[k] is the
+// smallest f64 with floor(nbins * (sqrt(T[k]) / hmax)) >= k.  k_contrast_thresholds finds the T[k] by
+// bisection over the f64 bit patterns with the reference's own expression; the pass then takes an f32
+// estimate of the bin and moves it to the interval that contains v (two f64 compares).
+__global__ __launch_bounds__(512) void k_contrast_thresholds(const unsigned long long* __restrict__ cmax, int nbins,
+                                                             double* __restrict__ thr)
+{
+    const int f = blockIdx.x, k = threadIdx.x;
+    if (k > nbins) return;
+    double* T = thr + (size_t)f * 512;
+    const double vmax = __longlong_as_double((long long)cmax[f]);
+    const double hmax = sqrt(vmax);
+    if (k == 0) { T[0] = 0.0; return; }
+    if (k == nbins || !(hmax > 0.0)) { T[k] = __longlong_as_double(0x7FF0000000000000ll); return; }   // +inf: bin nbins-1 is open-ended
+    // smallest bit pattern in [0, bits(vmax)] whose bin is >= k; if even vmax falls short, nothing reaches bin k
+    unsigned long long lo = 0, hi = cmax[f];
+    auto bin_of = [&](unsigned long long bits) {
+        double modg = sqrt(__longlong_as_double((long long)bits));
+        return floor((double)nbins * (modg / hmax));
+    };
+    if (bin_of(hi) < (double)k) { T[k] = __longlong_as_double(0x7FF0000000000000ll); return; }
+    while (lo < hi) {
+        unsigned long long mid = lo + ((hi - lo) >> 1);
+        if (bin_of(mid) >= (double)k) hi = mid;
+        else lo = mid + 1;
+    }
+    T[k] = __longlong_as_double((long long)lo);
+}
+
+template <typename InT, int EPI>
+__global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ in, int w, int h, size_t fs, int n,
+                                                        GaussTaps taps, unsigned long long* __restrict__ cmax,
+                                                        const double* __restrict__ thr, uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ npoints, int nbins)
+{
+    constexpr int R = 2, SG = 1, TH = kFTH, NT = kFNT;
+    constexpr int CI = kTW + 16, CG = kTW + 8;
+    constexpr int GH = TH + 2 * SG, IH = GH + 2 * R;
+    __shared__ __attribute__((aligned(16))) v2f s_a[IH * CI];
+    __shared__ __attribute__((aligned(16))) v2f s_h[IH * CG];
+    __shared__ uint32_t s_hist[(EPI == EPI_CHIST) ? 2 * 512 : 1];
+    __shared__ double s_thr[(EPI == EPI_CHIST) ? 2 * 512 : 1];
+    __shared__ double s_red[(EPI == EPI_CMAX) ? 2 * (NT / 64) : 1];
+    const int fa = 2 * blockIdx.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    if (EPI == EPI_CHIST) {
+        for (int i = tid; i < 2 * 512; i += NT) {
+            s_hist[i] = 0;
+            const int f = i >> 9, kk = i & 511;
+            s_thr[i] = kk <= nbins ? thr[(size_t)(f ? fb : fa) * 512 + kk] : 0.0;
+        }
+    }
+    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, taps, s_a, s_h);   // ends with a barrier
+    const float4* g4 = reinterpret_cast<const float4*>(s_a);
+    double lmax[2] = {-1.0, -1.0};
+    float inv_hmax[2] = {0.0f, 0.0f};
+    if (EPI == EPI_CHIST) {
+        inv_hmax[0] = 1.0f / sqrtf((float)__longlong_as_double((long long)cmax[fa]));
+        inv_hmax[1] = 1.0f / sqrtf((float)__longlong_as_double((long long)cmax[fb]));
+    }
+    for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
+        const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
+        const int x0 = tx0 + 4 * c, y = ty0 + q;
+        if (x0 >= w || y < 1 || y > h - 2) continue;   // contrast_factor.rs:27-37: interior pixels only
+        const int r0 = q + SG;
+        v2f m[12], z[12], pz[12];
+        lds_read12<CG, 3, 8>(g4, r0 - 1, c, m);
+        lds_read12<CG, 3, 8>(g4, r0, c, z);
+        lds_read12<CG, 3, 8>(g4, r0 + 1, c, pz);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            // simple Scharr (derivatives.rs:3-11) in the reference's lane order
+            v2f hx_m = m[5 + o] - m[3 + o];
+            v2f hx_0 = z[5 + o] - z[3 + o];
+            v2f hx_p = pz[5 + o] - pz[3 + o];
+            v2f lx = (splat(3.0f) * hx_m + splat(10.0f) * hx_0) + splat(3.0f) * hx_p;
+            v2f hy_m = (splat(3.0f) * m[3 + o] + splat(10.0f) * m[4 + o]) + splat(3.0f) * m[5 + o];
+            v2f hy_p = (splat(3.0f) * pz[3 + o] + splat(10.0f) * pz[4 + o]) + splat(3.0f) * pz[5 + o];
+            v2f ly = hy_p - hy_m;
+            v2f lx2 = lx * lx, ly2 = ly * ly;           // squares in f32, sum in f64
+            const int x = x0 + o;
+            if (x < 1 || x > w - 2) continue;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (f == 1 && !has_b) continue;
+                const double v = (double)lx2[f] + (double)ly2[f];
+                if (EPI == EPI_CMAX) {
+                    lmax[f] = v > lmax[f] ? v : lmax[f];
+                } else if (v != 0.0) {                 // modg != 0
+                    const double* T = s_thr + f * 512;
+                    int b = (int)((float)nbins * (sqrtf((float)v) * inv_hmax[f]));
+                    b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
+                    while (b > 0 && v < T[b]) --b;
+                    while (b < nbins - 1 && v >= T[b + 1]) ++b;
+                    atomicAdd(&s_hist[f * 512 + b], 1u);
+                    atomicAdd(&s_hist[f * 512 + 511], 1u);   // num_points
+                }
+            }
+        }
+    }
+    if (EPI == EPI_CMAX) {
+        // non-negative doubles order like their bit patterns: wave max by shuffles, one atomic per block and frame
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            double v = lmax[f];
+            for (int off = 32; off > 0; off >>= 1) {
+                double o = __shfl_down(v, off);
+                v = o > v ? o : v;
+            }
+            if ((tid & 63) == 0) s_red[f * (NT / 64) + (tid >> 6)] = v;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            double mx = s_red[tid * (NT / 64)];
+            for (int i = 1; i < NT / 64; ++i) mx = s_red[tid * (NT / 64) + i] > mx ? s_red[tid * (NT / 64) + i] : mx;
+            if (mx >= 0.0 && (tid == 0 || has_b))
+                atomicMax(&cmax[tid ? fb : fa], (unsigned long long)__double_as_longlong(mx));
+        }
+    }
+    if (EPI == EPI_CHIST) {
+        __syncthreads();
+        for (int i = tid; i < 2 * 512; i += NT) {
+            const int f = i >> 9, kk = i & 511;
+            if (f == 1 && !has_b) continue;
+            if (!s_hist[i]) continue;
+            if (kk < nbins) atomicAdd(&hist[(size_t)(f ? fb : fa) * nbins + kk], s_hist[i]);
+            else if (kk == 511) atomicAdd(&npoints[f ? fb : fa], s_hist[i]);
         }
     }
 }
@@ -1326,8 +1482,20 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
     AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * 32 * (size_t)n, s));
-    AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
-    AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
+    if ((w & 3) == 0 && c->front_pair && nbins <= 510) {
+        dim3 gridc(akz_div_up(w, kTW), akz_div_up(h, kFTH), (n + 1) / 2);
+        hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
+                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(512), 0, s, S.d_cmax, nbins, S.d_cthr);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CHIST>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
+                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins);
+        AKZ_LAUNCH_CHECK();
+    } else {
+        AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
+        AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
+    }
     hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
                        S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk);
     AKZ_LAUNCH_CHECK();
