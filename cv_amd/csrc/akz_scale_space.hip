@@ -162,12 +162,63 @@ __device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
 // (unclamped) windows over positions that hold values at clamped coordinates; positions of the blurred tile
 // that lie outside the image are then overwritten with the value at their clamped coordinate (border tiles
 // only), which is what the reference's edge replication produces stage by stage.
+// Raw (unconverted) 4-pixel loads, so a prefetched u8 tile costs one VGPR per item and frame
+__device__ __forceinline__ float4 load4_raw(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ uint32_t load4_raw(const uint8_t* p, size_t i) { return *reinterpret_cast<const uint32_t*>(p + i); }
+__device__ __forceinline__ float4 raw_px(float4 r) { return r; }
+__device__ __forceinline__ float4 raw_px(uint32_t u)   // image.rs:54 — f32::from(v) / 255f32
+{
+    return make_float4((float)(u & 0xFFu) / 255.0f, (float)((u >> 8) & 0xFFu) / 255.0f,
+                       (float)((u >> 16) & 0xFFu) / 255.0f, (float)(u >> 24) / 255.0f);
+}
+template <typename InT> struct RawOf { typedef float4 type; };
+template <> struct RawOf<uint8_t> { typedef uint32_t type; };
+
+// Register-held input tile of the NEXT row tile of a block (interior tile columns only): fetched right after
+// the current tile went to LDS, so the HBM/L2 latency of the loads hides behind the current tile's passes.
+template <int R, int SG, int TH, int NT, typename InT>
+struct PairTileRegs {
+    static constexpr int CI = kTW + 16, IH = TH + 2 * SG + 2 * R;
+    static constexpr int ITEMS = (IH * (CI / 4) + NT - 1) / NT;
+    typename RawOf<InT>::type ra[ITEMS], rb[ITEMS];
+    __device__ __forceinline__ void fetch(const InT* __restrict__ in, int w, int h, size_t fs, int fa, int fb, int tx0,
+                                          int ty0)
+    {
+        const InT* srca = in + (size_t)fa * fs;
+        const InT* srcb = in + (size_t)fb * fs;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            int idx = (int)threadIdx.x + i * NT;
+            if (idx < IH * (CI / 4)) {
+                int iy = idx / (CI / 4), c4 = idx - iy * (CI / 4);
+                int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
+                size_t o = (size_t)cy * w + (tx0 - 8 + 4 * c4);
+                ra[i] = load4_raw(srca, o);
+                rb[i] = load4_raw(srcb, o);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(v2f* __restrict__ s_in) const
+    {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            int idx = (int)threadIdx.x + i * NT;
+            if (idx < IH * (CI / 4)) {
+                int iy = idx / (CI / 4), c4 = idx - iy * (CI / 4);
+                float4 a = raw_px(ra[i]), b = raw_px(rb[i]);
+                lds_write4<CI>(&s_in[iy * CI], c4, (v2f){a.x, b.x}, (v2f){a.y, b.y}, (v2f){a.z, b.z}, (v2f){a.w, b.w});
+            }
+        }
+    }
+};
+
 // Blurred two-frame tile: loads the input tile of frames fa / fb, runs the separable blur and leaves the
 // blurred tile (GH x CG, split-plane layout) in s_a; s_h is scratch.  Shared by the level front-end and the
 // contrast-factor passes.
 template <int R, int SG, int TH, int NT, typename InT>
 __device__ __forceinline__ void pair_blur_tile(const InT* __restrict__ in, int w, int h, size_t fs, int fa, int fb,
-                                               int tx0, int ty0, const GaussTaps& taps, v2f* __restrict__ s_a,
+                                               int tx0, int ty0, int next_ty0, const GaussTaps& taps,
+                                               PairTileRegs<R, SG, TH, NT, InT>& regs, v2f* __restrict__ s_a,
                                                v2f* __restrict__ s_h)
 {
     constexpr int N = 2 * R + 1;
@@ -176,18 +227,14 @@ __device__ __forceinline__ void pair_blur_tile(const InT* __restrict__ in, int w
     v2f* s_in = s_a;
     v2f* s_g = s_a;
     const int tid = threadIdx.x;
-    const InT* srca = in + (size_t)fa * fs;
-    const InT* srcb = in + (size_t)fb * fs;
-    const bool x_inside = tx0 >= 8 && tx0 + kTW + 8 <= w;
+    const bool x_inside = tx0 >= 8 && tx0 + kTW + 8 <= w;   // same for every row tile of the block
     if (x_inside) {
-        for (int idx = tid; idx < IH * (CI / 4); idx += NT) {
-            int iy = idx / (CI / 4), c4 = idx - iy * (CI / 4);
-            int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
-            size_t o = (size_t)cy * w + (tx0 - 8 + 4 * c4);
-            float4 a = load4_px(srca, o), b = load4_px(srcb, o);
-            lds_write4<CI>(&s_in[iy * CI], c4, (v2f){a.x, b.x}, (v2f){a.y, b.y}, (v2f){a.z, b.z}, (v2f){a.w, b.w});
-        }
+        if (next_ty0 == -2) regs.fetch(in, w, h, fs, fa, fb, tx0, ty0);   // no prefetch: load this tile now
+        regs.commit(s_in);                                  // fetched by the caller / the previous tile
+        if (next_ty0 >= 0) regs.fetch(in, w, h, fs, fa, fb, tx0, next_ty0);
     } else {
+        const InT* srca = in + (size_t)fa * fs;
+        const InT* srcb = in + (size_t)fb * fs;
         for (int idx = tid; idx < IH * CI; idx += NT) {
             int iy = idx / CI, ix = idx - iy * CI;
             int cx = clampi(tx0 - 8 + ix, 0, w - 1);
@@ -238,8 +285,8 @@ __device__ __forceinline__ void pair_blur_tile(const InT* __restrict__ in, int w
     }
 }
 
-template <int R, int SG, int TH, int NT, typename InT, bool FLOW>
-__global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
+template <int R, int SG, int TH, int NT, typename InT, bool FLOW, int TPB>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const InT* __restrict__ in, int w, int h, size_t fs, int n,
                                                        GaussTaps taps, OffK k, float* __restrict__ out_g,
                                                        float* __restrict__ out_flow, float2* __restrict__ out_xy,
                                                        const float* __restrict__ invk, int invk_off)
@@ -252,11 +299,19 @@ __global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in,
     const int fa = 2 * blockIdx.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * TH;
+    const int tx0 = blockIdx.x * kTW;
     const int tid = threadIdx.x;
-    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, taps, s_a, s_h);
     v2f inverse_k = splat(0.0f);
     if (FLOW) inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
+    // TPB vertically adjacent tiles per block, the next tile's input prefetched into registers
+    PairTileRegs<R, SG, TH, NT, InT> regs;
+    if (TPB > 1 && tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)blockIdx.y * TPB * TH);
+    for (int it = 0; it < TPB; ++it) {
+    const int ty0 = ((int)blockIdx.y * TPB + it) * TH;
+    if (ty0 >= h) break;
+    if (it) __syncthreads();                     // the previous tile's readers are done with s_a
+    const int ty1 = TPB == 1 ? -2 : (it + 1 < TPB && ty0 + TH < h) ? ty0 + TH : -1;
+    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, ty1, taps, regs, s_a, s_h);
     for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
         const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
         const int x0 = tx0 + 4 * c, y = ty0 + q;
@@ -315,6 +370,7 @@ __global__ __launch_bounds__(NT) void k_level_front2(const InT* __restrict__ in,
             xy[0] = make_float4(res_x[0].y, res_y[0].y, res_x[1].y, res_y[1].y);
             xy[1] = make_float4(res_x[2].y, res_y[2].y, res_x[3].y, res_y[3].y);
         }
+    }
     }
 }
 
@@ -391,11 +447,14 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
     // kCTiles vertically adjacent tiles per block: the per-frame maximum / histogram is flushed to HBM once
     // per block, and with one flush per tile the device-scope atomics on the 300 bins of a frame (1350 blocks
     // each) took as long as the arithmetic (rocprof: 850 us vs 405 us for the max pass)
+    PairTileRegs<R, SG, TH, NT, InT> regs;
+    if (tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)blockIdx.y * kCTiles * TH);
     for (int it = 0; it < kCTiles; ++it) {
     const int ty0 = ((int)blockIdx.y * kCTiles + it) * TH;
     if (ty0 >= h) break;
     if (it) __syncthreads();                     // the previous tile's readers are done with s_a
-    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, taps, s_a, s_h);   // ends with a barrier
+    const int ty1 = (it + 1 < kCTiles && ty0 + TH < h) ? ty0 + TH : -1;
+    pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, ty1, taps, regs, s_a, s_h);   // ends with a barrier
     for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
         const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
         const int x0 = tx0 + 4 * c, y = ty0 + q;
@@ -1479,14 +1538,17 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
     const bool fused0 = P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
     if (fused0 && (w & 3) == 0 && c->front_pair) {
-        if (c->front_cfg == 1)
-            hipLaunchKernelGGL((k_level_front2<4, 2, 32, 256, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, 32), (n + 1) / 2),
-                               dim3(256), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
-                               (const float*)nullptr, 0);
-        else
-            hipLaunchKernelGGL((k_level_front2<4, 2, kFTH, kFNT, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kFTH), (n + 1) / 2),
-                               dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
-                               (const float*)nullptr, 0);
+#define AKZ_FRONT0(THV, NTV, TPBV)                                                                                  \
+    hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
+                       dim3(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s,    \
+                       d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0], (const float*)nullptr, 0)
+        // measured (ms of scale space per 64 frames): 32 rows x 256 threads 10.18, 24 x 512 10.50; five row
+        // tiles per block with register prefetch 10.83 / 11.03 (the loop costs ~25 VGPRs and a wave per SIMD)
+        switch (c->front_cfg) {
+        case 0: AKZ_FRONT0(kFTH, kFNT, 1); break;
+        default: AKZ_FRONT0(32, 256, 1); break;
+        }
+#undef AKZ_FRONT0
         AKZ_LAUNCH_CHECK();
     } else if (fused0) {
         hipLaunchKernelGGL((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
@@ -1553,15 +1615,16 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_FRONT(SGV)                                                                                               \
     hipLaunchKernelGGL((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
                        lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
-                dim3 gridp(akz_div_up(L.w, kTW), akz_div_up(L.h, kFTH), (n + 1) / 2);
-                dim3 gridq(akz_div_up(L.w, kTW), akz_div_up(L.h, 32), (n + 1) / 2);
+#define AKZ_FRONT2X(SGV, THV, NTV, TPBV)                                                                             \
+    hipLaunchKernelGGL((k_level_front2<2, SGV, THV, NTV, float, true, TPBV>),                                            \
+                       dim3(akz_div_up(L.w, kTW), akz_div_up(akz_div_up(L.h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s, \
+                       init, L.w, L.h, fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk,            \
+                       (int)L.octave)
 #define AKZ_FRONT2(SGV)                                                                                              \
-    if (c->front_cfg == 1)                                                                                           \
-        hipLaunchKernelGGL((k_level_front2<2, SGV, 32, 256, float, true>), gridq, dim3(256), 0, s, init, L.w, L.h, fs, \
-                           n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave);         \
-    else                                                                                                             \
-        hipLaunchKernelGGL((k_level_front2<2, SGV, kFTH, kFNT, float, true>), gridp, dim3(kFNT), 0, s, init, L.w, L.h, \
-                           fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+    switch (c->front_cfg) {                                                                                          \
+    case 0: AKZ_FRONT2X(SGV, kFTH, kFNT, 1); break;                                                                  \
+    default: AKZ_FRONT2X(SGV, 32, 256, 1); break;                                                                    \
+    }
                 const bool pair = (L.w & 3) == 0 && c->front_pair;
                 switch (L.deriv_sigma) {
                 case 2: if (pair) { AKZ_FRONT2(2); } else AKZ_FRONT(2); break;
@@ -1570,6 +1633,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 }
 #undef AKZ_FRONT
 #undef AKZ_FRONT2
+#undef AKZ_FRONT2X
                 AKZ_LAUNCH_CHECK();
             } else {
                 AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,
