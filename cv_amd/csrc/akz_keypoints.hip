@@ -677,88 +677,27 @@ __global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables
 
 // ---------------------------------------------------------------------------------------------
 // Fast path of A16 + A17 for the reference's default pattern (descriptor_pattern_size 10, 3 channels:
-// grids of 2x2 / 3x3 / 4x4 cells with sample steps 10 / 7 / 5).  One wave per keypoint, grid by grid:
-//   gather   lane <-> sample, consecutive lanes = consecutive samples of a cell row, i.e. neighbouring
-//            pixels: the wave's loads fall on a few cache lines instead of 64, and {Lx,Ly} is one 8-byte
-//            load.  Each sample's (Lt, rotated dx, rotated dy) goes to the wave's LDS segment.
+// grids of 2x2 / 3x3 / 4x4 cells with sample steps 10 / 7 / 5).  One wave per keypoint:
+//   gather   lane <-> lattice sample, consecutive lanes = consecutive samples of a lattice row, i.e.
+//            neighbouring pixels: the wave's loads fall on a few cache lines instead of 64, and {Lx,Ly} is one
+//            8-byte load.  Each sample's (Lt, rotated dx, rotated dy) goes to the wave's LDS segment.
 //   reduce   lane <-> cell: the cell's samples are summed from LDS sequentially in the reference's
 //            (k outer, l inner) order (descriptors.rs:123-159) — the order is what makes the f32 sums
 //            bit-exact, so there is no tree reduction.
 // A wave's DS instructions execute in order, so the reduce phase sees the gather phase's writes without
 // a barrier; waves never share LDS here.
-template <int ST, int SIDE, int VBASE>
-__device__ __forceinline__ bool desc_grid(const float* __restrict__ LT, const float2* __restrict__ LXY, int W, int Hh,
-                                          float xf, float yf, float co, float si, float scale, float* s_ri,
-                                          float* s_dx, float* s_dy, float* s_val, int lane)
-{
-    constexpr int CS = ST * ST;             // samples per cell
-    constexpr int NS = SIDE * SIDE * CS;    // samples of the grid
-    constexpr int NIT = (NS + 63) / 64;     // gather rounds (7 for every grid of the default pattern)
-    bool oob = false;
-    // round 1: all sample addresses, then ALL gathers back to back (2 * NIT loads in flight per lane: the
-    // kernel is bound by gather latency, not by issue), round 2: rotate and park in LDS
-    int idx[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int s = it * 64 + lane;
-        const bool on = s < NS;
-        const int cell = s / CS, rem = s - cell * CS;
-        const int kk = rem / ST, ll = rem - kk * ST;
-        // cell origins step from -pattern_size: i outer (k), j inner (l) — descriptors.rs:117-118
-        const float kf = (float)(-10 + (cell / SIDE) * ST + kk);
-        const float lf = (float)(-10 + (cell % SIDE) * ST + ll);
-        // descriptors.rs:127-128, exact expression order
-        float sample_y = yf + (lf * co * scale + kf * si * scale);
-        float sample_x = xf + (-lf * si * scale + kf * co * scale);
-        int y1 = sat_i32(roundf(sample_y));
-        int x1 = sat_i32(roundf(sample_x));
-        bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
-        oob |= on && bad;
-        idx[it] = (on && !bad) ? y1 * W + x1 : 0;
-    }
-    float ri[NIT];
-    float2 dd[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        ri[it] = LT[idx[it]];
-        dd[it] = LXY[idx[it]];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int s = it * 64 + lane;
-        float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
-        float rrx = -dd[it].x * si + dd[it].y * co;
-        if (s < NS) {
-            s_ri[s] = ri[it];
-            s_dx[s] = rrx;
-            s_dy[s] = rry;
-        }
-    }
-    if (__any(oob)) return true;  // Error::SampleOutOfBounds: the keypoint is dropped (descriptors.rs:28)
-    if (lane < SIDE * SIDE) {
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        const int b = lane * CS;
-#pragma unroll 5
-        for (int t = 0; t < CS; ++t) {
-            di += s_ri[b + t];
-            dx += s_dx[b + t];
-            dy += s_dy[b + t];
-        }
-        const float ns = (float)CS;
-        s_val[VBASE + lane * 3 + 0] = di / ns;
-        s_val[VBASE + lane * 3 + 1] = dx / ns;
-        s_val[VBASE + lane * 3 + 2] = dy / ns;
-    }
-    return false;
-}
-
+// The three grids sample the SAME lattice: sample (k, l) of any grid sits at
+// (xf + (-l*si*scale + k*co*scale), yf + (l*co*scale + k*si*scale)) with integer k, l in [-10, 10] (the 3x3 grid
+// of step 7 reaches +10, the other two stop at +9), so the 21 x 21 = 441 lattice values are gathered ONCE
+// (7 rounds of 64 lanes, all loads in flight) and parked in the wave's LDS segment; the 4 + 9 + 16 = 29 cells
+// are then summed concurrently, one lane per cell, each in the reference's (k outer, l inner) order.
 __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescTables* __restrict__ desc_p,
                                                        const DevKp* __restrict__ in,
                                                        const uint32_t* __restrict__ n_in, uint32_t stride,
                                                        const uint32_t* __restrict__ perm,
                                                        akz_descriptor* __restrict__ out, uint32_t* __restrict__ flag)
 {
-    constexpr int SMAX = 448;  // >= 441 samples of the largest grid
+    constexpr int LAT = 21, NS = LAT * LAT, NIT = (NS + 63) / 64, SMAX = 448;
     __shared__ float s_ri[4][SMAX], s_dx[4][SMAX], s_dy[4][SMAX];
     __shared__ float s_val[4][96];
     const DescTables& c_desc = *desc_p;
@@ -777,11 +716,65 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
     const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
     const float* LT = L.Lt + (size_t)frame * L.fs;
     const float2* LXY = L.Lxy + (size_t)frame * L.fs;
-    bool oob = desc_grid<10, 2, 0>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
-    if (!oob)
-        oob = desc_grid<7, 3, 12>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
-    if (!oob)
-        oob = desc_grid<5, 4, 39>(LT, LXY, L.w, L.h, xf, yf, co, si, scale, s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+    const int W = L.w, Hh = L.h;
+    bool oob = false;
+    int idx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
+        const bool on = s < NS;
+        const int kq = s / LAT;
+        const float kf = (float)(kq - 10), lf = (float)(s - kq * LAT - 10);
+        // descriptors.rs:127-128, exact expression order
+        float sample_y = yf + (lf * co * scale + kf * si * scale);
+        float sample_x = xf + (-lf * si * scale + kf * co * scale);
+        int y1 = sat_i32(roundf(sample_y));
+        int x1 = sat_i32(roundf(sample_x));
+        bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
+        oob |= on && bad;   // Error::SampleOutOfBounds in any grid drops the keypoint (descriptors.rs:28)
+        idx[it] = (on && !bad) ? y1 * W + x1 : 0;
+    }
+    float ri[NIT];
+    float2 dd[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        ri[it] = LT[idx[it]];
+        dd[it] = LXY[idx[it]];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
+        float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
+        float rrx = -dd[it].x * si + dd[it].y * co;
+        if (s < NS) {
+            s_ri[wv][s] = ri[it];
+            s_dx[wv][s] = rrx;
+            s_dy[wv][s] = rry;
+        }
+    }
+    oob = __any(oob);
+    if (!oob && lane < 29) {
+        // lane -> (grid, cell): lanes 0-3 the 2x2 grid (step 10), 4-12 the 3x3 grid (step 7), 13-28 the 4x4 grid (step 5)
+        const int st = lane < 4 ? 10 : (lane < 13 ? 7 : 5);
+        const int side = lane < 4 ? 2 : (lane < 13 ? 3 : 4);
+        const int cell = lane < 4 ? lane : (lane < 13 ? lane - 4 : lane - 13);
+        const int vbase = (lane < 4 ? 0 : (lane < 13 ? 12 : 39)) + cell * 3;
+        const int ci = cell / side, cj = cell - ci * side;          // i outer (k), j inner (l): descriptors.rs:117-118
+        const int base = (ci * st) * LAT + cj * st;
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        for (int kk = 0; kk < st; ++kk) {
+            const int row = base + kk * LAT;
+            for (int ll = 0; ll < st; ++ll) {                      // mldb_fill_values order, descriptors.rs:123-159
+                di += s_ri[wv][row + ll];
+                dx += s_dx[wv][row + ll];
+                dy += s_dy[wv][row + ll];
+            }
+        }
+        const float ns = (float)(st * st);
+        s_val[wv][vbase + 0] = di / ns;
+        s_val[wv][vbase + 1] = dx / ns;
+        s_val[wv][vbase + 2] = dy / ns;
+    }
     // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
     uint32_t byte = 0;
     if (!oob) {
