@@ -1255,13 +1255,13 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
 // determinant tile (plus its one-pixel ring) from LDS.  Staged positions hold the value at their clamped
 // coordinate, so the +-SG taps need no clamping of their own.  12 output rows per block: 18 strips x 14 ring
 // rows = 252 strips for 256 threads.
-template <int SG>
-__global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
+template <int SG, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
                                                             int w, int h, size_t fs, int n, OffK k, float sigma_quat,
                                                             CandParams cp, uint2* __restrict__ cand,
                                                             uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
 {
-    constexpr int TW = 64, TH = kDTH;
+    constexpr int TW = 64;
     constexpr int CS = TW + 16, RS = TH + 2 + 2 * SG;    // staged tiles: x = tx0 - 8 + col, y = ty0 - 1 - SG + row
     constexpr int CG = TW + 8, RG = TH + 2;              // determinant tile: x = tx0 - 4 + col, y = ty0 - 1 + row
     __shared__ __attribute__((aligned(16))) v2f s_x[RS * CS];
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __rest
     const float2* Db = Lxy + (size_t)fb * fs;
     if (tx0 >= 8 && tx0 + TW + 8 <= w) {
         // item = (row, pixel pair j): one 16-byte load per frame, one 16-byte chunk per plane
-        for (int idx = tid; idx < RS * (CS / 2); idx += 256) {
+        for (int idx = tid; idx < RS * (CS / 2); idx += NT) {
             int r = idx / (CS / 2), j = idx - r * (CS / 2);
             int cy = clampi(ty0 - 1 - SG + r, 0, h - 1);
             size_t o = (size_t)cy * w + (tx0 - 8 + 2 * j);
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __rest
             reinterpret_cast<float4*>(s_y)[chunk] = make_float4(a.y, b.y, a.w, b.w);
         }
     } else {
-        for (int idx = tid; idx < RS * CS; idx += 256) {
+        for (int idx = tid; idx < RS * CS; idx += NT) {
             int r = idx / CS, p = idx - r * CS;
             int cx = clampi(tx0 - 8 + p, 0, w - 1), cy = clampi(ty0 - 1 - SG + r, 0, h - 1);
             size_t o = (size_t)cy * w + cx;
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __rest
     __syncthreads();
     const float4* x4 = reinterpret_cast<const float4*>(s_x);
     const float4* y4 = reinterpret_cast<const float4*>(s_y);
-    for (int idx = tid; idx < RG * (CG / 4); idx += 256) {
+    for (int idx = tid; idx < RG * (CG / 4); idx += NT) {
         const int q = idx / (CG / 4), c = idx - q * (CG / 4);
         v2f xm[12], xz[12], xp[12], ym[12], yp[12], det[4];
         lds_read12<CS, 4 - SG, 7 + SG>(x4, q, c, xm);
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand2(const float2* __rest
     }
     __syncthreads();
     const float4* d4 = reinterpret_cast<const float4*>(s_d);
-    for (int idx = tid; idx < TH * (TW / 4); idx += 256) {
+    for (int idx = tid; idx < TH * (TW / 4); idx += NT) {
         const int q = idx / (TW / 4), c = idx - q * (TW / 4);
         const int x0 = tx0 + 4 * c, y = ty0 + q;
         if (x0 >= w || y < 1 || y > h - 2) continue;          // interior pixels only (:50)
@@ -1720,15 +1720,20 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_D2(SGV)                                                                                                  \
     hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,          \
                        (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
-            dim3 grid2p(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2);
 #define AKZ_D2P(SGV)                                                                                                 \
-    hipLaunchKernelGGL((k_deriv_second_cand2<SGV>), grid2p, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs, n, k,  \
-                       L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+    if (c->deriv_cfg == 1)                                                                                           \
+        hipLaunchKernelGGL((k_deriv_second_cand2<SGV, 26, 512>),                                                     \
+                           dim3(akz_div_up(L.w, 64), akz_div_up(L.h, 26), (n + 1) / 2), dim3(512), 0, s, S.Lxy[i],   \
+                           S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err);          \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_deriv_second_cand2<SGV, kDTH, 256>),                                                   \
+                           dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i], \
+                           S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
             switch (L.deriv_sigma) {
-            case 2: if (pair2) AKZ_D2P(2); else AKZ_D2(2); break;
-            case 3: if (pair2) AKZ_D2P(3); else AKZ_D2(3); break;
-            case 4: if (pair2) AKZ_D2P(4); else AKZ_D2(4); break;
+            case 2: if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
+            case 3: if (pair2) { AKZ_D2P(3); } else AKZ_D2(3); break;
+            case 4: if (pair2) { AKZ_D2P(4); } else AKZ_D2(4); break;
             default: AKZ_D2(0); break;
             }
 #undef AKZ_D2

@@ -24,7 +24,14 @@ def _all_gather(dist, out, inp):
     try:
         dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1))
     except (RuntimeError, NotImplementedError):
+        # gloo stages device tensors through host memory on its own streams; a full device sync on both
+        # sides keeps that staging ordered with the producer / consumer streams of this process (the RCCL
+        # path above is stream-ordered and needs none).  Seen without it: roughly one smoke run in fifteen
+        # matched a micro-batch against the previous micro-batch's gathered block.
+        import torch
+        torch.cuda.synchronize()
         dist.all_gather(list(out.unbind(0)), inp.contiguous())
+        torch.cuda.synchronize()
 
 
 def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, gath_d, gath_n, prev_descs,
