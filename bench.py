@@ -270,7 +270,7 @@ def main():
                                    "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
                        "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
                        "mean_matches_per_pair": round(n_match, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_fed_multi<T> (calculate_step, up to 4 steps per launch)",
+            "roofline": {"bound": "hbm", "kernel": "k_fed_pair<T> (calculate_step, two frames per block, up to 4 steps per launch)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(MB),
                          "launches": int(fed_launches),
@@ -292,7 +292,7 @@ def main():
 
 def pmc_traffic_per_launch(mb=None):
     """HBM bytes per FED launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the k_fed_multi dispatches of one micro-batch / launches;
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the k_fed_pair dispatches of one micro-batch / launches;
     FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction for 16-byte coalesced reads)."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
