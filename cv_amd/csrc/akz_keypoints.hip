@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
     __shared__ uint32_t s_lo[kMaxLevels + 1], s_hi[kMaxLevels + 1];
     __shared__ float4 s_j[256];  // x, y, response, class bits of a tile of later entries
     __shared__ uint32_t s_range[2];
+    __shared__ float s_ylo[4], s_yhi[4];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
     const uint32_t i0 = blockIdx.x * 256;
@@ -277,28 +278,47 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t rb = s_range[0], re = s_range[1];
+    const bool any_range = s_range[0] != 0xFFFFFFFFu;
+    const uint32_t rb = s_range[0] & ~63u, re = s_range[1];   // tiles start on a 64-slot boundary (chunk bounds)
     bool rep = false;
     const float size2 = ki.size * ki.size;
+    const float margin = ki.size * 1.001f + 0.01f;           // conservative: |dy| > margin  =>  dist > size^2
     const uint32_t want = ki.class_id + 1u;
-    if (rb != 0xFFFFFFFFu) {
+    if (any_range) {
         for (uint32_t t0 = rb; t0 <= re; t0 += 256) {
             uint32_t j = t0 + threadIdx.x;
+            float ylo = 3.0e38f, yhi = -3.0e38f;
             if (j <= re) {
                 const DevKp kj = ch[j];
                 s_j[threadIdx.x] = make_float4(kj.x, kj.y, kj.response, __uint_as_float(kj.class_id));
+                ylo = yhi = kj.y;
+            }
+            // y range of each 64-entry chunk: slots of a class are close to raster order, so most chunks lie
+            // entirely outside [y - size, y + size] of a given keypoint and are skipped without a distance test
+            for (int off = 32; off > 0; off >>= 1) {
+                ylo = fminf(ylo, __shfl_xor(ylo, off));
+                yhi = fmaxf(yhi, __shfl_xor(yhi, off));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                s_ylo[threadIdx.x >> 6] = ylo;
+                s_yhi[threadIdx.x >> 6] = yhi;
             }
             __syncthreads();
             if (!rep && jb <= je) {
                 const uint32_t lo = max(jb, t0), hi = min(je, min(re, t0 + 255u));
-                for (uint32_t jj = lo; jj <= hi && lo <= hi; ++jj) {
-                    const float4 q = s_j[jj - t0];
-                    if (__float_as_uint(q.w) == want) {
-                        float dx = ki.x - q.x, dy = ki.y - q.y;
-                        float dist = dx * dx + dy * dy;
-                        if (dist <= size2 && ki.response <= q.z) {
-                            rep = true;
-                            break;
+                for (uint32_t cb = lo & ~63u; cb <= hi && lo <= hi && !rep; cb += 64u) {
+                    const uint32_t ck = (cb - t0) >> 6;    // t0 is a multiple of 64 past rb's chunk: see below
+                    if (ki.y + margin < s_ylo[ck] || ki.y - margin > s_yhi[ck]) continue;
+                    const uint32_t a = max(lo, cb), b = min(hi, cb + 63u);
+                    for (uint32_t jj = a; jj <= b; ++jj) {
+                        const float4 q = s_j[jj - t0];
+                        if (__float_as_uint(q.w) == want) {
+                            float dx = ki.x - q.x, dy = ki.y - q.y;
+                            float dist = dx * dx + dy * dy;
+                            if (dist <= size2 && ki.response <= q.z) {
+                                rep = true;
+                                break;
+                            }
                         }
                     }
                 }
