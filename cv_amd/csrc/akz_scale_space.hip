@@ -38,6 +38,21 @@ enum { EPI_BLUR = 0, EPI_FLOW = 1, EPI_CMAX = 2, EPI_CHIST = 3 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (observed, not contractual: this is a
+// speed choice only), and each XCD has its own L2.  Tiles that share halo rows / columns should therefore have
+// ids that are congruent mod 8: the bijective remap below hands XCD x the x-th contiguous eighth of the tile
+// sequence (x fastest, then y, then frame pair), so a tile's neighbours hit the L2 that already holds the halo.
+__device__ __forceinline__ uint3 xcd_tile(uint3 bid, uint3 grid)
+{
+    const uint32_t nwg = grid.x * grid.y * grid.z;
+    const uint32_t orig = bid.x + grid.x * (bid.y + grid.y * bid.z);
+    const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+    const uint32_t z = t / (grid.x * grid.y), rem = t - z * (grid.x * grid.y);
+    const uint32_t y = rem / grid.x;
+    return make_uint3(rem - y * grid.x, y, z);
+}
+
 __device__ __forceinline__ float load_px(const float* p, size_t i) { return p[i]; }
 // image.rs:54 — f32::from(v) / 255f32: a true IEEE division per pixel.
 __device__ __forceinline__ float load_px(const uint8_t* p, size_t i) { return (float)p[i] / 255.0f; }
@@ -296,18 +311,19 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const In
     __shared__ __attribute__((aligned(16))) v2f s_a[IH * CI];   // input tile, later the blurred tile (GH x CG)
     __shared__ __attribute__((aligned(16))) v2f s_h[IH * CG];
     v2f* s_g = s_a;
-    const int fa = 2 * blockIdx.z;
+    const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
-    const int tx0 = blockIdx.x * kTW;
+    const int tx0 = (int)tile.x * kTW;
     const int tid = threadIdx.x;
     v2f inverse_k = splat(0.0f);
     if (FLOW) inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
     // TPB vertically adjacent tiles per block, the next tile's input prefetched into registers
     PairTileRegs<R, SG, TH, NT, InT> regs;
-    if (TPB > 1 && tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)blockIdx.y * TPB * TH);
+    if (TPB > 1 && tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)tile.y * TPB * TH);
     for (int it = 0; it < TPB; ++it) {
-    const int ty0 = ((int)blockIdx.y * TPB + it) * TH;
+    const int ty0 = ((int)tile.y * TPB + it) * TH;
     if (ty0 >= h) break;
     if (it) __syncthreads();                     // the previous tile's readers are done with s_a
     const int ty1 = TPB == 1 ? -2 : (it + 1 < TPB && ty0 + TH < h) ? ty0 + TH : -1;
@@ -424,10 +440,11 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
     __shared__ uint32_t s_hist[(EPI == EPI_CHIST) ? 2 * 512 : 1];
     __shared__ double s_thr[(EPI == EPI_CHIST) ? 2 * 512 : 1];
     __shared__ double s_red[(EPI == EPI_CMAX) ? 2 * (NT / 64) : 1];
-    const int fa = 2 * blockIdx.z;
+    const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
-    const int tx0 = blockIdx.x * kTW;
+    const int tx0 = (int)tile.x * kTW;
     const int tid = threadIdx.x, lane = tid & 63;
     if (EPI == EPI_CHIST) {
         for (int i = tid; i < 2 * 512; i += NT) {
@@ -448,9 +465,9 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
     // per block, and with one flush per tile the device-scope atomics on the 300 bins of a frame (1350 blocks
     // each) took as long as the arithmetic (rocprof: 850 us vs 405 us for the max pass)
     PairTileRegs<R, SG, TH, NT, InT> regs;
-    if (tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)blockIdx.y * kCTiles * TH);
+    if (tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)tile.y * kCTiles * TH);
     for (int it = 0; it < kCTiles; ++it) {
-    const int ty0 = ((int)blockIdx.y * kCTiles + it) * TH;
+    const int ty0 = ((int)tile.y * kCTiles + it) * TH;
     if (ty0 >= h) break;
     if (it) __syncthreads();                     // the previous tile's readers are done with s_a
     const int ty1 = (it + 1 < kCTiles && ty0 + TH < h) ? ty0 + TH : -1;
@@ -1000,11 +1017,12 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
 {
     __shared__ __attribute__((aligned(16))) float4 s_top[2][256 * 2];   // [parity][patch][4 px x 2 frames]
     __shared__ __attribute__((aligned(16))) float4 s_bot[2][256 * 2];
-    const int fa = 2 * blockIdx.z;
+    const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
     const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
-    const int x0 = (int)blockIdx.x * kFedU - 4 + 4 * pc, y0 = (int)blockIdx.y * kFedU - 4 + 4 * pr;
+    const int x0 = (int)tile.x * kFedU - 4 + 4 * pc, y0 = (int)tile.y * kFedU - 4 + 4 * pr;
     const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
     v2f L[4][4], C[4][4];
 #pragma unroll
@@ -1267,10 +1285,11 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
     __shared__ __attribute__((aligned(16))) v2f s_x[RS * CS];
     __shared__ __attribute__((aligned(16))) v2f s_y[RS * CS];
     __shared__ __attribute__((aligned(16))) v2f s_d[RG * CG];
-    const int fa = 2 * blockIdx.z;
+    const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int tx0 = (int)tile.x * TW, ty0 = (int)tile.y * TH;
     const int tid = threadIdx.x;
     const float2* Da = Lxy + (size_t)fa * fs;
     const float2* Db = Lxy + (size_t)fb * fs;
