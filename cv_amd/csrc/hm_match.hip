@@ -252,10 +252,20 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __re
     // 32 rows fall on distinct bank groups; double-buffered, filled with full 512-B-row coalesced loads
     constexpr int RS = 33;
     __shared__ uint4 s_t[2][32 * RS];
-    const HmProbX P = probs[blockIdx.y];
+    // XCD-aware order (workgroup b runs on XCD b % 8, observed): the query blocks of one problem stream the same
+    // target set, so they get ids that are congruent mod 8 and share one L2 instead of filling all eight
+    uint32_t bx, by;
+    {
+        const uint32_t nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+        by = t / gridDim.x;
+        bx = t - by * gridDim.x;
+    }
+    const HmProbX P = probs[by];
     const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t qblk = blockIdx.x * 256u;
+    const uint32_t qblk = bx * 256u;
     if (qblk >= nq) return;                             // whole block
     const uint32_t q0 = qblk + wv * 32u;                // 32 queries (one column block) per wave
     const bool wave_on = q0 < nq;                       // idle waves still help staging and hit the barriers
