@@ -391,6 +391,18 @@ __device__ __forceinline__ float fast_atan2_equiv(float y, float x)
     return a >= two_pi ? a - two_pi : a;
 }
 
+// XCD-aware block order for the one-wave-per-keypoint kernels (workgroup b runs on XCD b % 8, observed):
+// consecutive keypoints are spatial neighbours, so each XCD gets a contiguous run of (frame, keypoint block)
+// ids and its L2 keeps the pyramid lines the neighbours share.  Bijective for any grid size.
+__device__ __forceinline__ uint2 xcd_block2(uint32_t bx, uint32_t by, uint32_t gx, uint32_t gy)
+{
+    const uint32_t nwg = gx * gy, orig = bx + gx * by;
+    const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+    const uint32_t y = t / gx;
+    return make_uint2(t - y * gx, y);
+}
+
 __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* __restrict__ ori_p,
                                                 const DevKp* __restrict__ in,
                                                 const uint32_t* __restrict__ n_in, uint32_t stride,
@@ -399,10 +411,11 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
 {
     __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112];
     const OriTables& c_ori = *ori_p;
-    const int frame = blockIdx.y;
+    const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    const int frame = (int)blk.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n = min(n_in[frame], stride);
-    const uint32_t ki = blockIdx.x * 4 + wv;
+    const uint32_t ki = blk.x * 4 + wv;
     const bool active = ki < n;  // wave-uniform; inactive waves still join the block barriers
     const float PI_F = 3.14159274101257324219f;
     DevKp kp;
@@ -721,10 +734,11 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
     __shared__ float s_ri[4][SMAX], s_dx[4][SMAX], s_dy[4][SMAX];
     __shared__ float s_val[4][96];
     const DescTables& c_desc = *desc_p;
-    const int frame = blockIdx.y;
+    const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    const int frame = (int)blk.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n = min(n_in[frame], stride);
-    const uint32_t vi = blockIdx.x * 4 + wv;
+    const uint32_t vi = blk.x * 4 + wv;
     if (vi >= n) return;  // whole wave; no block-level barrier below
     const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
     const DevKp kp = in[(size_t)frame * stride + ki];
