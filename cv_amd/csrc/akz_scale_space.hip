@@ -154,10 +154,13 @@ __device__ __forceinline__ v2f lane4_dot_v(const v2f* v, const float* k)
     return ((a0 + a1) + a2) + a3;
 }
 
-__device__ __forceinline__ v2f off_combine(const OffK k, v2f a, v2f b, v2f c)
+// off_combine with the accumulation order fixed at compile time: make_offk(sigma).mode is 1 for sigma 4 (all
+// three taps in f32x4 lane 0) and 0 for sigma 2 and 3, the only derivative scales the two-frame kernels serve.
+template <int SG>
+__device__ __forceinline__ v2f off_combine_sg(const OffK k, v2f a, v2f b, v2f c)
 {
     v2f pa = a * splat(k.n) + splat(0.0f), pb = b * splat(k.m), pc = c * splat(k.n);
-    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+    return SG == 4 ? (pa + pb) + pc : (pa + pc) + pb;
 }
 
 __device__ __forceinline__ float4 load4_px(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
@@ -363,8 +366,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const In
                 v2f mm = m[4 + o - SG], m0 = m[4 + o], mp = m[4 + o + SG];
                 v2f zm = z[4 + o - SG], zp = z[4 + o + SG];
                 v2f pm = pz[4 + o - SG], p0 = pz[4 + o], pp = pz[4 + o + SG];
-                res_x[o] = off_combine(k, mp - mm, zp - zm, pp - pm);
-                res_y[o] = off_combine(k, pm, p0, pp) - off_combine(k, mm, m0, mp);
+                res_x[o] = off_combine_sg<SG>(k, mp - mm, zp - zm, pp - pm);
+                res_y[o] = off_combine_sg<SG>(k, pm, p0, pp) - off_combine_sg<SG>(k, mm, m0, mp);
             }
         }
         const size_t pix = (size_t)y * w + x0;
@@ -1328,9 +1331,9 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int jm = 4 + o - SG, j0 = 4 + o, jp = 4 + o + SG;
-            v2f lxx = off_combine(k, xm[jp] - xm[jm], xz[jp] - xz[jm], xp[jp] - xp[jm]);
-            v2f lxy = off_combine(k, xp[jm], xp[j0], xp[jp]) - off_combine(k, xm[jm], xm[j0], xm[jp]);
-            v2f lyy = off_combine(k, yp[jm], yp[j0], yp[jp]) - off_combine(k, ym[jm], ym[j0], ym[jp]);
+            v2f lxx = off_combine_sg<SG>(k, xm[jp] - xm[jm], xz[jp] - xz[jm], xp[jp] - xp[jm]);
+            v2f lxy = off_combine_sg<SG>(k, xp[jm], xp[j0], xp[jp]) - off_combine_sg<SG>(k, xm[jm], xm[j0], xm[jp]);
+            v2f lyy = off_combine_sg<SG>(k, yp[jm], yp[j0], yp[jp]) - off_combine_sg<SG>(k, ym[jm], ym[j0], ym[jp]);
             det[o] = (lxx * lyy - lxy * lxy) * splat(sigma_quat);
         }
         lds_write4<CG>(&s_d[q * CG], c, det[0], det[1], det[2], det[3]);
