@@ -1356,31 +1356,44 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
         lds_read12<CG, 3, 8>(d4, q, c, m);                    // v[4 + o] is pixel o of the strip (ring tile x = tx0 - 4 + col)
         lds_read12<CG, 3, 8>(d4, q + 1, c, z);
         lds_read12<CG, 3, 8>(d4, q + 2, c, p);
+        // branch-free extremum test of the strip's 8 pixel-frames; candidates are rare, so the (divergent) append
+        // path below runs for few strips
+        uint32_t hits = 0u;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int x = x0 + o;
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const float v = z[4 + o][f];
                 const float nb = fmaxf(fmaxf(fmaxf(m[3 + o][f], m[4 + o][f]), fmaxf(m[5 + o][f], z[3 + o][f])),
                                        fmaxf(fmaxf(z[5 + o][f], p[3 + o][f]), fmaxf(p[4 + o][f], p[5 + o][f])));
-                if (!(v > cp.thr && v > nb)) continue;
-                if (x < 1 || x > w - 2 || (f == 1 && !has_b)) continue;
-                // border test (:96-104); a candidate failing it can neither push nor replace (:105)
-                const float px = (float)x, py = (float)y;
-                float left_x = roundf(px - cp.border) - 1.0f;
-                float right_x = roundf(px + cp.border) + 1.0f;
-                float up_y = roundf(py - cp.border) - 1.0f;
-                float down_y = roundf(py + cp.border) + 1.0f;
-                bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
-                if (is_out) continue;
-                const size_t list = (size_t)(f ? fb : fa) * 32 + cp.level;
-                uint32_t slot = atomicAdd(&ncand[list], 1u);
-                if (slot < cp.cap)
-                    cand[list * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
-                else
-                    *err = 1u;
+                hits |= (v > cp.thr && v > nb ? 1u : 0u) << (2 * o + f);
             }
+        }
+        if (!has_b) hits &= 0x55u;
+        while (hits) {
+            const int bit = __ffs((int)hits) - 1;
+            hits &= hits - 1u;
+            const int o = bit >> 1, f = bit & 1;
+            const int x = x0 + o;
+            if (x < 1 || x > w - 2) continue;
+            float v = z[4][f];                                // z[4 + o][f] without dynamic register indexing
+            v = o == 1 ? z[5][f] : v;
+            v = o == 2 ? z[6][f] : v;
+            v = o == 3 ? z[7][f] : v;
+            // border test (:96-104); a candidate failing it can neither push nor replace (:105)
+            const float px = (float)x, py = (float)y;
+            float left_x = roundf(px - cp.border) - 1.0f;
+            float right_x = roundf(px + cp.border) + 1.0f;
+            float up_y = roundf(py - cp.border) - 1.0f;
+            float down_y = roundf(py + cp.border) + 1.0f;
+            bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
+            if (is_out) continue;
+            const size_t list = (size_t)(f ? fb : fa) * 32 + cp.level;
+            uint32_t slot = atomicAdd(&ncand[list], 1u);
+            if (slot < cp.cap)
+                cand[list * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
+            else
+                *err = 1u;
         }
     }
 }
