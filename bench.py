@@ -157,8 +157,14 @@ def main():
     def idx(vals):
         return (C.c_uint32 * len(vals))(*vals)
 
+    # multi-rank: the descriptor exchange runs on its own stream, so that the next micro-batch's scale space
+    # (which waits on the caller's stream only) does not queue behind the collective of this one
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+
     def step():
         cur = torch.cuda.current_stream()
+        if world > 1:
+            comm.wait_stream(cur)    # the previous step's matcher reads (cur waited for them) precede our writes
         for m0 in range(0, NF, MB):
             _lib.check(L.akz_extract_batch_device(
                 ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps[m0:m0 + MB].data_ptr(),
@@ -167,10 +173,11 @@ def main():
             if m0 + MB == NF:
                 js.append(0)
             if world > 1:
-                cur.wait_stream(akz_stream)
-                js = exchange_predecessors(dist, rank, world, m0, MB, NF, descs[m0:m0 + MB], counts[m0:m0 + MB],
-                                           gath_d, gath_n, prev_descs, prev_counts)
-                ia, ib, tb, nb, wait = idx(js), idx(js), prev_descs, prev_counts, cur
+                comm.wait_stream(akz_stream)
+                with torch.cuda.stream(comm):
+                    js = exchange_predecessors(dist, rank, world, m0, MB, NF, descs[m0:m0 + MB],
+                                               counts[m0:m0 + MB], gath_d, gath_n, prev_descs, prev_counts)
+                ia, ib, tb, nb, wait = idx(js), idx(js), prev_descs, prev_counts, comm
             else:
                 ia, ib, tb, nb, wait = idx(js), idx([(j - 1) % NF for j in js]), descs, counts, akz_stream
             # problem p writes pairs/npairs block p of the view starting at js[0]'s slot; keep them per frame
@@ -180,6 +187,8 @@ def main():
                 "match")
         cur.wait_stream(hm_stream)
         cur.wait_stream(akz_stream)
+        if world > 1:
+            cur.wait_stream(comm)
 
     def barrier():
         if world > 1:
