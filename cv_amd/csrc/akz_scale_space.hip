@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
 {
     __shared__ __attribute__((aligned(16))) float4 s_top[2][256 * 2];   // [parity][patch][4 px x 2 frames]
     __shared__ __attribute__((aligned(16))) float4 s_bot[2][256 * 2];
+    __shared__ __attribute__((aligned(16))) float4 s_ct[256 * 2], s_cb[256 * 2];   // top / bottom rows of C
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
     const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
@@ -1042,63 +1043,65 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
         L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
         C[r][0] = (v2f){ca.x, cb.x}; C[r][1] = (v2f){ca.y, cb.y}; C[r][2] = (v2f){ca.z, cb.z}; C[r][3] = (v2f){ca.w, cb.w};
     }
-    // conductivity of the facing edges: fixed for the whole launch
-    v2f Cl[4], Cr[4], Ct[4], Cb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        Cl[r] = dpp_row<0x111>(C[r][3]);   // row_shr:1 -> left neighbour's right column
-        Cr[r] = dpp_row<0x101>(C[r][0]);   // row_shl:1 -> right neighbour's left column
-    }
-    s_top[1][tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
-    s_top[1][tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
-    s_bot[1][tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
-    s_bot[1][tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
-    __syncthreads();
+    // conductivity of the facing edges: fixed for the whole launch.  Left/right are re-fetched from the
+    // neighbouring lanes each step and top/bottom re-read from a static LDS copy: holding all four in registers
+    // costs 32 VGPRs, which is the difference between two and three waves per SIMD for this kernel.
+    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+    s_cb[tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
+    s_cb[tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
-    {
-        float4 a = s_bot[1][up * 2], b = s_bot[1][up * 2 + 1], c = s_top[1][dn * 2], d = s_top[1][dn * 2 + 1];
-        Ct[0] = (v2f){a.x, a.y}; Ct[1] = (v2f){a.z, a.w}; Ct[2] = (v2f){b.x, b.y}; Ct[3] = (v2f){b.z, b.w};
-        Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
-    }
     // flows that cross the image border are +0 (see above)
     const bool z_left = x0 <= 0, z_right = x0 + 4 >= w, z_top = y0 <= 0;
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < T; ++t) {
         const v2f ht = splat(taus.half_tau[t]);
         const int par = t & 1;
+        // an unrolled step loop lets the compiler keep every c(x) + c(x+1) sum and every neighbour's c across the
+        // steps (190 VGPRs); the empty asm makes C opaque per step so they are recomputed instead
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));
         s_top[par][tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
         s_top[par][tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
         s_bot[par][tid * 2] = make_float4(L[3][0].x, L[3][0].y, L[3][1].x, L[3][1].y);
         s_bot[par][tid * 2 + 1] = make_float4(L[3][2].x, L[3][2].y, L[3][3].x, L[3][3].y);
         __syncthreads();   // also orders this step's reads after the previous-but-one step's (same parity) writes
-        v2f Lt[4], Lb[4];
-        {
-            float4 a = s_bot[par][up * 2], b = s_bot[par][up * 2 + 1], c = s_top[par][dn * 2], d = s_top[par][dn * 2 + 1];
-            Lt[0] = (v2f){a.x, a.y}; Lt[1] = (v2f){a.z, a.w}; Lt[2] = (v2f){b.x, b.y}; Lt[3] = (v2f){b.z, b.w};
-            Lb[0] = (v2f){c.x, c.y}; Lb[1] = (v2f){c.z, c.w}; Lb[2] = (v2f){d.x, d.y}; Lb[3] = (v2f){d.z, d.w};
-        }
         v2f vu[4];
+        {
+            float4 a = s_bot[par][up * 2], b = s_bot[par][up * 2 + 1], c = s_cb[up * 2], d = s_cb[up * 2 + 1];
+            const v2f Lt[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
+            const v2f Ct[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            vu[c] = fed_flow2(ht, Ct[c], C[0][c], Lt[c], L[0][c]);
-            if (z_top) vu[c] = splat(0.0f);
+            for (int cc = 0; cc < 4; ++cc) {
+                vu[cc] = fed_flow2(ht, Ct[cc], C[0][cc], Lt[cc], L[0][cc]);
+                if (z_top) vu[cc] = splat(0.0f);
+            }
+        }
+        v2f Lb[4], Cb[4];
+        {
+            float4 a = s_top[par][dn * 2], b = s_top[par][dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
+            Lb[0] = (v2f){a.x, a.y}; Lb[1] = (v2f){a.z, a.w}; Lb[2] = (v2f){b.x, b.y}; Lb[3] = (v2f){b.z, b.w};
+            Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const v2f Ll = dpp_row<0x111>(L[r][3]), Lr = dpp_row<0x101>(L[r][0]);
             v2f hf[5];
-            hf[0] = fed_flow2(ht, Cl[r], C[r][0], Ll, L[r][0]);
+            const v2f Cl = dpp_row<0x111>(C[r][3]), Cr = dpp_row<0x101>(C[r][0]);
+            hf[0] = fed_flow2(ht, Cl, C[r][0], Ll, L[r][0]);
             if (z_left) hf[0] = splat(0.0f);
 #pragma unroll
             for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
-            hf[4] = fed_flow2(ht, C[r][3], Cr[r], L[r][3], Lr);
+            hf[4] = fed_flow2(ht, C[r][3], Cr, L[r][3], Lr);
             if (z_right) hf[4] = splat(0.0f);
             const bool z_down = y0 + r >= h - 1;
             v2f vd[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 vd[c] = r < 3 ? fed_flow2(ht, C[r][c], C[r + 1][c], L[r][c], L[r + 1][c])
-                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);
+                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);   // Lb / Cb: loaded below for r == 3
                 if (z_down) vd[c] = splat(0.0f);
             }
 #pragma unroll
