@@ -1018,8 +1018,8 @@ template <int T>
 __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src, const float* __restrict__ cnd,
                                                   float* __restrict__ dst, int w, int h, size_t fs, int n, FedTaus taus)
 {
-    __shared__ __attribute__((aligned(16))) float4 s_top[2][256 * 2];   // [parity][patch][4 px x 2 frames]
-    __shared__ __attribute__((aligned(16))) float4 s_bot[2][256 * 2];
+    __shared__ __attribute__((aligned(16))) float4 s_top[1][256 * 2];   // [patch][4 px x 2 frames]
+    __shared__ __attribute__((aligned(16))) float4 s_bot[1][256 * 2];
     __shared__ __attribute__((aligned(16))) float4 s_ct[256 * 2], s_cb[256 * 2];   // top / bottom rows of C
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
     const int fa = 2 * (int)tile.z;
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         const v2f ht = splat(taus.half_tau[t]);
-        const int par = t & 1;
+        const int par = 0;
         // an unrolled step loop lets the compiler keep every c(x) + c(x+1) sum and every neighbour's c across the
         // steps (190 VGPRs); the empty asm makes C opaque per step so they are recomputed instead
 #pragma unroll
@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
                 vu[c] = vd[c];
             }
         }
+        if (t + 1 < T) __syncthreads();   // single exchange buffer: every reader is done before the next step's writes
     }
     if (pc >= 1 && pc <= 14 && pr >= 1 && pr <= 14 && col_in) {
 #pragma unroll
