@@ -292,11 +292,33 @@ def main():
             "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
                                   "extract": round(all_ms / args.steps, 2)},
         }
+        out["device"] = device_probe(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, args.cpu_frames)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def device_probe(torch, dev):
+    """What the numbers were measured on: device name, CU count, memory, and a
+    device-to-device copy probe (read + write of 1 GiB, best of 5) as the practical HBM ceiling of this box."""
+    p = torch.cuda.get_device_properties(dev)
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return {"name": p.name, "gcn_arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+            "hbm_gib": round(p.total_memory / 2**30, 1), "d2d_copy_gbs": round(best, 1),
+            "hbm_peak_gbs_spec": HBM_PEAK_GBS}
 
 
 def pmc_traffic_per_launch(mb=None):

@@ -59,7 +59,8 @@ ABI_SYMBOLS = [
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
-    "akz_half_size", "hm_create", "hm_destroy", "hm_knn2", "hm_match", "hm_match_batch_device", "hm_sync",
+    "akz_half_size", "hm_create", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
+    "hm_match_batch_device", "hm_sync",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
@@ -106,6 +107,8 @@ def lib():
     L.hm_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
     L.hm_destroy.argtypes = [vp]
     L.hm_knn2.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.hm_knn.argtypes = [vp, vp, u32, vp, u32, u32, vp]
+    L.hm_knn_views_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, vp, vp]
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]
     L.hm_sync.argtypes = [vp]

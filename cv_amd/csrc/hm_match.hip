@@ -151,74 +151,49 @@ struct HmProbX {           // like HmProb, on the +-1 recoded descriptors
 
 constexpr int kMfmaBlock = 512;   // 8 waves x 32 queries
 
-// One 32-target x 32-query tile: 16 chained MFMAs (K = 512 = 16 x 32) with the LDS fragment reads kept
-// four deep in flight, then the (distance, row) keys and the tile's two smallest, merged into (k0, k1).
-// D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
-// key = hamming << 22 | target = ((512 - acc) << 21) | target = acc * -(1 << 21) + (512 << 21 | target):
-// one v_mad_i32_i24 per accumulator register.  TAIL (the last, partial tile) masks rows >= nt.
-template <bool TAIL>
-__device__ __forceinline__ void knn2_keys(const v16i32& nacc, uint32_t t0, uint32_t half, uint32_t nt, int& k0, int& k1)
+// insert v into the ascending list l[0..K): K-1 min/max pairs and one min
+template <int K>
+__device__ __forceinline__ void topk_insert(int (&l)[K], int v)
 {
-    // nacc = -dot (the resident query fragments are negated).  The unsigned key (512 - dot) << 21 | row is
-    // carried as the signed value key - (512 << 21) = (nacc << 21) | row: one v_lshl_or_b32 per accumulator
-    // register with inline constants only; the lane's row offset (t0 + 4 * half) is added to the tile's two
-    // smallest afterwards (row bits never carry: row < 2^21).
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int lo = min(l[i], v);
+        v = max(l[i], v);
+        l[i] = lo;
+    }
+}
+
+// One 32-target x 32-query tile: 16 chained MFMAs (K = 512 = 16 x 32) with the LDS fragment reads kept
+// four deep in flight, then the (distance, row) keys and the tile's KNN smallest, merged into k[].
+// D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
+// nacc = -dot (the resident query fragments are negated).  The unsigned key (512 - dot) << 21 | row is
+// carried as the signed value key - (512 << 21) = (nacc << 21) | row: one v_lshl_or_b32 per accumulator
+// register with inline constants only; the lane's row offset (t0 + 4 * half) is added to the tile's
+// smallest afterwards (row bits never carry: row < 2^21).  TAIL (the last, partial tile) masks rows >= nt.
+template <bool TAIL, int KNN>
+__device__ __forceinline__ void knn_keys(const v16i32& nacc, uint32_t t0, uint32_t half, uint32_t nt, int (&k)[KNN])
+{
     const int row0 = (int)(t0 + 4u * half);
-    int l0 = 0x7FFFFFFF, l1 = 0x7FFFFFFF;
+    int l[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) l[i] = 0x7FFFFFFF;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int off = (r & 3) + 8 * (r >> 2);
         int key = (int)(((uint32_t)nacc[r] << 21) | (uint32_t)off);
         if (TAIL) key = (uint32_t)(row0 + off) < nt ? key : 0x7FFFFFFF - row0;
-        if (r == 0) {
-            l0 = key;
-        } else {
-            int hi = max(l0, key);
-            l0 = min(l0, key);
-            l1 = min(l1, hi);
-        }
+        topk_insert<KNN>(l, key);
     }
-    l0 += row0;            // masked keys become INT_MAX again
-    l1 += row0;
-    int hi = max(k0, l0);
-    k0 = min(k0, l0);
-    k1 = min(hi, min(k1, l1));
+    // 16 keys went in, so every l[i] is a key (masked ones become INT_MAX again): no overflow below
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) topk_insert<KNN>(k, l[i] + row0);
 }
 
-__device__ __forceinline__ void knn2_tile(const uint4* __restrict__ tp, const v4i32 (&qb)[16], uint32_t t0,
-                                          uint32_t half, uint32_t nt, int& k0, int& k1)
+template <int KNN>
+__device__ __forceinline__ void knn_tile(const uint4* __restrict__ tp, const v4i32 (&qb)[16], uint32_t t0,
+                                         uint32_t half, uint32_t nt, int (&k)[KNN])
 {
     v16i32 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint4 f[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) f[k] = tp[2 * k];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        uint4 av = f[k & 3];
-        v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
-        if (k + 4 < 16) f[k & 3] = tp[2 * (k + 4)];
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[k], acc, 0, 0, 0);
-    }
-    // keep the fragment reads four deep ahead of the dependent MFMA chain
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if (t0 + 32u <= nt) knn2_keys<false>(acc, t0, half, nt, k0, k1);
-    else knn2_keys<true>(acc, t0, half, nt, k0, k1);
-}
-
-
-// Two column blocks (64 queries) per wave: every target fragment read from LDS feeds two MFMAs on two
-// independent accumulator chains, halving the LDS read traffic per MAC.
-__device__ __forceinline__ void knn2_tile2(const uint4* __restrict__ tp, const v4i32 (&qa)[16], const v4i32 (&qc)[16],
-                                           uint32_t t0, uint32_t half, uint32_t nt, int (&k)[4])
-{
-    v16i32 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v16i32 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint4 f[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = tp[2 * i];
@@ -227,26 +202,24 @@ __device__ __forceinline__ void knn2_tile2(const uint4* __restrict__ tp, const v
         uint4 av = f[i & 3];
         v4i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w};
         if (i + 4 < 16) f[i & 3] = tp[2 * (i + 4)];
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qa[i], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qc[i], acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qb[i], acc, 0, 0, 0);
     }
+    // keep the fragment reads four deep ahead of the dependent MFMA chain
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    if (t0 + 32u <= nt) {
-        knn2_keys<false>(acc0, t0, half, nt, k[0], k[1]);
-        knn2_keys<false>(acc1, t0, half, nt, k[2], k[3]);
-    } else {
-        knn2_keys<true>(acc0, t0, half, nt, k[0], k[1]);
-        knn2_keys<true>(acc1, t0, half, nt, k[2], k[3]);
-    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (t0 + 32u <= nt) knn_keys<false, KNN>(acc, t0, half, nt, k);
+    else knn_keys<true, KNN>(acc, t0, half, nt, k);
 }
 
-__global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __restrict__ probs)
+// LinearKnn::knn(q, KNN) for every query of every problem: out[q][KNN], ascending (distance, index).
+// Neighbours that do not exist (nt < KNN) come back as {index 2^22 - 1, distance 1023}.
+template <int KNN>
+__global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma(const HmProbX* __restrict__ probs)
 {
     // target tile: 32 descriptors x 512 B, rows padded to 33 x 16 B so the 16-byte fragment reads of the
     // 32 rows fall on distinct bank groups; double-buffered, filled with full 512-B-row coalesced loads
@@ -270,119 +243,56 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn2_mfma(const HmProbX* __re
     const uint32_t q0 = qblk + wv * 32u;                // 32 queries (one column block) per wave
     const bool wave_on = q0 < nq;                       // idle waves still help staging and hit the barriers
     const uint32_t col = lane & 31u, half = lane >> 5;
-    // B fragments: query (q0 + col), bytes [32k + 16*half, +16) of its 512 -> 16 x v4i32, resident
-    v4i32 qb[16];
-    {
-        uint32_t qi = min(q0 + col, nq - 1u);
-        const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 128) + half;
+    int k[KNN];                                         // signed keys, see knn_keys
 #pragma unroll
-        for (int k = 0; k < 16; ++k) qb[k] = qp[2 * k] ^ (int)0xFEFEFEFE;   // +-1 bytes negated (see knn2_keys)
-    }
-    const uint4* tg = reinterpret_cast<const uint4*>(P.t);  // 32 uint4 per descriptor
-    // staging map: thread -> 2 x (row, 16-byte column): idx = tid + 512 i, row = idx >> 5, c = idx & 31
-    const uint32_t srow0 = threadIdx.x >> 5, srow1 = (threadIdx.x + 512u) >> 5, scol = threadIdx.x & 31u;
-    uint4 st0, st1;
-    st0 = tg[(size_t)min(srow0, nt - 1u) * 32 + scol];
-    st1 = tg[(size_t)min(srow1, nt - 1u) * 32 + scol];
-    s_t[0][srow0 * RS + scol] = st0;
-    s_t[0][srow1 * RS + scol] = st1;
-    int k0 = 0x7FFFFFFF, k1 = 0x7FFFFFFF;                // signed keys, see knn2_keys
-    int buf = 0;
-    for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
-        __syncthreads();                                 // tile `buf` is complete; tile `buf^1` is free
-        const bool more = t0 + 32u < nt;
-        if (more) {                                      // global loads in flight during the MFMAs
-            st0 = tg[(size_t)min(t0 + 32u + srow0, nt - 1u) * 32 + scol];
-            st1 = tg[(size_t)min(t0 + 32u + srow1, nt - 1u) * 32 + scol];
+    for (int i = 0; i < KNN; ++i) k[i] = 0x7FFFFFFF;
+    if (nt > 0) {
+        // B fragments: query (q0 + col), bytes [32k + 16*half, +16) of its 512 -> 16 x v4i32, resident
+        v4i32 qb[16];
+        {
+            uint32_t qi = min(q0 + col, nq - 1u);
+            const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 128) + half;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) qb[i] = qp[2 * i] ^ (int)0xFEFEFEFE;   // +-1 bytes negated (see knn_keys)
         }
-        if (wave_on) {
-            const uint4* tp = &s_t[buf][col * RS + half];
-            knn2_tile(tp, qb, t0, half, nt, k0, k1);
+        const uint4* tg = reinterpret_cast<const uint4*>(P.t);  // 32 uint4 per descriptor
+        // staging map: thread -> 2 x (row, 16-byte column): idx = tid + 512 i, row = idx >> 5, c = idx & 31
+        const uint32_t srow0 = threadIdx.x >> 5, srow1 = (threadIdx.x + 512u) >> 5, scol = threadIdx.x & 31u;
+        uint4 st0, st1;
+        st0 = tg[(size_t)min(srow0, nt - 1u) * 32 + scol];
+        st1 = tg[(size_t)min(srow1, nt - 1u) * 32 + scol];
+        s_t[0][srow0 * RS + scol] = st0;
+        s_t[0][srow1 * RS + scol] = st1;
+        int buf = 0;
+        for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
+            __syncthreads();                                 // tile `buf` is complete; tile `buf^1` is free
+            const bool more = t0 + 32u < nt;
+            if (more) {                                      // global loads in flight during the MFMAs
+                st0 = tg[(size_t)min(t0 + 32u + srow0, nt - 1u) * 32 + scol];
+                st1 = tg[(size_t)min(t0 + 32u + srow1, nt - 1u) * 32 + scol];
+            }
+            if (wave_on) knn_tile<KNN>(&s_t[buf][col * RS + half], qb, t0, half, nt, k);
+            if (more) {
+                s_t[buf ^ 1][srow0 * RS + scol] = st0;
+                s_t[buf ^ 1][srow1 * RS + scol] = st1;
+            }
+            buf ^= 1;
         }
-        if (more) {
-            s_t[buf ^ 1][srow0 * RS + scol] = st0;
-            s_t[buf ^ 1][srow1 * RS + scol] = st1;
-        }
-        buf ^= 1;
     }
     if (!wave_on) return;
-    // merge the two half-waves' sorted pairs, back to the unsigned key (INT_MAX = no neighbour -> all ones)
-    int o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
-    int s0 = min(k0, o0);
-    int s1 = min(max(k0, o0), min(k1, o1));
-    uint32_t m0 = s0 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s0 + (512u << 21);
-    uint32_t m1 = s1 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s1 + (512u << 21);
-    uint32_t qi = q0 + col;
+    // merge the two half-waves' sorted lists, back to the unsigned key (INT_MAX = no neighbour -> all ones)
+    int o[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) o[i] = __shfl_xor(k[i], 32);
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) topk_insert<KNN>(k, o[i]);
+    const uint32_t qi = q0 + col;
     if (half == 0 && qi < nq) {
-        akz_neighbor n0 = {m0 & ((1u << kIdxBits) - 1u), m0 >> kIdxBits};
-        akz_neighbor n1 = {m1 & ((1u << kIdxBits) - 1u), m1 >> kIdxBits};
-        P.out[(size_t)qi * 2 + 0] = n0;
-        P.out[(size_t)qi * 2 + 1] = n1;
-    }
-}
-
-constexpr int kMfma2Block = 512;  // 8 waves x 64 queries
-constexpr int kMfma2QPB = 512;
-__global__ __launch_bounds__(kMfma2Block, 2) void k_knn2_mfma2(const HmProbX* __restrict__ probs)
-{
-    constexpr int RS = 33;
-    __shared__ uint4 s_t[2][32 * RS];
-    const HmProbX P = probs[blockIdx.y];
-    const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t qblk = blockIdx.x * (uint32_t)kMfma2QPB;
-    if (qblk >= nq) return;                             // whole block
-    const uint32_t q0 = qblk + wv * 64u;                // 64 queries (two column blocks) per wave
-    const bool wave_on = q0 < nq;
-    const uint32_t col = lane & 31u, half = lane >> 5;
-    v4i32 qa[16], qc[16];
-    {
-        const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)min(q0 + col, nq - 1u) * 128) + half;
-        const v4i32* qr = reinterpret_cast<const v4i32*>(P.q + (size_t)min(q0 + 32u + col, nq - 1u) * 128) + half;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            qa[i] = qp[2 * i] ^ (int)0xFEFEFEFE;        // +-1 bytes negated (see knn2_keys)
-            qc[i] = qr[2 * i] ^ (int)0xFEFEFEFE;
-        }
-    }
-    const uint4* tg = reinterpret_cast<const uint4*>(P.t);
-    // staging map: thread -> 2 x (row, 16-byte column): row = (tid >> 5) + 16 i, c = tid & 31
-    const uint32_t srow = threadIdx.x >> 5, scol = threadIdx.x & 31u;
-    uint4 st0 = tg[(size_t)min(srow, nt - 1u) * 32 + scol];
-    uint4 st1 = tg[(size_t)min(srow + 16u, nt - 1u) * 32 + scol];
-    s_t[0][srow * RS + scol] = st0;
-    s_t[0][(srow + 16u) * RS + scol] = st1;
-    int k[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
-    int buf = 0;
-    for (uint32_t t0 = 0; t0 < nt; t0 += 32u) {
-        __syncthreads();
-        const bool more = t0 + 32u < nt;
-        if (more) {
-            st0 = tg[(size_t)min(t0 + 32u + srow, nt - 1u) * 32 + scol];
-            st1 = tg[(size_t)min(t0 + 48u + srow, nt - 1u) * 32 + scol];
-        }
-        if (wave_on) knn2_tile2(&s_t[buf][col * RS + half], qa, qc, t0, half, nt, k);
-        if (more) {
-            s_t[buf ^ 1][srow * RS + scol] = st0;
-            s_t[buf ^ 1][(srow + 16u) * RS + scol] = st1;
-        }
-        buf ^= 1;
-    }
-    if (!wave_on) return;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int k0 = k[2 * c], k1 = k[2 * c + 1];
-        int o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
-        int s0 = min(k0, o0);
-        int s1 = min(max(k0, o0), min(k1, o1));
-        uint32_t m0 = s0 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s0 + (512u << 21);
-        uint32_t m1 = s1 == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)s1 + (512u << 21);
-        uint32_t qi = q0 + 32u * c + col;
-        if (half == 0 && qi < nq) {
-            akz_neighbor n0 = {m0 & ((1u << kIdxBits) - 1u), m0 >> kIdxBits};
-            akz_neighbor n1 = {m1 & ((1u << kIdxBits) - 1u), m1 >> kIdxBits};
-            P.out[(size_t)qi * 2 + 0] = n0;
-            P.out[(size_t)qi * 2 + 1] = n1;
+        for (int i = 0; i < KNN; ++i) {
+            const uint32_t m = k[i] == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)k[i] + (512u << 21);
+            akz_neighbor nb = {m & ((1u << kIdxBits) - 1u), m >> kIdxBits};
+            P.out[(size_t)qi * KNN + i] = nb;
         }
     }
 }
@@ -476,7 +386,6 @@ struct hm_ctx {
     uint32_t* d_exp = nullptr;
     size_t exp_words = 0;
     bool use_mfma = true;
-    int mfma_variant = 1;   // AKZ_MATCH_MFMA: 1 = 32 queries per wave, 2 = 64 queries per wave
     akz_neighbor* d_bfwd = nullptr;
     akz_neighbor* d_brev = nullptr;
     size_t bscratch_elems = 0;
@@ -513,7 +422,8 @@ static int32_t hm_push_probs(hm_ctx* c, size_t off, const void* src, size_t byte
 
 extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out)
 {
-    if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << kIdxBits)) return AKZ_E_INVALID;
+    // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
+    if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
     AKZ_HIP(hipSetDevice(device));
@@ -535,7 +445,6 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
     {
         const char* mf = getenv("AKZ_MATCH_MFMA");
         c->use_mfma = !(mf && mf[0] == '0');
-        if (mf && mf[0] == '2') c->mfma_variant = 2;
     }
     AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
     AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
@@ -580,10 +489,11 @@ extern "C" int32_t hm_sync(hm_ctx* c)
     return AKZ_OK;
 }
 
-static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, uint32_t max_nq, size_t probs_off)
+static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, uint32_t max_nq, size_t probs_off,
+                           int knn = 2)
 {
     if (n_probs == 0) return AKZ_OK;
-    if (!c->use_mfma) {
+    if (!c->use_mfma && knn == 2) {   // the VALU kernel exists for k = 2 only
         HmProb* dp = reinterpret_cast<HmProb*>((char*)c->d_probs + probs_off);
         AKZ_TRY(hm_push_probs(c, probs_off, h_probs, sizeof(HmProb) * n_probs));
         dim3 grid((max_nq + kQPB - 1) / kQPB, n_probs);
@@ -629,12 +539,15 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
                        reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
     AKZ_LAUNCH_CHECK();
-    if (c->mfma_variant == 2)
-        hipLaunchKernelGGL(k_knn2_mfma2, dim3((max_nq + kMfma2QPB - 1) / kMfma2QPB, n_probs), dim3(kMfma2Block), 0, c->stream,
-                       reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off));
-    else
-        hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + 255) / 256, n_probs), dim3(kMfmaBlock), 0, c->stream,
-                       reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off));
+    {
+        dim3 grid((max_nq + 255) / 256, n_probs);
+        const HmProbX* dp = reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off);
+        switch (knn) {
+        case 1: hipLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+        case 3: hipLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+        default: hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+        }
+    }
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
@@ -663,6 +576,62 @@ extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, cons
     AKZ_HIP(hipMemcpyAsync(out, c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
     AKZ_HIP(hipStreamSynchronize(c->stream));
     return AKZ_OK;
+}
+
+// LinearKnn{metric: Hamming, iter: t}.knn(q, k) for k = 1, 2, 3 (cv-sfm/src/lib.rs:1474 uses 3).
+extern "C" int32_t hm_knn(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
+                          uint32_t k, akz_neighbor* out)
+{
+    if (!c || !q || !t || !out || k < 1 || k > 3) return AKZ_E_INVALID;
+    if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
+    if (nq == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
+    size_t need = (size_t)nq * 3;
+    if (need > c->bscratch_elems) {
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
+        if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
+        c->d_bfwd = c->d_brev = nullptr;
+        AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
+        AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
+        c->bscratch_elems = need;
+    }
+    uint32_t cnt[2] = {nq, nt};
+    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+    if (nt) AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+    HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt ? nt : 1u, c->d_bfwd};
+    AKZ_TRY(launch_knn2(c, &p, 1, nq, 0, (int)k));
+    AKZ_HIP(hipMemcpyAsync(out, c->d_bfwd, sizeof(akz_neighbor) * k * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+
+// One query frame against n_views stored views (cv-sfm/src/lib.rs:1468-1486: every feature of the new frame is
+// matched with knn(., 3) against each of the recent views).  Everything device-resident: d_q [cap][64] with
+// its count d_nq, d_views [>= max(view_idx)+1][cap][64] with counts d_nviews; view v of this call is block
+// view_idx[v].  d_out [n_views][cap][k].  Stream-ordered after `stream_to_wait`; results are ready on hm_stream().
+extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d_nq, const void* d_views,
+                                       const void* d_nviews, uint32_t cap_per_img, const uint32_t* view_idx,
+                                       uint32_t n_views, uint32_t k, void* d_out, void* stream_to_wait)
+{
+    if (!c || !d_q || !d_nq || !d_views || !d_nviews || !view_idx || !d_out || k < 1 || k > 3) return AKZ_E_INVALID;
+    if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+    if (n_views == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    if (stream_to_wait) {
+        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    }
+    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_views)));
+    std::vector<HmProb> hp(n_views);
+    for (uint32_t v = 0; v < n_views; ++v)
+        hp[v] = HmProb{(const uint4*)d_q, (const uint32_t*)d_nq, cap_per_img,
+                       (const uint4*)d_views + (size_t)view_idx[v] * cap_per_img * 4,
+                       (const uint32_t*)d_nviews + view_idx[v], cap_per_img,
+                       (akz_neighbor*)d_out + (size_t)v * cap_per_img * k};
+    return launch_knn2(c, hp.data(), n_views, cap_per_img, 0, (int)k);
 }
 
 extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uint32_t nb,
@@ -710,7 +679,7 @@ extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void*
                                          void* stream_to_wait)
 {
     if (!c || !d_a || !d_na || !d_b || !d_nb || !ia || !ib || !d_pairs || !d_n_out) return AKZ_E_INVALID;
-    if (rule < 0 || rule > 2 || cap_per_img == 0 || cap_per_img >= (1u << kIdxBits)) return AKZ_E_INVALID;
+    if (rule < 0 || rule > 2 || cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
     if (n_pairs == 0) return AKZ_OK;
     AKZ_HIP(hipSetDevice(c->device));
     if (stream_to_wait) {

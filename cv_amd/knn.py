@@ -58,6 +58,14 @@ class Matcher:
         check(_lib.lib().hm_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data), "hm_knn2")
         return out
 
+    def knn(self, q, t, k):
+        """LinearKnn.knn(q, k) for every row of q, k in {1, 2, 3}: [nq, k] (index, distance); slots past
+        len(t) hold the sentinel {2^22 - 1, 1023}."""
+        q = _desc(q); t = _desc(t)
+        out = np.zeros((len(q), k), NB_DTYPE)
+        check(_lib.lib().hm_knn(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), k, out.ctypes.data), "hm_knn")
+        return out
+
     def match(self, a, b, rule=RULE_STRICT, param_u=24, param_f=0.5, symmetric=True):
         a = _desc(a); b = _desc(b)
         cap = max(len(a), 1)
@@ -95,17 +103,18 @@ class LinearKnn:
         self.device = device
 
     def knn(self, query, num):
-        """Knn::knn(&self, query, num) -> Vec<Neighbor>, sorted by (distance, index).  The device path
-        implements num == 2 (every reference call site); other values raise."""
-        if num != 2:
-            raise NotImplementedError("the MI355X matcher implements knn(query, 2), the reference's only use")
-        nn = default_matcher(max(len(self.iter), 1), self.device).knn2(_desc(query)[:1], self.iter)
-        return [Neighbor(int(nn[0, 0]["index"]), int(nn[0, 0]["distance"])),
-                Neighbor(int(nn[0, 1]["index"]), int(nn[0, 1]["distance"]))]
+        """Knn::knn(&self, query, num) -> Vec<Neighbor>, sorted by (distance, index), min(num, len) long.
+        The device path implements num <= 3 (the reference asks for 2 when matching frame pairs and 3 when
+        registering a frame against recent views, cv-sfm/src/lib.rs:1474)."""
+        if not 1 <= num <= 3:
+            raise NotImplementedError("the MI355X matcher implements knn(query, k) for k <= 3")
+        nn = default_matcher(max(len(self.iter), 1), self.device).knn(_desc(query)[:1], self.iter, num)
+        return [Neighbor(int(nn[0, i]["index"]), int(nn[0, i]["distance"])) for i in range(min(num, len(self.iter)))]
 
-    def knn_batch(self, queries):
-        """knn(q, 2) for every row of `queries` in one launch: [nq,2] structured (index, distance)."""
-        return default_matcher(max(len(self.iter), len(queries), 1), self.device).knn2(queries, self.iter)
+    def knn_batch(self, queries, num=2):
+        """knn(q, num) for every row of `queries` in one launch: [nq,num] structured (index, distance)."""
+        m = default_matcher(max(len(self.iter), len(queries), 1), self.device)
+        return m.knn2(queries, self.iter) if num == 2 else m.knn(queries, self.iter, num)
 
 
 def matching(a_descriptors, b_descriptors, better_by=24, strict=True, device=0):

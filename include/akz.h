@@ -170,6 +170,19 @@ int32_t hm_destroy(hm_ctx* ctx);
  * reference asserts two neighbours, estimate_pose.rs:89). Host buffers. */
 int32_t hm_knn2(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t,
                 uint32_t nt, akz_neighbor* out);
+/* LinearKnn{metric: Hamming, iter: t}.knn(q, k) for k = 1, 2 or 3 — the registration path asks for 3
+ * (cv-sfm/src/lib.rs:1474).  out[nq][k], ascending (distance, index); the reference returns min(k, nt)
+ * neighbours, here the slots past nt hold {index 2^22 - 1, distance 1023}. */
+int32_t hm_knn(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
+               uint32_t k, akz_neighbor* out);
+/* Device-resident multi-view form of the same call (cv-sfm/src/lib.rs:1468-1486: every feature of the new
+ * frame against each of up to 32 recent views): d_q [cap][64] + count d_nq, d_views [..][cap][64] + counts
+ * d_nviews, view v of this call = block view_idx[v]; d_out [n_views][cap][k].  Stream-ordered after
+ * stream_to_wait; results are complete on hm_stream().  The landmark bookkeeping that follows in the
+ * reference (HashMap dedup, merge rules) is control plane and stays with the caller. */
+int32_t hm_knn_views_device(hm_ctx* ctx, const void* d_q, const void* d_nq, const void* d_views,
+                            const void* d_nviews, uint32_t cap_per_img, const uint32_t* view_idx,
+                            uint32_t n_views, uint32_t k, void* d_out, void* stream_to_wait);
 /* matching()/symmetric_matching() of tutorial ch5 main.rs:154-200 and cv-sfm/src/lib.rs:3097-3133,
  * and match_descriptors() of akaze/tests/estimate_pose.rs:78-97.
  *   rule 0: accept iff d0 + param_u <  d1   (tutorial, param_u = 24)

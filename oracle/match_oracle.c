@@ -64,6 +64,33 @@ int orc_knn2(const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint
     return 0;
 }
 
+/* LinearKnn::knn(q, k), any k >= 1 (space 0.17): the first min(k, nt) items sorted by distance (stable),
+ * then every later item inserted at partition_point(d <= new) and the tail popped.  out[nq][k]; slots
+ * past min(k, nt) are filled with {UINT32_MAX, UINT32_MAX} (the reference's Vec is simply shorter). */
+int orc_knn(const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt, uint32_t k, akz_neighbor* out)
+{
+    if (k == 0) return -1;
+    for (uint32_t i = 0; i < nq; ++i) {
+        akz_neighbor* o = out + (size_t)i * k;
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < nt; ++j) {
+            uint32_t d = hamming64(q[i].bytes, t[j].bytes);
+            /* position after every kept neighbour with distance <= d (for the first k items this is the
+             * stable insertion sort the initial sort amounts to) */
+            uint32_t pos = 0;
+            while (pos < n && o[pos].distance <= d) ++pos;
+            if (pos >= k) continue;
+            uint32_t last = n < k ? n : k - 1;
+            for (uint32_t m = last; m > pos; --m) o[m] = o[m - 1];
+            o[pos].index = j;
+            o[pos].distance = d;
+            if (n < k) ++n;
+        }
+        for (uint32_t m = n; m < k; ++m) o[m].index = o[m].distance = UINT32_MAX;
+    }
+    return 0;
+}
+
 static int accept(int rule, uint32_t d0, uint32_t d1, uint32_t pu, float pf)
 {
     switch (rule) {

@@ -103,6 +103,7 @@ def lib():
         L.orc_set_option.argtypes = [C.c_int, C.c_int]
         L.orc_get_option.argtypes = [C.c_int]
         L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
                                 C.c_float, C.c_int, C.c_void_p, C.c_uint32]
         L.orc_calibrate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -291,6 +292,16 @@ def knn2(q, t):
     r = lib().orc_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data)
     if r != 0:
         raise ValueError("knn2 needs at least two targets")
+    return out
+
+
+def knn(q, t, k):
+    """LinearKnn.knn(q, k): [nq, k] (index, distance); slots past min(k, len(t)) are (2^32-1, 2^32-1)."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 64)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 64)
+    out = np.empty((len(q), k), NB_DTYPE)
+    if lib().orc_knn(q.ctypes.data, len(q), t.ctypes.data, len(t), k, out.ctypes.data) != 0:
+        raise ValueError("k must be >= 1")
     return out
 
 

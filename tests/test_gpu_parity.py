@@ -218,6 +218,71 @@ def test_knn2_bit_exact_with_ties(gpu, oracle):
         m.knn2(_rand_desc(rng, 3), _rand_desc(rng, 1))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_knn_k_bit_exact(gpu, oracle, k):
+    """LinearKnn::knn(q, k) for k = 1..3 (cv-sfm's registration path uses 3): indices and distances equal the
+    oracle's, ties included; neighbours that do not exist come back as the documented sentinel."""
+    _, knn = gpu
+    rng = np.random.default_rng(100 + k)
+    m = knn.Matcher(8192)
+    for nq, nt in ((5, k), (7, k + 1), (513, 257), (333, 4097)):
+        q = _rand_desc(rng, nq); t = _rand_desc(rng, nt)
+        if nt > 8:
+            t[rng.integers(0, nt, nt // 3)] = t[rng.integers(0, nt, nt // 3)]   # exact duplicates -> ties
+            q[:4] = t[:4]
+        got, want = m.knn(q, t, k), oracle.knn(q, t, k)
+        _eq(got["index"], want["index"], f"knn{k} idx {nq}x{nt}")
+        _eq(got["distance"], want["distance"], f"knn{k} dist {nq}x{nt}")
+    if k > 1:   # fewer targets than k: the reference's Vec is shorter; the fixed-width output pads with the sentinel
+        q = _rand_desc(rng, 9); t = _rand_desc(rng, k - 1)
+        got, want = m.knn(q, t, k), oracle.knn(q, t, k)
+        _eq(got["index"][:, :k - 1], want["index"][:, :k - 1], "short idx")
+        _eq(got["distance"][:, :k - 1], want["distance"][:, :k - 1], "short dist")
+        assert (got["index"][:, k - 1:] == (1 << 22) - 1).all() and (got["distance"][:, k - 1:] == 1023).all()
+    # LinearKnn mirror
+    lk = knn.LinearKnn(knn.Hamming, t)
+    nn = lk.knn(q[0], k)
+    assert len(nn) == min(k, len(t))
+
+
+@pytest.mark.gpu
+def test_knn_views_device(gpu, oracle):
+    """hm_knn_views_device: one query frame against several stored views, k = 3, device-resident."""
+    import ctypes as C
+    import torch
+    _, knn = gpu
+    from cv_amd import _lib
+    rng = np.random.default_rng(77)
+    cap, nviews = 600, 5
+    counts = np.array([600, 123, 2, 511, 37], np.int32)
+    views = np.zeros((nviews, cap, 64), np.uint8)
+    for v in range(nviews):
+        views[v, :counts[v]] = _rand_desc(rng, int(counts[v]))
+    q = np.zeros((cap, 64), np.uint8)
+    nq = 421
+    q[:nq] = _rand_desc(rng, nq)
+    q[:3] = views[0, :3]
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(q).to(dev)
+    d_nq = torch.tensor([nq], dtype=torch.int32, device=dev)
+    d_views = torch.from_numpy(views).to(dev)
+    d_nv = torch.from_numpy(counts).to(dev)
+    out = torch.zeros((3, cap, 3, 2), dtype=torch.int32, device=dev)
+    m = knn.Matcher(cap)
+    sel = [4, 0, 3]
+    idx = (C.c_uint32 * 3)(*sel)
+    L = _lib.lib()
+    _lib.check(L.hm_knn_views_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_views.data_ptr(), d_nv.data_ptr(), cap,
+                                     idx, 3, 3, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn_views")
+    _lib.check(L.hm_sync(m.handle), "hm_sync")
+    got = out.cpu().numpy()
+    for j, v in enumerate(sel):
+        want = oracle.knn(q[:nq], views[v, :counts[v]], 3)
+        _eq(got[j, :nq, :, 0].astype(np.uint32), want["index"], f"view {v} idx")
+        _eq(got[j, :nq, :, 1].astype(np.uint32), want["distance"], f"view {v} dist")
+
+
 def test_matching_rules(gpu, oracle):
     _, knn = gpu
     rng = np.random.default_rng(22)

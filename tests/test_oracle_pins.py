@@ -185,3 +185,25 @@ def test_knn2_tie_rule_and_matching_rules(oracle):
     assert O.match(q2, t2, rule=O.RULE_LOWE, param_f=0.5, symmetric=False).tolist() == [[0, 0]]  # 0 < 12
     # cv-sfm guard: fewer than 2 on either side -> no matches (cv-sfm/src/lib.rs:3099-3101)
     assert len(O.match(q, t2[:1], rule=O.RULE_BETTER_BY, symmetric=True)) == 0
+
+
+def test_knn_general_k_matches_linear_knn_semantics(oracle):
+    """orc_knn(k) is LinearKnn::knn restated for any k: it agrees with orc_knn2 for k = 2, with a direct
+    (distance, index) sort for k = 1..4, and returns min(k, nt) real neighbours."""
+    O = oracle
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (40, 64), dtype=np.uint8)
+    t = rng.integers(0, 256, (90, 64), dtype=np.uint8)
+    t[10:30] = t[40:60]                      # duplicates: ties
+    q[:5] = t[:5]
+    n2 = O.knn2(q, t)
+    g2 = O.knn(q, t, 2)
+    assert np.array_equal(n2["index"], g2["index"]) and np.array_equal(n2["distance"], g2["distance"])
+    bits = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2).astype(np.int64)   # [nq, nt]
+    for k in (1, 2, 3, 4):
+        g = O.knn(q, t, k)
+        order = np.lexsort((np.broadcast_to(np.arange(len(t)), bits.shape), bits), axis=1)[:, :k]
+        assert np.array_equal(g["index"], order.astype(np.uint32))
+        assert np.array_equal(g["distance"], np.take_along_axis(bits, order, 1).astype(np.uint32))
+    short = O.knn(q, t[:2], 3)
+    assert (short["index"][:, 2] == 0xFFFFFFFF).all() and (short["index"][:, :2] < 2).all()
