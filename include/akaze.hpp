@@ -238,6 +238,21 @@ public:
         return {Neighbor{out[0].index, out[0].distance}, Neighbor{out[1].index, out[1].distance}};
     }
 
+    // Knn::knn(&self, query, num) -> Vec<Neighbor> for num = 1..3 (cv-sfm/src/lib.rs:1474 asks for 3):
+    // min(num, iter.len()) neighbours, as the reference returns.
+    std::vector<Neighbor> knn_vec(const akaze::BitArray64& query, std::size_t num) const
+    {
+        if (num < 1 || num > 3) throw std::invalid_argument("the MI355X matcher implements knn(query, k) for k <= 3");
+        akz_neighbor out[3];
+        akaze::check(hm_knn(m_.handle(), reinterpret_cast<const akz_descriptor*>(query.data()), 1,
+                            reinterpret_cast<const akz_descriptor*>(iter_.data()), (uint32_t)iter_.size(),
+                            (uint32_t)num, out),
+                     "hm_knn");
+        std::vector<Neighbor> r;
+        for (std::size_t i = 0; i < num && i < iter_.size(); ++i) r.push_back(Neighbor{out[i].index, out[i].distance});
+        return r;
+    }
+
 private:
     const std::vector<akaze::BitArray64>& iter_;
     Matcher& m_;
