@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
-    "akz_half_size", "hm_create", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
+    "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
     "hm_match_batch_device", "hm_sync",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
@@ -104,6 +104,7 @@ def lib():
     L.akz_horizontal_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]
     L.akz_vertical_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]
     L.akz_half_size.argtypes = [vp, vp, i32, i32, vp]
+    L.akz_sample_colors_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, u32, vp]
     L.hm_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
     L.hm_destroy.argtypes = [vp]
     L.hm_knn2.argtypes = [vp, vp, u32, vp, u32, vp]

@@ -226,6 +226,17 @@ class Context:
         check(_lib.lib().akz_debug_get_keypoints(self._h, img, stage, out.ctypes.data, self.max_kp, C.byref(n)))
         return out[:n.value].copy()
 
+    def sample_colors(self, rgb, kps):
+        """bicubic::interpolate_bicubic(&image.to_rgb8(), kp.point.0, kp.point.1, Rgb([0, 0, 0])) for every
+        keypoint (cv-sfm/src/lib.rs:2207-2216): rgb [h, w, 3] uint8, kps a KP_DTYPE array -> [n, 3] uint8."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        out = np.zeros((len(kps), 3), np.uint8)
+        check(_lib.lib().akz_sample_colors_rgb8(self._h, rgb.ctypes.data, rgb.shape[1], rgb.shape[0],
+                                                rgb.strides[0], kps.ctypes.data, len(kps), out.ctypes.data),
+              "akz_sample_colors_rgb8")
+        return out
+
     def timing_enable(self, on=True):
         check(_lib.lib().akz_timing_enable(self._h, int(on)))
 

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libakz.so")
-SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_plan.cpp"]
+SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_color.hip", "akz_plan.cpp"]
 HEADERS = ["akz_common.h", "akz_ctx.h", "../../include/akz.h", "../../include/akz_portable_math.h", "../../include/akz_ransac_math.h", "../../include/akz_p3p_math.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -179,6 +179,7 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
     timer_free(&c->t_ss);
     timer_free(&c->t_all);
     if (c->arena) hipFree(c->arena);
+    if (c->d_color) hipFree(c->d_color);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_kp) hipStreamDestroy(c->stream_kp);
     if (c->ev_input) hipEventDestroy(c->ev_input);

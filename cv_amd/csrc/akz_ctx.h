@@ -77,6 +77,8 @@ struct akz_ctx {
     int cur = 0;               // set used by the most recent call
     uint64_t calls = 0;
     hipStream_t stream_kp = nullptr;
+    void* d_color = nullptr;            // scratch of akz_sample_colors_rgb8 (image + keypoints + colours), grown on demand
+    size_t color_bytes = 0;
     hipEvent_t ev_ss_done[2] = {nullptr, nullptr};  // pyramid + candidates of set b ready
     hipEvent_t ev_kp_done[2] = {nullptr, nullptr};  // keypoint stage of set b finished (pyramid reusable)
     bool kp_pending[2] = {false, false};

@@ -161,6 +161,13 @@ int32_t akz_vertical_filter(akz_ctx* ctx, const float* img, int32_t w, int32_t h
 int32_t akz_half_size(akz_ctx* ctx, const float* img, int32_t w, int32_t h, float* out);
 
 /* ---- brute-force Hamming matcher (space::LinearKnn{metric: Hamming} + bitarray::BitArray<64>) ---- */
+/* Bicubic colour sampling at keypoints: cv-sfm/src/bicubic.rs:34-68 (interpolate_bicubic) as called by
+ * VSlam::kps_descriptors (cv-sfm/src/lib.rs:2207-2216) on image.to_rgb8() at kp.point.  rgb: host, h rows of
+ * `stride` bytes, 3 bytes per pixel; colors [n][3].  A 4x4 neighbourhood that leaves the image gives the
+ * reference's default [0,0,0]. */
+int32_t akz_sample_colors_rgb8(akz_ctx* ctx, const uint8_t* rgb, int32_t w, int32_t h, int32_t stride,
+                               const akz_keypoint* kps, uint32_t n, uint8_t* colors);
+
 typedef struct hm_ctx hm_ctx;
 int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out);
 int32_t hm_destroy(hm_ctx* ctx);

@@ -103,6 +103,7 @@ def lib():
         L.orc_set_option.argtypes = [C.c_int, C.c_int]
         L.orc_get_option.argtypes = [C.c_int]
         L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_sample_colors_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
                                 C.c_float, C.c_int, C.c_void_p, C.c_uint32]
@@ -292,6 +293,15 @@ def knn2(q, t):
     r = lib().orc_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data)
     if r != 0:
         raise ValueError("knn2 needs at least two targets")
+    return out
+
+
+def sample_colors_rgb8(rgb, kps):
+    """interpolate_bicubic at every keypoint of a KP_DTYPE array on an [h, w, 3] uint8 image -> [n, 3] uint8."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros((len(kps), 3), np.uint8)
+    lib().orc_sample_colors_rgb8(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], kps.ctypes.data, len(kps), out.ctypes.data)
     return out
 
 

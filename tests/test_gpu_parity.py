@@ -283,6 +283,26 @@ def test_knn_views_device(gpu, oracle):
         _eq(got[j, :nq, :, 1].astype(np.uint32), want["distance"], f"view {v} dist")
 
 
+def test_bicubic_colour_sampling(gpu, oracle, kitti):
+    """akz_sample_colors_rgb8 == oracle restatement of cv-sfm/src/bicubic.rs on real keypoints plus positions on
+    and across the image border (default colour)."""
+    akaze, _ = gpu
+    img = kitti[0]
+    rng = np.random.default_rng(3)
+    rgb = np.stack([img, np.roll(img, 7, 1), 255 - img], axis=2)
+    rgb = np.ascontiguousarray(rgb ^ rng.integers(0, 32, rgb.shape, dtype=np.uint8))
+    ak = akaze.Akaze.sparse()
+    ctx = ak.context(img.shape[1], img.shape[0], 1)
+    (kp, _), = ctx.extract_batch([img])
+    extra = np.zeros(64, kp.dtype)
+    extra["x"] = rng.uniform(-4, img.shape[1] + 4, 64).astype(np.float32)
+    extra["y"] = rng.uniform(-4, img.shape[0] + 4, 64).astype(np.float32)
+    kps = np.concatenate([kp, extra])
+    got, want = ctx.sample_colors(rgb, kps), oracle.sample_colors_rgb8(rgb, kps)
+    _eq(got, want, "bicubic colours")
+    assert len(kp) > 100 and (want[:len(kp)].max() > 0)
+
+
 def test_matching_rules(gpu, oracle):
     _, knn = gpu
     rng = np.random.default_rng(22)

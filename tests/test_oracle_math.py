@@ -64,3 +64,47 @@ def test_portable_sincos(oracle):
     assert _ulp_diff(s[:m], gs).max() <= 1 and _ulp_diff(c[:m], gc).max() <= 1
     # glibc 2.35 sinf/cosf are ~0.56-ulp functions, not correctly rounded: ~1.2 % of inputs differ by 1 ulp
     assert (s[:m] != gs).mean() < 0.03 and (c[:m] != gc).mean() < 0.03
+
+
+def test_bicubic_colour_sampling_matches_float32_restatement(oracle):
+    """cv-sfm/src/bicubic.rs: the C restatement agrees with an independent numpy float32 evaluation of the
+    same expressions (rows blended and truncated to u8 first, then the column), returns the default colour
+    when the 4x4 neighbourhood leaves the image, and reproduces pixels exactly at integer positions."""
+    O = oracle
+    rng = np.random.default_rng(9)
+    h, w = 37, 53
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    kps = np.zeros(300, O.KP_DTYPE)
+    kps["x"] = rng.uniform(-3, w + 3, 300).astype(np.float32)
+    kps["y"] = rng.uniform(-3, h + 3, 300).astype(np.float32)
+    kps["x"][:10] = np.arange(5, 15, dtype=np.float32)      # integer positions: weight 0 -> the pixel itself
+    kps["y"][:10] = np.arange(7, 17, dtype=np.float32)
+    got = O.sample_colors_rgb8(rgb, kps)
+
+    f = np.float32
+
+    def clamp(v):
+        return np.uint8(255) if not (v < f(255)) else (np.uint8(int(v)) if v > f(0) else np.uint8(0))
+
+    def blend(p0, p1, p2, p3, x):
+        p0, p1, p2, p3, x = f(p0), f(p1), f(p2), f(p3), f(x)
+        in3 = f(f(f(3) * f(p1 - p2)) + p3) - p0
+        in2 = f(f(f(f(f(2) * p0) - f(f(5) * p1)) + f(f(4) * p2)) - p3) + f(x * in3)
+        in1 = f(p2 - p0) + f(x * in2)
+        return clamp(f(p1 + f(f(f(0.5) * x) * in1)))
+
+    for i in range(len(kps)):
+        x, y = f(kps["x"][i]), f(kps["y"][i])
+        left, top = f(np.floor(x) - f(1)), f(np.floor(y) - f(1))
+        if left < 0 or left + f(4) >= w or top < 0 or top + f(4) >= h:
+            assert tuple(got[i]) == (0, 0, 0)
+            continue
+        xw, yw = f(x - f(left + f(1))), f(y - f(top + f(1)))
+        l, t = int(left), int(top)
+        want = []
+        for ch in range(3):
+            col = [blend(*[rgb[t + r, l + j, ch] for j in range(4)], xw) for r in range(4)]
+            want.append(blend(*col, yw))
+        assert tuple(got[i]) == tuple(want), (i, got[i], want)
+    for i in range(10):
+        assert tuple(got[i]) == tuple(rgb[int(kps["y"][i]), int(kps["x"][i])])
