@@ -131,6 +131,11 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     c->max_kp = max_keypoints ? max_keypoints : 16384u;
     if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
     c->max_cand = c->max_kp;  // per (frame, level) candidate capacity; k_cand_sort keeps one list in LDS
+    c->sup_cap = 4u * c->max_kp;   // all levels together: frames with more candidates take the serial pass
+    {
+        const char* sp = getenv("AKZ_SUP_PARALLEL");
+        c->sup_parallel = !(sp && sp[0] == '0');
+    }
     const char* keep = getenv("AKZ_KEEP_ALL");
     c->keep_all = keep && keep[0] == '1';
     const char* fp = getenv("AKZ_FRONT_PAIR");
@@ -252,6 +257,8 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     const size_t K = c->max_kp;
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);
+    S.d_sup = cv.take<uint32_t>(B * (size_t)c->sup_cap * (2 * 24 + 6));
+    S.d_sup_flag = cv.take<uint32_t>(B);
     S.d_kp_a = cv.take<DevKp>(B * K);
     S.d_n_a = cv.take<uint32_t>(B);
     S.d_kp_b = cv.take<DevKp>(B * K);

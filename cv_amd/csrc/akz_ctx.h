@@ -34,6 +34,8 @@ struct AkzSet {
     uint2* d_cand = nullptr;               // [B][32][max_cand] {x | y << 16, response bits}, raster-sorted per level
     DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
     uint32_t* d_ncache = nullptr;          // [B]
+    uint32_t* d_sup = nullptr;             // [B][sup_cap * (2 * 24 + 6)] scratch of the parallel suppression (k_sup_*)
+    uint32_t* d_sup_flag = nullptr;        // [B] 1 = this frame takes the serial k_suppress
     DevKp* d_kp_a = nullptr;               // [B][max_kp]  stage-0 list (find_scale_space_extrema output)
     uint32_t* d_n_a = nullptr;
     DevKp* d_kp_b = nullptr;               // [B][max_kp]  stage-1 list (refined + orientation), pre-compaction slots
@@ -77,6 +79,8 @@ struct akz_ctx {
     int cur = 0;               // set used by the most recent call
     uint64_t calls = 0;
     hipStream_t stream_kp = nullptr;
+    bool sup_parallel = true;           // AKZ_SUP_PARALLEL=0: serial suppression only
+    uint32_t sup_cap = 0;               // candidates per frame the parallel suppression is sized for
     void* d_color = nullptr;            // scratch of akz_sample_colors_rgb8 (image + keypoints + colours), grown on demand
     size_t color_bytes = 0;
     hipEvent_t ev_ss_done[2] = {nullptr, nullptr};  // pyramid + candidates of set b ready

@@ -83,8 +83,10 @@ __device__ __forceinline__ uint32_t rl_u(uint32_t v, uint32_t l) { return (uint3
 __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* __restrict__ ncand,
                                                  const uint2* __restrict__ cand, uint32_t max_cand,
                                                  DevKp* __restrict__ cache, uint32_t max_kp,
-                                                 uint32_t* __restrict__ ncache, uint32_t* __restrict__ err)
+                                                 uint32_t* __restrict__ ncache, uint32_t* __restrict__ err,
+                                                 const uint32_t* __restrict__ only_flagged)
 {
+    if (only_flagged && !only_flagged[blockIdx.x]) return;   // the parallel path (k_sup_*) did this frame
     // LDS: the active list only.  A single wave executes its DS instructions in order, so a ds_write by
     // lane 0 is seen by every later ds_read of the wave without any barrier.  The wave is issue-bound
     // (one dependent instruction stream), so the per-candidate path is kept as short as possible:
@@ -389,6 +391,254 @@ __device__ __forceinline__ float fast_atan2_equiv(float y, float x)
     const float two_pi = 2.0f * 3.14159274101257324219f;
     float a = akz_pm_atan2f(y, x) + two_pi;
     return a >= two_pi ? a - two_pi : a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A12b in parallel.  The serial pass above costs ~6 ms per frame on one wave; it is exact but it is the whole
+// latency of a single-frame call.  The same result can be computed without walking the candidates one by one:
+//
+//   * Everything a candidate c can ever match is static: an entry's position is K(n) = p_n * ratio_n + offset_n of
+//     the candidate n that currently occupies it, its class is n's level, and c's test is
+//     |F(c) - K(n)|^2 <= size_c^2 with class(n) in {level(c), level(c) - 1} (scale_space_extrema.rs:72-90).
+//     k_sup_adj lists, for every c, the EARLIER candidates n that satisfy it (adj) and the reverse lists (radj).
+//   * The pass is then a recurrence over records that depend on earlier candidates only:
+//       slot(c)   = the cache slot c ends up writing (named by the candidate that pushed it), or none if dropped,
+//       target(c) = the occupant c replaced, if any.
+//     n still occupies its slot when c is processed iff slot(n) exists and no m < c in radj(n) has target(m) = n.
+//     Among c's occupied neighbours the reference's linear scan finds the one in the lowest slot, i.e. the
+//     smallest pusher index; c replaces it if its response is larger, is dropped otherwise, and pushes a new
+//     slot when there is none.
+//   * k_sup_resolve evaluates all records of a 1024-candidate chunk in parallel and repeats until a full sweep
+//     changes nothing (the fixed point is unique by induction on the candidate order; chains inside a chunk are
+//     short), chunk after chunk in candidate order.  The cache is the pushed slots in pusher order, each with the
+//     data of its final occupant.
+// Frames whose lists overflow the fixed capacities (kSupDeg neighbours, kSupCap candidates) are flagged and
+// go through k_suppress instead, so the result is the same in every case.
+constexpr int kSupDeg = 24;            // neighbours kept per candidate (each direction)
+constexpr uint32_t kSupNone = 0xFFFFFFFFu;
+
+struct SupFrame {                      // per-frame views of the scratch arrays
+    uint32_t* adj;    // [cap][kSupDeg]
+    uint32_t* nadj;   // [cap]
+    uint32_t* radj;   // [cap][kSupDeg]
+    uint32_t* nradj;  // [cap]
+    uint2* state;     // [cap] {slot, target}
+    float* resp;      // [cap]
+    uint32_t* rank;   // [cap] exclusive count of pushes before the candidate
+};
+
+__device__ __forceinline__ SupFrame sup_frame(uint32_t* base, uint32_t cap, int frame, uint32_t nframes)
+{
+    // array-major layout over the whole batch: nradj[B][cap] first (one memset clears the counters), then
+    // nadj, state(2), resp, rank, adj, radj
+    const size_t fc = (size_t)frame * cap, bc = (size_t)nframes * cap;
+    SupFrame f;
+    f.nradj = base + fc;
+    f.nadj = base + bc + fc;
+    f.state = reinterpret_cast<uint2*>(base + 2 * bc) + fc;
+    f.resp = reinterpret_cast<float*>(base + 4 * bc) + fc;
+    f.rank = base + 5 * bc + fc;
+    f.adj = base + 6 * bc + fc * kSupDeg;
+    f.radj = base + (6 + (size_t)kSupDeg) * bc + fc * kSupDeg;
+    return f;
+}
+
+// level of global candidate index g and index inside the level, from the per-level prefix sums
+__device__ __forceinline__ int sup_level(const uint32_t* base, int nlev, uint32_t g, uint32_t* i)
+{
+    int e = 0;
+    while (e + 1 < nlev && g >= base[e + 1]) ++e;
+    *i = g - base[e];
+    return e;
+}
+
+__global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* __restrict__ ncand,
+                                                 const uint2* __restrict__ cand, uint32_t max_cand, uint32_t* scratch,
+                                                 uint32_t cap, uint32_t* __restrict__ fallback)
+{
+    __shared__ uint32_t s_base[kMaxLevels + 1];
+    const int frame = blockIdx.y;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int e = 0; e < T.n; ++e) {
+            s_base[e] = acc;
+            acc += min(ncand[(size_t)frame * 32 + e], max_cand);
+        }
+        s_base[T.n] = acc;
+        if (acc > cap && blockIdx.x == 0) fallback[frame] = 1u;
+    }
+    __syncthreads();
+    const uint32_t N = s_base[T.n];
+    if (N > cap) return;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    const SupFrame F = sup_frame(scratch, cap, frame, gridDim.y);
+    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
+    uint32_t i;
+    const int e = sup_level(s_base, T.n, g, &i);
+    const uint2 me = cd[(size_t)e * max_cand + i];
+    const float ratio = ldexpf(1.0f, (int)T.L[e].octave);
+    const float fx = (float)(me.x & 0xFFFFu) * ratio, fy = (float)(me.x >> 16) * ratio;
+    const float size = T.L[e].kp_size, size2 = size * size;
+    F.resp[g] = fabsf(__uint_as_float(me.y));
+    F.state[g] = make_uint2(kSupNone, kSupNone);
+    uint32_t cnt = 0;
+    bool over = false;
+    for (int Lv = (e > 0 ? e - 1 : 0); Lv <= e; ++Lv) {
+        const float rl = ldexpf(1.0f, (int)T.L[Lv].octave);
+        const float hoff = 0.5f * (rl - 1.0f);
+        const uint32_t nL = s_base[Lv + 1] - s_base[Lv];
+        const uint2* lst = cd + (size_t)Lv * max_cand;
+        const uint32_t lim = (Lv == e) ? i : nL;           // same level: earlier candidates only
+        // rows of level Lv that can hold an entry within `size` of (fx, fy): conservative bounds
+        const float lo = (fy - size - hoff) / rl - 1.0f, hi = (fy + size - hoff) / rl + 1.0f;
+        const uint32_t ylo = lo > 0.0f ? (uint32_t)lo : 0u;
+        const uint32_t yhi = hi > 0.0f ? (uint32_t)hi : 0u;
+        uint32_t a = 0, b = lim;                             // lower bound of row >= ylo in [0, lim)
+        while (a < b) {
+            uint32_t m = (a + b) >> 1;
+            if ((lst[m].x >> 16) < ylo) a = m + 1;
+            else b = m;
+        }
+        for (uint32_t j = a; j < lim; ++j) {
+            const uint32_t xy = lst[j].x;
+            if ((xy >> 16) > yhi) break;
+            // the entry n = (Lv, j) would hold: K(n) = p * ratio + 0.5 (ratio - 1)   (:106-109)
+            const float kx = (float)(xy & 0xFFFFu) * rl + hoff, ky = (float)(xy >> 16) * rl + hoff;
+            const float dx = fx - kx, dy = fy - ky;
+            if (dx * dx + dy * dy <= size2) {
+                const uint32_t nidx = s_base[Lv] + j;
+                if (cnt < (uint32_t)kSupDeg) F.adj[(size_t)g * kSupDeg + cnt] = nidx;
+                else over = true;
+                ++cnt;
+                const uint32_t r = atomicAdd(&F.nradj[nidx], 1u);
+                if (r < (uint32_t)kSupDeg) F.radj[(size_t)nidx * kSupDeg + r] = g;
+                else over = true;
+            }
+        }
+    }
+    F.nadj[g] = min(cnt, (uint32_t)kSupDeg);
+    if (over) fallback[frame] = 1u;
+}
+
+__global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32_t* __restrict__ ncand,
+                                                      const uint2* __restrict__ cand, uint32_t max_cand,
+                                                      uint32_t* scratch, uint32_t cap,
+                                                      const uint32_t* __restrict__ fallback, DevKp* __restrict__ cache,
+                                                      uint32_t max_kp, uint32_t* __restrict__ ncache,
+                                                      uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t s_base[kMaxLevels + 1];
+    __shared__ uint32_t s_scan[1024 / 64];
+    __shared__ uint32_t s_total;
+    const int frame = blockIdx.x;
+    if (fallback[frame]) return;                 // k_suppress takes this frame
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int e = 0; e < T.n; ++e) {
+            s_base[e] = acc;
+            acc += min(ncand[(size_t)frame * 32 + e], max_cand);
+        }
+        s_base[T.n] = acc;
+        s_total = 0;
+    }
+    __syncthreads();
+    const uint32_t N = s_base[T.n];
+    const SupFrame F = sup_frame(scratch, cap, frame, gridDim.x);
+    for (uint32_t cb = 0; cb < N; cb += 1024) {
+        const uint32_t c = cb + tid;
+        const bool on = c < N;
+        uint32_t nn = 0;
+        float rc = 0.0f;
+        if (on) {
+            nn = F.nadj[c];
+            rc = F.resp[c];
+        }
+        for (;;) {
+            bool changed = false;
+            if (on) {
+                uint32_t best_slot = kSupNone, best_n = kSupNone;
+                for (uint32_t a = 0; a < nn; ++a) {
+                    const uint32_t n = F.adj[(size_t)c * kSupDeg + a];
+                    const uint32_t sl = F.state[n].x;
+                    if (sl == kSupNone || sl >= best_slot) continue;   // dropped, or not the first in slot order
+                    // still the occupant when c is processed?  not if an earlier-than-c candidate replaced it
+                    bool replaced = false;
+                    const uint32_t nr = min(F.nradj[n], (uint32_t)kSupDeg);
+                    for (uint32_t q = 0; q < nr; ++q) {
+                        const uint32_t m = F.radj[(size_t)n * kSupDeg + q];
+                        if (m < c && F.state[m].y == n) {
+                            replaced = true;
+                            break;
+                        }
+                    }
+                    if (!replaced) {
+                        best_slot = sl;
+                        best_n = n;
+                    }
+                }
+                uint2 st;
+                if (best_n == kSupNone) st = make_uint2(c, kSupNone);                       // push
+                else if (rc > F.resp[best_n]) st = make_uint2(best_slot, best_n);           // is_repeated: in-place write
+                else st = make_uint2(kSupNone, kSupNone);                                   // is_extremum = false
+                const uint2 old = F.state[c];
+                if (old.x != st.x || old.y != st.y) {
+                    F.state[c] = st;
+                    changed = true;
+                }
+            }
+            if (!__syncthreads_or(changed ? 1 : 0)) break;
+        }
+    }
+    // pushed slots in pusher order -> cache positions
+    uint32_t running = 0;
+    for (uint32_t cb = 0; cb < N; cb += 1024) {
+        const uint32_t c = cb + tid;
+        const bool push = c < N && F.state[c].x == c;
+        const unsigned long long bal = __ballot(push);
+        const uint32_t lane = tid & 63u, wv = tid >> 6;
+        if (lane == 0) s_scan[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = running;
+        for (uint32_t k = 0; k < wv; ++k) off += s_scan[k];
+        if (c < N) F.rank[c] = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < 1024 / 64; ++k) tot += s_scan[k];
+        running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (running > max_kp || running >= (1u << 24)) *err = 2u;
+        ncache[frame] = min(running, max_kp);
+    }
+    // every slot's final occupant writes the entry
+    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
+    DevKp* ch = cache + (size_t)frame * max_kp;
+    for (uint32_t c = tid; c < N; c += 1024) {
+        const uint2 st = F.state[c];
+        if (st.x == kSupNone) continue;
+        bool replaced = false;
+        const uint32_t nr = min(F.nradj[c], (uint32_t)kSupDeg);
+        for (uint32_t q = 0; q < nr; ++q)
+            if (F.state[F.radj[(size_t)c * kSupDeg + q]].y == c) {
+                replaced = true;
+                break;
+            }
+        if (replaced) continue;
+        const uint32_t pos = F.rank[st.x];
+        if (pos >= max_kp) continue;
+        uint32_t i;
+        const int e = sup_level(s_base, T.n, c, &i);
+        const uint2 me = cd[(size_t)e * max_cand + i];
+        const float ratio = ldexpf(1.0f, (int)T.L[e].octave);
+        const float half_off = 0.5f * (ratio - 1.0f);
+        const float fx = (float)(me.x & 0xFFFFu) * ratio, fy = (float)(me.x >> 16) * ratio;
+        // keypoint.point = p * ratio + 0.5 * (ratio - 1)  (:106-109)
+        DevKp kp = {fx + half_off, fy + half_off, fabsf(__uint_as_float(me.y)), T.L[e].kp_size, 0.0f, T.L[e].octave,
+                    (uint32_t)e};
+        ch[pos] = kp;
+    }
 }
 
 // XCD-aware block order for the one-wave-per-keypoint kernels (workgroup b runs on XCD b % 8, observed):
@@ -956,8 +1206,19 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     s = c->stream_kp;
     AKZ_HIP(hipStreamWaitEvent(s, c->ev_ss_done[c->cur], 0));
     // A12b
+    if (c->sup_parallel) {
+        AKZ_HIP(hipMemsetAsync(S.d_sup_flag, 0, sizeof(uint32_t) * n, s));
+        AKZ_HIP(hipMemsetAsync(S.d_sup, 0, sizeof(uint32_t) * (size_t)n * c->sup_cap, s));   // the reverse-list counters
+        hipLaunchKernelGGL(k_sup_adj, dim3(akz_div_up((int)c->sup_cap, 256), n), dim3(256), 0, s, T, S.d_ncand, S.d_cand,
+                           c->max_cand, S.d_sup, c->sup_cap, S.d_sup_flag);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sup_resolve, dim3(n), dim3(1024), 0, s, T, S.d_ncand, S.d_cand, c->max_cand, S.d_sup,
+                           c->sup_cap, S.d_sup_flag, S.d_cache, c->max_kp, S.d_ncache, c->d_err);
+        AKZ_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T, S.d_ncand,
-                       S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err);
+                       S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err,
+                       c->sup_parallel ? (const uint32_t*)S.d_sup_flag : (const uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
     hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache, S.d_flag_b);
