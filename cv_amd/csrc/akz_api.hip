@@ -135,6 +135,8 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     {
         const char* sp = getenv("AKZ_SUP_PARALLEL");
         c->sup_parallel = !(sp && sp[0] == '0');
+        const char* sc = getenv("AKZ_SUP_CAP");   // test knob: a small value sends frames down the fallback
+        if (sc && atoi(sc) > 0) c->sup_cap = (uint32_t)atoi(sc);
     }
     const char* keep = getenv("AKZ_KEEP_ALL");
     c->keep_all = keep && keep[0] == '1';

@@ -173,6 +173,31 @@ def test_descriptor_channels(gpu, oracle, nch):
     assert not np.unpackbits(desc, axis=1, bitorder="little")[:, used_bits:].any()
 
 
+def test_serial_suppression_path(gpu, oracle, kitti, monkeypatch):
+    """AKZ_SUP_PARALLEL=0 routes every frame through the one-wave serial pass (the fallback of the parallel
+    suppression for frames that overflow its fixed-capacity lists): same keypoints, same descriptors."""
+    akaze, _ = gpu
+    monkeypatch.setenv("AKZ_SUP_PARALLEL", "0")
+    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2)   # a fresh context reads the switch
+    res = ctx.extract_batch([kitti[0], kitti[1]])
+    orc = oracle.Akaze(1392, 512, oracle.default_config(threshold=0.01))
+    for i in range(2):
+        okp, odesc = orc.extract(kitti[i])
+        _kp_eq(res[i][0], okp, f"serial suppression frame {i}")
+        _eq(res[i][1], odesc, f"serial suppression frame {i} desc")
+    ctx.close()
+    # frames with more candidates than the parallel path is sized for are flagged on the device and fall back
+    monkeypatch.delenv("AKZ_SUP_PARALLEL")
+    monkeypatch.setenv("AKZ_SUP_CAP", "700")          # frame 0 has 1022 candidates, frame 14 has 844
+    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2)
+    res = ctx.extract_batch([kitti[0], kitti[1]])
+    for i in range(2):
+        okp, odesc = orc.extract(kitti[i])
+        _kp_eq(res[i][0], okp, f"fallback frame {i}")
+        _eq(res[i][1], odesc, f"fallback frame {i} desc")
+    ctx.close()
+
+
 def test_maximum_features_and_capacity(gpu, oracle, kitti):
     """lib.rs:326-327 truncation; AKZ_E_CAPACITY reports the required count."""
     akaze, _ = gpu
