@@ -292,6 +292,13 @@ def main():
             "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
                                   "extract": round(all_ms / args.steps, 2)},
         }
+        rf = out["roofline"]
+        if rf["traffic"] and rf["avg_launch_us"]:
+            # what the memory system actually moved (PMC) over the same launch time: the number to hold against
+            # the 8 TB/s peak; `achieved` above counts the contract's 12 B per pixel-step and exceeds the peak
+            # because up to 4 steps share one pass over HBM
+            rf["hbm_side_gbs"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
+            rf["hbm_side_frac"] = round(rf["hbm_side_gbs"] / HBM_PEAK_GBS, 4)
         out["device"] = device_probe(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, args.cpu_frames)
