@@ -737,13 +737,16 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
         if (lane < c_ori.n_win) {
             float ang1 = c_ori.ang1[lane];
             float ang2 = (ang1 + PI_F / 3.0f > 2.0f * PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+            // branch-free: a sample outside the window adds +0.0, which leaves the sums bit-identical to skipping
+            // it (they start at +0 and x + (+0) = x for every x but -0, which a sum that started at +0 never is)
+            const bool plain = ang1 < ang2, wrap = ang2 < ang1;
+#pragma unroll 4
             for (int k = 0; k < 109; ++k) {
-                float ang = s_ang[wv][k];
-                if ((ang1 < ang2 && ang1 < ang && ang < ang2) ||
-                    (ang2 < ang1 && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * PI_F)))) {
-                    sum_x += s_rx[wv][k];
-                    sum_y += s_ry[wv][k];
-                }
+                const float ang = s_ang[wv][k];
+                const bool in = (plain && ang1 < ang && ang < ang2) ||
+                                (wrap && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * PI_F)));
+                sum_x += in ? s_rx[wv][k] : 0.0f;
+                sum_y += in ? s_ry[wv][k] : 0.0f;
             }
             val = sum_x * sum_x + sum_y * sum_y;
         }
