@@ -65,20 +65,16 @@ AKZ_PM_FN float akz_pm_atan2f(float yf, float xf)
     double ax = x < 0.0 ? -x : x;
     int xneg = __builtin_signbit(xf);
     int yneg = __builtin_signbit(yf);
-    double a;
-    if (ay == 0.0) {
-        a = 0.0; /* also covers atan2(0,0) */
-    } else if (ay > ax) {
-        a = PIO2 - akz_pm_atan01(ax / ay);
-    } else {
-        a = akz_pm_atan01(ay / ax);
-    }
-    if (ay > ax) {
-        /* quadrant fold for |y|>|x| is about pi/2: x<0 mirrors to pi - a */
-        if (xneg) a = PI - a;
-    } else if (xneg) {
-        a = PI - a;
-    }
+    /* one division: min / max of the magnitudes (the same operands the two branches of the textbook form
+     * divide), folded about pi/4 afterwards; a zero numerator gives 0 (also atan2(0, 0), where 0 / 0 is
+     * replaced) */
+    const int steep = ay > ax;
+    const double num = steep ? ax : ay, den = steep ? ay : ax;
+    double a = akz_pm_atan01(den == 0.0 ? 0.0 : num / den);
+    if (steep) a = PIO2 - a;
+    if (ay == 0.0) a = 0.0;
+    /* quadrant fold: x < 0 mirrors to pi - a (for |y| > |x| as well, about pi/2) */
+    if (xneg) a = PI - a;
     if (yneg) a = -a;
     return (float)a;
 }
