@@ -1357,7 +1357,14 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
         const int x0 = tx0 + 4 * c, y = ty0 + q;
         if (x0 >= w || y < 1 || y > h - 2) continue;          // interior pixels only (:50)
         v2f m[12], z[12], p[12];
-        lds_read12<CG, 3, 8>(d4, q, c, m);                    // v[4 + o] is pixel o of the strip (ring tile x = tx0 - 4 + col)
+        lds_read12<CG, 4, 7>(d4, q + 1, c, z);                // v[4 + o] is pixel o of the strip (ring tile x = tx0 - 4 + col)
+        // most of an image is below the detector threshold: the 3x3 comparison runs only for waves that hold
+        // at least one pixel above it
+        bool above = false;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) above |= z[4 + o].x > cp.thr || z[4 + o].y > cp.thr;
+        if (!__any(above)) continue;
+        lds_read12<CG, 3, 8>(d4, q, c, m);
         lds_read12<CG, 3, 8>(d4, q + 1, c, z);
         lds_read12<CG, 3, 8>(d4, q + 2, c, p);
         // branch-free extremum test of the strip's 8 pixel-frames; candidates are rare, so the (divergent) append
