@@ -530,7 +530,6 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
 {
     __shared__ uint32_t s_base[kMaxLevels + 1];
     __shared__ uint32_t s_scan[1024 / 64];
-    __shared__ uint32_t s_total;
     const int frame = blockIdx.x;
     if (fallback[frame]) return;                 // k_suppress takes this frame
     const uint32_t tid = threadIdx.x;
@@ -541,7 +540,6 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
             acc += min(ncand[(size_t)frame * 32 + e], max_cand);
         }
         s_base[T.n] = acc;
-        s_total = 0;
     }
     __syncthreads();
     const uint32_t N = s_base[T.n];
