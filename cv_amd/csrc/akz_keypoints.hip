@@ -970,6 +970,24 @@ __global__ __launch_bounds__(256) void k_describe(LevelTable T, const DescTables
 //            bit-exact, so there is no tree reduction.
 // A wave's DS instructions execute in order, so the reduce phase sees the gather phase's writes without
 // a barrier; waves never share LDS here.
+// Cell means of one M-LDB grid (step ST, SIDE x SIDE cells) from the wave's lattice values: lane <-> (cell,
+// channel), every sum sequential in mldb_fill_values' order (descriptors.rs:123-159), then / nsamples.
+template <int ST, int SIDE, int VBASE>
+__device__ __forceinline__ void desc_cells(const float* s_ri, const float* s_dx, const float* s_dy, float* s_val, int lane)
+{
+    constexpr int LAT = 21;
+    if (lane >= SIDE * SIDE * 3) return;
+    const int cell = lane / 3, ch = lane - cell * 3;
+    const int ci = cell / SIDE, cj = cell - ci * SIDE;          // i outer (k), j inner (l): descriptors.rs:117-118
+    const float* src = (ch == 0 ? s_ri : (ch == 1 ? s_dx : s_dy)) + (ci * ST) * LAT + cj * ST;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < ST; ++kk)
+#pragma unroll
+        for (int ll = 0; ll < ST; ++ll) acc += src[kk * LAT + ll];
+    s_val[VBASE + cell * 3 + ch] = acc / (float)(ST * ST);
+}
+
 // The three grids sample the SAME lattice: sample (k, l) of any grid sits at
 // (xf + (-l*si*scale + k*co*scale), yf + (l*co*scale + k*si*scale)) with integer k, l in [-10, 10] (the 3x3 grid
 // of step 7 reaches +10, the other two stop at +9), so the 21 x 21 = 441 lattice values are gathered ONCE
@@ -1038,27 +1056,12 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
         }
     }
     oob = __any(oob);
-    if (!oob && lane < 29) {
-        // lane -> (grid, cell): lanes 0-3 the 2x2 grid (step 10), 4-12 the 3x3 grid (step 7), 13-28 the 4x4 grid (step 5)
-        const int st = lane < 4 ? 10 : (lane < 13 ? 7 : 5);
-        const int side = lane < 4 ? 2 : (lane < 13 ? 3 : 4);
-        const int cell = lane < 4 ? lane : (lane < 13 ? lane - 4 : lane - 13);
-        const int vbase = (lane < 4 ? 0 : (lane < 13 ? 12 : 39)) + cell * 3;
-        const int ci = cell / side, cj = cell - ci * side;          // i outer (k), j inner (l): descriptors.rs:117-118
-        const int base = (ci * st) * LAT + cj * st;
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        for (int kk = 0; kk < st; ++kk) {
-            const int row = base + kk * LAT;
-            for (int ll = 0; ll < st; ++ll) {                      // mldb_fill_values order, descriptors.rs:123-159
-                di += s_ri[wv][row + ll];
-                dx += s_dx[wv][row + ll];
-                dy += s_dy[wv][row + ll];
-            }
-        }
-        const float ns = (float)(st * st);
-        s_val[wv][vbase + 0] = di / ns;
-        s_val[wv][vbase + 1] = dx / ns;
-        s_val[wv][vbase + 2] = dy / ns;
+    if (!oob) {
+        // one lane per (cell, channel): 12 + 27 + 48 independent serial sums, each grid a pass with compile-time
+        // loop bounds (one LDS read and one add per sample), in the reference's (k outer, l inner) order
+        desc_cells<10, 2, 0>(s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+        desc_cells<7, 3, 12>(s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
+        desc_cells<5, 4, 39>(s_ri[wv], s_dx[wv], s_dy[wv], s_val[wv], lane);
     }
     // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
     uint32_t byte = 0;
