@@ -33,6 +33,7 @@ FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FED_BYTES_PER_PIXEL_STEP = 12.0
+MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
 
 
 def make_world(seed, w, h):
@@ -200,11 +201,16 @@ def main():
     barrier()
     ctx.timing_enable(True)
     ctx.timing_reset()
+    _lib.check(L.hm_timing_get(matcher.handle, None, None, 1), "hm_timing_get")
+    _lib.check(L.hm_timing_enable(matcher.handle, 1), "hm_timing_enable")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    knn_ms, knn_launches = C.c_double(), C.c_uint64()
+    _lib.check(L.hm_timing_get(matcher.handle, C.byref(knn_ms), C.byref(knn_launches), 1), "hm_timing_get")
+    _lib.check(L.hm_timing_enable(matcher.handle, 0), "hm_timing_enable")
     _lib.check(L.akz_sync(ctx.handle), "akz_sync")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -292,6 +298,19 @@ def main():
             "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
                                   "extract": round(all_ms / args.steps, 2)},
         }
+        if knn_ms.value > 0:
+            # second roofline, for the matcher: 2 directions x nq x nt x 512-bit contractions per frame pair as
+            # int8 MACs (2 ops each) over the HIP-event time of the k_knn_mfma launches on the matcher's stream
+            pairs_total = NF * args.steps
+            macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
+            tops = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
+            out["roofline_matcher"] = {
+                "bound": "mfma", "kernel": "k_knn_mfma<2> (v_mfma_i32_32x32x32_i8)", "achieved": round(tops, 1),
+                "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
+                "launches": int(knn_launches.value),
+                "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
+                "note": "ops = 2 x 512 int8 MACs per (query, target) pair with the mean keypoint count; peak = the "
+                        "int8 micro-benchmark ceiling of MI355X_MICROARCH.md (no spec figure is listed for dense I8)"}
         rf = out["roofline"]
         if rf["traffic"] and rf["avg_launch_us"]:
             # what the memory system actually moved (PMC) over the same launch time: the number to hold against

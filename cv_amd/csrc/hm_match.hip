@@ -386,6 +386,12 @@ struct hm_ctx {
     uint32_t* d_exp = nullptr;
     size_t exp_words = 0;
     bool use_mfma = true;
+    // optional timing of the k-NN launches (HIP events on the matcher stream), for bench.py's MFMA roofline
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pending;
+    std::vector<hipEvent_t> t_pool;
+    double t_ms = 0.0;
+    uint64_t t_launches = 0, t_macs = 0;
     akz_neighbor* d_bfwd = nullptr;
     akz_neighbor* d_brev = nullptr;
     size_t bscratch_elems = 0;
@@ -472,6 +478,8 @@ extern "C" int32_t hm_destroy(hm_ctx* c)
     hipFree(c->d_probs);
     if (c->h_probs) hipHostFree(c->h_probs);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    for (auto& pr : c->t_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : c->t_pool) hipEventDestroy(e);
     hipFree(c->d_exp);
     hipFree(c->d_bfwd);
     hipFree(c->d_brev);
@@ -539,6 +547,18 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
                        reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
     AKZ_LAUNCH_CHECK();
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->timing) {
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->t_pool.empty()) { e = c->t_pool.back(); c->t_pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        ev0 = take();
+        ev1 = take();
+        if (ev0) hipEventRecord(ev0, c->stream);
+    }
     {
         dim3 grid((max_nq + 255) / 256, n_probs);
         const HmProbX* dp = reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off);
@@ -547,6 +567,11 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
         case 3: hipLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
         default: hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
         }
+    }
+    if (ev0 && ev1) {
+        hipEventRecord(ev1, c->stream);
+        c->t_pending.emplace_back(ev0, ev1);
+        c->t_launches += 1;
     }
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
@@ -632,6 +657,34 @@ extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d
                        (const uint32_t*)d_nviews + view_idx[v], cap_per_img,
                        (akz_neighbor*)d_out + (size_t)v * cap_per_img * k};
     return launch_knn2(c, hp.data(), n_views, cap_per_img, 0, (int)k);
+}
+
+// Timing of the k-NN kernel launches (HIP events on hm_stream()): enable, run, then read the accumulated
+// milliseconds and launch count.  hm_timing_get synchronises the pending events.
+extern "C" int32_t hm_timing_enable(hm_ctx* c, int32_t on)
+{
+    if (!c) return AKZ_E_INVALID;
+    c->timing = on != 0;
+    return AKZ_OK;
+}
+extern "C" int32_t hm_timing_get(hm_ctx* c, double* ms, uint64_t* launches, int32_t reset)
+{
+    if (!c) return AKZ_E_INVALID;
+    for (auto& pr : c->t_pending) {
+        float t = 0.0f;
+        hipEventSynchronize(pr.second);
+        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) c->t_ms += (double)t;
+        c->t_pool.push_back(pr.first);
+        c->t_pool.push_back(pr.second);
+    }
+    c->t_pending.clear();
+    if (ms) *ms = c->t_ms;
+    if (launches) *launches = c->t_launches;
+    if (reset) {
+        c->t_ms = 0.0;
+        c->t_launches = 0;
+    }
+    return AKZ_OK;
 }
 
 extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uint32_t nb,

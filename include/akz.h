@@ -213,6 +213,10 @@ int32_t hm_match_batch_device(hm_ctx* ctx, const void* d_a, const void* d_na, co
                               float param_f, int32_t symmetric, void* d_pairs, void* d_n_out,
                               void* stream_to_wait);
 int32_t hm_sync(hm_ctx* ctx);
+/* Optional timing of the k-NN kernel launches with HIP events on hm_stream() (bench.py's matcher roofline):
+ * hm_timing_get waits for the pending events and returns the accumulated milliseconds / launch count. */
+int32_t hm_timing_enable(hm_ctx* ctx, int32_t on);
+int32_t hm_timing_get(hm_ctx* ctx, double* ms, uint64_t* launches, int32_t reset);
 void* hm_stream(hm_ctx* ctx);
 
 /* ---- two-view geometric verification (second phase) ---- */

@@ -81,3 +81,25 @@ def test_gaussian_kernel_host_entry(lib):
     known = [0.10628852, 0.14032133, 0.16577007, 0.17524014, 0.16577007, 0.14032133, 0.10628852]
     assert np.all(np.abs(out - np.array(known, np.float32)) < 1e-4)
     assert lib.akz_gaussian_kernel(3.0, 6, out.ctypes.data) == -1  # even size: the reference asserts
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_final.json is the JSON line bench.py printed on the MI355X: the driver's keys, the
+    roofline object of the dominant kernel and the bounded CPU baseline must all be there."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r01_bench_final.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 2000.0          # BASELINE.json's target for one MI355X
