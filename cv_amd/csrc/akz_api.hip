@@ -142,10 +142,6 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     c->keep_all = keep && keep[0] == '1';
     const char* fp = getenv("AKZ_FRONT_PAIR");
     c->front_pair = !(fp && fp[0] == '0');
-    const char* fc = getenv("AKZ_FRONT_CFG");
-    if (fc) c->front_cfg = atoi(fc);
-    const char* dc = getenv("AKZ_DERIV_CFG");
-    if (dc) c->deriv_cfg = atoi(dc);
     int32_t st = AKZ_OK;
     // The scale-space stream is the critical path of the pipeline: it gets the highest priority so its
     // HBM-bound kernels are dispatched first; the keypoint stream fills the remaining wave slots.

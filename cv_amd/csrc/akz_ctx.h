@@ -61,8 +61,6 @@ struct akz_ctx {
     uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
     int desc_tile_shift = 5;  // log2 of the tile edge of the descriptor visiting order; env AKZ_DESC_TILE_SHIFT
     int fed_block = 4;        // FED steps fused per launch (1 = one launch per step); env AKZ_FED_BLOCK
-    int deriv_cfg = 0;        // AKZ_DERIV_CFG: 0 = 12-row tiles x 256 threads, 1 = 26-row tiles x 512 threads
-    int front_cfg = 1;        // AKZ_FRONT_CFG: 0 = 24-row tiles x 512 threads, 1 = 32-row tiles x 256 threads
     bool front_pair = true;   // two-frame packed front kernel (AKZ_FRONT_PAIR=0 selects the one-frame kernel)
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
 

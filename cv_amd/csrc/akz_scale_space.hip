@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
 constexpr int kTH = 32;  // output tile height
-constexpr int kFTH = 24; // output tile height of the two-frame front kernel (LDS: 2 x 22 KB -> 3 blocks per CU)
+constexpr int kFTH = 24; // row tile of the contrast passes (24 rows x 512 threads, 9 tiles per block)
 constexpr int kDTH = 12; // output tile height of the two-frame determinant kernel
 constexpr int kCTiles = 9; // row tiles per block of the contrast passes
 constexpr int kFNT = 512; // its block size: 3 blocks x 8 waves per CU
@@ -838,158 +838,10 @@ __global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src,
     dst[base] = v;
 }
 
-// 4 pixels per lane (w % 4 == 0): row segments move as dwordx4, a wave covers 256 contiguous pixels.
-__global__ __launch_bounds__(256) void k_fed_step_x4(const float* __restrict__ src, const float* __restrict__ c,
-                                                     float* __restrict__ dst, int w, int h, size_t fs,
-                                                     float half_tau)
-{
-    int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    size_t base = (size_t)blockIdx.z * fs + (size_t)y * w + x;
-    const float* L = src + base;
-    const float* C = c + base;
-    float4 l = *reinterpret_cast<const float4*>(L);
-    float4 cc = *reinterpret_cast<const float4*>(C);
-    float lv[6], cv[6];
-    lv[1] = l.x; lv[2] = l.y; lv[3] = l.z; lv[4] = l.w;
-    cv[1] = cc.x; cv[2] = cc.y; cv[3] = cc.z; cv[4] = cc.w;
-    bool has_l = x > 0, has_r = x + 4 < w;
-    lv[0] = has_l ? L[-1] : 0.0f;
-    cv[0] = has_l ? C[-1] : 0.0f;
-    lv[5] = has_r ? L[4] : 0.0f;
-    cv[5] = has_r ? C[4] : 0.0f;
-    float hf[5];  // hf[i] = flow between pixel (x-1+i) and (x+i)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) hf[i] = fed_flow(half_tau, cv[i], cv[i + 1], lv[i], lv[i + 1]);
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v = lv[i + 1];
-        if (i < 3 || has_r) v = v + hf[i + 1];
-        if (i > 0 || has_l) v = v - hf[i];
-        r[i] = v;
-    }
-    if (y < h - 1) {
-        float4 ld = *reinterpret_cast<const float4*>(L + w);
-        float4 cd = *reinterpret_cast<const float4*>(C + w);
-        r[0] = r[0] + fed_flow(half_tau, cc.x, cd.x, l.x, ld.x);
-        r[1] = r[1] + fed_flow(half_tau, cc.y, cd.y, l.y, ld.y);
-        r[2] = r[2] + fed_flow(half_tau, cc.z, cd.z, l.z, ld.z);
-        r[3] = r[3] + fed_flow(half_tau, cc.w, cd.w, l.w, ld.w);
-    }
-    if (y > 0) {
-        float4 lu = *reinterpret_cast<const float4*>(L - w);
-        float4 cu = *reinterpret_cast<const float4*>(C - w);
-        r[0] = r[0] - fed_flow(half_tau, cu.x, cc.x, lu.x, l.x);
-        r[1] = r[1] - fed_flow(half_tau, cu.y, cc.y, lu.y, l.y);
-        r[2] = r[2] - fed_flow(half_tau, cu.z, cc.z, lu.z, l.z);
-        r[3] = r[3] - fed_flow(half_tau, cu.w, cc.w, lu.w, l.w);
-    }
-    *reinterpret_cast<float4*>(dst + base) = make_float4(r[0], r[1], r[2], r[3]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Temporally blocked FED: T (<= 4) consecutive calculate_step()s per launch.  A block owns a 64x32 output
-// tile; it stages the tile plus a halo (4 columns, T rows each side) of L and c in LDS once, runs the T
-// Jacobi steps LDS -> LDS (ping-pong), and writes the tile once.  Per pixel the arithmetic of every step is
-// exactly that of k_fed_step (same expression order, same border rules by GLOBAL coordinates); halo pixels
-// are recomputed redundantly by neighbouring blocks, and a value at distance d from the staged region's
-// edge is exact after step t whenever d >= t, which holds for the tile itself at t = T.
-// HBM traffic per pixel for T steps: ~1.4 x 8 B read + 4 B write, instead of T x 12 B.
+// up to four half-tau values of one temporally blocked launch
 struct FedTaus {
     float half_tau[4];
 };
-
-template <int T>
-__global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src, const float* __restrict__ cnd,
-                                                   float* __restrict__ dst, int w, int h, size_t fs, FedTaus taus)
-{
-    constexpr int TW = 64, TH = 32, HX = 4;
-    constexpr int LW = TW + 2 * HX;   // 72 floats per LDS row (16-byte aligned segments)
-    constexpr int ROWS = TH + 2 * T;
-    constexpr int SEGS = LW / 4;      // 18
-    __shared__ __attribute__((aligned(16))) float sL[2][ROWS * LW];
-    __shared__ __attribute__((aligned(16))) float sC[ROWS * LW];
-    const int frame = blockIdx.z;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const float* L = src + (size_t)frame * fs;
-    const float* C = cnd + (size_t)frame * fs;
-    // stage (w % 4 == 0 and tx0 % 4 == 0: a 4-pixel segment is entirely inside or outside the image)
-    for (int sidx = threadIdx.x; sidx < ROWS * SEGS; sidx += 256) {
-        int row = sidx / SEGS, c4 = (sidx - row * SEGS) * 4;
-        int gx = tx0 - HX + c4, gy = ty0 - T + row;
-        float4 l = make_float4(0.f, 0.f, 0.f, 0.f), c = l;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-            l = *reinterpret_cast<const float4*>(L + (size_t)gy * w + gx);
-            c = *reinterpret_cast<const float4*>(C + (size_t)gy * w + gx);
-        }
-        *reinterpret_cast<float4*>(&sL[0][row * LW + c4]) = l;
-        *reinterpret_cast<float4*>(&sC[row * LW + c4]) = c;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float half_tau = taus.half_tau[t];
-        const float* in = sL[t & 1];
-        float* out = sL[(t + 1) & 1];
-        for (int sidx = threadIdx.x; sidx < (ROWS - 2) * SEGS; sidx += 256) {
-            int row = sidx / SEGS + 1, c4 = (sidx - (row - 1) * SEGS) * 4;
-            int gx = tx0 - HX + c4, gy = ty0 - T + row;
-            if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-            const float* lp = in + row * LW + c4;
-            const float* cp = sC + row * LW + c4;
-            float4 l = *reinterpret_cast<const float4*>(lp);
-            float4 cc = *reinterpret_cast<const float4*>(cp);
-            float lv[6], cv[6];
-            lv[1] = l.x; lv[2] = l.y; lv[3] = l.z; lv[4] = l.w;
-            cv[1] = cc.x; cv[2] = cc.y; cv[3] = cc.z; cv[4] = cc.w;
-            const bool has_l = gx > 0, has_r = gx + 4 < w;
-            lv[0] = (c4 > 0) ? lp[-1] : 0.0f;
-            cv[0] = (c4 > 0) ? cp[-1] : 0.0f;
-            lv[5] = (c4 + 4 < LW) ? lp[4] : 0.0f;
-            cv[5] = (c4 + 4 < LW) ? cp[4] : 0.0f;
-            float hf[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) hf[i] = fed_flow(half_tau, cv[i], cv[i + 1], lv[i], lv[i + 1]);
-            float r[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = lv[i + 1];
-                if (i < 3 || has_r) v = v + hf[i + 1];
-                if (i > 0 || has_l) v = v - hf[i];
-                r[i] = v;
-            }
-            if (gy < h - 1) {
-                float4 ld = *reinterpret_cast<const float4*>(lp + LW);
-                float4 cd = *reinterpret_cast<const float4*>(cp + LW);
-                r[0] = r[0] + fed_flow(half_tau, cc.x, cd.x, l.x, ld.x);
-                r[1] = r[1] + fed_flow(half_tau, cc.y, cd.y, l.y, ld.y);
-                r[2] = r[2] + fed_flow(half_tau, cc.z, cd.z, l.z, ld.z);
-                r[3] = r[3] + fed_flow(half_tau, cc.w, cd.w, l.w, ld.w);
-            }
-            if (gy > 0) {
-                float4 lu = *reinterpret_cast<const float4*>(lp - LW);
-                float4 cu = *reinterpret_cast<const float4*>(cp - LW);
-                r[0] = r[0] - fed_flow(half_tau, cu.x, cc.x, lu.x, l.x);
-                r[1] = r[1] - fed_flow(half_tau, cu.y, cc.y, lu.y, l.y);
-                r[2] = r[2] - fed_flow(half_tau, cu.z, cc.z, lu.z, l.z);
-                r[3] = r[3] - fed_flow(half_tau, cu.w, cc.w, lu.w, l.w);
-            }
-            *reinterpret_cast<float4*>(out + row * LW + c4) = make_float4(r[0], r[1], r[2], r[3]);
-        }
-        __syncthreads();
-    }
-    const float* fin = sL[T & 1];
-    float* D = dst + (size_t)frame * fs;
-    for (int sidx = threadIdx.x; sidx < TH * (TW / 4); sidx += 256) {
-        int q = sidx / (TW / 4), p4 = (sidx - q * (TW / 4)) * 4;
-        int gx = tx0 + p4, gy = ty0 + q;
-        if (gx < w && gy < h)
-            *reinterpret_cast<float4*>(D + (size_t)gy * w + gx) =
-                *reinterpret_cast<const float4*>(fin + (q + T) * LW + HX + p4);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // calculate_step for two frames per block with the image held in REGISTERS across the T steps of a launch.
@@ -1588,12 +1440,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
                        dim3(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s,    \
                        d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0], (const float*)nullptr, 0)
-        // measured (ms of scale space per 64 frames): 32 rows x 256 threads 10.18, 24 x 512 10.50; five row
-        // tiles per block with register prefetch 10.83 / 11.03 (the loop costs ~25 VGPRs and a wave per SIMD)
-        switch (c->front_cfg) {
-        case 0: AKZ_FRONT0(kFTH, kFNT, 1); break;
-        default: AKZ_FRONT0(32, 256, 1); break;
-        }
+        // 32-row tiles x 256 threads (measured against 24 x 512 and against 5 row tiles per block with register
+        // prefetch: 10.18 vs 10.50 / 10.83 ms of scale space per 64 frames)
+        AKZ_FRONT0(32, 256, 1);
 #undef AKZ_FRONT0
         AKZ_LAUNCH_CHECK();
     } else if (fused0) {
@@ -1638,7 +1487,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // Ping-pong so the last FED step lands in Lt[i]; `init` is where the un-diffused Lt[i] lives.
             float* bufA = S.Lt[i];
             float* bufB = S.tmp;
-            const bool blocked = (L.w & 3) == 0 && c->fed_block > 1;
+            const bool blocked = (L.w & 3) == 0 && c->fed_block > 1 && c->front_pair;   // k_fed_pair
             const int nwrites = blocked ? (nsteps + c->fed_block - 1) / c->fed_block : nsteps;  // FED launches
             const float* init;
             if (L.new_octave) {
@@ -1667,10 +1516,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                        init, L.w, L.h, fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk,            \
                        (int)L.octave)
 #define AKZ_FRONT2(SGV)                                                                                              \
-    switch (c->front_cfg) {                                                                                          \
-    case 0: AKZ_FRONT2X(SGV, kFTH, kFNT, 1); break;                                                                  \
-    default: AKZ_FRONT2X(SGV, 32, 256, 1); break;                                                                    \
-    }
+    AKZ_FRONT2X(SGV, 32, 256, 1)
                 const bool pair = (L.w & 3) == 0 && c->front_pair;
                 switch (L.deriv_sigma) {
                 case 2: if (pair) { AKZ_FRONT2(2); } else AKZ_FRONT(2); break;
@@ -1704,21 +1550,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                     float* dstb = ((ng - 1 - gi) % 2 == 0) ? bufA : bufB;
                     FedTaus ft;
                     for (int q = 0; q < 4; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
-                    dim3 grid(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
                     dim3 gridp(akz_div_up(L.w, kFedU), akz_div_up(L.h, kFedU), (n + 1) / 2);
-                    if (c->front_pair) {
-                        switch (groups[gi]) {
-                        case 1: hipLaunchKernelGGL((k_fed_pair<1>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                        case 2: hipLaunchKernelGGL((k_fed_pair<2>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                        case 3: hipLaunchKernelGGL((k_fed_pair<3>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                        default: hipLaunchKernelGGL((k_fed_pair<4>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                        }
-                    } else
                     switch (groups[gi]) {
-                    case 1: hipLaunchKernelGGL((k_fed_multi<1>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
-                    case 2: hipLaunchKernelGGL((k_fed_multi<2>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
-                    case 3: hipLaunchKernelGGL((k_fed_multi<3>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
-                    default: hipLaunchKernelGGL((k_fed_multi<4>), grid, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, ft); break;
+                    case 1: hipLaunchKernelGGL((k_fed_pair<1>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                    case 2: hipLaunchKernelGGL((k_fed_pair<2>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                    case 3: hipLaunchKernelGGL((k_fed_pair<3>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                    default: hipLaunchKernelGGL((k_fed_pair<4>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
                     }
                     AKZ_LAUNCH_CHECK();
                     j += groups[gi];
@@ -1728,13 +1565,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             for (int j = 0; j < nsteps; ++j) {
                 float* dst = ((nsteps - 1 - j) % 2 == 0) ? bufA : bufB;
                 float half_tau = 0.5f * (float)L.tau[j];
-                if ((L.w & 3) == 0) {
-                    hipLaunchKernelGGL(k_fed_step_x4, dim3(akz_div_up(L.w, 256), akz_div_up(L.h, 4), n), dim3(256), 0,
-                                       s, src, S.Lflow[i], dst, L.w, L.h, fs, half_tau);
-                } else {
-                    hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, S.Lflow[i], dst, L.w,
-                                       L.h, fs, half_tau);
-                }
+                hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, S.Lflow[i], dst, L.w, L.h, fs,
+                                   half_tau);
                 AKZ_LAUNCH_CHECK();
                 src = dst;
             }
@@ -1767,14 +1599,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,          \
                        (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
 #define AKZ_D2P(SGV)                                                                                                 \
-    if (c->deriv_cfg == 1)                                                                                           \
-        hipLaunchKernelGGL((k_deriv_second_cand2<SGV, 26, 512>),                                                     \
-                           dim3(akz_div_up(L.w, 64), akz_div_up(L.h, 26), (n + 1) / 2), dim3(512), 0, s, S.Lxy[i],   \
-                           S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err);          \
-    else                                                                                                             \
-        hipLaunchKernelGGL((k_deriv_second_cand2<SGV, kDTH, 256>),                                                   \
-                           dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i], \
-                           S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+    hipLaunchKernelGGL((k_deriv_second_cand2<SGV, kDTH, 256>),                                                       \
+                       dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i],     \
+                       S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
             switch (L.deriv_sigma) {
             case 2: if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
