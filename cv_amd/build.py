@@ -40,7 +40,8 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, "lib", s.replace(".", "_") + ".o")
-        cmd = [hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        extra = os.environ.get("AKZ_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DKNN_ABLATE=1)
+        cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
