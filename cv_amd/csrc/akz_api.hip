@@ -252,6 +252,8 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_invk = cv.take<float>(B * 8);
     S.d_ncand = cv.take<uint32_t>(B * 32);
     S.d_cand = cv.take<uint2>(B * 32 * (size_t)c->max_cand);
+    S.d_cand_u = cv.take<float>(B * 32 * (size_t)c->max_cand * 10);   // CandU = 40 bytes
+    S.d_cand_nb = cv.take<float>(B * 32 * (size_t)c->max_cand * 8);
     const size_t K = c->max_kp;
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);
@@ -523,6 +525,7 @@ extern "C" int32_t akz_debug_get_level(akz_ctx* c, int32_t img, int32_t level, i
     if (!src && comp < 0) return AKZ_E_INVALID;
     // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
     if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
+    if (!c->keep_all && which == AKZ_BUF_LDET) return AKZ_E_INVALID;   // Ldet planes exist only for the parity taps
     AKZ_HIP(hipSetDevice(c->device));
     AKZ_TRY(sync_all(c));
     size_t px = c->plan.levels[level].pixels();
@@ -565,6 +568,10 @@ extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stag
     uint32_t m = n < cap ? n : cap;
     if (m && !out) return AKZ_E_INVALID;
     if (m) AKZ_HIP(hipMemcpy(out, src + (size_t)img * c->max_kp, sizeof(akz_keypoint) * m, hipMemcpyDeviceToHost));
+    // before refinement the angle field carries the candidate index (internal bookkeeping): the reference's
+    // keypoints have angle 0 at that stage (scale_space_extrema.rs:111)
+    if (stage == 0)
+        for (uint32_t i = 0; i < m; ++i) out[i].angle = 0.0f;
     return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
 }
 

@@ -31,6 +31,8 @@ struct AkzSet {
     float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
     // keypoint stage
     uint32_t* d_ncand = nullptr;           // [B][32] candidates per (frame, level)
+    void* d_cand_u = nullptr;              // [B][32][max_cand] CandU records in append order (akz_scale_space.hip)
+    float* d_cand_nb = nullptr;            // [B][32][max_cand][8] determinant values around each sorted candidate
     uint2* d_cand = nullptr;               // [B][32][max_cand] {x | y << 16, response bits}, raster-sorted per level
     DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
     uint32_t* d_ncache = nullptr;          // [B]

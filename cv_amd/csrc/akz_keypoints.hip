@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
                 // keypoint.point = p * ratio + 0.5 * (ratio - 1)  (:106-109)
                 const float kx = fx + half_off, ky = fy + half_off;
                 if (lane == 0) {
-                    DevKp kp = {kx, ky, resp, size, 0.0f, L.octave, (uint32_t)e};
+                    DevKp kp = {kx, ky, resp, size, __uint_as_float(cb + t - c_begin), L.octave, (uint32_t)e};   // angle <- index in level
                     ch[slot] = kp;
                     ActEntry w = {kx, ky, resp, (slot << 8) | (uint32_t)e};
                     act[ai] = w;
@@ -633,8 +633,10 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
         const float half_off = 0.5f * (ratio - 1.0f);
         const float fx = (float)(me.x & 0xFFFFu) * ratio, fy = (float)(me.x >> 16) * ratio;
         // keypoint.point = p * ratio + 0.5 * (ratio - 1)  (:106-109)
-        DevKp kp = {fx + half_off, fy + half_off, fabsf(__uint_as_float(me.y)), T.L[e].kp_size, 0.0f, T.L[e].octave,
-                    (uint32_t)e};
+        // the angle field is not computed yet: it carries the candidate's index inside its level, which is where
+        // the refinement finds the determinant values around the keypoint (k_refine overwrites it)
+        DevKp kp = {fx + half_off, fy + half_off, fabsf(__uint_as_float(me.y)), T.L[e].kp_size, __uint_as_float(i),
+                    T.L[e].octave, (uint32_t)e};
         ch[pos] = kp;
     }
 }
@@ -655,7 +657,8 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
                                                 const DevKp* __restrict__ in,
                                                 const uint32_t* __restrict__ n_in, uint32_t stride,
                                                 DevKp* __restrict__ out, uint32_t* __restrict__ flag,
-                                                uint32_t* __restrict__ err)
+                                                uint32_t* __restrict__ err, const float* __restrict__ cand_nb,
+                                                uint32_t max_cand)
 {
     __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112];
     const OriTables& c_ori = *ori_p;
@@ -677,14 +680,15 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
         ratio = ldexpf(1.0f, (int)kp.octave);
         int x = (int)sat_u32(roundf(kp.x / ratio));
         int y = (int)sat_u32(roundf(kp.y / ratio));
-        const float* D = Lp->Ldet + (size_t)frame * Lp->fs;
-        const int w = Lp->w;
-        // the suppression pass guarantees a >= 15 px margin (scale_space_extrema.rs:97-104)
-        x = clampi(x, 1, w - 2);
-        y = clampi(y, 1, Lp->h - 2);
-        const float* p = D + (size_t)y * w + x;
-        float x_i = p[0], x_p = p[1], x_m = p[-1], y_p = p[w], y_m = p[-w];
-        float x_p_y_p = p[w + 1], x_p_y_m = p[-w + 1], x_m_y_p = p[w - 1], x_m_y_m = p[-w - 1];
+        // Ldet around (x, y): the keypoint sits on the pixel of the candidate that occupies its cache slot, and the
+        // candidate list carries those nine values (k_deriv_second_cand*, k_cand_sort), so the Ldet planes are
+        // never read here.  kp.angle holds the candidate's index inside its level until it is overwritten below.
+        const uint32_t cidx = __float_as_uint(kp.angle);
+        const float4* nbp = reinterpret_cast<const float4*>(cand_nb + (((size_t)frame * 32 + kp.class_id) * max_cand + cidx) * 8);
+        const float4 n0 = nbp[0], n1 = nbp[1];
+        kp.angle = 0.0f;
+        float x_i = kp.response;   // Ldet at the pixel (> threshold > 0, so |v| = v)
+        float x_m_y_m = n0.x, y_m = n0.y, x_p_y_m = n0.z, x_m = n0.w, x_p = n1.x, x_m_y_p = n1.y, y_p = n1.z, x_p_y_p = n1.w;
         float d_x = 0.5f * (x_p - x_m);
         float d_y = 0.5f * (y_p - y_m);
         float d_xx = x_p + x_m - 2.0f * x_i;
@@ -1234,7 +1238,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A13 + A14
     const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
     hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, S.d_kp_a, S.d_n_a, c->max_kp, S.d_kp_b,
-                       S.d_flag_b, c->d_err);
+                       S.d_flag_b, c->d_err, (const float*)S.d_cand_nb, c->max_cand);
     AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_kp_b, (const akz_descriptor*)nullptr,
                        S.d_flag_b, S.d_n_a, c->max_kp, S.d_kp_c, (akz_descriptor*)nullptr, c->max_kp, S.d_n_c,

@@ -1041,6 +1041,16 @@ __global__ __launch_bounds__(256) void k_deriv_second(const float2* __restrict__
 // first, so each input pixel crosses the L1 once instead of eight times.  Candidates that also pass
 // the border test are appended to the frame's per-level list in arbitrary order; k_cand_sort restores
 // the reference's raster order afterwards.
+// A candidate as the determinant kernels append it (arbitrary order): position, response and the eight
+// determinant values around it, which is all do_subpixel_refinement (scale_space_extrema.rs:297-347) ever reads
+// of Ldet.  With them in the list the Ldet planes need not go to HBM at all (10 % of the scale space's traffic);
+// they are still written when the parity taps are on (AKZ_KEEP_ALL=1).
+struct CandU {
+    uint32_t xy;     // x | y << 16
+    float v;         // Ldet at the pixel
+    float nb[8];     // (x-1,y-1) (x,y-1) (x+1,y-1) (x-1,y) (x+1,y) (x-1,y+1) (x,y+1) (x+1,y+1)
+};
+
 struct CandParams {
     float thr;         // detector_threshold as f32
     float border;      // smax * sigma_size  (scale_space_extrema.rs:97-100)
@@ -1051,7 +1061,7 @@ struct CandParams {
 template <int SG>  // SG = deriv_sigma (2, 3 or 4); 0 = generic (direct global gathers)
 __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
                                                            int w, int h, size_t fs, int s, OffK k, float sigma_quat,
-                                                           CandParams cp, uint2* __restrict__ cand,
+                                                           CandParams cp, CandU* __restrict__ cand,
                                                            uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
 {
     constexpr int TW = 64, TH = 32, GW = TW + 2, GH = TH + 2;
@@ -1096,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
             float lxy = off_combine(k, pm.x, p0.x, pp.x) - off_combine(k, mm.x, m0.x, mp.x);
             float lyy = off_combine(k, pm.y, p0.y, pp.y) - off_combine(k, mm.y, m0.y, mp.y);
             v = (lxx * lyy - lxy * lxy) * sigma_quat;
-            if (p >= 1 && p <= TW && q >= 1 && q <= TH) Ldet[(size_t)frame * fs + (size_t)y * w + x] = v;
+            if (Ldet && p >= 1 && p <= TW && q >= 1 && q <= TH) Ldet[(size_t)frame * fs + (size_t)y * w + x] = v;
         }
         s_d[idx] = v;
     }
@@ -1119,10 +1129,13 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
         bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
         if (is_out) continue;
         uint32_t slot = atomicAdd(&ncand[(size_t)frame * 32 + cp.level], 1u);
-        if (slot < cp.cap)
-            cand[((size_t)frame * 32 + cp.level) * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
-        else
+        if (slot < cp.cap) {
+            CandU cu = {(uint32_t)x | ((uint32_t)y << 16), v,
+                        {c[-GW - 1], c[-GW], c[-GW + 1], c[-1], c[1], c[GW - 1], c[GW], c[GW + 1]}};
+            cand[((size_t)frame * 32 + cp.level) * cp.cap + slot] = cu;
+        } else {
             *err = 1u;
+        }
     }
 }
 
@@ -1135,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
 template <int SG, int TH, int NT>
 __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
                                                             int w, int h, size_t fs, int n, OffK k, float sigma_quat,
-                                                            CandParams cp, uint2* __restrict__ cand,
+                                                            CandParams cp, CandU* __restrict__ cand,
                                                             uint32_t* __restrict__ ncand, uint32_t* __restrict__ err)
 {
     constexpr int TW = 64;
@@ -1194,7 +1207,7 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
         }
         lds_write4<CG>(&s_d[q * CG], c, det[0], det[1], det[2], det[3]);
         const int x0 = tx0 - 4 + 4 * c, y = ty0 - 1 + q;
-        if (c >= 1 && c <= TW / 4 && q >= 1 && q <= TH && x0 < w && y < h) {
+        if (Ldet && c >= 1 && c <= TW / 4 && q >= 1 && q <= TH && x0 < w && y < h) {
             const size_t pix = (size_t)y * w + x0;
             *reinterpret_cast<float4*>(Ldet + (size_t)fa * fs + pix) = make_float4(det[0].x, det[1].x, det[2].x, det[3].x);
             if (has_b)
@@ -1239,10 +1252,19 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
             const int o = bit >> 1, f = bit & 1;
             const int x = x0 + o;
             if (x < 1 || x > w - 2) continue;
-            float v = z[4][f];                                // z[4 + o][f] without dynamic register indexing
-            v = o == 1 ? z[5][f] : v;
-            v = o == 2 ? z[6][f] : v;
-            v = o == 3 ? z[7][f] : v;
+            // rows of the 3x3 neighbourhood, columns 3 + o .. 5 + o, without dynamic register indexing
+            float r3[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float a = m[3 + j][f], b = z[3 + j][f], d = p[3 + j][f];
+                a = o == 1 ? m[4 + j][f] : a; b = o == 1 ? z[4 + j][f] : b; d = o == 1 ? p[4 + j][f] : d;
+                a = o == 2 ? m[5 + j][f] : a; b = o == 2 ? z[5 + j][f] : b; d = o == 2 ? p[5 + j][f] : d;
+                a = o == 3 ? m[6 + j][f] : a; b = o == 3 ? z[6 + j][f] : b; d = o == 3 ? p[6 + j][f] : d;
+                r3[0][j] = a;
+                r3[1][j] = b;
+                r3[2][j] = d;
+            }
+            const float v = r3[1][1];
             // border test (:96-104); a candidate failing it can neither push nor replace (:105)
             const float px = (float)x, py = (float)y;
             float left_x = roundf(px - cp.border) - 1.0f;
@@ -1253,33 +1275,38 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
             if (is_out) continue;
             const size_t list = (size_t)(f ? fb : fa) * 32 + cp.level;
             uint32_t slot = atomicAdd(&ncand[list], 1u);
-            if (slot < cp.cap)
-                cand[list * cp.cap + slot] = make_uint2((uint32_t)x | ((uint32_t)y << 16), __float_as_uint(v));
-            else
+            if (slot < cp.cap) {
+                CandU cu = {(uint32_t)x | ((uint32_t)y << 16), v,
+                            {r3[0][0], r3[0][1], r3[0][2], r3[1][0], r3[1][2], r3[2][0], r3[2][1], r3[2][2]}};
+                cand[list * cp.cap + slot] = cu;
+            } else {
                 *err = 1u;
+            }
         }
     }
 }
 
-// Restore raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
-// (y << 48 | x << 32 | response bits) in LDS; (x, y) is unique so the order is total.
-__global__ __launch_bounds__(1024) void k_cand_sort(uint2* __restrict__ cand, const uint32_t* __restrict__ ncand,
-                                                    uint32_t cap)
+// Raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
+// (y << 48 | x << 32 | slot) in LDS ((x, y) is unique, so the order is total), then a gather of the unsorted
+// records into the sorted position / response list and the sorted neighbourhood list.
+__global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ cand_u, const uint32_t* __restrict__ ncand,
+                                                    uint32_t cap, uint2* __restrict__ cand, float* __restrict__ cand_nb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
     const uint32_t level = blockIdx.x, frame = blockIdx.y;
     const uint32_t n = min(ncand[(size_t)frame * 32 + level], cap);
-    if (n < 2) return;
-    uint2* seg = cand + ((size_t)frame * 32 + level) * cap;
+    if (n == 0) return;
+    const size_t list = ((size_t)frame * 32 + level) * cap;
+    const CandU* seg = cand_u + list;
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
         unsigned long long kk = ~0ull;
         if (i < n) {
-            uint2 c = seg[i];
-            uint32_t yx = ((c.x >> 16) << 16) | (c.x & 0xFFFFu);  // y in the high half: raster order
-            kk = ((unsigned long long)yx << 32) | (unsigned long long)c.y;
+            const uint32_t xy = seg[i].xy;
+            const uint32_t yx = ((xy >> 16) << 16) | (xy & 0xFFFFu);  // y in the high half: raster order
+            kk = ((unsigned long long)yx << 32) | (unsigned long long)i;
         }
         key[i] = kk;
     }
@@ -1301,8 +1328,11 @@ __global__ __launch_bounds__(1024) void k_cand_sort(uint2* __restrict__ cand, co
         }
     }
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        unsigned long long kk = key[i];
-        seg[i] = make_uint2((uint32_t)(kk >> 32), (uint32_t)kk);
+        const CandU cu = seg[(uint32_t)key[i]];
+        cand[list + i] = make_uint2(cu.xy, __float_as_uint(cu.v));
+        float4* nb = reinterpret_cast<float4*>(cand_nb + (list + i) * 8);
+        nb[0] = make_float4(cu.nb[0], cu.nb[1], cu.nb[2], cu.nb[3]);
+        nb[1] = make_float4(cu.nb[4], cu.nb[5], cu.nb[6], cu.nb[7]);
     }
 }
 
@@ -1595,13 +1625,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             cp.level = (uint32_t)i;
             cp.cap = c->max_cand;
             dim3 grid2(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
+            float* ldet_out = c->keep_all ? S.Ldet[i] : nullptr;   // refinement reads the candidates' own 3x3 values
 #define AKZ_D2(SGV)                                                                                                  \
-    hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], S.Ldet[i], L.w, L.h, fs,          \
-                       (int)L.deriv_sigma, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+    hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], ldet_out, L.w, L.h, fs,          \
+                       (int)L.deriv_sigma, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err)
 #define AKZ_D2P(SGV)                                                                                                 \
     hipLaunchKernelGGL((k_deriv_second_cand2<SGV, kDTH, 256>),                                                       \
                        dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i],     \
-                       S.Ldet[i], L.w, L.h, fs, n, k, L.sigma_quat, cp, S.d_cand, S.d_ncand, c->d_err)
+                       ldet_out, L.w, L.h, fs, n, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
             switch (L.deriv_sigma) {
             case 2: if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
@@ -1617,8 +1648,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     {
         uint32_t np2 = 1;
         while (np2 < c->max_cand) np2 <<= 1;
-        hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * np2, s, S.d_cand,
-                           S.d_ncand, c->max_cand);
+        hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * np2, s, (const CandU*)S.d_cand_u,
+                           S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
         AKZ_LAUNCH_CHECK();
     }
     akz_timer_end(c, &c->t_ss, 0, (uint64_t)n);
