@@ -124,6 +124,30 @@ def test_ragged_sizes(gpu, oracle, shape):
     _compare_pyramid(akaze, oracle, img, 0.001, f"synth {w}x{h}")
 
 
+@pytest.mark.parametrize("name", ["constant", "checkerboard16", "noise_dense", "tiny", "gradient"])
+def test_pathological_inputs(gpu, oracle, name):
+    """Inputs the reference's tests do not have: no structure at all, a lattice full of exact ties, noise at the
+    dense threshold (21 091 candidates, 10 262 keypoints at 640x480 - exercises the capacity paths of the
+    parallel suppression), an image smaller than two tiles, a pure ramp.  Same keypoints, same descriptors."""
+    akaze, _ = gpu
+    rng = np.random.default_rng(1)
+    yy, xx = np.indices((480, 640))
+    img, thr = {
+        "constant": (np.full((240, 320), 128, np.uint8), 0.001),
+        "checkerboard16": ((((yy // 16) + (xx // 16)) % 2 * 255).astype(np.uint8), 0.001),
+        "noise_dense": (rng.integers(0, 256, (480, 640), dtype=np.uint8), 0.0001),
+        "tiny": (rng.integers(0, 256, (48, 64), dtype=np.uint8), 0.001),
+        "gradient": (np.tile(np.linspace(0, 255, 640).astype(np.uint8), (480, 1)), 0.0001),
+    }[name]
+    h, w = img.shape
+    ctx = akaze.Context(akaze.Akaze.new(thr), w, h, 1)
+    (kp, desc), = ctx.extract_batch([img])
+    okp, odesc = oracle.Akaze(w, h, oracle.default_config(threshold=thr)).extract(img)
+    _kp_eq(kp, okp, name)
+    _eq(desc, odesc, name + " desc")
+    ctx.close()
+
+
 def test_f32_input_path(gpu, oracle):
     akaze, _ = gpu
     img = oracle.u8_to_f32(synth_frame(320, 240, 11))
