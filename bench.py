@@ -141,14 +141,22 @@ def main():
     akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
     hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
 
-    kps = torch.zeros((NF, CAP, 28), dtype=torch.uint8, device=dev)
-    descs = torch.zeros((NF, CAP, 64), dtype=torch.uint8, device=dev)
-    counts = torch.zeros((NF,), dtype=torch.int32, device=dev)
+    # Every output exists twice and consecutive steps alternate between the two sets, so a step never has to
+    # wait for the previous step's matcher before its extraction may overwrite descriptors: the stages of
+    # neighbouring steps overlap exactly like the stages of neighbouring micro-batches inside a step.
+    def zeros2(shape, dtype):
+        return [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(2)]
+    kps2 = zeros2((NF, CAP, 28), torch.uint8)
+    descs2 = zeros2((NF, CAP, 64), torch.uint8)
+    counts2 = zeros2((NF,), torch.int32)
     # predecessor descriptor blocks: prev[j] = descriptors of global frame g-1 for local frame j
-    prev_descs = torch.zeros((NF, CAP, 64), dtype=torch.uint8, device=dev) if world > 1 else None
-    prev_counts = torch.zeros((NF,), dtype=torch.int32, device=dev) if world > 1 else None
-    pairs = torch.zeros((NF + 2, CAP, 2), dtype=torch.int32, device=dev)   # +2: a micro-batch can carry mb+1 pairs
-    npairs = torch.zeros((NF + 2,), dtype=torch.int32, device=dev)
+    prev_descs2 = zeros2((NF, CAP, 64), torch.uint8) if world > 1 else [None, None]
+    prev_counts2 = zeros2((NF,), torch.int32) if world > 1 else [None, None]
+    pairs2 = zeros2((NF + 2, CAP, 2), torch.int32)   # +2: a micro-batch can carry mb+1 pairs
+    npairs2 = zeros2((NF + 2,), torch.int32)
+    match_done = [torch.cuda.Event(), torch.cuda.Event()]   # the matcher finished reading output set p
+    step_no = [0]
+    host_trace = [] if os.environ.get("AKZ_BENCH_TRACE") else None   # (step, m0, ms in extract call, ms in match call)
     if world > 1:
         gath_d = torch.zeros((world, MB, CAP, 64), dtype=torch.uint8, device=dev)
         gath_n = torch.zeros((world, MB), dtype=torch.int32, device=dev)
@@ -164,12 +172,19 @@ def main():
 
     def step():
         cur = torch.cuda.current_stream()
-        if world > 1:
-            comm.wait_stream(cur)    # the previous step's matcher reads (cur waited for them) precede our writes
+        p = step_no[0] & 1
+        kps, descs, counts, pairs, npairs = kps2[p], descs2[p], counts2[p], pairs2[p], npairs2[p]
+        prev_descs, prev_counts = prev_descs2[p], prev_counts2[p]
+        if step_no[0] >= 2:          # set p was last read by the matcher two steps ago (long finished)
+            cur.wait_event(match_done[p])
+            if world > 1:
+                comm.wait_event(match_done[p])
         for m0 in range(0, NF, MB):
+            tA = time.perf_counter()
             _lib.check(L.akz_extract_batch_device(
                 ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps[m0:m0 + MB].data_ptr(),
                 descs[m0:m0 + MB].data_ptr(), CAP, counts[m0:m0 + MB].data_ptr(), cur.cuda_stream), "extract")
+            tB = time.perf_counter()
             js = [j for j in range(m0, m0 + MB) if j > 0]
             if m0 + MB == NF:
                 js.append(0)
@@ -186,10 +201,10 @@ def main():
                 matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib,
                 len(js), RULE_STRICT, 24, 0.0, 1, pairs[m0:].data_ptr(), npairs[m0:].data_ptr(), wait.cuda_stream),
                 "match")
-        cur.wait_stream(hm_stream)
-        cur.wait_stream(akz_stream)
-        if world > 1:
-            cur.wait_stream(comm)
+            if host_trace is not None:
+                host_trace.append((step_no[0], m0, round((tB - tA) * 1e3, 2), round((time.perf_counter() - tB) * 1e3, 2)))
+        match_done[p].record(hm_stream)
+        step_no[0] += 1
 
     def barrier():
         if world > 1:
@@ -208,6 +223,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    last = (step_no[0] - 1) & 1
+    kps, descs, counts, pairs, npairs = kps2[last], descs2[last], counts2[last], pairs2[last], npairs2[last]
     knn_ms, knn_launches = C.c_double(), C.c_uint64()
     _lib.check(L.hm_timing_get(matcher.handle, C.byref(knn_ms), C.byref(knn_launches), 1), "hm_timing_get")
     _lib.check(L.hm_timing_enable(matcher.handle, 0), "hm_timing_enable")
@@ -270,6 +287,8 @@ def main():
 
     n_kp = counts.float().mean().item()
     n_match = npairs[:NF].float().mean().item()
+    if rank == 0 and host_trace is not None:
+        print("host ms per call (step, m0, extract, match):", host_trace, file=sys.stderr)
     if rank == 0:
         total_frames = NF * world * args.steps
         fps = total_frames / elapsed

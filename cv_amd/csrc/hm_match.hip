@@ -376,11 +376,22 @@ struct hm_ctx {
     uint32_t* d_pairs = nullptr;
     uint32_t* d_npairs = nullptr;
     // problem descriptor ring (device) for batched calls
-    void* d_probs = nullptr;
-    void* h_probs = nullptr;   // pinned staging twin of d_probs
-    size_t probs_bytes = 0;
-    hipEvent_t ev_copy = nullptr;  // recorded after the last staging -> device descriptor copy
-    bool copy_pending = false;
+    // (a ring of kStageRing slots: a call waits only for the copies of the call that used its slot four calls
+    // ago, so the host can run several micro-batches ahead of the GPU; with a single slot every call waited
+    // for the previous call's copies, i.e. for the previous micro-batch's whole extraction)
+    struct StageSlot {
+        void* d = nullptr;
+        void* h = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+    };
+    static constexpr int kStageRing = 4;
+    StageSlot ring[kStageRing];
+    uint64_t ring_pos = 0;
+    StageSlot* slot = nullptr;     // the current call's slot
+    void* d_probs = nullptr;       // = slot->d
+    void* h_probs = nullptr;       // = slot->h, pinned staging twin
     // scratch knn results for batched device calls
     // MFMA path: +-1 recoded descriptor blocks
     uint32_t* d_exp = nullptr;
@@ -402,27 +413,34 @@ struct hm_ctx {
 // buffer is reused only after the previous copy has completed.
 static int32_t hm_ensure_probs(hm_ctx* c, size_t bytes)
 {
-    if (c->copy_pending) {
-        AKZ_HIP(hipEventSynchronize(c->ev_copy));
-        c->copy_pending = false;
+    hm_ctx::StageSlot& S = c->ring[c->ring_pos++ % hm_ctx::kStageRing];
+    c->slot = &S;
+    if (S.pending) {
+        AKZ_HIP(hipEventSynchronize(S.ev));
+        S.pending = false;
     }
-    if (bytes <= c->probs_bytes) return AKZ_OK;
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    if (c->d_probs) AKZ_HIP(hipFree(c->d_probs));
-    if (c->h_probs) AKZ_HIP(hipHostFree(c->h_probs));
-    c->d_probs = c->h_probs = nullptr;
-    size_t nb = akz_align_up(bytes * 2, 4096);
-    AKZ_HIP(hipMalloc(&c->d_probs, nb));
-    AKZ_HIP(hipHostMalloc(&c->h_probs, nb, hipHostMallocDefault));
-    c->probs_bytes = nb;
+    if (!S.ev) AKZ_HIP(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+    if (bytes > S.bytes) {
+        AKZ_HIP(hipStreamSynchronize(c->stream));   // kernels still reading the old device copy
+        if (S.d) AKZ_HIP(hipFree(S.d));
+        if (S.h) AKZ_HIP(hipHostFree(S.h));
+        S.d = S.h = nullptr;
+        S.bytes = 0;
+        size_t nb = akz_align_up(bytes * 2, 4096);
+        AKZ_HIP(hipMalloc(&S.d, nb));
+        AKZ_HIP(hipHostMalloc(&S.h, nb, hipHostMallocDefault));
+        S.bytes = nb;
+    }
+    c->d_probs = S.d;
+    c->h_probs = S.h;
     return AKZ_OK;
 }
 static int32_t hm_push_probs(hm_ctx* c, size_t off, const void* src, size_t bytes)
 {
     memcpy((char*)c->h_probs + off, src, bytes);
     AKZ_HIP(hipMemcpyAsync((char*)c->d_probs + off, (char*)c->h_probs + off, bytes, hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipEventRecord(c->ev_copy, c->stream));
-    c->copy_pending = true;
+    AKZ_HIP(hipEventRecord(c->slot->ev, c->stream));
+    c->slot->pending = true;
     return AKZ_OK;
 }
 
@@ -447,7 +465,6 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
         AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (pr && pr[0] == '1') ? prio_lo : 0));
     }
     AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-    AKZ_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     {
         const char* mf = getenv("AKZ_MATCH_MFMA");
         c->use_mfma = !(mf && mf[0] == '0');
@@ -475,9 +492,11 @@ extern "C" int32_t hm_destroy(hm_ctx* c)
     hipFree(c->d_rev);
     hipFree(c->d_pairs);
     hipFree(c->d_npairs);
-    hipFree(c->d_probs);
-    if (c->h_probs) hipHostFree(c->h_probs);
-    if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    for (auto& S : c->ring) {
+        if (S.d) hipFree(S.d);
+        if (S.h) hipHostFree(S.h);
+        if (S.ev) hipEventDestroy(S.ev);
+    }
     for (auto& pr : c->t_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->t_pool) hipEventDestroy(e);
     hipFree(c->d_exp);
