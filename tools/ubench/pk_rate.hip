@@ -1,5 +1,6 @@
-// Microbenchmark (result on MI355X: packed 75 T element-ops/s = the f32 vector peak, scalar 52):
+// Microbenchmark: unfused f32 multiply+add throughput, scalar (v_mul_f32 + v_add_f32) vs packed
 // (v_pk_mul_f32 + v_pk_add_f32), same number of element operations.  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// Result on MI355X: packed 75 T element-ops/s (= the f32 vector peak), scalar (-fno-slp-vectorize) 52.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float v2f __attribute__((ext_vector_type(2)));
