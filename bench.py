@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=128, help="frames per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU smoke test of the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
@@ -340,6 +341,8 @@ def main():
         out["device"] = device_probe(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, args.cpu_frames)
+            if args.cpu_procs > 0:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(frames, args.cpu_procs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -400,6 +403,34 @@ def cpu_baseline(frames, n):
             "host_cores_available": os.cpu_count(),
             "sample": f"first {n} frames of the bench batch: Akaze::default() extract + symmetric match vs previous "
                       f"frame, single thread, {dt:.1f} s, {nk // n} keypoints/frame"}
+
+
+def _cpu_worker(args):
+    """One frame pair on one core: extract both frames with the oracle, match them symmetrically."""
+    a, b = args
+    from oracle import oracle as O
+    orc = O.Akaze(W, H, O.default_config())
+    _, da = orc.extract(a)
+    _, db = orc.extract(b)
+    O.match(db, da, rule=O.RULE_STRICT, param_u=24, symmetric=True)
+    return len(da) + len(db)
+
+
+def cpu_baseline_all_cores(frames, procs):
+    """The same oracle on `procs` host cores at once (one process per frame pair, nothing shared): what the
+    reference's per-frame parallelism (cv-sfm processes frames independently) could reach on this host."""
+    import multiprocessing as mp
+    procs = max(1, min(procs, os.cpu_count() or 1, frames.shape[0] // 2))
+    host = frames[:2 * procs].cpu().numpy()
+    tasks = [(host[2 * i], host[2 * i + 1]) for i in range(procs)]
+    ctx = mp.get_context("spawn")            # the parent holds a HIP context: never fork it
+    with ctx.Pool(procs) as pool:
+        pool.map(_cpu_worker, tasks[:1])     # warm the workers' imports (oracle build check, page-in)
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, tasks, chunksize=1)
+        dt = time.perf_counter() - t0
+    return {"value": round(2 * procs / dt, 2), "unit": "frames/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} processes x 2 frames (extract both, one symmetric match), {dt:.1f} s"}
 
 
 if __name__ == "__main__":
