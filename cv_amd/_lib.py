@@ -77,6 +77,14 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m cv_amd.build` (hipcc, gfx950). "
             "cv_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP/HSA runtime.  A process must initialise only one: if libakz pulls in the
+    # system runtime first and torch is imported afterwards (or the other way round with the roles swapped), the
+    # second copy finds "no ROCm-capable device".  Importing torch first makes libakz resolve against the
+    # runtime that is already loaded, whatever order the caller uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
     L.akz_strerror.restype = C.c_char_p
