@@ -1240,8 +1240,10 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const float v = z[4 + o][f];
-                const float nb = fmaxf(fmaxf(fmaxf(m[3 + o][f], m[4 + o][f]), fmaxf(m[5 + o][f], z[3 + o][f])),
-                                       fmaxf(fmaxf(z[5 + o][f], p[3 + o][f]), fmaxf(p[4 + o][f], p[5 + o][f])));
+                // three-operand groups: four v_max3_f32 per pixel-frame
+                const float n0 = fmaxf(fmaxf(m[3 + o][f], m[4 + o][f]), m[5 + o][f]);
+                const float n1 = fmaxf(fmaxf(p[3 + o][f], p[4 + o][f]), p[5 + o][f]);
+                const float nb = fmaxf(fmaxf(n0, n1), fmaxf(z[3 + o][f], z[5 + o][f]));
                 hits |= (v > cp.thr && v > nb ? 1u : 0u) << (2 * o + f);
             }
         }
