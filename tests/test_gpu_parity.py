@@ -168,6 +168,49 @@ def test_batch_equals_single(gpu, oracle):
         _eq(res[i][1], odesc, f"batch frame {i} desc")
 
 
+def test_pipelined_device_calls_match_host_api(gpu):
+    """akz_extract_batch_device back to back without any synchronisation in between (two buffer sets, three
+    streams inside the library, an odd batch so the last frame pair is half empty): every call's outputs equal
+    what the blocking host-buffer API returns for the same frames, and a second pass reproduces them bit for
+    bit (size-independent properties at BASELINE's frame size: independence of frames, determinism)."""
+    import torch
+    akaze, _ = gpu
+    from cv_amd import _lib
+    L = _lib.lib()
+    W, H, B, CAP, NCALL = 1920, 1080, 3, 8192, 4
+    dev = torch.device("cuda", 0)
+    frames = [synth_frame(W, H, 900 + i, n_rect=150, n_disc=150) for i in range(B * NCALL)]
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    ak = akaze.Akaze.default()
+    ak.max_keypoints = CAP
+    ctx = akaze.Context(ak, W, H, B)
+    outs = []
+    for rep in range(2):
+        kps = torch.zeros((NCALL, B, CAP, 28), dtype=torch.uint8, device=dev)
+        descs = torch.zeros((NCALL, B, CAP, 64), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((NCALL, B), dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream()
+        for k in range(NCALL):
+            _lib.check(L.akz_extract_batch_device(ctx.handle, d_frames[k * B:(k + 1) * B].data_ptr(), 0, B, W, H,
+                                                  kps[k].data_ptr(), descs[k].data_ptr(), CAP, cnt[k].data_ptr(),
+                                                  cur.cuda_stream), "extract")
+        _lib.check(L.akz_sync(ctx.handle), "sync")
+        outs.append((kps.cpu().numpy(), descs.cpu().numpy(), cnt.cpu().numpy()))
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    ref = akaze.Context(ak, W, H, 1)
+    kps, descs, cnt = outs[0]
+    for k in range(NCALL):
+        for j in range(B):
+            (rkp, rdesc), = ref.extract_batch([frames[k * B + j]])
+            n = int(cnt[k, j])
+            assert n == len(rkp) and n > 1000, (k, j, n, len(rkp))
+            assert np.array_equal(descs[k, j, :n], rdesc)
+            assert kps[k, j, :n].tobytes() == rkp.tobytes()
+    ctx.close()
+    ref.close()
+
+
 def test_full_hd_frame(gpu, oracle):
     """One frame at BASELINE's full size (1920x1080, 16 levels, 166 FED steps)."""
     akaze, _ = gpu
