@@ -395,6 +395,30 @@ def test_bicubic_colour_sampling(gpu, oracle, kitti):
     assert len(kp) > 100 and (want[:len(kp)].max() > 0)
 
 
+def test_matcher_properties_at_full_size(gpu):
+    """BASELINE config 3 sizes (two 1080p frames, ~5 000 descriptors each), checked through properties that do
+    not need the oracle: every reported distance is the popcount of the XOR with the reported index, the first
+    neighbour is a true minimum with the lowest index among ties, and symmetric matching is symmetric."""
+    akaze, knn = gpu
+    ak = akaze.Akaze.default()
+    img = synth_frame(1920, 1080, 31, n_rect=200, n_disc=200)
+    a = ak.extract_arrays(img)[1]
+    b = ak.extract_arrays(np.ascontiguousarray(np.roll(img, (2, 3), axis=(0, 1))))[1]   # the same scene, shifted
+    assert len(a) > 3000 and len(b) > 3000
+    m = knn.Matcher(8192)
+    nn = m.knn(a, b, 3)
+    pop = np.unpackbits(a[:, None, :] ^ b[nn["index"].astype(np.int64)], axis=2).sum(axis=2)
+    assert np.array_equal(pop.astype(np.uint32), nn["distance"])
+    assert (np.diff(nn["distance"].astype(np.int64), axis=1) >= 0).all()
+    rows = np.random.default_rng(0).choice(len(a), 64, replace=False)        # exhaustive check on a sample
+    full = np.unpackbits(a[rows, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(full.min(axis=1).astype(np.uint32), nn["distance"][rows, 0])
+    assert np.array_equal(full.argmin(axis=1).astype(np.uint32), nn["index"][rows, 0])   # argmin = lowest index
+    ab = knn.symmetric_matching(a, b)
+    ba = knn.symmetric_matching(b, a)
+    assert len(ab) > 100 and sorted((x, y) for x, y in ab) == sorted((y, x) for x, y in ba)
+
+
 def test_matching_rules(gpu, oracle):
     _, knn = gpu
     rng = np.random.default_rng(22)
