@@ -419,6 +419,21 @@ def test_matcher_properties_at_full_size(gpu):
     assert len(ab) > 100 and sorted((x, y) for x, y in ab) == sorted((y, x) for x, y in ba)
 
 
+def test_valu_matcher_path(gpu, oracle, monkeypatch):
+    """AKZ_MATCH_MFMA=0: the xor/popcount kernel (kept as the reference implementation of the MFMA one)."""
+    _, knn = gpu
+    monkeypatch.setenv("AKZ_MATCH_MFMA", "0")
+    rng = np.random.default_rng(5)
+    m = knn.Matcher(4096)
+    q = _rand_desc(rng, 700); t = _rand_desc(rng, 1300)
+    t[rng.integers(0, 1300, 300)] = t[rng.integers(0, 1300, 300)]
+    got, want = m.knn2(q, t), oracle.knn2(q, t)
+    _eq(got["index"], want["index"], "valu knn idx")
+    _eq(got["distance"], want["distance"], "valu knn dist")
+    assert m.match(q, t).tolist() == oracle.match(q, t).tolist()
+    m.close()
+
+
 def test_matching_rules(gpu, oracle):
     _, knn = gpu
     rng = np.random.default_rng(22)
