@@ -849,7 +849,7 @@ struct FedTaus {
 // = a 64x64 window whose outer patch ring is the halo (valid region shrinks by one pixel per step, T <= 4),
 // so it produces a 56x56 tile.  Per step a thread needs only the neighbouring patches' facing edges:
 // left/right columns come from the adjacent lanes with DPP row shifts (a 16-lane DPP row is one patch row),
-// top/bottom rows go through a small double-buffered LDS exchange (one barrier per step).  Every flow is
+// top/bottom rows go through a 16 KB LDS exchange (two barriers per step).  Every flow is
 // evaluated once (the reference's Jacobi update needs each twice, as +flow for one pixel and -flow for the
 // other).  A flow across the image border is replaced by +0: L is never -0 (it starts from sums of
 // non-negative products and x + (-0) = x, (+0) - (+0) = +0), so adding or subtracting +0 leaves every value
