@@ -53,6 +53,8 @@ extern "C" {
     fn hm_create(device: i32, max_q: u32, max_t: u32, out: *mut *mut c_void) -> i32;
     fn hm_destroy(ctx: *mut c_void) -> i32;
     fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
+    fn hm_knn(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, k: u32,
+              out: *mut AkzNeighbor) -> i32;
 }
 
 /// `akaze::KeyPoint` (akaze/src/lib.rs:69-93).
@@ -200,17 +202,21 @@ impl<'a> space::Knn for Mi355xLinearKnn<'a> {
     type Point = BitArray<64>;
     type KnnIter = Vec<space::Neighbor<u32, usize>>;
     fn knn(&self, query: &BitArray<64>, num: usize) -> Self::KnnIter {
-        assert_eq!(num, 2, "the MI355X matcher implements knn(query, 2)");
+        // cv-sfm asks for 2 when matching frame pairs (lib.rs:3103) and 3 when registering a frame (lib.rs:1474)
+        assert!((1..=3).contains(&num), "the MI355X matcher implements knn(query, k) for k <= 3");
         let mut ctx: *mut c_void = ptr::null_mut();
         let n = self.targets.len() as u32;
         assert_eq!(unsafe { hm_create(0, 1, n.max(2), &mut ctx) }, 0);
-        let mut out = [AkzNeighbor { index: 0, distance: 0 }; 2];
+        let mut out = [AkzNeighbor { index: 0, distance: 0 }; 3];
         let st = unsafe {
-            hm_knn2(ctx, query.bytes() as *const [u8; 64], 1, self.targets.as_ptr() as *const [u8; 64], n, out.as_mut_ptr())
+            hm_knn(ctx, query.bytes() as *const [u8; 64], 1, self.targets.as_ptr() as *const [u8; 64], n, num as u32,
+                   out.as_mut_ptr())
         };
         unsafe { hm_destroy(ctx) };
         assert_eq!(st, 0);
-        out.iter().map(|o| space::Neighbor { index: o.index as usize, distance: o.distance }).collect()
+        // LinearKnn returns min(num, len) neighbours
+        out.iter().take(num.min(self.targets.len()))
+            .map(|o| space::Neighbor { index: o.index as usize, distance: o.distance }).collect()
     }
     fn nn(&self, query: &BitArray<64>) -> Option<space::Neighbor<u32, usize>> {
         self.knn(query, 2).into_iter().next()
