@@ -60,7 +60,8 @@ ABI_SYMBOLS = [
     "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
-    "hm_match_batch_device", "hm_sync", "hm_timing_enable", "hm_timing_get",
+    "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
+    "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
@@ -121,6 +122,9 @@ def lib():
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]
     L.hm_sync.argtypes = [vp]
+    L.hm_hash_bag.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    L.hm_hash_bag_device.argtypes = [vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
+    L.hm_hash_knn.argtypes = [vp, vp, vp, u32, u32, u32, vp, C.POINTER(u32)]
     L.hm_timing_enable.argtypes = [vp, i32]
     L.hm_timing_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i32]
     L.hm_stream.restype = vp

@@ -407,6 +407,9 @@ struct hm_ctx {
     akz_neighbor* d_brev = nullptr;
     size_t bscratch_elems = 0;
     hipEvent_t ev = nullptr;
+    // scratch of the host-buffer place-recognition calls (hm_hash_bag, hm_hash_knn)
+    void* d_lsh = nullptr;
+    size_t lsh_bytes = 0;
 };
 
 // Problem descriptors are built in pinned host memory and copied stream-ordered; the staging
@@ -502,6 +505,7 @@ extern "C" int32_t hm_destroy(hm_ctx* c)
     hipFree(c->d_exp);
     hipFree(c->d_bfwd);
     hipFree(c->d_brev);
+    hipFree(c->d_lsh);
     if (c->ev) hipEventDestroy(c->ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -794,5 +798,147 @@ extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void*
     hipLaunchKernelGGL(k_pairs, dim3(n_pairs), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f,
                        (int)symmetric);
     AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frame-level place recognition.  Replaces
+//   hasher.hash_bag(features)                      cv-sfm/src/lib.rs:672   (HammingHasher<64, 512>, :205,216)
+//   lsh_to_frame.knn_values(&lsh, search_num)      cv-sfm/src/lib.rs:622-624
+// hash_bag is the matcher's own workload with the codebook as the target set: k_knn_mfma<1> gives every feature
+// its nearest codeword (lowest index among equals), k_bag_bits ORs the word bits into the frame's hash.  The
+// hashing crate (hamming-lsh 0.3.2) is not vendored in the reference: parity unpinned, see oracle/lsh_oracle.c.
+
+// hash bit w of frame f <- some feature of f has nearest codeword w (bit w at byte w >> 3, position w & 7)
+__global__ __launch_bounds__(256) void k_bag_bits(const akz_neighbor* __restrict__ words, const uint32_t* __restrict__ counts,
+                                                  uint32_t cap, uint32_t hash_words, uint32_t* __restrict__ hash)
+{
+    const uint32_t f = blockIdx.y;
+    const uint32_t n = min(counts[f], cap);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = words[(size_t)f * cap + i].index;
+    atomicOr(&hash[(size_t)f * hash_words + (w >> 5)], 1u << (w & 31u));
+}
+
+static int32_t hash_bag_launch(hm_ctx* c, const uint4* d_descs, const uint32_t* d_counts, uint32_t cap, uint32_t n_frames,
+                               const uint4* d_codewords, uint32_t n_codewords, uint32_t* d_hash, akz_neighbor* d_words)
+{
+    // the codeword count has to be readable on the device like every other count: it rides in the staging slot
+    const size_t cnt_off = akz_align_up(knn_stage_bytes(n_frames), 256);
+    AKZ_TRY(hm_ensure_probs(c, cnt_off + 64));
+    AKZ_TRY(hm_push_probs(c, cnt_off, &n_codewords, sizeof(uint32_t)));
+    const uint32_t* d_ncw = reinterpret_cast<const uint32_t*>((char*)c->d_probs + cnt_off);
+    std::vector<HmProb> hp(n_frames);
+    for (uint32_t f = 0; f < n_frames; ++f)
+        hp[f] = HmProb{d_descs + (size_t)f * cap * 4, d_counts + f, cap, d_codewords, d_ncw, n_codewords,
+                       d_words + (size_t)f * cap};
+    AKZ_TRY(launch_knn2(c, hp.data(), n_frames, cap, 0, 1));
+    const uint32_t hash_words = n_codewords / 32u;
+    AKZ_HIP(hipMemsetAsync(d_hash, 0, sizeof(uint32_t) * (size_t)n_frames * hash_words, c->stream));
+    hipLaunchKernelGGL(k_bag_bits, dim3((cap + 255u) / 256u, n_frames), dim3(256), 0, c->stream, d_words, d_counts, cap,
+                       hash_words, d_hash);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_hash_bag_device(hm_ctx* c, const void* d_descs, const void* d_counts, uint32_t cap_per_img,
+                                      uint32_t n_frames, const void* d_codewords, uint32_t n_codewords, void* d_hash,
+                                      void* d_words, void* stream_to_wait)
+{
+    if (!c || !d_descs || !d_counts || !d_codewords || !d_hash || !d_words) return AKZ_E_INVALID;
+    if (n_codewords == 0 || (n_codewords & 31u) || n_codewords >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+    if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1)) || n_frames > 65535u) return AKZ_E_INVALID;
+    if (n_frames == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    if (stream_to_wait) {
+        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    }
+    return hash_bag_launch(c, (const uint4*)d_descs, (const uint32_t*)d_counts, cap_per_img, n_frames,
+                           (const uint4*)d_codewords, n_codewords, (uint32_t*)d_hash, (akz_neighbor*)d_words);
+}
+
+// grow-only device scratch of the host-buffer place-recognition calls
+static int32_t hm_lsh_scratch(hm_ctx* c, size_t bytes)
+{
+    if (bytes <= c->lsh_bytes) return AKZ_OK;
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_lsh) AKZ_HIP(hipFree(c->d_lsh));
+    c->d_lsh = nullptr;
+    c->lsh_bytes = 0;
+    AKZ_HIP(hipMalloc(&c->d_lsh, bytes));
+    c->lsh_bytes = bytes;
+    return AKZ_OK;
+}
+
+extern "C" int32_t hm_hash_bag(hm_ctx* c, const akz_descriptor* feats, uint32_t n, const akz_descriptor* codewords,
+                               uint32_t n_codewords, uint8_t* hash, akz_neighbor* words)
+{
+    if (!c || (n && !feats) || !codewords || !hash) return AKZ_E_INVALID;
+    if (n_codewords == 0 || (n_codewords & 31u)) return AKZ_E_INVALID;
+    if (n > c->max_q || n_codewords > c->max_t) return AKZ_E_TOO_LARGE;
+    AKZ_HIP(hipSetDevice(c->device));
+    const uint32_t cap = n ? n : 1u;
+    const size_t hash_off = akz_align_up(sizeof(akz_neighbor) * (size_t)cap, 256);
+    AKZ_TRY(hm_lsh_scratch(c, hash_off + n_codewords / 8));
+    akz_neighbor* d_words = reinterpret_cast<akz_neighbor*>(c->d_lsh);
+    uint32_t* d_hash = reinterpret_cast<uint32_t*>((char*)c->d_lsh + hash_off);
+    AKZ_HIP(hipMemcpyAsync(c->d_na, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (n) AKZ_HIP(hipMemcpyAsync(c->d_a, feats, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, codewords, (size_t)n_codewords * 64, hipMemcpyHostToDevice, c->stream));
+    AKZ_TRY(hash_bag_launch(c, c->d_a, c->d_na, cap, 1, c->d_b, n_codewords, d_hash, d_words));
+    AKZ_HIP(hipMemcpyAsync(hash, d_hash, n_codewords / 8, hipMemcpyDeviceToHost, c->stream));
+    if (words && n)
+        AKZ_HIP(hipMemcpyAsync(words, d_words, sizeof(akz_neighbor) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    return AKZ_OK;
+}
+
+// Hamming distance of one query hash to every stored hash: one wave per stored hash (512-byte hashes are one
+// 8-byte load per lane), wave reduction.
+__global__ __launch_bounds__(256) void k_hash_dist(const uint32_t* __restrict__ q, const uint32_t* __restrict__ hashes,
+                                                   uint32_t n, uint32_t words, uint32_t* __restrict__ dist)
+{
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= n) return;
+    const uint32_t* h = hashes + (size_t)i * words;
+    uint32_t acc = 0;
+    for (uint32_t w = lane; w < words; w += 64u) acc += (uint32_t)__popc(q[w] ^ h[w]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) dist[i] = acc;
+}
+
+// The k stored hashes nearest to `query` in (distance, index) order — the exact answer where the reference
+// asks an approximate index (HggLite::knn_values).  Distances on the device, the k-selection over n (one entry
+// per stored frame) on the host.
+extern "C" int32_t hm_hash_knn(hm_ctx* c, const uint8_t* query, const uint8_t* hashes, uint32_t n, uint32_t hash_bytes,
+                               uint32_t k, akz_neighbor* out, uint32_t* n_out)
+{
+    if (!c || !query || (n && !hashes) || !n_out || (k && !out)) return AKZ_E_INVALID;
+    if (hash_bytes == 0 || (hash_bytes & 3u)) return AKZ_E_INVALID;
+    *n_out = 0;
+    if (n == 0 || k == 0) return AKZ_OK;
+    AKZ_HIP(hipSetDevice(c->device));
+    const uint32_t words = hash_bytes / 4u;
+    const size_t q_off = akz_align_up((size_t)n * hash_bytes, 256), d_off = q_off + akz_align_up(hash_bytes, 256);
+    AKZ_TRY(hm_lsh_scratch(c, d_off + sizeof(uint32_t) * (size_t)n));
+    uint32_t* d_h = reinterpret_cast<uint32_t*>(c->d_lsh);
+    uint32_t* d_q = reinterpret_cast<uint32_t*>((char*)c->d_lsh + q_off);
+    uint32_t* d_d = reinterpret_cast<uint32_t*>((char*)c->d_lsh + d_off);
+    AKZ_HIP(hipMemcpyAsync(d_h, hashes, (size_t)n * hash_bytes, hipMemcpyHostToDevice, c->stream));
+    AKZ_HIP(hipMemcpyAsync(d_q, query, hash_bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_hash_dist, dim3((n + 3u) / 4u), dim3(256), 0, c->stream, d_q, d_h, n, words, d_d);
+    AKZ_LAUNCH_CHECK();
+    std::vector<uint32_t> dist(n);
+    AKZ_HIP(hipMemcpyAsync(dist.data(), d_d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    AKZ_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> keys(n);
+    for (uint32_t i = 0; i < n; ++i) keys[i] = ((uint64_t)dist[i] << 32) | i;
+    const uint32_t m = k < n ? k : n;
+    std::partial_sort(keys.begin(), keys.begin() + m, keys.end());
+    for (uint32_t i = 0; i < m; ++i) out[i] = akz_neighbor{(uint32_t)keys[i], (uint32_t)(keys[i] >> 32)};
+    *n_out = m;
     return AKZ_OK;
 }

@@ -213,6 +213,25 @@ int32_t hm_match_batch_device(hm_ctx* ctx, const void* d_a, const void* d_na, co
                               float param_f, int32_t symmetric, void* d_pairs, void* d_n_out,
                               void* stream_to_wait);
 int32_t hm_sync(hm_ctx* ctx);
+
+/* ---- frame-level place recognition ----
+ * HammingHasher<64, 512>::hash_bag (cv-sfm/src/lib.rs:672; hasher built from the 4096-word codebook at :216):
+ * every feature sets the hash bit of its nearest codeword (lowest index among equal distances), bit w at byte
+ * w >> 3, position w & 7.  hash = n_codewords / 8 bytes (n_codewords a multiple of 32); words[i] (optional) =
+ * {nearest codeword, distance} of feature i.  The hashing crate (hamming-lsh 0.3.2) is not vendored in the
+ * reference: parity unpinned (oracle/lsh_oracle.c). */
+int32_t hm_hash_bag(hm_ctx* ctx, const akz_descriptor* feats, uint32_t n, const akz_descriptor* codewords,
+                    uint32_t n_codewords, uint8_t* hash, akz_neighbor* words);
+/* Batched device-resident form: frame f = d_descs block f ([cap_per_img][64]) with count d_counts[f];
+ * d_codewords [n_codewords][64]; d_hash [n_frames][n_codewords / 8]; d_words [n_frames][cap_per_img] of
+ * akz_neighbor, required: it is the pass's intermediate.  Stream-ordered after stream_to_wait on hm_stream(). */
+int32_t hm_hash_bag_device(hm_ctx* ctx, const void* d_descs, const void* d_counts, uint32_t cap_per_img,
+                           uint32_t n_frames, const void* d_codewords, uint32_t n_codewords, void* d_hash,
+                           void* d_words, void* stream_to_wait);
+/* lsh_to_frame.knn_values(&lsh, k) (cv-sfm/src/lib.rs:622-624) as an exact search: the min(k, n) stored hashes
+ * nearest to `query`, ascending (distance, index); hash_bytes a multiple of 4 (512 in cv-sfm). */
+int32_t hm_hash_knn(hm_ctx* ctx, const uint8_t* query, const uint8_t* hashes, uint32_t n, uint32_t hash_bytes,
+                    uint32_t k, akz_neighbor* out, uint32_t* n_out);
 /* Optional timing of the k-NN kernel launches with HIP events on hm_stream() (bench.py's matcher roofline):
  * hm_timing_get waits for the pending events and returns the accumulated milliseconds / launch count. */
 int32_t hm_timing_enable(hm_ctx* ctx, int32_t on);

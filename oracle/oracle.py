@@ -50,7 +50,8 @@ BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6,
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "color_oracle.c", "lsh_oracle.c",
+                                        "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -120,6 +121,9 @@ def lib():
         L.orc_w2c_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_p3p_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hash_bag.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_hash_knn.restype = C.c_uint32
+        L.orc_hash_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_pm_atan2f_v.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_pm_sincosf_v.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         _lib = L
@@ -313,6 +317,27 @@ def knn(q, t, k):
     if lib().orc_knn(q.ctypes.data, len(q), t.ctypes.data, len(t), k, out.ctypes.data) != 0:
         raise ValueError("k must be >= 1")
     return out
+
+
+def hash_bag(features, codewords):
+    """HammingHasher::hash_bag (lsh_oracle.c): (hash [len(codewords) / 8] u8, words [n] (index, distance))."""
+    f = np.ascontiguousarray(features, np.uint8).reshape(-1, 64)
+    cw = np.ascontiguousarray(codewords, np.uint8).reshape(-1, 64)
+    h = np.empty(len(cw) // 8, np.uint8)
+    words = np.empty(len(f), NB_DTYPE)
+    if lib().orc_hash_bag(f.ctypes.data, len(f), cw.ctypes.data, len(cw), h.ctypes.data, words.ctypes.data) != 0:
+        raise ValueError("the codeword count must be a positive multiple of 32")
+    return h, words
+
+
+def hash_knn(query, hashes, k):
+    """The k stored hashes nearest to `query`, ascending (distance, index)."""
+    hs = np.ascontiguousarray(hashes, np.uint8)
+    q = np.ascontiguousarray(query, np.uint8).reshape(-1)
+    hs = hs.reshape(-1, len(q))
+    out = np.empty(max(k, 1), NB_DTYPE)
+    m = lib().orc_hash_knn(q.ctypes.data, hs.ctypes.data, len(hs), len(q), k, out.ctypes.data)
+    return out[:m].copy()
 
 
 RULE_STRICT, RULE_BETTER_BY, RULE_LOWE = 0, 1, 2

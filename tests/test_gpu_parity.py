@@ -375,6 +375,77 @@ def test_knn_views_device(gpu, oracle):
         _eq(got[j, :nq, :, 1].astype(np.uint32), want["distance"], f"view {v} dist")
 
 
+def test_place_recognition_hash_and_search(gpu, oracle, kitti_golden):
+    """hm_hash_bag / hm_hash_bag_device / hm_hash_knn == oracle/lsh_oracle.c (cv-sfm/src/lib.rs:672, :622-624):
+    nearest-codeword bag hash over a 4096-word codebook with duplicate words (tie -> lowest index), an empty
+    bag, the batched device-resident form on ragged frames, and the exact nearest-hash search with ties."""
+    import ctypes as C
+    import torch
+    _, knn = gpu
+    from cv_amd import _lib, lsh
+    rng = np.random.default_rng(2024)
+    cw = _rand_desc(rng, 4096)
+    cw[100] = cw[7]
+    cw[4095] = cw[7]
+    hasher = lsh.HammingHasher.new_with_codewords(cw)
+    assert hasher.hash_bytes == 512
+    feats = _rand_desc(rng, 1500)
+    feats[:40] = cw[rng.integers(0, 4096, 40)]          # exact hits, some on the duplicated word
+    feats[40] = cw[7]
+    h, words = hasher.hash_bag(feats, return_words=True)
+    want_h, want_w = oracle.hash_bag(feats, cw)
+    _eq(words["index"], want_w["index"], "word index")
+    _eq(words["distance"], want_w["distance"], "word distance")
+    _eq(h, want_h, "hash")
+    assert words["index"][40] == 7
+    _eq(hasher.hash_bag(np.zeros((0, 64), np.uint8)), np.zeros(512, np.uint8), "empty bag")
+    # real descriptors
+    for name in ("default_desc0", "default_desc14"):
+        _eq(hasher.hash_bag(kitti_golden[name]), oracle.hash_bag(kitti_golden[name], cw)[0], name + " hash")
+    # batched, device-resident, ragged
+    cap, nf = 700, 5
+    counts = np.array([700, 0, 1, 333, 64], np.int32)
+    blocks = np.zeros((nf, cap, 64), np.uint8)
+    for f in range(nf):
+        blocks[f, :counts[f]] = _rand_desc(rng, int(counts[f]))
+        blocks[f, counts[f]:] = 0xA5                      # garbage past the count must not vote
+    dev = torch.device("cuda", 0)
+    d_blocks = torch.from_numpy(blocks).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_cw = torch.from_numpy(cw).to(dev)
+    d_hash = torch.full((nf, 512), 0xFF, dtype=torch.uint8, device=dev)
+    d_words = torch.zeros((nf, cap, 2), dtype=torch.int32, device=dev)
+    m = knn.Matcher(4096)
+    L = _lib.lib()
+    for _ in range(2):                                    # the second call reuses the staging ring
+        _lib.check(L.hm_hash_bag_device(m.handle, d_blocks.data_ptr(), d_counts.data_ptr(), cap, nf, d_cw.data_ptr(), 4096,
+                                        d_hash.data_ptr(), d_words.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "hash_bag_device")
+    _lib.check(L.hm_sync(m.handle), "hm_sync")
+    got_h, got_w = d_hash.cpu().numpy(), d_words.cpu().numpy()
+    hashes = []
+    for f in range(nf):
+        wh, ww = oracle.hash_bag(blocks[f, :counts[f]], cw)
+        _eq(got_h[f], wh, f"frame {f} hash")
+        _eq(got_w[f, :counts[f], 0].astype(np.uint32), ww["index"], f"frame {f} words")
+        hashes.append(wh)
+    assert not got_h[1].any()
+    # frame search: exact (distance, insertion order)
+    index = lsh.HashIndex(512)
+    store = [rng.integers(0, 256, 512, dtype=np.uint8) for _ in range(300)] + hashes
+    store[17] = store[5].copy()
+    for i, hsh in enumerate(store):
+        index.insert(hsh, f"frame{i}")
+    for qi, k in ((5, 10), (302, 512), (0, 1)):
+        got = index.knn_values(store[qi], k)
+        want = oracle.hash_knn(store[qi], np.stack(store), k)
+        assert len(got) == len(want) == min(k, len(store))
+        _eq(np.array([g[0][0] for g in got], np.uint32), want["index"], "hash knn index")
+        _eq(np.array([g[0][1] for g in got], np.uint32), want["distance"], "hash knn distance")
+        assert got[0][1] == f"frame{want['index'][0]}"
+    assert [g[0][0] for g in index.knn_values(store[5], 2)] == [5, 17]
+
+
 def test_bicubic_colour_sampling(gpu, oracle, kitti):
     """akz_sample_colors_rgb8 == oracle restatement of cv-sfm/src/bicubic.rs on real keypoints plus positions on
     and across the image border (default colour)."""
