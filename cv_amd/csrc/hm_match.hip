@@ -155,11 +155,19 @@ constexpr int kMfmaBlock = 512;   // 8 waves x 32 queries
 template <int K>
 __device__ __forceinline__ void topk_insert(int (&l)[K], int v)
 {
+    if constexpr (K == 2) {
+        // l[0] <= l[1]: the new second is the median of (l0, l1, v) — one v_med3_i32 and one v_min_i32
+        int m;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(l[0]), "v"(l[1]), "v"(v));
+        l[0] = min(l[0], v);
+        l[1] = m;
+    } else {
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const int lo = min(l[i], v);
-        v = max(l[i], v);
-        l[i] = lo;
+        for (int i = 0; i < K; ++i) {
+            const int lo = min(l[i], v);
+            v = max(l[i], v);
+            l[i] = lo;
+        }
     }
 }
 
@@ -297,6 +305,173 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma(const HmProbX* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FP4 form of the same contraction.  +1 / -1 are exact E2M1 values (0x2 / 0xA), so the block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (E8M0 0x7F) computes the same integer dot products in f32
+// (|sum| <= 512, exact), at twice the K per instruction and half the bytes per descriptor: 8 MFMAs and 8 KB of
+// LDS fragments per 32 x 32 tile instead of 16 and 16 KB.  The accumulators start at 1.5 * 2^23, where one ulp is
+// 1: the f32 bit pattern is 0x4B400000 + nacc, and the key's `<< 21` drops the constant (its lowest set bit is
+// bit 22), so knn_keys takes the raw bits unchanged.  (tools/ubench/fp4_probe.hip checks both facts on the GPU.)
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+
+// descriptor bits -> E2M1 nibbles (bit b -> nibble b: 1 -> 0x2 = +1.0, 0 -> 0xA = -1.0), 256 B per descriptor
+__global__ __launch_bounds__(256) void k_expand4(const HmExpandJob* __restrict__ jobs)
+{
+    const HmExpandJob J = jobs[blockIdx.y];
+    const uint32_t n = min(*J.count, J.cap);
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;  // one thread per (descriptor, 32-bit word)
+    const uint32_t d = t >> 4, wd = t & 15u;
+    if (d >= n) return;
+    const uint32_t bits = J.src[(size_t)d * 16 + wd];
+    uint4 o;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t b = (bits >> (8 * g)) & 0xFFu;
+        // spread 8 bits to 8 nibbles (bit i -> bit 4 i)
+        uint32_t sp = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sp |= (b & (1u << i)) << (3 * i);
+        ow[g] = 0xAAAAAAAAu ^ (sp << 3);                 // set bit -> clear the sign: 0xA -> 0x2
+    }
+    reinterpret_cast<uint4*>(J.dst + (size_t)d * 64)[wd] = o;
+}
+
+// The 8 chained MFMAs of tile `tp` into `out`, interleaved with the key epilogue of the PREVIOUS tile's accumulators
+// (`prev`, always a full tile): a dependent MFMA issues every ~32 cycles, the seven or so VALU instructions of the
+// epilogue that fit in between are independent of it, so the matrix pipe and the VALU of one wave overlap.
+template <int KNN, bool EPI>
+__device__ __forceinline__ void knn_chain4(const uint4* __restrict__ tp, const v4i32 (&qb)[8], const v16f32& bias,
+                                           v16f32& out, const v16f32& prev, uint32_t tprev, uint32_t half, int (&k)[KNN])
+{
+    uint4 f[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = tp[2 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 av = f[i & 3];
+        const v8i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+        const v8i32 b = {qb[i][0], qb[i][1], qb[i][2], qb[i][3], 0, 0, 0, 0};
+        if (i + 4 < 8) f[i & 3] = tp[2 * (i + 4)];
+        // the chain starts from the resident bias block (D != C): no per-tile accumulator initialisation
+        if (i == 0) out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, bias, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        else out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, out, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    if (EPI) knn_keys<false, KNN>(__builtin_bit_cast(v16i32, prev), tprev, half, 0u, k);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, KNN == 3 ? 12 : 7, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+}
+
+// k_knn_mfma on the E2M1 recoding: same block shape (8 waves x 32 queries), same staging scheme (one 16-byte
+// load per thread and tile), same key arithmetic; the tile loop is software-pipelined by one tile (two
+// accumulator sets, loop unrolled by two so they never move).
+template <int KNN>
+__global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma4(const HmProbX* __restrict__ probs)
+{
+    constexpr int RS = 17;                               // 16 chunks per descriptor, padded
+    __shared__ uint4 s_t[2][32 * RS];
+    uint32_t bx, by;
+    {
+        const uint32_t nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+        by = t / gridDim.x;
+        bx = t - by * gridDim.x;
+    }
+    const HmProbX P = probs[by];
+    const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t qblk = bx * 256u;
+    if (qblk >= nq) return;
+    const uint32_t q0 = qblk + wv * 32u;
+    const bool wave_on = q0 < nq;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    int k[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) k[i] = 0x7FFFFFFF;
+    if (nt > 0) {
+        // B fragments: query (q0 + col), nibbles [64 j + 32 half, +32) of its 512 -> 8 x 16 bytes, resident, negated
+        v4i32 qb[8];
+        {
+            const uint32_t qi = min(q0 + col, nq - 1u);
+            const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 64) + half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qb[i] = qp[2 * i] ^ (int)0x88888888;
+        }
+        const uint4* tg = reinterpret_cast<const uint4*>(P.t);  // 16 uint4 per descriptor
+        const uint32_t srow = threadIdx.x >> 4, scol = threadIdx.x & 15u;
+        const uint4* tlane = &s_t[0][col * RS + half];
+        uint4 st = tg[(size_t)min(srow, nt - 1u) * 16 + scol];
+        s_t[0][srow * RS + scol] = st;
+        // 1.5 * 2^23 in sixteen registers that stay put (opaque to the compiler, or it re-creates them per tile)
+        v16f32 bias;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias[i] = 12582912.0f;
+        asm volatile("" : "+v"(bias));
+        v16f32 acc0 = bias, acc1 = bias;
+        // one pipeline step: tile at t0 (in buffer `buf`) -> `out`, epilogue of `prev` (tile t0 - 32)
+        uint32_t t0 = 0;
+        int buf = 0;
+        bool more;
+#define HM_STEP(EPI, out, prev)                                                                                  \
+        __syncthreads();                                                                                         \
+        more = t0 + 32u < nt;                                                                                    \
+        if (more) st = tg[(size_t)min(t0 + 32u + srow, nt - 1u) * 16 + scol];                                    \
+        if (wave_on) knn_chain4<KNN, EPI>(tlane + buf * (32 * RS), qb, bias, out, prev, t0 - 32u, half, k);      \
+        if (more) s_t[buf ^ 1][srow * RS + scol] = st;                                                           \
+        buf ^= 1;
+        // the last tile's keys (the only tile that can be partial) are taken where its accumulator set is known
+#define HM_LAST(acc)                                                                                             \
+        if (wave_on) {                                                                                           \
+            const v16i32 nacc = __builtin_bit_cast(v16i32, acc);                                                 \
+            if (t0 + 32u <= nt) knn_keys<false, KNN>(nacc, t0, half, nt, k);                                     \
+            else knn_keys<true, KNN>(nacc, t0, half, nt, k);                                                     \
+        }
+        HM_STEP(false, acc0, acc1)
+        if (!more) {
+            HM_LAST(acc0)
+        } else {
+            for (;;) {
+                t0 += 32u;
+                HM_STEP(true, acc1, acc0)
+                if (!more) {
+                    HM_LAST(acc1)
+                    break;
+                }
+                t0 += 32u;
+                HM_STEP(true, acc0, acc1)
+                if (!more) {
+                    HM_LAST(acc0)
+                    break;
+                }
+            }
+        }
+#undef HM_LAST
+#undef HM_STEP
+    }
+    if (!wave_on) return;
+    int o[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) o[i] = __shfl_xor(k[i], 32);
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) topk_insert<KNN>(k, o[i]);
+    const uint32_t qi = q0 + col;
+    if (half == 0 && qi < nq) {
+#pragma unroll
+        for (int i = 0; i < KNN; ++i) {
+            const uint32_t m = k[i] == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)k[i] + (512u << 21);
+            akz_neighbor nb = {m & ((1u << kIdxBits) - 1u), m >> kIdxBits};
+            P.out[(size_t)qi * KNN + i] = nb;
+        }
+    }
+}
+
 struct HmPairProb {
     const akz_neighbor* fwd;  // [na][2]  a -> b
     const akz_neighbor* rev;  // [nb][2]  b -> a (symmetric only)
@@ -397,6 +572,7 @@ struct hm_ctx {
     uint32_t* d_exp = nullptr;
     size_t exp_words = 0;
     bool use_mfma = true;
+    bool use_fp4 = true;           // E2M1 recoding + v_mfma_scale_f32_32x32x64_f8f6f4 (AKZ_MATCH_FP4=0: int8 MFMA)
     // optional timing of the k-NN launches (HIP events on the matcher stream), for bench.py's MFMA roofline
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pending;
@@ -471,6 +647,8 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
     {
         const char* mf = getenv("AKZ_MATCH_MFMA");
         c->use_mfma = !(mf && mf[0] == '0');
+        const char* f4 = getenv("AKZ_MATCH_FP4");
+        c->use_fp4 = !(f4 && f4[0] == '0');
     }
     AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
     AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
@@ -537,12 +715,13 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     std::vector<size_t> job_off;   // word offset of each job's output inside d_exp
     std::vector<HmProbX> px(n_probs);
     size_t words = 0;
+    const size_t ew = c->use_fp4 ? 64 : 128;   // words of recoded descriptor
     auto expanded = [&](const uint4* src, const uint32_t* cnt, uint32_t cap) -> size_t {
         for (size_t i = 0; i < jobs.size(); ++i)
             if (jobs[i].src == (const uint32_t*)src) return job_off[i];
         jobs.push_back(HmExpandJob{(const uint32_t*)src, cnt, cap, nullptr});
         job_off.push_back(words);
-        words += (size_t)cap * 128;
+        words += (size_t)cap * ew;
         return job_off.back();
     };
     std::vector<size_t> qoff(n_probs), toff(n_probs);
@@ -567,8 +746,12 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     const size_t jobs_off = probs_off + akz_align_up(sizeof(HmProbX) * n_probs, 64);
     AKZ_TRY(hm_push_probs(c, probs_off, px.data(), sizeof(HmProbX) * n_probs));
     AKZ_TRY(hm_push_probs(c, jobs_off, jobs.data(), sizeof(HmExpandJob) * jobs.size()));
-    hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
-                       reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
+    if (c->use_fp4)
+        hipLaunchKernelGGL(k_expand4, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
+                           reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
+    else
+        hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
+                           reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
     AKZ_LAUNCH_CHECK();
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing) {
@@ -585,10 +768,18 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     {
         dim3 grid((max_nq + 255) / 256, n_probs);
         const HmProbX* dp = reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off);
-        switch (knn) {
-        case 1: hipLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-        case 3: hipLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-        default: hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+        if (c->use_fp4) {
+            switch (knn) {
+            case 1: hipLaunchKernelGGL(k_knn_mfma4<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            case 3: hipLaunchKernelGGL(k_knn_mfma4<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            default: hipLaunchKernelGGL(k_knn_mfma4<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            }
+        } else {
+            switch (knn) {
+            case 1: hipLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            case 3: hipLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            default: hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            }
         }
     }
     if (ev0 && ev1) {
