@@ -34,6 +34,7 @@ CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_f
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FED_BYTES_PER_PIXEL_STEP = 12.0
 MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
+MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4/FP6 MFMA (MI355X_MICROARCH.md; AMD's 20 PF headline is 2:1 sparse)
 
 
 def make_world(seed, w, h):
@@ -324,12 +325,18 @@ def main():
             pairs_total = NF * args.steps
             macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
             tops = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
+            fp4 = os.environ.get("AKZ_MATCH_FP4", "1") != "0"
+            peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
             out["roofline_matcher"] = {
-                "bound": "mfma", "kernel": "k_knn_mfma<2> (v_mfma_i32_32x32x32_i8)", "achieved": round(tops, 1),
-                "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
+                "bound": "mfma",
+                "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)" if fp4
+                          else "k_knn_mfma<2> (v_mfma_i32_32x32x32_i8)",
+                "achieved": round(tops, 1), "peak": peak, "unit": "TOP/s", "frac": round(tops / peak, 4),
                 "launches": int(knn_launches.value),
                 "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
-                "note": "ops = 2 x 512 int8 MACs per (query, target) pair with the mean keypoint count; peak = the "
+                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count; peak = the dense "
+                        "FP4 MFMA figure of MI355X_MICROARCH.md (~10 PF; micro-benchmark ceiling 9.1 PF)" if fp4 else
+                        "ops = 2 x 512 int8 MACs per (query, target) pair with the mean keypoint count; peak = the "
                         "int8 micro-benchmark ceiling of MI355X_MICROARCH.md (no spec figure is listed for dense I8)"}
         rf = out["roofline"]
         if rf["traffic"] and rf["avg_launch_us"]:
