@@ -1166,15 +1166,20 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
     const float2* Da = Lxy + (size_t)fa * fs;
     const float2* Db = Lxy + (size_t)fb * fs;
     if (tx0 >= 8 && tx0 + TW + 8 <= w) {
-        // item = (row, pixel pair j): one 16-byte load per frame, one 16-byte chunk per plane
-        for (int idx = tid; idx < RS * (CS / 2); idx += NT) {
-            int r = idx / (CS / 2), j = idx - r * (CS / 2);
+        // item = (row, 4-pixel group g): two 16-byte loads per frame, one 16-byte chunk per plane and tile —
+        // consecutive lanes store consecutive chunks of a plane (a pixel-pair item alternates between the planes
+        // and its stores collide on the banks)
+        for (int idx = tid; idx < RS * (CS / 4); idx += NT) {
+            int r = idx / (CS / 4), g = idx - r * (CS / 4);
             int cy = clampi(ty0 - 1 - SG + r, 0, h - 1);
-            size_t o = (size_t)cy * w + (tx0 - 8 + 2 * j);
-            float4 a = *reinterpret_cast<const float4*>(Da + o), b = *reinterpret_cast<const float4*>(Db + o);
-            const int chunk = r * (CS / 2) + (j >> 1) + ((j & 1) ? CS / 4 : 0);
-            reinterpret_cast<float4*>(s_x)[chunk] = make_float4(a.x, b.x, a.z, b.z);
-            reinterpret_cast<float4*>(s_y)[chunk] = make_float4(a.y, b.y, a.w, b.w);
+            size_t o = (size_t)cy * w + (tx0 - 8 + 4 * g);
+            float4 a0 = *reinterpret_cast<const float4*>(Da + o), a1 = *reinterpret_cast<const float4*>(Da + o + 2);
+            float4 b0 = *reinterpret_cast<const float4*>(Db + o), b1 = *reinterpret_cast<const float4*>(Db + o + 2);
+            const int chunk = r * (CS / 2) + g;
+            reinterpret_cast<float4*>(s_x)[chunk] = make_float4(a0.x, b0.x, a0.z, b0.z);
+            reinterpret_cast<float4*>(s_x)[chunk + CS / 4] = make_float4(a1.x, b1.x, a1.z, b1.z);
+            reinterpret_cast<float4*>(s_y)[chunk] = make_float4(a0.y, b0.y, a0.w, b0.w);
+            reinterpret_cast<float4*>(s_y)[chunk + CS / 4] = make_float4(a1.y, b1.y, a1.w, b1.w);
         }
     } else {
         for (int idx = tid; idx < RS * CS; idx += NT) {
