@@ -306,7 +306,7 @@ def main():
                                    "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
                        "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
                        "mean_matches_per_pair": round(n_match, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_fed_pair<T> (calculate_step, two frames per block, up to 4 steps per launch)",
+            "roofline": {"bound": "hbm", "kernel": "k_fed_pair<T> (calculate_step, two frames per block, up to 8 steps per launch)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(MB),
                          "launches": int(fed_launches),
@@ -342,7 +342,7 @@ def main():
         if rf["traffic"] and rf["avg_launch_us"]:
             # what the memory system actually moved (PMC) over the same launch time: the number to hold against
             # the 8 TB/s peak; `achieved` above counts the contract's 12 B per pixel-step and exceeds the peak
-            # because up to 4 steps share one pass over HBM
+            # because up to 8 steps share one pass over HBM
             rf["hbm_side_gbs"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
             rf["hbm_side_frac"] = round(rf["hbm_side_gbs"] / HBM_PEAK_GBS, 4)
         out["device"] = device_probe(torch, dev)

@@ -160,7 +160,7 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
     const char* dts = getenv("AKZ_DESC_TILE_SHIFT");
     if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
     const char* fb = getenv("AKZ_FED_BLOCK");
-    if (fb && fb[0] >= '1' && fb[0] <= '4') c->fed_block = fb[0] - '0';
+    if (fb && fb[0] >= '1' && fb[0] <= '8' && !fb[1]) c->fed_block = fb[0] - '0';
     const char* pipe = getenv("AKZ_PIPELINE");
     c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
     if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);

@@ -62,7 +62,7 @@ struct akz_ctx {
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
     uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
     int desc_tile_shift = 5;  // log2 of the tile edge of the descriptor visiting order; env AKZ_DESC_TILE_SHIFT
-    int fed_block = 4;        // FED steps fused per launch (1 = one launch per step); env AKZ_FED_BLOCK
+    int fed_block = 8;        // most FED steps fused per launch (1 = one launch per step; the first octave stops at 4); env AKZ_FED_BLOCK
     bool front_pair = true;   // two-frame packed front kernel (AKZ_FRONT_PAIR=0 selects the one-frame kernel)
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
 

@@ -838,23 +838,27 @@ __global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src,
     dst[base] = v;
 }
 
-// up to four half-tau values of one temporally blocked launch
+// the half-tau values of one temporally blocked launch (up to 8 steps)
 struct FedTaus {
-    float half_tau[4];
+    float half_tau[8];
 };
 
 // ---------------------------------------------------------------------------------------------
 // calculate_step for two frames per block with the image held in REGISTERS across the T steps of a launch.
 // A thread owns a 4x4 pixel patch of both frames ({a, b} pairs, packed arithmetic); a block is 16x16 patches
-// = a 64x64 window whose outer patch ring is the halo (valid region shrinks by one pixel per step, T <= 4),
-// so it produces a 56x56 tile.  Per step a thread needs only the neighbouring patches' facing edges:
+// = a 64x64 window whose outer patch ring(s) are the halo: the valid region shrinks by one pixel per step, so one
+// ring (56x56 tile) serves T <= 4 and two rings (48x48) T <= 8 — on the smaller octaves, which run 4 to 29 steps
+// per level, halving the launches and the passes over memory outweighs the smaller useful tile.  Per step a thread needs only the neighbouring patches' facing edges:
 // left/right columns come from the adjacent lanes with DPP row shifts (a 16-lane DPP row is one patch row),
 // top/bottom rows go through a 16 KB LDS exchange (two barriers per step).  Every flow is
 // evaluated once (the reference's Jacobi update needs each twice, as +flow for one pixel and -flow for the
 // other).  A flow across the image border is replaced by +0: L is never -0 (it starts from sums of
 // non-negative products and x + (-0) = x, (+0) - (+0) = +0), so adding or subtracting +0 leaves every value
 // bit-identical to skipping the term as nonlinear_diffusion.rs:31-52 does.
-constexpr int kFedU = 56;   // output tile edge of k_fed_pair
+// Output tile edge of k_fed_pair<T>: the 64 x 64 window minus a halo of whole 4-pixel patches that covers the T
+// pixels a launch invalidates on every side (one patch up to 4 steps, two up to 8).
+constexpr int fed_halo_patches(int T) { return (T + 3) / 4; }
+constexpr int fed_tile_edge(int T) { return 64 - 8 * fed_halo_patches(T); }
 
 __device__ __forceinline__ v2f fed_flow2(v2f ht, v2f ca, v2f cb, v2f a, v2f b) { return (ht * (ca + cb)) * (b - a); }
 
@@ -878,7 +882,8 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
     const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
-    const int x0 = (int)tile.x * kFedU - 4 + 4 * pc, y0 = (int)tile.y * kFedU - 4 + 4 * pr;
+    constexpr int HP = fed_halo_patches(T), U = fed_tile_edge(T);
+    const int x0 = (int)tile.x * U - 4 * HP + 4 * pc, y0 = (int)tile.y * U - 4 * HP + 4 * pr;
     const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
     v2f L[4][4], C[4][4];
 #pragma unroll
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
         }
         if (t + 1 < T) __syncthreads();   // single exchange buffer: every reader is done before the next step's writes
     }
-    if (pc >= 1 && pc <= 14 && pr >= 1 && pr <= 14 && col_in) {
+    if (pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int y = y0 + r;
@@ -1525,7 +1530,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             float* bufA = S.Lt[i];
             float* bufB = S.tmp;
             const bool blocked = (L.w & 3) == 0 && c->fed_block > 1 && c->front_pair;   // k_fed_pair
-            const int nwrites = blocked ? (nsteps + c->fed_block - 1) / c->fed_block : nsteps;  // FED launches
+            // steps per launch: the first octave's levels have 3-4 steps; deeper octaves run more steps on smaller
+            // images, where fewer, longer launches win over the smaller useful tile
+            // (measured, 256 x 1080p: 4 / 5 / 6 / 8 steps per launch below the first octave -> 5186 / 5216 / 5259 /
+            // 5299 frames/s; a three-patch halo for up to 12 steps loses again)
+            const int fed_block = L.octave == 0 ? (c->fed_block < 4 ? c->fed_block : 4) : c->fed_block;
+            const int nwrites = blocked ? (nsteps + fed_block - 1) / fed_block : nsteps;  // FED launches
             const float* init;
             if (L.new_octave) {
                 const AkzLevel& Lp = P.levels[i - 1];
@@ -1576,7 +1586,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 // chosen per GROUP so that the last group lands in Lt[i]
                 std::vector<int> groups;
                 for (int left = nsteps; left > 0;) {
-                    int ngr = (left + c->fed_block - 1) / c->fed_block;  // groups still to emit
+                    int ngr = (left + fed_block - 1) / fed_block;  // groups still to emit
                     int g = (left + ngr - 1) / ngr;                      // balanced sizes, e.g. 5 -> 3+2
                     groups.push_back(g);
                     left -= g;
@@ -1586,14 +1596,17 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 for (int gi = 0; gi < ng; ++gi) {
                     float* dstb = ((ng - 1 - gi) % 2 == 0) ? bufA : bufB;
                     FedTaus ft;
-                    for (int q = 0; q < 4; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
-                    dim3 gridp(akz_div_up(L.w, kFedU), akz_div_up(L.h, kFedU), (n + 1) / 2);
+                    for (int q = 0; q < 8; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
+#define AKZ_FED_CASE(TT)                                                                                              \
+    case TT: {                                                                                                        \
+        dim3 gridp(akz_div_up(L.w, fed_tile_edge(TT)), akz_div_up(L.h, fed_tile_edge(TT)), (n + 1) / 2);              \
+        hipLaunchKernelGGL((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
+    } break;
                     switch (groups[gi]) {
-                    case 1: hipLaunchKernelGGL((k_fed_pair<1>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                    case 2: hipLaunchKernelGGL((k_fed_pair<2>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                    case 3: hipLaunchKernelGGL((k_fed_pair<3>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
-                    default: hipLaunchKernelGGL((k_fed_pair<4>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft); break;
+                        AKZ_FED_CASE(1) AKZ_FED_CASE(2) AKZ_FED_CASE(3) AKZ_FED_CASE(4)
+                        AKZ_FED_CASE(5) AKZ_FED_CASE(6) AKZ_FED_CASE(7) AKZ_FED_CASE(8)
                     }
+#undef AKZ_FED_CASE
                     AKZ_LAUNCH_CHECK();
                     j += groups[gi];
                     src = dstb;
