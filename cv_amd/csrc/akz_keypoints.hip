@@ -15,6 +15,10 @@
 // order; the suppression cache is processed strictly sequentially per frame (parallel across the
 // frames of the batch and, inside a frame, across the cache entries tested for one candidate);
 // list compactions preserve order; the response sort is (response desc, index asc).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "akz_ctx.h"
 #include "../../include/akz_portable_math.h"
 
@@ -382,7 +386,23 @@ struct OriTables {
     float gw[109];                 // GAUSS25[id[j+6]][id[i+6]]
     float ang1[48];                // window starts: f32 accumulation of 0.15 (scale_space_extrema.rs:259-287)
     int n_win;
+    // Which windows contain an angle depends only on where the angle falls among the windows' end points (plus 0
+    // and 2 pi): bnd[] holds those values sorted (padded with +inf), m_open[r] the membership bits (bit = window)
+    // of every angle strictly between bnd[r-1] and bnd[r], m_eq[r] those of the angle bnd[r] itself.  Built on
+    // the host with ori_window_contains, the predicate the summation used to evaluate per (window, sample).
+    float bnd[128];
+    uint2 m_open[128], m_eq[128];
 };
+
+// scale_space_extrema.rs:261-287: is `ang` inside the window that starts at ang1 (width pi/3, wrapping at 2 pi)
+__host__ __device__ __forceinline__ bool ori_window_contains(float ang1, float ang)
+{
+    const float PI_F = 3.14159274101257324219f;
+    const float ang2 = (ang1 + PI_F / 3.0f > 2.0f * PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+    const bool plain = ang1 < ang2, wrap = ang2 < ang1;
+    return (plain && ang1 < ang && ang < ang2) ||
+           (wrap && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * PI_F)));
+}
 
 __device__ __forceinline__ float fast_atan2_equiv(float y, float x)
 {
@@ -660,8 +680,17 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
                                                 uint32_t* __restrict__ err, const float* __restrict__ cand_nb,
                                                 uint32_t max_cand)
 {
-    __shared__ float s_rx[4][112], s_ry[4][112], s_ang[4][112];
+    __shared__ float s_rx[4][112], s_ry[4][112];
+    __shared__ uint32_t s_msk[4][112][2];   // per sample: the windows that contain its angle (bit = window)
+    __shared__ float s_bnd[128];
+    __shared__ uint2 s_mopen[128], s_meq[128];
     const OriTables& c_ori = *ori_p;
+    if (threadIdx.x < 128) {
+        s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
+        s_mopen[threadIdx.x] = c_ori.m_open[threadIdx.x];
+        s_meq[threadIdx.x] = c_ori.m_eq[threadIdx.x];
+    }
+    __syncthreads();
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -730,23 +759,29 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
             float ry = g * dxy.y;
             s_rx[wv][idx] = rx;
             s_ry[wv][idx] = ry;
-            s_ang[wv][idx] = fast_atan2_equiv(ry, rx);
+            // Window membership of this sample (:261-287) from the end-point table: the summation below (windows
+            // across the lanes, samples in order) then needs one bit test per sample instead of the predicate.
+            const float ang = fast_atan2_equiv(ry, rx);
+            // r = number of end points below ang (branch-free binary search over the padded table)
+            int r = 0;
+#pragma unroll
+            for (int step = 64; step > 0; step >>= 1) r += s_bnd[r + step - 1] < ang ? step : 0;
+            const uint2 mm = (r < 128 && s_bnd[r & 127] == ang) ? s_meq[r & 127] : s_mopen[r & 127];
+            const uint32_t mlo = mm.x, mhi = mm.y;
+            s_msk[wv][idx][0] = mlo;
+            s_msk[wv][idx][1] = mhi;
         }
     }
     __syncthreads();
     if (active && keep) {
         float val = -1.0f, sum_x = 0.0f, sum_y = 0.0f;
         if (lane < c_ori.n_win) {
-            float ang1 = c_ori.ang1[lane];
-            float ang2 = (ang1 + PI_F / 3.0f > 2.0f * PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
             // branch-free: a sample outside the window adds +0.0, which leaves the sums bit-identical to skipping
             // it (they start at +0 and x + (+0) = x for every x but -0, which a sum that started at +0 never is)
-            const bool plain = ang1 < ang2, wrap = ang2 < ang1;
+            const int word = lane >> 5, bit = lane & 31;
 #pragma unroll 4
             for (int k = 0; k < 109; ++k) {
-                const float ang = s_ang[wv][k];
-                const bool in = (plain && ang1 < ang && ang < ang2) ||
-                                (wrap && ((ang > 0.0f && ang < ang2) || (ang > ang1 && ang < 2.0f * PI_F)));
+                const bool in = (s_msk[wv][k][word] >> bit) & 1u;
                 sum_x += in ? s_rx[wv][k] : 0.0f;
                 sum_y += in ? s_ry[wv][k] : 0.0f;
             }
@@ -1144,6 +1179,42 @@ int32_t akz_upload_tables(akz_ctx* c)
         }
         if (nw >= 48) return AKZ_E_INTERNAL;
         ot.n_win = nw;
+        // end points of every window, 0 and 2 pi, sorted and distinct
+        std::vector<float> b = {0.0f, 2.0f * PI_F};
+        for (int wd = 0; wd < nw; ++wd) {
+            volatile float a1 = ot.ang1[wd];
+            volatile float a2 = (a1 + PI_F / 3.0f > 2.0f * PI_F) ? a1 - 5.0f * PI_F / 3.0f : a1 + PI_F / 3.0f;
+            b.push_back((float)a1);
+            b.push_back((float)a2);
+        }
+        std::sort(b.begin(), b.end());
+        b.erase(std::unique(b.begin(), b.end()), b.end());
+        const int nb = (int)b.size();
+        if (nb > 127) return AKZ_E_INTERNAL;
+        auto mask_of = [&](float ang) {
+            uint64_t m = 0;
+            for (int wd = 0; wd < nw; ++wd) m |= (uint64_t)(ori_window_contains(ot.ang1[wd], ang) ? 1 : 0) << wd;
+            return make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+        };
+        for (int r = 0; r < 128; ++r) {
+            ot.bnd[r] = r < nb ? b[r] : INFINITY;
+            ot.m_eq[r] = r < nb ? mask_of(b[r]) : make_uint2(0u, 0u);
+            // any angle strictly between b[r-1] and b[r] (membership is constant there): the float above b[r-1],
+            // or one below b[0]; above the last end point (>= 2 pi) nothing is a member
+            float probe = r == 0 ? -1.0f : (r <= nb ? nextafterf(b[r - 1], INFINITY) : INFINITY);
+            ot.m_open[r] = (r <= nb && !(r < nb && probe >= b[r])) ? mask_of(probe) : make_uint2(0u, 0u);
+        }
+        // self-check of the table against the predicate at every end point and the floats next to it
+        auto lookup = [&](float ang) {
+            int r = 0;
+            for (int step = 64; step > 0; step >>= 1) r += ot.bnd[r + step - 1] < ang ? step : 0;
+            return (r < 128 && ot.bnd[r & 127] == ang) ? ot.m_eq[r & 127] : ot.m_open[r & 127];
+        };
+        for (int r = 0; r < nb; ++r)
+            for (float ang : {nextafterf(b[r], -INFINITY), b[r], nextafterf(b[r], INFINITY)}) {
+                const uint2 want = mask_of(ang), got = lookup(ang);
+                if (want.x != got.x || want.y != got.y) return AKZ_E_INTERNAL;
+            }
     }
     AKZ_HIP(hipMemcpy(c->d_ori, &ot, sizeof(ot), hipMemcpyHostToDevice));
 
