@@ -287,3 +287,64 @@ inline std::vector<std::array<std::size_t, 2>> match_descriptors(Matcher& m, con
 }
 
 }  // namespace space
+
+// hamming_lsh::HammingHasher<64, H> and the lsh_to_frame map of cv-sfm (cv-sfm/src/lib.rs:205-217, 672, 622-624) over
+// hm_hash_bag / hm_hash_knn.  The hashing crate is not vendored in the reference: see oracle/lsh_oracle.c for what
+// is restated (nearest-codeword bag hash, one bit per codeword).
+namespace hamming_lsh {
+
+class HammingHasher {
+public:
+    // new_with_codewords: codewords.size() = 8 x hash bytes (4096 for cv-sfm's BitArray<512>)
+    HammingHasher(std::vector<akaze::BitArray64> codewords, space::Matcher& m) : cw_(std::move(codewords)), m_(m)
+    {
+        if (cw_.empty() || cw_.size() % 32) throw std::invalid_argument("codeword count must be a multiple of 32");
+    }
+    std::size_t hash_bytes() const { return cw_.size() / 8; }
+    // hash_bag(features) -> BitArray<H> as bytes
+    std::vector<uint8_t> hash_bag(const std::vector<akaze::BitArray64>& features) const
+    {
+        std::vector<uint8_t> h(hash_bytes());
+        akaze::check(hm_hash_bag(m_.handle(), reinterpret_cast<const akz_descriptor*>(features.data()),
+                                 (uint32_t)features.size(), reinterpret_cast<const akz_descriptor*>(cw_.data()),
+                                 (uint32_t)cw_.size(), h.data(), nullptr),
+                     "hm_hash_bag");
+        return h;
+    }
+
+private:
+    std::vector<akaze::BitArray64> cw_;
+    space::Matcher& m_;
+};
+
+// insert(hash, value) / knn_values(hash, num): exact nearest hashes in (distance, insertion order)
+template <typename V>
+class HashIndex {
+public:
+    HashIndex(std::size_t hash_bytes, space::Matcher& m) : hb_(hash_bytes), m_(m) {}
+    void insert(const std::vector<uint8_t>& hash, V value)
+    {
+        if (hash.size() != hb_) throw std::invalid_argument("hash size");
+        store_.insert(store_.end(), hash.begin(), hash.end());
+        values_.push_back(std::move(value));
+    }
+    std::vector<std::pair<space::Neighbor, V>> knn_values(const std::vector<uint8_t>& hash, std::size_t num) const
+    {
+        std::vector<akz_neighbor> out(num ? num : 1);
+        uint32_t n = 0;
+        akaze::check(hm_hash_knn(m_.handle(), hash.data(), store_.data(), (uint32_t)values_.size(), (uint32_t)hb_,
+                                 (uint32_t)num, out.data(), &n),
+                     "hm_hash_knn");
+        std::vector<std::pair<space::Neighbor, V>> r;
+        for (uint32_t i = 0; i < n; ++i) r.push_back({space::Neighbor{out[i].index, out[i].distance}, values_[out[i].index]});
+        return r;
+    }
+
+private:
+    std::size_t hb_;
+    space::Matcher& m_;
+    std::vector<uint8_t> store_;
+    std::vector<V> values_;
+};
+
+}  // namespace hamming_lsh

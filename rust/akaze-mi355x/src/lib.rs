@@ -55,6 +55,10 @@ extern "C" {
     fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
     fn hm_knn(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, k: u32,
               out: *mut AkzNeighbor) -> i32;
+    fn hm_hash_bag(ctx: *mut c_void, feats: *const [u8; 64], n: u32, codewords: *const [u8; 64], n_codewords: u32,
+                   hash: *mut u8, words: *mut AkzNeighbor) -> i32;
+    fn hm_hash_knn(ctx: *mut c_void, query: *const u8, hashes: *const u8, n: u32, hash_bytes: u32, k: u32,
+                   out: *mut AkzNeighbor, n_out: *mut u32) -> i32;
 }
 
 /// `akaze::KeyPoint` (akaze/src/lib.rs:69-93).
@@ -221,4 +225,48 @@ impl<'a> space::Knn for Mi355xLinearKnn<'a> {
     fn nn(&self, query: &BitArray<64>) -> Option<space::Neighbor<u32, usize>> {
         self.knn(query, 2).into_iter().next()
     }
+}
+
+/// `hamming_lsh::HammingHasher<64, 512>` as cv-sfm uses it (cv-sfm/src/lib.rs:205,216,672): a bag of descriptors
+/// -> 512-byte hash over a 4096-word codebook, on the MI355X.  (hamming-lsh is not vendored in the reference; the
+/// nearest-codeword form restated in oracle/lsh_oracle.c is what runs here.)
+pub struct Mi355xHammingHasher {
+    codewords: Vec<BitArray<64>>,
+}
+impl Mi355xHammingHasher {
+    pub fn new_with_codewords(codewords: Vec<BitArray<64>>) -> Self {
+        assert_eq!(codewords.len(), 512 * 8);
+        Self { codewords }
+    }
+    pub fn hash_bag<'a>(&self, features: impl IntoIterator<Item = &'a BitArray<64>>) -> BitArray<512> {
+        let feats: Vec<BitArray<64>> = features.into_iter().cloned().collect();
+        let mut ctx: *mut c_void = ptr::null_mut();
+        let cap = (feats.len() as u32).max(self.codewords.len() as u32);
+        assert_eq!(unsafe { hm_create(0, cap, cap, &mut ctx) }, 0);
+        let mut hash = [0u8; 512];
+        let st = unsafe {
+            hm_hash_bag(ctx, feats.as_ptr() as *const [u8; 64], feats.len() as u32,
+                        self.codewords.as_ptr() as *const [u8; 64], self.codewords.len() as u32, hash.as_mut_ptr(),
+                        ptr::null_mut())
+        };
+        unsafe { hm_destroy(ctx) };
+        assert_eq!(st, 0);
+        BitArray::new(hash)
+    }
+}
+
+/// `lsh_to_frame.knn_values(&lsh, num)` (cv-sfm/src/lib.rs:622-624) as an exact search over the stored hashes:
+/// (index into `hashes`, distance), ascending (distance, index).
+pub fn nearest_hashes(query: &BitArray<512>, hashes: &[BitArray<512>], num: usize) -> Vec<(usize, u32)> {
+    let mut ctx: *mut c_void = ptr::null_mut();
+    assert_eq!(unsafe { hm_create(0, 2, 2, &mut ctx) }, 0);
+    let mut out = vec![AkzNeighbor { index: 0, distance: 0 }; num.max(1)];
+    let mut n: u32 = 0;
+    let st = unsafe {
+        hm_hash_knn(ctx, query.bytes().as_ptr(), hashes.as_ptr() as *const u8, hashes.len() as u32, 512, num as u32,
+                    out.as_mut_ptr(), &mut n)
+    };
+    unsafe { hm_destroy(ctx) };
+    assert_eq!(st, 0);
+    out.iter().take(n as usize).map(|o| (o.index as usize, o.distance)).collect()
 }
