@@ -490,18 +490,26 @@ def test_matcher_properties_at_full_size(gpu):
     assert len(ab) > 100 and sorted((x, y) for x, y in ab) == sorted((y, x) for x, y in ba)
 
 
-def test_valu_matcher_path(gpu, oracle, monkeypatch):
-    """AKZ_MATCH_MFMA=0: the xor/popcount kernel (kept as the reference implementation of the MFMA one)."""
+@pytest.mark.parametrize("switch", ["AKZ_MATCH_MFMA", "AKZ_MATCH_FP4"])
+def test_alternative_matcher_kernels(gpu, oracle, monkeypatch, switch):
+    """AKZ_MATCH_MFMA=0: the xor/popcount kernel (the reference implementation of the MFMA ones, k = 2);
+    AKZ_MATCH_FP4=0: the int8 MFMA kernel (k = 1..3).  The default is the FP4 MFMA kernel, which every other
+    matcher test exercises."""
     _, knn = gpu
-    monkeypatch.setenv("AKZ_MATCH_MFMA", "0")
+    monkeypatch.setenv(switch, "0")
     rng = np.random.default_rng(5)
     m = knn.Matcher(4096)
     q = _rand_desc(rng, 700); t = _rand_desc(rng, 1300)
     t[rng.integers(0, 1300, 300)] = t[rng.integers(0, 1300, 300)]
     got, want = m.knn2(q, t), oracle.knn2(q, t)
-    _eq(got["index"], want["index"], "valu knn idx")
-    _eq(got["distance"], want["distance"], "valu knn dist")
+    _eq(got["index"], want["index"], switch + " knn idx")
+    _eq(got["distance"], want["distance"], switch + " knn dist")
     assert m.match(q, t).tolist() == oracle.match(q, t).tolist()
+    if switch == "AKZ_MATCH_FP4":
+        for k in (1, 3):
+            got, want = m.knn(q, t[:1001], k), oracle.knn(q, t[:1001], k)
+            _eq(got["index"], want["index"], f"int8 knn{k} idx")
+            _eq(got["distance"], want["distance"], f"int8 knn{k} dist")
     m.close()
 
 
