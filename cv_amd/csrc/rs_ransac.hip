@@ -166,10 +166,18 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
             }
     }
     akz_rm_jacobi4(design, V, 1, kEpsRes, kItersRes);
-    int best = 0;
-    for (int i = 1; i < 4; ++i)
-        if (fabs(design[i * 4 + i]) < fabs(design[best * 4 + best])) best = i;
-    double p[4] = {V[0 * 4 + best], V[1 * 4 + best], V[2 * 4 + best], V[3 * 4 + best]};
+    // eigenvector of the eigenvalue with the smallest magnitude (first one on ties), selected without a runtime
+    // index into V: a dynamic index would move both matrices from registers to scratch memory
+    double bestv = fabs(design[0]);
+    double p[4] = {V[0], V[4], V[8], V[12]};
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const double d = fabs(design[i * 4 + i]);
+        const bool take = d < bestv;
+        bestv = take ? d : bestv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = take ? V[r * 4 + i] : p[r];
+    }
     if (__builtin_signbit(p[3]))
         for (int i = 0; i < 4; ++i) p[i] = -p[i];
     double nrm = AKZ_RM_SQRT(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
