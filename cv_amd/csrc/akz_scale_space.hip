@@ -1509,9 +1509,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
                        dim3(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s,    \
                        d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0], (const float*)nullptr, 0)
-        // 32-row tiles x 256 threads (measured against 24 x 512 and against 5 row tiles per block with register
-        // prefetch: 10.18 vs 10.50 / 10.83 ms of scale space per 64 frames)
-        AKZ_FRONT0(32, 256, 1);
+        // 32-row tiles (measured against 24 x 512 and against 5 row tiles per block with register prefetch: 10.18
+        // vs 10.50 / 10.83 ms of scale space per 64 frames); 512 threads here, where the u8 input leaves registers
+        // for eight waves per block (441 vs 490 us per 64 frames), 256 on the f32 levels (178 vs 184 us)
+        AKZ_FRONT0(32, 512, 1);
 #undef AKZ_FRONT0
         AKZ_LAUNCH_CHECK();
     } else if (fused0) {
