@@ -165,7 +165,7 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
                 design[r * 4 + c] += s;
             }
     }
-    akz_rm_jacobi4(design, V, 1, kEpsRes, kItersRes);
+    akz_rm_jacobi4_sym(design, V, kEpsRes, kItersRes);
     // eigenvector of the eigenvalue with the smallest magnitude (first one on ties), selected without a runtime
     // index into V: a dynamic index would move both matrices from registers to scratch memory
     double bestv = fabs(design[0]);

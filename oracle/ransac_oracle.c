@@ -182,7 +182,7 @@ double orc_residual(const double* pose, const double* a, const double* b, double
             }
     }
     double V[16];
-    akz_rm_jacobi4(design, V, 1, eps, iters);
+    akz_rm_jacobi4_sym(design, V, eps, iters);
     int best = 0;
     for (int i = 1; i < 4; ++i)
         if (fabs(design[i * 4 + i]) < fabs(design[best * 4 + best])) best = i; /* min_by_key(|l|.to_bits()) */
