@@ -67,3 +67,35 @@ ScharrW akz_scharr_weights(uint32_t sigma);
 
 static inline int akz_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t akz_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// Ascending bitonic sort of np2 (a power of two) 64-bit keys in LDS by one block of NT threads (NT a multiple of
+// 64, all threads call it; the keys must be complete and a barrier passed before).  Work item t owns the pair
+// (i, i | j) with i = t with a zero inserted at bit log2(j), so every thread compares one pair per item.  The
+// elements a wave touches at strides j <= 64 form 128-element blocks that no other wave touches before the next
+// stride >= 128, and a wave's LDS operations execute in order: those stages need no block barrier (28 of the 91
+// stages of an 8192-key sort keep one).  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_lds_u64(unsigned long long* key, uint32_t np2)
+{
+    const uint32_t half = np2 >> 1;
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += NT) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), ixj = i | j;
+                const unsigned long long a = key[i], b = key[ixj];
+                const bool up = (i & k2) == 0;
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[ixj] = a;
+                }
+            }
+            if (j > 64u || j == 1u) __syncthreads();          // next stride (k2 of the next phase) may cross waves
+            else __builtin_amdgcn_wave_barrier();              // same wave owns the same 128-element blocks
+        }
+    }
+    __syncthreads();
+}
+#endif
+

@@ -826,22 +826,7 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
         key[i] = k;
     }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = key[i], b = key[ixj];
-                    bool up = (i & k2) == 0;
-                    if ((a > b) == up) {
-                        key[i] = b;
-                        key[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds_u64<1024>(key, np2);
     uint32_t m = n < max_features ? n : max_features;
     for (uint32_t i = threadIdx.x; i < m; i += 1024) out[(size_t)frame * stride + i] = src[(uint32_t)(key[i] & 0xFFFFFFFFull)];
     if (threadIdx.x == 0) n_out[frame] = m;
@@ -875,22 +860,7 @@ __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevK
         key[i] = k;
     }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = key[i], b = key[ixj];
-                    bool up = (i & k2) == 0;
-                    if ((a > b) == up) {
-                        key[i] = b;
-                        key[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds_u64<1024>(key, np2);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) perm[(size_t)frame * stride + i] = (uint32_t)(key[i] & 0xFFFFFFFFull);
 }
 

@@ -1350,22 +1350,7 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
         key[i] = kk;
     }
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    unsigned long long a = key[i], b = key[ixj];
-                    bool up = (i & k2) == 0;
-                    if ((a > b) == up) {
-                        key[i] = b;
-                        key[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds_u64<1024>(key, np2);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const CandU cu = seg[(uint32_t)key[i]];
         cand[list + i] = make_uint2(cu.xy, __float_as_uint(cu.v));
