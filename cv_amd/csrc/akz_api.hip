@@ -112,86 +112,90 @@ static int32_t validate_config(const akz_config* cfg)
 extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h, int32_t max_batch,
                               uint32_t max_keypoints, akz_ctx** out)
 {
-    if (!cfg || !out || max_w < 3 || max_h < 3 || max_batch < 1 || max_w > 65535 || max_h > 65535) return AKZ_E_INVALID;
-    AKZ_TRY(validate_config(cfg));
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
-        g_akz_last_hip = (int)e;
-        return AKZ_E_NO_DEVICE;  // no CPU fallback, by design
-    }
-    AKZ_HIP(hipSetDevice(device));
-    akz_ctx* c = new (std::nothrow) akz_ctx();
-    if (!c) return AKZ_E_OOM;
-    c->cfg = *cfg;
-    c->device = device;
-    c->max_w = max_w;
-    c->max_h = max_h;
-    c->max_batch = max_batch;
-    c->max_kp = max_keypoints ? max_keypoints : 16384u;
-    if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
-    c->max_cand = c->max_kp;  // per (frame, level) candidate capacity; k_cand_sort keeps one list in LDS
-    c->sup_cap = 4u * c->max_kp;   // all levels together: frames with more candidates take the serial pass
-    {
-        const char* sp = getenv("AKZ_SUP_PARALLEL");
-        c->sup_parallel = !(sp && sp[0] == '0');
-        const char* sc = getenv("AKZ_SUP_CAP");   // test knob: a small value sends frames down the fallback
-        if (sc && atoi(sc) > 0) c->sup_cap = (uint32_t)atoi(sc);
-    }
-    const char* keep = getenv("AKZ_KEEP_ALL");
-    c->keep_all = keep && keep[0] == '1';
-    const char* fp = getenv("AKZ_FRONT_PAIR");
-    c->front_pair = !(fp && fp[0] == '0');
-    int32_t st = AKZ_OK;
-    // The scale-space stream is the critical path of the pipeline: it gets the highest priority so its
-    // HBM-bound kernels are dispatched first; the keypoint stream fills the remaining wave slots.
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = numerically greatest = least urgent
-    const char* pr = getenv("AKZ_STREAM_PRIORITY");
-    const bool use_prio = pr && pr[0] == '1';  // measured: no gain on MI355X (1982 vs 2029 fps), off by default
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
-    if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
-        st = AKZ_E_HIP;
-    if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_input, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
-    for (int b = 0; b < 2 && st == AKZ_OK; ++b) {
-        if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
-        if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
-    }
-    const char* dts = getenv("AKZ_DESC_TILE_SHIFT");
-    if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
-    const char* fb = getenv("AKZ_FED_BLOCK");
-    if (fb && fb[0] >= '1' && fb[0] <= '8' && !fb[1]) c->fed_block = fb[0] - '0';
-    const char* pipe = getenv("AKZ_PIPELINE");
-    c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
-    if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
-    if (st != AKZ_OK) {
-        akz_destroy(c);
-        return st;
-    }
-    *out = c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!cfg || !out || max_w < 3 || max_h < 3 || max_batch < 1 || max_w > 65535 || max_h > 65535) return AKZ_E_INVALID;
+        AKZ_TRY(validate_config(cfg));
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+            g_akz_last_hip = (int)e;
+            return AKZ_E_NO_DEVICE;  // no CPU fallback, by design
+        }
+        AKZ_HIP(hipSetDevice(device));
+        akz_ctx* c = new (std::nothrow) akz_ctx();
+        if (!c) return AKZ_E_OOM;
+        c->cfg = *cfg;
+        c->device = device;
+        c->max_w = max_w;
+        c->max_h = max_h;
+        c->max_batch = max_batch;
+        c->max_kp = max_keypoints ? max_keypoints : 16384u;
+        if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
+        c->max_cand = c->max_kp;  // per (frame, level) candidate capacity; k_cand_sort keeps one list in LDS
+        c->sup_cap = 4u * c->max_kp;   // all levels together: frames with more candidates take the serial pass
+        {
+            const char* sp = getenv("AKZ_SUP_PARALLEL");
+            c->sup_parallel = !(sp && sp[0] == '0');
+            const char* sc = getenv("AKZ_SUP_CAP");   // test knob: a small value sends frames down the fallback
+            if (sc && atoi(sc) > 0) c->sup_cap = (uint32_t)atoi(sc);
+        }
+        const char* keep = getenv("AKZ_KEEP_ALL");
+        c->keep_all = keep && keep[0] == '1';
+        const char* fp = getenv("AKZ_FRONT_PAIR");
+        c->front_pair = !(fp && fp[0] == '0');
+        int32_t st = AKZ_OK;
+        // The scale-space stream is the critical path of the pipeline: it gets the highest priority so its
+        // HBM-bound kernels are dispatched first; the keypoint stream fills the remaining wave slots.
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = numerically greatest = least urgent
+        const char* pr = getenv("AKZ_STREAM_PRIORITY");
+        const bool use_prio = pr && pr[0] == '1';  // measured: no gain on MI355X (1982 vs 2029 fps), off by default
+        if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
+        if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
+            st = AKZ_E_HIP;
+        if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_input, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+        for (int b = 0; b < 2 && st == AKZ_OK; ++b) {
+            if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+            if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+        }
+        const char* dts = getenv("AKZ_DESC_TILE_SHIFT");
+        if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
+        const char* fb = getenv("AKZ_FED_BLOCK");
+        if (fb && fb[0] >= '1' && fb[0] <= '8' && !fb[1]) c->fed_block = fb[0] - '0';
+        const char* pipe = getenv("AKZ_PIPELINE");
+        c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
+        if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
+        if (st != AKZ_OK) {
+            akz_destroy(c);
+            return st;
+        }
+        *out = c;
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t akz_destroy(akz_ctx* c)
 {
-    if (!c) return AKZ_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->stream_kp) hipStreamSynchronize(c->stream_kp);
-    timer_free(&c->t_fed);
-    timer_free(&c->t_ss);
-    timer_free(&c->t_all);
-    if (c->arena) hipFree(c->arena);
-    if (c->d_color) hipFree(c->d_color);
-    if (c->stream) hipStreamDestroy(c->stream);
-    if (c->stream_kp) hipStreamDestroy(c->stream_kp);
-    if (c->ev_input) hipEventDestroy(c->ev_input);
-    for (int b = 0; b < 2; ++b) {
-        if (c->ev_ss_done[b]) hipEventDestroy(c->ev_ss_done[b]);
-        if (c->ev_kp_done[b]) hipEventDestroy(c->ev_kp_done[b]);
-    }
-    delete c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_OK;
+        hipSetDevice(c->device);
+        if (c->stream) hipStreamSynchronize(c->stream);
+        if (c->stream_kp) hipStreamSynchronize(c->stream_kp);
+        timer_free(&c->t_fed);
+        timer_free(&c->t_ss);
+        timer_free(&c->t_all);
+        if (c->arena) hipFree(c->arena);
+        if (c->d_color) hipFree(c->d_color);
+        if (c->stream) hipStreamDestroy(c->stream);
+        if (c->stream_kp) hipStreamDestroy(c->stream_kp);
+        if (c->ev_input) hipEventDestroy(c->ev_input);
+        for (int b = 0; b < 2; ++b) {
+            if (c->ev_ss_done[b]) hipEventDestroy(c->ev_ss_done[b]);
+            if (c->ev_kp_done[b]) hipEventDestroy(c->ev_kp_done[b]);
+        }
+        delete c;
+        return AKZ_OK;
+    });
 }
 
 namespace {
@@ -355,101 +359,113 @@ static int32_t wait_for(akz_ctx* c, void* stream_to_wait)
 extern "C" void* akz_stream(akz_ctx* c) { return c ? (void*)c->stream_kp : nullptr; }
 extern "C" int32_t akz_sync(akz_ctx* c)
 {
-    if (!c) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
-    return check_device_err(c);  // synchronises both streams
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        return check_device_err(c);  // synchronises both streams
+    });
 }
 
 extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
                                           void* stream_to_wait)
 {
-    if (!c || !d_imgs || n < 1 || (fmt != 0 && fmt != 1)) return AKZ_E_INVALID;
-    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(akz_ctx_prepare(c, w, h));
-    AKZ_TRY(begin_call(c));
-    AKZ_TRY(wait_for(c, stream_to_wait));
-    c->cur_n = n;
-    AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
-    // completion is observable on akz_stream() like every other call
-    AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
-    AKZ_HIP(hipStreamWaitEvent(c->stream_kp, c->ev_ss_done[c->cur], 0));
-    AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
-    c->kp_pending[c->cur] = true;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_imgs || n < 1 || (fmt != 0 && fmt != 1)) return AKZ_E_INVALID;
+        if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(akz_ctx_prepare(c, w, h));
+        AKZ_TRY(begin_call(c));
+        AKZ_TRY(wait_for(c, stream_to_wait));
+        c->cur_n = n;
+        AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
+        // completion is observable on akz_stream() like every other call
+        AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
+        AKZ_HIP(hipStreamWaitEvent(c->stream_kp, c->ev_ss_done[c->cur], 0));
+        AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
+        c->kp_pending[c->cur] = true;
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
                                             int32_t h, void* d_kps, void* d_descs, uint32_t cap_per_img,
                                             void* d_n_out, void* stream_to_wait)
 {
-    if (!c || !d_imgs || !d_kps || !d_descs || !d_n_out || n < 1 || (fmt != 0 && fmt != 1) || cap_per_img == 0)
-        return AKZ_E_INVALID;
-    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(akz_ctx_prepare(c, w, h));
-    AKZ_TRY(begin_call(c));
-    AKZ_TRY(wait_for(c, stream_to_wait));
-    c->cur_n = n;
-    akz_timer_begin(c, &c->t_all);
-    AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
-    AKZ_TRY(akz_run_keypoints(c, n, (DevKp*)d_kps, (akz_descriptor*)d_descs, cap_per_img, (uint32_t*)d_n_out));
-    akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_imgs || !d_kps || !d_descs || !d_n_out || n < 1 || (fmt != 0 && fmt != 1) || cap_per_img == 0)
+            return AKZ_E_INVALID;
+        if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(akz_ctx_prepare(c, w, h));
+        AKZ_TRY(begin_call(c));
+        AKZ_TRY(wait_for(c, stream_to_wait));
+        c->cur_n = n;
+        akz_timer_begin(c, &c->t_all);
+        AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
+        AKZ_TRY(akz_run_keypoints(c, n, (DevKp*)d_kps, (akz_descriptor*)d_descs, cap_per_img, (uint32_t*)d_n_out));
+        akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
                                      int32_t stride, akz_keypoint* kps, akz_descriptor* descs, uint32_t cap_per_img,
                                      uint32_t* n_out)
 {
-    if (!c || !imgs || !n_out || n < 1 || (fmt != 0 && fmt != 1) || stride < w) return AKZ_E_INVALID;
-    if (cap_per_img && (!kps || !descs)) return AKZ_E_INVALID;
-    if (n > c->max_batch) return AKZ_E_TOO_LARGE;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(akz_ctx_prepare(c, w, h));
-    AKZ_TRY(begin_call(c));
-    const size_t esz = fmt == 0 ? 1 : 4;
-    const size_t P0 = (size_t)w * h;
-    for (int i = 0; i < n; ++i) {
-        if (!imgs[i]) return AKZ_E_INVALID;
-        AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
-                                 (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
-    }
-    c->cur_n = n;
-    akz_timer_begin(c, &c->t_all);
-    AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
-    AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
-    akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
-    std::vector<uint32_t> cnt(n);
-    AKZ_TRY(check_device_err(c));  // synchronises both streams
-    AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-    int32_t status = AKZ_OK;
-    for (int i = 0; i < n; ++i) {
-        n_out[i] = cnt[i];
-        if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;
-        if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
-        uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
-        if (m) {
-            AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->S().d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
-                              hipMemcpyDeviceToHost));
-            AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->S().d_desc_out + (size_t)i * c->max_kp,
-                              sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
+    return akz_guard([&]() -> int32_t {
+        if (!c || !imgs || !n_out || n < 1 || (fmt != 0 && fmt != 1) || stride < w) return AKZ_E_INVALID;
+        if (cap_per_img && (!kps || !descs)) return AKZ_E_INVALID;
+        if (n > c->max_batch) return AKZ_E_TOO_LARGE;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(akz_ctx_prepare(c, w, h));
+        AKZ_TRY(begin_call(c));
+        const size_t esz = fmt == 0 ? 1 : 4;
+        const size_t P0 = (size_t)w * h;
+        for (int i = 0; i < n; ++i) {
+            if (!imgs[i]) return AKZ_E_INVALID;
+            AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
+                                     (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
         }
-    }
-    return status;
+        c->cur_n = n;
+        akz_timer_begin(c, &c->t_all);
+        AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
+        AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
+        akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+        std::vector<uint32_t> cnt(n);
+        AKZ_TRY(check_device_err(c));  // synchronises both streams
+        AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        int32_t status = AKZ_OK;
+        for (int i = 0; i < n; ++i) {
+            n_out[i] = cnt[i];
+            if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;
+            if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
+            uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
+            if (m) {
+                AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->S().d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
+                                  hipMemcpyDeviceToHost));
+                AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->S().d_desc_out + (size_t)i * c->max_kp,
+                                  sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
+            }
+        }
+        return status;
+    });
 }
 
 extern "C" int32_t akz_extract_gray_u8(akz_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                                        akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
 {
-    const void* p = img;
-    return akz_extract_batch(c, &p, 0, 1, w, h, stride, kps, descs, cap, n_out);
+    return akz_guard([&]() -> int32_t {
+        const void* p = img;
+        return akz_extract_batch(c, &p, 0, 1, w, h, stride, kps, descs, cap, n_out);
+    });
 }
 extern "C" int32_t akz_extract_gray_f32(akz_ctx* c, const float* img, int32_t w, int32_t h, int32_t stride,
                                         akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
 {
-    const void* p = img;
-    return akz_extract_batch(c, &p, 1, 1, w, h, stride, kps, descs, cap, n_out);
+    return akz_guard([&]() -> int32_t {
+        const void* p = img;
+        return akz_extract_batch(c, &p, 1, 1, w, h, stride, kps, descs, cap, n_out);
+    });
 }
 
 // ---- introspection -----------------------------------------------------------------------------
@@ -467,120 +483,134 @@ static int32_t plan_for(akz_ctx* c, int w, int h, AkzPlan* tmp, const AkzPlan** 
 }
 extern "C" int32_t akz_num_levels(akz_ctx* c, int32_t w, int32_t h, int32_t* n_levels)
 {
-    AkzPlan tmp;
-    const AkzPlan* P;
-    if (!n_levels) return AKZ_E_INVALID;
-    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
-    *n_levels = (int32_t)P->levels.size();
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        AkzPlan tmp;
+        const AkzPlan* P;
+        if (!n_levels) return AKZ_E_INVALID;
+        AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+        *n_levels = (int32_t)P->levels.size();
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_level(akz_ctx* c, int32_t w, int32_t h, int32_t level, akz_level_info* out)
 {
-    AkzPlan tmp;
-    const AkzPlan* P;
-    if (!out) return AKZ_E_INVALID;
-    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
-    if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
-    const AkzLevel& L = P->levels[level];
-    out->width = L.w;
-    out->height = L.h;
-    out->octave = L.octave;
-    out->sublevel = L.sublevel;
-    out->esigma = L.esigma;
-    out->etime = L.etime;
-    out->n_fed_steps = (uint32_t)L.tau.size();
-    out->deriv_sigma = L.deriv_sigma;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        AkzPlan tmp;
+        const AkzPlan* P;
+        if (!out) return AKZ_E_INVALID;
+        AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+        if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
+        const AkzLevel& L = P->levels[level];
+        out->width = L.w;
+        out->height = L.h;
+        out->octave = L.octave;
+        out->sublevel = L.sublevel;
+        out->esigma = L.esigma;
+        out->etime = L.etime;
+        out->n_fed_steps = (uint32_t)L.tau.size();
+        out->deriv_sigma = L.deriv_sigma;
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_fed_tau(akz_ctx* c, int32_t w, int32_t h, int32_t level, double* tau, uint32_t cap,
                                uint32_t* n_out)
 {
-    AkzPlan tmp;
-    const AkzPlan* P;
-    if (!n_out) return AKZ_E_INVALID;
-    AKZ_TRY(plan_for(c, w, h, &tmp, &P));
-    if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
-    const auto& t = P->levels[level].tau;
-    *n_out = (uint32_t)t.size();
-    if (t.size() > cap) return AKZ_E_CAPACITY;
-    for (size_t i = 0; i < t.size(); ++i) tau[i] = t[i];
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        AkzPlan tmp;
+        const AkzPlan* P;
+        if (!n_out) return AKZ_E_INVALID;
+        AKZ_TRY(plan_for(c, w, h, &tmp, &P));
+        if (level < 0 || level >= (int)P->levels.size()) return AKZ_E_INVALID;
+        const auto& t = P->levels[level].tau;
+        *n_out = (uint32_t)t.size();
+        if (t.size() > cap) return AKZ_E_CAPACITY;
+        for (size_t i = 0; i < t.size(); ++i) tau[i] = t[i];
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t akz_debug_get_level(akz_ctx* c, int32_t img, int32_t level, int32_t which, float* out)
 {
-    if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
-    if (level < 0 || level >= (int)c->plan.levels.size()) return AKZ_E_INVALID;
-    const float* src = nullptr;
-    int comp = -1;
-    switch (which) {
-    case AKZ_BUF_LT: src = c->S().Lt[level]; break;
-    case AKZ_BUF_LSMOOTH: src = c->S().Lsm[level]; break;
-    case AKZ_BUF_LX: comp = 0; break;
-    case AKZ_BUF_LY: comp = 1; break;
-    case AKZ_BUF_LDET: src = c->S().Ldet[level]; break;
-    case AKZ_BUF_LFLOW: src = c->S().Lflow[level]; break;
-    default: return AKZ_E_INVALID;
-    }
-    if (!src && comp < 0) return AKZ_E_INVALID;
-    // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
-    if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
-    if (!c->keep_all && which == AKZ_BUF_LDET) return AKZ_E_INVALID;   // Ldet planes exist only for the parity taps
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(sync_all(c));
-    size_t px = c->plan.levels[level].pixels();
-    if (comp >= 0) {  // Lx / Ly live interleaved; split one component into the (idle) FED scratch plane
-        AKZ_TRY(akz_dev_deinterleave(c->stream, c->S().Lxy[level] + (size_t)img * px, c->S().tmp, px, comp));
-        AKZ_HIP(hipStreamSynchronize(c->stream));
-        src = c->S().tmp;
-        AKZ_HIP(hipMemcpy(out, src, sizeof(float) * px, hipMemcpyDeviceToHost));
+    return akz_guard([&]() -> int32_t {
+        if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+        if (level < 0 || level >= (int)c->plan.levels.size()) return AKZ_E_INVALID;
+        const float* src = nullptr;
+        int comp = -1;
+        switch (which) {
+        case AKZ_BUF_LT: src = c->S().Lt[level]; break;
+        case AKZ_BUF_LSMOOTH: src = c->S().Lsm[level]; break;
+        case AKZ_BUF_LX: comp = 0; break;
+        case AKZ_BUF_LY: comp = 1; break;
+        case AKZ_BUF_LDET: src = c->S().Ldet[level]; break;
+        case AKZ_BUF_LFLOW: src = c->S().Lflow[level]; break;
+        default: return AKZ_E_INVALID;
+        }
+        if (!src && comp < 0) return AKZ_E_INVALID;
+        // Lsmooth / Lflow are transient scratch unless the context was created with AKZ_KEEP_ALL=1
+        if (!c->keep_all && level > 0 && (which == AKZ_BUF_LSMOOTH || which == AKZ_BUF_LFLOW)) return AKZ_E_INVALID;
+        if (!c->keep_all && which == AKZ_BUF_LDET) return AKZ_E_INVALID;   // Ldet planes exist only for the parity taps
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(sync_all(c));
+        size_t px = c->plan.levels[level].pixels();
+        if (comp >= 0) {  // Lx / Ly live interleaved; split one component into the (idle) FED scratch plane
+            AKZ_TRY(akz_dev_deinterleave(c->stream, c->S().Lxy[level] + (size_t)img * px, c->S().tmp, px, comp));
+            AKZ_HIP(hipStreamSynchronize(c->stream));
+            src = c->S().tmp;
+            AKZ_HIP(hipMemcpy(out, src, sizeof(float) * px, hipMemcpyDeviceToHost));
+            return AKZ_OK;
+        }
+        AKZ_HIP(hipMemcpy(out, src + (size_t)img * px, sizeof(float) * px, hipMemcpyDeviceToHost));
         return AKZ_OK;
-    }
-    AKZ_HIP(hipMemcpy(out, src + (size_t)img * px, sizeof(float) * px, hipMemcpyDeviceToHost));
-    return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_debug_get_contrast(akz_ctx* c, int32_t img, double* out)
 {
-    if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(sync_all(c));
-    AKZ_HIP(hipMemcpy(out, c->S().d_contrast + img, sizeof(double), hipMemcpyDeviceToHost));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(sync_all(c));
+        AKZ_HIP(hipMemcpy(out, c->S().d_contrast + img, sizeof(double), hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stage, akz_keypoint* out, uint32_t cap,
                                            uint32_t* n_out)
 {
-    if (!c || !n_out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
-    const DevKp* src;
-    const uint32_t* cnt;
-    switch (stage) {
-    case 0: src = c->S().d_kp_a; cnt = c->S().d_n_a; break;
-    case 1: src = c->S().d_kp_c; cnt = c->S().d_n_c; break;
-    case 2: src = c->S().d_kp_d; cnt = c->S().d_n_d; break;
-    default: return AKZ_E_INVALID;
-    }
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(sync_all(c));
-    uint32_t n = 0;
-    AKZ_HIP(hipMemcpy(&n, cnt + img, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    *n_out = n;
-    if (n > c->max_kp) return AKZ_E_INTERNAL;
-    uint32_t m = n < cap ? n : cap;
-    if (m && !out) return AKZ_E_INVALID;
-    if (m) AKZ_HIP(hipMemcpy(out, src + (size_t)img * c->max_kp, sizeof(akz_keypoint) * m, hipMemcpyDeviceToHost));
-    // before refinement the angle field carries the candidate index (internal bookkeeping): the reference's
-    // keypoints have angle 0 at that stage (scale_space_extrema.rs:111)
-    if (stage == 0)
-        for (uint32_t i = 0; i < m; ++i) out[i].angle = 0.0f;
-    return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !n_out || img < 0 || img >= c->cur_n) return AKZ_E_INVALID;
+        const DevKp* src;
+        const uint32_t* cnt;
+        switch (stage) {
+        case 0: src = c->S().d_kp_a; cnt = c->S().d_n_a; break;
+        case 1: src = c->S().d_kp_c; cnt = c->S().d_n_c; break;
+        case 2: src = c->S().d_kp_d; cnt = c->S().d_n_d; break;
+        default: return AKZ_E_INVALID;
+        }
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(sync_all(c));
+        uint32_t n = 0;
+        AKZ_HIP(hipMemcpy(&n, cnt + img, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        *n_out = n;
+        if (n > c->max_kp) return AKZ_E_INTERNAL;
+        uint32_t m = n < cap ? n : cap;
+        if (m && !out) return AKZ_E_INVALID;
+        if (m) AKZ_HIP(hipMemcpy(out, src + (size_t)img * c->max_kp, sizeof(akz_keypoint) * m, hipMemcpyDeviceToHost));
+        // before refinement the angle field carries the candidate index (internal bookkeeping): the reference's
+        // keypoints have angle 0 at that stage (scale_space_extrema.rs:111)
+        if (stage == 0)
+            for (uint32_t i = 0; i < m; ++i) out[i].angle = 0.0f;
+        return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
 }
 
 // ---- akaze::image stand-alone ops ----------------------------------------------------------------
 extern "C" int32_t akz_gaussian_kernel(float r, uint32_t kernel_size, float* out)
 {
-    if (!out || kernel_size % 2 != 1 || !(r > 0.0f)) return AKZ_E_INVALID;  // image.rs:361 asserts odd
-    akz_host_gaussian_kernel(r, (int)kernel_size, out);
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!out || kernel_size % 2 != 1 || !(r > 0.0f)) return AKZ_E_INVALID;  // image.rs:361 asserts odd
+        akz_host_gaussian_kernel(r, (int)kernel_size, out);
+        return AKZ_OK;
+    });
 }
 
 static int32_t filter_host(akz_ctx* c, const float* img, int w, int h, const float* kernel, uint32_t ksize,
@@ -612,57 +642,69 @@ static int32_t filter_host(akz_ctx* c, const float* img, int w, int h, const flo
 extern "C" int32_t akz_horizontal_filter(akz_ctx* c, const float* img, int32_t w, int32_t h, const float* kernel,
                                          uint32_t ksize, float* out)
 {
-    return filter_host(c, img, w, h, kernel, ksize, out, 0);
+    return akz_guard([&]() -> int32_t {
+        return filter_host(c, img, w, h, kernel, ksize, out, 0);
+    });
 }
 extern "C" int32_t akz_vertical_filter(akz_ctx* c, const float* img, int32_t w, int32_t h, const float* kernel,
                                        uint32_t ksize, float* out)
 {
-    return filter_host(c, img, w, h, kernel, ksize, out, 1);
+    return akz_guard([&]() -> int32_t {
+        return filter_host(c, img, w, h, kernel, ksize, out, 1);
+    });
 }
 extern "C" int32_t akz_half_size(akz_ctx* c, const float* img, int32_t w, int32_t h, float* out)
 {
-    if (!c || !img || !out || w < 2 || h < 2) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
-    float *d_in = nullptr, *d_out = nullptr;
-    size_t px = (size_t)w * h, opx = (size_t)(w / 2) * (h / 2);
-    int32_t st = AKZ_OK;
-    if (hipMalloc(&d_in, px * 4) != hipSuccess || hipMalloc(&d_out, opx * 4) != hipSuccess) st = AKZ_E_OOM;
-    if (st == AKZ_OK) {
-        hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
-        st = akz_dev_half_size(c->stream, d_in, d_out, w, h, 1, px, opx);
-        if (st == AKZ_OK && hipMemcpyAsync(out, d_out, opx * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
-    }
-    hipFree(d_in);
-    hipFree(d_out);
-    return st;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !img || !out || w < 2 || h < 2) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        float *d_in = nullptr, *d_out = nullptr;
+        size_t px = (size_t)w * h, opx = (size_t)(w / 2) * (h / 2);
+        int32_t st = AKZ_OK;
+        if (hipMalloc(&d_in, px * 4) != hipSuccess || hipMalloc(&d_out, opx * 4) != hipSuccess) st = AKZ_E_OOM;
+        if (st == AKZ_OK) {
+            hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
+            st = akz_dev_half_size(c->stream, d_in, d_out, w, h, 1, px, opx);
+            if (st == AKZ_OK && hipMemcpyAsync(out, d_out, opx * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
+            if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
+        }
+        hipFree(d_in);
+        hipFree(d_out);
+        return st;
+    });
 }
 
 // ---- timing -----------------------------------------------------------------------------------
 extern "C" int32_t akz_timing_enable(akz_ctx* c, int32_t on)
 {
-    if (!c) return AKZ_E_INVALID;
-    c->timing = on != 0;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        c->timing = on != 0;
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_timing_reset(akz_ctx* c)
 {
-    if (!c) return AKZ_E_INVALID;
-    for (AkzTimer* t : {&c->t_fed, &c->t_ss, &c->t_all}) {
-        timer_resolve(t);
-        t->ms = 0.0;
-        t->launches = t->units = 0;
-    }
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        for (AkzTimer* t : {&c->t_fed, &c->t_ss, &c->t_all}) {
+            timer_resolve(t);
+            t->ms = 0.0;
+            t->launches = t->units = 0;
+        }
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t akz_timing_get(akz_ctx* c, int32_t which, double* ms, uint64_t* launches, uint64_t* units)
 {
-    if (!c || which < 0 || which > 2) return AKZ_E_INVALID;
-    AkzTimer* t = which == 0 ? &c->t_fed : (which == 1 ? &c->t_ss : &c->t_all);
-    AKZ_HIP(hipSetDevice(c->device));
-    timer_resolve(t);
-    if (ms) *ms = t->ms;
-    if (launches) *launches = t->launches;
-    if (units) *units = t->units;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || which < 0 || which > 2) return AKZ_E_INVALID;
+        AkzTimer* t = which == 0 ? &c->t_fed : (which == 1 ? &c->t_ss : &c->t_all);
+        AKZ_HIP(hipSetDevice(c->device));
+        timer_resolve(t);
+        if (ms) *ms = t->ms;
+        if (launches) *launches = t->launches;
+        if (units) *units = t->units;
+        return AKZ_OK;
+    });
 }

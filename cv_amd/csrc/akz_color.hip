@@ -59,28 +59,30 @@ __global__ __launch_bounds__(256) void k_bicubic_rgb8(const uint8_t* __restrict_
 extern "C" int32_t akz_sample_colors_rgb8(akz_ctx* c, const uint8_t* rgb, int32_t w, int32_t h, int32_t stride,
                                           const akz_keypoint* kps, uint32_t n, uint8_t* colors)
 {
-    if (!c || !rgb || w <= 0 || h <= 0 || stride < 3 * w || (n && (!kps || !colors))) return AKZ_E_INVALID;
-    if (n == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    const size_t img_bytes = (size_t)w * h * 3, kp_bytes = sizeof(akz_keypoint) * (size_t)n, col_bytes = 3 * (size_t)n;
-    const size_t need = akz_align_up(img_bytes, 256) + akz_align_up(kp_bytes, 256) + akz_align_up(col_bytes, 256);
-    if (need > c->color_bytes) {
-        AKZ_HIP(hipStreamSynchronize(c->stream_kp));
-        if (c->d_color) AKZ_HIP(hipFree(c->d_color));
-        c->d_color = nullptr;
-        c->color_bytes = 0;
-        AKZ_HIP(hipMalloc(&c->d_color, need));
-        c->color_bytes = need;
-    }
-    uint8_t* d_img = (uint8_t*)c->d_color;
-    akz_keypoint* d_kp = (akz_keypoint*)(d_img + akz_align_up(img_bytes, 256));
-    uint8_t* d_col = (uint8_t*)d_kp + akz_align_up(kp_bytes, 256);
-    hipStream_t s = c->stream_kp;
-    AKZ_HIP(hipMemcpy2DAsync(d_img, (size_t)w * 3, rgb, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(d_kp, kps, kp_bytes, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_bicubic_rgb8, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, d_kp, n, d_col);
-    AKZ_LAUNCH_CHECK();
-    AKZ_HIP(hipMemcpyAsync(colors, d_col, col_bytes, hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipStreamSynchronize(s));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !rgb || w <= 0 || h <= 0 || stride < 3 * w || (n && (!kps || !colors))) return AKZ_E_INVALID;
+        if (n == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        const size_t img_bytes = (size_t)w * h * 3, kp_bytes = sizeof(akz_keypoint) * (size_t)n, col_bytes = 3 * (size_t)n;
+        const size_t need = akz_align_up(img_bytes, 256) + akz_align_up(kp_bytes, 256) + akz_align_up(col_bytes, 256);
+        if (need > c->color_bytes) {
+            AKZ_HIP(hipStreamSynchronize(c->stream_kp));
+            if (c->d_color) AKZ_HIP(hipFree(c->d_color));
+            c->d_color = nullptr;
+            c->color_bytes = 0;
+            AKZ_HIP(hipMalloc(&c->d_color, need));
+            c->color_bytes = need;
+        }
+        uint8_t* d_img = (uint8_t*)c->d_color;
+        akz_keypoint* d_kp = (akz_keypoint*)(d_img + akz_align_up(img_bytes, 256));
+        uint8_t* d_col = (uint8_t*)d_kp + akz_align_up(kp_bytes, 256);
+        hipStream_t s = c->stream_kp;
+        AKZ_HIP(hipMemcpy2DAsync(d_img, (size_t)w * 3, rgb, (size_t)stride, (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(d_kp, kps, kp_bytes, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_bicubic_rgb8, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, d_kp, n, d_col);
+        AKZ_LAUNCH_CHECK();
+        AKZ_HIP(hipMemcpyAsync(colors, d_col, col_bytes, hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipStreamSynchronize(s));
+        return AKZ_OK;
+    });
 }

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "../../include/akz.h"
@@ -64,6 +65,19 @@ struct ScharrW {   // computer_scharr_kernel, derivatives.rs:57-79
     int sigma;
 };
 ScharrW akz_scharr_weights(uint32_t sigma);
+
+// C++ exceptions must not cross the C ABI: every int32_t entry point runs its body through this.
+template <typename F>
+static inline int32_t akz_guard(F&& f) noexcept
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return AKZ_E_OOM;
+    } catch (...) {
+        return AKZ_E_INTERNAL;
+    }
+}
 
 static inline int akz_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t akz_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -625,77 +625,83 @@ static int32_t hm_push_probs(hm_ctx* c, size_t off, const void* src, size_t byte
 
 extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out)
 {
-    // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
-    if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
-    AKZ_HIP(hipSetDevice(device));
-    hm_ctx* c = new hm_ctx();
-    c->device = device;
-    c->max_q = max_queries;
-    c->max_t = max_targets;
-    uint32_t m = max_queries > max_targets ? max_queries : max_targets;
-    c->max_q = c->max_t = m;  // symmetric matching swaps the roles
-    {
-        int prio_lo = 0, prio_hi = 0;
-        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        const char* pr = getenv("AKZ_STREAM_PRIORITY");
-        // the matcher is VALU-bound filler work: least urgent, so it yields to the scale-space stream
-        AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (pr && pr[0] == '1') ? prio_lo : 0));
-    }
-    AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-    {
-        const char* mf = getenv("AKZ_MATCH_MFMA");
-        c->use_mfma = !(mf && mf[0] == '0');
-        const char* f4 = getenv("AKZ_MATCH_FP4");
-        c->use_fp4 = !(f4 && f4[0] == '0');
-    }
-    AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
-    AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
-    AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
-    AKZ_HIP(hipMalloc(&c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)m));
-    AKZ_HIP(hipMalloc(&c->d_rev, sizeof(akz_neighbor) * 2 * (size_t)m));
-    AKZ_HIP(hipMalloc(&c->d_pairs, sizeof(uint32_t) * 2 * (size_t)m));
-    AKZ_HIP(hipMalloc(&c->d_npairs, sizeof(uint32_t) * 4));
-    *out = c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
+        if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
+        AKZ_HIP(hipSetDevice(device));
+        hm_ctx* c = new hm_ctx();
+        c->device = device;
+        c->max_q = max_queries;
+        c->max_t = max_targets;
+        uint32_t m = max_queries > max_targets ? max_queries : max_targets;
+        c->max_q = c->max_t = m;  // symmetric matching swaps the roles
+        {
+            int prio_lo = 0, prio_hi = 0;
+            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            const char* pr = getenv("AKZ_STREAM_PRIORITY");
+            // the matcher is VALU-bound filler work: least urgent, so it yields to the scale-space stream
+            AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (pr && pr[0] == '1') ? prio_lo : 0));
+        }
+        AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+        {
+            const char* mf = getenv("AKZ_MATCH_MFMA");
+            c->use_mfma = !(mf && mf[0] == '0');
+            const char* f4 = getenv("AKZ_MATCH_FP4");
+            c->use_fp4 = !(f4 && f4[0] == '0');
+        }
+        AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
+        AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
+        AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
+        AKZ_HIP(hipMalloc(&c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)m));
+        AKZ_HIP(hipMalloc(&c->d_rev, sizeof(akz_neighbor) * 2 * (size_t)m));
+        AKZ_HIP(hipMalloc(&c->d_pairs, sizeof(uint32_t) * 2 * (size_t)m));
+        AKZ_HIP(hipMalloc(&c->d_npairs, sizeof(uint32_t) * 4));
+        *out = c;
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t hm_destroy(hm_ctx* c)
 {
-    if (!c) return AKZ_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_a);
-    hipFree(c->d_b);
-    hipFree(c->d_na);
-    hipFree(c->d_fwd);
-    hipFree(c->d_rev);
-    hipFree(c->d_pairs);
-    hipFree(c->d_npairs);
-    for (auto& S : c->ring) {
-        if (S.d) hipFree(S.d);
-        if (S.h) hipHostFree(S.h);
-        if (S.ev) hipEventDestroy(S.ev);
-    }
-    for (auto& pr : c->t_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (auto e : c->t_pool) hipEventDestroy(e);
-    hipFree(c->d_exp);
-    hipFree(c->d_bfwd);
-    hipFree(c->d_brev);
-    hipFree(c->d_lsh);
-    if (c->ev) hipEventDestroy(c->ev);
-    if (c->stream) hipStreamDestroy(c->stream);
-    delete c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_OK;
+        hipSetDevice(c->device);
+        if (c->stream) hipStreamSynchronize(c->stream);
+        hipFree(c->d_a);
+        hipFree(c->d_b);
+        hipFree(c->d_na);
+        hipFree(c->d_fwd);
+        hipFree(c->d_rev);
+        hipFree(c->d_pairs);
+        hipFree(c->d_npairs);
+        for (auto& S : c->ring) {
+            if (S.d) hipFree(S.d);
+            if (S.h) hipHostFree(S.h);
+            if (S.ev) hipEventDestroy(S.ev);
+        }
+        for (auto& pr : c->t_pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        for (auto e : c->t_pool) hipEventDestroy(e);
+        hipFree(c->d_exp);
+        hipFree(c->d_bfwd);
+        hipFree(c->d_brev);
+        hipFree(c->d_lsh);
+        if (c->ev) hipEventDestroy(c->ev);
+        if (c->stream) hipStreamDestroy(c->stream);
+        delete c;
+        return AKZ_OK;
+    });
 }
 
 extern "C" void* hm_stream(hm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int32_t hm_sync(hm_ctx* c)
 {
-    if (!c) return AKZ_E_INVALID;
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        return AKZ_OK;
+    });
 }
 
 static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, uint32_t max_nq, size_t probs_off,
@@ -800,51 +806,55 @@ static size_t knn_stage_bytes(uint32_t n_probs)
 extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
                            akz_neighbor* out)
 {
-    if (!c || !q || !t || !out) return AKZ_E_INVALID;
-    if (nt < 2) return AKZ_E_INVALID;  // the reference asserts two neighbours (estimate_pose.rs:89)
-    if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
-    if (nq == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
-    uint32_t cnt[2] = {nq, nt};
-    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
-    HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt, c->d_fwd};
-    AKZ_TRY(launch_knn2(c, &p, 1, nq, 0));
-    AKZ_HIP(hipMemcpyAsync(out, c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !q || !t || !out) return AKZ_E_INVALID;
+        if (nt < 2) return AKZ_E_INVALID;  // the reference asserts two neighbours (estimate_pose.rs:89)
+        if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
+        if (nq == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
+        uint32_t cnt[2] = {nq, nt};
+        AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+        HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt, c->d_fwd};
+        AKZ_TRY(launch_knn2(c, &p, 1, nq, 0));
+        AKZ_HIP(hipMemcpyAsync(out, c->d_fwd, sizeof(akz_neighbor) * 2 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        return AKZ_OK;
+    });
 }
 
 // LinearKnn{metric: Hamming, iter: t}.knn(q, k) for k = 1, 2, 3 (cv-sfm/src/lib.rs:1474 uses 3).
 extern "C" int32_t hm_knn(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
                           uint32_t k, akz_neighbor* out)
 {
-    if (!c || !q || !t || !out || k < 1 || k > 3) return AKZ_E_INVALID;
-    if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
-    if (nq == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
-    size_t need = (size_t)nq * 3;
-    if (need > c->bscratch_elems) {
+    return akz_guard([&]() -> int32_t {
+        if (!c || !q || !t || !out || k < 1 || k > 3) return AKZ_E_INVALID;
+        if (nq > c->max_q || nt > c->max_t) return AKZ_E_TOO_LARGE;
+        if (nq == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
+        size_t need = (size_t)nq * 3;
+        if (need > c->bscratch_elems) {
+            AKZ_HIP(hipStreamSynchronize(c->stream));
+            if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
+            if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
+            c->d_bfwd = c->d_brev = nullptr;
+            AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
+            AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
+            c->bscratch_elems = need;
+        }
+        uint32_t cnt[2] = {nq, nt};
+        AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+        if (nt) AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+        HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt ? nt : 1u, c->d_bfwd};
+        AKZ_TRY(launch_knn2(c, &p, 1, nq, 0, (int)k));
+        AKZ_HIP(hipMemcpyAsync(out, c->d_bfwd, sizeof(akz_neighbor) * k * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
         AKZ_HIP(hipStreamSynchronize(c->stream));
-        if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
-        if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
-        c->d_bfwd = c->d_brev = nullptr;
-        AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
-        AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
-        c->bscratch_elems = need;
-    }
-    uint32_t cnt[2] = {nq, nt};
-    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
-    if (nt) AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
-    HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt ? nt : 1u, c->d_bfwd};
-    AKZ_TRY(launch_knn2(c, &p, 1, nq, 0, (int)k));
-    AKZ_HIP(hipMemcpyAsync(out, c->d_bfwd, sizeof(akz_neighbor) * k * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    return AKZ_OK;
+        return AKZ_OK;
+    });
 }
 
 // One query frame against n_views stored views (cv-sfm/src/lib.rs:1468-1486: every feature of the new frame is
@@ -855,88 +865,96 @@ extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d
                                        const void* d_nviews, uint32_t cap_per_img, const uint32_t* view_idx,
                                        uint32_t n_views, uint32_t k, void* d_out, void* stream_to_wait)
 {
-    if (!c || !d_q || !d_nq || !d_views || !d_nviews || !view_idx || !d_out || k < 1 || k > 3) return AKZ_E_INVALID;
-    if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-    if (n_views == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    if (stream_to_wait) {
-        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
-        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
-    }
-    AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_views)));
-    std::vector<HmProb> hp(n_views);
-    for (uint32_t v = 0; v < n_views; ++v)
-        hp[v] = HmProb{(const uint4*)d_q, (const uint32_t*)d_nq, cap_per_img,
-                       (const uint4*)d_views + (size_t)view_idx[v] * cap_per_img * 4,
-                       (const uint32_t*)d_nviews + view_idx[v], cap_per_img,
-                       (akz_neighbor*)d_out + (size_t)v * cap_per_img * k};
-    return launch_knn2(c, hp.data(), n_views, cap_per_img, 0, (int)k);
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_q || !d_nq || !d_views || !d_nviews || !view_idx || !d_out || k < 1 || k > 3) return AKZ_E_INVALID;
+        if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+        if (n_views == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_views)));
+        std::vector<HmProb> hp(n_views);
+        for (uint32_t v = 0; v < n_views; ++v)
+            hp[v] = HmProb{(const uint4*)d_q, (const uint32_t*)d_nq, cap_per_img,
+                           (const uint4*)d_views + (size_t)view_idx[v] * cap_per_img * 4,
+                           (const uint32_t*)d_nviews + view_idx[v], cap_per_img,
+                           (akz_neighbor*)d_out + (size_t)v * cap_per_img * k};
+        return launch_knn2(c, hp.data(), n_views, cap_per_img, 0, (int)k);
+    });
 }
 
 // Timing of the k-NN kernel launches (HIP events on hm_stream()): enable, run, then read the accumulated
 // milliseconds and launch count.  hm_timing_get synchronises the pending events.
 extern "C" int32_t hm_timing_enable(hm_ctx* c, int32_t on)
 {
-    if (!c) return AKZ_E_INVALID;
-    c->timing = on != 0;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        c->timing = on != 0;
+        return AKZ_OK;
+    });
 }
 extern "C" int32_t hm_timing_get(hm_ctx* c, double* ms, uint64_t* launches, int32_t reset)
 {
-    if (!c) return AKZ_E_INVALID;
-    for (auto& pr : c->t_pending) {
-        float t = 0.0f;
-        hipEventSynchronize(pr.second);
-        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) c->t_ms += (double)t;
-        c->t_pool.push_back(pr.first);
-        c->t_pool.push_back(pr.second);
-    }
-    c->t_pending.clear();
-    if (ms) *ms = c->t_ms;
-    if (launches) *launches = c->t_launches;
-    if (reset) {
-        c->t_ms = 0.0;
-        c->t_launches = 0;
-    }
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        for (auto& pr : c->t_pending) {
+            float t = 0.0f;
+            hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) c->t_ms += (double)t;
+            c->t_pool.push_back(pr.first);
+            c->t_pool.push_back(pr.second);
+        }
+        c->t_pending.clear();
+        if (ms) *ms = c->t_ms;
+        if (launches) *launches = c->t_launches;
+        if (reset) {
+            c->t_ms = 0.0;
+            c->t_launches = 0;
+        }
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uint32_t nb,
                             int32_t rule, uint32_t param_u, float param_f, int32_t symmetric, uint32_t* pairs,
                             uint32_t cap, uint32_t* n_out)
 {
-    if (!c || !n_out || (na && !a) || (nb && !b) || (cap && !pairs)) return AKZ_E_INVALID;
-    if (rule < 0 || rule > 2) return AKZ_E_INVALID;
-    if (na > c->max_q || nb > c->max_t) return AKZ_E_TOO_LARGE;
-    *n_out = 0;
-    if (na < 2 || nb < 2) {
-        // cv-sfm returns no matches (cv-sfm/src/lib.rs:3099-3101); the tutorial/test call sites would
-        // panic indexing knn[1] — reported as an invalid argument instead of aborting.
-        return rule == HM_RULE_BETTER_BY ? AKZ_OK : AKZ_E_INVALID;
-    }
-    AKZ_HIP(hipSetDevice(c->device));
-    const size_t pair_off = akz_align_up(knn_stage_bytes(2), 256);
-    AKZ_TRY(hm_ensure_probs(c, pair_off + sizeof(HmPairProb) + 256));
-    uint32_t cnt[2] = {na, nb};
-    AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_a, a, (size_t)na * 64, hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_b, b, (size_t)nb * 64, hipMemcpyHostToDevice, c->stream));
-    HmProb p[2] = {{c->d_a, c->d_na, na, c->d_b, c->d_na + 1, nb, c->d_fwd},
-                   {c->d_b, c->d_na + 1, nb, c->d_a, c->d_na, na, c->d_rev}};
-    AKZ_TRY(launch_knn2(c, p, symmetric ? 2 : 1, na > nb ? na : nb, 0));
-    uint32_t kcap = cap < na ? cap : na;
-    HmPairProb pp = {c->d_fwd, c->d_rev, c->d_na, c->d_na + 1, na, nb, c->d_pairs, kcap, c->d_npairs};
-    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + pair_off);
-    AKZ_TRY(hm_push_probs(c, pair_off, &pp, sizeof(pp)));
-    hipLaunchKernelGGL(k_pairs, dim3(1), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f, (int)symmetric);
-    AKZ_LAUNCH_CHECK();
-    uint32_t n = 0;
-    AKZ_HIP(hipMemcpyAsync(&n, c->d_npairs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    *n_out = n;
-    uint32_t ncopy = n < kcap ? n : kcap;
-    if (ncopy) AKZ_HIP(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * (size_t)ncopy, hipMemcpyDeviceToHost));
-    return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !n_out || (na && !a) || (nb && !b) || (cap && !pairs)) return AKZ_E_INVALID;
+        if (rule < 0 || rule > 2) return AKZ_E_INVALID;
+        if (na > c->max_q || nb > c->max_t) return AKZ_E_TOO_LARGE;
+        *n_out = 0;
+        if (na < 2 || nb < 2) {
+            // cv-sfm returns no matches (cv-sfm/src/lib.rs:3099-3101); the tutorial/test call sites would
+            // panic indexing knn[1] — reported as an invalid argument instead of aborting.
+            return rule == HM_RULE_BETTER_BY ? AKZ_OK : AKZ_E_INVALID;
+        }
+        AKZ_HIP(hipSetDevice(c->device));
+        const size_t pair_off = akz_align_up(knn_stage_bytes(2), 256);
+        AKZ_TRY(hm_ensure_probs(c, pair_off + sizeof(HmPairProb) + 256));
+        uint32_t cnt[2] = {na, nb};
+        AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_a, a, (size_t)na * 64, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_b, b, (size_t)nb * 64, hipMemcpyHostToDevice, c->stream));
+        HmProb p[2] = {{c->d_a, c->d_na, na, c->d_b, c->d_na + 1, nb, c->d_fwd},
+                       {c->d_b, c->d_na + 1, nb, c->d_a, c->d_na, na, c->d_rev}};
+        AKZ_TRY(launch_knn2(c, p, symmetric ? 2 : 1, na > nb ? na : nb, 0));
+        uint32_t kcap = cap < na ? cap : na;
+        HmPairProb pp = {c->d_fwd, c->d_rev, c->d_na, c->d_na + 1, na, nb, c->d_pairs, kcap, c->d_npairs};
+        HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + pair_off);
+        AKZ_TRY(hm_push_probs(c, pair_off, &pp, sizeof(pp)));
+        hipLaunchKernelGGL(k_pairs, dim3(1), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f, (int)symmetric);
+        AKZ_LAUNCH_CHECK();
+        uint32_t n = 0;
+        AKZ_HIP(hipMemcpyAsync(&n, c->d_npairs, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        *n_out = n;
+        uint32_t ncopy = n < kcap ? n : kcap;
+        if (ncopy) AKZ_HIP(hipMemcpy(pairs, c->d_pairs, sizeof(uint32_t) * 2 * (size_t)ncopy, hipMemcpyDeviceToHost));
+        return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
 }
 
 extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void* d_na, const void* d_b,
@@ -945,51 +963,53 @@ extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void*
                                          float param_f, int32_t symmetric, void* d_pairs, void* d_n_out,
                                          void* stream_to_wait)
 {
-    if (!c || !d_a || !d_na || !d_b || !d_nb || !ia || !ib || !d_pairs || !d_n_out) return AKZ_E_INVALID;
-    if (rule < 0 || rule > 2 || cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-    if (n_pairs == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    if (stream_to_wait) {
-        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
-        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
-    }
-    const uint32_t ndir = symmetric ? 2u : 1u;
-    size_t need = (size_t)n_pairs * cap_per_img * 2;
-    if (need > c->bscratch_elems) {
-        AKZ_HIP(hipStreamSynchronize(c->stream));
-        if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
-        if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
-        c->d_bfwd = c->d_brev = nullptr;
-        AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
-        AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
-        c->bscratch_elems = need;
-    }
-    size_t knn_bytes = akz_align_up(knn_stage_bytes(n_pairs * ndir), 256);
-    AKZ_TRY(hm_ensure_probs(c, knn_bytes + sizeof(HmPairProb) * n_pairs));
-    std::vector<HmProb> hp(n_pairs * ndir);
-    std::vector<HmPairProb> hpp(n_pairs);
-    const uint4* A = (const uint4*)d_a;
-    const uint4* B = (const uint4*)d_b;
-    const uint32_t* NA = (const uint32_t*)d_na;
-    const uint32_t* NB = (const uint32_t*)d_nb;
-    for (uint32_t p = 0; p < n_pairs; ++p) {
-        const uint4* qa = A + (size_t)ia[p] * cap_per_img * 4;
-        const uint4* tb = B + (size_t)ib[p] * cap_per_img * 4;
-        akz_neighbor* fwd = c->d_bfwd + (size_t)p * cap_per_img * 2;
-        akz_neighbor* rev = c->d_brev + (size_t)p * cap_per_img * 2;
-        hp[p] = HmProb{qa, NA + ia[p], cap_per_img, tb, NB + ib[p], cap_per_img, fwd};
-        if (symmetric) hp[n_pairs + p] = HmProb{tb, NB + ib[p], cap_per_img, qa, NA + ia[p], cap_per_img, rev};
-        hpp[p] = HmPairProb{fwd, rev, NA + ia[p], NB + ib[p], cap_per_img, cap_per_img,
-                            (uint32_t*)d_pairs + (size_t)p * cap_per_img * 2, cap_per_img,
-                            (uint32_t*)d_n_out + p};
-    }
-    AKZ_TRY(launch_knn2(c, hp.data(), n_pairs * ndir, cap_per_img, 0));
-    HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + knn_bytes);
-    AKZ_TRY(hm_push_probs(c, knn_bytes, hpp.data(), sizeof(HmPairProb) * n_pairs));
-    hipLaunchKernelGGL(k_pairs, dim3(n_pairs), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f,
-                       (int)symmetric);
-    AKZ_LAUNCH_CHECK();
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_a || !d_na || !d_b || !d_nb || !ia || !ib || !d_pairs || !d_n_out) return AKZ_E_INVALID;
+        if (rule < 0 || rule > 2 || cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+        if (n_pairs == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        const uint32_t ndir = symmetric ? 2u : 1u;
+        size_t need = (size_t)n_pairs * cap_per_img * 2;
+        if (need > c->bscratch_elems) {
+            AKZ_HIP(hipStreamSynchronize(c->stream));
+            if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
+            if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
+            c->d_bfwd = c->d_brev = nullptr;
+            AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
+            AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
+            c->bscratch_elems = need;
+        }
+        size_t knn_bytes = akz_align_up(knn_stage_bytes(n_pairs * ndir), 256);
+        AKZ_TRY(hm_ensure_probs(c, knn_bytes + sizeof(HmPairProb) * n_pairs));
+        std::vector<HmProb> hp(n_pairs * ndir);
+        std::vector<HmPairProb> hpp(n_pairs);
+        const uint4* A = (const uint4*)d_a;
+        const uint4* B = (const uint4*)d_b;
+        const uint32_t* NA = (const uint32_t*)d_na;
+        const uint32_t* NB = (const uint32_t*)d_nb;
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            const uint4* qa = A + (size_t)ia[p] * cap_per_img * 4;
+            const uint4* tb = B + (size_t)ib[p] * cap_per_img * 4;
+            akz_neighbor* fwd = c->d_bfwd + (size_t)p * cap_per_img * 2;
+            akz_neighbor* rev = c->d_brev + (size_t)p * cap_per_img * 2;
+            hp[p] = HmProb{qa, NA + ia[p], cap_per_img, tb, NB + ib[p], cap_per_img, fwd};
+            if (symmetric) hp[n_pairs + p] = HmProb{tb, NB + ib[p], cap_per_img, qa, NA + ia[p], cap_per_img, rev};
+            hpp[p] = HmPairProb{fwd, rev, NA + ia[p], NB + ib[p], cap_per_img, cap_per_img,
+                                (uint32_t*)d_pairs + (size_t)p * cap_per_img * 2, cap_per_img,
+                                (uint32_t*)d_n_out + p};
+        }
+        AKZ_TRY(launch_knn2(c, hp.data(), n_pairs * ndir, cap_per_img, 0));
+        HmPairProb* dpp = reinterpret_cast<HmPairProb*>((char*)c->d_probs + knn_bytes);
+        AKZ_TRY(hm_push_probs(c, knn_bytes, hpp.data(), sizeof(HmPairProb) * n_pairs));
+        hipLaunchKernelGGL(k_pairs, dim3(n_pairs), dim3(1024), 0, c->stream, dpp, (int)rule, param_u, param_f,
+                           (int)symmetric);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1037,17 +1057,19 @@ extern "C" int32_t hm_hash_bag_device(hm_ctx* c, const void* d_descs, const void
                                       uint32_t n_frames, const void* d_codewords, uint32_t n_codewords, void* d_hash,
                                       void* d_words, void* stream_to_wait)
 {
-    if (!c || !d_descs || !d_counts || !d_codewords || !d_hash || !d_words) return AKZ_E_INVALID;
-    if (n_codewords == 0 || (n_codewords & 31u) || n_codewords >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-    if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1)) || n_frames > 65535u) return AKZ_E_INVALID;
-    if (n_frames == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    if (stream_to_wait) {
-        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
-        AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
-    }
-    return hash_bag_launch(c, (const uint4*)d_descs, (const uint32_t*)d_counts, cap_per_img, n_frames,
-                           (const uint4*)d_codewords, n_codewords, (uint32_t*)d_hash, (akz_neighbor*)d_words);
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_descs || !d_counts || !d_codewords || !d_hash || !d_words) return AKZ_E_INVALID;
+        if (n_codewords == 0 || (n_codewords & 31u) || n_codewords >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+        if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1)) || n_frames > 65535u) return AKZ_E_INVALID;
+        if (n_frames == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        return hash_bag_launch(c, (const uint4*)d_descs, (const uint32_t*)d_counts, cap_per_img, n_frames,
+                               (const uint4*)d_codewords, n_codewords, (uint32_t*)d_hash, (akz_neighbor*)d_words);
+    });
 }
 
 // grow-only device scratch of the host-buffer place-recognition calls
@@ -1066,24 +1088,26 @@ static int32_t hm_lsh_scratch(hm_ctx* c, size_t bytes)
 extern "C" int32_t hm_hash_bag(hm_ctx* c, const akz_descriptor* feats, uint32_t n, const akz_descriptor* codewords,
                                uint32_t n_codewords, uint8_t* hash, akz_neighbor* words)
 {
-    if (!c || (n && !feats) || !codewords || !hash) return AKZ_E_INVALID;
-    if (n_codewords == 0 || (n_codewords & 31u)) return AKZ_E_INVALID;
-    if (n > c->max_q || n_codewords > c->max_t) return AKZ_E_TOO_LARGE;
-    AKZ_HIP(hipSetDevice(c->device));
-    const uint32_t cap = n ? n : 1u;
-    const size_t hash_off = akz_align_up(sizeof(akz_neighbor) * (size_t)cap, 256);
-    AKZ_TRY(hm_lsh_scratch(c, hash_off + n_codewords / 8));
-    akz_neighbor* d_words = reinterpret_cast<akz_neighbor*>(c->d_lsh);
-    uint32_t* d_hash = reinterpret_cast<uint32_t*>((char*)c->d_lsh + hash_off);
-    AKZ_HIP(hipMemcpyAsync(c->d_na, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if (n) AKZ_HIP(hipMemcpyAsync(c->d_a, feats, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(c->d_b, codewords, (size_t)n_codewords * 64, hipMemcpyHostToDevice, c->stream));
-    AKZ_TRY(hash_bag_launch(c, c->d_a, c->d_na, cap, 1, c->d_b, n_codewords, d_hash, d_words));
-    AKZ_HIP(hipMemcpyAsync(hash, d_hash, n_codewords / 8, hipMemcpyDeviceToHost, c->stream));
-    if (words && n)
-        AKZ_HIP(hipMemcpyAsync(words, d_words, sizeof(akz_neighbor) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || (n && !feats) || !codewords || !hash) return AKZ_E_INVALID;
+        if (n_codewords == 0 || (n_codewords & 31u)) return AKZ_E_INVALID;
+        if (n > c->max_q || n_codewords > c->max_t) return AKZ_E_TOO_LARGE;
+        AKZ_HIP(hipSetDevice(c->device));
+        const uint32_t cap = n ? n : 1u;
+        const size_t hash_off = akz_align_up(sizeof(akz_neighbor) * (size_t)cap, 256);
+        AKZ_TRY(hm_lsh_scratch(c, hash_off + n_codewords / 8));
+        akz_neighbor* d_words = reinterpret_cast<akz_neighbor*>(c->d_lsh);
+        uint32_t* d_hash = reinterpret_cast<uint32_t*>((char*)c->d_lsh + hash_off);
+        AKZ_HIP(hipMemcpyAsync(c->d_na, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (n) AKZ_HIP(hipMemcpyAsync(c->d_a, feats, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_b, codewords, (size_t)n_codewords * 64, hipMemcpyHostToDevice, c->stream));
+        AKZ_TRY(hash_bag_launch(c, c->d_a, c->d_na, cap, 1, c->d_b, n_codewords, d_hash, d_words));
+        AKZ_HIP(hipMemcpyAsync(hash, d_hash, n_codewords / 8, hipMemcpyDeviceToHost, c->stream));
+        if (words && n)
+            AKZ_HIP(hipMemcpyAsync(words, d_words, sizeof(akz_neighbor) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        return AKZ_OK;
+    });
 }
 
 // Hamming distance of one query hash to every stored hash: one wave per stored hash (512-byte hashes are one
@@ -1107,29 +1131,31 @@ __global__ __launch_bounds__(256) void k_hash_dist(const uint32_t* __restrict__ 
 extern "C" int32_t hm_hash_knn(hm_ctx* c, const uint8_t* query, const uint8_t* hashes, uint32_t n, uint32_t hash_bytes,
                                uint32_t k, akz_neighbor* out, uint32_t* n_out)
 {
-    if (!c || !query || (n && !hashes) || !n_out || (k && !out)) return AKZ_E_INVALID;
-    if (hash_bytes == 0 || (hash_bytes & 3u)) return AKZ_E_INVALID;
-    *n_out = 0;
-    if (n == 0 || k == 0) return AKZ_OK;
-    AKZ_HIP(hipSetDevice(c->device));
-    const uint32_t words = hash_bytes / 4u;
-    const size_t q_off = akz_align_up((size_t)n * hash_bytes, 256), d_off = q_off + akz_align_up(hash_bytes, 256);
-    AKZ_TRY(hm_lsh_scratch(c, d_off + sizeof(uint32_t) * (size_t)n));
-    uint32_t* d_h = reinterpret_cast<uint32_t*>(c->d_lsh);
-    uint32_t* d_q = reinterpret_cast<uint32_t*>((char*)c->d_lsh + q_off);
-    uint32_t* d_d = reinterpret_cast<uint32_t*>((char*)c->d_lsh + d_off);
-    AKZ_HIP(hipMemcpyAsync(d_h, hashes, (size_t)n * hash_bytes, hipMemcpyHostToDevice, c->stream));
-    AKZ_HIP(hipMemcpyAsync(d_q, query, hash_bytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_hash_dist, dim3((n + 3u) / 4u), dim3(256), 0, c->stream, d_q, d_h, n, words, d_d);
-    AKZ_LAUNCH_CHECK();
-    std::vector<uint32_t> dist(n);
-    AKZ_HIP(hipMemcpyAsync(dist.data(), d_d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    AKZ_HIP(hipStreamSynchronize(c->stream));
-    std::vector<uint64_t> keys(n);
-    for (uint32_t i = 0; i < n; ++i) keys[i] = ((uint64_t)dist[i] << 32) | i;
-    const uint32_t m = k < n ? k : n;
-    std::partial_sort(keys.begin(), keys.begin() + m, keys.end());
-    for (uint32_t i = 0; i < m; ++i) out[i] = akz_neighbor{(uint32_t)keys[i], (uint32_t)(keys[i] >> 32)};
-    *n_out = m;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !query || (n && !hashes) || !n_out || (k && !out)) return AKZ_E_INVALID;
+        if (hash_bytes == 0 || (hash_bytes & 3u)) return AKZ_E_INVALID;
+        *n_out = 0;
+        if (n == 0 || k == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        const uint32_t words = hash_bytes / 4u;
+        const size_t q_off = akz_align_up((size_t)n * hash_bytes, 256), d_off = q_off + akz_align_up(hash_bytes, 256);
+        AKZ_TRY(hm_lsh_scratch(c, d_off + sizeof(uint32_t) * (size_t)n));
+        uint32_t* d_h = reinterpret_cast<uint32_t*>(c->d_lsh);
+        uint32_t* d_q = reinterpret_cast<uint32_t*>((char*)c->d_lsh + q_off);
+        uint32_t* d_d = reinterpret_cast<uint32_t*>((char*)c->d_lsh + d_off);
+        AKZ_HIP(hipMemcpyAsync(d_h, hashes, (size_t)n * hash_bytes, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(d_q, query, hash_bytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_hash_dist, dim3((n + 3u) / 4u), dim3(256), 0, c->stream, d_q, d_h, n, words, d_d);
+        AKZ_LAUNCH_CHECK();
+        std::vector<uint32_t> dist(n);
+        AKZ_HIP(hipMemcpyAsync(dist.data(), d_d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        std::vector<uint64_t> keys(n);
+        for (uint32_t i = 0; i < n; ++i) keys[i] = ((uint64_t)dist[i] << 32) | i;
+        const uint32_t m = k < n ? k : n;
+        std::partial_sort(keys.begin(), keys.begin() + m, keys.end());
+        for (uint32_t i = 0; i < m; ++i) out[i] = akz_neighbor{(uint32_t)keys[i], (uint32_t)(keys[i] >> 32)};
+        *n_out = m;
+        return AKZ_OK;
+    });
 }

@@ -385,122 +385,132 @@ struct rs_ctx {
 
 extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_hyp, rs_ctx** out)
 {
-    if (!out || max_matches < 8 || max_hyp == 0 || max_hyp > (1u << 28)) return AKZ_E_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
-    AKZ_HIP(hipSetDevice(device));
-    rs_ctx* c = new rs_ctx();
-    c->device = device;
-    c->max_matches = max_matches;
-    c->max_hyp = max_hyp;
-    AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * (size_t)max_matches));
-    AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 3 * (size_t)max_matches));
-    AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * (size_t)max_hyp));
-    AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12));
-    AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * (size_t)max_hyp));
-    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * (size_t)max_hyp));
-    AKZ_HIP(hipMalloc(&c->d_w, sizeof(double) * 4 * (size_t)max_matches));
-    AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * (size_t)max_hyp));
-    AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
-    AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
-    AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * 4));
-    *out = c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!out || max_matches < 8 || max_hyp == 0 || max_hyp > (1u << 28)) return AKZ_E_INVALID;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
+        AKZ_HIP(hipSetDevice(device));
+        rs_ctx* c = new rs_ctx();
+        c->device = device;
+        c->max_matches = max_matches;
+        c->max_hyp = max_hyp;
+        AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * (size_t)max_matches));
+        AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 3 * (size_t)max_matches));
+        AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12));
+        AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_w, sizeof(double) * 4 * (size_t)max_matches));
+        AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
+        AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
+        AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * 4));
+        *out = c;
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t rs_destroy(rs_ctx* c)
 {
-    if (!c) return AKZ_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
-    hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
-    if (c->stream) hipStreamDestroy(c->stream);
-    delete c;
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_OK;
+        hipSetDevice(c->device);
+        if (c->stream) hipStreamSynchronize(c->stream);
+        hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
+        hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
+        if (c->stream) hipStreamDestroy(c->stream);
+        delete c;
+        return AKZ_OK;
+    });
 }
 
 // cv_pinhole::CameraIntrinsics::calibrate / CameraIntrinsicsK1Distortion::calibrate: host scalar math.
 extern "C" int32_t rs_calibrate(const double* intr, int32_t use_k1, double k1, const akz_keypoint* kps, uint32_t n,
                                 double* out)
 {
-    if (!intr || (n && (!kps || !out))) return AKZ_E_INVALID;
-    for (uint32_t i = 0; i < n; ++i) {
-        double cx = (double)kps[i].x - intr[2], cy = (double)kps[i].y - intr[3];
-        double y = cy / intr[1];
-        double x = (cx - intr[4] * y) / intr[0];
-        if (use_k1) {
-            double r2 = x * x + y * y;
-            double d = 1.0 + k1 * r2;
-            x = x / d;
-            y = y / d;
+    return akz_guard([&]() -> int32_t {
+        if (!intr || (n && (!kps || !out))) return AKZ_E_INVALID;
+        for (uint32_t i = 0; i < n; ++i) {
+            double cx = (double)kps[i].x - intr[2], cy = (double)kps[i].y - intr[3];
+            double y = cy / intr[1];
+            double x = (cx - intr[4] * y) / intr[0];
+            if (use_k1) {
+                double r2 = x * x + y * y;
+                double d = 1.0 + k1 * r2;
+                x = x / d;
+                y = y / d;
+            }
+            double nrm = sqrt(x * x + y * y + 1.0 * 1.0);
+            out[3 * i + 0] = x / nrm;
+            out[3 * i + 1] = y / nrm;
+            out[3 * i + 2] = 1.0 / nrm;
         }
-        double nrm = sqrt(x * x + y * y + 1.0 * 1.0);
-        out[3 * i + 0] = x / nrm;
-        out[3 * i + 1] = y / nrm;
-        out[3 * i + 2] = 1.0 / nrm;
-    }
-    return AKZ_OK;
+        return AKZ_OK;
+    });
 }
 
 extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
                                       const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
                                       uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
 {
-    if (!c || !bearings_a || !bearings_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
-        return AKZ_E_INVALID;
-    if (n < 8 || n_hyp == 0) return AKZ_E_INVALID;  // EightPoint::MIN_SAMPLES (eight-point/src/lib.rs:73)
-    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
-    for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
-        if (sample_idx[i] >= n) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-    hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
-                       c->d_samples, n_hyp, c->d_poses, c->d_ok);
-    AKZ_LAUNCH_CHECK();
-    // grid.y is limited to 65535: score the poses in slabs
-    const uint32_t n_pose = n_hyp * 4;
-    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
-        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
-        hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
-                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+    return akz_guard([&]() -> int32_t {
+        if (!c || !bearings_a || !bearings_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
+            return AKZ_E_INVALID;
+        if (n < 8 || n_hyp == 0) return AKZ_E_INVALID;  // EightPoint::MIN_SAMPLES (eight-point/src/lib.rs:73)
+        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+        for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
+            if (sample_idx[i] >= n) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
+                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
         AKZ_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
-    AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
-                       c->d_inl, n, c->d_ninl, c->d_best_pose);
-    AKZ_LAUNCH_CHECK();
-    uint32_t best[2] = {0, 0}, ninl = 0;
-    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipStreamSynchronize(s));
-    c->last_hyp = n_hyp;
-    *best_id = best[0];
-    *n_inliers = ninl;
-    if (best[0] == 0xFFFFFFFFu) {
-        *n_inliers = 0;
-        return AKZ_OK;  // Consensus::model_inliers returned None: no hypothesis produced a model
-    }
-    uint32_t ncopy = ninl < cap ? ninl : cap;
-    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+        // grid.y is limited to 65535: score the poses in slabs
+        const uint32_t n_pose = n_hyp * 4;
+        for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+            uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
+                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+            AKZ_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
+                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+        AKZ_LAUNCH_CHECK();
+        uint32_t best[2] = {0, 0}, ninl = 0;
+        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipStreamSynchronize(s));
+        c->last_hyp = n_hyp;
+        *best_id = best[0];
+        *n_inliers = ninl;
+        if (best[0] == 0xFFFFFFFFu) {
+            *n_inliers = 0;
+            return AKZ_OK;  // Consensus::model_inliers returned None: no hypothesis produced a model
+        }
+        uint32_t ncopy = ninl < cap ? ninl : cap;
+        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
 }
 
 // parity tap: inlier count of every (hypothesis, pose) of the last rs_essential_batch call
 extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
 {
-    if (!c || !counts) return AKZ_E_INVALID;
-    if (cap < c->last_hyp * 4) return AKZ_E_CAPACITY;
-    AKZ_HIP(hipSetDevice(c->device));
-    AKZ_HIP(hipMemcpy(counts, c->d_counts, sizeof(uint32_t) * 4 * (size_t)c->last_hyp, hipMemcpyDeviceToHost));
-    return AKZ_OK;
+    return akz_guard([&]() -> int32_t {
+        if (!c || !counts) return AKZ_E_INVALID;
+        if (cap < c->last_hyp * 4) return AKZ_E_CAPACITY;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_HIP(hipMemcpy(counts, c->d_counts, sizeof(uint32_t) * 4 * (size_t)c->last_hyp, hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    });
 }
 
 // Consensus::model_inliers(&LambdaTwist::new(), world_matches) with the sampler factored out
@@ -509,46 +519,48 @@ extern "C" int32_t rs_p3p_batch(rs_ctx* c, const double* bearings, const double*
                                 const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
                                 uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
 {
-    if (!c || !bearings || !world || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
-        return AKZ_E_INVALID;
-    if (n < 3 || n_hyp == 0) return AKZ_E_INVALID;  // LambdaTwist::MIN_SAMPLES (lambda-twist/src/lib.rs:333)
-    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
-    for (size_t i = 0; i < (size_t)n_hyp * 3; ++i)
-        if (sample_idx[i] >= n) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    AKZ_HIP(hipMemcpyAsync(c->d_a, bearings, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(c->d_w, world, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 3 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-    hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
-                       c->d_poses, c->d_ok);
-    AKZ_LAUNCH_CHECK();
-    const uint32_t n_pose = n_hyp * 4;
-    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
-        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
-        hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_w, n,
-                           c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+    return akz_guard([&]() -> int32_t {
+        if (!c || !bearings || !world || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
+            return AKZ_E_INVALID;
+        if (n < 3 || n_hyp == 0) return AKZ_E_INVALID;  // LambdaTwist::MIN_SAMPLES (lambda-twist/src/lib.rs:333)
+        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+        for (size_t i = 0; i < (size_t)n_hyp * 3; ++i)
+            if (sample_idx[i] >= n) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_w, world, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 3 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+        hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
+                           c->d_poses, c->d_ok);
         AKZ_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
-    AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, thresh,
-                       c->d_inl, n, c->d_ninl, c->d_best_pose);
-    AKZ_LAUNCH_CHECK();
-    uint32_t best[2] = {0, 0}, ninl = 0;
-    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipStreamSynchronize(s));
-    c->last_hyp = n_hyp;
-    *best_id = best[0];
-    *n_inliers = ninl;
-    if (best[0] == 0xFFFFFFFFu) {
-        *n_inliers = 0;
-        return AKZ_OK;
-    }
-    uint32_t ncopy = ninl < cap ? ninl : cap;
-    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+        const uint32_t n_pose = n_hyp * 4;
+        for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+            uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+            hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_w, n,
+                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+            AKZ_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, thresh,
+                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+        AKZ_LAUNCH_CHECK();
+        uint32_t best[2] = {0, 0}, ninl = 0;
+        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipStreamSynchronize(s));
+        c->last_hyp = n_hyp;
+        *best_id = best[0];
+        *n_inliers = ninl;
+        if (best[0] == 0xFFFFFFFFu) {
+            *n_inliers = 0;
+            return AKZ_OK;
+        }
+        uint32_t ncopy = ninl < cap ? ninl : cap;
+        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
 }
