@@ -197,6 +197,35 @@ __device__ __forceinline__ void knn_keys(const v16i32& nacc, uint32_t t0, uint32
     for (int i = 0; i < KNN; ++i) topk_insert<KNN>(k, l[i] + row0);
 }
 
+// knn_keys for accumulators that already ARE tile-local keys (the FP4 kernel): with the targets' block scale at
+// 2^5 and the bias block at 1.5 * 2^23 + off(r), register r holds the f32 1.5 * 2^23 + 32 nacc + off(r), whose bit
+// pattern 0x4B400000 + 32 nacc + off orders like (nacc, off) as a signed integer — no key has to be built.  The
+// tile's KNN smallest become global keys (nacc << 21) | (row0 + off): `<< 16` moves 32 nacc to bit 21 and drops
+// the constant (its lowest set bit is bit 22), the low five bits are off, and off never uses bit 2, so
+// `| row0` (row0 = t0 + 4 half) adds it.  Three instructions per survivor instead of one per register.
+template <bool TAIL, int KNN>
+__device__ __forceinline__ void knn_keys_tagged(const v16i32& raw, uint32_t t0, uint32_t half, uint32_t nt, int (&k)[KNN])
+{
+    const int row0 = (int)(t0 + 4u * half);
+    int l[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) l[i] = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int off = (r & 3) + 8 * (r >> 2);
+        int key = raw[r];
+        if (TAIL) key = (uint32_t)(row0 + off) < nt ? key : 0x7FFFFFFF;
+        topk_insert<KNN>(l, key);
+    }
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) {
+        const int low = (l[i] & 31) | row0;
+        int g = (int)(((uint32_t)l[i] << 16) & 0xFFE00000u) | low;
+        if (TAIL) g = l[i] == 0x7FFFFFFF ? 0x7FFFFFFF : g;
+        topk_insert<KNN>(k, g);
+    }
+}
+
 template <int KNN>
 __device__ __forceinline__ void knn_tile(const uint4* __restrict__ tp, const v4i32 (&qb)[16], uint32_t t0,
                                          uint32_t half, uint32_t nt, int (&k)[KNN])
@@ -355,15 +384,17 @@ __device__ __forceinline__ void knn_chain4(const uint4* __restrict__ tp, const v
         const v8i32 b = {qb[i][0], qb[i][1], qb[i][2], qb[i][3], 0, 0, 0, 0};
         if (i + 4 < 8) f[i & 3] = tp[2 * (i + 4)];
         // the chain starts from the resident bias block (D != C): no per-tile accumulator initialisation
-        if (i == 0) out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, bias, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-        else out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, out, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        // block scales: targets 2^5 (E8M0 0x84), queries 1 (0x7F): the accumulators are tile-local keys, see
+        // knn_keys_tagged
+        if (i == 0) out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+        else out = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, out, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
     }
-    if (EPI) knn_keys<false, KNN>(__builtin_bit_cast(v16i32, prev), tprev, half, 0u, k);
+    if (EPI) knn_keys_tagged<false, KNN>(__builtin_bit_cast(v16i32, prev), tprev, half, 0u, k);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, KNN == 3 ? 12 : 7, 0);
+        if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, KNN == 3 ? 10 : 6, 0);
         if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 }
@@ -412,7 +443,7 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma4(const HmProbX* __re
         // 1.5 * 2^23 in sixteen registers that stay put (opaque to the compiler, or it re-creates them per tile)
         v16f32 bias;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bias[i] = 12582912.0f;
+        for (int i = 0; i < 16; ++i) bias[i] = 12582912.0f + (float)((i & 3) + 8 * (i >> 2));   // + off(r): the row tag
         asm volatile("" : "+v"(bias));
         v16f32 acc0 = bias, acc1 = bias;
         // one pipeline step: tile at t0 (in buffer `buf`) -> `out`, epilogue of `prev` (tile t0 - 32)
@@ -430,8 +461,8 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma4(const HmProbX* __re
 #define HM_LAST(acc)                                                                                             \
         if (wave_on) {                                                                                           \
             const v16i32 nacc = __builtin_bit_cast(v16i32, acc);                                                 \
-            if (t0 + 32u <= nt) knn_keys<false, KNN>(nacc, t0, half, nt, k);                                     \
-            else knn_keys<true, KNN>(nacc, t0, half, nt, k);                                                     \
+            if (t0 + 32u <= nt) knn_keys_tagged<false, KNN>(nacc, t0, half, nt, k);                              \
+            else knn_keys_tagged<true, KNN>(nacc, t0, half, nt, k);                                              \
         }
         HM_STEP(false, acc0, acc1)
         if (!more) {

@@ -6,7 +6,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 // A: 32 rows x 64 k (fp4), B: 64 k x 32 cols. lane l: row/col = l & 31, k block = l >> 5 (32 values = 16 bytes)
-__global__ void k(const uint4* a, const uint4* b, float* out, float init)
+__global__ void k(const uint4* a, const uint4* b, float* out, float init, int scaled)
 {
     const int lane = threadIdx.x;
     uint4 av = a[lane], bv = b[lane];
@@ -14,7 +14,9 @@ __global__ void k(const uint4* a, const uint4* b, float* out, float init)
     v8i B = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
     v16f c;
     for (int i = 0; i < 16; ++i) c[i] = init;
-    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    // scaled: A carries the E8M0 scale 2^5 (0x84), so the product sum arrives multiplied by 32
+    if (scaled) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+    else c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     for (int i = 0; i < 16; ++i) out[lane * 16 + i] = c[i];
 }
 int main()
@@ -35,8 +37,9 @@ int main()
     uint4 *da, *db; float* dout;
     hipMalloc(&da, 1024); hipMalloc(&db, 1024); hipMalloc(&dout, 64 * 16 * 4);
     hipMemcpy(da, ha.data(), 1024, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), 1024, hipMemcpyHostToDevice);
+    for (int scaled = 0; scaled < 2; ++scaled)
     for (float init : {0.0f, 12582912.0f}) {
-        k<<<1, 64>>>(da, db, dout, init);
+        k<<<1, 64>>>(da, db, dout, init, scaled);
         std::vector<float> o(1024);
         hipMemcpy(o.data(), dout, 4096, hipMemcpyDeviceToHost);
         int bad = 0;
@@ -45,9 +48,9 @@ int main()
                 int col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                 int dot = 0;
                 for (int kk = 0; kk < 64; ++kk) dot += A[row * 64 + kk] * B[col * 64 + kk];
-                if (o[l * 16 + r] != init + (float)dot) { if (bad < 5) printf("lane %d r %d got %f want %f\n", l, r, o[l*16+r], init + dot); ++bad; }
+                if (o[l * 16 + r] != init + (float)(scaled ? 32 * dot : dot)) { if (bad < 5) printf("lane %d r %d got %f want %f\n", l, r, o[l*16+r], init + dot); ++bad; }
             }
-        printf("init %.1f: %d mismatches\n", init, bad);
+        printf("scaled %d init %.1f: %d mismatches\n", scaled, init, bad);
     }
     return 0;
 }
