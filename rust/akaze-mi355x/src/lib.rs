@@ -3,10 +3,12 @@
 //! NOT BUILT in this repository (no Rust toolchain in the build image); kept as the reference-side
 //! binding of INTEGRATION.md.  The public surface is the one rust-cv callers use
 //! (`akaze/src/lib.rs:69-185,295-366` of rust-cv/cv): `Akaze` with its 11 public fields,
-//! `Akaze::{new, sparse, dense, extract, extract_from_gray_float_image, extract_path}` and `KeyPoint`.
+//! `Akaze::{new, sparse, dense, extract, extract_from_gray_float_image, extract_path}`, `KeyPoint`, the `image`
+//! module (`GrayFloatImage`, the separable filters, `gaussian_kernel`), a `space::Knn` implementor, the two-view
+//! consensus and the place-recognition hasher.
 use bitarray::BitArray;
 use cv_core::{nalgebra::Point2, ImagePoint};
-use image::{DynamicImage, ImageResult};
+use ::image::{DynamicImage, ImageResult};
 use std::{os::raw::c_void, path::Path, ptr};
 
 #[repr(C)]
@@ -50,6 +52,17 @@ extern "C" {
                            descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
     fn akz_extract_gray_f32(ctx: *mut c_void, img: *const f32, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
                             descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
+    fn akz_gaussian_kernel(r: f32, kernel_size: u32, out: *mut f32) -> i32;
+    fn akz_horizontal_filter(ctx: *mut c_void, img: *const f32, w: i32, h: i32, kernel: *const f32, ksize: u32,
+                             out: *mut f32) -> i32;
+    fn akz_vertical_filter(ctx: *mut c_void, img: *const f32, w: i32, h: i32, kernel: *const f32, ksize: u32,
+                           out: *mut f32) -> i32;
+    fn akz_half_size(ctx: *mut c_void, img: *const f32, w: i32, h: i32, out: *mut f32) -> i32;
+    fn rs_create(device: i32, max_matches: u32, max_hypotheses: u32, out: *mut *mut c_void) -> i32;
+    fn rs_destroy(ctx: *mut c_void) -> i32;
+    fn rs_essential_batch(ctx: *mut c_void, bearings_a: *const f64, bearings_b: *const f64, n: u32,
+                          sample_idx: *const u32, n_hyp: u32, thresh: f64, best_pose: *mut f64, best_id: *mut u32,
+                          inlier_idx: *mut u32, cap: u32, n_inliers: *mut u32) -> i32;
     fn hm_create(device: i32, max_q: u32, max_t: u32, out: *mut *mut c_void) -> i32;
     fn hm_destroy(ctx: *mut c_void) -> i32;
     fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
@@ -190,9 +203,17 @@ impl Akaze {
         }
     }
 
+    /// `Akaze::extract_from_gray_float_image` (akaze/src/lib.rs:309).
+    pub fn extract_from_gray_float_image(&self, img: &crate::image::GrayFloatImage) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
+        let (w, h) = (img.width() as u32, img.height() as u32);
+        self.run(w, h, |ctx, k, d, n| unsafe {
+            akz_extract_gray_f32(ctx, img.0.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
+        })
+    }
+
     /// `Akaze::extract_path` (akaze/src/lib.rs:361).
     pub fn extract_path(&self, path: impl AsRef<Path>) -> ImageResult<(Vec<KeyPoint>, Vec<BitArray<64>>)> {
-        Ok(self.extract(&image::open(path)?))
+        Ok(self.extract(&::image::open(path)?))
     }
 }
 
@@ -270,3 +291,120 @@ pub fn nearest_hashes(query: &BitArray<512>, hashes: &[BitArray<512>], num: usiz
     assert_eq!(st, 0);
     out.iter().take(n as usize).map(|o| (o.index as usize, o.distance)).collect()
 }
+
+/// `akaze::image` (akaze/src/image.rs): the f32 image wrapper and the separable filters, on the MI355X.
+pub mod image {
+    use super::*;
+    use ::image::{ImageBuffer, Luma};
+
+    pub type GrayImageBuffer = ImageBuffer<Luma<f32>, Vec<f32>>;
+
+    /// `GrayFloatImage` (image.rs:36).
+    #[derive(Debug, Clone)]
+    pub struct GrayFloatImage(pub GrayImageBuffer);
+
+    fn with_ctx<R>(w: u32, h: u32, f: impl FnOnce(*mut c_void) -> R) -> R {
+        let cfg = Akaze::default().config();
+        let mut ctx: *mut c_void = ptr::null_mut();
+        assert_eq!(unsafe { akz_create(&cfg, 0, w as i32, h as i32, 1, 16, &mut ctx) }, 0);
+        let r = f(ctx);
+        unsafe { akz_destroy(ctx) };
+        r
+    }
+
+    impl GrayFloatImage {
+        /// image.rs:45-109 (8-bit gray takes v / 255 per pixel; everything else goes through `to_luma32f`)
+        pub fn from_dynamic(input_image: &DynamicImage) -> Self {
+            match input_image.grayscale() {
+                DynamicImage::ImageLuma8(g) => Self(ImageBuffer::from_fn(g.width(), g.height(), |x, y| {
+                    Luma([f32::from(g.get_pixel(x, y)[0]) / 255f32])
+                })),
+                other => Self(other.to_luma32f()),
+            }
+        }
+        pub fn width(&self) -> usize { self.0.width() as usize }
+        pub fn height(&self) -> usize { self.0.height() as usize }
+        pub fn new(width: usize, height: usize) -> Self { Self(ImageBuffer::new(width as u32, height as u32)) }
+        pub fn get(&self, x: usize, y: usize) -> f32 { self.0.get_pixel(x as u32, y as u32)[0] }
+        pub fn put(&mut self, x: usize, y: usize, v: f32) { self.0.put_pixel(x as u32, y as u32, Luma([v])) }
+        /// image.rs:154-199
+        pub fn half_size(&self) -> Self {
+            let (w, h) = (self.0.width(), self.0.height());
+            let mut out = vec![0f32; ((w / 2) * (h / 2)) as usize];
+            let st = with_ctx(w, h, |ctx| unsafe {
+                akz_half_size(ctx, self.0.as_raw().as_ptr(), w as i32, h as i32, out.as_mut_ptr())
+            });
+            assert_eq!(st, 0);
+            Self(ImageBuffer::from_raw(w / 2, h / 2, out).unwrap())
+        }
+    }
+
+    fn filter(image: &GrayImageBuffer, kernel: &[f32], vertical: bool) -> GrayImageBuffer {
+        let (w, h) = (image.width(), image.height());
+        let mut out = vec![0f32; (w * h) as usize];
+        let st = with_ctx(w, h, |ctx| unsafe {
+            if vertical {
+                akz_vertical_filter(ctx, image.as_raw().as_ptr(), w as i32, h as i32, kernel.as_ptr(), kernel.len() as u32,
+                                    out.as_mut_ptr())
+            } else {
+                akz_horizontal_filter(ctx, image.as_raw().as_ptr(), w as i32, h as i32, kernel.as_ptr(),
+                                      kernel.len() as u32, out.as_mut_ptr())
+            }
+        });
+        assert_eq!(st, 0);
+        ImageBuffer::from_raw(w, h, out).unwrap()
+    }
+    /// image.rs:202
+    pub fn horizontal_filter(image: &GrayImageBuffer, kernel: &[f32]) -> GrayImageBuffer { filter(image, kernel, false) }
+    /// image.rs:253
+    pub fn vertical_filter(image: &GrayImageBuffer, kernel: &[f32]) -> GrayImageBuffer { filter(image, kernel, true) }
+    /// image.rs:333
+    pub fn separable_filter(image: &GrayImageBuffer, h_kernel: &[f32], v_kernel: &[f32]) -> GrayImageBuffer {
+        vertical_filter(&horizontal_filter(image, h_kernel), v_kernel)
+    }
+    /// image.rs:360
+    pub fn gaussian_kernel(r: f32, kernel_size: usize) -> Vec<f32> {
+        let mut k = vec![0f32; kernel_size];
+        assert_eq!(unsafe { akz_gaussian_kernel(r, kernel_size as u32, k.as_mut_ptr()) }, 0);
+        k
+    }
+    /// image.rs:383
+    pub fn gaussian_blur(image: &GrayFloatImage, r: f32) -> GrayFloatImage {
+        let size = (2.0 * (1.0 + (r - 0.8) / 0.3)).ceil() as usize;   // image.rs:385
+        let k = gaussian_kernel(r, if size % 2 == 0 { size + 1 } else { size });
+        GrayFloatImage(separable_filter(&image.0, &k, &k))
+    }
+}
+
+/// Two-view consensus on the MI355X: what `Consensus::model_inliers(&EightPoint::new(), matches)` computes
+/// (akaze/tests/estimate_pose.rs:63-67, tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1406), with the
+/// minimal samples drawn by the caller's RNG (`arrsac` draws them inside; the crate is not part of this
+/// repository).  `bearings_a[i]` / `bearings_b[i]` are the unit bearings of match i; `samples` holds 8 match
+/// indices per hypothesis.  Returns the winning pose as a row-major 3x4 `[R | t]` and the inlier indices.
+pub struct Mi355xEssentialConsensus {
+    pub inlier_threshold: f64,
+}
+impl Mi355xEssentialConsensus {
+    pub fn model_inliers(&mut self, bearings_a: &[[f64; 3]], bearings_b: &[[f64; 3]], samples: &[[u32; 8]])
+        -> Option<([f64; 12], Vec<usize>)> {
+        assert_eq!(bearings_a.len(), bearings_b.len());
+        let n = bearings_a.len() as u32;
+        let mut ctx: *mut c_void = ptr::null_mut();
+        assert_eq!(unsafe { rs_create(0, n.max(8), samples.len().max(1) as u32, &mut ctx) }, 0);
+        let mut pose = [0f64; 12];
+        let (mut best, mut n_inl) = (0u32, 0u32);
+        let mut inl = vec![0u32; n as usize];
+        let st = unsafe {
+            rs_essential_batch(ctx, bearings_a.as_ptr() as *const f64, bearings_b.as_ptr() as *const f64, n,
+                               samples.as_ptr() as *const u32, samples.len() as u32, self.inlier_threshold,
+                               pose.as_mut_ptr(), &mut best, inl.as_mut_ptr(), n, &mut n_inl)
+        };
+        unsafe { rs_destroy(ctx) };
+        assert_eq!(st, 0);
+        if best == u32::MAX {
+            return None;
+        }
+        Some((pose, inl[..n_inl as usize].iter().map(|&i| i as usize).collect()))
+    }
+}
+
