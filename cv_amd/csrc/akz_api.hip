@@ -162,7 +162,11 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
         if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
         const char* fb = getenv("AKZ_FED_BLOCK");
         if (fb && fb[0] >= '1' && fb[0] <= '8' && !fb[1]) c->fed_block = fb[0] - '0';
-        const char* pipe = getenv("AKZ_PIPELINE");
+        if (const char* e = getenv("AKZ_CONTRAST_FINE")) {
+        c->contrast_fine = !(e[0] == '0');
+        c->contrast_force_odd = e[0] == '2';
+    }
+    const char* pipe = getenv("AKZ_PIPELINE");
         c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
         if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
         if (st != AKZ_OK) {
@@ -252,6 +256,8 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_hist = cv.take<uint32_t>(B * 512);
     S.d_npoints = cv.take<uint32_t>(B);
     S.d_cthr = cv.take<double>(B * 512);
+    S.d_fine = cv.take<uint32_t>(B * 2048);
+    S.d_cflag = cv.take<uint32_t>(B);
     S.d_contrast = cv.take<double>(B);
     S.d_invk = cv.take<float>(B * 8);
     S.d_ncand = cv.take<uint32_t>(B * 32);

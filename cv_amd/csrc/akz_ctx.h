@@ -27,6 +27,8 @@ struct AkzSet {
     uint32_t* d_hist = nullptr;            // [B][nbins]
     uint32_t* d_npoints = nullptr;         // [B]
     double* d_cthr = nullptr;              // [B][512] histogram bin thresholds in magnitude^2 space
+    uint32_t* d_fine = nullptr;            // [B][2048] histogram over the f64 exponent + 6 mantissa bits of magnitude^2
+    uint32_t* d_cflag = nullptr;           // [B] 1 = the frame needs the exact histogram pass
     double* d_contrast = nullptr;          // [B]
     float* d_invk = nullptr;               // [B][8]  (1/(k_o*k_o)) as f32 per octave (nonlinear_diffusion.rs:73)
     // keypoint stage
@@ -62,6 +64,8 @@ struct akz_ctx {
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
     uint32_t max_cand = 0;    // capacity of each per-(frame, level) candidate list
     int desc_tile_shift = 5;  // log2 of the tile edge of the descriptor visiting order; env AKZ_DESC_TILE_SHIFT
+    bool contrast_force_odd = false; // AKZ_CONTRAST_FINE=2: odd frames are sent to the exact pass regardless (test knob)
+    bool contrast_fine = true; // contrast factor from the fine histogram of the max pass where that is unambiguous (AKZ_CONTRAST_FINE=0: always the exact histogram pass)
     int fed_block = 8;        // most FED steps fused per launch (1 = one launch per step; the first octave stops at 4); env AKZ_FED_BLOCK
     bool front_pair = true;   // two-frame packed front kernel (AKZ_FRONT_PAIR=0 selects the one-frame kernel)
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch

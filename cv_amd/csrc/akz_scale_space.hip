@@ -417,6 +417,113 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const In
     }
 }
 
+// ---- contrast factor without the histogram pass -------------------------------------------------------------
+// contrast_factor.rs:41-64 walks the histogram until the running count reaches threshold = floor(npoints *
+// percentile): the bin it stops after is the bin of the threshold-th smallest non-zero magnitude, so the result is
+// an ORDER STATISTIC of v = lx^2 + ly^2, k = bin(v_(threshold)) + 1.  The max pass therefore also files every
+// non-zero v by its f64 exponent and top 6 mantissa bits (kFineBins keys over [2^-22, 2^10), clamped outside);
+// k_contrast_resolve finds the key that holds rank `threshold`, and when the reference bin of the key's smallest
+// and largest possible value agree (the bin is monotone in v) that bin is the answer and the exact histogram
+// pass is skipped for the frame; otherwise the frame is flagged and k_contrast_pair<EPI_CHIST> +
+// k_contrast_finish settle it as before.
+constexpr int kFineBins = 2048;
+constexpr int kFineBase = (1023 - 22) << 6;
+__device__ __forceinline__ int fine_key(double v)
+{
+    const int k = (__double2hiint(v) >> 14) - kFineBase;
+    return k < 0 ? 0 : (k > kFineBins - 1 ? kFineBins - 1 : k);
+}
+// smallest value of key j (j >= 1) as a bit pattern
+__device__ __forceinline__ unsigned long long fine_lo_bits(int j) { return (unsigned long long)(unsigned)((j + kFineBase) << 14) << 32; }
+
+__device__ __forceinline__ void contrast_write(int f, double hmax, unsigned long long k, bool reached, int nbins,
+                                               int n_octaves, double* __restrict__ contrast, float* __restrict__ invk)
+{
+    double cf = reached ? hmax * (double)k / (double)nbins : 0.03;
+    contrast[f] = cf;
+    for (int o = 0; o < 8; ++o) {
+        if (o > 0) cf *= 0.75;
+        invk[(size_t)f * 8 + o] = (o < n_octaves) ? (float)(1.0 / (cf * cf)) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_contrast_resolve(const unsigned long long* __restrict__ cmax,
+                                                          const uint32_t* __restrict__ fine,
+                                                          const uint32_t* __restrict__ npoints,
+                                                          const double* __restrict__ thr, int nbins, double percentile,
+                                                          int n_octaves, double* __restrict__ contrast,
+                                                          float* __restrict__ invk, uint32_t* __restrict__ flag,
+                                                          int force_odd)
+{
+    __shared__ uint32_t s_sum[256];
+    __shared__ int s_key;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (force_odd && (f & 1)) {                    // test knob: odd frames always take the exact pass
+        if (tid == 0) flag[f] = 1u;
+        return;
+    }
+    const double hmax = sqrt(__longlong_as_double((long long)cmax[f]));
+    const double t = (double)npoints[f] * percentile;
+    const unsigned long long threshold = t > 0.0 ? (unsigned long long)t : 0ull;
+    if (threshold == 0ull) {                       // the reference's loop does not run: k = 0
+        if (tid == 0) {
+            contrast_write(f, hmax, 0ull, true, nbins, n_octaves, contrast, invk);
+            flag[f] = 0u;
+        }
+        return;
+    }
+    // key that holds rank `threshold`: 8 keys per thread, block scan of the partial sums
+    const uint32_t* F = fine + (size_t)f * kFineBins;
+    uint32_t loc[8], part = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        loc[i] = F[tid * 8 + i];
+        part += loc[i];
+    }
+    s_sum[tid] = part;
+    if (tid == 0) s_key = -1;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int i = 0; i < tid; ++i) before += s_sum[i];
+    if (before < threshold && before + part >= threshold) {   // exactly one thread
+        unsigned long long run = before;
+        int key = tid * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (run < threshold && run + loc[i] >= threshold) key = tid * 8 + i;
+            run += loc[i];
+        }
+        s_key = key;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const int key = s_key;
+    if (key < 0) {                                  // counts and points disagree: let the exact pass decide
+        flag[f] = 1u;
+        return;
+    }
+    const double* T = thr + (size_t)f * 512;
+    auto bin_of = [&](double x) {                   // max k in [0, nbins-1] with T[k] <= x (T ascending, T[0] = 0)
+        int lo = 0, hi = nbins - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (T[mid] <= x) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    };
+    const double vlo = key == 0 ? __longlong_as_double(1ll) : __longlong_as_double((long long)fine_lo_bits(key));
+    const double vhi = key == kFineBins - 1 ? __longlong_as_double(0x7FEFFFFFFFFFFFFFll)
+                                            : __longlong_as_double((long long)(fine_lo_bits(key + 1) - 1ull));
+    const int b0 = bin_of(vlo), b1 = bin_of(vhi);
+    if (b0 == b1) {
+        contrast_write(f, hmax, (unsigned long long)(b0 + 1), true, nbins, n_octaves, contrast, invk);
+        flag[f] = 0u;
+    } else {
+        flag[f] = 1u;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Contrast factor on two frames per block (contrast_factor.rs:16-64): the same blurred two-frame tile as the
 // level front-end (sigma 1.0, one-pixel ring), then the simple Scharr gradient and
@@ -457,7 +564,8 @@ template <typename InT, int EPI>
 __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ in, int w, int h, size_t fs, int n,
                                                         GaussTaps taps, unsigned long long* __restrict__ cmax,
                                                         const double* __restrict__ thr, uint32_t* __restrict__ hist,
-                                                        uint32_t* __restrict__ npoints, int nbins)
+                                                        uint32_t* __restrict__ npoints, int nbins,
+                                                        uint32_t* __restrict__ fine, const uint32_t* __restrict__ flag)
 {
     constexpr int R = 2, SG = 1, TH = kFTH, NT = kFNT;
     constexpr int CI = kTW + 16, CG = kTW + 8;
@@ -467,12 +575,18 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
     __shared__ uint32_t s_hist[(EPI == EPI_CHIST) ? 2 * 512 : 1];
     __shared__ double s_thr[(EPI == EPI_CHIST) ? 2 * 512 : 1];
     __shared__ double s_red[(EPI == EPI_CMAX) ? 2 * (NT / 64) : 1];
+    __shared__ uint32_t s_fine[(EPI == EPI_CMAX) ? 2 * kFineBins : 1];
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
     const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
     const int tx0 = (int)tile.x * kTW;
     const int tid = threadIdx.x, lane = tid & 63;
+    // the exact histogram is only needed for the frames k_contrast_resolve could not settle
+    if (EPI == EPI_CHIST && flag && !flag[fa] && !flag[fb]) return;
+    if (EPI == EPI_CMAX && fine) {
+        for (int i = tid; i < 2 * kFineBins; i += NT) s_fine[i] = 0;   // ordered before use by the tile barriers
+    }
     if (EPI == EPI_CHIST) {
         for (int i = tid; i < 2 * 512; i += NT) {
             s_hist[i] = 0;
@@ -527,6 +641,10 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
                 const double v = (double)lx2[f] + (double)ly2[f];
                 if (EPI == EPI_CMAX) {
                     lmax[f] = v > lmax[f] ? v : lmax[f];
+                    if (fine && v != 0.0) {            // modg != 0: counted, and filed by magnitude for the order statistic
+                        atomicAdd(&s_fine[f * kFineBins + fine_key(v)], 1u);
+                        npts[f] += 1u;
+                    }
                 } else if (v != 0.0) {                 // modg != 0
                     const double* T = s_thr + f * 512;
                     int b = (int)((float)nbins * (sqrtf((float)v) * inv_hmax[f]));
@@ -561,11 +679,23 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
             if (mx >= 0.0 && (tid == 0 || has_b))
                 atomicMax(&cmax[tid ? fb : fa], (unsigned long long)__double_as_longlong(mx));
         }
+        if (fine) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                uint32_t v = npts[f];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                if (lane == 0 && v && (f == 0 || has_b)) atomicAdd(&npoints[f ? fb : fa], v);
+            }
+            for (int i = tid; i < 2 * kFineBins; i += NT) {   // s_fine is complete: the barrier above
+                const int f = i / kFineBins;
+                if (s_fine[i] && (f == 0 || has_b)) atomicAdd(&fine[(size_t)(f ? fb : fa) * kFineBins + (i - f * kFineBins)], s_fine[i]);
+            }
+        }
     }
     if (EPI == EPI_CHIST) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            uint32_t v = npts[f];
+            uint32_t v = flag ? 0u : npts[f];         // with the fine pass on, the points were counted there
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&s_hist[f * 512 + 511], v);
         }
@@ -784,10 +914,12 @@ __global__ __launch_bounds__(256) void k_blur_tile(const InT* __restrict__ in, i
 // inverse_k of nonlinear_diffusion.rs:73.  One thread per frame (scalar f64 work).
 __global__ void k_contrast_finish(const unsigned long long* __restrict__ cmax, const uint32_t* __restrict__ hist,
                                   const uint32_t* __restrict__ npoints, int nbins, double percentile, int n,
-                                  int n_octaves, double* __restrict__ contrast, float* __restrict__ invk)
+                                  int n_octaves, double* __restrict__ contrast, float* __restrict__ invk,
+                                  const uint32_t* __restrict__ flag)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
+    if (flag && !flag[f]) return;                  // settled by k_contrast_resolve
     double hmax = sqrt(__longlong_as_double((long long)cmax[f]));
     double num_points = (double)npoints[f];
     double t = num_points * percentile;
@@ -798,12 +930,7 @@ __global__ void k_contrast_finish(const unsigned long long* __restrict__ cmax, c
         num_elements += hist[(size_t)f * nbins + k];
         k += 1;
     }
-    double cf = (num_elements >= threshold) ? hmax * (double)k / (double)nbins : 0.03;
-    contrast[f] = cf;
-    for (int o = 0; o < 8; ++o) {
-        if (o > 0) cf *= 0.75;
-        invk[(size_t)f * 8 + o] = (o < n_octaves) ? (float)(1.0 / (cf * cf)) : 0.0f;
-    }
+    contrast_write(f, hmax, (unsigned long long)k, num_elements >= threshold, nbins, n_octaves, contrast, invk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1513,22 +1640,34 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
     AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * 32 * (size_t)n, s));
-    if ((w & 3) == 0 && c->front_pair && nbins <= 510) {
+    const bool pairc = (w & 3) == 0 && c->front_pair && nbins <= 510;
+    const bool fine = pairc && c->contrast_fine;
+    if (pairc) {
         dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), kCTiles), (n + 1) / 2);
+        if (fine) AKZ_HIP(hipMemsetAsync(S.d_fine, 0, sizeof(uint32_t) * (size_t)n * kFineBins, s));
         hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
-                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins);
+                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, fine ? S.d_fine : (uint32_t*)nullptr,
+                           (const uint32_t*)nullptr);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(512), 0, s, S.d_cmax, nbins, S.d_cthr);
         AKZ_LAUNCH_CHECK();
+        if (fine) {
+            hipLaunchKernelGGL(k_contrast_resolve, dim3(n), dim3(256), 0, s, S.d_cmax, S.d_fine, S.d_npoints,
+                               (const double*)S.d_cthr, nbins, c->cfg.contrast_percentile, P.n_octaves, S.d_contrast,
+                               S.d_invk, S.d_cflag, c->contrast_force_odd ? 1 : 0);
+            AKZ_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CHIST>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
-                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins);
+                           (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, (uint32_t*)nullptr,
+                           fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
         AKZ_LAUNCH_CHECK();
     } else {
         AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
         AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
     }
     hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
-                       S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk);
+                       S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk,
+                       fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
 
     uint64_t fed_launches = 0, fed_units = 0;

@@ -148,6 +148,26 @@ def test_pathological_inputs(gpu, oracle, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_contrast_factor_paths(gpu, oracle, monkeypatch, mode):
+    """The contrast factor normally comes from the order statistic of the max pass's fine histogram; frames whose
+    fine key straddles a reference bin take the exact histogram pass.  AKZ_CONTRAST_FINE=0 sends every frame
+    through the exact pass, =2 every odd frame (mixed pairs): same contrast factor, bit for bit, either way."""
+    akaze, _ = gpu
+    monkeypatch.setenv("AKZ_CONTRAST_FINE", mode)
+    frames = [synth_frame(320, 240, seed=500 + i, n_rect=10 + 7 * i, n_disc=5 + 3 * i) for i in range(5)]
+    frames[3] = np.full((240, 320), 77, np.uint8)                     # no gradient at all: zero points
+    ctx = akaze.Context(akaze.Akaze.default(), 320, 240, 5)
+    got = ctx.extract_batch(frames)
+    for i, img in enumerate(frames):
+        orc = oracle.Akaze(320, 240, oracle.default_config())
+        okp, od = orc.extract(img)
+        assert ctx.contrast(i) == orc.contrast, f"frame {i} contrast"
+        _kp_eq(got[i][0], okp, f"frame {i}")
+        _eq(got[i][1], od, f"frame {i} desc")
+    ctx.close()
+
+
 def test_f32_input_path(gpu, oracle):
     akaze, _ = gpu
     img = oracle.u8_to_f32(synth_frame(320, 240, 11))
