@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
                                                 uint32_t* __restrict__ err, const float* __restrict__ cand_nb,
                                                 uint32_t max_cand)
 {
-    __shared__ float s_rx[4][112], s_ry[4][112];
+    __shared__ float2 s_r[4][112];           // weighted {Lx, Ly} of every sample
     __shared__ uint32_t s_msk[4][112][2];   // per sample: the windows that contain its angle (bit = window)
     __shared__ float s_bnd[128];
     __shared__ uint2 s_mopen[128], s_meq[128];
@@ -757,8 +757,7 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
             float2 dxy = LXY[(size_t)iy * Lp->w + ix];
             float rx = g * dxy.x;
             float ry = g * dxy.y;
-            s_rx[wv][idx] = rx;
-            s_ry[wv][idx] = ry;
+            s_r[wv][idx] = make_float2(rx, ry);
             // Window membership of this sample (:261-287) from the end-point table: the summation below (windows
             // across the lanes, samples in order) then needs one bit test per sample instead of the predicate.
             const float ang = fast_atan2_equiv(ry, rx);
@@ -779,12 +778,16 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
             // branch-free: a sample outside the window adds +0.0, which leaves the sums bit-identical to skipping
             // it (they start at +0 and x + (+0) = x for every x but -0, which a sum that started at +0 never is)
             const int word = lane >> 5, bit = lane & 31;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
 #pragma unroll 4
             for (int k = 0; k < 109; ++k) {
                 const bool in = (s_msk[wv][k][word] >> bit) & 1u;
-                sum_x += in ? s_rx[wv][k] : 0.0f;
-                sum_y += in ? s_ry[wv][k] : 0.0f;
+                const float2 r = s_r[wv][k];
+                sum += (v2f){in ? r.x : 0.0f, in ? r.y : 0.0f};
             }
+            sum_x = sum.x;
+            sum_y = sum.y;
             val = sum_x * sum_x + sum_y * sum_y;
         }
         // the serial loop keeps the FIRST window whose val exceeds every earlier one: the earliest
