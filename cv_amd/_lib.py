@@ -39,6 +39,34 @@ class Config(C.Structure):
     ]
 
 
+class Options(C.Structure):
+    """akz_options (include/akz.h): behaviour switches of one context; all-zero = the defaults."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("flags", C.c_uint32), ("fed_block", C.c_uint32),
+        ("sup_capacity", C.c_uint32), ("max_candidates", C.c_uint32), ("desc_tile_shift", C.c_uint32),
+        ("reserved", C.c_uint32 * 10),
+    ]
+
+
+OPT_KEEP_ALL, OPT_NO_FRAME_PAIRS, OPT_SERIAL_SUPPRESSION, OPT_NO_PIPELINE = 1, 2, 4, 8
+OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD = 16, 32, 64
+HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY = 1, 2, 4
+FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
+
+
+def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=False,
+                 contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0):
+    """Options with readable names.  contrast: "fine" (default), "exact", "force_odd"."""
+    o = Options()
+    o.struct_size = C.sizeof(Options)
+    o.flags = ((OPT_KEEP_ALL if keep_all else 0) | (0 if frame_pairs else OPT_NO_FRAME_PAIRS)
+               | (0 if parallel_suppression else OPT_SERIAL_SUPPRESSION) | (0 if pipeline else OPT_NO_PIPELINE)
+               | (OPT_STREAM_PRIORITY if stream_priority else 0)
+               | {"fine": 0, "exact": OPT_CONTRAST_EXACT, "force_odd": OPT_CONTRAST_FORCE_ODD}[contrast])
+    o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift
+    return o
+
+
 class LevelInfo(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32),
@@ -55,11 +83,12 @@ assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
-    "akz_config_default", "akz_create", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_f32",
+    "akz_config_default", "akz_create", "akz_create_ex", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_u16",
+    "akz_extract_gray_f32",
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
-    "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
+    "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
@@ -94,7 +123,9 @@ def lib():
     L.akz_version.restype = C.c_char_p
     L.akz_config_default.argtypes = [C.POINTER(Config)]
     L.akz_create.argtypes = [C.POINTER(Config), i32, i32, i32, i32, u32, C.POINTER(vp)]
+    L.akz_create_ex.argtypes = [C.POINTER(Config), i32, i32, i32, i32, u32, C.POINTER(Options), C.POINTER(vp)]
     L.akz_destroy.argtypes = [vp]
+    L.akz_extract_gray_u16.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_gray_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_batch.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, vp, u32, vp]
@@ -115,6 +146,7 @@ def lib():
     L.akz_half_size.argtypes = [vp, vp, i32, i32, vp]
     L.akz_sample_colors_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, u32, vp]
     L.hm_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
+    L.hm_create_ex.argtypes = [i32, u32, u32, u32, C.POINTER(vp)]
     L.hm_destroy.argtypes = [vp]
     L.hm_knn2.argtypes = [vp, vp, u32, vp, u32, vp]
     L.hm_knn.argtypes = [vp, vp, u32, vp, u32, u32, vp]

@@ -16,9 +16,10 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import KP_DTYPE, AkzError, Config, LevelInfo, check
+from ._lib import KP_DTYPE, AkzError, Config, LevelInfo, Options, check, make_options  # noqa: F401
 
 USIZE_MAX = 2 ** 64 - 1
+MAX_KEYPOINTS = 16384   # kAkzMaxKeypoints (cv_amd/csrc/akz_common.h)
 BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5}
 
 
@@ -98,14 +99,17 @@ class Akaze:
                 self.derivative_factor, self.detector_threshold, self.descriptor_channels,
                 self.descriptor_pattern_size, self.device, self.max_keypoints)
 
-    def context(self, w, h, batch=1):
-        """A device context able to process `batch` frames of w x h (cached on the instance)."""
+    def context(self, w, h, batch=1, options=None):
+        """A device context able to process `batch` frames of w x h (cached on the instance).  `options`: an
+        akz_options (cv_amd._lib.make_options) selecting fall-back kernels / parity taps; None = defaults."""
         ctx = self.__dict__.get("_ctx")
-        if ctx is not None and (ctx.key != self._key() or w > ctx.max_w or h > ctx.max_h or batch > ctx.max_batch):
+        okey = bytes(options) if options is not None else None
+        if ctx is not None and (ctx.key != self._key() or ctx.okey != okey or w > ctx.max_w or h > ctx.max_h
+                                or batch > ctx.max_batch):
             ctx.close()
             ctx = None
         if ctx is None:
-            ctx = Context(self, w, h, batch)
+            ctx = Context(self, w, h, batch, options)
             self.__dict__["_ctx"] = ctx
         return ctx
 
@@ -128,20 +132,20 @@ class Akaze:
 
     def extract_path(self, path):
         """Akaze::extract_path (lib.rs:361): decoding errors propagate (ImageResult in the reference)."""
-        from PIL import Image  # decoding only; mirrors image::open + DynamicImage::grayscale
+        from PIL import Image  # decoding only; mirrors image::open
         im = Image.open(path)
-        if im.mode not in ("L", "I;16"):
-            im = im.convert("L")
-        return self.extract(np.asarray(im))
+        if im.mode in ("L", "I;16"):
+            return self.extract(np.asarray(im))
+        if im.mode == "LA":
+            return self.extract(np.asarray(im)[..., 0])
+        return self.extract(grayscale(np.asarray(im.convert("RGB") if im.mode not in ("RGB", "RGBA") else im)))
 
     def extract_arrays(self, image):
         """extract() returning the raw structured keypoint array instead of KeyPoint objects."""
         img = np.asarray(image)
         if img.ndim != 2:
             raise ValueError("expected a single-channel HxW image")
-        if img.dtype == np.uint16:   # image.rs:57-66: f32::from(v) / 65535f32
-            img = (img.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
-        elif img.dtype != np.uint8:
+        if img.dtype not in (np.uint8, np.uint16):   # Luma8 / Luma16 go to the device as they are (image.rs:47-66)
             img = np.ascontiguousarray(img, dtype=np.float32)
         h, w = img.shape
         return self.context(w, h, 1).extract_batch([img])[0]
@@ -150,14 +154,16 @@ class Akaze:
 class Context:
     """Owns one akz_ctx (device pyramid for up to `batch` frames of up to w x h)."""
 
-    def __init__(self, akaze, w, h, batch):
+    def __init__(self, akaze, w, h, batch, options=None):
         self.key = akaze._key()
+        self.okey = bytes(options) if options is not None else None
         self.max_w, self.max_h, self.max_batch = w, h, batch
-        self.max_kp = min(int(akaze.max_keypoints), 16384)
+        self.max_kp = min(int(akaze.max_keypoints), MAX_KEYPOINTS)
         self._h = C.c_void_p()
         cfg = akaze.config()
-        check(_lib.lib().akz_create(C.byref(cfg), akaze.device, w, h, batch, self.max_kp, C.byref(self._h)),
-              "akz_create")
+        check(_lib.lib().akz_create_ex(C.byref(cfg), akaze.device, w, h, batch, self.max_kp,
+                                       C.byref(options) if options is not None else None, C.byref(self._h)),
+              "akz_create_ex")
 
     def close(self):
         if self._h:
@@ -179,8 +185,8 @@ class Context:
         n = len(images)
         imgs = [np.ascontiguousarray(im) for im in images]
         h, w = imgs[0].shape
-        fmt = 0 if imgs[0].dtype == np.uint8 else 1
-        if fmt == 1:
+        fmt = {np.dtype(np.uint8): _lib.FMT_U8, np.dtype(np.uint16): _lib.FMT_U16}.get(imgs[0].dtype, _lib.FMT_F32)
+        if fmt == _lib.FMT_F32:
             imgs = [np.ascontiguousarray(im, dtype=np.float32) for im in imgs]
         assert all(im.shape == (h, w) and im.dtype == imgs[0].dtype for im in imgs)
         cap = self.max_kp
@@ -247,6 +253,17 @@ class Context:
         ms = C.c_double(); la = C.c_uint64(); un = C.c_uint64()
         check(_lib.lib().akz_timing_get(self._h, which, C.byref(ms), C.byref(la), C.byref(un)))
         return ms.value, la.value, un.value
+
+
+def grayscale(rgb):
+    """DynamicImage::grayscale() for RGB(A) 8/16-bit pixels as the `image` 0.24 crate computes it (integer
+    Rec. 709: (2126 R + 7152 G + 722 B) / 10000, truncating).  The crate is not vendored in the reference
+    checkout (akaze/Cargo.toml:16): colour-input parity is unpinned; gray inputs never come through here."""
+    a = np.asarray(rgb)
+    if a.ndim != 3 or a.shape[2] < 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("expected an HxWx3/4 uint8 or uint16 image")
+    l = (2126 * a[..., 0].astype(np.uint64) + 7152 * a[..., 1].astype(np.uint64) + 722 * a[..., 2].astype(np.uint64)) // 10000
+    return l.astype(a.dtype)
 
 
 # ---- akaze::image ---------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ extern "C" const char* akz_strerror(int32_t s)
     case AKZ_E_CAPACITY: return "output buffer too small";
     case AKZ_E_HIP: return "HIP runtime error";
     case AKZ_E_TOO_LARGE: return "image or batch larger than the context was created for";
-    case AKZ_E_INTERNAL: return "internal work list overflow (raise max_keypoints)";
+    case AKZ_E_INTERNAL: return "device-side overflow of an internal work list (create the context with a larger max_keypoints / akz_options.max_candidates)";
     default: return "unknown status";
     }
 }
@@ -103,18 +103,34 @@ static int32_t validate_config(const akz_config* cfg)
     if (cfg->contrast_factor_num_bins == 0 || cfg->contrast_factor_num_bins > 510) return AKZ_E_INVALID;
     if (cfg->descriptor_channels < 1 || cfg->descriptor_channels > 3) return AKZ_E_INVALID;
     if (cfg->descriptor_pattern_size < 1 || cfg->descriptor_pattern_size > 100) return AKZ_E_INVALID;
-    // the fused Gaussian tile kernel is instantiated for the radii of sigma = base_scale_offset in
-    // (1.5, 2.0] (9 taps) — the reference default 1.6 — and the fixed sigma 1.0 (5 taps)
-    if (akz_gaussian_radius((float)cfg->base_scale_offset) != 4) return AKZ_E_INVALID;
+    // any base_scale_offset the reference accepts (gaussian_blur asserts r > 0, image.rs:384); the fused tile
+    // kernel serves radius 4 (sigma in (1.5, 2.0], the default 1.6), other radii the dense filter
+    if (2 * akz_gaussian_radius((float)cfg->base_scale_offset) + 1 > kAkzMaxTaps) return AKZ_E_INVALID;
     return AKZ_OK;
 }
 
-extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h, int32_t max_batch,
-                              uint32_t max_keypoints, akz_ctx** out)
+extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h, int32_t max_batch,
+                                 uint32_t max_keypoints, const akz_options* opts, akz_ctx** out)
 {
     return akz_guard([&]() -> int32_t {
         if (!cfg || !out || max_w < 3 || max_h < 3 || max_batch < 1 || max_w > 65535 || max_h > 65535) return AKZ_E_INVALID;
         AKZ_TRY(validate_config(cfg));
+        akz_options o;
+        memset(&o, 0, sizeof(o));
+        if (opts) {
+            // a caller built against an older (shorter) struct passes its own size; unknown tail = defaults
+            if (opts->struct_size < 2 * sizeof(uint32_t) || opts->struct_size > 4096) return AKZ_E_INVALID;
+            memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
+            for (uint32_t r : o.reserved)
+                if (r) return AKZ_E_INVALID;
+            if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
+        }
+        {
+            // every per-frame table has kAkzMaxLevels slots per frame: refuse before anything is launched
+            AkzPlan probe;
+            akz_build_plan(*cfg, max_w, max_h, &probe);
+            if ((int)probe.levels.size() > kAkzMaxLevels) return AKZ_E_INVALID;
+        }
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -130,26 +146,26 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
         c->max_h = max_h;
         c->max_batch = max_batch;
         c->max_kp = max_keypoints ? max_keypoints : 16384u;
-        if (c->max_kp > 16384u) c->max_kp = 16384u;  // k_sort keeps the keys of one frame in LDS
-        c->max_cand = c->max_kp;  // per (frame, level) candidate capacity; k_cand_sort keeps one list in LDS
-        c->sup_cap = 4u * c->max_kp;   // all levels together: frames with more candidates take the serial pass
-        {
-            const char* sp = getenv("AKZ_SUP_PARALLEL");
-            c->sup_parallel = !(sp && sp[0] == '0');
-            const char* sc = getenv("AKZ_SUP_CAP");   // test knob: a small value sends frames down the fallback
-            if (sc && atoi(sc) > 0) c->sup_cap = (uint32_t)atoi(sc);
-        }
-        const char* keep = getenv("AKZ_KEEP_ALL");
-        c->keep_all = keep && keep[0] == '1';
-        const char* fp = getenv("AKZ_FRONT_PAIR");
-        c->front_pair = !(fp && fp[0] == '0');
+        if (c->max_kp > kAkzMaxKeypoints) c->max_kp = kAkzMaxKeypoints;
+        // per (frame, level) candidate capacity: independent of the keypoint capacity (a level can hold more raw
+        // extrema than survive suppression); lists longer than 16384 are sorted through global memory
+        c->max_cand = o.max_candidates ? o.max_candidates : c->max_kp;
+        if (c->max_cand > kAkzMaxKeypoints) c->max_cand = kAkzMaxKeypoints;
+        c->sup_cap = o.sup_capacity ? o.sup_capacity : 4u * c->max_kp;   // all levels together: frames with more take the serial pass
+        c->sup_parallel = !(o.flags & AKZ_OPT_SERIAL_SUPPRESSION);
+        c->keep_all = (o.flags & AKZ_OPT_KEEP_ALL) != 0;
+        c->front_pair = !(o.flags & AKZ_OPT_NO_FRAME_PAIRS);
+        c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);
+        c->contrast_force_odd = (o.flags & AKZ_OPT_CONTRAST_FORCE_ODD) != 0;
+        c->nsets = (o.flags & AKZ_OPT_NO_PIPELINE) ? 1 : 2;
+        if (o.fed_block) c->fed_block = (int)o.fed_block;
+        if (o.desc_tile_shift) c->desc_tile_shift = (int)o.desc_tile_shift;
         int32_t st = AKZ_OK;
-        // The scale-space stream is the critical path of the pipeline: it gets the highest priority so its
-        // HBM-bound kernels are dispatched first; the keypoint stream fills the remaining wave slots.
+        // Stream priorities (scale space urgent, keypoint stage filler) were measured without gain on MI355X
+        // (1982 vs 2029 fps): off unless asked for.
         int prio_lo = 0, prio_hi = 0;
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = numerically greatest = least urgent
-        const char* pr = getenv("AKZ_STREAM_PRIORITY");
-        const bool use_prio = pr && pr[0] == '1';  // measured: no gain on MI355X (1982 vs 2029 fps), off by default
+        const bool use_prio = (o.flags & AKZ_OPT_STREAM_PRIORITY) != 0;
         if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
             st = AKZ_E_HIP;
@@ -158,16 +174,6 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
             if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
             if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
         }
-        const char* dts = getenv("AKZ_DESC_TILE_SHIFT");
-        if (dts && dts[0] >= '2' && dts[0] <= '9') c->desc_tile_shift = dts[0] - '0';
-        const char* fb = getenv("AKZ_FED_BLOCK");
-        if (fb && fb[0] >= '1' && fb[0] <= '8' && !fb[1]) c->fed_block = fb[0] - '0';
-        if (const char* e = getenv("AKZ_CONTRAST_FINE")) {
-        c->contrast_fine = !(e[0] == '0');
-        c->contrast_force_odd = e[0] == '2';
-    }
-    const char* pipe = getenv("AKZ_PIPELINE");
-        c->nsets = (pipe && pipe[0] == '0') ? 1 : 2;
         if (st == AKZ_OK) st = akz_ctx_prepare(c, max_w, max_h);
         if (st != AKZ_OK) {
             akz_destroy(c);
@@ -176,6 +182,12 @@ extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max
         *out = c;
         return AKZ_OK;
     });
+}
+
+extern "C" int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h, int32_t max_batch,
+                              uint32_t max_keypoints, akz_ctx** out)
+{
+    return akz_create_ex(cfg, device, max_w, max_h, max_batch, max_keypoints, nullptr, out);
 }
 
 extern "C" int32_t akz_destroy(akz_ctx* c)
@@ -260,10 +272,10 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_cflag = cv.take<uint32_t>(B);
     S.d_contrast = cv.take<double>(B);
     S.d_invk = cv.take<float>(B * 8);
-    S.d_ncand = cv.take<uint32_t>(B * 32);
-    S.d_cand = cv.take<uint2>(B * 32 * (size_t)c->max_cand);
-    S.d_cand_u = cv.take<float>(B * 32 * (size_t)c->max_cand * 10);   // CandU = 40 bytes
-    S.d_cand_nb = cv.take<float>(B * 32 * (size_t)c->max_cand * 8);
+    S.d_ncand = cv.take<uint32_t>(B * kAkzMaxLevels);
+    S.d_cand = cv.take<uint2>(B * kAkzMaxLevels * (size_t)c->max_cand);
+    S.d_cand_u = cv.take<float>(B * kAkzMaxLevels * (size_t)c->max_cand * 10);   // CandU = 40 bytes
+    S.d_cand_nb = cv.take<float>(B * kAkzMaxLevels * (size_t)c->max_cand * 8);
     const size_t K = c->max_kp;
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);
@@ -292,6 +304,7 @@ static void carve(akz_ctx* c, char* base, size_t* total)
     c->d_err = cv.take<uint32_t>(4);
     c->d_ori = cv.take<char>(akz_ori_table_bytes());
     c->d_desc = cv.take<char>(akz_desc_table_bytes());
+    c->d_taps = cv.take<float>(kAkzMaxTaps + 1);
     *total = akz_align_up(cv.off, 256);
 }
 
@@ -376,7 +389,7 @@ extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_
                                           void* stream_to_wait)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !d_imgs || n < 1 || (fmt != 0 && fmt != 1)) return AKZ_E_INVALID;
+        if (!c || !d_imgs || n < 1 || (fmt < 0 || fmt > 2)) return AKZ_E_INVALID;
         if (n > c->max_batch) return AKZ_E_TOO_LARGE;
         AKZ_HIP(hipSetDevice(c->device));
         AKZ_TRY(akz_ctx_prepare(c, w, h));
@@ -398,7 +411,7 @@ extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int3
                                             void* d_n_out, void* stream_to_wait)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !d_imgs || !d_kps || !d_descs || !d_n_out || n < 1 || (fmt != 0 && fmt != 1) || cap_per_img == 0)
+        if (!c || !d_imgs || !d_kps || !d_descs || !d_n_out || n < 1 || (fmt < 0 || fmt > 2) || cap_per_img == 0)
             return AKZ_E_INVALID;
         if (n > c->max_batch) return AKZ_E_TOO_LARGE;
         AKZ_HIP(hipSetDevice(c->device));
@@ -419,13 +432,13 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
                                      uint32_t* n_out)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !imgs || !n_out || n < 1 || (fmt != 0 && fmt != 1) || stride < w) return AKZ_E_INVALID;
+        if (!c || !imgs || !n_out || n < 1 || (fmt < 0 || fmt > 2) || stride < w) return AKZ_E_INVALID;
         if (cap_per_img && (!kps || !descs)) return AKZ_E_INVALID;
         if (n > c->max_batch) return AKZ_E_TOO_LARGE;
         AKZ_HIP(hipSetDevice(c->device));
         AKZ_TRY(akz_ctx_prepare(c, w, h));
         AKZ_TRY(begin_call(c));
-        const size_t esz = fmt == 0 ? 1 : 4;
+        const size_t esz = fmt == AKZ_FMT_U8 ? 1 : (fmt == AKZ_FMT_U16 ? 2 : 4);
         const size_t P0 = (size_t)w * h;
         for (int i = 0; i < n; ++i) {
             if (!imgs[i]) return AKZ_E_INVALID;
@@ -463,6 +476,14 @@ extern "C" int32_t akz_extract_gray_u8(akz_ctx* c, const uint8_t* img, int32_t w
     return akz_guard([&]() -> int32_t {
         const void* p = img;
         return akz_extract_batch(c, &p, 0, 1, w, h, stride, kps, descs, cap, n_out);
+    });
+}
+extern "C" int32_t akz_extract_gray_u16(akz_ctx* c, const uint16_t* img, int32_t w, int32_t h, int32_t stride,
+                                        akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
+{
+    return akz_guard([&]() -> int32_t {
+        const void* p = img;
+        return akz_extract_batch(c, &p, AKZ_FMT_U16, 1, w, h, stride, kps, descs, cap, n_out);
     });
 }
 extern "C" int32_t akz_extract_gray_f32(akz_ctx* c, const float* img, int32_t w, int32_t h, int32_t stride,

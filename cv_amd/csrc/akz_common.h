@@ -28,6 +28,14 @@ extern thread_local int g_akz_last_hip;
     } while (0)
 #define AKZ_LAUNCH_CHECK() AKZ_HIP(hipGetLastError())
 
+// Slots per frame in every per-(frame, level) table (candidate counts and lists, the keypoint kernels' level
+// table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
+constexpr int kAkzMaxLevels = 32;
+// Largest per-frame keypoint list / per-(frame, level) candidate list a context can be created for.
+constexpr uint32_t kAkzMaxKeypoints = 16384u;
+// Longest Gaussian kernel of the generic blur path (base_scale_offset up to 255.5)
+constexpr int kAkzMaxTaps = 1023;
+
 // ---- host-side plan: what Akaze::allocate_evolutions computes (akaze/src/evolution.rs:80-126) ---
 struct AkzLevel {
     int w, h;

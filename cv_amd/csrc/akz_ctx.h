@@ -95,6 +95,8 @@ struct akz_ctx {
     uint32_t* d_err = nullptr;             // [1] sticky device-side overflow flag
     void* d_ori = nullptr;                 // OriTables (orientation sample/window tables)
     void* d_desc = nullptr;                // DescTables (M-LDB cell + comparison tables)
+    float* d_taps = nullptr;               // [kAkzMaxTaps + 1] Gaussian taps of the generic level-0 blur
+    std::vector<float> h_taps;             // their host copy (must outlive the asynchronous upload)
 
     // timing (akz_timing_*)
     bool timing = false;

@@ -46,7 +46,7 @@ struct LevelDesc {  // per-level constants for the keypoint kernels
     uint32_t octave;
     float kp_size;    // (esigma * derivative_factor) as f32
 };
-constexpr int kMaxLevels = 32;
+constexpr int kMaxLevels = kAkzMaxLevels;
 struct LevelTable {
     LevelDesc L[kMaxLevels];
     int n;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
     ActEntry* act = reinterpret_cast<ActEntry*>(smem);
     const int frame = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
+    const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
     uint32_t nact = 0, nslots = 0;  // wave-uniform
     // chunk bounds live in registers: lane l holds [ymin, ymax] of chunks l and l + 64
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
         const float margin = size * 1.001f + 0.01f;  // conservative: |dy| > margin  =>  dist > size^2
         // this level's raster-sorted candidates (overflow beyond the capacity was flagged by the producer)
         const uint32_t c_begin = (uint32_t)e * max_cand;
-        const uint32_t c_end = c_begin + min(ncand[(size_t)frame * 32 + e], max_cand);
+        const uint32_t c_end = c_begin + min(ncand[(size_t)frame * kAkzMaxLevels + e], max_cand);
         for (uint32_t cb = c_begin; cb < c_end; cb += 64) {
             // one coalesced load of the next 64 candidates, then broadcast lane by lane
             uint2 mine = (cb + lane < c_end) ? cd[cb + lane] : make_uint2(0u, 0u);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
         uint32_t acc = 0;
         for (int e = 0; e < T.n; ++e) {
             s_base[e] = acc;
-            acc += min(ncand[(size_t)frame * 32 + e], max_cand);
+            acc += min(ncand[(size_t)frame * kAkzMaxLevels + e], max_cand);
         }
         s_base[T.n] = acc;
         if (acc > cap && blockIdx.x == 0) fallback[frame] = 1u;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= N) return;
     const SupFrame F = sup_frame(scratch, cap, frame, gridDim.y);
-    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
+    const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
     uint32_t i;
     const int e = sup_level(s_base, T.n, g, &i);
     const uint2 me = cd[(size_t)e * max_cand + i];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
         uint32_t acc = 0;
         for (int e = 0; e < T.n; ++e) {
             s_base[e] = acc;
-            acc += min(ncand[(size_t)frame * 32 + e], max_cand);
+            acc += min(ncand[(size_t)frame * kAkzMaxLevels + e], max_cand);
         }
         s_base[T.n] = acc;
     }
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
         ncache[frame] = min(running, max_kp);
     }
     // every slot's final occupant writes the entry
-    const uint2* cd = cand + (size_t)frame * 32 * max_cand;
+    const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
     for (uint32_t c = tid; c < N; c += 1024) {
         const uint2 st = F.state[c];
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
         // candidate list carries those nine values (k_deriv_second_cand*, k_cand_sort), so the Ldet planes are
         // never read here.  kp.angle holds the candidate's index inside its level until it is overwritten below.
         const uint32_t cidx = __float_as_uint(kp.angle);
-        const float4* nbp = reinterpret_cast<const float4*>(cand_nb + (((size_t)frame * 32 + kp.class_id) * max_cand + cidx) * 8);
+        const float4* nbp = reinterpret_cast<const float4*>(cand_nb + (((size_t)frame * kAkzMaxLevels + kp.class_id) * max_cand + cidx) * 8);
         const float4 n0 = nbp[0], n1 = nbp[1];
         kp.angle = 0.0f;
         float x_i = kp.response;   // Ldet at the pixel (> threshold > 0, so |v| = v)

@@ -56,6 +56,8 @@ __device__ __forceinline__ uint3 xcd_tile(uint3 bid, uint3 grid)
 __device__ __forceinline__ float load_px(const float* p, size_t i) { return p[i]; }
 // image.rs:54 — f32::from(v) / 255f32: a true IEEE division per pixel.
 __device__ __forceinline__ float load_px(const uint8_t* p, size_t i) { return (float)p[i] / 255.0f; }
+// image.rs:57-66 — Luma16: f32::from(v) / 65535f32
+__device__ __forceinline__ float load_px(const uint16_t* p, size_t i) { return (float)p[i] / 65535.0f; }
 
 // wide::f32x4 accumulate + reduce_add as used by horizontal_filter/vertical_filter
 // (image.rs:242-247, :320-325): tap i goes to lane i&3, lanes accumulate in chunk order with an
@@ -207,7 +209,13 @@ __device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
 // Raw (unconverted) 4-pixel loads, so a prefetched u8 tile costs one VGPR per item and frame
 __device__ __forceinline__ float4 load4_raw(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
 __device__ __forceinline__ uint32_t load4_raw(const uint8_t* p, size_t i) { return *reinterpret_cast<const uint32_t*>(p + i); }
+__device__ __forceinline__ uint2 load4_raw(const uint16_t* p, size_t i) { return *reinterpret_cast<const uint2*>(p + i); }
 __device__ __forceinline__ float4 raw_px(float4 r) { return r; }
+__device__ __forceinline__ float4 raw_px(uint2 u)     // image.rs:57-66 — f32::from(v) / 65535f32
+{
+    return make_float4((float)(u.x & 0xFFFFu) / 65535.0f, (float)(u.x >> 16) / 65535.0f,
+                       (float)(u.y & 0xFFFFu) / 65535.0f, (float)(u.y >> 16) / 65535.0f);
+}
 __device__ __forceinline__ float4 raw_px(uint32_t u)   // image.rs:54 — f32::from(v) / 255f32
 {
     return make_float4((float)(u & 0xFFu) / 255.0f, (float)((u >> 8) & 0xFFu) / 255.0f,
@@ -215,6 +223,7 @@ __device__ __forceinline__ float4 raw_px(uint32_t u)   // image.rs:54 — f32::f
 }
 template <typename InT> struct RawOf { typedef float4 type; };
 template <> struct RawOf<uint8_t> { typedef uint32_t type; };
+template <> struct RawOf<uint16_t> { typedef uint2 type; };
 
 // Register-held input tile of the NEXT row tile of a block (interior tile columns only): fetched right after
 // the current tile went to LDS, so the HBM/L2 latency of the loads hides behind the current tile's passes.
@@ -1284,11 +1293,11 @@ __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restr
         float down_y = roundf(py + cp.border) + 1.0f;
         bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
         if (is_out) continue;
-        uint32_t slot = atomicAdd(&ncand[(size_t)frame * 32 + cp.level], 1u);
+        uint32_t slot = atomicAdd(&ncand[(size_t)frame * kAkzMaxLevels + cp.level], 1u);
         if (slot < cp.cap) {
             CandU cu = {(uint32_t)x | ((uint32_t)y << 16), v,
                         {c[-GW - 1], c[-GW], c[-GW + 1], c[-1], c[1], c[GW - 1], c[GW], c[GW + 1]}};
-            cand[((size_t)frame * 32 + cp.level) * cp.cap + slot] = cu;
+            cand[((size_t)frame * kAkzMaxLevels + cp.level) * cp.cap + slot] = cu;
         } else {
             *err = 1u;
         }
@@ -1439,7 +1448,7 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
             float down_y = roundf(py + cp.border) + 1.0f;
             bool is_out = left_x < 0.0f || right_x >= (float)w || up_y < 0.0f || down_y >= (float)h;
             if (is_out) continue;
-            const size_t list = (size_t)(f ? fb : fa) * 32 + cp.level;
+            const size_t list = (size_t)(f ? fb : fa) * kAkzMaxLevels + cp.level;
             uint32_t slot = atomicAdd(&ncand[list], 1u);
             if (slot < cp.cap) {
                 CandU cu = {(uint32_t)x | ((uint32_t)y << 16), v,
@@ -1461,9 +1470,9 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
     const uint32_t level = blockIdx.x, frame = blockIdx.y;
-    const uint32_t n = min(ncand[(size_t)frame * 32 + level], cap);
+    const uint32_t n = min(ncand[(size_t)frame * kAkzMaxLevels + level], cap);
     if (n == 0) return;
-    const size_t list = ((size_t)frame * 32 + level) * cap;
+    const size_t list = ((size_t)frame * kAkzMaxLevels + level) * cap;
     const CandU* seg = cand_u + list;
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
@@ -1485,6 +1494,14 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
         nb[0] = make_float4(cu.nb[0], cu.nb[1], cu.nb[2], cu.nb[3]);
         nb[1] = make_float4(cu.nb[4], cu.nb[5], cu.nb[6], cu.nb[7]);
     }
+}
+
+// GrayFloatImage::from_dynamic (image.rs:45-109) on its own: pixels -> f32 (the generic-radius path of level 0)
+template <typename InT>
+__global__ __launch_bounds__(256) void k_to_f32(const InT* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = load_px(in, i);
 }
 
 __global__ __launch_bounds__(256) void k_deinterleave(const float2* __restrict__ in, float* __restrict__ out, size_t n,
@@ -1609,13 +1626,19 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 
     // base_scale_offset and the gradient-histogram scale are config values; the fused tile kernel is
     // instantiated for the radii the AKAZE path uses (sigma 1.6 -> 4, sigma 1.0 -> 2).
-    GaussTaps t0 = make_taps((float)c->cfg.base_scale_offset);
+    // the fused tile kernels are instantiated for the radii of the default configuration (base_scale_offset in
+    // (1.5, 2.0] -> radius 4, and the fixed sigma 1.0 -> radius 2); any other base_scale_offset takes the dense
+    // stand-alone filter (k_filter1d) for the one blur that depends on it
+    const float sigma0 = (float)c->cfg.base_scale_offset;
+    const int r0 = akz_gaussian_radius(sigma0);
+    const bool tile0 = r0 == 4;
+    GaussTaps t0 = make_taps(tile0 ? sigma0 : 1.6f);
     GaussTaps t1 = make_taps(1.0f);
-    if (t0.n != 9 || t1.n != 5) return AKZ_E_INVALID;
+    if (t1.n != 5 || (tile0 && t0.n != 9)) return AKZ_E_INTERNAL;
 
     akz_timer_begin(c, &c->t_ss);
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
-    const bool fused0 = P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
+    const bool fused0 = tile0 && P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
     if (fused0 && (w & 3) == 0 && c->front_pair) {
 #define AKZ_FRONT0(THV, NTV, TPBV)                                                                                  \
     hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
@@ -1632,14 +1655,31 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                            s, d_imgs, w, h, P0, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
                            (const float*)nullptr, 0);
         AKZ_LAUNCH_CHECK();
-    } else {
+    } else if (tile0) {
         AKZ_TRY((launch_blur<4, 0, InT, EPI_BLUR>(c, d_imgs, w, h, P0, t0, S.Lt[0], nullptr, P0, 0, n)));
+    } else {
+        // generic radius: pixels -> f32 (scratch plane), horizontal pass -> Ldet[0] (free until the determinant
+        // kernel of level 0 runs), vertical pass -> Lt[0], frame by frame
+        const int ks = 2 * r0 + 1;
+        if (ks > kAkzMaxTaps) return AKZ_E_INVALID;
+        c->h_taps.assign((size_t)ks, 0.0f);
+        akz_host_gaussian_kernel(sigma0, ks, c->h_taps.data());
+        AKZ_HIP(hipMemcpyAsync(c->d_taps, c->h_taps.data(), sizeof(float) * ks, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL((k_to_f32<InT>), dim3((unsigned)((P0 * n + 255) / 256)), dim3(256), 0, s, d_imgs, S.tmp, P0 * n);
+        AKZ_LAUNCH_CHECK();
+        for (int f = 0; f < n; ++f) {
+            hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.tmp + (size_t)f * P0),
+                               S.Ldet[0] + (size_t)f * P0, w, h, (const float*)c->d_taps, ks, 0);
+            hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.Ldet[0] + (size_t)f * P0),
+                               S.Lt[0] + (size_t)f * P0, w, h, (const float*)c->d_taps, ks, 1);
+            AKZ_LAUNCH_CHECK();
+        }
     }
     // lib.rs:206-211 — contrast factor on the ORIGINAL image
     AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
     AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
-    AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * 32 * (size_t)n, s));
+    AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * kAkzMaxLevels * (size_t)n, s));
     const bool pairc = (w & 3) == 0 && c->front_pair && nbins <= 510;
     const bool fine = pairc && c->contrast_fine;
     if (pairc) {
@@ -1832,6 +1872,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 
 int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n)
 {
-    if (fmt == 0) return scale_space_impl<uint8_t>(c, (const uint8_t*)d_imgs, n);
+    if (fmt == AKZ_FMT_U8) return scale_space_impl<uint8_t>(c, (const uint8_t*)d_imgs, n);
+    if (fmt == AKZ_FMT_U16) return scale_space_impl<uint16_t>(c, (const uint16_t*)d_imgs, n);
     return scale_space_impl<float>(c, (const float*)d_imgs, n);
 }

@@ -654,7 +654,7 @@ static int32_t hm_push_probs(hm_ctx* c, size_t off, const void* src, size_t byte
     return AKZ_OK;
 }
 
-extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out)
+extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t max_targets, uint32_t flags, hm_ctx** out)
 {
     return akz_guard([&]() -> int32_t {
         // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
@@ -671,17 +671,12 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
         {
             int prio_lo = 0, prio_hi = 0;
             hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            const char* pr = getenv("AKZ_STREAM_PRIORITY");
-            // the matcher is VALU-bound filler work: least urgent, so it yields to the scale-space stream
-            AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (pr && pr[0] == '1') ? prio_lo : 0));
+            // HM_OPT_STREAM_PRIORITY: the matcher as least-urgent filler work that yields to the scale-space stream
+            AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (flags & HM_OPT_STREAM_PRIORITY) ? prio_lo : 0));
         }
         AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-        {
-            const char* mf = getenv("AKZ_MATCH_MFMA");
-            c->use_mfma = !(mf && mf[0] == '0');
-            const char* f4 = getenv("AKZ_MATCH_FP4");
-            c->use_fp4 = !(f4 && f4[0] == '0');
-        }
+        c->use_mfma = !(flags & HM_OPT_NO_MFMA);
+        c->use_fp4 = !(flags & HM_OPT_NO_FP4);
         AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
         AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
         AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
@@ -692,6 +687,11 @@ extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_
         *out = c;
         return AKZ_OK;
     });
+}
+
+extern "C" int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out)
+{
+    return hm_create_ex(device, max_queries, max_targets, 0u, out);
 }
 
 extern "C" int32_t hm_destroy(hm_ctx* c)

@@ -32,10 +32,12 @@ class Neighbor:
 class Matcher:
     """Owns one hm_ctx."""
 
-    def __init__(self, max_descriptors=16384, device=0):
+    def __init__(self, max_descriptors=16384, device=0, kernel="fp4"):
+        """kernel: "fp4" (default, FP4 MFMA), "int8" (int8 MFMA) or "valu" (xor/popcount, k = 2 only)."""
         self._h = C.c_void_p()
         self.cap = max_descriptors
-        check(_lib.lib().hm_create(device, max_descriptors, max_descriptors, C.byref(self._h)), "hm_create")
+        flags = {"fp4": 0, "int8": _lib.HM_OPT_NO_FP4, "valu": _lib.HM_OPT_NO_MFMA}[kernel]
+        check(_lib.lib().hm_create_ex(device, max_descriptors, max_descriptors, flags, C.byref(self._h)), "hm_create_ex")
 
     def close(self):
         if self._h:

@@ -87,19 +87,54 @@ int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t
                    int32_t max_batch, uint32_t max_keypoints, akz_ctx** out);
 int32_t akz_destroy(akz_ctx* ctx);
 
+/* Behaviour switches of ONE context.  The library reads no environment variable: two contexts in one
+ * process can differ, and nothing outside the caller's code changes what a context does.  The defaults
+ * (all zero) are the measured-best paths; the other values select the fall-back / reference kernels that
+ * the parity tests and A/B runs exercise.  Results are bit-identical under every combination. */
+enum {
+    AKZ_OPT_KEEP_ALL = 1u << 0,           /* keep per-level Lsmooth / Lflow and write the Ldet planes (parity taps) */
+    AKZ_OPT_NO_FRAME_PAIRS = 1u << 1,     /* one-frame kernels even for widths divisible by 4 */
+    AKZ_OPT_SERIAL_SUPPRESSION = 1u << 2, /* one-wave serial walk of scale_space_extrema.rs:61-118 for every frame */
+    AKZ_OPT_NO_PIPELINE = 1u << 3,        /* one buffer set: consecutive calls do not overlap */
+    AKZ_OPT_STREAM_PRIORITY = 1u << 4,    /* scale-space stream at high, keypoint stream at low priority */
+    AKZ_OPT_CONTRAST_EXACT = 1u << 5,     /* contrast factor always through the exact histogram pass */
+    AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6  /* test knob: odd frames through the exact pass (mixed pairs) */
+};
+typedef struct akz_options {
+    uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */
+    uint32_t flags;           /* AKZ_OPT_* */
+    uint32_t fed_block;       /* most FED steps fused per launch, 1..8; 0 = default (8; the first octave stops at 4) */
+    uint32_t sup_capacity;    /* candidates per frame the parallel suppression is sized for; 0 = 4 x max_keypoints */
+    uint32_t max_candidates;  /* capacity of each per-(frame, level) extrema candidate list; 0 = max_keypoints */
+    uint32_t desc_tile_shift; /* log2 tile edge of the descriptor visiting order, 2..9; 0 = default (5) */
+    uint32_t reserved[10];    /* must be zero */
+} akz_options;
+/* akz_create with explicit options (NULL = defaults = akz_create). */
+int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h,
+                      int32_t max_batch, uint32_t max_keypoints, const akz_options* opts, akz_ctx** out);
+
 /* Akaze::extract on a DynamicImage::ImageLuma8 (akaze/src/lib.rs:295, image.rs:47-56):
  * img is host memory, h rows of w bytes, `stride` bytes apart.  Outputs are index-aligned,
  * ordered by response descending, exactly as the reference returns them. */
 int32_t akz_extract_gray_u8(akz_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                             akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
 
+/* Akaze::extract on a DynamicImage::ImageLuma16 (akaze/src/image.rs:57-66: f32::from(v) / 65535f32 per
+ * pixel); stride in elements. */
+int32_t akz_extract_gray_u16(akz_ctx* ctx, const uint16_t* img, int32_t w, int32_t h, int32_t stride,
+                             akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
+
 /* Akaze::extract_from_gray_float_image (akaze/src/lib.rs:309): f32 pixels in [0,1], stride in
  * elements. */
 int32_t akz_extract_gray_f32(akz_ctx* ctx, const float* img, int32_t w, int32_t h, int32_t stride,
                              akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
 
+/* Pixel formats of the batched / device entry points: the arms of GrayFloatImage::from_dynamic
+ * (akaze/src/image.rs:45-109) that need no colour conversion. */
+enum { AKZ_FMT_U8 = 0 /* Luma8: v / 255 */, AKZ_FMT_F32 = 1 /* GrayFloatImage, [0,1] */, AKZ_FMT_U16 = 2 /* Luma16: v / 65535 */ };
+
 /* Batched extract: n host images of identical size (what a caller looping Akaze::extract over
- * frames does, cv-sfm/src/lib.rs:2200-2204).  fmt: 0 = u8, 1 = f32.  kps/descs hold
+ * frames does, cv-sfm/src/lib.rs:2200-2204).  fmt: AKZ_FMT_*; stride in elements.  kps/descs hold
  * n * cap_per_img entries, frame i at offset i*cap_per_img; n_out[i] = count of frame i. */
 int32_t akz_extract_batch(akz_ctx* ctx, const void* const* imgs, int32_t fmt, int32_t n, int32_t w,
                           int32_t h, int32_t stride, akz_keypoint* kps, akz_descriptor* descs,
@@ -170,6 +205,10 @@ int32_t akz_sample_colors_rgb8(akz_ctx* ctx, const uint8_t* rgb, int32_t w, int3
 
 typedef struct hm_ctx hm_ctx;
 int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out);
+/* hm_create with kernel-selection flags (0 = defaults): the k-NN kernel is the FP4 MFMA one unless a flag
+ * selects the int8 MFMA or the xor/popcount VALU kernel (k = 2 only); all three are bit-identical. */
+enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2 };
+int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t max_targets, uint32_t flags, hm_ctx** out);
 int32_t hm_destroy(hm_ctx* ctx);
 /* LinearKnn::knn(q, 2) for every query (akaze/tests/estimate_pose.rs:82-88): out[2*i+0/1] are the
  * nearest and second-nearest targets of query i under Hamming distance over all 64 bytes, ordered

@@ -1046,6 +1046,22 @@ int orc_extract_u8(orc_ctx* c, const uint8_t* image, int stride)
     return r;
 }
 
+/* GrayFloatImage::from_dynamic, ImageLuma16 arm (akaze/src/image.rs:57-66): f32::from(v) / 65535f32 */
+void orc_u16_to_f32(const uint16_t* in, int w, int h, int stride, float* out)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) out[(size_t)y * w + x] = (float)in[(size_t)y * stride + x] / 65535.0f;
+}
+
+int orc_extract_u16(orc_ctx* c, const uint16_t* image, int stride)
+{
+    float* f = (float*)malloc(sizeof(float) * (size_t)c->w * c->h);
+    orc_u16_to_f32(image, c->w, c->h, stride, f);
+    int r = orc_extract_f32(c, f);
+    free(f);
+    return r;
+}
+
 /* Scale space + detector response only (BASELINE configs[1]); used by the cpu_baseline leg. */
 int orc_scale_space_u8(orc_ctx* c, const uint8_t* image, int stride)
 {

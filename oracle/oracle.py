@@ -76,6 +76,7 @@ def lib():
         L.orc_fed_tau.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
         L.orc_extract_f32.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_extract_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_extract_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_scale_space_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_level_buffer.restype = fp
         L.orc_level_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -243,11 +244,13 @@ class Akaze:
         return np.array(buf[:n], np.float64)
 
     def extract(self, img):
-        """img: HxW uint8 or float32. Returns (keypoints structured array, descriptors [n,64] u8)."""
+        """img: HxW uint8 (Luma8), uint16 (Luma16) or float32. Returns (keypoints structured array, descriptors [n,64] u8)."""
         img = np.ascontiguousarray(img)
         assert img.shape == (self.h, self.w), (img.shape, self.h, self.w)
         if img.dtype == np.uint8:
             n = lib().orc_extract_u8(self._c, img.ctypes.data, self.w)
+        elif img.dtype == np.uint16:
+            n = lib().orc_extract_u16(self._c, img.ctypes.data, self.w)
         else:
             img = _f32(img)
             n = lib().orc_extract_f32(self._c, img.ctypes.data)

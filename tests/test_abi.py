@@ -59,6 +59,41 @@ def test_error_strings_and_no_cpu_fallback(lib):
             Akaze.sparse().extract(np.zeros((64, 64), np.uint8))
 
 
+def test_options_struct_and_early_validation(lib):
+    """akz_options is 64 bytes; akz_create_ex validates the configuration and the options BEFORE it looks for a
+    device, so the refusals are checkable without a GPU: a pyramid of more than 32 levels (every per-frame level
+    table has 32 slots — the check sits in front of every launch), malformed options."""
+    from cv_amd import _lib
+    assert C.sizeof(_lib.Options) == 64
+    cfg = _lib.Config()
+    lib.akz_config_default(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.num_sublevels, cfg.max_octave_evolution = 8, 5          # 40 levels at 1920x1080
+    assert lib.akz_create_ex(C.byref(cfg), 0, 1920, 1080, 1, 0, None, C.byref(h)) == -1
+    cfg.num_sublevels, cfg.max_octave_evolution = 9, 4
+    assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, None, C.byref(h)) == -1
+    lib.akz_config_default(C.byref(cfg))
+    o = _lib.make_options()
+    o.reserved[3] = 1
+    assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
+    o = _lib.make_options(fed_block=9)
+    assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
+    o = _lib.make_options()
+    o.struct_size = 4
+    assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
+    # a valid call gets as far as the device probe
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(_lib.make_options(keep_all=True)), C.byref(h)) == -2
+
+
+def test_library_reads_no_environment_variable():
+    """Behaviour switches live in akz_options / hm_create_ex flags: no getenv in the library sources."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "cv_amd", "csrc", "*")):
+        assert "getenv" not in open(f).read(), f
+
+
 def test_host_mirror_surface():
     """The Python mirror keeps the reference's names (akaze/src/lib.rs:109-185, 295-366)."""
     from cv_amd.akaze import Akaze, KeyPoint

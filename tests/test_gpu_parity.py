@@ -11,7 +11,9 @@ from conftest import synth_frame
 
 pytestmark = pytest.mark.gpu
 
-os.environ.setdefault("AKZ_KEEP_ALL", "1")  # keep per-level Lsmooth/Lflow so every buffer can be tapped
+# Contexts are created with the library's DEFAULT options (the configuration bench.py measures: transient
+# Lsmooth/Lflow scratch, no Ldet planes) unless a test asks for something else through akz_options; the tests that
+# tap every pyramid buffer pass keep_all=True.  The library reads no environment variable.
 
 
 @pytest.fixture(scope="module")
@@ -22,6 +24,11 @@ def gpu():
     build.build()
     from cv_amd import akaze, knn
     return akaze, knn
+
+
+def _opts(**kw):
+    from cv_amd import _lib
+    return _lib.make_options(**kw)
 
 
 def _eq(a, b, what):
@@ -74,12 +81,15 @@ def test_half_size_bit_exact(gpu, oracle):
         _eq(akaze.half_size(img, ctx), oracle.half_size(img), f"half_size {w}x{h}")
 
 
-def _compare_pyramid(akaze, O, img, thr, what):
+def _compare_pyramid(akaze, O, img, thr, what, ak=None, ocfg=None):
+    """Every pyramid buffer, the contrast factor, every keypoint stage and the final outputs of one frame, HIP
+    (keep_all context: all taps) vs oracle; then the final outputs once more from a DEFAULT-options context (the
+    benchmarked mode: scratch-aliased Lsmooth/Lflow, no Ldet planes)."""
     h, w = img.shape
-    ak = akaze.Akaze.new(thr)
-    ctx = ak.context(w, h, 1)
+    ak = ak or akaze.Akaze.new(thr)
+    ctx = akaze.Context(ak, w, h, 1, _opts(keep_all=True))
     (kp, desc), = ctx.extract_batch([img])
-    orc = O.Akaze(w, h, O.default_config(threshold=thr))
+    orc = O.Akaze(w, h, ocfg or O.default_config(threshold=thr))
     okp, odesc = orc.extract(img)
     assert ctx.num_levels(w, h) == orc.num_levels
     for lvl in range(orc.num_levels):
@@ -97,6 +107,12 @@ def _compare_pyramid(akaze, O, img, thr, what):
         _kp_eq(ctx.keypoints(0, stage), orc.keypoints(stage), f"{what} stage{stage}")
     _kp_eq(kp, okp, f"{what} final keypoints")
     _eq(desc, odesc, f"{what} descriptors")
+    ctx.close()
+    ctx = akaze.Context(ak, w, h, 1)
+    (kp2, desc2), = ctx.extract_batch([img])
+    _kp_eq(kp2, okp, f"{what} final keypoints (default options)")
+    _eq(desc2, odesc, f"{what} descriptors (default options)")
+    ctx.close()
     return kp, desc
 
 
@@ -148,16 +164,16 @@ def test_pathological_inputs(gpu, oracle, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["0", "2"])
-def test_contrast_factor_paths(gpu, oracle, monkeypatch, mode):
+@pytest.mark.parametrize("mode", ["exact", "force_odd"])
+def test_contrast_factor_paths(gpu, oracle, mode):
     """The contrast factor normally comes from the order statistic of the max pass's fine histogram; frames whose
-    fine key straddles a reference bin take the exact histogram pass.  AKZ_CONTRAST_FINE=0 sends every frame
-    through the exact pass, =2 every odd frame (mixed pairs): same contrast factor, bit for bit, either way."""
+    fine key straddles a reference bin take the exact histogram pass.  AKZ_OPT_CONTRAST_EXACT sends every frame
+    through the exact pass, AKZ_OPT_CONTRAST_FORCE_ODD every odd frame (mixed pairs): same contrast factor, bit for
+    bit, either way."""
     akaze, _ = gpu
-    monkeypatch.setenv("AKZ_CONTRAST_FINE", mode)
     frames = [synth_frame(320, 240, seed=500 + i, n_rect=10 + 7 * i, n_disc=5 + 3 * i) for i in range(5)]
     frames[3] = np.full((240, 320), 77, np.uint8)                     # no gradient at all: zero points
-    ctx = akaze.Context(akaze.Akaze.default(), 320, 240, 5)
+    ctx = akaze.Context(akaze.Akaze.default(), 320, 240, 5, _opts(contrast=mode))
     got = ctx.extract_batch(frames)
     for i, img in enumerate(frames):
         orc = oracle.Akaze(320, 240, oracle.default_config())
@@ -260,12 +276,11 @@ def test_descriptor_channels(gpu, oracle, nch):
     assert not np.unpackbits(desc, axis=1, bitorder="little")[:, used_bits:].any()
 
 
-def test_serial_suppression_path(gpu, oracle, kitti, monkeypatch):
-    """AKZ_SUP_PARALLEL=0 routes every frame through the one-wave serial pass (the fallback of the parallel
+def test_serial_suppression_path(gpu, oracle, kitti):
+    """AKZ_OPT_SERIAL_SUPPRESSION routes every frame through the one-wave serial pass (the fallback of the parallel
     suppression for frames that overflow its fixed-capacity lists): same keypoints, same descriptors."""
     akaze, _ = gpu
-    monkeypatch.setenv("AKZ_SUP_PARALLEL", "0")
-    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2)   # a fresh context reads the switch
+    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2, _opts(parallel_suppression=False))
     res = ctx.extract_batch([kitti[0], kitti[1]])
     orc = oracle.Akaze(1392, 512, oracle.default_config(threshold=0.01))
     for i in range(2):
@@ -274,9 +289,7 @@ def test_serial_suppression_path(gpu, oracle, kitti, monkeypatch):
         _eq(res[i][1], odesc, f"serial suppression frame {i} desc")
     ctx.close()
     # frames with more candidates than the parallel path is sized for are flagged on the device and fall back
-    monkeypatch.delenv("AKZ_SUP_PARALLEL")
-    monkeypatch.setenv("AKZ_SUP_CAP", "700")          # frame 0 has 1022 candidates, frame 14 has 844
-    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2)
+    ctx = akaze.Context(akaze.Akaze.sparse(), 1392, 512, 2, _opts(sup_capacity=700))   # frame 0 has 1022 candidates, frame 14 has 844
     res = ctx.extract_batch([kitti[0], kitti[1]])
     for i in range(2):
         okp, odesc = orc.extract(kitti[i])
@@ -510,22 +523,21 @@ def test_matcher_properties_at_full_size(gpu):
     assert len(ab) > 100 and sorted((x, y) for x, y in ab) == sorted((y, x) for x, y in ba)
 
 
-@pytest.mark.parametrize("switch", ["AKZ_MATCH_MFMA", "AKZ_MATCH_FP4"])
-def test_alternative_matcher_kernels(gpu, oracle, monkeypatch, switch):
-    """AKZ_MATCH_MFMA=0: the xor/popcount kernel (the reference implementation of the MFMA ones, k = 2);
-    AKZ_MATCH_FP4=0: the int8 MFMA kernel (k = 1..3).  The default is the FP4 MFMA kernel, which every other
+@pytest.mark.parametrize("switch", ["valu", "int8"])
+def test_alternative_matcher_kernels(gpu, oracle, switch):
+    """HM_OPT_NO_MFMA: the xor/popcount kernel (the reference implementation of the MFMA ones, k = 2);
+    HM_OPT_NO_FP4: the int8 MFMA kernel (k = 1..3).  The default is the FP4 MFMA kernel, which every other
     matcher test exercises."""
     _, knn = gpu
-    monkeypatch.setenv(switch, "0")
     rng = np.random.default_rng(5)
-    m = knn.Matcher(4096)
+    m = knn.Matcher(4096, kernel=switch)
     q = _rand_desc(rng, 700); t = _rand_desc(rng, 1300)
     t[rng.integers(0, 1300, 300)] = t[rng.integers(0, 1300, 300)]
     got, want = m.knn2(q, t), oracle.knn2(q, t)
     _eq(got["index"], want["index"], switch + " knn idx")
     _eq(got["distance"], want["distance"], switch + " knn dist")
     assert m.match(q, t).tolist() == oracle.match(q, t).tolist()
-    if switch == "AKZ_MATCH_FP4":
+    if switch == "int8":
         for k in (1, 3):
             got, want = m.knn(q, t[:1001], k), oracle.knn(q, t[:1001], k)
             _eq(got["index"], want["index"], f"int8 knn{k} idx")
@@ -712,7 +724,7 @@ def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     m1, m2 = tmp_path / "m1.npy", tmp_path / "m2.npy"
     common = ["--micro-batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
-    env = dict(os.environ); env.pop("AKZ_KEEP_ALL", None)
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "32", "--dump-matches", str(m1)] + common,
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -726,3 +738,193 @@ def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     assert a.shape == b.shape == (32, 2)
     assert np.array_equal(a, b), (a.T, b.T)
     assert a[:, 0].min() > 1000 and a[:, 1].min() > 500
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 2: the benchmarked configuration, non-default configurations and input arms under the oracle
+def _oracle_frames(frames, cfg_kw=None, procs=8):
+    """oracle.extract of every frame (a process pool: a 1080p frame takes the C oracle about a second)."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(procs, len(frames))) as pool:
+        return pool.map(_oracle_one, [(f, cfg_kw or {}) for f in frames], chunksize=1)
+
+
+def _oracle_one(args):
+    img, kw = args
+    from oracle import oracle as O
+    cfg = O.default_config()
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return O.Akaze(img.shape[1], img.shape[0], cfg).extract(img)
+
+
+def test_benchmark_mode_full_hd_pipelined_vs_oracle(gpu):
+    """The configuration bench.py measures, checked against the ORACLE (not against the library's other API):
+    default options (scratch-aliased Lsmooth/Lflow, no Ldet planes, two buffer sets, two streams), 1920x1080,
+    an odd micro-batch (the last frame pair is half empty), three akz_extract_batch_device calls back to back with
+    no synchronisation in between; keypoints and descriptor bytes of all nine frames equal oracle.extract's."""
+    import torch
+    akaze, _ = gpu
+    from cv_amd import _lib
+    L = _lib.lib()
+    W, H, B, CAP, NCALL = 1920, 1080, 3, 8192, 3
+    dev = torch.device("cuda", 0)
+    frames = [synth_frame(W, H, 7100 + i, n_rect=150, n_disc=150) for i in range(B * NCALL)]
+    want = _oracle_frames(frames)
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    ak = akaze.Akaze.default()
+    ak.max_keypoints = CAP
+    ctx = akaze.Context(ak, W, H, B)
+    kps = torch.zeros((NCALL, B, CAP, 28), dtype=torch.uint8, device=dev)
+    descs = torch.zeros((NCALL, B, CAP, 64), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((NCALL, B), dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream()
+    for k in range(NCALL):
+        _lib.check(L.akz_extract_batch_device(ctx.handle, d_frames[k * B:(k + 1) * B].data_ptr(), 0, B, W, H,
+                                              kps[k].data_ptr(), descs[k].data_ptr(), CAP, cnt[k].data_ptr(),
+                                              cur.cuda_stream), "extract")
+    _lib.check(L.akz_sync(ctx.handle), "sync")
+    kps, descs, cnt = kps.cpu().numpy(), descs.cpu().numpy(), cnt.cpu().numpy()
+    for k in range(NCALL):
+        for j in range(B):
+            okp, od = want[k * B + j]
+            n = int(cnt[k, j])
+            assert n == len(okp) and n > 1000, (k, j, n, len(okp))
+            _eq(descs[k, j, :n], od, f"call {k} frame {j} descriptors")
+            assert kps[k, j, :n].tobytes() == okp.tobytes(), f"call {k} frame {j} keypoints"
+    ctx.close()
+
+
+def _stress_case(i, seed=2):
+    rng = np.random.default_rng(seed * 7919 + i)
+    w = int(rng.integers(40, 230)) * 4 if i % 3 else int(rng.integers(120, 900))
+    h = int(rng.integers(100, 700))
+    thr = float(rng.choice([0.01, 0.003, 0.001, 0.0003]))
+    kind = i % 4
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        img = synth_frame(w, h, seed=int(rng.integers(1 << 30)), n_rect=int(rng.integers(5, 60)), n_disc=int(rng.integers(5, 60)))
+    if kind == 2:
+        img = (img.astype(np.int16) // 16 * 16).astype(np.uint8)      # plateaus: exact ties
+    return thr, img
+
+
+def test_randomised_parity_slice(gpu):
+    """48 cases of tools/stress_parity.py's sweep inside the suite: random sizes (widths divisible by 4 and not),
+    contents (noise, shapes, quantised plateaus full of ties) and thresholds, default options, HIP vs oracle."""
+    akaze, _ = gpu
+    cases = [_stress_case(i) for i in range(48)]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(8) as pool:
+        want = pool.map(_oracle_one, [(img, {"detector_threshold": thr}) for thr, img in cases], chunksize=1)
+    total = 0
+    for i, (thr, img) in enumerate(cases):
+        h, w = img.shape
+        c = akaze.Context(akaze.Akaze.new(thr), w, h, 1)
+        (kp, d), = c.extract_batch([img])
+        c.close()
+        okp, od = want[i]
+        _kp_eq(kp, okp, f"case {i} ({w}x{h}, thr {thr})")
+        _eq(d, od, f"case {i} descriptors")
+        total += len(kp)
+    assert total > 20000
+
+
+NON_DEFAULT = [
+    ("num_sublevels=2", dict(num_sublevels=2)),
+    ("num_sublevels=3", dict(num_sublevels=3)),
+    ("max_octave_evolution=2", dict(max_octave_evolution=2)),
+    ("max_octave_evolution=3", dict(max_octave_evolution=3)),
+    ("sublevels=5,octaves=5", dict(num_sublevels=5, max_octave_evolution=5)),
+    ("contrast_percentile=0.5", dict(contrast_percentile=0.5)),
+    ("contrast_factor_num_bins=128", dict(contrast_factor_num_bins=128)),
+    ("derivative_factor=1.0", dict(derivative_factor=1.0)),
+    ("derivative_factor=2.0", dict(derivative_factor=2.0)),          # sigma 5: the generic derivative kernels
+    ("descriptor_pattern_size=8", dict(descriptor_pattern_size=8)),
+    ("descriptor_pattern_size=12", dict(descriptor_pattern_size=12)),
+    ("base_scale_offset=1.2", dict(base_scale_offset=1.2)),          # 7-tap level-0 blur: the dense filter path
+    ("base_scale_offset=2.4", dict(base_scale_offset=2.4)),          # 11 taps
+    ("base_scale_offset=1.9", dict(base_scale_offset=1.9)),          # still radius 4: the fused tile kernel
+    ("maximum_features=50,threshold=0.003", dict(maximum_features=50, detector_threshold=0.003)),
+]
+
+
+@pytest.mark.parametrize("name,kw", NON_DEFAULT, ids=[n for n, _ in NON_DEFAULT])
+def test_non_default_configurations(gpu, oracle, name, kw):
+    """Every field of akaze::Akaze (akaze/src/lib.rs:109-142) away from its default: pyramid schedule
+    (evolution.rs:46-58,80-126), contrast factor (contrast_factor.rs:16-64), derivative scale
+    (detector_response.rs:11-13) and descriptor pattern (descriptors.rs:75-98), every buffer and stage vs the
+    oracle, on a width divisible by 4 (two-frame kernels) and on a ragged one (one-frame kernels)."""
+    akaze, _ = gpu
+    for (w, h, seed) in ((640, 400, 5), (333, 251, 6)):
+        img = synth_frame(w, h, seed=seed, n_rect=40, n_disc=40)
+        ak = akaze.Akaze(**kw)
+        cfg = oracle.default_config()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        kp, _ = _compare_pyramid(akaze, oracle, img, None, f"{name} {w}x{h}", ak=ak, ocfg=cfg)
+        assert len(kp) > 20, (name, len(kp))
+
+
+def test_configurations_the_library_refuses(gpu):
+    """What akz_create answers AKZ_E_INVALID to instead of computing something else than the reference:
+    a pyramid of more than 32 levels (the per-frame level tables), more than 510 histogram bins, zero values the
+    reference would divide by, a descriptor pattern whose grids do not have (n+2)^2 cells."""
+    akaze, _ = gpu
+    from cv_amd import _lib
+    for kw, wh in ((dict(num_sublevels=8, max_octave_evolution=5), (1920, 1080)),
+                   (dict(contrast_factor_num_bins=511), (320, 240)),
+                   (dict(num_sublevels=0), (320, 240)), (dict(max_octave_evolution=0), (320, 240)),
+                   (dict(descriptor_channels=4), (320, 240)), (dict(descriptor_pattern_size=1), (320, 240)),
+                   (dict(base_scale_offset=0.0), (320, 240))):
+        with pytest.raises(_lib.AkzError) as ei:
+            akaze.Context(akaze.Akaze(**kw), wh[0], wh[1], 1)
+        assert ei.value.status == -1, (kw, ei.value.status)
+    # 8 sublevels x 4 octaves = 32 levels is the largest pyramid and works
+    ctx = akaze.Context(akaze.Akaze(num_sublevels=8), 640, 480, 1)
+    assert ctx.num_levels(640, 480) == 32
+    ctx.close()
+
+
+def test_luma16_input_arm(gpu, oracle):
+    """GrayFloatImage::from_dynamic, ImageLuma16 arm (image.rs:57-66): v / 65535 on the device == oracle."""
+    akaze, _ = gpu
+    rng = np.random.default_rng(16)
+    for (w, h) in ((320, 240), (333, 251)):
+        img8 = synth_frame(w, h, seed=w, n_rect=30, n_disc=30)
+        img = (img8.astype(np.uint16) * 257 + rng.integers(-120, 121, img8.shape)).clip(0, 65535).astype(np.uint16)
+        kp, desc = akaze.Akaze.default().extract_arrays(img)
+        okp, od = oracle.Akaze(w, h, oracle.default_config()).extract(img)
+        _kp_eq(kp, okp, f"luma16 {w}x{h}")
+        _eq(desc, od, f"luma16 {w}x{h} desc")
+        assert len(kp) > 50
+    # and through the literal ABI entry point
+    import ctypes as C
+    from cv_amd import _lib
+    ctx = akaze.Akaze.default().context(333, 251)
+    kps = np.zeros(8192, _lib.KP_DTYPE); descs = np.zeros((8192, 64), np.uint8); n = C.c_uint32()
+    _lib.check(_lib.lib().akz_extract_gray_u16(ctx.handle, img.ctypes.data, 333, 251, 333, kps.ctypes.data,
+                                               descs.ctypes.data, 8192, C.byref(n)), "akz_extract_gray_u16")
+    assert n.value == len(okp) and kps[:n.value].tobytes() == okp.tobytes()
+
+
+def test_two_contexts_with_different_options_in_one_process(gpu, oracle):
+    """Options are per context (no process-global switches): a keep_all context and a default one side by side,
+    used alternately, give the same outputs; only the former can tap Ldet."""
+    akaze, _ = gpu
+    from cv_amd import _lib
+    img = synth_frame(480, 270, 91)
+    ak = akaze.Akaze.default()
+    a = akaze.Context(ak, 480, 270, 1, _opts(keep_all=True, frame_pairs=False, parallel_suppression=False, pipeline=False))
+    b = akaze.Context(ak, 480, 270, 1)
+    okp, od = oracle.Akaze(480, 270, oracle.default_config()).extract(img)
+    for _ in range(2):
+        for c in (a, b):
+            (kp, d), = c.extract_batch([img])
+            _kp_eq(kp, okp, "ctx")
+            _eq(d, od, "ctx desc")
+    assert a.level_buffer(0, 1, "Ldet", 480, 270).shape == (270, 480)
+    with pytest.raises(_lib.AkzError):
+        b.level_buffer(0, 1, "Ldet", 480, 270)
+    a.close(); b.close()
