@@ -9,12 +9,23 @@ frame g -> rank g mod N; the only exchange is an RCCL all-gathe
 descriptor blocks so that the owner of frame g holds frame g-1's descriptors.  Weak scaling: every rank
 processes its own 256 frames per step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      — the FED diffusion step kernel (calculate_step, the dominant kernel): algorithmic bytes per
-                  launch (12 B per pixel-step x pixels x frames) / HIP-event time on the library's
-                  stream, against the 8 TB/s HBM3E peak.
-  cpu_baseline  — the CPU oracle (a restatement of the reference, kind "port") timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline        — the kernel family that took the most GPU time IN THIS RUN (HIP events recorded by the library
+                    around its launches, on the stream they run on): achieved = the kernel's own algorithmic bytes
+                    (what it must read and write once, given what it fuses: DESIGN.md §5) / its event time, against
+                    the 8 TB/s HBM3E peak, so frac <= 1 by construction; `traffic` = PMC HBM bytes per launch from
+                    the committed rocprofv3 counter passes when they were taken at this micro-batch, else null.
+  roofline_top    — the same triple for the four most expensive kernel families of the run.
+  algorithmic_gbs — SURVEY §8d's contract figure (1.0535 GB per 1080p frame) x the isolated scale-space rate: it
+                    counts every named pyramid buffer once per consuming stage and therefore exceeds what the fused
+                    kernels move; kept for continuity, never used as a roofline fraction.
+  parity_checked  — the GPU keypoints / descriptors / match pairs of the cpu_baseline frames compared with what the
+                    oracle just computed for them (the run FAILS, rc 1, on any mismatch).
+  configs_extra   — BASELINE configs[2] (1 000 x 5 000 Bernoulli descriptors, 999 consecutive pairs) and configs[3]
+                    (10 000 eight-point hypotheses on a 1 000-match scene), each oracle-checked on a sample, each with
+                    its own roofline triple.
+  cpu_baseline    — the CPU oracle (a restatement of the reference, kind "port") timed on this box's host
+                    cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -33,6 +44,24 @@ FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FED_BYTES_PER_PIXEL_STEP = 12.0
+CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage
+FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
+# Kernel families the library times (include/akz.h AKZ_T_*): name, timer id, algorithmic HBM bytes per unit.  A unit
+# is one pixel of one frame covered by one launch; the bytes are what the kernel must move once given what it fuses
+# (DESIGN.md §5): front-end f32 levels 4 in + 4 Lflow + 8 {Lx,Ly} out; level 0: 1 (u8) in + 4 Lt + 8 {Lx,Ly};
+# determinant: 8 in ({Lx,Ly}), candidates only out; FED: 4 L + 4 c in, 4 L out per LAUNCH (up to 8 steps);
+# contrast: 1 (u8) in per pass.
+KERNEL_FAMILIES = [
+    ("k_level_front2<4,2,..,u8> (level 0: u8->f32, blur 1.6, Lt, {Lx,Ly})", 3, 13.0),
+    ("k_level_front2<2,2,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 2)", 4, 16.0),
+    ("k_level_front2<2,3,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 3)", 5, 16.0),
+    ("k_level_front2<2,4,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 4)", 6, 16.0),
+    ("k_deriv_second_cand2<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
+    ("k_deriv_second_cand2<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
+    ("k_deriv_second_cand2<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),
+    ("k_fed_pair<T> (calculate_step, up to 8 steps per launch)", 13, 12.0),
+    ("k_contrast_pair (contrast factor passes)", 10, 1.0),
+]
 MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
 MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4/FP6 MFMA (MI355X_MICROARCH.md; AMD's 20 PF headline is 2:1 sparse)
 
@@ -92,6 +121,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one buffer set in the library (AKZ_OPT_NO_PIPELINE): "
+                    "consecutive calls do not overlap; for counter passes and serial phase profiles")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3])")
+    ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
+    ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU smoke test of the multi-rank path)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
@@ -138,7 +172,7 @@ def main():
     ak = Akaze.default()
     ak.device = local_rank
     ak.max_keypoints = CAP
-    ctx = ak.context(W, H, MB)
+    ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False) if args.no_pipeline else None)
     matcher = Matcher(CAP, device=local_rank)
     akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
     hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
@@ -235,30 +269,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    fam_pipe = read_families(ctx)                 # kernel families inside the timed region (all streams busy)
     fed_ms, fed_launches, fed_units = ctx.timing_get(0)
     ss_ms, _, _ = ctx.timing_get(1)
     all_ms, _, _ = ctx.timing_get(2)
+    desc_ms, _, _ = ctx.timing_get(11)
+    refine_ms, _, _ = ctx.timing_get(12)
     ctx.timing_enable(False)
 
-    # Isolated pass for the roofline: the same FED launches with nothing else on the GPU (in the timed region
-    # above they share the chip with the keypoint and matcher streams of neighbouring micro-batches).
-    iso = None
+    # Isolated pass: the same scale-space launches with nothing else on the GPU (in the timed region above they
+    # share the chip with the keypoint and matcher streams of neighbouring micro-batches).
+    fam_iso, iso_fps = None, None
     if rank == 0:
-        barrier_local = torch.cuda.synchronize
-        barrier_local()
+        torch.cuda.synchronize()
         ctx.timing_enable(True)
         ctx.timing_reset()
         for _ in range(3):
             _lib.check(L.akz_scale_space_device(ctx.handle, frames[:MB].data_ptr(), 0, MB, W, H, None), "scale_space")
             _lib.check(L.akz_sync(ctx.handle), "akz_sync")
-        i_ms, i_launches, i_units = ctx.timing_get(0)
+        fam_iso = read_families(ctx)
         s_ms, _, _ = ctx.timing_get(1)
         ctx.timing_enable(False)
-        if i_ms > 0:
-            iso = {"achieved": round(FED_BYTES_PER_PIXEL_STEP * i_units / (i_ms * 1e-3) / 1e9, 1),
-                   "avg_launch_us": round(i_ms * 1e3 / max(1, i_launches), 2),
-                   "scale_space_frames_per_s": round(3 * MB / (s_ms * 1e-3), 1)}
-            iso["frac"] = round(iso["achieved"] / HBM_PEAK_GBS, 4)
+        iso_fps = 3 * MB / (s_ms * 1e-3) if s_ms > 0 else None
     if world > 1:
         dist.barrier()
 
@@ -294,8 +326,7 @@ def main():
     if rank == 0:
         total_frames = NF * world * args.steps
         fps = total_frames / elapsed
-        fed_bytes = FED_BYTES_PER_PIXEL_STEP * fed_units
-        achieved = fed_bytes / (fed_ms * 1e-3) / 1e9 if fed_ms > 0 else 0.0
+        tops = roofline_entries(fam_pipe, fam_iso, MB)
         out = {
             "metric": "frames/sec AKAZE detect+describe+BF-Hamming-match, 1080p",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -306,53 +337,245 @@ def main():
                                    "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
                        "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
                        "mean_matches_per_pair": round(n_match, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_fed_pair<T> (calculate_step, two frames per block, up to 8 steps per launch)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(MB),
-                         "launches": int(fed_launches),
-                         "avg_launch_us": round(fed_ms * 1e3 / max(1, fed_launches), 2),
-                         "algorithmic_bytes_per_launch": round(fed_bytes / max(1, fed_launches), 0),
-                         "note": "achieved = 12 B x pixel-steps / HIP-event time of the FED launches inside the timed "
-                                 "region (they share the GPU with the other two streams); temporal blocking moves "
-                                 "fewer HBM bytes than the 12 B/pixel-step contract figure, see traffic",
-                         "isolated": iso},
+            "roofline": tops[0] if tops else None,
+            "roofline_top": tops[:4],
             "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
-                                  "extract": round(all_ms / args.steps, 2)},
+                                  "extract": round(all_ms / args.steps, 2), "describe": round(desc_ms / args.steps, 2),
+                                  "refine": round(refine_ms / args.steps, 2)},
         }
+        if iso_fps:
+            out["scale_space_isolated"] = {
+                "frames_per_s": round(iso_fps, 1),
+                "algorithmic_gbs": round(iso_fps * CONTRACT_BYTES_PER_FRAME / 1e9, 1),
+                "note": "configs[1] 'scale-space kernels only' (A1-A11, nothing else on the GPU); algorithmic_gbs = "
+                        "frames/s x SURVEY 8d's 1.0535 GB contract figure, which counts every pyramid buffer once per "
+                        "consuming stage: fused kernels and temporal blocking move less, so it is NOT a roofline "
+                        "fraction (see roofline / roofline_top for those)"}
         if knn_ms.value > 0:
-            # second roofline, for the matcher: 2 directions x nq x nt x 512-bit contractions per frame pair as
-            # int8 MACs (2 ops each) over the HIP-event time of the k_knn_mfma launches on the matcher's stream
+            # the matcher's roofline: 2 directions x nq x nt x 512-bit contractions per frame pair as MACs (2 ops
+            # each) over the HIP-event time of the k-NN launches on the matcher's stream
             pairs_total = NF * args.steps
             macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
-            tops = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
-            fp4 = os.environ.get("AKZ_MATCH_FP4", "1") != "0"
-            peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
+            tops_m = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
             out["roofline_matcher"] = {
-                "bound": "mfma",
-                "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)" if fp4
-                          else "k_knn_mfma<2> (v_mfma_i32_32x32x32_i8)",
-                "achieved": round(tops, 1), "peak": peak, "unit": "TOP/s", "frac": round(tops / peak, 4),
-                "launches": int(knn_launches.value),
+                "bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
+                "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
+                "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4), "traffic": None, "launches": int(knn_launches.value),
                 "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
-                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count; peak = the dense "
-                        "FP4 MFMA figure of MI355X_MICROARCH.md (~10 PF; micro-benchmark ceiling 9.1 PF)" if fp4 else
-                        "ops = 2 x 512 int8 MACs per (query, target) pair with the mean keypoint count; peak = the "
-                        "int8 micro-benchmark ceiling of MI355X_MICROARCH.md (no spec figure is listed for dense I8)"}
-        rf = out["roofline"]
-        if rf["traffic"] and rf["avg_launch_us"]:
-            # what the memory system actually moved (PMC) over the same launch time: the number to hold against
-            # the 8 TB/s peak; `achieved` above counts the contract's 12 B per pixel-step and exceeds the peak
-            # because up to 8 steps share one pass over HBM
-            rf["hbm_side_gbs"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
-            rf["hbm_side_frac"] = round(rf["hbm_side_gbs"] / HBM_PEAK_GBS, 4)
+                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count, inside the timed "
+                        "region; peak = the dense FP4 MFMA figure of MI355X_MICROARCH.md (~10 PF)"}
         out["device"] = device_probe(torch, dev)
+        rc = 0
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, args.cpu_frames)
+            base, oracle_out = cpu_baseline(frames, args.cpu_frames)
+            out["cpu_baseline"] = base
+            # the benchmarked configuration under the oracle: what the GPU produced for those same frames in the
+            # last timed step (default options, micro-batch MB, pipelined) vs what the oracle just computed
+            out["parity_checked"] = parity_check(oracle_out, kps, descs, counts, pairs, npairs, MB)
+            if out["parity_checked"]["mismatches"]:
+                rc = 1
             if args.cpu_procs > 0:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(frames, args.cpu_procs)
+        if world == 1 and not args.no_extras:
+            out["configs_extra"] = {"configs[2]": extra_match(torch, dev, L, _lib, args.extra_frames),
+                                    "configs[3]": extra_ransac(args.extra_hyp)}
+            for v in out["configs_extra"].values():
+                if v.get("parity", {}).get("mismatches"):
+                    rc = 1
         print(json.dumps(out), flush=True)
+        if rc:
+            print("bench.py: GPU output differs from the oracle (see parity_checked / configs_extra)", file=sys.stderr)
+            sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
+
+
+def read_families(ctx):
+    """(name, ms, launches, units, bytes_per_unit) of every timed kernel family since the last timing_reset."""
+    fam = []
+    for name, tid, bpu in KERNEL_FAMILIES:
+        ms, launches, units = ctx.timing_get(tid)
+        if launches:
+            fam.append((name, ms, launches, units, bpu))
+    return fam
+
+
+def roofline_entries(fam_pipe, fam_iso, mb):
+    """Roofline objects of the timed kernel families, most expensive (inside the timed region) first."""
+    iso = {f[0]: f for f in (fam_iso or [])}
+    pmc = pmc_traffic(mb)
+    out = []
+    for name, ms, launches, units, bpu in sorted(fam_pipe, key=lambda f: -f[1]):
+        gbs = units * bpu / (ms * 1e-3) / 1e9
+        e = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(launches),
+             "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2),
+             "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_pixel": bpu,
+             "timed": "HIP events around the launches on the library's scale-space stream, inside the timed region "
+                      "(the keypoint and matcher streams of neighbouring micro-batches share the GPU)"}
+        if name in iso:
+            _, ims, il, iu, _ = iso[name]
+            igbs = iu * bpu / (ims * 1e-3) / 1e9
+            e["isolated"] = {"achieved": round(igbs, 1), "frac": round(igbs / HBM_PEAK_GBS, 4),
+                             "avg_launch_us": round(ims * 1e3 / il, 2)}
+        key = name.split(" ")[0]
+        if pmc and key in pmc["kernels"]:
+            k = pmc["kernels"][key]
+            e["traffic"] = round(k["hbm_bytes_per_launch"])
+            e["traffic_source"] = {"file": pmc["file"], "micro_batch": pmc["micro_batch"],
+                                   "launches_counted": k["launches"]}
+        out.append(e)
+    return out
+
+
+def parity_check(oracle_out, kps, descs, counts, pairs, npairs, mb):
+    """GPU outputs of the first len(oracle_out) frames of the last timed step vs the oracle's (keypoints as raw
+    bytes, descriptor bytes, symmetric better-by-24 match pairs of (frame j, frame j-1))."""
+    n = len(oracle_out)
+    cnt = counts[:n].cpu().numpy()
+    bad = []
+    for j, (okp, od, om) in enumerate(oracle_out):
+        c = int(cnt[j])
+        gk = kps[j, :min(c, CAP)].cpu().numpy().tobytes()
+        gd = descs[j, :min(c, CAP)].cpu().numpy()
+        if c != len(okp) or gk != okp.tobytes() or not np.array_equal(gd, od):
+            bad.append(f"frame {j}: keypoints/descriptors ({c} vs {len(okp)})")
+        if om is not None and j < mb:          # problem j-1 of micro-batch 0 is (frame j, frame j-1)
+            m = int(npairs[j - 1].item())
+            gp = pairs[j - 1, :m].cpu().numpy().astype(np.uint32)
+            if m != len(om) or not np.array_equal(gp, om.astype(np.uint32)):
+                bad.append(f"pair ({j},{j - 1}): matches ({m} vs {len(om)})")
+    return {"frames": n, "pairs": sum(1 for o in oracle_out if o[2] is not None), "mismatches": len(bad),
+            "what": "keypoint bytes, descriptor bytes and symmetric match pairs of the cpu_baseline frames: last timed "
+                    "step's GPU output (default options, pipelined micro-batches) vs the oracle", "detail": bad[:4]}
+
+
+def extra_match(torch, dev, L, _lib, n_frames):
+    """BASELINE configs[2] as SURVEY 8d defines it: n_frames x 5 000 descriptors; frame 0 = 486 i.i.d. Bernoulli(1/2)
+    bits (seed 0xD35C); frame f+1 = 60 % of frame f's descriptors with every bit flipped w.p. 0.05 + 40 % fresh ones,
+    shuffled; consecutive pairs matched symmetrically with d0 + 24 < d1.  Device-resident, one call."""
+    from cv_amd.knn import Matcher, RULE_STRICT
+    from oracle import oracle as O
+    ND, cap = 5000, 5000
+    g = torch.Generator(device=dev).manual_seed(0xD35C)
+    bitmask = torch.zeros(64, dtype=torch.uint8, device=dev)
+    bitmask[:60] = 0xFF
+    bitmask[60] = 0x3F                      # bits 486..511 stay zero
+    w8 = (1 << torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
+
+    def fresh(n):
+        return torch.randint(0, 256, (n, 64), generator=g, device=dev, dtype=torch.uint8) & bitmask
+
+    descs = torch.empty((n_frames, cap, 64), dtype=torch.uint8, device=dev)
+    descs[0] = fresh(ND)
+    for f in range(1, n_frames):
+        keep = torch.randperm(ND, generator=g, device=dev)[:ND * 6 // 10]
+        flips = (torch.rand((len(keep), 64, 8), generator=g, device=dev) < 0.05).to(torch.uint8)
+        flip_bytes = (flips * w8).sum(dim=2).to(torch.uint8) & bitmask
+        nxt = torch.cat([descs[f - 1][keep] ^ flip_bytes, fresh(ND - len(keep))])
+        descs[f] = nxt[torch.randperm(ND, generator=g, device=dev)]
+    counts = torch.full((n_frames,), ND, dtype=torch.int32, device=dev)
+    npr = n_frames - 1
+    pairs = torch.zeros((npr, cap, 2), dtype=torch.int32, device=dev)
+    npairs = torch.zeros((npr,), dtype=torch.int32, device=dev)
+    m = Matcher(cap)
+    ia = (C.c_uint32 * npr)(*range(1, n_frames))
+    ib = (C.c_uint32 * npr)(*range(0, n_frames - 1))
+
+    def run():
+        _lib.check(L.hm_match_batch_device(m.handle, descs.data_ptr(), counts.data_ptr(), descs.data_ptr(),
+                                           counts.data_ptr(), cap, ia, ib, npr, RULE_STRICT, 24, 0.0, 1,
+                                           pairs.data_ptr(), npairs.data_ptr(), None), "match")
+    torch.cuda.synchronize()
+    run()
+    _lib.check(L.hm_sync(m.handle), "sync")
+    _lib.check(L.hm_timing_get(m.handle, None, None, 1), "timing")
+    _lib.check(L.hm_timing_enable(m.handle, 1), "timing")
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    _lib.check(L.hm_sync(m.handle), "sync")
+    dt = (time.perf_counter() - t0) / reps
+    ms, launches = C.c_double(), C.c_uint64()
+    _lib.check(L.hm_timing_get(m.handle, C.byref(ms), C.byref(launches), 1), "timing")
+    _lib.check(L.hm_timing_enable(m.handle, 0), "timing")
+    # oracle on a sample of the pairs
+    sample = sorted({0, npr // 2, npr - 1})
+    bad = 0
+    hd = descs.cpu().numpy()
+    for p_ in sample:
+        want = O.match(hd[p_ + 1], hd[p_], rule=O.RULE_STRICT, param_u=24, symmetric=True).astype(np.uint32)
+        k = int(npairs[p_].item())
+        got = pairs[p_, :k].cpu().numpy().astype(np.uint32)
+        bad += int(k != len(want) or not np.array_equal(got, want))
+    dist_per_pair = 2.0 * ND * ND                      # both directions
+    ops = 2.0 * 512.0 * dist_per_pair * npr * reps     # one MAC = 2 ops per bit of the 512-deep contraction
+    tops = ops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    out = {"workload": f"{n_frames} frames x {ND} descriptors (Bernoulli(1/2) x 486 bits, 60 % carried over with 5 % "
+                       f"bit flips), {npr} consecutive pairs, symmetric d0 + 24 < d1, device-resident",
+           "pairs_per_s": round(npr / dt, 1), "distances_per_s": round(dist_per_pair * npr / dt, 1),
+           "ms_per_call": round(dt * 1e3, 3), "mean_matches_per_pair": round(npairs.float().mean().item(), 1),
+           "roofline": {"bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
+                        "achieved": round(tops, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
+                        "frac": round(tops / MFMA_FP4_PEAK_TOPS, 4), "traffic": None,
+                        "launches": int(launches.value),
+                        "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2)},
+           "parity": {"pairs_checked": len(sample), "mismatches": bad,
+                      "what": "match pair lists of the sampled frame pairs vs oracle/match_oracle.c"}}
+    m.close()
+    return out
+
+
+def extra_ransac(n_hyp):
+    """BASELINE configs[3] as SURVEY 8d defines it: the scene of eight-point/tests/random.rs with 1 000 matches, 30 %
+    outliers, seed 0x5AC, n_hyp eight-sample hypotheses, threshold 1e-7; host buffers in and out."""
+    from cv_amd.ransac import EssentialConsensus
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _two_view_scene
+    rng = np.random.default_rng(0x5AC)
+    n, thr = 1000, 1e-7
+    a, b = _two_view_scene(rng, n, 0.3)
+    samples = np.stack([rng.choice(n, 8, replace=False) for _ in range(n_hyp)]).astype(np.uint32)
+    cons = EssentialConsensus(n, n_hyp)
+    cons.model_inliers(a, b, samples, thr)          # warm-up
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pose, inl, best = cons.model_inliers(a, b, samples, thr)
+    dt = (time.perf_counter() - t0) / reps
+    counts = cons.counts(n_hyp)
+    # oracle: the first `sub` hypotheses in full (per-(hypothesis, pose) inlier counts), and the winning hypothesis
+    # on its own (pose bits and inlier set)
+    sub = min(256, n_hyp)
+    t0 = time.perf_counter()
+    _, _, _, wcounts = O.essential_batch(a, b, samples[:sub], thr)
+    cpu_s = time.perf_counter() - t0
+    bad = int(not np.array_equal(counts[:sub], wcounts))
+    h = best // 4
+    wpose, wbest, winl, wc1 = O.essential_batch(a, b, samples[h:h + 1], thr)
+    bad += int(wbest != best % 4 or wpose.tobytes() != pose.tobytes() or not np.array_equal(winl, inl))
+    bad += int(int(counts.max()) != len(inl) or not np.array_equal(wc1[0], counts[h]))
+    # f64 work per (pose, match) residual: 4x4 design matrix (~250 flops) + cyclic Jacobi (~6 sweeps x 6 rotations x
+    # ~60 flops) ~ 2.4 kflop (DESIGN.md 7); a bound on the order of magnitude, the kernel is f64-VALU bound
+    flops = 2400.0 * n_hyp * 4 * n
+    tf = flops / dt / 1e12
+    out = {"workload": f"{n_hyp} eight-point hypotheses x 4 poses x {n} matches (30 % outliers), threshold 1e-7, "
+                       "host buffers in and out",
+           "hypotheses_per_s": round(n_hyp / dt, 1), "residuals_per_s": round(n_hyp * 4 * n / dt, 1),
+           "ms_per_scene": round(dt * 1e3, 3), "inliers": int(len(inl)), "best_id": int(best),
+           "roofline": {"bound": "fp64-valu", "kernel": "k_rs_score (CameraToCamera::residual, 4x4 Jacobi per (pose, match))",
+                        "achieved": round(tf, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": "~2.4 kflop per residual (estimate, DESIGN.md 7); includes the host<->device copies"},
+           "cpu_oracle": {"hypotheses_per_s": round(sub / cpu_s, 1), "cores": 1,
+                          "sample": f"first {sub} hypotheses, {cpu_s:.1f} s"},
+           "parity": {"hypotheses_checked": sub + 1, "mismatches": bad,
+                      "what": "inlier counts of the first hypotheses x 4 poses, and the winning hypothesis' pose bits, "
+                              "pose index and inlier set, vs oracle/ransac_oracle.c"}}
+    cons.close()
+    return out
 
 
 def device_probe(torch, dev):
@@ -376,22 +599,25 @@ def device_probe(torch, dev):
             "hbm_peak_gbs_spec": HBM_PEAK_GBS}
 
 
-def pmc_traffic_per_launch(mb=None):
-    """HBM bytes per FED launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the k_fed_pair dispatches of one micro-batch / launches;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction for 16-byte coalesced reads)."""
+def pmc_traffic(mb):
+    """HBM bytes per launch of each kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json,
+    made by tools/pmc_traffic.py: WRITE_SIZE and doubled FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction,
+    separate --pmc passes).  Only used when the counters were taken at THIS micro-batch: nothing is rescaled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            fed = json.load(f)["fed"]
-        per_frame = fed["hbm_bytes_per_launch"] / fed["frames_per_launch"]   # a launch covers a whole micro-batch
-        return round(per_frame * (mb or fed["frames_per_launch"]))
+        name = "r02_pmc_traffic.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        if int(d["micro_batch"]) != int(mb):
+            return None
+        return {"file": "profiles/" + name, "micro_batch": d["micro_batch"], "kernels": d["kernels"]}
     except Exception:
         return None
 
 
 def cpu_baseline(frames, n):
     """The CPU oracle (a C restatement of the reference's akaze crate + BF matcher; kind 'port') on the
-    first n frames of the same workload, single thread, on this box's host cores."""
+    first n frames of the same workload, single thread, on this box's host cores.  Also returns what it computed
+    (keypoints, descriptors, match pairs per frame) so the caller can hold the GPU's output against it."""
     from oracle import oracle as O
     n = max(2, min(n, frames.shape[0]))
     host = frames[:n].cpu().numpy()
@@ -399,17 +625,18 @@ def cpu_baseline(frames, n):
     t0 = time.perf_counter()
     prev = None
     nk = 0
+    results = []
     for i in range(n):
         kp, d = orc.extract(host[i])
         nk += len(d)
-        if prev is not None:
-            O.match(d, prev, rule=O.RULE_STRICT, param_u=24, symmetric=True)
+        m = O.match(d, prev, rule=O.RULE_STRICT, param_u=24, symmetric=True) if prev is not None else None
+        results.append((kp, d, m))
         prev = d
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "host_cores_available": os.cpu_count(),
-            "sample": f"first {n} frames of the bench batch: Akaze::default() extract + symmetric match vs previous "
-                      f"frame, single thread, {dt:.1f} s, {nk // n} keypoints/frame"}
+    return ({"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+             "host_cores_available": os.cpu_count(),
+             "sample": f"first {n} frames of the bench batch: Akaze::default() extract + symmetric match vs previous "
+                       f"frame, single thread, {dt:.1f} s, {nk // n} keypoints/frame"}, results)
 
 
 def _cpu_worker(args):

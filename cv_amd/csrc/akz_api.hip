@@ -58,23 +58,25 @@ static hipEvent_t timer_event(AkzTimer* t)
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-void akz_timer_begin(akz_ctx* c, AkzTimer* t)
+void akz_timer_begin(akz_ctx* c, int which, hipStream_t s)
 {
     if (!c->timing) return;
+    AkzTimer* t = &c->timers[which];
     t->cur_start = timer_event(t);
-    if (t->cur_start) hipEventRecord(t->cur_start, c->stream);
+    if (t->cur_start) hipEventRecord(t->cur_start, s);
 }
-void akz_timer_end(akz_ctx* c, AkzTimer* t, uint64_t launches, uint64_t units)
+void akz_timer_end(akz_ctx* c, int which, hipStream_t s, uint64_t launches, uint64_t units, uint64_t units2)
 {
+    AkzTimer* t = &c->timers[which];
     if (!c->timing || !t->cur_start) return;
     hipEvent_t stop = timer_event(t);
     if (!stop) return;
-    // the whole-extract timer closes where the outputs complete: on the keypoint stream
-    hipEventRecord(stop, t == &c->t_all ? c->stream_kp : c->stream);
+    hipEventRecord(stop, s);
     t->pending.emplace_back(t->cur_start, stop);
     t->cur_start = nullptr;
     t->launches += launches;
     t->units += units;
+    t->units2 += units2;
 }
 static void timer_resolve(AkzTimer* t)
 {
@@ -197,9 +199,7 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
         if (c->stream_kp) hipStreamSynchronize(c->stream_kp);
-        timer_free(&c->t_fed);
-        timer_free(&c->t_ss);
-        timer_free(&c->t_all);
+        for (AkzTimer& t : c->timers) timer_free(&t);
         if (c->arena) hipFree(c->arena);
         if (c->d_color) hipFree(c->d_color);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -419,10 +419,10 @@ extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int3
         AKZ_TRY(begin_call(c));
         AKZ_TRY(wait_for(c, stream_to_wait));
         c->cur_n = n;
-        akz_timer_begin(c, &c->t_all);
+        akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
         AKZ_TRY(akz_run_keypoints(c, n, (DevKp*)d_kps, (akz_descriptor*)d_descs, cap_per_img, (uint32_t*)d_n_out));
-        akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+        akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
         return AKZ_OK;
     });
 }
@@ -446,10 +446,10 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
                                      (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
         }
         c->cur_n = n;
-        akz_timer_begin(c, &c->t_all);
+        akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
         AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
-        akz_timer_end(c, &c->t_all, 0, (uint64_t)n);
+        akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
         std::vector<uint32_t> cnt(n);
         AKZ_TRY(check_device_err(c));  // synchronises both streams
         AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
@@ -714,10 +714,10 @@ extern "C" int32_t akz_timing_reset(akz_ctx* c)
 {
     return akz_guard([&]() -> int32_t {
         if (!c) return AKZ_E_INVALID;
-        for (AkzTimer* t : {&c->t_fed, &c->t_ss, &c->t_all}) {
-            timer_resolve(t);
-            t->ms = 0.0;
-            t->launches = t->units = 0;
+        for (AkzTimer& t : c->timers) {
+            timer_resolve(&t);
+            t.ms = 0.0;
+            t.launches = t.units = t.units2 = 0;
         }
         return AKZ_OK;
     });
@@ -725,13 +725,13 @@ extern "C" int32_t akz_timing_reset(akz_ctx* c)
 extern "C" int32_t akz_timing_get(akz_ctx* c, int32_t which, double* ms, uint64_t* launches, uint64_t* units)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || which < 0 || which > 2) return AKZ_E_INVALID;
-        AkzTimer* t = which == 0 ? &c->t_fed : (which == 1 ? &c->t_ss : &c->t_all);
+        if (!c || which < 0 || which >= AKZ_T_COUNT) return AKZ_E_INVALID;
+        AkzTimer* t = &c->timers[which == AKZ_T_FED_PASS ? AKZ_T_FED : which];
         AKZ_HIP(hipSetDevice(c->device));
         timer_resolve(t);
         if (ms) *ms = t->ms;
         if (launches) *launches = t->launches;
-        if (units) *units = t->units;
+        if (units) *units = which == AKZ_T_FED_PASS ? t->units2 : t->units;
         return AKZ_OK;
     });
 }

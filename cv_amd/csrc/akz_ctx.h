@@ -12,7 +12,7 @@ struct AkzTimer {
     std::vector<hipEvent_t> pool;                            // recycled events
     hipEvent_t cur_start = nullptr;
     double ms = 0.0;
-    uint64_t launches = 0, units = 0;
+    uint64_t launches = 0, units = 0, units2 = 0;
 };
 
 // Every per-batch device buffer (pyramid, work lists, outputs).
@@ -100,7 +100,7 @@ struct akz_ctx {
 
     // timing (akz_timing_*)
     bool timing = false;
-    AkzTimer t_fed, t_ss, t_all;
+    AkzTimer timers[AKZ_T_COUNT];   // indexed by the AKZ_T_* ids of include/akz.h
 };
 
 // (Re)build plan + carve the arena for images of w x h. Allocates lazily.
@@ -122,5 +122,6 @@ int32_t akz_upload_tables(akz_ctx* c);
 size_t akz_ori_table_bytes();
 size_t akz_desc_table_bytes();
 
-void akz_timer_begin(akz_ctx* c, AkzTimer* t);
-void akz_timer_end(akz_ctx* c, AkzTimer* t, uint64_t launches, uint64_t units);
+// HIP-event brackets around a group of launches on stream `s` (no-ops unless akz_timing_enable is on)
+void akz_timer_begin(akz_ctx* c, int which, hipStream_t s);
+void akz_timer_end(akz_ctx* c, int which, hipStream_t s, uint64_t launches, uint64_t units, uint64_t units2 = 0);

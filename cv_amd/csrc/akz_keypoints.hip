@@ -1281,9 +1281,11 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     AKZ_LAUNCH_CHECK();
     // A13 + A14
     const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
+    akz_timer_begin(c, AKZ_T_REFINE, s);
     hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, S.d_kp_a, S.d_n_a, c->max_kp, S.d_kp_b,
                        S.d_flag_b, c->d_err, (const float*)S.d_cand_nb, c->max_cand);
     AKZ_LAUNCH_CHECK();
+    akz_timer_end(c, AKZ_T_REFINE, s, 1, (uint64_t)n);
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_kp_b, (const akz_descriptor*)nullptr,
                        S.d_flag_b, S.d_n_a, c->max_kp, S.d_kp_c, (akz_descriptor*)nullptr, c->max_kp, S.d_n_c,
                        c->d_err);
@@ -1296,6 +1298,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                        c->max_kp, maxf, S.d_kp_d, S.d_n_d);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
+    akz_timer_begin(c, AKZ_T_DESCRIBE, s);
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
         hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, T, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift);
@@ -1307,6 +1310,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                            S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
     }
     AKZ_LAUNCH_CHECK();
+    akz_timer_end(c, AKZ_T_DESCRIBE, s, 1, (uint64_t)n);
     hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, S.d_kp_d, S.d_desc_tmp, S.d_flag_d, S.d_n_d,
                        c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();

@@ -1636,9 +1636,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     GaussTaps t1 = make_taps(1.0f);
     if (t1.n != 5 || (tile0 && t0.n != 9)) return AKZ_E_INTERNAL;
 
-    akz_timer_begin(c, &c->t_ss);
+    akz_timer_begin(c, AKZ_T_SCALE_SPACE, s);
     // lib.rs:199-201 — Lt[0] = gaussian_blur(image, base_scale_offset); Lsmooth[0] = Lt[0]
     const bool fused0 = tile0 && P.levels[0].deriv_sigma == 2;  // fused blur + first derivatives (default config)
+    akz_timer_begin(c, AKZ_T_FRONT0, s);
     if (fused0 && (w & 3) == 0 && c->front_pair) {
 #define AKZ_FRONT0(THV, NTV, TPBV)                                                                                  \
     hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
@@ -1675,12 +1676,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             AKZ_LAUNCH_CHECK();
         }
     }
+    akz_timer_end(c, AKZ_T_FRONT0, s, 1, (uint64_t)P0 * n);
     // lib.rs:206-211 — contrast factor on the ORIGINAL image
     AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
     AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
     AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * kAkzMaxLevels * (size_t)n, s));
     const bool pairc = (w & 3) == 0 && c->front_pair && nbins <= 510;
+    akz_timer_begin(c, AKZ_T_CONTRAST, s);
     const bool fine = pairc && c->contrast_fine;
     if (pairc) {
         dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), kCTiles), (n + 1) / 2);
@@ -1709,6 +1712,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                        S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk,
                        fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
+    akz_timer_end(c, AKZ_T_CONTRAST, s, 2, (uint64_t)P0 * n);
 
     uint64_t fed_launches = 0, fed_units = 0;
     for (int i = 0; i < nlev; ++i) {
@@ -1742,7 +1746,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             }
             // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
             fused_front = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
+            const int t_front = AKZ_T_FRONT_SG2 + (int)L.deriv_sigma - 2;
             if (fused_front) {
+                akz_timer_begin(c, t_front, s);
                 float* lsm_out = c->keep_all ? S.Lsm[i] : nullptr;  // Lsmooth stays on chip unless the taps want it
                 dim3 gridf(akz_div_up(L.w, kTW), akz_div_up(L.h, kTH), n);
                 OffK kk = make_offk(L.deriv_sigma);
@@ -1766,12 +1772,13 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #undef AKZ_FRONT2
 #undef AKZ_FRONT2X
                 AKZ_LAUNCH_CHECK();
+                akz_timer_end(c, t_front, s, 1, (uint64_t)fs * n);
             } else {
                 AKZ_TRY((launch_blur<2, 1, float, EPI_FLOW>(c, init, L.w, L.h, fs, t1, S.Lsm[i], S.Lflow[i], fs,
                                                            (int)L.octave, n)));
             }
             // lib.rs:251-256 — FED cycle
-            akz_timer_begin(c, &c->t_fed);
+            akz_timer_begin(c, AKZ_T_FED, s);
             const float* src = init;
             if (blocked) {
                 // temporally blocked: groups of up to fed_block steps per launch; the ping-pong parity is
@@ -1812,7 +1819,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 AKZ_LAUNCH_CHECK();
                 src = dst;
             }
-            akz_timer_end(c, &c->t_fed, (uint64_t)nwrites, (uint64_t)nsteps * fs * n);
+            akz_timer_end(c, AKZ_T_FED, s, (uint64_t)nwrites, (uint64_t)nsteps * fs * n, (uint64_t)nwrites * fs * n);
             fed_launches += nsteps;
             fed_units += (uint64_t)nsteps * fs * n;
             if (nsteps == 0 && init != bufA)
@@ -1846,6 +1853,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                        dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i],     \
                        ldet_out, L.w, L.h, fs, n, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
+            const bool t_det_on = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
+            if (t_det_on) akz_timer_begin(c, AKZ_T_DET_SG2 + (int)L.deriv_sigma - 2, s);
             switch (L.deriv_sigma) {
             case 2: if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
             case 3: if (pair2) { AKZ_D2P(3); } else AKZ_D2(3); break;
@@ -1855,6 +1864,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #undef AKZ_D2
 #undef AKZ_D2P
             AKZ_LAUNCH_CHECK();
+            if (t_det_on) akz_timer_end(c, AKZ_T_DET_SG2 + (int)L.deriv_sigma - 2, s, 1, (uint64_t)fs * n);
         }
     }
     {
@@ -1864,7 +1874,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                            S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
         AKZ_LAUNCH_CHECK();
     }
-    akz_timer_end(c, &c->t_ss, 0, (uint64_t)n);
+    akz_timer_end(c, AKZ_T_SCALE_SPACE, s, 0, (uint64_t)n);
     (void)fed_launches;
     (void)fed_units;
     return AKZ_OK;

@@ -316,9 +316,28 @@ int32_t akz_last_hip_error(void);
 const char* akz_last_hip_error_string(void);
 const char* akz_version(void);
 
-/* HIP-event timing of the dominant kernels of the last batch (for bench.py's roofline object):
- * which: 0 = FED diffusion steps (calculate_step), 1 = whole scale space, 2 = whole extract.
- * Returns accumulated milliseconds and launch count since akz_timing_reset(). */
+/* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Events are recorded by the
+ * library on the stream each family is launched on, around the launches themselves.  `which` is an AKZ_T_* id;
+ * the call returns the milliseconds, launch count and processed units accumulated since akz_timing_reset():
+ * units = pixel-frames the launches covered (FED: pixel-steps, the contract's unit; AKZ_T_FED_PASS reports the
+ * same launches with units = pixel-frames per launch, i.e. passes over memory). */
+enum {
+    AKZ_T_FED = 0,        /* k_fed_pair / k_fed_step (calculate_step)                          units: pixel-steps */
+    AKZ_T_SCALE_SPACE = 1, /* the whole scale space of a call                                  units: frames */
+    AKZ_T_EXTRACT = 2,    /* the whole extract call (closes on the keypoint stream)            units: frames */
+    AKZ_T_FRONT0 = 3,     /* level-0 front end: pixels -> blur 1.6 -> Lt[0], {Lx,Ly}           units: pixel-frames */
+    AKZ_T_FRONT_SG2 = 4,  /* level front end (blur 1.0, Lflow, {Lx,Ly}) at derivative sigma 2  units: pixel-frames */
+    AKZ_T_FRONT_SG3 = 5,
+    AKZ_T_FRONT_SG4 = 6,
+    AKZ_T_DET_SG2 = 7,    /* second derivatives + determinant + extrema candidates, sigma 2    units: pixel-frames */
+    AKZ_T_DET_SG3 = 8,
+    AKZ_T_DET_SG4 = 9,
+    AKZ_T_CONTRAST = 10,  /* contrast-factor passes                                            units: pixel-frames per pass */
+    AKZ_T_DESCRIBE = 11,  /* M-LDB descriptors (keypoint stream)                               units: frames */
+    AKZ_T_REFINE = 12,    /* sub-pixel refinement + orientation (keypoint stream)              units: frames */
+    AKZ_T_FED_PASS = 13,  /* = AKZ_T_FED with units = pixel-frames per launch */
+    AKZ_T_COUNT = 14
+};
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);
 int32_t akz_timing_get(akz_ctx* ctx, int32_t which, double* ms, uint64_t* launches, uint64_t* units);

@@ -723,7 +723,7 @@ def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     m1, m2 = tmp_path / "m1.npy", tmp_path / "m2.npy"
-    common = ["--micro-batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    common = ["--micro-batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "32", "--dump-matches", str(m1)] + common,
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)

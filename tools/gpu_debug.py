@@ -7,13 +7,12 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("AKZ_KEEP_ALL", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cv_amd import build  # noqa: E402
 build.build()
-from cv_amd import akaze, knn  # noqa: E402
+from cv_amd import _lib, akaze, knn  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from conftest import synth_frame  # noqa: E402
 
@@ -34,7 +33,7 @@ def run(img, thr, name):
     h, w = img.shape
     print(f"=== {name} {w}x{h} thr={thr}")
     ak = akaze.Akaze.new(thr)
-    ctx = ak.context(w, h, 1)
+    ctx = ak.context(w, h, 1, options=_lib.make_options(keep_all=True))
     t = time.time()
     (kp, desc), = ctx.extract_batch([img])
     print(f"gpu extract {time.time()-t:.3f}s n={len(kp)}")

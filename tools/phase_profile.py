@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Serial phase profile: the bench workload's micro-batch run one phase at a time with a device sync in
 between (no cross-stream overlap), so `rocprofv3 --kernel-trace --stats` durations are per-kernel costs on an
-otherwise idle GPU.  usage: AKZ_PIPELINE=0 rocprofv3 ... -- python tools/phase_profile.py [--mb 64] [--reps 3]"""
+otherwise idle GPU (the context is created with AKZ_OPT_NO_PIPELINE).
+usage: rocprofv3 ... -- python tools/phase_profile.py [--mb 64] [--reps 3]"""
 import argparse
 import ctypes as C
 import os
 import sys
 import time
 
-os.environ.setdefault("AKZ_PIPELINE", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
@@ -33,7 +33,7 @@ def main():
     frames = bench.make_frames(torch, dev, 0, MB, 1)
     ak = Akaze.default()
     ak.max_keypoints = CAP
-    ctx = ak.context(W, H, MB)
+    ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False))
     matcher = Matcher(CAP, device=0)
     kps = torch.zeros((MB, CAP, 28), dtype=torch.uint8, device=dev)
     descs = torch.zeros((MB, CAP, 64), dtype=torch.uint8, device=dev)

@@ -1,13 +1,34 @@
 #!/usr/bin/env python3
-"""Build profiles/r01_pmc_traffic.json from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs
-of `bench.py --frames 64 --micro-batch 64 --steps 1 --warmup 0 --no-cpu-baseline` with AKZ_PIPELINE=0).
-usage: pmc_traffic.py fetch.db write.db out.json [frames_per_launch]"""
+"""Build profiles/rNN_pmc_traffic.json from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
+`bench.py --frames MB --micro-batch MB --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-pipeline`).
+HBM bytes = WRITE_SIZE + 2 x FETCH_SIZE (KiB units; FETCH_SIZE doubled: the gfx950 correction for 16-byte reads of
+MI355X_MICROARCH.md).  bench.py attaches these per-launch figures as roofline.traffic only when its micro-batch
+equals the one recorded here.
+usage: pmc_traffic.py fetch.db write.db out.json micro_batch"""
 import json
 import re
 import sqlite3
 import sys
 
-FED_BYTES_PER_PIXEL_STEP = 12
+
+def family_key(name):
+    """rocprof kernel name -> the family key bench.py's KERNEL_FAMILIES use (template arguments that do not
+    change the algorithm are folded)."""
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void\s+", "", n)
+    n = re.sub(r"\(.*$", "", n)
+    m = re.match(r"k_level_front2<(\d+), (\d+), \d+, \d+, ([a-z ]+),", n)
+    if m:
+        src = {"unsigned char": ",u8", "unsigned short": ",u16"}.get(m.group(3), "") if m.group(1) == "4" else ""
+        return f"k_level_front2<{m.group(1)},{m.group(2)},..{src}>"
+    m = re.match(r"k_deriv_second_cand2<(\d+),", n)
+    if m:
+        return f"k_deriv_second_cand2<{m.group(1)},..>"
+    if n.startswith("k_fed_pair<"):
+        return "k_fed_pair<T>"
+    if n.startswith("k_contrast_pair<"):
+        return "k_contrast_pair"
+    return n
 
 
 def per_kernel(path, counter):
@@ -15,35 +36,30 @@ def per_kernel(path, counter):
     rows = db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
     agg = {}
     for name, val in rows:
-        n = re.sub(r"\(anonymous namespace\)::", "", name)
-        n = re.sub(r"^void\s+", "", n)
-        n = re.sub(r"\(.*$", "", n)
-        a = agg.setdefault(n, [0, 0.0])
+        a = agg.setdefault(family_key(name), [0, 0.0])
         a[0] += 1
         a[1] += float(val)
     return agg
 
 
-def main(fetch_db, write_db, out, frames=64):
+def main(fetch_db, write_db, out, mb):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --frames 64 "
-                     "--micro-batch 64 --steps 1 --warmup 0, AKZ_PIPELINE=0; units KiB; FETCH_SIZE doubled (gfx950 "
-                     "16-byte-read correction, MI355X_MICROARCH.md)"}
-    fed_f = sum(v[1] for k, v in f.items() if k.startswith("k_fed_"))
-    fed_w = sum(v[1] for k, v in w.items() if k.startswith("k_fed_"))
-    fed_n = sum(v[0] for k, v in f.items() if k.startswith("k_fed_"))
-    res["fed"] = {"launches": fed_n, "fetch_size_kib": round(2 * fed_f, 1), "write_size_kib": round(fed_w, 1),
-                  "hbm_bytes_per_launch": round((2 * fed_f + fed_w) * 1024 / max(1, fed_n)),
-                  "frames_per_launch": int(frames)}
-    for k in sorted(f, key=lambda k: -f[k][1])[:12]:
-        if k.startswith("k_fed_"):
-            continue
-        res[k] = {"dispatches": f[k][0], "fetch_size_kib": round(2 * f[k][1], 1),
-                  "write_size_kib": round(w.get(k, [0, 0.0])[1], 1)}
+    res = {"micro_batch": int(mb),
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --frames {mb} "
+                     f"--micro-batch {mb} --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-pipeline; KiB units; "
+                     "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 16-byte-read correction, "
+                     "MI355X_MICROARCH.md); every dispatch of the run is counted (the isolated scale-space passes "
+                     "included: same kernels, same sizes)",
+           "kernels": {}}
+    for k in sorted(f, key=lambda k: -f[k][1]):
+        n = f[k][0]
+        wk = w.get(k, [0, 0.0])[1]
+        res["kernels"][k] = {"launches": n, "fetch_size_kib_x2": round(2 * f[k][1], 1), "write_size_kib": round(wk, 1),
+                             "hbm_bytes_per_launch": round((2 * f[k][1] + wk) * 1024 / max(1, n))}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res["fed"]))
+    print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in list(res["kernels"].items())[:8]}))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else 64)
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4])

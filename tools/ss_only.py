@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Scale space alone (akz_scale_space_device, 128 synthetic 1080p frames), best of several runs: frames/s.
-For quick A/B runs of scale-space changes under different AKZ_* switches."""
+For quick A/B runs of scale-space changes."""
 import os
 import sys
 import time
