@@ -69,6 +69,9 @@ struct akz_ctx {
     int fed_block = 8;        // most FED steps fused per launch (1 = one launch per step; the first octave stops at 4); env AKZ_FED_BLOCK
     bool front_pair = true;   // two-frame packed front kernel (AKZ_FRONT_PAIR=0 selects the one-frame kernel)
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
+    bool stream_kernels = true;   // row-streaming kernels (k_det_stream) instead of the tile kernels (AKZ_OPT_TILE_KERNELS)
+    int det_stream_waves = 8192;  // waves a streaming launch aims for (sets the row-segment length)
+    size_t stream_min_pixels = 0; // launches covering fewer pixel-frames than this take the tile kernels
 
     AkzPlan plan;             // for (cur_w, cur_h)
     int cur_w = 0, cur_h = 0, cur_n = 0;

@@ -1221,7 +1221,33 @@ struct CandParams {
     float border;      // smax * sigma_size  (scale_space_extrema.rs:97-100)
     uint32_t level;
     uint32_t cap;      // per-level capacity of the candidate list
+    // the pixels that are interior (:50) AND pass the border test (:96-104), as inclusive integer ranges: the test is
+    // monotone in x and in y, so the host evaluates the reference's f32 expressions once per column / row
+    int x_lo, x_hi, y_lo, y_hi;
 };
+
+// scale_space_extrema.rs:96-104 for one coordinate: round(p - border) - 1 >= 0 and round(p + border) + 1 < extent
+static bool border_ok_1d(int p, float border, int extent)
+{
+    const float f = (float)p;
+    volatile float lo = f - border, hi = f + border;     // one f32 rounding each, as on the device
+    return !(roundf(lo) - 1.0f < 0.0f) && !(roundf(hi) + 1.0f >= (float)extent);
+}
+static void cand_ranges(CandParams* cp, int w, int h)
+{
+    cp->x_lo = cp->y_lo = 1 << 30;
+    cp->x_hi = cp->y_hi = -1;
+    for (int x = 1; x <= w - 2; ++x)
+        if (border_ok_1d(x, cp->border, w)) {
+            if (x < cp->x_lo) cp->x_lo = x;
+            cp->x_hi = x;
+        }
+    for (int y = 1; y <= h - 2; ++y)
+        if (border_ok_1d(y, cp->border, h)) {
+            if (y < cp->y_lo) cp->y_lo = y;
+            cp->y_hi = y;
+        }
+}
 
 template <int SG>  // SG = deriv_sigma (2, 3 or 4); 0 = generic (direct global gathers)
 __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
@@ -1459,6 +1485,223 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the second-order pass (detector_response.rs:65-67,:46 + scale_space_extrema.rs:34-60,96-104).
+// The tile kernels above re-stage {Lx,Ly} rows for every 12-row tile (a 1.5-1.8x halo), evaluate each horizontal
+// partial once per OUTPUT row that uses it (three times for H_main(Lx), twice for the H_off rows), park at block
+// barriers and append every candidate with its own atomic (thousands of returns on one counter per launch).
+// Here a WAVE walks down the rows of a band of 128 columns of one frame (two columns per lane) with NO shared memory
+// in its loop:
+//   * every {Lx,Ly} row is read once (per pixel, at clamped coordinates: any width, borders included — a position
+//     outside the image holds the value at its clamped coordinate, which is the reference's edge replication);
+//   * the neighbouring columns come from the adjacent lanes by DPP wave shifts (the lanes at the ends of the wave
+//     receive zeros: they are the band's halo and produce nothing);
+//   * the horizontal partials of the row
+//         hm = Lx(x+s) - Lx(x-s)                       (H_main of scharr_horizontal(Lx),     -> Lxx)
+//         ho = off(P(x-s), P(x), P(x+s)), P = {Lx,Ly}  (H_off  of scharr_vertical(Lx / Ly), -> Lxy, Lyy; one packed chain)
+//     are computed ONCE and kept in a register ring of the last 2s+1 rows; the loop is unrolled by the ring length,
+//     so every ring index is a compile-time constant;
+//   * determinant row r comes out of ring rows r-s, r, r+s in exactly the reference's operation order:
+//         Lxx = off(hm[r-s], hm[r], hm[r+s]),  {Lxy, Lyy} = ho[r+s] - ho[r-s],  Ldet = (Lxx*Lyy - Lxy*Lxy) * s^4;
+//   * the last three determinant rows stay in registers with their horizontal 3-maxima, so the 3x3 extremum test of
+//     row r-1 is three max operations and two compares per pixel (strictly greater than all eight neighbours ==
+//     strictly greater than their maximum);
+//   * candidates (rare) collect in a small LDS buffer private to the wave and reach the frame's list with one atomic
+//     per flush.
+template <int SG>
+__device__ __forceinline__ float off_combine_s(const OffK k, float a, float b, float c)
+{
+    const float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
+    return SG == 4 ? (pa + pb) + pc : (pa + pc) + pb;
+}
+
+constexpr int det_stream_halo(int SG) { return (SG + 2) & ~1; }                    // columns each side: even, >= SG + 1
+constexpr int det_stream_band(int SG) { return 128 - 2 * det_stream_halo(SG); }     // useful columns per wave
+
+// value of lane (lane - N) [N > 0] or (lane + |N|) [N < 0] of the WAVE, 0 beyond its ends: DPP wave_shr:1 /
+// wave_shl:1 (GFX9 encodings 0x138 / 0x130, one lane per instruction; two hops for |N| = 2)
+template <int N>
+__device__ __forceinline__ float dpp_shift(float v)
+{
+    static_assert(N >= -2 && N <= 2 && N != 0, "one or two lanes");
+    constexpr int ctrl = N > 0 ? 0x138 : 0x130;
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true);
+    if (N == 2 || N == -2) x = __builtin_amdgcn_update_dpp(0, x, ctrl, 0xF, 0xF, true);
+    return __int_as_float(x);
+}
+
+constexpr int kCandBuf = 64;   // candidates a wave collects before it appends them with one atomic
+
+// append the n buffered candidates of a wave to the (frame, level) list (n is wave-uniform)
+__device__ __forceinline__ void cand_flush(const CandU* buf, int n, int lane, CandU* __restrict__ cand,
+                                           uint32_t* __restrict__ ncand, size_t list, uint32_t cap, uint32_t* __restrict__ err)
+{
+    if (n == 0) return;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ncand[list], (uint32_t)n);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + (uint32_t)n > cap) *err = 1u;
+    // 10 dwords per record, copied dword by dword: consecutive lanes write consecutive addresses
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(buf);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(cand + list * cap + base);
+    const int room = base < cap ? (int)min((uint32_t)n, cap - base) : 0;
+    for (int i = lane; i < room * 10; i += 64) dst[i] = src[i];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int SG, bool WRITE_DET>
+__global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
+                                                    size_t fs, OffK k, float sigma_quat, CandParams cp,
+                                                    CandU* __restrict__ cand, uint32_t* __restrict__ ncand,
+                                                    uint32_t* __restrict__ err, int nbands, int seg_rows)
+{
+    constexpr int NR = 2 * SG + 1;                 // ring length = unroll factor
+    constexpr int KC = (SG + 1) / 2;               // neighbour lanes (2 pixels each) needed on either side
+    constexpr int HB = det_stream_halo(SG), BW = det_stream_band(SG);
+    constexpr int NP = 2 * (2 * KC + 1);           // pixels in a lane's window: offsets -2 KC .. 2 KC + 1
+    constexpr int PF = 2;                          // rows in flight (deeper prefetch measured no different)
+    __shared__ __attribute__((aligned(16))) CandU s_cb[4][kCandBuf];        // the wave's pending candidates
+    int nbuf = 0;                                                            // wave-uniform
+    // the wave index is wave-uniform: tell the compiler, so the whole row walk (row numbers, clamps, row base
+    // addresses, loop control) lives in SGPRs and on the scalar unit
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int frame = blockIdx.y;
+    const int item = (int)blockIdx.x * 4 + wv;
+    const int band = item % nbands, seg = item / nbands;
+    const int ys = seg * seg_rows;
+    if (ys >= h) return;                            // whole wave (no block barrier anywhere)
+    const int ye = min(ys + seg_rows, h);
+    // the lane's columns x0, x0 + 1 and the useful columns [bx, ux_hi) of the band
+    const int bx = band * BW;
+    const int x0 = bx - HB + 2 * lane;
+    const int ux_hi = min(bx + BW, w);
+    const float2* D = Lxy + (size_t)frame * fs;
+    const int cx0 = clampi(x0, 0, w - 1), cx1 = clampi(x0 + 1, 0, w - 1);
+    const size_t list = (size_t)frame * kAkzMaxLevels + cp.level;
+    auto load_row = [&](int y) {
+        const float2* r = D + (size_t)clampi(y, 0, h - 1) * w;     // scalar base + per-lane 32-bit offsets
+        const float2 a = r[cx0], b = r[cx1];
+        return make_float4(a.x, a.y, b.x, b.y);
+    };
+    float hm[NR][2];
+    v2f ho[NR][2];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        hm[i][0] = hm[i][1] = 0.0f;
+        ho[i][0] = ho[i][1] = splat(0.0f);
+    }
+    // determinant rows ys-1 .. ye are needed (the candidate rows and their 3x3 ring): input rows ys-1-SG .. ye+SG
+    const int y_first = ys - 1 - SG, y_last = ye + SG;
+    // candidate rows [rc_lo, rc_hi) and columns: interior (:50) and inside the border test (:96-104; a candidate
+    // failing it can neither push nor replace, :105) — integer ranges from the host (CandParams)
+    const int rc_lo = max(ys, cp.y_lo), rc_hi = min(ye, cp.y_hi + 1);
+    const bool in0 = x0 >= bx && x0 < ux_hi, in1 = x0 + 1 >= bx && x0 + 1 < ux_hi;   // columns this lane answers for
+    const bool useful0 = in0 && x0 >= cp.x_lo && x0 <= cp.x_hi, useful1 = in1 && x0 + 1 >= cp.x_lo && x0 + 1 <= cp.x_hi;
+    // determinant rows r-2 (A), r-1 (B) of the lane's two pixels, the 3-maxima of row A and of row B, and the
+    // side maximum (left, right) of row B
+    float dA[2] = {0.f, 0.f}, dB[2] = {0.f, 0.f}, h3A[2] = {0.f, 0.f}, h3B[2] = {0.f, 0.f}, s2B[2] = {0.f, 0.f};
+    float4 nx[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) nx[i] = load_row(y_first + i);
+    for (int base = y_first; base <= y_last; base += NR) {
+#pragma unroll
+        for (int kk = 0; kk < NR; ++kk) {
+            const int yi = base + kk;
+            const float4 cur = nx[0];
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i) nx[i] = nx[i + 1];
+            nx[PF - 1] = load_row(yi + PF);
+            // the row's window: pixels -2 KC .. 2 KC + 1 relative to x0, from the neighbouring lanes
+            v2f P[NP];
+            {
+                float4 t[2 * KC + 1];
+                t[KC] = cur;
+                t[KC - 1] = make_float4(dpp_shift<1>(cur.x), dpp_shift<1>(cur.y), dpp_shift<1>(cur.z), dpp_shift<1>(cur.w));
+                t[KC + 1] = make_float4(dpp_shift<-1>(cur.x), dpp_shift<-1>(cur.y), dpp_shift<-1>(cur.z), dpp_shift<-1>(cur.w));
+                if (KC > 1) {
+                    t[KC - 2] = make_float4(dpp_shift<2>(cur.x), dpp_shift<2>(cur.y), dpp_shift<2>(cur.z), dpp_shift<2>(cur.w));
+                    t[KC + 2] = make_float4(dpp_shift<-2>(cur.x), dpp_shift<-2>(cur.y), dpp_shift<-2>(cur.z), dpp_shift<-2>(cur.w));
+                }
+#pragma unroll
+                for (int j = 0; j <= 2 * KC; ++j) {
+                    P[2 * j] = (v2f){t[j].x, t[j].y};
+                    P[2 * j + 1] = (v2f){t[j].z, t[j].w};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                constexpr int C0 = 2 * KC;
+                hm[kk][j] = P[C0 + j + SG].x - P[C0 + j - SG].x;
+                ho[kk][j] = off_combine_sg<SG>(k, P[C0 + j - SG], P[C0 + j], P[C0 + j + SG]);
+            }
+            // determinant row r = yi - SG: ring rows r - SG (oldest), r, r + SG (the one just made)
+            const int so = (kk + 1) % NR, sm = (kk + 1 + SG) % NR;
+            float dC[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float lxx = off_combine_s<SG>(k, hm[so][j], hm[sm][j], hm[kk][j]);
+                const v2f d2 = ho[kk][j] - ho[so][j];                      // {Lxy, Lyy}
+                dC[j] = (lxx * d2.y - d2.x * d2.x) * sigma_quat;
+            }
+            const int r = yi - SG;
+            if (WRITE_DET && r >= ys && r < ye) {              // the Ldet planes exist for the parity taps only
+                float* dst = Ldet + (size_t)frame * fs + (size_t)r * w;
+                if (in0) dst[x0] = dC[0];
+                if (in1) dst[x0 + 1] = dC[1];
+            }
+            // horizontal maxima of the new row: pixel 0 has neighbours (left lane's pixel 1, own pixel 1), pixel 1
+            // has (own pixel 0, right lane's pixel 0)
+            const float lC = dpp_shift<1>(dC[1]), rC = dpp_shift<-1>(dC[0]);
+            const float s2C[2] = {fmaxf(lC, dC[1]), fmaxf(dC[0], rC)};
+            const float h3C[2] = {fmaxf(s2C[0], dC[0]), fmaxf(s2C[1], dC[1])};
+            // extremum test of row rc = r - 1 (rows A, B, C = rc - 1, rc, rc + 1)
+            const int rc = r - 1;
+            if (rc >= rc_lo && rc < rc_hi) {                    // wave-uniform
+                bool isc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float nbm = fmaxf(fmaxf(h3A[j], h3C[j]), s2B[j]);
+                    isc[j] = (j == 0 ? useful0 : useful1) && dB[j] > cp.thr && dB[j] > nbm;
+                }
+                const unsigned long long m0 = __ballot(isc[0]), m1 = __ballot(isc[1]);
+                if ((m0 | m1) != 0ull) {                        // wave-uniform and rare: build the records
+                    const float lA = dpp_shift<1>(dA[1]), rA = dpp_shift<-1>(dA[0]);
+                    const float lB = dpp_shift<1>(dB[1]), rB = dpp_shift<-1>(dB[0]);
+                    // columns x0-1 .. x0+2 of the three rows
+                    const float rm[4] = {lA, dA[0], dA[1], rA};
+                    const float rz[4] = {lB, dB[0], dB[1], rB};
+                    const float rp[4] = {lC, dC[0], dC[1], rC};
+                    const int cnt = __popcll(m0) + __popcll(m1);
+                    if (nbuf + cnt > kCandBuf) {
+                        cand_flush(s_cb[wv], nbuf, lane, cand, ncand, list, cp.cap, err);
+                        nbuf = 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned long long m = j == 0 ? m0 : m1;
+                        if (isc[j]) {
+                            const int slot = nbuf + (j == 1 ? __popcll(m0) : 0) +
+                                             (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            CandU cu = {(uint32_t)(x0 + j) | ((uint32_t)rc << 16), rz[1 + j],
+                                        {rm[j], rm[j + 1], rm[j + 2], rz[j], rz[j + 2], rp[j], rp[j + 1], rp[j + 2]}};
+                            s_cb[wv][slot] = cu;
+                        }
+                    }
+                    nbuf += cnt;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                dA[j] = dB[j]; dB[j] = dC[j];
+                h3A[j] = h3B[j]; h3B[j] = h3C[j];
+                s2B[j] = s2C[j];
+            }
+        }
+    }
+    cand_flush(s_cb[wv], nbuf, lane, cand, ncand, list, cp.cap, err);
 }
 
 // Raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
@@ -1843,6 +2086,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             cp.border = smax * sigma_size;
             cp.level = (uint32_t)i;
             cp.cap = c->max_cand;
+            cand_ranges(&cp, L.w, L.h);
             dim3 grid2(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
             float* ldet_out = c->keep_all ? S.Ldet[i] : nullptr;   // refinement reads the candidates' own 3x3 values
 #define AKZ_D2(SGV)                                                                                                  \
@@ -1855,12 +2099,34 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
             const bool t_det_on = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
             if (t_det_on) akz_timer_begin(c, AKZ_T_DET_SG2 + (int)L.deriv_sigma - 2, s);
+            // streaming kernel: a wave per (band of columns, segment of rows, frame); segments sized so that the
+            // launch holds a few waves per SIMD of the chip, never shorter than 32 rows (each segment re-reads
+            // 2 sigma + 2 rows of warm-up)
+#define AKZ_DS(SGV)                                                                                                  \
+    {                                                                                                                \
+        const int nb = akz_div_up(L.w, det_stream_band(SGV));                                                        \
+        int nseg = akz_div_up(c->det_stream_waves, nb * n);                                                          \
+        const int max_seg = akz_div_up(L.h, 32);                                                                     \
+        nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);                                                     \
+        const int seg_rows = akz_div_up(L.h, nseg);                                                                  \
+        nseg = akz_div_up(L.h, seg_rows);                                                                            \
+        if (ldet_out)                                                                                                \
+            hipLaunchKernelGGL((k_det_stream<SGV, true>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i],  \
+                               ldet_out, L.w, L.h, fs, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err, nb, \
+                               seg_rows);                                                                            \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_det_stream<SGV, false>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i], \
+                               ldet_out, L.w, L.h, fs, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err, nb, \
+                               seg_rows);                                                                            \
+    }
+            const bool stream = c->stream_kernels && t_det_on && L.w >= 8 && fs * (size_t)n >= c->stream_min_pixels;
             switch (L.deriv_sigma) {
-            case 2: if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
-            case 3: if (pair2) { AKZ_D2P(3); } else AKZ_D2(3); break;
-            case 4: if (pair2) { AKZ_D2P(4); } else AKZ_D2(4); break;
+            case 2: if (stream) { AKZ_DS(2); } else if (pair2) { AKZ_D2P(2); } else AKZ_D2(2); break;
+            case 3: if (stream) { AKZ_DS(3); } else if (pair2) { AKZ_D2P(3); } else AKZ_D2(3); break;
+            case 4: if (stream) { AKZ_DS(4); } else if (pair2) { AKZ_D2P(4); } else AKZ_D2(4); break;
             default: AKZ_D2(0); break;
             }
+#undef AKZ_DS
 #undef AKZ_D2
 #undef AKZ_D2P
             AKZ_LAUNCH_CHECK();

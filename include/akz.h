@@ -98,7 +98,8 @@ enum {
     AKZ_OPT_NO_PIPELINE = 1u << 3,        /* one buffer set: consecutive calls do not overlap */
     AKZ_OPT_STREAM_PRIORITY = 1u << 4,    /* scale-space stream at high, keypoint stream at low priority */
     AKZ_OPT_CONTRAST_EXACT = 1u << 5,     /* contrast factor always through the exact histogram pass */
-    AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6  /* test knob: odd frames through the exact pass (mixed pairs) */
+    AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6, /* test knob: odd frames through the exact pass (mixed pairs) */
+    AKZ_OPT_TILE_KERNELS = 1u << 7        /* LDS-tile kernels of round 1 instead of the row-streaming ones */
 };
 typedef struct akz_options {
     uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */
@@ -107,7 +108,9 @@ typedef struct akz_options {
     uint32_t sup_capacity;    /* candidates per frame the parallel suppression is sized for; 0 = 4 x max_keypoints */
     uint32_t max_candidates;  /* capacity of each per-(frame, level) extrema candidate list; 0 = max_keypoints */
     uint32_t desc_tile_shift; /* log2 tile edge of the descriptor visiting order, 2..9; 0 = default (5) */
-    uint32_t reserved[10];    /* must be zero */
+    uint32_t stream_waves;    /* waves a row-streaming launch aims for (sets its row-segment length); 0 = default (8192) */
+    uint32_t stream_min_kpixels; /* launches covering fewer than this many x 1024 pixel-frames take the tile kernels; 0 = default */
+    uint32_t reserved[8];     /* must be zero */
 } akz_options;
 /* akz_create with explicit options (NULL = defaults = akz_create). */
 int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h,

@@ -882,8 +882,8 @@ def test_configurations_the_library_refuses(gpu):
             akaze.Context(akaze.Akaze(**kw), wh[0], wh[1], 1)
         assert ei.value.status == -1, (kw, ei.value.status)
     # 8 sublevels x 4 octaves = 32 levels is the largest pyramid and works
-    ctx = akaze.Context(akaze.Akaze(num_sublevels=8), 640, 480, 1)
-    assert ctx.num_levels(640, 480) == 32
+    ctx = akaze.Context(akaze.Akaze(num_sublevels=8), 640, 640, 1)     # every octave keeps min(w, h) >= 80: 8 sublevels each
+    assert ctx.num_levels(640, 640) == 32
     ctx.close()
 
 

@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mb", type=int, default=64)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--opt", action="append", default=[], help="akz_options field for the context, key=value "
+                    "(cv_amd._lib.make_options keywords), e.g. --opt stream_prefetch=4 --opt stream_kernels=0")
     a = ap.parse_args()
     from cv_amd import build
     build.build()
@@ -33,7 +35,14 @@ def main():
     frames = bench.make_frames(torch, dev, 0, MB, 1)
     ak = Akaze.default()
     ak.max_keypoints = CAP
-    ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False))
+    kw = {}
+    for kv in a.opt:
+        key, val = kv.split("=")
+        kw[key] = val if key == "contrast" else int(val)
+    for key in ("keep_all", "frame_pairs", "parallel_suppression", "stream_kernels", "stream_priority"):
+        if key in kw:
+            kw[key] = bool(kw[key])
+    ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False, **kw))
     matcher = Matcher(CAP, device=0)
     kps = torch.zeros((MB, CAP, 28), dtype=torch.uint8, device=dev)
     descs = torch.zeros((MB, CAP, 64), dtype=torch.uint8, device=dev)

@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--n", type=int, default=48)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--procs", type=int, default=32)
+    ap.add_argument("--opt", action="append", default=[], help="akz_options field, key=value (make_options keywords)")
     a = ap.parse_args()
+    kw = {k: int(v) for k, v in (kv.split("=") for kv in a.opt)}
     from oracle import oracle as O
     O.build()
     ctx = mp.get_context("spawn")
@@ -51,12 +53,12 @@ def main():
         want = {r[0]: r[1:] for r in pool.map(oracle_case, [(i, a.seed) for i in range(a.n)], chunksize=1)}
     from cv_amd import build
     build.build()
-    from cv_amd import akaze
+    from cv_amd import _lib, akaze
     bad = 0
     total = 0
     for i in range(a.n):
         w, h, thr, img = make_case(i, a.seed)
-        c = akaze.Context(akaze.Akaze.new(thr), w, h, 1)
+        c = akaze.Context(akaze.Akaze.new(thr), w, h, 1, _lib.make_options(**kw) if kw else None)
         (kp, d), = c.extract_batch([img])
         c.close()
         okp, od, n = want[i]
