@@ -158,7 +158,6 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->keep_all = (o.flags & AKZ_OPT_KEEP_ALL) != 0;
         c->front_pair = !(o.flags & AKZ_OPT_NO_FRAME_PAIRS);
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
-        c->stream_front = !(o.flags & AKZ_OPT_TILE_FRONT);
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
         if (o.stream_min_kpixels) c->stream_min_pixels = (size_t)o.stream_min_kpixels * 1024u;
         c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);

@@ -70,7 +70,6 @@ struct akz_ctx {
     bool front_pair = true;   // two-frame packed front kernel (AKZ_FRONT_PAIR=0 selects the one-frame kernel)
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
     bool stream_kernels = true;   // row-streaming kernels (k_det_stream) instead of the tile kernels (AKZ_OPT_TILE_KERNELS)
-    bool stream_front = true;     // k_front_stream for the level front-ends (AKZ_OPT_TILE_FRONT keeps the tile kernel)
     int det_stream_waves = 8192;  // waves a streaming launch aims for (sets the row-segment length)
     size_t stream_min_pixels = 0; // launches covering fewer pixel-frames than this take the tile kernels
 

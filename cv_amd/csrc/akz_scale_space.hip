@@ -1704,217 +1704,6 @@ __global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ L
     cand_flush(s_cb[wv], nbuf, lane, cand, ncand, list, cp.cap, err);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Streaming form of the level front-end (levels >= 1; lib.rs:232-248 + detector_response.rs:63-64), same organisation
-// as k_det_stream: a wave walks a band of 128 columns (two per lane) of a frame PAIR down the rows ({frame a, frame b}
-// packed arithmetic as in the tile kernels), neighbours by DPP wave shifts, no shared memory, no barrier:
-//   input row -> horizontal blur (5 taps) -> ring of 5 H rows -> vertical blur = Lsmooth row S (never stored unless
-//   the parity taps ask) -> the row's horizontal partials
-//       hm = S(x+s) - S(x-s), ho = off(S(x-s), S(x), S(x+s))          (multiscale Scharr, rings of 2s+1 rows)
-//       hx = S(x+1) - S(x-1), hy = (3 S(x-1) + 10 S(x)) + 3 S(x+1)    (simple Scharr, two rows of history)
-//   -> Lx = off(hm[r-s], hm[r], hm[r+s]), Ly = ho[r+s] - ho[r-s] of row r = t - s, and
-//      lx = (3 hx[t-2] + 10 hx[t-1]) + 3 hx[t], ly = hy[t] - hy[t-2], Lflow = 1 / (1 + inv_k (lx^2 + ly^2)) of row t - 1.
-// Every partial is evaluated once per row (the tile kernel evaluates the H rows of the multiscale taps 2-3 times
-// and the simple ones 2-3 times), nothing is re-staged for a tile halo, and each input row is read once.
-// Border rule as everywhere: a position outside the image holds the value at its clamped coordinate AT EVERY STAGE —
-// input rows / columns are loaded at clamped coordinates, a virtual Lsmooth row t outside the image is the row at
-// clamp(t) (the walk simply does not advance there), and Lsmooth columns outside the image are overwritten with the
-// edge column's value before the partials read them.
-constexpr int front_stream_halo(int SG) { return (SG + 3) & ~1; }                     // columns each side: even, >= SG + 2
-constexpr int front_stream_band(int SG) { return 128 - 2 * front_stream_halo(SG); }   // useful columns per wave
-
-template <int N>
-__device__ __forceinline__ v2f dpp_shift_v(v2f v) { return (v2f){dpp_shift<N>(v.x), dpp_shift<N>(v.y)}; }
-
-template <int SG, bool WRITE_SM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_front_stream(const float* __restrict__ in, int w, int h, size_t fs, int n,
-                                                      GaussTaps taps, OffK k, float* __restrict__ out_g,
-                                                      float* __restrict__ out_flow, float2* __restrict__ out_xy,
-                                                      const float* __restrict__ invk, int invk_off, int nbands, int seg_rows)
-{
-    constexpr int NR = 2 * SG + 1;                  // ring length of the multiscale partials = unroll factor
-    constexpr int HB = front_stream_halo(SG), BW = front_stream_band(SG);
-    constexpr int PF = 4;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int fa = 2 * (int)blockIdx.y;
-    const bool has_b = fa + 1 < n;
-    const int fb = has_b ? fa + 1 : fa;
-    const int item = (int)blockIdx.x * 4 + wv;
-    const int band = item % nbands, seg = item / nbands;
-    const int ys = seg * seg_rows;
-    if (ys >= h) return;                             // whole wave (no block barrier anywhere)
-    const int ye = min(ys + seg_rows, h);
-    const int bx = band * BW;
-    const int x0 = bx - HB + 2 * lane;               // the lane's columns x0, x0 + 1 (w % 4 == 0: both inside or both outside)
-    const bool mine = x0 >= bx && x0 < min(bx + BW, w);
-    const int cx0 = clampi(x0, 0, w - 1), cx1 = clampi(x0 + 1, 0, w - 1);
-    const float* Ia = in + (size_t)fa * fs;
-    const float* Ib = in + (size_t)fb * fs;
-    const v2f inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
-    // columns outside the image (edge bands only): the lanes that hold column 0 / w - 1
-    const bool left_edge = bx == 0, right_edge = bx - HB + 128 > w;
-    const int lane_l = HB / 2, lane_r = (w - 1 - (bx - HB)) >> 1;      // column 0 = pixel 0 of lane_l; w - 1 = pixel 1 of lane_r
-    struct Row { v2f p0, p1; };
-    auto load_row = [&](int y) {
-        const size_t o = (size_t)clampi(y, 0, h - 1) * w;
-        Row r;
-        if (cx1 == cx0 + 1) {
-            const float2 a = *reinterpret_cast<const float2*>(Ia + o + cx0), b = *reinterpret_cast<const float2*>(Ib + o + cx0);
-            r.p0 = (v2f){a.x, b.x};
-            r.p1 = (v2f){a.y, b.y};
-        } else {                                     // both columns clamp to the same edge column
-            const float a = Ia[o + cx0], b = Ib[o + cx0];
-            r.p0 = r.p1 = (v2f){a, b};
-        }
-        return r;
-    };
-    // horizontal blur of one input row at the lane's two columns: window columns -2 .. 3
-    auto hblur = [&](const Row& c, v2f& h0, v2f& h1) {
-        v2f win[6];
-        win[0] = dpp_shift_v<1>(c.p0);
-        win[1] = dpp_shift_v<1>(c.p1);
-        win[2] = c.p0;
-        win[3] = c.p1;
-        win[4] = dpp_shift_v<-1>(c.p0);
-        win[5] = dpp_shift_v<-1>(c.p1);
-        h0 = lane4_dot_v<5>(win, taps.k);
-        h1 = lane4_dot_v<5>(win + 1, taps.k);
-    };
-    // walk: virtual Lsmooth rows t = ys - SG .. ye - 1 + SG; cS = clamp(t); H ring = virtual H rows cS - 2 .. cS + 2
-    const int t_first = ys - SG, t_last = ye - 1 + SG;
-    const int cS0 = clampi(t_first, 0, h - 1);
-    int v_in = cS0 - 2;                              // next virtual H row (input row clamp(v_in))
-    Row nx[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) nx[i] = load_row(v_in + i);
-    v2f hr[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) hr[i][0] = hr[i][1] = splat(0.0f);
-#pragma unroll
-    for (int i = 1; i < 5; ++i) {                    // virtual H rows cS0 - 2 .. cS0 + 1 into slots 1 .. 4
-        const Row c = nx[0];
-#pragma unroll
-        for (int q = 0; q + 1 < PF; ++q) nx[q] = nx[q + 1];
-        nx[PF - 1] = load_row(v_in + PF);
-        ++v_in;
-        hblur(c, hr[i][0], hr[i][1]);
-    }
-    int cS_prev = cS0 - 1;
-    v2f hm[NR][2], ho[NR][2];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) hm[i][0] = hm[i][1] = ho[i][0] = ho[i][1] = splat(0.0f);
-    v2f hmT[2] = {splat(0.f), splat(0.f)}, hoT[2] = {splat(0.f), splat(0.f)};     // partials of the current Lsmooth row
-    v2f hxT[2] = {splat(0.f), splat(0.f)}, hyT[2] = {splat(0.f), splat(0.f)};
-    v2f hxP[2] = {splat(0.f), splat(0.f)}, aP[2] = {splat(0.f), splat(0.f)};       // hx of row t-1; 3 hx[t-2] + 10 hx[t-1]
-    v2f hyP[2] = {splat(0.f), splat(0.f)}, hyPP[2] = {splat(0.f), splat(0.f)};     // hy of rows t-1, t-2
-    for (int base = t_first; base <= t_last; base += NR) {
-#pragma unroll
-        for (int kk = 0; kk < NR; ++kk) {
-            const int t = base + kk;
-            const int cS = clampi(t, 0, h - 1);
-            if (cS != cS_prev) {                      // wave-uniform; false only on the virtual rows above / below the image
-                cS_prev = cS;
-                const Row c = nx[0];
-#pragma unroll
-                for (int q = 0; q + 1 < PF; ++q) nx[q] = nx[q + 1];
-                nx[PF - 1] = load_row(v_in + PF);
-                ++v_in;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    hr[i][0] = hr[i + 1][0];
-                    hr[i][1] = hr[i + 1][1];
-                }
-                hblur(c, hr[4][0], hr[4][1]);
-                // vertical blur -> Lsmooth row cS at the lane's two columns
-                v2f S[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const v2f col[5] = {hr[0][j], hr[1][j], hr[2][j], hr[3][j], hr[4][j]};
-                    S[j] = lane4_dot_v<5>(col, taps.k);
-                }
-                if (left_edge || right_edge) {        // wave-uniform: columns outside the image take the edge column's value
-                    if (left_edge) {
-                        const v2f e = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[0].x), lane_l)),
-                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[0].y), lane_l))};
-                        if (x0 < 0) S[0] = S[1] = e;
-                    }
-                    if (right_edge) {
-                        const v2f e = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[1].x), lane_r)),
-                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[1].y), lane_r))};
-                        if (x0 >= w) S[0] = S[1] = e;
-                    }
-                }
-                if (WRITE_SM && mine && cS >= ys && cS < ye) {
-                    const size_t o = (size_t)cS * w + x0;
-                    *reinterpret_cast<float2*>(out_g + (size_t)fa * fs + o) = make_float2(S[0].x, S[1].x);
-                    if (has_b) *reinterpret_cast<float2*>(out_g + (size_t)fb * fs + o) = make_float2(S[0].y, S[1].y);
-                }
-                // the row's window: columns -4 .. 5 relative to x0 (index i <-> column i - 4)
-                v2f W[10];
-                W[4] = S[0];
-                W[5] = S[1];
-                W[2] = dpp_shift_v<1>(S[0]);
-                W[3] = dpp_shift_v<1>(S[1]);
-                W[6] = dpp_shift_v<-1>(S[0]);
-                W[7] = dpp_shift_v<-1>(S[1]);
-                if (SG > 1) {
-                    W[0] = dpp_shift_v<2>(S[0]);
-                    W[1] = dpp_shift_v<2>(S[1]);
-                    W[8] = dpp_shift_v<-2>(S[0]);
-                    W[9] = dpp_shift_v<-2>(S[1]);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c0 = 4 + j;
-                    hmT[j] = W[c0 + SG] - W[c0 - SG];
-                    hoT[j] = off_combine_sg<SG>(k, W[c0 - SG], W[c0], W[c0 + SG]);
-                    hxT[j] = W[c0 + 1] - W[c0 - 1];                                             // derivatives.rs:3-11
-                    hyT[j] = (splat(3.0f) * W[c0 - 1] + splat(10.0f) * W[c0]) + splat(3.0f) * W[c0 + 1];
-                }
-            }
-            hm[kk][0] = hmT[0]; hm[kk][1] = hmT[1];
-            ho[kk][0] = hoT[0]; ho[kk][1] = hoT[1];
-            // simple Scharr + pm_g2 of row t - 1 (nonlinear_diffusion.rs:80)
-            {
-                const int rf = t - 1;
-                v2f fl[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const v2f lx = aP[j] + splat(3.0f) * hxT[j];
-                    const v2f ly = hyT[j] - hyPP[j];
-                    fl[j] = splat(1.0f) / (splat(1.0f) + inverse_k * (lx * lx + ly * ly));
-                    aP[j] = splat(3.0f) * hxP[j] + splat(10.0f) * hxT[j];
-                    hxP[j] = hxT[j];
-                    hyPP[j] = hyP[j];
-                    hyP[j] = hyT[j];
-                }
-                if (mine && rf >= ys && rf < ye) {
-                    const size_t o = (size_t)rf * w + x0;
-                    *reinterpret_cast<float2*>(out_flow + (size_t)fa * fs + o) = make_float2(fl[0].x, fl[1].x);
-                    if (has_b) *reinterpret_cast<float2*>(out_flow + (size_t)fb * fs + o) = make_float2(fl[0].y, fl[1].y);
-                }
-            }
-            // multiscale Scharr first derivatives of row r = t - SG: ring rows r - SG (oldest), r, r + SG (this one)
-            {
-                const int r = t - SG;
-                const int so = (kk + 1) % NR, sm = (kk + 1 + SG) % NR;
-                v2f lx[2], ly[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    lx[j] = off_combine_sg<SG>(k, hm[so][j], hm[sm][j], hm[kk][j]);
-                    ly[j] = ho[kk][j] - ho[so][j];
-                }
-                if (mine && r >= ys && r < ye) {
-                    const size_t o = (size_t)r * w + x0;
-                    *reinterpret_cast<float4*>(out_xy + (size_t)fa * fs + o) = make_float4(lx[0].x, ly[0].x, lx[1].x, ly[1].x);
-                    if (has_b)
-                        *reinterpret_cast<float4*>(out_xy + (size_t)fb * fs + o) = make_float4(lx[0].y, ly[0].y, lx[1].y, ly[1].y);
-                }
-            }
-        }
-    }
-}
-
 // Raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
 // (y << 48 | x << 32 | slot) in LDS ((x, y) is unique, so the order is total), then a gather of the unsorted
 // records into the sorted position / response list and the sorted neighbourhood list.
@@ -2217,31 +2006,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_FRONT2(SGV)                                                                                              \
     AKZ_FRONT2X(SGV, 32, 256, 1)
                 const bool pair = (L.w & 3) == 0 && c->front_pair;
-                const bool fstream = pair && c->stream_kernels && c->stream_front && fs * (size_t)n >= c->stream_min_pixels;
-#define AKZ_FS(SGV)                                                                                                  \
-    {                                                                                                                \
-        const int nb = akz_div_up(L.w, front_stream_band(SGV));                                                      \
-        const int npair = (n + 1) / 2;                                                                               \
-        int nseg = akz_div_up(c->det_stream_waves / 2, nb * npair);                                                  \
-        const int max_seg = akz_div_up(L.h, 32);                                                                     \
-        nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);                                                     \
-        const int seg_rows = akz_div_up(L.h, nseg);                                                                  \
-        nseg = akz_div_up(L.h, seg_rows);                                                                            \
-        if (lsm_out)                                                                                                 \
-            hipLaunchKernelGGL((k_front_stream<SGV, true>), dim3(akz_div_up(nb * nseg, 4), npair), dim3(256), 0, s, init, \
-                               L.w, L.h, fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk,       \
-                               (int)L.octave, nb, seg_rows);                                                         \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_front_stream<SGV, false>), dim3(akz_div_up(nb * nseg, 4), npair), dim3(256), 0, s, init, \
-                               L.w, L.h, fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk,       \
-                               (int)L.octave, nb, seg_rows);                                                         \
-    }
                 switch (L.deriv_sigma) {
-                case 2: if (fstream) { AKZ_FS(2); } else if (pair) { AKZ_FRONT2(2); } else AKZ_FRONT(2); break;
-                case 3: if (fstream) { AKZ_FS(3); } else if (pair) { AKZ_FRONT2(3); } else AKZ_FRONT(3); break;
-                default: if (fstream) { AKZ_FS(4); } else if (pair) { AKZ_FRONT2(4); } else AKZ_FRONT(4); break;
+                case 2: if (pair) { AKZ_FRONT2(2); } else AKZ_FRONT(2); break;
+                case 3: if (pair) { AKZ_FRONT2(3); } else AKZ_FRONT(3); break;
+                default: if (pair) { AKZ_FRONT2(4); } else AKZ_FRONT(4); break;
                 }
-#undef AKZ_FS
 #undef AKZ_FRONT
 #undef AKZ_FRONT2
 #undef AKZ_FRONT2X
