@@ -5,8 +5,8 @@ One step = one pass of the hot path over one batch of 256 synthetic 1920x1080 fr
 (BASELINE.json configs[1], plus the consecutive-frame symmetric better-by-24 match of configs[2]'s
 matcher): Akaze::default() extract of every frame, then frame g is matched against frame g-1.
 Inputs are resident in HBM before the timed region.  Multi-GPU: one process per GPU, frames sharded
-frame g -> rank g mod N; the only exchange is an RCCL all-gather of the fixed-capacity
-descriptor blocks so that the owner of frame g holds frame g-1's descriptors.  Weak scaling: every rank
+frame g -> rank g mod N; the only exchange is a ring shift of the fixed-capacity descriptor
+blocks (RCCL send/recv to rank + 1) so that the owner of frame g holds frame g-1's descriptors.  Weak scaling: every rank
 processes its own 256 frames per step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
@@ -56,9 +56,9 @@ KERNEL_FAMILIES = [
     ("k_level_front2<2,2,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 2)", 4, 16.0),
     ("k_level_front2<2,3,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 3)", 5, 16.0),
     ("k_level_front2<2,4,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 4)", 6, 16.0),
-    ("k_deriv_second_cand2<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
-    ("k_deriv_second_cand2<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
-    ("k_deriv_second_cand2<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),
+    ("k_det_stream<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
+    ("k_det_stream<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
+    ("k_det_stream<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),
     ("k_fed_pair<T> (calculate_step, up to 8 steps per launch)", 13, 12.0),
     ("k_contrast_pair (contrast factor passes)", 10, 1.0),
 ]
@@ -162,7 +162,7 @@ def main():
     from cv_amd import _lib
     from cv_amd.akaze import Akaze
     from cv_amd.knn import Matcher, RULE_STRICT
-    from cv_amd.sharding import exchange_predecessors
+    from cv_amd.sharding import exchange_predecessors, pred_row
     L = _lib.lib()
 
     NF, MB = args.frames, min(args.micro_batch, args.frames)
@@ -186,24 +186,24 @@ def main():
     descs2 = zeros2((NF, CAP, 64), torch.uint8)
     counts2 = zeros2((NF,), torch.int32)
     # predecessor descriptor blocks: prev[j] = descriptors of global frame g-1 for local frame j
-    prev_descs2 = zeros2((NF, CAP, 64), torch.uint8) if world > 1 else [None, None]
-    prev_counts2 = zeros2((NF,), torch.int32) if world > 1 else [None, None]
+    # (row NF holds the predecessor of local frame 0 on rank 0: cv_amd/sharding.py)
+    prev_descs2 = zeros2((NF + 1, CAP, 64), torch.uint8) if world > 1 else [None, None]
+    prev_counts2 = zeros2((NF + 1,), torch.int32) if world > 1 else [None, None]
     pairs2 = zeros2((NF + 2, CAP, 2), torch.int32)   # +2: a micro-batch can carry mb+1 pairs
     npairs2 = zeros2((NF + 2,), torch.int32)
     match_done = [torch.cuda.Event(), torch.cuda.Event()]   # the matcher finished reading output set p
     step_no = [0]
     host_trace = [] if os.environ.get("AKZ_BENCH_TRACE") else None   # (step, m0, ms in extract call, ms in match call)
-    if world > 1:
-        gath_d = torch.zeros((world, MB, CAP, 64), dtype=torch.uint8, device=dev)
-        gath_n = torch.zeros((world, MB), dtype=torch.int32, device=dev)
     # match problems are issued per micro-batch so the VALU-bound matcher of micro-batch m overlaps the
     # HBM-bound scale space of micro-batch m+1: frame j pairs with frame j-1; frame 0 pairs with the step's
     # last frame once that exists.
     def idx(vals):
         return (C.c_uint32 * len(vals))(*vals)
 
-    # multi-rank: the descriptor exchange runs on its own stream, so that the next micro-batch's scale space
-    # (which waits on the caller's stream only) does not queue behind the collective of this one
+    # multi-rank: the descriptor exchange (a ring shift: every rank sends its block to rank + 1 and receives its
+    # predecessor's straight into the rows the matcher reads) runs on its own stream, so that the next micro-batch's
+    # scale space (which waits on the caller's stream only) does not queue behind it; ordering contract in
+    # cv_amd/sharding.py
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def step():
@@ -228,8 +228,8 @@ def main():
                 comm.wait_stream(akz_stream)
                 with torch.cuda.stream(comm):
                     js = exchange_predecessors(dist, rank, world, m0, MB, NF, descs[m0:m0 + MB],
-                                               counts[m0:m0 + MB], gath_d, gath_n, prev_descs, prev_counts)
-                ia, ib, tb, nb, wait = idx(js), idx(js), prev_descs, prev_counts, comm
+                                               counts[m0:m0 + MB], prev_descs, prev_counts)
+                ia, ib, tb, nb, wait = idx(js), idx([pred_row(rank, j, NF) for j in js]), prev_descs, prev_counts, comm
             else:
                 ia, ib, tb, nb, wait = idx(js), idx([(j - 1) % NF for j in js]), descs, counts, akz_stream
             # problem p writes pairs/npairs block p of the view starting at js[0]'s slot; keep them per frame
@@ -250,8 +250,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.timing_enable(True)
-    ctx.timing_reset()
+    # the timed region runs without the per-kernel event brackets (about 250 event records per call would be
+    # part of the measurement); one more, untimed, instrumented step afterwards gives the in-pipeline breakdown
+    ctx.timing_enable(False)
     _lib.check(L.hm_timing_get(matcher.handle, None, None, 1), "hm_timing_get")
     _lib.check(L.hm_timing_enable(matcher.handle, 1), "hm_timing_enable")
     t0 = time.perf_counter()
@@ -259,6 +260,12 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    step()
+    step()                          # two steps: both output sets, so `last` below still names the newest one
+    barrier()
+    INSTR_STEPS = 2
     last = (step_no[0] - 1) & 1
     kps, descs, counts, pairs, npairs = kps2[last], descs2[last], counts2[last], pairs2[last], npairs2[last]
     knn_ms, knn_launches = C.c_double(), C.c_uint64()
@@ -269,7 +276,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fam_pipe = read_families(ctx)                 # kernel families inside the timed region (all streams busy)
+    fam_pipe = read_families(ctx)                 # kernel families of the instrumented pipelined pass (all streams busy)
     fed_ms, fed_launches, fed_units = ctx.timing_get(0)
     ss_ms, _, _ = ctx.timing_get(1)
     all_ms, _, _ = ctx.timing_get(2)
@@ -318,6 +325,20 @@ def main():
             for r in range(world):
                 glob[r::world] = allf[r].cpu().numpy()
             np.save(args.dump_matches, glob)
+        # the pair lists themselves, one file per rank, keyed by GLOBAL frame (variable lengths)
+        slot_of = {}
+        for m0 in range(0, NF, MB):
+            if world > 1 and rank > 0:
+                js = list(range(m0, m0 + MB))
+            elif world > 1:
+                js = list(range(m0 + 1, m0 + MB)) + ([m0] if m0 > 0 else []) + ([0] if m0 + MB == NF else [])
+            else:
+                js = [j for j in range(m0, m0 + MB) if j > 0] + ([0] if m0 + MB == NF else [])
+            for q, j in enumerate(js):
+                slot_of[j] = m0 + q
+        hp, hn = pairs.cpu().numpy(), npairs.cpu().numpy()
+        np.savez(f"{args.dump_matches}.r{rank}.npz",
+                 **{f"g{j * world + rank}": hp[slot_of[j], :hn[slot_of[j]]].copy() for j in range(NF)})
 
     n_kp = counts.float().mean().item()
     n_match = npairs[:NF].float().mean().item()
@@ -339,9 +360,11 @@ def main():
                        "mean_matches_per_pair": round(n_match, 1)},
             "roofline": tops[0] if tops else None,
             "roofline_top": tops[:4],
-            "phase_ms_per_step": {"fed": round(fed_ms / args.steps, 2), "scale_space": round(ss_ms / args.steps, 2),
-                                  "extract": round(all_ms / args.steps, 2), "describe": round(desc_ms / args.steps, 2),
-                                  "refine": round(refine_ms / args.steps, 2)},
+            "phase_ms_per_step": {"fed": round(fed_ms / INSTR_STEPS, 2), "scale_space": round(ss_ms / INSTR_STEPS, 2),
+                                  "extract": round(all_ms / INSTR_STEPS, 2), "describe": round(desc_ms / INSTR_STEPS, 2),
+                                  "refine": round(refine_ms / INSTR_STEPS, 2),
+                                  "note": "HIP-event brackets of an instrumented pass of 2 steps run after the timed "
+                                          "region (same pipelined workload)"},
         }
         if iso_fps:
             out["scale_space_isolated"] = {
@@ -354,7 +377,7 @@ def main():
         if knn_ms.value > 0:
             # the matcher's roofline: 2 directions x nq x nt x 512-bit contractions per frame pair as MACs (2 ops
             # each) over the HIP-event time of the k-NN launches on the matcher's stream
-            pairs_total = NF * args.steps
+            pairs_total = NF * (args.steps + INSTR_STEPS)
             macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
             tops_m = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
             out["roofline_matcher"] = {
@@ -362,8 +385,9 @@ def main():
                 "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4), "traffic": None, "launches": int(knn_launches.value),
                 "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
-                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count, inside the timed "
-                        "region; peak = the dense FP4 MFMA figure of MI355X_MICROARCH.md (~10 PF)"}
+                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count, HIP events on the "
+                        "matcher's stream over the timed and the instrumented steps; peak = the dense FP4 MFMA figure "
+                        "of MI355X_MICROARCH.md (~10 PF)"}
         out["device"] = device_probe(torch, dev)
         rc = 0
         if world == 1 and not args.no_cpu_baseline:
@@ -411,8 +435,9 @@ def roofline_entries(fam_pipe, fam_iso, mb):
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(launches),
              "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2),
              "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_pixel": bpu,
-             "timed": "HIP events around the launches on the library's scale-space stream, inside the timed region "
-                      "(the keypoint and matcher streams of neighbouring micro-batches share the GPU)"}
+             "timed": "HIP events around the launches on the library's scale-space stream during an instrumented pass "
+                      "of the same pipelined workload (the keypoint and matcher streams of neighbouring micro-batches "
+                      "share the GPU); gpu_ms covers 2 steps"}
         if name in iso:
             _, ims, il, iu, _ = iso[name]
             igbs = iu * bpu / (ims * 1e-3) / 1e9

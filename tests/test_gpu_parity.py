@@ -717,8 +717,9 @@ def test_p3p_bit_exact(gpu, oracle):
 
 def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     """The N>1 path of bench.py end to end on ONE GPU: two ranks (gloo, both on cuda:0) shard 32 global frames
-    g -> rank g % 2, all-gather the descriptor blocks and match every frame against its predecessor; the
-    per-global-frame keypoint and match counts must equal the single-rank run over the same 32 frames."""
+    g -> rank g % 2, pass their descriptor blocks one rank up the ring and match every frame against its
+    predecessor; the per-global-frame keypoint counts AND the match pair lists (every [a, b] index pair, byte for
+    byte) must equal the single-rank run over the same 32 frames."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -738,6 +739,12 @@ def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     assert a.shape == b.shape == (32, 2)
     assert np.array_equal(a, b), (a.T, b.T)
     assert a[:, 0].min() > 1000 and a[:, 1].min() > 500
+    single = np.load(str(m1) + ".r0.npz")
+    ranks = [np.load(str(m2) + f".r{r}.npz") for r in range(2)]
+    for g in range(32):
+        want, got = single[f"g{g}"], ranks[g % 2][f"g{g}"]
+        assert want.shape == got.shape and np.array_equal(want, got), f"pairs of global frame {g} differ"
+        assert len(want) == a[g, 1]
 
 
 # ---------------------------------------------------------------------------------------------

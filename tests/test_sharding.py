@@ -1,6 +1,7 @@
-"""The N>1 path's exchange step on CPU: world_size 2 over gloo.  Descriptor blocks are
-fake but tagged with their global frame index, so the test checks that after the all-gather every local
-frame holds exactly its predecessor's block and that every frame becomes matchable exactly once."""
+"""The N>1 path's exchange step on CPU: world_size 2 and 3 over gloo.  Descriptor blocks are
+fake but tagged with their global frame index, so the test checks that after the ring shift every local
+frame holds exactly its predecessor's block, that the rows a rank does not own are never written, and that every
+frame becomes matchable exactly once."""
 import os
 import socket
 
@@ -22,14 +23,12 @@ def _worker(rank, world, port, nf, mb, cap, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from cv_amd.sharding import exchange_predecessors, global_index
+    from cv_amd.sharding import exchange_predecessors, global_index, pred_row
     try:
         descs = torch.zeros((nf, cap, 64), dtype=torch.uint8)
         counts = torch.zeros((nf,), dtype=torch.int32)
-        prev_descs = torch.full((nf, cap, 64), 255, dtype=torch.uint8)
-        prev_counts = torch.full((nf,), -1, dtype=torch.int32)
-        gath_d = torch.zeros((world, mb, cap, 64), dtype=torch.uint8)
-        gath_n = torch.zeros((world, mb), dtype=torch.int32)
+        prev_descs = torch.full((nf + 1, cap, 64), 255, dtype=torch.uint8)
+        prev_counts = torch.full((nf + 1,), -1, dtype=torch.int32)
         ready_all = []
         for m0 in range(0, nf, mb):
             for j in range(m0, m0 + mb):          # "extract": tag the block with its global frame index
@@ -37,12 +36,16 @@ def _worker(rank, world, port, nf, mb, cap, q):
                 descs[j] = g % 251
                 counts[j] = 1000 + g
             ready = exchange_predecessors(dist, rank, world, m0, mb, nf, descs[m0:m0 + mb], counts[m0:m0 + mb],
-                                          gath_d, gath_n, prev_descs, prev_counts)
+                                          prev_descs, prev_counts)
             for j in ready:                        # a frame must only be reported once its predecessor is filed
                 gp = (global_index(rank, j, world) - 1) % (nf * world)
-                assert int(prev_counts[j]) == 1000 + gp, (rank, j, int(prev_counts[j]), gp)
-                assert bool((prev_descs[j] == gp % 251).all())
+                row = pred_row(rank, j, nf)
+                assert int(prev_counts[row]) == 1000 + gp, (rank, j, int(prev_counts[row]), gp)
+                assert bool((prev_descs[row] == gp % 251).all())
             ready_all += ready
+        # the spare row is used by rank 0 only (the predecessor of its frame 0), row 0 by every other rank
+        untouched = 0 if rank == 0 else nf
+        assert int(prev_counts[untouched]) == -1 and bool((prev_descs[untouched] == 255).all())
         assert sorted(ready_all) == list(range(nf)), (rank, sorted(ready_all))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
@@ -51,9 +54,8 @@ def _worker(rank, world, port, nf, mb, cap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nf,mb", [(8, 4), (6, 2), (4, 4), (3, 1)])
-def test_predecessor_exchange_world2(nf, mb):
-    world = 2
+@pytest.mark.parametrize("nf,mb,world", [(8, 4, 2), (6, 2, 2), (4, 4, 2), (3, 1, 2), (6, 3, 3)])
+def test_predecessor_exchange(nf, mb, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
