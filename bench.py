@@ -582,6 +582,26 @@ def extra_ransac(n_hyp):
     wpose, wbest, winl, wc1 = O.essential_batch(a, b, samples[h:h + 1], thr)
     bad += int(wbest != best % 4 or wpose.tobytes() != pose.tobytes() or not np.array_equal(winl, inl))
     bad += int(int(counts.max()) != len(inl) or not np.array_equal(wc1[0], counts[h]))
+    # the same scene through the ARRSAC-shaped entry point: samples drawn on the device, block scoring with the exact
+    # bound, the candidate cap and the SPRT test (vslam-sandbox's parameters); and with the bound alone
+    arr = {}
+    for name, kw in (("bound_cap_sprt", dict(max_candidates=1024, bound=True, sprt=True)),
+                     ("bound_only", dict(max_candidates=0, bound=True, sprt=False))):
+        cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, **kw)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            apose, ainl, abest, ast = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, **kw)
+        adt = (time.perf_counter() - t0) / reps
+        arr[name] = {"hypotheses_per_s": round(n_hyp / adt, 1), "ms_per_scene": round(adt * 1e3, 3),
+                     "residuals_evaluated_frac": round(ast["residuals_evaluated"] / ast["residuals_exhaustive"], 4),
+                     "survivors": ast["survivors"], "inliers": int(len(ainl)), "best_id": int(abest)}
+    # exhaustive scoring of the device-drawn samples: the bound-only run must give the same winner
+    dsamples = cons.arrsac_samples(0, n, n_hyp)
+    epose, einl, ebest = cons.model_inliers(a, b, dsamples, thr)
+    bad += int(arr["bound_only"]["best_id"] != ebest or arr["bound_only"]["inliers"] != len(einl))
+    arr["note"] = ("rs_essential_arrsac, minimal samples drawn on the device (xoshiro256++, seed 0); bound_only is "
+                   "checked against exhaustive scoring of the same samples; exhaustive_same_samples_best_id "
+                   f"{int(ebest)}, inliers {len(einl)}")
     # f64 work per (pose, match) residual: 4x4 design matrix (~250 flops) + cyclic Jacobi (~6 sweeps x 6 rotations x
     # ~60 flops) ~ 2.4 kflop; a bound on the order of magnitude, the kernel is f64-VALU bound
     flops = 2400.0 * n_hyp * 4 * n
@@ -594,6 +614,7 @@ def extra_ransac(n_hyp):
                         "achieved": round(tf, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4), "traffic": None,
                         "note": "~2.4 kflop per residual (estimate, DESIGN.md 7); includes the host<->device copies"},
+           "arrsac": arr,
            "cpu_oracle": {"hypotheses_per_s": round(sub / cpu_s, 1), "cores": 1,
                           "sample": f"first {sub} hypotheses, {cpu_s:.1f} s"},
            "parity": {"hypotheses_checked": sub + 1, "mismatches": bad,

@@ -69,6 +69,21 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
     return o
 
 
+class ArrsacParams(C.Structure):
+    """rs_arrsac_params (include/akz.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("n_hypotheses", C.c_uint32), ("block_size", C.c_uint32),
+                ("init_blocks", C.c_uint32), ("max_candidates", C.c_uint32), ("flags", C.c_uint32),
+                ("threshold", C.c_double), ("sprt_delta", C.c_double), ("sprt_ratio", C.c_double), ("seed", C.c_uint64)]
+
+
+class ArrsacStats(C.Structure):
+    _fields_ = [("poses", C.c_uint32), ("survivors", C.c_uint32), ("blocks", C.c_uint32), ("reserved", C.c_uint32),
+                ("residuals_evaluated", C.c_uint64), ("residuals_exhaustive", C.c_uint64)]
+
+
+RS_PRUNE_BOUND, RS_PRUNE_SPRT = 1, 2
+
+
 class LevelInfo(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32),
@@ -93,7 +108,8 @@ ABI_SYMBOLS = [
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
-    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_p3p_batch", "rs_debug_counts",
+    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_arrsac_samples",
+    "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
 ]
@@ -167,6 +183,9 @@ def lib():
     L.rs_destroy.argtypes = [vp]
     L.rs_calibrate.argtypes = [vp, i32, C.c_double, vp, u32, vp]
     L.rs_essential_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
+    L.rs_essential_arrsac.argtypes = [vp, vp, vp, u32, vp, C.POINTER(ArrsacParams), vp, C.POINTER(u32), vp, u32, C.POINTER(u32),
+                                      C.POINTER(ArrsacStats)]
+    L.rs_arrsac_samples.argtypes = [C.c_uint64, u32, u32, vp]
     L.rs_p3p_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
     L.rs_debug_counts.argtypes = [vp, vp, u32]
     L.akz_timing_enable.argtypes = [vp, i32]

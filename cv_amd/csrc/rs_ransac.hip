@@ -287,6 +287,251 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
     if (threadIdx.x == 0) *n_inliers = base;
 }
 
+// ---- ARRSAC-shaped consensus (row R4) ---------------------------------------------------
+// arrsac::Arrsac::model_inliers (un-vendored crate, arrsac 0.10; call sites vslam-sandbox/src/main.rs:105-117,
+// cv-sfm/src/lib.rs:1394-1412) scores its hypotheses breadth-first, block of matches by block of matches, and drops
+// the ones that can no longer win.  The same shape on the device:
+//   k_rs_sample        xoshiro256++ minimal samples drawn on the device (the caller need not ship n_hyp x 8 indices)
+//   k_rs_score_block   every live pose against the next `block` matches (one wave per pose and 64 matches)
+//   k_rs_prune         after each block: the best count so far B, then a pose is retired when
+//                        (bound)  count + matches_left < B            — it cannot reach the best: exact, always on
+//                        (cap)    it is not among the max_candidates best after the initialisation blocks
+//                        (SPRT)   its likelihood ratio (delta/eps)^c ((1-delta)/(1-eps))^(seen-c) exceeds the threshold,
+//                                 eps = B / seen (Wald's test as in SPRT-RANSAC; arrsac's likelihood_ratio_threshold)
+//                      and the survivors are compacted in ascending pose order (device-side count, no host round trip).
+// With the bound alone the winner, its count and its inlier set are those of exhaustive scoring.
+struct Xo256 {
+    unsigned long long s[4];
+};
+__host__ __device__ __forceinline__ unsigned long long xo_rotl(unsigned long long x, int k) { return (x << k) | (x >> (64 - k)); }
+__host__ __device__ __forceinline__ unsigned long long xo_splitmix(unsigned long long* x)
+{
+    unsigned long long z = (*x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ unsigned long long xo_next(Xo256* g)   // xoshiro256++ (Blackman & Vigna)
+{
+    const unsigned long long r = xo_rotl(g->s[0] + g->s[3], 23) + g->s[0];
+    const unsigned long long t = g->s[1] << 17;
+    g->s[2] ^= g->s[0];
+    g->s[3] ^= g->s[1];
+    g->s[1] ^= g->s[2];
+    g->s[0] ^= g->s[3];
+    g->s[2] ^= t;
+    g->s[3] = xo_rotl(g->s[3], 45);
+    return r;
+}
+// hypothesis h draws K distinct match indices from its own stream: state = splitmix64 chain of seed + h (the
+// seed_from_u64 construction), index = high 32 bits x n >> 32, duplicates redrawn
+template <int K>
+__host__ __device__ __forceinline__ void rs_draw_sample(unsigned long long seed, uint32_t h, uint32_t n, uint32_t* out)
+{
+    unsigned long long x = seed + 0xD1B54A32D192ED03ull * (unsigned long long)(h + 1u);
+    Xo256 g;
+    for (int i = 0; i < 4; ++i) g.s[i] = xo_splitmix(&x);
+    for (int i = 0; i < K; ++i) {
+        uint32_t v;
+        bool dup;
+        do {
+            v = (uint32_t)(((xo_next(&g) >> 32) * (unsigned long long)n) >> 32);
+            dup = false;
+            for (int j = 0; j < i; ++j) dup = dup || out[j] == v;
+        } while (dup);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rs_sample(unsigned long long seed, uint32_t n, uint32_t n_hyp, uint32_t* __restrict__ sample_idx)
+{
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n_hyp) return;
+    uint32_t s[8];
+    rs_draw_sample<8>(seed, h, n, s);
+    for (int i = 0; i < 8; ++i) sample_idx[(size_t)h * 8 + i] = s[i];
+}
+
+// alive list initialisation: valid poses in ascending order (one block)
+__global__ __launch_bounds__(1024) void k_rs_alive_init(const uint32_t* __restrict__ ok, uint32_t n_pose, uint32_t* __restrict__ alive,
+                                                        uint32_t* __restrict__ n_alive)
+{
+    __shared__ uint32_t s_wave[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < n_pose; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool keep = i < n_pose && ok[i] != 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (keep) alive[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_alive = base;
+}
+
+// one wave per (live pose, 64 matches of the block); grid.x covers the worst case, waves beyond the live count exit
+__global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict__ ba, const double* __restrict__ bb, uint32_t m_lo,
+                                                        uint32_t m_hi, const double* __restrict__ poses,
+                                                        const uint32_t* __restrict__ alive, const uint32_t* __restrict__ n_alive,
+                                                        double thresh, uint32_t* __restrict__ counts,
+                                                        unsigned long long* __restrict__ n_eval)
+{
+    const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= *n_alive) return;
+    const uint32_t pid = alive[slot];
+    const uint32_t lane = threadIdx.x & 63;
+    double pose[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    uint32_t cnt = 0;
+    for (uint32_t m0 = m_lo + blockIdx.y * 64; m0 < m_hi; m0 += gridDim.y * 64) {
+        const uint32_t m = m0 + lane;
+        bool inl = false;
+        if (m < m_hi) {
+            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+            inl = rs_residual(pose, a, b) < thresh;
+        }
+        cnt += (uint32_t)__popcll(__ballot(inl));
+    }
+    if (lane == 0) {
+        if (cnt) atomicAdd(&counts[pid], cnt);
+        if (blockIdx.y == 0) atomicAdd(n_eval, (unsigned long long)(m_hi - m_lo));
+    }
+}
+
+struct RsPrune {
+    uint32_t seen, n_total;       // matches scored so far / in all
+    uint32_t cap;                 // keep at most this many poses from now on (0 = no cap)
+    uint32_t use_sprt;
+    double log_delta, log_1m_delta, log_ratio;   // ln(delta), ln(1 - delta), ln(likelihood ratio threshold)
+};
+
+__global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ alive_in,
+                                                   const uint32_t* __restrict__ n_in, uint32_t* __restrict__ alive_out,
+                                                   uint32_t* __restrict__ n_out)
+{
+    __shared__ uint32_t s_wave[16], s_wave_t[16];
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint32_t s_best, s_T, s_budget;
+    const uint32_t n = *n_in;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_best = 0;
+    for (int i = threadIdx.x; i < 2048; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    uint32_t lmax = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t c = counts[alive_in[i]];
+        lmax = c > lmax ? c : lmax;
+        if (P.cap) atomicAdd(&s_hist[c < 2047u ? c : 2047u], 1u);
+    }
+    atomicMax(&s_best, lmax);
+    __syncthreads();
+    const uint32_t best = s_best, left = P.n_total - P.seen;
+    if (threadIdx.x == 0) {
+        // count threshold of the cap: poses with count > T all stay, those with count == T in pose order up to the budget
+        uint32_t T = 0, budget = 0xFFFFFFFFu;
+        if (P.cap && n > P.cap) {
+            uint32_t acc = 0;
+            int t = 2047;
+            for (; t >= 0; --t) {
+                if (acc + s_hist[t] >= P.cap) break;
+                acc += s_hist[t];
+            }
+            T = (uint32_t)(t < 0 ? 0 : t);
+            budget = P.cap - acc;
+        }
+        s_T = T;
+        s_budget = budget;
+    }
+    __syncthreads();
+    const uint32_t T = s_T;
+    // SPRT constants: eps = best / seen
+    double l_in = 0.0, l_out = 0.0;
+    if (P.use_sprt && best > 0 && best < P.seen) {
+        const double eps = (double)best / (double)P.seen;
+        l_in = P.log_delta - log(eps);               // per inlier  (negative: evidence for a good model)
+        l_out = P.log_1m_delta - log(1.0 - eps);     // per outlier (positive)
+    }
+    uint32_t base = 0, ties_before = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool keep = false, tie = false;
+        uint32_t pid = 0;
+        if (i < n) {
+            pid = alive_in[i];
+            const uint32_t c = counts[pid];
+            keep = c + left >= best;                                                   // bound (exact)
+            if (keep && P.use_sprt && l_out > 0.0)
+                keep = (double)c * l_in + (double)(P.seen - c) * l_out <= P.log_ratio || c == best;
+            const uint32_t cc = c < 2047u ? c : 2047u;
+            if (keep && P.cap && n > P.cap) {
+                if (cc < T) keep = false;
+                tie = keep && cc == T;
+            }
+        }
+        // ties at the cap threshold are admitted in pose order while the budget lasts
+        const unsigned long long tb = __ballot(tie);
+        if (lane == 0) s_wave_t[wv] = (uint32_t)__popcll(tb);
+        __syncthreads();
+        uint32_t toff = 0, ttot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) toff += s_wave_t[q];
+            ttot += s_wave_t[q];
+        }
+        if (tie) {
+            const uint32_t rank = ties_before + toff + (uint32_t)__popcll(tb & ((1ull << lane) - 1ull));
+            if (rank >= s_budget) keep = false;
+        }
+        ties_before += ttot;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (keep) alive_out[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = pid;
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = base;
+}
+
+// argmax of (count, -id) over the survivors (all of them have seen every match)
+__global__ __launch_bounds__(1024) void k_rs_best_alive(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ alive,
+                                                        const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ best)
+{
+    __shared__ unsigned long long s_key[16];
+    unsigned long long key = 0ull;
+    const uint32_t n = *n_alive;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t pid = alive[i];
+        const unsigned long long k = ((unsigned long long)(counts[pid] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - pid);
+        key = k > key ? k : key;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(key, off);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
+        best[0] = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
+        best[1] = key ? (uint32_t)(key >> 32) - 1u : 0u;
+        best[2] = n;
+    }
+}
+
 // ---- PnP: Lambda Twist hypotheses + WorldToCamera residual (row R5) ----------------------------------
 __global__ __launch_bounds__(64) void k_p3p_hypotheses(const double* __restrict__ bearings, const double* __restrict__ world,
                                                        const uint32_t* __restrict__ sample_idx, uint32_t n_hyp,
@@ -380,6 +625,8 @@ struct rs_ctx {
     double *d_a = nullptr, *d_b = nullptr, *d_w = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
     uint32_t *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_best = nullptr, *d_inl = nullptr,
              *d_ninl = nullptr;
+    uint32_t *d_alive[2] = {nullptr, nullptr}, *d_nalive = nullptr;   // ARRSAC: live pose lists (ping-pong) + counts [2]
+    unsigned long long* d_neval = nullptr;                             // residuals evaluated
     uint32_t last_hyp = 0;
 };
 
@@ -406,6 +653,10 @@ extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_
         AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
         AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
         AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * 4));
+        AKZ_HIP(hipMalloc(&c->d_alive[0], sizeof(uint32_t) * 4 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_alive[1], sizeof(uint32_t) * 4 * (size_t)max_hyp));
+        AKZ_HIP(hipMalloc(&c->d_nalive, sizeof(uint32_t) * 4));
+        AKZ_HIP(hipMalloc(&c->d_neval, sizeof(unsigned long long) * 2));
         *out = c;
         return AKZ_OK;
     });
@@ -419,6 +670,7 @@ extern "C" int32_t rs_destroy(rs_ctx* c)
         if (c->stream) hipStreamSynchronize(c->stream);
         hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
         hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
+        hipFree(c->d_alive[0]); hipFree(c->d_alive[1]); hipFree(c->d_nalive); hipFree(c->d_neval);
         if (c->stream) hipStreamDestroy(c->stream);
         delete c;
         return AKZ_OK;
@@ -498,6 +750,119 @@ extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const
         uint32_t ncopy = ninl < cap ? ninl : cap;
         if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
         return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
+}
+
+// Consensus::model_inliers(&EightPoint::new(), matches) in ARRSAC's shape: breadth-first block scoring with
+// retirement (see the kernels above).  sample_idx == NULL draws the minimal samples on the device.
+extern "C" int32_t rs_essential_arrsac(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
+                                       const uint32_t* sample_idx, const rs_arrsac_params* prm, double* best_pose,
+                                       uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
+                                       rs_arrsac_stats* stats)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !bearings_a || !bearings_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
+            return AKZ_E_INVALID;
+        if (prm->struct_size != sizeof(rs_arrsac_params)) return AKZ_E_INVALID;
+        const uint32_t n_hyp = prm->n_hypotheses;
+        if (n < 8 || n_hyp == 0 || prm->block_size == 0) return AKZ_E_INVALID;
+        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+        if ((prm->flags & RS_PRUNE_SPRT) && !(prm->sprt_delta > 0.0 && prm->sprt_delta < 1.0 && prm->sprt_ratio > 1.0))
+            return AKZ_E_INVALID;
+        if (sample_idx)
+            for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
+                if (sample_idx[i] >= n) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+        if (sample_idx) {
+            AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+        } else {
+            hipLaunchKernelGGL(k_rs_sample, dim3((n_hyp + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed, n, n_hyp,
+                               c->d_samples);
+            AKZ_LAUNCH_CHECK();
+        }
+        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+        AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long) * 2, s));
+        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
+                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
+        AKZ_LAUNCH_CHECK();
+        const uint32_t n_pose = n_hyp * 4;
+        hipLaunchKernelGGL(k_rs_alive_init, dim3(1), dim3(1024), 0, s, c->d_ok, n_pose, c->d_alive[0], c->d_nalive);
+        AKZ_LAUNCH_CHECK();
+        // (the cap ranks poses through a 2048-bin histogram of their counts: counts above 2046 share the top bin)
+        int cur = 0;
+        uint32_t blocks = 0;
+        // the live count is known to the host only as an upper bound: n_pose before the cap applies, the cap after
+        uint32_t live_bound = n_pose;
+        const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0;
+        for (uint32_t m_lo = 0; m_lo < n;) {
+            // without pruning there is nothing to decide between blocks: one block = all matches
+            const uint32_t bs = prune ? prm->block_size : n;
+            const uint32_t m_hi = m_lo + bs < n ? m_lo + bs : n;
+            const uint32_t chunks = (m_hi - m_lo + 63) / 64;
+            const uint32_t gy = chunks < 16 ? chunks : 16;
+            hipLaunchKernelGGL(k_rs_score_block, dim3((live_bound + 3) / 4, gy), dim3(256), 0, s, c->d_a, c->d_b, m_lo, m_hi,
+                               c->d_poses, c->d_alive[cur], c->d_nalive + cur, prm->threshold, c->d_counts, c->d_neval);
+            AKZ_LAUNCH_CHECK();
+            ++blocks;
+            m_lo = m_hi;
+            if (prune && m_lo < n) {
+                RsPrune P;
+                P.seen = m_lo;
+                P.n_total = n;
+                P.cap = (prm->max_candidates && blocks >= prm->init_blocks) ? prm->max_candidates : 0u;
+                P.use_sprt = (prm->flags & RS_PRUNE_SPRT) ? 1u : 0u;
+                P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
+                P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
+                P.log_ratio = P.use_sprt ? log(prm->sprt_ratio) : 0.0;
+                hipLaunchKernelGGL(k_rs_prune, dim3(1), dim3(1024), 0, s, P, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
+                                   c->d_alive[cur ^ 1], c->d_nalive + (cur ^ 1));
+                AKZ_LAUNCH_CHECK();
+                cur ^= 1;
+                if (P.cap && P.cap < live_bound) live_bound = P.cap;
+            }
+        }
+        hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur, c->d_best);
+        AKZ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, prm->threshold,
+                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+        AKZ_LAUNCH_CHECK();
+        uint32_t best[3] = {0, 0, 0}, ninl = 0;
+        unsigned long long neval = 0;
+        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(&neval, c->d_neval, sizeof(neval), hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+        AKZ_HIP(hipStreamSynchronize(s));
+        c->last_hyp = n_hyp;
+        if (stats) {
+            stats->poses = n_pose;
+            stats->survivors = best[2];
+            stats->blocks = blocks;
+            stats->residuals_evaluated = neval;
+            stats->residuals_exhaustive = (uint64_t)n_pose * n;
+        }
+        *best_id = best[0];
+        *n_inliers = ninl;
+        if (best[0] == 0xFFFFFFFFu) {
+            *n_inliers = 0;
+            return AKZ_OK;
+        }
+        uint32_t ncopy = ninl < cap ? ninl : cap;
+        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
+}
+
+// the minimal samples rs_essential_arrsac draws on the device for (seed, n): host restatement for callers and tests
+extern "C" int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t* sample_idx)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!sample_idx || n < 8) return AKZ_E_INVALID;
+        for (uint32_t h = 0; h < n_hyp; ++h) rs_draw_sample<8>((unsigned long long)seed, h, n, sample_idx + (size_t)h * 8);
+        return AKZ_OK;
     });
 }
 

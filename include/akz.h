@@ -301,6 +301,42 @@ int32_t rs_calibrate(const double* intrinsics, int32_t use_k1, double k1, const 
 int32_t rs_essential_batch(rs_ctx* ctx, const double* bearings_a, const double* bearings_b, uint32_t n,
                            const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
                            uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers);
+/* The same consensus in arrsac's shape (arrsac::Arrsac::model_inliers; parameters as its builder exposes them at
+ * vslam-sandbox/src/main.rs:105-117: initialization_hypotheses, max_candidate_hypotheses, block_size,
+ * likelihood_ratio_threshold): the hypotheses are scored breadth-first, `block_size` matches at a time, and after
+ * every block a pose is retired when
+ *   RS_PRUNE_BOUND  its count plus the matches still to come cannot reach the best count so far (exact: the winner,
+ *                   its count and its inlier set equal exhaustive scoring's — rs_essential_batch on the same samples);
+ *   max_candidates  it is not among the max_candidates best once init_blocks blocks have been scored (0 = no cap);
+ *   RS_PRUNE_SPRT   Wald's sequential test rejects it: (delta/eps)^c ((1-delta)/(1-eps))^(seen-c) > sprt_ratio with
+ *                   eps = best count / seen and delta = sprt_delta, the inlier rate expected of a wrong model.
+ * sample_idx == NULL draws the n_hypotheses minimal samples on the device from xoshiro256++ streams seeded with
+ * `seed` (rs_arrsac_samples reproduces them on the host).  The arrsac crate is not vendored in the reference: the
+ * sampler, the retirement rules and their order are this library's (parity unpinned beyond the count pin of
+ * akaze/tests/estimate_pose.rs:75); inlier-guided re-sampling (arrsac's estimations_per_block) is not done.
+ * best_id / best_pose / inlier_idx as for rs_essential_batch. */
+enum { RS_PRUNE_BOUND = 1u << 0, RS_PRUNE_SPRT = 1u << 1 };
+typedef struct rs_arrsac_params {
+    uint32_t struct_size;      /* sizeof(rs_arrsac_params) */
+    uint32_t n_hypotheses;     /* initialization_hypotheses */
+    uint32_t block_size;       /* matches per scoring block */
+    uint32_t init_blocks;      /* blocks scored before max_candidates applies */
+    uint32_t max_candidates;   /* max_candidate_hypotheses (poses kept); 0 = no cap */
+    uint32_t flags;            /* RS_PRUNE_* */
+    double threshold;          /* inlier threshold on CameraToCamera::residual */
+    double sprt_delta;         /* P(inlier | wrong model), e.g. 0.05 */
+    double sprt_ratio;         /* likelihood ratio threshold, arrsac default 1e3 */
+    uint64_t seed;             /* sampler seed (Xoshiro256PlusPlus::seed_from_u64 at the call sites) */
+} rs_arrsac_params;
+typedef struct rs_arrsac_stats {
+    uint32_t poses, survivors, blocks, reserved;
+    uint64_t residuals_evaluated, residuals_exhaustive;
+} rs_arrsac_stats;
+int32_t rs_essential_arrsac(rs_ctx* ctx, const double* bearings_a, const double* bearings_b, uint32_t n,
+                            const uint32_t* sample_idx, const rs_arrsac_params* params, double* best_pose,
+                            uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
+                            rs_arrsac_stats* stats);
+int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t* sample_idx);
 /* Consensus::model_inliers(&LambdaTwist::new(), matches) for 3D-2D registration (cv-sfm/src/lib.rs:1619-1622,
  * lambda-twist/tests/consensus.rs:59-61), sampler factored out as above: n_hyp sample triples; each gives up
  * to four WorldToCamera poses (lambda-twist/src/lib.rs:107-318), scored with WorldToCamera::residual

@@ -935,3 +935,42 @@ def test_two_contexts_with_different_options_in_one_process(gpu, oracle):
     with pytest.raises(_lib.AkzError):
         b.level_buffer(0, 1, "Ldet", 480, 270)
     a.close(); b.close()
+
+
+def test_arrsac_shaped_consensus(gpu, oracle):
+    """rs_essential_arrsac (row R4): (a) with the exact bound alone — block scoring, retirement of poses that cannot
+    reach the best count — the winner, its pose bits and its inlier set equal EXHAUSTIVE scoring by the oracle, on
+    samples drawn by the device sampler (== rs_arrsac_samples on the host) and on caller samples; (b) with the
+    candidate cap and the SPRT test on (arrsac's parameters at vslam-sandbox/src/main.rs:112-117) the same winner
+    comes out on the BASELINE configs[3] scene while most residuals are never evaluated."""
+    from cv_amd.ransac import EssentialConsensus
+    rng = np.random.default_rng(0x5AC)
+    n, n_hyp, thr = 1000, 2000, 1e-7
+    a, b = _two_view_scene(rng, n, 0.3)
+    cons = EssentialConsensus(n, 8192)
+    samples = cons.arrsac_samples(0, n, n_hyp)
+    assert samples.shape == (n_hyp, 8) and samples.max() < n
+    assert all(len(set(r)) == 8 for r in samples[:200].tolist())            # distinct indices per sample
+    wpose, wbest, winl, wcounts = oracle.essential_batch(a, b, samples, thr)
+    for kw in (dict(sample_idx=None), dict(sample_idx=samples)):
+        for bs in (64, 250, 1000):
+            pose, inl, best, st = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, block_size=bs,
+                                                            max_candidates=0, bound=True, sprt=False, **kw)
+            assert best == wbest, (bs, best, wbest)
+            _eq(pose, wpose, "arrsac pose (bound only)")
+            _eq(inl, winl, "arrsac inliers (bound only)")
+            assert st["residuals_evaluated"] <= st["residuals_exhaustive"]
+    # no pruning at all == rs_essential_batch
+    pose, inl, best, st = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, max_candidates=0, bound=False, sprt=False)
+    assert best == wbest and st["blocks"] == 1 and st["residuals_evaluated"] <= st["residuals_exhaustive"]
+    _eq(cons.counts(n_hyp), wcounts, "unpruned counts")
+    # arrsac's own shape: cap + SPRT
+    pose, inl, best, st = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, block_size=64, init_blocks=4,
+                                                    max_candidates=1024, bound=True, sprt=True)
+    assert best == wbest
+    _eq(pose, wpose, "arrsac pose (cap + SPRT)")
+    _eq(inl, winl, "arrsac inliers (cap + SPRT)")
+    assert st["residuals_evaluated"] < 0.35 * st["residuals_exhaustive"], st
+    assert st["survivors"] <= 1024
+    # a different seed draws different samples
+    assert not np.array_equal(cons.arrsac_samples(1, n, 16), samples[:16])
