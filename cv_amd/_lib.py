@@ -84,6 +84,11 @@ class ArrsacStats(C.Structure):
 RS_PRUNE_BOUND, RS_PRUNE_SPRT = 1, 2
 
 
+class OverflowInfo(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("needed_candidates", C.c_uint32), ("candidate_capacity", C.c_uint32),
+                ("keypoint_capacity", C.c_uint32)]
+
+
 class LevelInfo(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32),
@@ -103,7 +108,7 @@ ABI_SYMBOLS = [
     "akz_config_default", "akz_create", "akz_create_ex", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_u16",
     "akz_extract_gray_f32",
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
-    "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
+    "akz_last_overflow", "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
@@ -152,6 +157,7 @@ def lib():
     L.akz_sync.argtypes = [vp]
     L.akz_stream.restype = vp
     L.akz_stream.argtypes = [vp]
+    L.akz_last_overflow.argtypes = [vp, C.POINTER(OverflowInfo), u32, C.POINTER(u32)]
     L.akz_num_levels.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.akz_level.argtypes = [vp, i32, i32, i32, C.POINTER(LevelInfo)]
     L.akz_fed_tau.argtypes = [vp, i32, i32, i32, vp, u32, C.POINTER(u32)]

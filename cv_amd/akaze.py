@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import KP_DTYPE, AkzError, Config, LevelInfo, Options, check, make_options  # noqa: F401
 
 USIZE_MAX = 2 ** 64 - 1
-MAX_KEYPOINTS = 16384   # kAkzMaxKeypoints (cv_amd/csrc/akz_common.h)
+MAX_KEYPOINTS = 65536   # kAkzMaxKeypoints (cv_amd/csrc/akz_common.h)
 BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5}
 
 
@@ -194,9 +194,27 @@ class Context:
         descs = np.zeros((n, cap, 64), np.uint8)
         cnt = np.zeros(n, np.uint32)
         ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
-        check(_lib.lib().akz_extract_batch(self._h, ptrs, fmt, n, w, h, w, kps.ctypes.data, descs.ctypes.data, cap,
-                                           cnt.ctypes.data), "akz_extract_batch")
+        st = _lib.lib().akz_extract_batch(self._h, ptrs, fmt, n, w, h, w, kps.ctypes.data, descs.ctypes.data, cap,
+                                          cnt.ctypes.data)
+        if st == -7:
+            raise AkzError(st, "akz_extract_batch: " + self.overflow_report())
+        check(st, "akz_extract_batch")
         return [(kps[i, :cnt[i]].copy(), descs[i, :cnt[i]].copy()) for i in range(n)]
+
+    def overflow_report(self):
+        """akz_last_overflow as text: which frame's internal list overflowed and what it needed."""
+        info = (_lib.OverflowInfo * self.max_batch)()
+        n = C.c_uint32()
+        if _lib.lib().akz_last_overflow(self._h, info, self.max_batch, C.byref(n)) != 0:
+            return "overflow report unavailable"
+        out = []
+        for i in range(n.value):
+            if info[i].flags & 1:
+                out.append(f"frame {i}: a level holds {info[i].needed_candidates} extrema, capacity "
+                           f"{info[i].candidate_capacity} (akz_options.max_candidates / max_keypoints)")
+            if info[i].flags & 2:
+                out.append(f"frame {i}: more than {info[i].keypoint_capacity} keypoints (max_keypoints)")
+        return "; ".join(out) or "no list over capacity"
 
     # ---- parity taps -------------------------------------------------------------------
     def num_levels(self, w, h):

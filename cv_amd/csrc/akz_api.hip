@@ -298,6 +298,13 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_kp_out = cv.take<DevKp>(B * K);
     S.d_desc_out = cv.take<akz_descriptor>(B * K);
     S.d_n_out = cv.take<uint32_t>(B);
+    auto np2_of = [](uint32_t v) {
+        size_t p = 1;
+        while (p < v) p <<= 1;
+        return p;
+    };
+    S.d_keys_kp = c->max_kp > kAkzLdsSortKeys ? cv.take<unsigned long long>(B * np2_of(c->max_kp)) : nullptr;
+    S.d_keys_cand = c->max_cand > kAkzLdsSortKeys ? cv.take<unsigned long long>(B * kAkzMaxLevels * np2_of(c->max_cand)) : nullptr;
 }
 
 static void carve(akz_ctx* c, char* base, size_t* total)
@@ -630,6 +637,33 @@ extern "C" int32_t akz_debug_get_keypoints(akz_ctx* c, int32_t img, int32_t stag
         if (stage == 0)
             for (uint32_t i = 0; i < m; ++i) out[i].angle = 0.0f;
         return n > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    });
+}
+
+extern "C" int32_t akz_last_overflow(akz_ctx* c, akz_overflow_info* per_frame, uint32_t cap, uint32_t* n_frames)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !n_frames) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(sync_all(c));
+        const int n = c->cur_n;
+        *n_frames = (uint32_t)n;
+        if ((uint32_t)n > cap) return AKZ_E_CAPACITY;
+        if (n && !per_frame) return AKZ_E_INVALID;
+        std::vector<uint32_t> ncand((size_t)n * kAkzMaxLevels), ncache(n);
+        if (n) {
+            AKZ_HIP(hipMemcpy(ncand.data(), c->S().d_ncand, sizeof(uint32_t) * ncand.size(), hipMemcpyDeviceToHost));
+            AKZ_HIP(hipMemcpy(ncache.data(), c->S().d_ncache, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        }
+        for (int f = 0; f < n; ++f) {
+            uint32_t mx = 0;
+            for (int l = 0; l < kAkzMaxLevels; ++l) mx = ncand[(size_t)f * kAkzMaxLevels + l] > mx ? ncand[(size_t)f * kAkzMaxLevels + l] : mx;
+            per_frame[f].needed_candidates = mx;               // the counters keep counting past the capacity
+            per_frame[f].candidate_capacity = c->max_cand;
+            per_frame[f].keypoint_capacity = c->max_kp;
+            per_frame[f].flags = (mx > c->max_cand ? 1u : 0u) | (ncache[f] >= c->max_kp ? 2u : 0u);
+        }
+        return AKZ_OK;
     });
 }
 

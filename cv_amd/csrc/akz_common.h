@@ -32,7 +32,9 @@ extern thread_local int g_akz_last_hip;
 // table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
 constexpr int kAkzMaxLevels = 32;
 // Largest per-frame keypoint list / per-(frame, level) candidate list a context can be created for.
-constexpr uint32_t kAkzMaxKeypoints = 16384u;
+constexpr uint32_t kAkzMaxKeypoints = 65536u;
+// Keys a per-frame / per-level sort keeps in LDS (128 KB of the CU's 160 KB); longer lists sort through global memory.
+constexpr uint32_t kAkzLdsSortKeys = 16384u;
 // Longest Gaussian kernel of the generic blur path (base_scale_offset up to 255.5)
 constexpr int kAkzMaxTaps = 1023;
 
@@ -118,6 +120,69 @@ __device__ __forceinline__ void bitonic_sort_lds_u64(unsigned long long* key, ui
         }
     }
     __syncthreads();
+}
+// Ascending sort of np2 (a power of two) 64-bit keys that live in GLOBAL memory, by one block of NT threads with an
+// LDS buffer of lds_n keys (a power of two): lists of up to lds_n keys never leave LDS (bitonic_sort_lds_u64 on a
+// copy); longer ones run the same bitonic network with the strides >= lds_n as passes over global memory and the
+// strides below it chunk by chunk in LDS (one load / store of every chunk per merge level).  The rare path of the
+// keypoint sorts: frames with more than 16384 keypoints or a level with more than 16384 extrema.
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_big_u64(unsigned long long* g, uint32_t np2, unsigned long long* lds, uint32_t lds_n)
+{
+    const uint32_t tid = threadIdx.x;
+    auto local_passes = [&](uint32_t gbase, uint32_t k2, uint32_t jstart) {   // passes j = jstart .. 1 of merge level k2
+        for (uint32_t j = jstart; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (lds_n >> 1); t += NT) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), ixj = i | j;
+                const unsigned long long a = lds[i], b = lds[ixj];
+                const bool up = ((gbase + i) & k2) == 0;
+                if ((a > b) == up) {
+                    lds[i] = b;
+                    lds[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (np2 <= lds_n) {
+        for (uint32_t i = tid; i < np2; i += NT) lds[i] = g[i];
+        __syncthreads();
+        bitonic_sort_lds_u64<NT>(lds, np2);
+        for (uint32_t i = tid; i < np2; i += NT) g[i] = lds[i];
+        __syncthreads();
+        return;
+    }
+    // merge levels up to lds_n inside each chunk (direction by the chunk's global position)
+    for (uint32_t base = 0; base < np2; base += lds_n) {
+        for (uint32_t i = tid; i < lds_n; i += NT) lds[i] = g[base + i];
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= lds_n; k2 <<= 1) local_passes(base, k2, k2 >> 1);
+        for (uint32_t i = tid; i < lds_n; i += NT) g[base + i] = lds[i];
+        __syncthreads();
+    }
+    for (uint32_t k2 = lds_n << 1; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j >= lds_n; j >>= 1) {                  // strides that cross chunks: global passes
+            for (uint32_t t = tid; t < (np2 >> 1); t += NT) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), ixj = i | j;
+                const unsigned long long a = g[i], b = g[ixj];
+                const bool up = (i & k2) == 0;
+                if ((a > b) == up) {
+                    g[i] = b;
+                    g[ixj] = a;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (uint32_t base = 0; base < np2; base += lds_n) {              // the remaining strides, chunk by chunk
+            for (uint32_t i = tid; i < lds_n; i += NT) lds[i] = g[base + i];
+            __syncthreads();
+            local_passes(base, k2, lds_n >> 1);
+            for (uint32_t i = tid; i < lds_n; i += NT) g[base + i] = lds[i];
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
 }
 #endif
 

@@ -54,6 +54,9 @@ struct AkzSet {
     DevKp* d_kp_out = nullptr;             // [B][max_kp]  final (internal copy used by the host-buffer API)
     akz_descriptor* d_desc_out = nullptr;  // [B][max_kp]
     uint32_t* d_n_out = nullptr;           // [B]
+    // global key scratch of the sorts for lists longer than kAkzLdsSortKeys (null when the capacities fit in LDS)
+    unsigned long long* d_keys_kp = nullptr;    // [B][np2(max_kp)]
+    unsigned long long* d_keys_cand = nullptr;  // [B][kAkzMaxLevels][np2(max_cand)]
 };
 
 struct akz_ctx {

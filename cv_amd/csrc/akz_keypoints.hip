@@ -810,15 +810,19 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
 // Bitonic sort of 64-bit keys (~response_bits << 32 | index) in LDS, one block per frame.
 __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
                                                uint32_t stride, uint32_t max_features, DevKp* __restrict__ out,
-                                               uint32_t* __restrict__ n_out)
+                                               uint32_t* __restrict__ n_out, unsigned long long* __restrict__ gkeys,
+                                               uint32_t gstride, uint32_t lds_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* lds = reinterpret_cast<unsigned long long*>(smem);
     const int frame = blockIdx.x;
     const uint32_t n = min(n_in[frame], stride);
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     const DevKp* src = in + (size_t)frame * stride;
+    // lists longer than the LDS buffer sort through the frame's global key scratch (akz_common.h)
+    const bool big = np2 > lds_keys;
+    unsigned long long* key = big ? gkeys + (size_t)frame * gstride : lds;
     for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
         unsigned long long k = ~0ull;
         if (i < n) {
@@ -828,8 +832,10 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
         }
         key[i] = k;
     }
+    __threadfence_block();
     __syncthreads();
-    bitonic_sort_lds_u64<1024>(key, np2);
+    if (big) bitonic_sort_big_u64<1024>(key, np2, lds, lds_keys);
+    else bitonic_sort_lds_u64<1024>(key, np2);
     uint32_t m = n < max_features ? n : max_features;
     for (uint32_t i = threadIdx.x; i < m; i += 1024) out[(size_t)frame * stride + i] = src[(uint32_t)(key[i] & 0xFFFFFFFFull)];
     if (threadIdx.x == 0) n_out[frame] = m;
@@ -842,15 +848,18 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
 // (response descending) is untouched.
 __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevKp* __restrict__ in,
                                                         const uint32_t* __restrict__ n_in, uint32_t stride,
-                                                        uint32_t* __restrict__ perm, int tile_shift)
+                                                        uint32_t* __restrict__ perm, int tile_shift,
+                                                        unsigned long long* __restrict__ gkeys, uint32_t gstride, uint32_t lds_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* lds = reinterpret_cast<unsigned long long*>(smem);
     const int frame = blockIdx.x;
     const uint32_t n = min(n_in[frame], stride);
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     const DevKp* src = in + (size_t)frame * stride;
+    const bool big = np2 > lds_keys;
+    unsigned long long* key = big ? gkeys + (size_t)frame * gstride : lds;
     for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
         unsigned long long k = ~0ull;
         if (i < n) {
@@ -862,8 +871,10 @@ __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevK
         }
         key[i] = k;
     }
+    __threadfence_block();
     __syncthreads();
-    bitonic_sort_lds_u64<1024>(key, np2);
+    if (big) bitonic_sort_big_u64<1024>(key, np2, lds, lds_keys);
+    else bitonic_sort_lds_u64<1024>(key, np2);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) perm[(size_t)frame * stride + i] = (uint32_t)(key[i] & 0xFFFFFFFFull);
 }
 
@@ -1293,15 +1304,16 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A15
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
+    const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;   // longer lists: global key scratch
     uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
-    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, S.d_kp_c, S.d_n_c,
-                       c->max_kp, maxf, S.d_kp_d, S.d_n_d);
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, S.d_kp_c, S.d_n_c,
+                       c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
     akz_timer_begin(c, AKZ_T_DESCRIBE, s);
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
-        hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * np2, s, T, S.d_kp_d,
-                           S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift);
+        hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
+                           S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);

@@ -1708,10 +1708,11 @@ __global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ L
 // (y << 48 | x << 32 | slot) in LDS ((x, y) is unique, so the order is total), then a gather of the unsorted
 // records into the sorted position / response list and the sorted neighbourhood list.
 __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ cand_u, const uint32_t* __restrict__ ncand,
-                                                    uint32_t cap, uint2* __restrict__ cand, float* __restrict__ cand_nb)
+                                                    uint32_t cap, uint2* __restrict__ cand, float* __restrict__ cand_nb,
+                                                    unsigned long long* __restrict__ gkeys, uint32_t gstride, uint32_t lds_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* lds = reinterpret_cast<unsigned long long*>(smem);
     const uint32_t level = blockIdx.x, frame = blockIdx.y;
     const uint32_t n = min(ncand[(size_t)frame * kAkzMaxLevels + level], cap);
     if (n == 0) return;
@@ -1719,6 +1720,9 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
     const CandU* seg = cand_u + list;
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
+    // lists longer than the LDS buffer sort through the list's global key scratch (akz_common.h)
+    const bool big = np2 > lds_keys;
+    unsigned long long* key = big ? gkeys + ((size_t)frame * kAkzMaxLevels + level) * gstride : lds;
     for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
         unsigned long long kk = ~0ull;
         if (i < n) {
@@ -1728,8 +1732,10 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
         }
         key[i] = kk;
     }
+    __threadfence_block();
     __syncthreads();
-    bitonic_sort_lds_u64<1024>(key, np2);
+    if (big) bitonic_sort_big_u64<1024>(key, np2, lds, lds_keys);
+    else bitonic_sort_lds_u64<1024>(key, np2);
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const CandU cu = seg[(uint32_t)key[i]];
         cand[list + i] = make_uint2(cu.xy, __float_as_uint(cu.v));
@@ -2136,8 +2142,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     {
         uint32_t np2 = 1;
         while (np2 < c->max_cand) np2 <<= 1;
-        hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * np2, s, (const CandU*)S.d_cand_u,
-                           S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
+        const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;
+        hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, (const CandU*)S.d_cand_u,
+                           S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb, S.d_keys_cand, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
     }
     akz_timer_end(c, AKZ_T_SCALE_SPACE, s, 0, (uint64_t)n);

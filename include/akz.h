@@ -162,6 +162,19 @@ void* akz_stream(akz_ctx* ctx);
 int32_t akz_scale_space_device(akz_ctx* ctx, const void* d_imgs, int32_t fmt, int32_t n, int32_t w,
                                int32_t h, void* stream_to_wait);
 
+/* After a call answered AKZ_E_INTERNAL: which internal list of which frame of that batch overflowed, and what it
+ * would have needed (the reference's Vecs grow without bound, akaze/src/lib.rs:169-171 maximum_features =
+ * usize::MAX; here every list has a capacity fixed at akz_create_ex: max_keypoints per frame — at most 65536 — and
+ * akz_options.max_candidates raw extrema per (frame, level)).  flags bit 0: a per-level candidate list (needed_candidates
+ * = the longest list of the frame); bit 1: the frame's keypoint lists after suppression. */
+typedef struct akz_overflow_info {
+    uint32_t flags;
+    uint32_t needed_candidates;   /* largest per-level extrema count of the frame */
+    uint32_t candidate_capacity;
+    uint32_t keypoint_capacity;
+} akz_overflow_info;
+int32_t akz_last_overflow(akz_ctx* ctx, akz_overflow_info* per_frame, uint32_t cap, uint32_t* n_frames);
+
 /* ---- pyramid introspection / parity taps (what Akaze::allocate_evolutions returns) ---- */
 typedef struct akz_level_info {
     int32_t width, height;

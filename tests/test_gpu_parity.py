@@ -974,3 +974,30 @@ def test_arrsac_shaped_consensus(gpu, oracle):
     assert st["survivors"] <= 1024
     # a different seed draws different samples
     assert not np.array_equal(cons.arrsac_samples(1, n, 16), samples[:16])
+
+
+def test_large_keypoint_lists_and_overflow_report(gpu, oracle):
+    """Beyond 16384 keypoints per frame / extrema per level (the reference's lists are unbounded,
+    akaze/src/lib.rs:169-171): a noise frame at Akaze::dense() has ~27 000 extrema on level 0 and ~40 000 keypoints.
+    With max_keypoints = 65536 every sort takes its global-memory path and the result equals the oracle; with the
+    default capacity the call fails with AKZ_E_INTERNAL and akz_last_overflow names the frame and what it needed."""
+    akaze, _ = gpu
+    from cv_amd import _lib
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (960, 1280), dtype=np.uint8)
+    okp, od = oracle.Akaze(1280, 960, oracle.default_config(threshold=0.0001)).extract(img)
+    assert len(okp) > 16384
+    ak = akaze.Akaze.dense()
+    ak.max_keypoints = 65536
+    ctx = akaze.Context(ak, 1280, 960, 1)
+    (kp, d), = ctx.extract_batch([img])
+    _kp_eq(kp, okp, "dense noise keypoints")
+    _eq(d, od, "dense noise descriptors")
+    ctx.close()
+    small = akaze.Akaze.dense()
+    small.max_keypoints = 16384
+    ctx = akaze.Context(small, 1280, 960, 1)
+    with pytest.raises(_lib.AkzError) as ei:
+        ctx.extract_batch([img])
+    assert ei.value.status == -7 and "frame 0" in str(ei.value), str(ei.value)
+    ctx.close()
