@@ -916,6 +916,82 @@ extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d
     });
 }
 
+// Best-of-views landmark selection of the registration path (cv-sfm/src/lib.rs:1489-1542): every feature of the new
+// frame got k neighbours in each of n_views views (hm_knn_views_device); a neighbour is an observation of a
+// landmark (landmarks[view block][feature index]).  Per feature: keep the best (smallest) distance of every
+// distinct landmark, take the three best landmarks, and classify them with the reference's two rules:
+//   best[0].d + better_by <= best[1].d                   -> 1: unique match to best[0]
+//   else best[1].d + better_by <= best[2].d              -> 2: best[0] and best[1] are merge candidates (the caller
+//                                                              still checks are_landmarks_sharing_view, :1528)
+//   else                                                 -> 0
+// The reference collects the landmarks in a HashMap, so its order among equal distances is unspecified; here ties
+// go to the lower landmark key (parity unpinned for ties).  One thread per feature: n_views * k <= 96 entries.
+__global__ __launch_bounds__(256) void k_best_of_views(const akz_neighbor* __restrict__ knn, const uint32_t* __restrict__ nq,
+                                                       uint32_t cap, uint32_t n_views, uint32_t k,
+                                                       const uint32_t* __restrict__ landmarks, const uint32_t* __restrict__ view_idx,
+                                                       const uint32_t* __restrict__ nviews, uint32_t better_by,
+                                                       uint2* __restrict__ best, uint32_t* __restrict__ decision)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(*nq, cap)) return;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t bl[3] = {NONE, NONE, NONE}, bd[3] = {NONE, NONE, NONE};   // ascending (distance, landmark)
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const uint32_t blk = view_idx[v], nt = min(nviews[blk], cap);
+        for (uint32_t j = 0; j < k && j < nt; ++j) {
+            const akz_neighbor nb = knn[((size_t)v * cap + i) * k + j];
+            const uint32_t l = landmarks[(size_t)blk * cap + nb.index], d = nb.distance;
+            // already among the best three: keep the smaller distance
+            int at = -1;
+            for (int q = 0; q < 3; ++q)
+                if (bl[q] == l && bd[q] != NONE) at = q;
+            if (at >= 0) {
+                if (d >= bd[at]) continue;
+                for (int q = at; q < 2; ++q) { bl[q] = bl[q + 1]; bd[q] = bd[q + 1]; }   // take it out, re-insert below
+                bl[2] = NONE; bd[2] = NONE;
+            }
+            int pos = 3;
+            for (int q = 2; q >= 0; --q)
+                if (d < bd[q] || (d == bd[q] && l < bl[q])) pos = q;
+            if (pos == 3) continue;
+            for (int q = 2; q > pos; --q) { bl[q] = bl[q - 1]; bd[q] = bd[q - 1]; }
+            bl[pos] = l; bd[pos] = d;
+        }
+    }
+    for (int q = 0; q < 3; ++q) best[(size_t)i * 3 + q] = make_uint2(bl[q], bd[q]);
+    uint32_t dec = 0;
+    // the reference unwraps three landmarks (:1509-1513): with fewer than three there is no decision
+    if (bd[2] != NONE) {
+        if (bd[0] + better_by <= bd[1]) dec = 1;
+        else if (bd[1] + better_by <= bd[2]) dec = 2;
+    }
+    decision[i] = dec;
+}
+
+extern "C" int32_t hm_best_of_views_device(hm_ctx* c, const void* d_knn, const void* d_nq, uint32_t cap_per_img,
+                                           const uint32_t* view_idx, uint32_t n_views, uint32_t k, const void* d_landmarks,
+                                           const void* d_nviews, uint32_t better_by, void* d_best, void* d_decision,
+                                           void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_knn || !d_nq || !view_idx || !d_landmarks || !d_nviews || !d_best || !d_decision) return AKZ_E_INVALID;
+        if (k < 1 || k > 3 || n_views == 0 || n_views > 64 || cap_per_img == 0) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        AKZ_TRY(hm_ensure_probs(c, 256));
+        AKZ_TRY(hm_push_probs(c, 0, view_idx, sizeof(uint32_t) * n_views));
+        hipLaunchKernelGGL(k_best_of_views, dim3((cap_per_img + 255) / 256), dim3(256), 0, c->stream, (const akz_neighbor*)d_knn,
+                           (const uint32_t*)d_nq, cap_per_img, n_views, k, (const uint32_t*)d_landmarks,
+                           (const uint32_t*)c->d_probs, (const uint32_t*)d_nviews, better_by, (uint2*)d_best,
+                           (uint32_t*)d_decision);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    });
+}
+
 // Timing of the k-NN kernel launches (HIP events on hm_stream()): enable, run, then read the accumulated
 // milliseconds and launch count.  hm_timing_get synchronises the pending events.
 extern "C" int32_t hm_timing_enable(hm_ctx* c, int32_t on)

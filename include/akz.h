@@ -245,6 +245,18 @@ int32_t hm_knn(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_desc
 int32_t hm_knn_views_device(hm_ctx* ctx, const void* d_q, const void* d_nq, const void* d_views,
                             const void* d_nviews, uint32_t cap_per_img, const uint32_t* view_idx,
                             uint32_t n_views, uint32_t k, void* d_out, void* stream_to_wait);
+/* What follows hm_knn_views_device in the reference (cv-sfm/src/lib.rs:1489-1542): per feature, the best distance of
+ * every distinct landmark among its n_views x k neighbours, the three best landmarks (ascending (distance, landmark
+ * key): the reference's HashMap leaves the order of equal distances unspecified), and the decision of :1516-1532 —
+ * 1: best[0] is a unique match (best[0].d + better_by <= best[1].d); 2: best[0], best[1] are merge candidates
+ * (best[1].d + better_by <= best[2].d; the caller still applies are_landmarks_sharing_view); 0: neither, or fewer
+ * than three distinct landmarks.  d_knn = hm_knn_views_device's d_out [n_views][cap][k]; d_landmarks
+ * [view blocks][cap] u32 = the landmark key observed by each feature of each stored view (reconstruction.views[v]
+ * .landmarks); d_best [cap][3] {landmark, distance} (0xFFFFFFFF when absent), d_decision [cap] u32. */
+int32_t hm_best_of_views_device(hm_ctx* ctx, const void* d_knn, const void* d_nq, uint32_t cap_per_img,
+                                const uint32_t* view_idx, uint32_t n_views, uint32_t k, const void* d_landmarks,
+                                const void* d_nviews, uint32_t better_by, void* d_best, void* d_decision,
+                                void* stream_to_wait);
 /* matching()/symmetric_matching() of tutorial ch5 main.rs:154-200 and cv-sfm/src/lib.rs:3097-3133,
  * and match_descriptors() of akaze/tests/estimate_pose.rs:78-97.
  *   rule 0: accept iff d0 + param_u <  d1   (tutorial, param_u = 24)

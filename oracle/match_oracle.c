@@ -144,3 +144,44 @@ int orc_match(const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uin
     free(rev);
     return n;
 }
+
+/* Best-of-views landmark selection, cv-sfm/src/lib.rs:1489-1532: per feature the minimum distance of every distinct
+ * landmark over the n_views x k neighbours (the HashMap of :1489-1501), the three best by (distance, landmark key)
+ * — the reference's order among equal distances is its HashMap's iteration order, i.e. unspecified: parity unpinned
+ * for ties — and the decision of :1516-1532.  knn [n_views][cap][k]; landmarks [blocks][cap]; best [nq][3][2]. */
+void orc_best_of_views(const akz_neighbor* knn, uint32_t nq, uint32_t cap, uint32_t n_views, uint32_t k,
+                       const uint32_t* landmarks, const uint32_t* view_idx, const uint32_t* nviews, uint32_t better_by,
+                       uint32_t* best, uint32_t* decision)
+{
+    for (uint32_t i = 0; i < nq; ++i) {
+        /* the dedup map as a small array (at most n_views * k entries) */
+        uint32_t ml[192], md[192], nm = 0;
+        for (uint32_t v = 0; v < n_views; ++v) {
+            uint32_t blk = view_idx[v], nt = nviews[blk] < cap ? nviews[blk] : cap;
+            for (uint32_t j = 0; j < k && j < nt; ++j) {
+                akz_neighbor nb = knn[((size_t)v * cap + i) * k + j];
+                uint32_t l = landmarks[(size_t)blk * cap + nb.index], found = nm;
+                for (uint32_t q = 0; q < nm; ++q)
+                    if (ml[q] == l) found = q;
+                if (found == nm) { ml[nm] = l; md[nm] = nb.distance; nm++; }
+                else if (md[found] > nb.distance) md[found] = nb.distance;
+            }
+        }
+        uint32_t bl[3] = {UINT32_MAX, UINT32_MAX, UINT32_MAX}, bd[3] = {UINT32_MAX, UINT32_MAX, UINT32_MAX};
+        for (uint32_t q = 0; q < nm; ++q) {                      /* selection of the three smallest (distance, key) */
+            int pos = 3;
+            for (int r = 2; r >= 0; --r)
+                if (md[q] < bd[r] || (md[q] == bd[r] && ml[q] < bl[r])) pos = r;
+            if (pos == 3) continue;
+            for (int r = 2; r > pos; --r) { bl[r] = bl[r - 1]; bd[r] = bd[r - 1]; }
+            bl[pos] = ml[q]; bd[pos] = md[q];
+        }
+        for (int r = 0; r < 3; ++r) { best[((size_t)i * 3 + r) * 2] = bl[r]; best[((size_t)i * 3 + r) * 2 + 1] = bd[r]; }
+        uint32_t dec = 0;
+        if (nm >= 3) {
+            if (bd[0] + better_by <= bd[1]) dec = 1;
+            else if (bd[1] + better_by <= bd[2]) dec = 2;
+        }
+        decision[i] = dec;
+    }
+}

@@ -107,6 +107,8 @@ def lib():
         L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_sample_colors_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_best_of_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
                                 C.c_float, C.c_int, C.c_void_p, C.c_uint32]
         L.orc_calibrate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -446,3 +448,16 @@ def p3p_batch(bearings, world, sample_idx, thresh):
     if r != 0:
         return None
     return pose, best.value, inl[:ninl.value].copy(), counts
+
+
+def best_of_views(knn_out, nq, landmarks, view_idx, nviews, better_by=24):
+    """cv-sfm/src/lib.rs:1489-1532 (oracle/match_oracle.c: orc_best_of_views).  knn_out [n_views, cap, k] of
+    NB_DTYPE; landmarks [blocks, cap] u32.  Returns (best [nq,3,2] u32, decision [nq] u32)."""
+    knn_out = np.ascontiguousarray(knn_out, NB_DTYPE)
+    n_views, cap, k = knn_out.shape
+    landmarks = np.ascontiguousarray(landmarks, np.uint32)
+    vi = np.ascontiguousarray(view_idx, np.uint32); nv = np.ascontiguousarray(nviews, np.uint32)
+    best = np.zeros((nq, 3, 2), np.uint32); dec = np.zeros(nq, np.uint32)
+    lib().orc_best_of_views(knn_out.ctypes.data, nq, cap, n_views, k, landmarks.ctypes.data, vi.ctypes.data, nv.ctypes.data,
+                            better_by, best.ctypes.data, dec.ctypes.data)
+    return best, dec

@@ -406,6 +406,22 @@ def test_knn_views_device(gpu, oracle):
         want = oracle.knn(q[:nq], views[v, :counts[v]], 3)
         _eq(got[j, :nq, :, 0].astype(np.uint32), want["index"], f"view {v} idx")
         _eq(got[j, :nq, :, 1].astype(np.uint32), want["distance"], f"view {v} dist")
+    # best-of-views landmark selection on top of it (cv-sfm/src/lib.rs:1489-1532): few distinct landmarks, so the
+    # same landmark shows up in several views and with equal distances
+    landmarks = rng.integers(0, 900, (nviews, cap), dtype=np.uint32)
+    d_lm = torch.from_numpy(landmarks.view(np.int32)).to(dev)
+    d_best = torch.zeros((cap, 3, 2), dtype=torch.int32, device=dev)
+    d_dec = torch.full((cap,), 7, dtype=torch.int32, device=dev)
+    for better_by in (24, 1):
+        _lib.check(L.hm_best_of_views_device(m.handle, out.data_ptr(), d_nq.data_ptr(), cap, idx, 3, 3, d_lm.data_ptr(),
+                                             d_nv.data_ptr(), better_by, d_best.data_ptr(), d_dec.data_ptr(), None), "best_of_views")
+        _lib.check(L.hm_sync(m.handle), "hm_sync")
+        gnb = np.zeros((3, cap, 3), _lib.NB_DTYPE)
+        gnb["index"] = got[..., 0]; gnb["distance"] = got[..., 1]
+        wbest, wdec = oracle.best_of_views(gnb, nq, landmarks, sel, counts, better_by)
+        _eq(d_best.cpu().numpy()[:nq].astype(np.uint32), wbest, f"best of views (better_by {better_by})")
+        _eq(d_dec.cpu().numpy()[:nq].astype(np.uint32), wdec, f"decisions (better_by {better_by})")
+        assert set(np.unique(wdec)) <= {0, 1, 2} and (wdec == 1).any()
 
 
 def test_place_recognition_hash_and_search(gpu, oracle, kitti_golden):
