@@ -1016,21 +1016,23 @@ __device__ __forceinline__ void desc_cells(const float* s_ri, const float* s_dx,
 // of step 7 reaches +10, the other two stop at +9), so the 21 x 21 = 441 lattice values are gathered ONCE
 // (7 rounds of 64 lanes, all loads in flight) and parked in the wave's LDS segment; the 4 + 9 + 16 = 29 cells
 // are then summed concurrently, one lane per cell, each in the reference's (k outer, l inner) order.
-__global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescTables* __restrict__ desc_p,
+constexpr int kDescWaves = 1;   // waves (keypoints) per block: one, so a block's 6 KB of LDS fits beside the scale-space
+                                // stream's blocks, which fill most of a CU's LDS (four per block: 0.6 % slower end to end)
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe_fast(LevelTable T, const DescTables* __restrict__ desc_p,
                                                        const DevKp* __restrict__ in,
                                                        const uint32_t* __restrict__ n_in, uint32_t stride,
                                                        const uint32_t* __restrict__ perm,
                                                        akz_descriptor* __restrict__ out, uint32_t* __restrict__ flag)
 {
     constexpr int LAT = 21, NS = LAT * LAT, NIT = (NS + 63) / 64, SMAX = 448;
-    __shared__ float s_ri[4][SMAX], s_dx[4][SMAX], s_dy[4][SMAX];
-    __shared__ float s_val[4][96];
+    __shared__ float s_ri[kDescWaves][SMAX], s_dx[kDescWaves][SMAX], s_dy[kDescWaves][SMAX];
+    __shared__ float s_val[kDescWaves][96];
     const DescTables& c_desc = *desc_p;
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n = min(n_in[frame], stride);
-    const uint32_t vi = blk.x * 4 + wv;
+    const uint32_t vi = blk.x * kDescWaves + wv;
     if (vi >= n) return;  // whole wave; no block-level barrier below
     const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
     const DevKp kp = in[(size_t)frame * stride + ki];
@@ -1044,13 +1046,19 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
     const float2* LXY = L.Lxy + (size_t)frame * L.fs;
     const int W = L.w, Hh = L.h;
     bool oob = false;
-    int idx[NIT];
+    int idx[NIT], canon[NIT];
+    // consecutive lanes take consecutive lattice samples along the lattice axis whose image-space step is the more
+    // HORIZONTAL one (k steps by scale * (co, si), l by scale * (-si, co)): the lanes of a quad then fall on the same
+    // row and mostly the same cache line, which is what the texture addresser coalesces (wave-uniform choice)
+    const bool k_fast = fabsf(co) > fabsf(si);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int s = it * 64 + lane;
         const bool on = s < NS;
-        const int kq = s / LAT;
-        const float kf = (float)(kq - 10), lf = (float)(s - kq * LAT - 10);
+        const int qa = s / LAT, qb = s - qa * LAT;
+        const int kq = k_fast ? qb : qa, lq = k_fast ? qa : qb;
+        canon[it] = kq * LAT + lq;                       // position in the (k outer, l inner) lattice the sums walk
+        const float kf = (float)(kq - 10), lf = (float)(lq - 10);
         // descriptors.rs:127-128, exact expression order
         float sample_y = yf + (lf * co * scale + kf * si * scale);
         float sample_x = xf + (-lf * si * scale + kf * co * scale);
@@ -1073,9 +1081,9 @@ __global__ __launch_bounds__(256) void k_describe_fast(LevelTable T, const DescT
         float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
         float rrx = -dd[it].x * si + dd[it].y * co;
         if (s < NS) {
-            s_ri[wv][s] = ri[it];
-            s_dx[wv][s] = rrx;
-            s_dy[wv][s] = rry;
+            s_ri[wv][canon[it]] = ri[it];
+            s_dx[wv][canon[it]] = rrx;
+            s_dy[wv][canon[it]] = rry;
         }
     }
     oob = __any(oob);
@@ -1315,7 +1323,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_describe_fast, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
+        hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);
     } else {
         hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,

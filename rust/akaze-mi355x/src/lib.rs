@@ -48,6 +48,8 @@ extern "C" {
     fn akz_create(cfg: *const AkzConfig, device: i32, max_w: i32, max_h: i32, max_batch: i32, max_kp: u32,
                   out: *mut *mut c_void) -> i32;
     fn akz_destroy(ctx: *mut c_void) -> i32;
+    fn akz_extract_gray_u16(ctx: *mut c_void, img: *const u16, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
+                            descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
     fn akz_extract_gray_u8(ctx: *mut c_void, img: *const u8, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
                            descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
     fn akz_extract_gray_f32(ctx: *mut c_void, img: *const f32, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
@@ -192,8 +194,15 @@ impl Akaze {
                     akz_extract_gray_u8(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
                 })
             }
+            DynamicImage::ImageLuma16(g) => {
+                // image.rs:57-66: f32::from(v) / 65535f32, done on the device
+                let (w, h) = (g.width(), g.height());
+                self.run(w, h, |ctx, k, d, n| unsafe {
+                    akz_extract_gray_u16(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
+                })
+            }
             other => {
-                // remaining arms of GrayFloatImage::from_dynamic (image.rs:57-106): convert on the host
+                // remaining arms of GrayFloatImage::from_dynamic (image.rs:67-106): convert on the host
                 let f = other.to_luma32f();
                 let (w, h) = (f.width(), f.height());
                 self.run(w, h, |ctx, k, d, n| unsafe {
@@ -370,8 +379,9 @@ pub mod image {
     }
     /// image.rs:383
     pub fn gaussian_blur(image: &GrayFloatImage, r: f32) -> GrayFloatImage {
-        let size = (2.0 * (1.0 + (r - 0.8) / 0.3)).ceil() as usize;   // image.rs:385
-        let k = gaussian_kernel(r, if size % 2 == 0 { size + 1 } else { size });
+        assert!(r > 0.0, "sigma must be > 0.0");                       // image.rs:384
+        let radius = (2.0 * r).ceil() as usize;                        // image.rs:385
+        let k = gaussian_kernel(r, 2 * radius + 1);
         GrayFloatImage(separable_filter(&image.0, &k, &k))
     }
 }

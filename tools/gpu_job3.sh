@@ -1,4 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${1:+-k "$1"} 2>&1 | tail -25
+export KSTAT_LINES=40
+python tools/stress_parity.py --n 24 2>&1 | tail -1
+bash tools/kstat.sh "$@" 2>&1 | grep -E "describe|refine|ms per"
