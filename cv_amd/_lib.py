@@ -44,7 +44,7 @@ class Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32), ("fed_block", C.c_uint32),
         ("sup_capacity", C.c_uint32), ("max_candidates", C.c_uint32), ("desc_tile_shift", C.c_uint32),
-        ("stream_waves", C.c_uint32), ("stream_min_kpixels", C.c_uint32), ("reserved", C.c_uint32 * 8),
+        ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("reserved", C.c_uint32 * 8),
     ]
 
 
@@ -56,7 +56,7 @@ FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
 
 def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=False,
                  contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0, stream_kernels=True,
-                 stream_waves=0, stream_min_kpixels=0):
+                 stream_waves=0, stream_min_waves=0):
     """Options with readable names.  contrast: "fine" (default), "exact", "force_odd"."""
     o = Options()
     o.struct_size = C.sizeof(Options)
@@ -65,7 +65,7 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
                | (OPT_STREAM_PRIORITY if stream_priority else 0) | (0 if stream_kernels else OPT_TILE_KERNELS)
                | {"fine": 0, "exact": OPT_CONTRAST_EXACT, "force_odd": OPT_CONTRAST_FORCE_ODD}[contrast])
     o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift
-    o.stream_waves, o.stream_min_kpixels = stream_waves, stream_min_kpixels
+    o.stream_waves, o.stream_min_waves = stream_waves, stream_min_waves
     return o
 
 

@@ -159,7 +159,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->front_pair = !(o.flags & AKZ_OPT_NO_FRAME_PAIRS);
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
-        if (o.stream_min_kpixels) c->stream_min_pixels = (size_t)o.stream_min_kpixels * 1024u;
+        if (o.stream_min_waves) c->stream_min_waves = (size_t)o.stream_min_waves;
         c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);
         c->contrast_force_odd = (o.flags & AKZ_OPT_CONTRAST_FORCE_ODD) != 0;
         c->nsets = (o.flags & AKZ_OPT_NO_PIPELINE) ? 1 : 2;

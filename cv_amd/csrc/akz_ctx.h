@@ -54,7 +54,7 @@ struct AkzSet {
     DevKp* d_kp_out = nullptr;             // [B][max_kp]  final (internal copy used by the host-buffer API)
     akz_descriptor* d_desc_out = nullptr;  // [B][max_kp]
     uint32_t* d_n_out = nullptr;           // [B]
-    // global key scratch of the sorts for lists longer than kAkzLdsSortKeys (null when the capacities fit in LDS)
+    // global key scratch of the bitonic sorts for lists longer than kAkzLdsSortKeys (null when they fit in LDS)
     unsigned long long* d_keys_kp = nullptr;    // [B][np2(max_kp)]
     unsigned long long* d_keys_cand = nullptr;  // [B][kAkzMaxLevels][np2(max_cand)]
 };
@@ -74,7 +74,7 @@ struct akz_ctx {
     bool keep_all = false;    // keep per-level Lsmooth/Lflow (parity taps) instead of per-octave scratch
     bool stream_kernels = true;   // row-streaming kernels (k_det_stream) instead of the tile kernels (AKZ_OPT_TILE_KERNELS)
     int det_stream_waves = 8192;  // waves a streaming launch aims for (sets the row-segment length)
-    size_t stream_min_pixels = 0; // launches covering fewer pixel-frames than this take the tile kernels
+    size_t stream_min_waves = 2048;  // launches that cannot field this many streaming waves take the tile kernels
 
     AkzPlan plan;             // for (cur_w, cur_h)
     int cur_w = 0, cur_h = 0, cur_n = 0;

@@ -806,8 +806,74 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// A15: sort by response descending (ties: lower pre-sort index first), truncate to maximum_features.
-// Bitonic sort of 64-bit keys (~response_bits << 32 | index) in LDS, one block per frame.
+// A15: sort by response descending (ties: lower pre-sort index first), truncate to maximum_features — and the
+// visiting order of the descriptor stage — as RANK sorts: the keys are unique (the index rides in the low bits),
+// so the sorted position of an element is the number of keys smaller than its own.  Every keypoint counts that
+// against all keys of its frame (tiles of 1024 keys through LDS, every lane reading the same address: a
+// broadcast), 256 keypoints per block: n^2 comparisons spread over the whole chip instead of one block's bitonic
+// network (a single 1080p frame: 154 -> ~20 us per sort; no 128 KB LDS buffer, no capacity limit).
+//   RANK_RESPONSE: key = (~response_bits, index); out[rank] = keypoint for rank < maximum_features
+//   RANK_SPATIAL:  key = (level, 32-px tile row, tile column, index); perm[rank] = index.  The response-sorted list
+//                  is spatially random, so consecutive keypoints (one per wave of the descriptor kernel) would
+//                  sample unrelated patches; the kernel walks this permutation and still writes each descriptor
+//                  to its keypoint's own slot, so the output order (response descending) is untouched.
+enum { RANK_RESPONSE = 0, RANK_SPATIAL = 1 };
+
+template <int MODE>
+__device__ __forceinline__ unsigned long long rank_key(const DevKp& kp, uint32_t i, int tile_shift)
+{
+    if (MODE == RANK_RESPONSE) {
+        // responses are |Ldet| > 0: the IEEE bit pattern is monotone in the value
+        return ((unsigned long long)(~__float_as_uint(kp.response)) << 32) | (unsigned long long)i;
+    }
+    const float ratio = (float)(1u << kp.octave);
+    const uint32_t tx = (uint32_t)max(kp.x / ratio, 0.0f) >> tile_shift, ty = (uint32_t)max(kp.y / ratio, 0.0f) >> tile_shift;
+    const uint32_t sk = (min(kp.class_id, 63u) << 24) | (min(ty, 4095u) << 12) | min(tx, 4095u);
+    return ((unsigned long long)sk << 32) | (unsigned long long)i;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
+                                                   uint32_t stride, uint32_t max_features, int tile_shift,
+                                                   DevKp* __restrict__ out, uint32_t* __restrict__ n_out,
+                                                   uint32_t* __restrict__ perm)
+{
+    __shared__ unsigned long long s_key[1024];
+    const int frame = blockIdx.y;
+    const uint32_t n = min(n_in[frame], stride);
+    if (blockIdx.x * 256u >= n && !(blockIdx.x == 0 && MODE == RANK_RESPONSE)) return;    // whole block
+    const DevKp* src = in + (size_t)frame * stride;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    DevKp me;
+    unsigned long long mine = ~0ull;
+    if (i < n) {
+        me = src[i];
+        mine = rank_key<MODE>(me, i, tile_shift);
+    }
+    uint32_t rank = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < 1024; j += 256)
+            s_key[j] = t0 + j < n ? rank_key<MODE>(src[t0 + j], t0 + j, tile_shift) : ~0ull;
+        __syncthreads();
+        const uint32_t m = min(1024u, n - t0);
+#pragma unroll 8
+        for (uint32_t j = 0; j < m; ++j) rank += s_key[j] < mine ? 1u : 0u;
+    }
+    if (i < n) {
+        if (MODE == RANK_RESPONSE) {
+            if (rank < max_features) out[(size_t)frame * stride + rank] = me;
+        } else {
+            perm[(size_t)frame * stride + rank] = i;
+        }
+    }
+    if (MODE == RANK_RESPONSE && blockIdx.x == 0 && threadIdx.x == 0) n_out[frame] = n < max_features ? n : max_features;
+}
+
+// The same two orders by one block per frame: bitonic networks of 64-bit keys in LDS (lists beyond 16384 keys through
+// the frame's global key scratch, akz_common.h).  A batch of many frames keeps every CU busy with one block per
+// frame, and there the networks cost less than the n^2 comparisons (74 vs 190 us per 64 frames of ~5 000 keypoints):
+// akz_run_keypoints picks by batch size.
 __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
                                                uint32_t stride, uint32_t max_features, DevKp* __restrict__ out,
                                                uint32_t* __restrict__ n_out, unsigned long long* __restrict__ gkeys,
@@ -1310,18 +1376,28 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                        c->d_err);
     AKZ_LAUNCH_CHECK();
     // A15
+    uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
+    const bool rank_sorts = n <= 8;            // few frames: the chip-wide rank sort; many: one bitonic block per frame
+    const dim3 grid_rank((uint32_t)akz_div_up((int)c->max_kp, 256), n);
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
     const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;   // longer lists: global key scratch
-    uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
-    hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, S.d_kp_c, S.d_n_c,
-                       c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys);
+    if (rank_sorts)
+        hipLaunchKernelGGL((k_rank_sort<RANK_RESPONSE>), grid_rank, dim3(256), 0, s, S.d_kp_c, S.d_n_c, c->max_kp, maxf, 0,
+                           S.d_kp_d, S.d_n_d, (uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, S.d_kp_c, S.d_n_c,
+                           c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
     akz_timer_begin(c, AKZ_T_DESCRIBE, s);
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
-        hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
-                           S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
+        if (rank_sorts)
+            hipLaunchKernelGGL((k_rank_sort<RANK_SPATIAL>), grid_rank, dim3(256), 0, s, S.d_kp_d, S.d_n_d, c->max_kp, 0u,
+                               c->desc_tile_shift, (DevKp*)nullptr, (uint32_t*)nullptr, S.d_perm);
+        else
+            hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
+                               S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);

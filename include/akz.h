@@ -109,7 +109,7 @@ typedef struct akz_options {
     uint32_t max_candidates;  /* capacity of each per-(frame, level) extrema candidate list; 0 = max_keypoints */
     uint32_t desc_tile_shift; /* log2 tile edge of the descriptor visiting order, 2..9; 0 = default (5) */
     uint32_t stream_waves;    /* waves a row-streaming launch aims for (sets its row-segment length); 0 = default (8192) */
-    uint32_t stream_min_kpixels; /* launches covering fewer than this many x 1024 pixel-frames take the tile kernels; 0 = default */
+    uint32_t stream_min_waves; /* launches that cannot field this many streaming waves take the tile kernel; 0 = default (2048) */
     uint32_t reserved[8];     /* must be zero */
 } akz_options;
 /* akz_create with explicit options (NULL = defaults = akz_create). */

@@ -1006,9 +1006,14 @@ def test_large_keypoint_lists_and_overflow_report(gpu, oracle):
     ak = akaze.Akaze.dense()
     ak.max_keypoints = 65536
     ctx = akaze.Context(ak, 1280, 960, 1)
-    (kp, d), = ctx.extract_batch([img])
+    (kp, d), = ctx.extract_batch([img])                        # a single frame: the chip-wide rank sorts
     _kp_eq(kp, okp, "dense noise keypoints")
     _eq(d, od, "dense noise descriptors")
+    ctx.close()
+    ctx = akaze.Context(ak, 1280, 960, 9)
+    for j, (kp, d) in enumerate(ctx.extract_batch([img] * 9)):  # a batch: one bitonic block per frame, global key scratch
+        _kp_eq(kp, okp, f"dense noise keypoints, batch frame {j}")
+        _eq(d, od, f"dense noise descriptors, batch frame {j}")
     ctx.close()
     small = akaze.Akaze.dense()
     small.max_keypoints = 16384
