@@ -119,22 +119,32 @@ def test_gaussian_kernel_host_entry(lib):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench_final.json is the JSON line bench.py printed on the MI355X: the driver's keys, the
-    roofline object of the dominant kernel and the bounded CPU baseline must all be there."""
+    """profiles/r02_bench.json is the JSON line bench.py printed on the MI355X: the driver's keys, the roofline object
+    of the run's dominant kernel family (a fraction of the HBM peak, so <= 1), the same for the top four, the parity
+    check against the oracle, the extra BASELINE configs and the bounded CPU baseline must all be there."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r01_bench_final.json")) as f:
+    with open(os.path.join(root, "profiles", "r02_bench.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_top", "cpu_baseline", "parity_checked",
+              "configs_extra"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    for r in [d["roofline"]] + d["roofline_top"]:
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, k
+        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
+        if r["traffic"] is not None:       # counters were taken at this micro-batch; the kernel moves >= its algorithmic bytes
+            assert r["traffic_source"]["micro_batch"] == d["config"]["micro_batch"]
+            assert r["traffic"] >= 0.98 * r["algorithmic_bytes_per_launch"]
+    assert d["roofline"]["kernel"] == d["roofline_top"][0]["kernel"]
+    assert d["roofline_top"][0]["gpu_ms"] >= d["roofline_top"][1]["gpu_ms"]
+    assert d["parity_checked"]["mismatches"] == 0 and d["parity_checked"]["frames"] >= 2
+    for cfg in ("configs[2]", "configs[3]"):
+        assert d["configs_extra"][cfg]["parity"]["mismatches"] == 0 and "roofline" in d["configs_extra"][cfg]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 2000.0          # BASELINE.json's target for one MI355X
