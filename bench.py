@@ -49,7 +49,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
 # Kernel families the library times (include/akz.h AKZ_T_*): name, timer id, algorithmic HBM bytes per unit.  A unit
 # is one pixel of one frame covered by one launch; the bytes are what the kernel must move once given what it fuses
 # (DESIGN.md §5): front-end f32 levels 4 in + 4 Lflow + 8 {Lx,Ly} out; level 0: 1 (u8) in + 4 Lt + 8 {Lx,Ly};
-# determinant: 8 in ({Lx,Ly}), candidates only out; FED: 4 L + 4 c in, 4 L out per LAUNCH (up to 8 steps);
+# determinant: 8 in ({Lx,Ly}), candidates only out; FED: 4 L + 4 c in, 4 L out per LAUNCH (T steps share the pass);
 # contrast: 1 (u8) in per pass.
 KERNEL_FAMILIES = [
     ("k_level_front2<4,2,..,u8> (level 0: u8->f32, blur 1.6, Lt, {Lx,Ly})", 3, 13.0),
@@ -59,7 +59,14 @@ KERNEL_FAMILIES = [
     ("k_det_stream<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
     ("k_det_stream<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
     ("k_det_stream<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),
-    ("k_fed_pair<T> (calculate_step, up to 8 steps per launch)", 13, 12.0),
+    ("k_fed_pair<1> (calculate_step, 1 step per launch)", 14, 12.0),
+    ("k_fed_pair<2> (calculate_step, 2 steps per launch)", 15, 12.0),
+    ("k_fed_pair<3> (calculate_step, 3 steps per launch)", 16, 12.0),
+    ("k_fed_pair<4> (calculate_step, 4 steps per launch)", 17, 12.0),
+    ("k_fed_pair<5> (calculate_step, 5 steps per launch)", 18, 12.0),
+    ("k_fed_pair<6> (calculate_step, 6 steps per launch)", 19, 12.0),
+    ("k_fed_pair<7> (calculate_step, 7 steps per launch)", 20, 12.0),
+    ("k_fed_pair<8> (calculate_step, 8 steps per launch)", 21, 12.0),
     ("k_contrast_pair (contrast factor passes)", 10, 1.0),
 ]
 MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)

@@ -48,6 +48,8 @@ struct AkzLevel {
     float kp_size;              // (esigma*derivative_factor) as f32, scale_space_extrema.rs:63
     std::vector<double> tau;    // fed_tau_steps (f64); each step uses tau as f32 (lib.rs:254)
     bool new_octave;            // octave > previous level's octave (lib.rs:219)
+    float cand_border;          // smax * sigma_size of the border test (scale_space_extrema.rs:97-100)
+    int cand_x_lo, cand_x_hi, cand_y_lo, cand_y_hi;   // candidates may sit at these pixels only (akz_plan.cpp)
     size_t pixels() const { return (size_t)w * (size_t)h; }
 };
 struct AkzPlan {

@@ -100,6 +100,32 @@ void akz_build_plan(const akz_config& cfg, int w, int h, AkzPlan* plan)
         double ttime = plan->levels[i].etime - plan->levels[i - 1].etime;
         plan->levels[i].tau = fed_tau_cycle(ttime / 1.0, 0.25);
     }
+    // The pixels that are interior (scale_space_extrema.rs:50) AND pass the border test (:96-104) as inclusive
+    // integer ranges: the test is monotone in x and in y, so the reference's f32 expressions are evaluated once per
+    // column / row here instead of per candidate on the device (the streaming determinant kernel compares integers).
+    for (auto& L : plan->levels) {
+        const float ratio = ldexpf(1.0f, (int)L.octave);
+        const float sigma_size = roundf(L.kp_size / ratio);          // scale_space_extrema.rs:69-70
+        const float smax = 10.0f * sqrtf(2.0f);                      // :16
+        L.cand_border = smax * sigma_size;
+        auto ok = [&](int p, int extent) {
+            const float f = (float)p;
+            volatile float lo = f - L.cand_border, hi = f + L.cand_border;   // one f32 rounding each, as on the device
+            return !(roundf(lo) - 1.0f < 0.0f) && !(roundf(hi) + 1.0f >= (float)extent);
+        };
+        L.cand_x_lo = L.cand_y_lo = 1 << 30;
+        L.cand_x_hi = L.cand_y_hi = -1;
+        for (int x = 1; x <= L.w - 2; ++x)
+            if (ok(x, L.w)) {
+                if (x < L.cand_x_lo) L.cand_x_lo = x;
+                L.cand_x_hi = x;
+            }
+        for (int y = 1; y <= L.h - 2; ++y)
+            if (ok(y, L.h)) {
+                if (y < L.cand_y_lo) L.cand_y_lo = y;
+                L.cand_y_hi = y;
+            }
+    }
     plan->sum_pixels = 0;
     for (auto& L : plan->levels) {
         plan->sum_pixels += L.pixels();

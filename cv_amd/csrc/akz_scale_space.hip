@@ -1222,32 +1222,10 @@ struct CandParams {
     uint32_t level;
     uint32_t cap;      // per-level capacity of the candidate list
     // the pixels that are interior (:50) AND pass the border test (:96-104), as inclusive integer ranges: the test is
-    // monotone in x and in y, so the host evaluates the reference's f32 expressions once per column / row
+    // monotone in x and in y, so the host evaluates the reference's f32 expressions once per column / row (akz_plan.cpp)
     int x_lo, x_hi, y_lo, y_hi;
 };
 
-// scale_space_extrema.rs:96-104 for one coordinate: round(p - border) - 1 >= 0 and round(p + border) + 1 < extent
-static bool border_ok_1d(int p, float border, int extent)
-{
-    const float f = (float)p;
-    volatile float lo = f - border, hi = f + border;     // one f32 rounding each, as on the device
-    return !(roundf(lo) - 1.0f < 0.0f) && !(roundf(hi) + 1.0f >= (float)extent);
-}
-static void cand_ranges(CandParams* cp, int w, int h)
-{
-    cp->x_lo = cp->y_lo = 1 << 30;
-    cp->x_hi = cp->y_hi = -1;
-    for (int x = 1; x <= w - 2; ++x)
-        if (border_ok_1d(x, cp->border, w)) {
-            if (x < cp->x_lo) cp->x_lo = x;
-            cp->x_hi = x;
-        }
-    for (int y = 1; y <= h - 2; ++y)
-        if (border_ok_1d(y, cp->border, h)) {
-            if (y < cp->y_lo) cp->y_lo = y;
-            cp->y_hi = y;
-        }
-}
 
 template <int SG>  // SG = deriv_sigma (2, 3 or 4); 0 = generic (direct global gathers)
 __global__ __launch_bounds__(256) void k_deriv_second_cand(const float2* __restrict__ Lxy, float* __restrict__ Ldet,
@@ -2050,12 +2028,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         dim3 gridp(akz_div_up(L.w, fed_tile_edge(TT)), akz_div_up(L.h, fed_tile_edge(TT)), (n + 1) / 2);              \
         hipLaunchKernelGGL((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
     } break;
+                    akz_timer_begin(c, AKZ_T_FED_T1 + groups[gi] - 1, s);
                     switch (groups[gi]) {
                         AKZ_FED_CASE(1) AKZ_FED_CASE(2) AKZ_FED_CASE(3) AKZ_FED_CASE(4)
                         AKZ_FED_CASE(5) AKZ_FED_CASE(6) AKZ_FED_CASE(7) AKZ_FED_CASE(8)
                     }
 #undef AKZ_FED_CASE
                     AKZ_LAUNCH_CHECK();
+                    akz_timer_end(c, AKZ_T_FED_T1 + groups[gi] - 1, s, 1, (uint64_t)fs * n);
                     j += groups[gi];
                     src = dstb;
                 }
@@ -2083,16 +2063,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             AKZ_LAUNCH_CHECK();
         }
         {
-            // sigma_size = round(size / ratio) in f32 and smax = 10*sqrt(2) in f32 (scale_space_extrema.rs:16,69-70)
-            const float ratio = ldexpf(1.0f, (int)L.octave);
-            const float sigma_size = roundf(L.kp_size / ratio);
-            const float smax = 10.0f * sqrtf(2.0f);
             CandParams cp;
             cp.thr = (float)c->cfg.detector_threshold;
-            cp.border = smax * sigma_size;
+            cp.border = L.cand_border;
             cp.level = (uint32_t)i;
             cp.cap = c->max_cand;
-            cand_ranges(&cp, L.w, L.h);
+            cp.x_lo = L.cand_x_lo; cp.x_hi = L.cand_x_hi; cp.y_lo = L.cand_y_lo; cp.y_hi = L.cand_y_hi;
             dim3 grid2(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
             float* ldet_out = c->keep_all ? S.Ldet[i] : nullptr;   // refinement reads the candidates' own 3x3 values
 #define AKZ_D2(SGV)                                                                                                  \

@@ -400,7 +400,8 @@ enum {
     AKZ_T_DESCRIBE = 11,  /* M-LDB descriptors (keypoint stream)                               units: frames */
     AKZ_T_REFINE = 12,    /* sub-pixel refinement + orientation (keypoint stream)              units: frames */
     AKZ_T_FED_PASS = 13,  /* = AKZ_T_FED with units = pixel-frames per launch */
-    AKZ_T_COUNT = 14
+    AKZ_T_FED_T1 = 14,    /* k_fed_pair<T> launches by T = 1..8 (ids 14..21), units = pixel-frames per launch */
+    AKZ_T_COUNT = 22
 };
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);

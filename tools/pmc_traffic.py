@@ -27,8 +27,9 @@ def family_key(name):
     m = re.match(r"k_deriv_second_cand2<(\d+),", n)
     if m:
         return f"k_deriv_second_cand2<{m.group(1)},..>"
-    if n.startswith("k_fed_pair<"):
-        return "k_fed_pair<T>"
+    m = re.match(r"k_fed_pair<(\d+)>", n)
+    if m:
+        return f"k_fed_pair<{m.group(1)}>"
     if n.startswith("k_contrast_pair<"):
         return "k_contrast_pair"
     return n
