@@ -99,6 +99,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
+// 1.0f / d for both halves, correctly rounded, for d that is finite and >= 1 (pm_g2's denominator 1 + k (lx^2 + ly^2),
+// nonlinear_diffusion.rs:80): the compiler's IEEE f32 division is v_div_scale x2, v_rcp, a chain of six FMAs,
+// v_div_fmas and v_div_fixup per lane half — 22 scalar instructions for a {frame a, frame b} pair.  In that range
+// the scaling and the fix-up are identities, so the same chain on the raw operands gives the same bits: two v_rcp_f32
+// and six v_pk_fma_f32.  Callers route anything else (NaN, infinity) to the plain division.
+__device__ __forceinline__ v2f rcp_pair_finite(v2f d)
+{
+    const v2f one = splat(1.0f);
+    const v2f r0 = (v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const v2f e0 = __builtin_elementwise_fma(-d, r0, one);
+    const v2f r1 = __builtin_elementwise_fma(e0, r0, r0);
+    const v2f q0 = r1;                                   // numerator 1
+    const v2f e1 = __builtin_elementwise_fma(-d, q0, one);
+    const v2f q1 = __builtin_elementwise_fma(e1, r1, q0);
+    const v2f e2 = __builtin_elementwise_fma(-d, q1, one);
+    return __builtin_elementwise_fma(e2, r1, q1);
+}
+// v_cmp_class_f32: signalling NaN 0x1, quiet NaN 0x2, -infinity 0x4, +infinity 0x200
+__device__ __forceinline__ bool not_finite(float v) { return __builtin_amdgcn_classf(v, 0x207); }
+
 // On-chip tile layout for the two-frame kernels.  A row of C columns (C % 4 == 0) is stored as two planes:
 // plane 0 holds the column pairs {4c, 4c+1}, plane 1 the pairs {4c+2, 4c+3}, each pair being 16 bytes
 // ({col, frame a}, {col, frame b}, {col+1, a}, {col+1, b}).  A thread works on a 4-column strip c and reads
@@ -386,7 +406,19 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const In
                 v2f hy_m = (splat(3.0f) * m[3 + o] + splat(10.0f) * m[4 + o]) + splat(3.0f) * m[5 + o];
                 v2f hy_p = (splat(3.0f) * pz[3 + o] + splat(10.0f) * pz[4 + o]) + splat(3.0f) * pz[5 + o];
                 v2f ly = hy_p - hy_m;
-                res_f[o] = splat(1.0f) / (splat(1.0f) + inverse_k * (lx * lx + ly * ly));
+                res_f[o] = splat(1.0f) + inverse_k * (lx * lx + ly * ly);   // the denominator; inverted below
+            }
+            // a wave whose denominators are all finite (always, unless a frame has no gradient at all: then
+            // inverse_k is infinite and the reference's quotient is NaN) takes the packed reciprocal
+            bool odd = false;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) odd = odd || not_finite(res_f[o].x) || not_finite(res_f[o].y);
+            if (__any(odd)) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) res_f[o] = splat(1.0f) / res_f[o];
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) res_f[o] = rcp_pair_finite(res_f[o]);
             }
         }
         {
