@@ -113,7 +113,7 @@ ABI_SYMBOLS = [
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_best_of_views_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
-    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_arrsac_samples",
+    "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
@@ -192,7 +192,8 @@ def lib():
     L.rs_essential_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
     L.rs_essential_arrsac.argtypes = [vp, vp, vp, u32, vp, C.POINTER(ArrsacParams), vp, C.POINTER(u32), vp, u32, C.POINTER(u32),
                                       C.POINTER(ArrsacStats)]
-    L.rs_arrsac_samples.argtypes = [C.c_uint64, u32, u32, vp]
+    L.rs_p3p_arrsac.argtypes = L.rs_essential_arrsac.argtypes
+    L.rs_arrsac_samples.argtypes = [C.c_uint64, u32, u32, u32, vp]
     L.rs_p3p_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
     L.rs_debug_counts.argtypes = [vp, vp, u32]
     L.akz_timing_enable.argtypes = [vp, i32]

@@ -343,13 +343,14 @@ __host__ __device__ __forceinline__ void rs_draw_sample(unsigned long long seed,
     }
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void k_rs_sample(unsigned long long seed, uint32_t n, uint32_t n_hyp, uint32_t* __restrict__ sample_idx)
 {
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h >= n_hyp) return;
-    uint32_t s[8];
-    rs_draw_sample<8>(seed, h, n, s);
-    for (int i = 0; i < 8; ++i) sample_idx[(size_t)h * 8 + i] = s[i];
+    uint32_t s[K];
+    rs_draw_sample<K>(seed, h, n, s);
+    for (int i = 0; i < K; ++i) sample_idx[(size_t)h * K + i] = s[i];
 }
 
 // alive list initialisation: valid poses in ascending order (one block)
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(1024) void k_rs_alive_init(const uint32_t* __restri
 }
 
 // one wave per (live pose, 64 matches of the block); grid.x covers the worst case, waves beyond the live count exit
+template <bool P3P>   // P3P: ba = bearings [n][3], bb = world points [n][4], WorldToCamera::residual (cv-core/src/pose.rs:194-201)
 __global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict__ ba, const double* __restrict__ bb, uint32_t m_lo,
                                                         uint32_t m_hi, const double* __restrict__ poses,
                                                         const uint32_t* __restrict__ alive, const uint32_t* __restrict__ n_alive,
@@ -396,8 +398,13 @@ __global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict
         bool inl = false;
         if (m < m_hi) {
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
-            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-            inl = rs_residual(pose, a, b) < thresh;
+            if (P3P) {
+                double wp[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
+                inl = akz_w2c_residual(pose, a, wp) < thresh;
+            } else {
+                double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+                inl = rs_residual(pose, a, b) < thresh;
+            }
         }
         cnt += (uint32_t)__popcll(__ballot(inl));
     }
@@ -753,115 +760,149 @@ extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const
     });
 }
 
-// Consensus::model_inliers(&EightPoint::new(), matches) in ARRSAC's shape: breadth-first block scoring with
-// retirement (see the kernels above).  sample_idx == NULL draws the minimal samples on the device.
+// Consensus::model_inliers in ARRSAC's shape: breadth-first block scoring with retirement (see the kernels above), for
+// EightPoint (two bearing sets, 8-match samples) and for LambdaTwist (bearings + world points, 3-match samples).
+// sample_idx == NULL draws the minimal samples on the device.
+template <bool P3P>
+static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uint32_t n, const uint32_t* sample_idx,
+                          const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx,
+                          uint32_t cap, uint32_t* n_inliers, rs_arrsac_stats* stats)
+{
+    constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;   // sample size; doubles per element of the second input
+    if (!c || !in_a || !in_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    if (prm->struct_size != sizeof(rs_arrsac_params)) return AKZ_E_INVALID;
+    const uint32_t n_hyp = prm->n_hypotheses;
+    if (n < K || n_hyp == 0 || prm->block_size == 0) return AKZ_E_INVALID;   // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
+    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+    if ((prm->flags & RS_PRUNE_SPRT) && !(prm->sprt_delta > 0.0 && prm->sprt_delta < 1.0 && prm->sprt_ratio > 1.0))
+        return AKZ_E_INVALID;
+    if (sample_idx)
+        for (size_t i = 0; i < (size_t)n_hyp * K; ++i)
+            if (sample_idx[i] >= n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    double* d_second = P3P ? c->d_w : c->d_b;
+    AKZ_HIP(hipMemcpyAsync(c->d_a, in_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(d_second, in_b, sizeof(double) * BW * (size_t)n, hipMemcpyHostToDevice, s));
+    if (sample_idx) {
+        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * K * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+    } else {
+        hipLaunchKernelGGL((k_rs_sample<(int)K>), dim3((n_hyp + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed, n,
+                           n_hyp, c->d_samples);
+        AKZ_LAUNCH_CHECK();
+    }
+    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+    AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long) * 2, s));
+    if (P3P)
+        hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
+                           c->d_poses, c->d_ok);
+    else
+        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
+                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
+    AKZ_LAUNCH_CHECK();
+    const uint32_t n_pose = n_hyp * 4;
+    hipLaunchKernelGGL(k_rs_alive_init, dim3(1), dim3(1024), 0, s, c->d_ok, n_pose, c->d_alive[0], c->d_nalive);
+    AKZ_LAUNCH_CHECK();
+    // (the cap ranks poses through a 2048-bin histogram of their counts: counts above 2046 share the top bin)
+    int cur = 0;
+    uint32_t blocks = 0;
+    // the live count is known to the host only as an upper bound: n_pose before the cap applies, the cap after
+    uint32_t live_bound = n_pose;
+    const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0;
+    for (uint32_t m_lo = 0; m_lo < n;) {
+        // without pruning there is nothing to decide between blocks: one block = all matches
+        const uint32_t bs = prune ? prm->block_size : n;
+        const uint32_t m_hi = m_lo + bs < n ? m_lo + bs : n;
+        const uint32_t chunks = (m_hi - m_lo + 63) / 64;
+        const uint32_t gy = chunks < 16 ? chunks : 16;
+        hipLaunchKernelGGL((k_rs_score_block<P3P>), dim3((live_bound + 3) / 4, gy), dim3(256), 0, s, c->d_a, d_second, m_lo, m_hi,
+                           c->d_poses, c->d_alive[cur], c->d_nalive + cur, prm->threshold, c->d_counts, c->d_neval);
+        AKZ_LAUNCH_CHECK();
+        ++blocks;
+        m_lo = m_hi;
+        if (prune && m_lo < n) {
+            RsPrune P;
+            P.seen = m_lo;
+            P.n_total = n;
+            P.cap = (prm->max_candidates && blocks >= prm->init_blocks) ? prm->max_candidates : 0u;
+            P.use_sprt = (prm->flags & RS_PRUNE_SPRT) ? 1u : 0u;
+            P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
+            P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
+            P.log_ratio = P.use_sprt ? log(prm->sprt_ratio) : 0.0;
+            hipLaunchKernelGGL(k_rs_prune, dim3(1), dim3(1024), 0, s, P, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
+                               c->d_alive[cur ^ 1], c->d_nalive + (cur ^ 1));
+            AKZ_LAUNCH_CHECK();
+            cur ^= 1;
+            if (P.cap && P.cap < live_bound) live_bound = P.cap;
+        }
+    }
+    hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur, c->d_best);
+    AKZ_LAUNCH_CHECK();
+    if (P3P)
+        hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, prm->threshold,
+                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+    else
+        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, prm->threshold,
+                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+    AKZ_LAUNCH_CHECK();
+    uint32_t best[3] = {0, 0, 0}, ninl = 0;
+    unsigned long long neval = 0;
+    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&neval, c->d_neval, sizeof(neval), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipStreamSynchronize(s));
+    c->last_hyp = n_hyp;
+    if (stats) {
+        stats->poses = n_pose;
+        stats->survivors = best[2];
+        stats->blocks = blocks;
+        stats->reserved = 0;
+        stats->residuals_evaluated = neval;
+        stats->residuals_exhaustive = (uint64_t)n_pose * n;
+    }
+    *best_id = best[0];
+    *n_inliers = ninl;
+    if (best[0] == 0xFFFFFFFFu) {
+        *n_inliers = 0;
+        return AKZ_OK;
+    }
+    uint32_t ncopy = ninl < cap ? ninl : cap;
+    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+}
+
 extern "C" int32_t rs_essential_arrsac(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
                                        const uint32_t* sample_idx, const rs_arrsac_params* prm, double* best_pose,
                                        uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
                                        rs_arrsac_stats* stats)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !bearings_a || !bearings_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
-            return AKZ_E_INVALID;
-        if (prm->struct_size != sizeof(rs_arrsac_params)) return AKZ_E_INVALID;
-        const uint32_t n_hyp = prm->n_hypotheses;
-        if (n < 8 || n_hyp == 0 || prm->block_size == 0) return AKZ_E_INVALID;
-        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
-        if ((prm->flags & RS_PRUNE_SPRT) && !(prm->sprt_delta > 0.0 && prm->sprt_delta < 1.0 && prm->sprt_ratio > 1.0))
-            return AKZ_E_INVALID;
-        if (sample_idx)
-            for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
-                if (sample_idx[i] >= n) return AKZ_E_INVALID;
-        AKZ_HIP(hipSetDevice(c->device));
-        hipStream_t s = c->stream;
-        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-        if (sample_idx) {
-            AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-        } else {
-            hipLaunchKernelGGL(k_rs_sample, dim3((n_hyp + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed, n, n_hyp,
-                               c->d_samples);
-            AKZ_LAUNCH_CHECK();
-        }
-        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-        AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long) * 2, s));
-        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
-                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
-        AKZ_LAUNCH_CHECK();
-        const uint32_t n_pose = n_hyp * 4;
-        hipLaunchKernelGGL(k_rs_alive_init, dim3(1), dim3(1024), 0, s, c->d_ok, n_pose, c->d_alive[0], c->d_nalive);
-        AKZ_LAUNCH_CHECK();
-        // (the cap ranks poses through a 2048-bin histogram of their counts: counts above 2046 share the top bin)
-        int cur = 0;
-        uint32_t blocks = 0;
-        // the live count is known to the host only as an upper bound: n_pose before the cap applies, the cap after
-        uint32_t live_bound = n_pose;
-        const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0;
-        for (uint32_t m_lo = 0; m_lo < n;) {
-            // without pruning there is nothing to decide between blocks: one block = all matches
-            const uint32_t bs = prune ? prm->block_size : n;
-            const uint32_t m_hi = m_lo + bs < n ? m_lo + bs : n;
-            const uint32_t chunks = (m_hi - m_lo + 63) / 64;
-            const uint32_t gy = chunks < 16 ? chunks : 16;
-            hipLaunchKernelGGL(k_rs_score_block, dim3((live_bound + 3) / 4, gy), dim3(256), 0, s, c->d_a, c->d_b, m_lo, m_hi,
-                               c->d_poses, c->d_alive[cur], c->d_nalive + cur, prm->threshold, c->d_counts, c->d_neval);
-            AKZ_LAUNCH_CHECK();
-            ++blocks;
-            m_lo = m_hi;
-            if (prune && m_lo < n) {
-                RsPrune P;
-                P.seen = m_lo;
-                P.n_total = n;
-                P.cap = (prm->max_candidates && blocks >= prm->init_blocks) ? prm->max_candidates : 0u;
-                P.use_sprt = (prm->flags & RS_PRUNE_SPRT) ? 1u : 0u;
-                P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
-                P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
-                P.log_ratio = P.use_sprt ? log(prm->sprt_ratio) : 0.0;
-                hipLaunchKernelGGL(k_rs_prune, dim3(1), dim3(1024), 0, s, P, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
-                                   c->d_alive[cur ^ 1], c->d_nalive + (cur ^ 1));
-                AKZ_LAUNCH_CHECK();
-                cur ^= 1;
-                if (P.cap && P.cap < live_bound) live_bound = P.cap;
-            }
-        }
-        hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur, c->d_best);
-        AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, prm->threshold,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose);
-        AKZ_LAUNCH_CHECK();
-        uint32_t best[3] = {0, 0, 0}, ninl = 0;
-        unsigned long long neval = 0;
-        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(&neval, c->d_neval, sizeof(neval), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipStreamSynchronize(s));
-        c->last_hyp = n_hyp;
-        if (stats) {
-            stats->poses = n_pose;
-            stats->survivors = best[2];
-            stats->blocks = blocks;
-            stats->residuals_evaluated = neval;
-            stats->residuals_exhaustive = (uint64_t)n_pose * n;
-        }
-        *best_id = best[0];
-        *n_inliers = ninl;
-        if (best[0] == 0xFFFFFFFFu) {
-            *n_inliers = 0;
-            return AKZ_OK;
-        }
-        uint32_t ncopy = ninl < cap ? ninl : cap;
-        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+        return arrsac_run<false>(c, bearings_a, bearings_b, n, sample_idx, prm, best_pose, best_id, inlier_idx, cap, n_inliers, stats);
+    });
+}
+
+// the registration path's consensus (cv-sfm/src/lib.rs:1619-1622; vslam-sandbox/src/main.rs:105-111: Arrsac with 16384
+// initialisation hypotheses, 1024 candidates) in the same shape: Lambda Twist hypotheses from 3-match samples
+extern "C" int32_t rs_p3p_arrsac(rs_ctx* c, const double* bearings, const double* world, uint32_t n,
+                                 const uint32_t* sample_idx, const rs_arrsac_params* prm, double* best_pose,
+                                 uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
+                                 rs_arrsac_stats* stats)
+{
+    return akz_guard([&]() -> int32_t {
+        return arrsac_run<true>(c, bearings, world, n, sample_idx, prm, best_pose, best_id, inlier_idx, cap, n_inliers, stats);
     });
 }
 
 // the minimal samples rs_essential_arrsac draws on the device for (seed, n): host restatement for callers and tests
-extern "C" int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t* sample_idx)
+extern "C" int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t sample_size, uint32_t* sample_idx)
 {
     return akz_guard([&]() -> int32_t {
-        if (!sample_idx || n < 8) return AKZ_E_INVALID;
-        for (uint32_t h = 0; h < n_hyp; ++h) rs_draw_sample<8>((unsigned long long)seed, h, n, sample_idx + (size_t)h * 8);
+        if (!sample_idx || (sample_size != 8 && sample_size != 3) || n < sample_size) return AKZ_E_INVALID;
+        for (uint32_t h = 0; h < n_hyp; ++h) {
+            if (sample_size == 8) rs_draw_sample<8>((unsigned long long)seed, h, n, sample_idx + (size_t)h * 8);
+            else rs_draw_sample<3>((unsigned long long)seed, h, n, sample_idx + (size_t)h * 3);
+        }
         return AKZ_OK;
     });
 }

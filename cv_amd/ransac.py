@@ -68,10 +68,11 @@ class EssentialConsensus:
 
     def arrsac_model_inliers(self, bearings_a, bearings_b, threshold, n_hypotheses=8192, seed=0, sample_idx=None,
                              block_size=64, init_blocks=4, max_candidates=1024, bound=True, sprt=True, sprt_delta=0.05,
-                             sprt_ratio=1e3):
+                             sprt_ratio=1e3, p3p=False):
         """Arrsac::new(threshold, Xoshiro256PlusPlus::seed_from_u64(seed)).initialization_hypotheses(n)
         .max_candidate_hypotheses(k).model_inliers(&EightPoint::new(), matches) in this library's shape (include/akz.h:
-        rs_essential_arrsac).  Returns (pose, inliers, best_id, stats dict) or None."""
+        rs_essential_arrsac).  p3p=True: the same for LambdaTwist (bearings_a = bearings [n,3], bearings_b = world
+        points [n,4]; 3-match samples; rs_p3p_arrsac).  Returns (pose, inliers, best_id, stats dict) or None."""
         a = np.ascontiguousarray(bearings_a, np.float64); b = np.ascontiguousarray(bearings_b, np.float64)
         n = len(a)
         prm = _lib.ArrsacParams()
@@ -81,14 +82,15 @@ class EssentialConsensus:
         prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = float(threshold), sprt_delta, sprt_ratio, seed
         si = None
         if sample_idx is not None:
-            si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 8)
+            si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 3 if p3p else 8)
             prm.n_hypotheses = len(si)
         pose = np.empty((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
         inl = np.empty(max(n, 1), np.uint32)
         st = _lib.ArrsacStats()
-        check(_lib.lib().rs_essential_arrsac(self._h, a.ctypes.data, b.ctypes.data, n, si.ctypes.data if si is not None else None,
-                                             C.byref(prm), pose.ctypes.data, C.byref(best), inl.ctypes.data, n, C.byref(ninl),
-                                             C.byref(st)), "rs_essential_arrsac")
+        fn = _lib.lib().rs_p3p_arrsac if p3p else _lib.lib().rs_essential_arrsac
+        check(fn(self._h, a.ctypes.data, b.ctypes.data, n, si.ctypes.data if si is not None else None,
+                 C.byref(prm), pose.ctypes.data, C.byref(best), inl.ctypes.data, n, C.byref(ninl), C.byref(st)),
+              "rs_p3p_arrsac" if p3p else "rs_essential_arrsac")
         if best.value == 0xFFFFFFFF:
             return None
         stats = {"poses": st.poses, "survivors": st.survivors, "blocks": st.blocks,
@@ -96,10 +98,10 @@ class EssentialConsensus:
         return pose, inl[:ninl.value].copy(), best.value, stats
 
     @staticmethod
-    def arrsac_samples(seed, n, n_hypotheses):
-        """The minimal samples rs_essential_arrsac draws on the device for (seed, n)."""
-        out = np.empty((n_hypotheses, 8), np.uint32)
-        check(_lib.lib().rs_arrsac_samples(seed, n, n_hypotheses, out.ctypes.data), "rs_arrsac_samples")
+    def arrsac_samples(seed, n, n_hypotheses, sample_size=8):
+        """The minimal samples rs_essential_arrsac (8) / rs_p3p_arrsac (3) draw on the device for (seed, n)."""
+        out = np.empty((n_hypotheses, sample_size), np.uint32)
+        check(_lib.lib().rs_arrsac_samples(seed, n, n_hypotheses, sample_size, out.ctypes.data), "rs_arrsac_samples")
         return out
 
     def p3p_model_inliers(self, bearings, world, sample_idx, threshold):

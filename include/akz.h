@@ -361,7 +361,15 @@ int32_t rs_essential_arrsac(rs_ctx* ctx, const double* bearings_a, const double*
                             const uint32_t* sample_idx, const rs_arrsac_params* params, double* best_pose,
                             uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
                             rs_arrsac_stats* stats);
-int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t* sample_idx);
+/* The same for Consensus::model_inliers(&LambdaTwist::new(), landmark matches) — the registration path's consensus
+ * (cv-sfm/src/lib.rs:1619-1622; vslam-sandbox/src/main.rs:105-111: 16384 initialisation hypotheses, 1024 candidates):
+ * 3-match samples, WorldToCamera::residual; bearings / world as for rs_p3p_batch. */
+int32_t rs_p3p_arrsac(rs_ctx* ctx, const double* bearings, const double* world, uint32_t n,
+                      const uint32_t* sample_idx, const rs_arrsac_params* params, double* best_pose,
+                      uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
+                      rs_arrsac_stats* stats);
+/* The minimal samples the two functions draw on the device for (seed, n): sample_size 8 (eight-point) or 3 (P3P). */
+int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t sample_size, uint32_t* sample_idx);
 /* Consensus::model_inliers(&LambdaTwist::new(), matches) for 3D-2D registration (cv-sfm/src/lib.rs:1619-1622,
  * lambda-twist/tests/consensus.rs:59-61), sampler factored out as above: n_hyp sample triples; each gives up
  * to four WorldToCamera poses (lambda-twist/src/lib.rs:107-318), scored with WorldToCamera::residual

@@ -1022,3 +1022,32 @@ def test_large_keypoint_lists_and_overflow_report(gpu, oracle):
         ctx.extract_batch([img])
     assert ei.value.status == -7 and "frame 0" in str(ei.value), str(ei.value)
     ctx.close()
+
+
+def test_p3p_arrsac_shaped_consensus(gpu, oracle):
+    """rs_p3p_arrsac: the registration path's consensus (cv-sfm/src/lib.rs:1619-1622) in ARRSAC's shape.  With the
+    exact bound alone the winner, pose bits and inlier set equal the oracle's exhaustive scoring of the same (device
+    drawn) 3-match samples; with cap + SPRT the same winner on this scene at a fraction of the residuals."""
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import _projective, _rot
+    rng = np.random.default_rng(78)
+    n, n_hyp, thr = 1000, 4000, 1e-6
+    Rr = _rot(rng.random(3) * 0.8); tr = rng.random(3)
+    pts = rng.random((n, 3)) * 4.0 - 2.0
+    pts[:, 2] += 6.0
+    cam = pts @ Rr.T + tr
+    bb = cam / np.linalg.norm(cam, axis=1, keepdims=True)
+    bad = rng.random(n) < 0.3
+    rb = rng.standard_normal((n, 3)); rb[:, 2] = np.abs(rb[:, 2]) + 0.5
+    bb[bad] = (rb / np.linalg.norm(rb, axis=1, keepdims=True))[bad]
+    world = _projective(pts)
+    cons = EssentialConsensus(n, 8192)
+    samples = cons.arrsac_samples(3, n, n_hyp, 3)
+    wpose, wbest, winl, _ = oracle.p3p_batch(bb, world, samples, thr)
+    for kw in (dict(max_candidates=0, sprt=False), dict(max_candidates=1024, sprt=True)):
+        pose, inl, best, st = cons.arrsac_model_inliers(bb, world, thr, n_hypotheses=n_hyp, seed=3, p3p=True, **kw)
+        assert best == wbest, (kw, best, wbest)
+        _eq(pose, wpose, "p3p arrsac pose")
+        _eq(inl, winl, "p3p arrsac inliers")
+    assert st["residuals_evaluated"] < 0.35 * st["residuals_exhaustive"], st
+    assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6
