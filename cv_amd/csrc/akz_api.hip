@@ -125,6 +125,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
+            if (o.flags & ~((AKZ_OPT_TILE_KERNELS << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
         }
         {

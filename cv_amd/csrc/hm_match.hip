@@ -659,6 +659,7 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
     return akz_guard([&]() -> int32_t {
         // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
         if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
+        if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY)) return AKZ_E_INVALID;   // unknown switches
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
         AKZ_HIP(hipSetDevice(device));

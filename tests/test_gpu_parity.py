@@ -1051,3 +1051,45 @@ def test_p3p_arrsac_shaped_consensus(gpu, oracle):
         _eq(inl, winl, "p3p arrsac inliers")
     assert st["residuals_evaluated"] < 0.35 * st["residuals_exhaustive"], st
     assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6
+
+
+OPTION_SETS = [
+    ("tile determinant kernels", dict(stream_kernels=False)),
+    ("streaming kernels everywhere", dict(stream_min_waves=1, stream_waves=64)),
+    ("long streaming segments", dict(stream_min_waves=1, stream_waves=1)),
+    ("one-frame kernels", dict(frame_pairs=False)),
+    ("one FED step per launch", dict(fed_block=1)),
+    ("three FED steps per launch", dict(fed_block=3)),
+    ("serial suppression, no pipeline", dict(parallel_suppression=False, pipeline=False)),
+    ("exact contrast, stream priorities", dict(contrast="exact", stream_priority=True)),
+    ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
+]
+
+
+@pytest.mark.parametrize("name,kw", OPTION_SETS, ids=[n for n, _ in OPTION_SETS])
+def test_every_option_gives_the_same_bits(gpu, oracle, name, kw):
+    """akz_options select kernels, never results: a batch of five frames (odd: a half-empty frame pair) at 640x400
+    and a ragged 333x251 one under each option set equal the oracle byte for byte."""
+    akaze, _ = gpu
+    for (w, h, nfr) in ((640, 400, 5), (333, 251, 2)):
+        frames = [synth_frame(w, h, seed=3000 + i, n_rect=40, n_disc=40) for i in range(nfr)]
+        ctx = akaze.Context(akaze.Akaze.default(), w, h, nfr, _opts(**kw))
+        got = ctx.extract_batch(frames)
+        orc = oracle.Akaze(w, h, oracle.default_config())
+        for i, f in enumerate(frames):
+            okp, od = orc.extract(f)
+            _kp_eq(got[i][0], okp, f"{name} {w}x{h} frame {i}")
+            _eq(got[i][1], od, f"{name} {w}x{h} frame {i} desc")
+        ctx.close()
+
+
+def test_unknown_option_bits_are_refused(gpu):
+    import ctypes as C
+    from cv_amd import _lib
+    cfg = _lib.Config()
+    _lib.lib().akz_config_default(C.byref(cfg))
+    o = _lib.make_options()
+    o.flags = 1 << 20
+    h = C.c_void_p()
+    assert _lib.lib().akz_create_ex(C.byref(cfg), 0, 64, 64, 1, 0, C.byref(o), C.byref(h)) == -1
+    assert _lib.lib().hm_create_ex(0, 64, 64, 1 << 20, C.byref(h)) == -1
