@@ -570,7 +570,8 @@ def extra_ransac(n_hyp):
     n, thr = 1000, 1e-7
     a, b = _two_view_scene(rng, n, 0.3)
     samples = np.stack([rng.choice(n, 8, replace=False) for _ in range(n_hyp)]).astype(np.uint32)
-    cons = EssentialConsensus(n, n_hyp)
+    resample = 64                                   # arrsac's estimations_per_block in the full-shape leg
+    cons = EssentialConsensus(n, n_hyp + resample * 16)
     cons.model_inliers(a, b, samples, thr)          # warm-up
     reps = 3
     t0 = time.perf_counter()
@@ -592,8 +593,10 @@ def extra_ransac(n_hyp):
     # the same scene through the ARRSAC-shaped entry point: samples drawn on the device, block scoring with the exact
     # bound, the candidate cap and the SPRT test (vslam-sandbox's parameters); and with the bound alone
     arr = {}
+    full = dict(max_candidates=1024, bound=True, sprt=True, halve=True, estimations_per_block=resample)
     for name, kw in (("bound_cap_sprt", dict(max_candidates=1024, bound=True, sprt=True)),
-                     ("bound_only", dict(max_candidates=0, bound=True, sprt=False))):
+                     ("bound_only", dict(max_candidates=0, bound=True, sprt=False)),
+                     ("halving_cap_sprt_resampling", full)):
         cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, **kw)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -606,9 +609,20 @@ def extra_ransac(n_hyp):
     dsamples = cons.arrsac_samples(0, n, n_hyp)
     epose, einl, ebest = cons.model_inliers(a, b, dsamples, thr)
     bad += int(arr["bound_only"]["best_id"] != ebest or arr["bound_only"]["inliers"] != len(einl))
+    # the full shape against its specification (oracle/arrsac_oracle.c) at a size the CPU finishes in seconds
+    sub_h = min(2048, n_hyp)
+    got = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=sub_h, seed=0, **full)
+    want = O.arrsac(a, b, thr, sub_h, seed=0, **full)
+    spec_bad = int(got[2] != want[2] or got[0].tobytes() != want[0].tobytes() or not np.array_equal(got[1], want[1])
+                   or any(got[3][k] != want[3][k] for k in ("survivors", "blocks", "poses", "residuals_evaluated")))
+    bad += spec_bad
+    arr["spec_parity"] = {"hypotheses": sub_h, "mismatches": spec_bad,
+                          "what": "winner id, pose bits, inlier list, survivors, blocks, poses made and residuals "
+                                  "evaluated of halving_cap_sprt_resampling vs oracle/arrsac_oracle.c"}
     arr["note"] = ("rs_essential_arrsac, minimal samples drawn on the device (xoshiro256++, seed 0); bound_only is "
                    "checked against exhaustive scoring of the same samples; exhaustive_same_samples_best_id "
-                   f"{int(ebest)}, inliers {len(einl)}")
+                   f"{int(ebest)}, inliers {len(einl)}; halving_cap_sprt_resampling: candidate cap 1024 halving per "
+                   f"block, SPRT, {resample} hypotheses re-sampled from the best pose's inliers after every block")
     # f64 work per (pose, match) residual: 4x4 design matrix (~250 flops) + cyclic Jacobi (~6 sweeps x 6 rotations x
     # ~60 flops) ~ 2.4 kflop; a bound on the order of magnitude, the kernel is f64-VALU bound
     flops = 2400.0 * n_hyp * 4 * n

@@ -73,7 +73,8 @@ class ArrsacParams(C.Structure):
     """rs_arrsac_params (include/akz.h)."""
     _fields_ = [("struct_size", C.c_uint32), ("n_hypotheses", C.c_uint32), ("block_size", C.c_uint32),
                 ("init_blocks", C.c_uint32), ("max_candidates", C.c_uint32), ("flags", C.c_uint32),
-                ("threshold", C.c_double), ("sprt_delta", C.c_double), ("sprt_ratio", C.c_double), ("seed", C.c_uint64)]
+                ("threshold", C.c_double), ("sprt_delta", C.c_double), ("sprt_ratio", C.c_double), ("seed", C.c_uint64),
+                ("estimations_per_block", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ArrsacStats(C.Structure):
@@ -81,7 +82,7 @@ class ArrsacStats(C.Structure):
                 ("residuals_evaluated", C.c_uint64), ("residuals_exhaustive", C.c_uint64)]
 
 
-RS_PRUNE_BOUND, RS_PRUNE_SPRT = 1, 2
+RS_PRUNE_BOUND, RS_PRUNE_SPRT, RS_PRUNE_HALVE = 1, 2, 4
 
 
 class OverflowInfo(C.Structure):

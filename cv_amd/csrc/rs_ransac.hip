@@ -14,6 +14,7 @@
 // of include/akz_ransac_math.h, the minimal samples are supplied by the caller, and every hypothesis is
 // scored against every match (parity: oracle == HIP, bit for bit).
 #include <math.h>
+#include <vector>
 
 #include "akz_common.h"
 #include "../../include/akz_ransac_math.h"
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
                                                      uint32_t n, const double* __restrict__ poses,
                                                      const uint32_t* __restrict__ best, double thresh,
                                                      uint32_t* __restrict__ inlier_idx, uint32_t cap,
-                                                     uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose)
+                                                     uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose,
+                                                     unsigned long long* __restrict__ n_eval)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t pid = best[0];
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
         if (threadIdx.x == 0) *n_inliers = 0;
         return;
     }
+    if (threadIdx.x == 0 && n_eval) atomicAdd(n_eval, (unsigned long long)n);
     double pose[12];
     for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
     if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
@@ -383,10 +386,11 @@ template <bool P3P>   // P3P: ba = bearings [n][3], bb = world points [n][4], Wo
 __global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict__ ba, const double* __restrict__ bb, uint32_t m_lo,
                                                         uint32_t m_hi, const double* __restrict__ poses,
                                                         const uint32_t* __restrict__ alive, const uint32_t* __restrict__ n_alive,
-                                                        double thresh, uint32_t* __restrict__ counts,
-                                                        unsigned long long* __restrict__ n_eval)
+                                                        const uint32_t* __restrict__ first, double thresh,
+                                                        uint32_t* __restrict__ counts, unsigned long long* __restrict__ n_eval)
 {
-    const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // `first` (optional): score only the list entries from *first on (the poses a re-sampling round appended)
+    const uint32_t slot = (first ? *first : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= *n_alive) return;
     const uint32_t pid = alive[slot];
     const uint32_t lane = threadIdx.x & 63;
@@ -419,6 +423,7 @@ struct RsPrune {
     uint32_t cap;                 // keep at most this many poses from now on (0 = no cap)
     uint32_t use_sprt;
     double log_delta, log_1m_delta, log_ratio;   // ln(delta), ln(1 - delta), ln(likelihood ratio threshold)
+    const double* log_table;      // ln(k), k = 0 .. n_total, filled by the host's libm (no device transcendental decides)
 };
 
 __global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ alive_in,
@@ -463,9 +468,9 @@ __global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __
     // SPRT constants: eps = best / seen
     double l_in = 0.0, l_out = 0.0;
     if (P.use_sprt && best > 0 && best < P.seen) {
-        const double eps = (double)best / (double)P.seen;
-        l_in = P.log_delta - log(eps);               // per inlier  (negative: evidence for a good model)
-        l_out = P.log_1m_delta - log(1.0 - eps);     // per outlier (positive)
+        // eps = best / seen: ln(eps) = ln(best) - ln(seen), ln(1 - eps) = ln(seen - best) - ln(seen)
+        l_in = P.log_delta - (P.log_table[best] - P.log_table[P.seen]);                  // per inlier  (negative)
+        l_out = P.log_1m_delta - (P.log_table[P.seen - best] - P.log_table[P.seen]);     // per outlier (positive)
     }
     uint32_t base = 0, ties_before = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
@@ -511,6 +516,61 @@ __global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __
         __syncthreads();
     }
     if (threadIdx.x == 0) *n_out = base;
+}
+
+// inlier-guided re-sampling (arrsac's estimations_per_block): E new minimal samples drawn among the inliers (over the
+// matches seen so far, list L of length *nL) of the best pose; disabled (flag 0) when there are fewer than K inliers
+template <int K>
+__global__ __launch_bounds__(256) void k_rs_resample(unsigned long long seed, uint32_t next_h, uint32_t E,
+                                                     const uint32_t* __restrict__ L, const uint32_t* __restrict__ nL,
+                                                     uint32_t* __restrict__ sample_idx, uint32_t* __restrict__ enable)
+{
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = *nL;
+    if (e == 0) *enable = n >= (uint32_t)K ? 1u : 0u;
+    if (e >= E) return;
+    const uint32_t h = next_h + e;
+    uint32_t s[K];
+    if (n >= (uint32_t)K) {
+        rs_draw_sample<K>(seed ^ 0xA5A5A5A55A5A5A5Aull, h, n, s);
+        for (int i = 0; i < K; ++i) s[i] = L[s[i]];
+    } else {
+        for (int i = 0; i < K; ++i) s[i] = (uint32_t)i;    // placeholder: the hypotheses are gated off below
+    }
+    for (int i = 0; i < K; ++i) sample_idx[(size_t)h * K + i] = s[i];
+}
+
+// valid new poses join the live list in (hypothesis, pose) order — their ids exceed every id already in it — with
+// zeroed counters; *first receives the list length before the append
+__global__ __launch_bounds__(1024) void k_rs_alive_append(const uint32_t* __restrict__ ok, uint32_t base_pid, uint32_t n_new,
+                                                          const uint32_t* __restrict__ enable, uint32_t* __restrict__ alive,
+                                                          uint32_t* __restrict__ n_alive, uint32_t* __restrict__ first,
+                                                          uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_wave[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t old = *n_alive, on = *enable;
+    uint32_t base = old;
+    for (uint32_t i0 = 0; i0 < n_new; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool keep = on && i < n_new && ok[base_pid + i] != 0;
+        if (i < n_new) counts[base_pid + i] = 0u;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (keep) alive[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = base_pid + i;
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *first = old;
+        *n_alive = base;
+    }
 }
 
 // argmax of (count, -id) over the survivors (all of them have seen every match)
@@ -584,7 +644,8 @@ __global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__
                                                       uint32_t n, const double* __restrict__ poses,
                                                       const uint32_t* __restrict__ best, double thresh,
                                                       uint32_t* __restrict__ inlier_idx, uint32_t cap,
-                                                      uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose)
+                                                      uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose,
+                                                      unsigned long long* __restrict__ n_eval)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t pid = best[0];
@@ -592,6 +653,7 @@ __global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__
         if (threadIdx.x == 0) *n_inliers = 0;
         return;
     }
+    if (threadIdx.x == 0 && n_eval) atomicAdd(n_eval, (unsigned long long)n);
     double pose[12];
     for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
     if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
@@ -634,6 +696,8 @@ struct rs_ctx {
              *d_ninl = nullptr;
     uint32_t *d_alive[2] = {nullptr, nullptr}, *d_nalive = nullptr;   // ARRSAC: live pose lists (ping-pong) + counts [2]
     unsigned long long* d_neval = nullptr;                             // residuals evaluated
+    double* d_logtab = nullptr;                                        // ln(k), k = 0 .. max_matches (host libm values)
+    uint32_t *d_first = nullptr, *d_enable = nullptr;                  // re-sampling: first appended slot, enable flag
     uint32_t last_hyp = 0;
 };
 
@@ -664,6 +728,16 @@ extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_
         AKZ_HIP(hipMalloc(&c->d_alive[1], sizeof(uint32_t) * 4 * (size_t)max_hyp));
         AKZ_HIP(hipMalloc(&c->d_nalive, sizeof(uint32_t) * 4));
         AKZ_HIP(hipMalloc(&c->d_neval, sizeof(unsigned long long) * 2));
+        AKZ_HIP(hipMalloc(&c->d_first, sizeof(uint32_t) * 2));
+        c->d_enable = c->d_first + 1;
+        {
+            // the SPRT's logarithms come from the host's libm, tabulated once: the retirement decisions then do not
+            // depend on the device's log() (oracle/arrsac_oracle.c builds the same table)
+            std::vector<double> tab((size_t)max_matches + 1);
+            for (uint32_t k = 0; k <= max_matches; ++k) tab[k] = log((double)k);
+            AKZ_HIP(hipMalloc(&c->d_logtab, sizeof(double) * tab.size()));
+            AKZ_HIP(hipMemcpy(c->d_logtab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+        }
         *out = c;
         return AKZ_OK;
     });
@@ -678,6 +752,7 @@ extern "C" int32_t rs_destroy(rs_ctx* c)
         hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
         hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
         hipFree(c->d_alive[0]); hipFree(c->d_alive[1]); hipFree(c->d_nalive); hipFree(c->d_neval);
+        hipFree(c->d_logtab); hipFree(c->d_first);
         if (c->stream) hipStreamDestroy(c->stream);
         delete c;
         return AKZ_OK;
@@ -740,7 +815,7 @@ extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const
         hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
         AKZ_LAUNCH_CHECK();
         uint32_t best[2] = {0, 0}, ninl = 0;
         AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
@@ -773,7 +848,12 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
     if (prm->struct_size != sizeof(rs_arrsac_params)) return AKZ_E_INVALID;
     const uint32_t n_hyp = prm->n_hypotheses;
     if (n < K || n_hyp == 0 || prm->block_size == 0) return AKZ_E_INVALID;   // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
-    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+    if (prm->reserved != 0 || (prm->flags & ~(RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE))) return AKZ_E_INVALID;
+    const uint32_t E = prm->estimations_per_block;
+    // every block but the last may add E hypotheses: they need room in the context's pose arrays
+    const uint64_t n_blocks_max = ((uint64_t)n + prm->block_size - 1) / prm->block_size;
+    if (n > c->max_matches || n_hyp > c->max_hyp || (uint64_t)n_hyp + (uint64_t)E * n_blocks_max > c->max_hyp)
+        return AKZ_E_TOO_LARGE;
     if ((prm->flags & RS_PRUNE_SPRT) && !(prm->sprt_delta > 0.0 && prm->sprt_delta < 1.0 && prm->sprt_ratio > 1.0))
         return AKZ_E_INVALID;
     if (sample_idx)
@@ -808,7 +888,8 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
     uint32_t blocks = 0;
     // the live count is known to the host only as an upper bound: n_pose before the cap applies, the cap after
     uint32_t live_bound = n_pose;
-    const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0;
+    const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0 || E != 0;
+    uint32_t next_h = n_hyp;                                  // first hypothesis slot of the next re-sampling round
     for (uint32_t m_lo = 0; m_lo < n;) {
         // without pruning there is nothing to decide between blocks: one block = all matches
         const uint32_t bs = prune ? prm->block_size : n;
@@ -816,7 +897,8 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
         const uint32_t chunks = (m_hi - m_lo + 63) / 64;
         const uint32_t gy = chunks < 16 ? chunks : 16;
         hipLaunchKernelGGL((k_rs_score_block<P3P>), dim3((live_bound + 3) / 4, gy), dim3(256), 0, s, c->d_a, d_second, m_lo, m_hi,
-                           c->d_poses, c->d_alive[cur], c->d_nalive + cur, prm->threshold, c->d_counts, c->d_neval);
+                           c->d_poses, c->d_alive[cur], c->d_nalive + cur, (const uint32_t*)nullptr, prm->threshold, c->d_counts,
+                           c->d_neval);
         AKZ_LAUNCH_CHECK();
         ++blocks;
         m_lo = m_hi;
@@ -824,7 +906,16 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
             RsPrune P;
             P.seen = m_lo;
             P.n_total = n;
-            P.cap = (prm->max_candidates && blocks >= prm->init_blocks) ? prm->max_candidates : 0u;
+            P.cap = 0u;
+            if (prm->max_candidates && blocks >= prm->init_blocks) {
+                P.cap = prm->max_candidates;
+                if (prm->flags & RS_PRUNE_HALVE) {             // ARRSAC's shrinking candidate set: half per block, never empty
+                    const uint32_t sh = blocks - prm->init_blocks;
+                    P.cap = sh >= 31 ? 0u : P.cap >> sh;
+                    if (P.cap == 0) P.cap = 1;
+                }
+            }
+            P.log_table = c->d_logtab;
             P.use_sprt = (prm->flags & RS_PRUNE_SPRT) ? 1u : 0u;
             P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
             P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
@@ -834,16 +925,50 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
             AKZ_LAUNCH_CHECK();
             cur ^= 1;
             if (P.cap && P.cap < live_bound) live_bound = P.cap;
+            if (E && blocks >= prm->init_blocks) {
+                // inlier-guided re-sampling: list the inliers (matches seen so far) of the best survivor, draw E minimal
+                // samples among them, estimate, and let the valid poses join the live list after catching up on [0, seen)
+                hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
+                                   c->d_best);
+                AKZ_LAUNCH_CHECK();
+                if (P3P)
+                    hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, m_lo, c->d_poses, c->d_best,
+                                       prm->threshold, c->d_inl, m_lo, c->d_ninl, c->d_best_pose, c->d_neval);
+                else
+                    hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, m_lo, c->d_poses, c->d_best,
+                                       prm->threshold, c->d_inl, m_lo, c->d_ninl, c->d_best_pose, c->d_neval);
+                AKZ_LAUNCH_CHECK();
+                hipLaunchKernelGGL((k_rs_resample<(int)K>), dim3((E + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed,
+                                   next_h, E, c->d_inl, c->d_ninl, c->d_samples, c->d_enable);
+                AKZ_LAUNCH_CHECK();
+                if (P3P)
+                    hipLaunchKernelGGL(k_p3p_hypotheses, dim3((E + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w,
+                                       c->d_samples + (size_t)next_h * K, E, c->d_poses + (size_t)next_h * 48, c->d_ok + (size_t)next_h * 4);
+                else
+                    hipLaunchKernelGGL(k_rs_hypotheses, dim3((E + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
+                                       c->d_samples + (size_t)next_h * K, E, c->d_poses + (size_t)next_h * 48, c->d_ok + (size_t)next_h * 4);
+                AKZ_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_rs_alive_append, dim3(1), dim3(1024), 0, s, c->d_ok, next_h * 4, E * 4, c->d_enable,
+                                   c->d_alive[cur], c->d_nalive + cur, c->d_first, c->d_counts);
+                AKZ_LAUNCH_CHECK();
+                const uint32_t cchunks = (m_lo + 63) / 64;
+                hipLaunchKernelGGL((k_rs_score_block<P3P>), dim3(E, cchunks < 16 ? cchunks : 16), dim3(256), 0, s, c->d_a, d_second,
+                                   0u, m_lo, c->d_poses, c->d_alive[cur], c->d_nalive + cur, (const uint32_t*)c->d_first,
+                                   prm->threshold, c->d_counts, c->d_neval);
+                AKZ_LAUNCH_CHECK();
+                next_h += E;
+                live_bound += 4 * E;
+            }
         }
     }
     hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur, c->d_best);
     AKZ_LAUNCH_CHECK();
     if (P3P)
         hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, prm->threshold,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, prm->threshold,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
     AKZ_LAUNCH_CHECK();
     uint32_t best[3] = {0, 0, 0}, ninl = 0;
     unsigned long long neval = 0;
@@ -852,14 +977,14 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
     AKZ_HIP(hipMemcpyAsync(&neval, c->d_neval, sizeof(neval), hipMemcpyDeviceToHost, s));
     AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
     AKZ_HIP(hipStreamSynchronize(s));
-    c->last_hyp = n_hyp;
+    c->last_hyp = next_h;
     if (stats) {
-        stats->poses = n_pose;
+        stats->poses = next_h * 4;
         stats->survivors = best[2];
         stats->blocks = blocks;
         stats->reserved = 0;
         stats->residuals_evaluated = neval;
-        stats->residuals_exhaustive = (uint64_t)n_pose * n;
+        stats->residuals_exhaustive = (uint64_t)next_h * 4 * n;
     }
     *best_id = best[0];
     *n_inliers = ninl;
@@ -951,7 +1076,7 @@ extern "C" int32_t rs_p3p_batch(rs_ctx* c, const double* bearings, const double*
         hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
         AKZ_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, thresh,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose);
+                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
         AKZ_LAUNCH_CHECK();
         uint32_t best[2] = {0, 0}, ninl = 0;
         AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));

@@ -68,17 +68,22 @@ class EssentialConsensus:
 
     def arrsac_model_inliers(self, bearings_a, bearings_b, threshold, n_hypotheses=8192, seed=0, sample_idx=None,
                              block_size=64, init_blocks=4, max_candidates=1024, bound=True, sprt=True, sprt_delta=0.05,
-                             sprt_ratio=1e3, p3p=False):
+                             sprt_ratio=1e3, p3p=False, estimations_per_block=0, halve=False):
         """Arrsac::new(threshold, Xoshiro256PlusPlus::seed_from_u64(seed)).initialization_hypotheses(n)
         .max_candidate_hypotheses(k).model_inliers(&EightPoint::new(), matches) in this library's shape (include/akz.h:
         rs_essential_arrsac).  p3p=True: the same for LambdaTwist (bearings_a = bearings [n,3], bearings_b = world
-        points [n,4]; 3-match samples; rs_p3p_arrsac).  Returns (pose, inliers, best_id, stats dict) or None."""
+        points [n,4]; 3-match samples; rs_p3p_arrsac).  estimations_per_block: hypotheses re-sampled from the best
+        pose's inliers after every block (.estimations_per_block(e)); halve: the candidate cap halves block by block.
+        The context needs room for n_hypotheses + estimations_per_block x ceil(n / block_size) hypotheses.
+        Returns (pose, inliers, best_id, stats dict) or None."""
         a = np.ascontiguousarray(bearings_a, np.float64); b = np.ascontiguousarray(bearings_b, np.float64)
         n = len(a)
         prm = _lib.ArrsacParams()
         prm.struct_size = C.sizeof(_lib.ArrsacParams)
         prm.n_hypotheses, prm.block_size, prm.init_blocks, prm.max_candidates = n_hypotheses, block_size, init_blocks, max_candidates
-        prm.flags = (_lib.RS_PRUNE_BOUND if bound else 0) | (_lib.RS_PRUNE_SPRT if sprt else 0)
+        prm.flags = ((_lib.RS_PRUNE_BOUND if bound else 0) | (_lib.RS_PRUNE_SPRT if sprt else 0)
+                     | (_lib.RS_PRUNE_HALVE if halve else 0))
+        prm.estimations_per_block, prm.reserved = estimations_per_block, 0
         prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = float(threshold), sprt_delta, sprt_ratio, seed
         si = None
         if sample_idx is not None:

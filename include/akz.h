@@ -334,13 +334,15 @@ int32_t rs_essential_batch(rs_ctx* ctx, const double* bearings_a, const double* 
  *                   its count and its inlier set equal exhaustive scoring's — rs_essential_batch on the same samples);
  *   max_candidates  it is not among the max_candidates best once init_blocks blocks have been scored (0 = no cap);
  *   RS_PRUNE_SPRT   Wald's sequential test rejects it: (delta/eps)^c ((1-delta)/(1-eps))^(seen-c) > sprt_ratio with
- *                   eps = best count / seen and delta = sprt_delta, the inlier rate expected of a wrong model.
+ *                   eps = best count / seen and delta = sprt_delta, the inlier rate expected of a wrong model;
+ *   RS_PRUNE_HALVE  the candidate cap halves with every block after init_blocks (ARRSAC's preemption function
+ *                   f(i) = floor(M 2^-floor(i/B))), down to one survivor.
  * sample_idx == NULL draws the n_hypotheses minimal samples on the device from xoshiro256++ streams seeded with
  * `seed` (rs_arrsac_samples reproduces them on the host).  The arrsac crate is not vendored in the reference: the
- * sampler, the retirement rules and their order are this library's (parity unpinned beyond the count pin of
- * akaze/tests/estimate_pose.rs:75); inlier-guided re-sampling (arrsac's estimations_per_block) is not done.
+ * sampler, the retirement rules and their order are this library's, specified by oracle/arrsac_oracle.c and held to
+ * it bit for bit (parity with the crate unpinned beyond the count pin of akaze/tests/estimate_pose.rs:75).
  * best_id / best_pose / inlier_idx as for rs_essential_batch. */
-enum { RS_PRUNE_BOUND = 1u << 0, RS_PRUNE_SPRT = 1u << 1 };
+enum { RS_PRUNE_BOUND = 1u << 0, RS_PRUNE_SPRT = 1u << 1, RS_PRUNE_HALVE = 1u << 2 };
 typedef struct rs_arrsac_params {
     uint32_t struct_size;      /* sizeof(rs_arrsac_params) */
     uint32_t n_hypotheses;     /* initialization_hypotheses */
@@ -352,6 +354,11 @@ typedef struct rs_arrsac_params {
     double sprt_delta;         /* P(inlier | wrong model), e.g. 0.05 */
     double sprt_ratio;         /* likelihood ratio threshold, arrsac default 1e3 */
     uint64_t seed;             /* sampler seed (Xoshiro256PlusPlus::seed_from_u64 at the call sites) */
+    uint32_t estimations_per_block; /* hypotheses generated after every block (from init_blocks on) from minimal samples
+                                  * drawn among the inliers of the best pose so far — arrsac's inlier-guided
+                                  * re-sampling; each is scored on all matches seen so far and joins the candidates;
+                                  * 0 = off.  The context must hold n_hypotheses + this x blocks hypotheses. */
+    uint32_t reserved;         /* must be zero */
 } rs_arrsac_params;
 typedef struct rs_arrsac_stats {
     uint32_t poses, survivors, blocks, reserved;

@@ -50,7 +50,7 @@ BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6,
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "color_oracle.c", "lsh_oracle.c",
+    src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "color_oracle.c", "lsh_oracle.c", "arrsac_oracle.c",
                                         "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
@@ -107,6 +107,9 @@ def lib():
         L.orc_knn2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_sample_colors_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_knn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_arrsac_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_arrsac.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_best_of_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
@@ -461,3 +464,45 @@ def best_of_views(knn_out, nq, landmarks, view_idx, nviews, better_by=24):
     lib().orc_best_of_views(knn_out.ctypes.data, nq, cap, n_views, k, landmarks.ctypes.data, vi.ctypes.data, nv.ctypes.data,
                             better_by, best.ctypes.data, dec.ctypes.data)
     return best, dec
+
+
+class ArrsacParams(C.Structure):
+    """rs_arrsac_params (include/akz.h), restated here so that tests/ can drive the oracle without the product's
+    Python package."""
+    _fields_ = [("struct_size", C.c_uint32), ("n_hypotheses", C.c_uint32), ("block_size", C.c_uint32),
+                ("init_blocks", C.c_uint32), ("max_candidates", C.c_uint32), ("flags", C.c_uint32),
+                ("threshold", C.c_double), ("sprt_delta", C.c_double), ("sprt_ratio", C.c_double), ("seed", C.c_uint64),
+                ("estimations_per_block", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def arrsac_draw(seed, h, n, k):
+    out = np.empty(k, np.uint32)
+    lib().orc_arrsac_draw(seed, h, n, k, out.ctypes.data)
+    return out
+
+
+def arrsac(a, b, threshold, n_hypotheses, seed=0, sample_idx=None, block_size=64, init_blocks=4, max_candidates=1024,
+           bound=True, sprt=True, sprt_delta=0.05, sprt_ratio=1e3, p3p=False, estimations_per_block=0, halve=False):
+    """oracle/arrsac_oracle.c: orc_arrsac — the specification of rs_essential_arrsac / rs_p3p_arrsac.
+    Returns (pose, inliers, best_id, stats dict) or None."""
+    a = _f64(a); b = _f64(b)
+    n = len(a)
+    prm = ArrsacParams()
+    prm.struct_size = C.sizeof(ArrsacParams)
+    prm.n_hypotheses, prm.block_size, prm.init_blocks, prm.max_candidates = n_hypotheses, block_size, init_blocks, max_candidates
+    prm.flags = (1 if bound else 0) | (2 if sprt else 0) | (4 if halve else 0)
+    prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = float(threshold), sprt_delta, sprt_ratio, seed
+    prm.estimations_per_block = estimations_per_block
+    si = None
+    if sample_idx is not None:
+        si = np.ascontiguousarray(sample_idx, np.uint32).reshape(-1, 3 if p3p else 8)
+        prm.n_hypotheses = len(si)
+    pose = np.empty((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
+    inl = np.empty(max(n, 1), np.uint32); st = np.zeros(5, np.uint32)
+    r = lib().orc_arrsac(1 if p3p else 0, a.ctypes.data, b.ctypes.data, n, si.ctypes.data if si is not None else None,
+                         C.byref(prm), pose.ctypes.data, C.byref(best), inl.ctypes.data, C.byref(ninl), st.ctypes.data)
+    if r != 0:
+        return None
+    stats = {"residuals_evaluated": int(st[0]) | (int(st[1]) << 32), "survivors": int(st[2]), "blocks": int(st[3]),
+             "poses": int(st[4]) * 4}
+    return pose, inl[:ninl.value].copy(), best.value, stats

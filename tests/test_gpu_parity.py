@@ -1053,6 +1053,74 @@ def test_p3p_arrsac_shaped_consensus(gpu, oracle):
     assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6
 
 
+ARRSAC_RULES = [
+    ("bound", dict(max_candidates=0, sprt=False)),
+    ("cap", dict(max_candidates=96, sprt=False)),
+    ("cap+sprt", dict(max_candidates=96, sprt=True)),
+    ("cap+sprt+halve", dict(max_candidates=96, sprt=True, halve=True)),
+    ("cap+resample", dict(max_candidates=32, sprt=False, estimations_per_block=16)),
+    ("everything", dict(max_candidates=64, sprt=True, halve=True, estimations_per_block=24, sprt_delta=0.02, sprt_ratio=200.0)),
+    ("resample only", dict(max_candidates=0, sprt=False, bound=False, estimations_per_block=8)),
+]
+
+
+@pytest.mark.parametrize("p3p", [False, True], ids=["eight-point", "p3p"])
+@pytest.mark.parametrize("name,kw", ARRSAC_RULES, ids=[n for n, _ in ARRSAC_RULES])
+def test_arrsac_equals_its_specification(gpu, oracle, name, kw, p3p):
+    """rs_essential_arrsac / rs_p3p_arrsac against oracle/arrsac_oracle.c under every retirement rule and with
+    inlier-guided re-sampling, on a noisy scene (where re-sampling changes the winner): the winner's id, the 12 f64 of
+    its pose, its inlier list, the survivor count, the block count, the number of poses made and the number of
+    residuals evaluated are all equal — i.e. every retirement decision and every re-sampled index was the same."""
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import _projective, _rot
+    rng = np.random.default_rng(0xA22 + int(p3p))
+    n, n_hyp = 700, 300
+    if p3p:
+        Rr = _rot(rng.random(3) * 0.8); tr = rng.random(3)
+        pts = rng.random((n, 3)) * 4.0 - 2.0
+        pts[:, 2] += 6.0
+        cam = pts @ Rr.T + tr
+        a = cam / np.linalg.norm(cam, axis=1, keepdims=True)
+        a = a + rng.standard_normal(a.shape) * 1e-3
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        bad = rng.random(n) < 0.3
+        rb = rng.standard_normal((n, 3)); rb[:, 2] = np.abs(rb[:, 2]) + 0.5
+        a[bad] = (rb / np.linalg.norm(rb, axis=1, keepdims=True))[bad]
+        b = _projective(pts)
+        thr = 2e-3
+    else:
+        a, b = _two_view_scene(rng, n, 0.3)
+        b = b + rng.standard_normal(b.shape) * 2e-3
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        thr = 1e-4
+    cons = EssentialConsensus(n, 1024)
+    for bs, ib in ((64, 2), (100, 1)):
+        want = oracle.arrsac(a, b, thr, n_hyp, seed=9, block_size=bs, init_blocks=ib, p3p=p3p, **kw)
+        got = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=9, block_size=bs, init_blocks=ib, p3p=p3p, **kw)
+        assert (got is None) == (want is None)
+        wpose, winl, wbest, wst = want
+        pose, inl, best, st = got
+        assert best == wbest, (name, bs, best, wbest, st, wst)
+        _eq(pose, wpose, f"arrsac pose ({name})")
+        _eq(inl, winl, f"arrsac inliers ({name})")
+        for key in ("survivors", "blocks", "poses", "residuals_evaluated"):
+            assert st[key] == wst[key], (name, bs, key, st, wst)
+        assert len(inl) > 0.4 * n
+
+
+def test_arrsac_refusals(gpu):
+    """Re-sampling needs room for its hypotheses; reserved fields and unknown flags are refused."""
+    from cv_amd import _lib
+    from cv_amd.ransac import EssentialConsensus
+    rng = np.random.default_rng(5)
+    a, b = _two_view_scene(rng, 256, 0.2)
+    cons = EssentialConsensus(256, 128)
+    with pytest.raises(_lib.AkzError) as e:
+        cons.arrsac_model_inliers(a, b, 1e-6, n_hypotheses=120, block_size=64, estimations_per_block=4)   # 120 + 4 x 4 > 128
+    assert e.value.status == -6                                # AKZ_E_TOO_LARGE
+    assert cons.arrsac_model_inliers(a, b, 1e-6, n_hypotheses=112, block_size=64, estimations_per_block=4) is not None
+
+
 OPTION_SETS = [
     ("tile determinant kernels", dict(stream_kernels=False)),
     ("streaming kernels everywhere", dict(stream_min_waves=1, stream_waves=64)),
