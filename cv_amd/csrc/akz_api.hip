@@ -125,7 +125,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
-            if (o.flags & ~((AKZ_OPT_TILE_KERNELS << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
+            if (o.flags & ~((AKZ_OPT_SERIAL_DET << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
         }
         {
@@ -159,6 +159,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->keep_all = (o.flags & AKZ_OPT_KEEP_ALL) != 0;
         c->front_pair = !(o.flags & AKZ_OPT_NO_FRAME_PAIRS);
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
+        c->det_side_stream = !(o.flags & AKZ_OPT_SERIAL_DET);
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
         if (o.stream_min_waves) c->stream_min_waves = (size_t)o.stream_min_waves;
         c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);
@@ -175,7 +176,12 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
             st = AKZ_E_HIP;
+        if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_det, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess)
+            st = AKZ_E_HIP;
         if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_input, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+        if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_det_done, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
+        for (int l = 0; l < kAkzMaxLevels && st == AKZ_OK; ++l)
+            if (hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
         for (int b = 0; b < 2 && st == AKZ_OK; ++b) {
             if (hipEventCreateWithFlags(&c->ev_ss_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
             if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_kp_done[b], hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
@@ -203,12 +209,19 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
         if (c->stream_kp) hipStreamSynchronize(c->stream_kp);
+        if (c->stream_det) hipStreamSynchronize(c->stream_det);
         for (AkzTimer& t : c->timers) timer_free(&t);
         if (c->arena) hipFree(c->arena);
         if (c->d_color) hipFree(c->d_color);
+        if (c->h_in) hipHostFree(c->h_in);
+        if (c->h_out) hipHostFree(c->h_out);
         if (c->stream) hipStreamDestroy(c->stream);
         if (c->stream_kp) hipStreamDestroy(c->stream_kp);
+        if (c->stream_det) hipStreamDestroy(c->stream_det);
         if (c->ev_input) hipEventDestroy(c->ev_input);
+        if (c->ev_det_done) hipEventDestroy(c->ev_det_done);
+        for (hipEvent_t e : c->ev_level)
+            if (e) hipEventDestroy(e);
         for (int b = 0; b < 2; ++b) {
             if (c->ev_ss_done[b]) hipEventDestroy(c->ev_ss_done[b]);
             if (c->ev_kp_done[b]) hipEventDestroy(c->ev_kp_done[b]);
@@ -268,23 +281,26 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     }
     S.tmp = cv.take<float>(P0 * B);
     S.d_in = cv.take<float>(P0 * B);
+    // everything a call zeroes before the contrast pass is one contiguous block: one memset instead of five
     S.d_cmax = cv.take<unsigned long long>(B);
-    S.d_hist = cv.take<uint32_t>(B * 512);
     S.d_npoints = cv.take<uint32_t>(B);
-    S.d_cthr = cv.take<double>(B * 512);
+    S.d_ncand = cv.take<uint32_t>(B * kAkzMaxLevels);
+    S.d_hist = cv.take<uint32_t>(B * 512);
     S.d_fine = cv.take<uint32_t>(B * 2048);
+    S.zero_bytes = (size_t)((char*)(S.d_fine + B * 2048) - (char*)S.d_cmax);
+    S.d_cthr = cv.take<double>(B * 512);
     S.d_cflag = cv.take<uint32_t>(B);
     S.d_contrast = cv.take<double>(B);
     S.d_invk = cv.take<float>(B * 8);
-    S.d_ncand = cv.take<uint32_t>(B * kAkzMaxLevels);
     S.d_cand = cv.take<uint2>(B * kAkzMaxLevels * (size_t)c->max_cand);
     S.d_cand_u = cv.take<float>(B * kAkzMaxLevels * (size_t)c->max_cand * 10);   // CandU = 40 bytes
     S.d_cand_nb = cv.take<float>(B * kAkzMaxLevels * (size_t)c->max_cand * 8);
     const size_t K = c->max_kp;
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);
-    S.d_sup = cv.take<uint32_t>(B * (size_t)c->sup_cap * (2 * 24 + 6));
-    S.d_sup_flag = cv.take<uint32_t>(B);
+    S.d_lvl_slot = cv.take<uint32_t>((size_t)B * (kAkzMaxLevels + 1));
+    S.d_sup_flag = cv.take<uint32_t>(B);   // directly before d_sup: flags and the reverse-list counters clear in one memset
+    S.d_sup = cv.take<uint32_t>(sup_scratch_words(c->sup_cap, (uint32_t)B));
     S.d_kp_a = cv.take<DevKp>(B * K);
     S.d_n_a = cv.take<uint32_t>(B);
     S.d_kp_b = cv.take<DevKp>(B * K);
@@ -357,6 +373,22 @@ static int32_t check_device_err(akz_ctx* c)
         AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
         return AKZ_E_INTERNAL;
     }
+    return AKZ_OK;
+}
+
+// pinned, device-visible host block of at least `bytes` (grown on demand, never shrunk)
+constexpr size_t kAkzHostStageMax = (size_t)96 << 20;
+static int32_t host_block(void** p, size_t* have, size_t bytes)
+{
+    if (*p && *have >= bytes) return AKZ_OK;
+    if (*p) {
+        AKZ_HIP(hipHostFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    AKZ_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+    *have = want;
     return AKZ_OK;
 }
 
@@ -451,20 +483,68 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
         AKZ_TRY(begin_call(c));
         const size_t esz = fmt == AKZ_FMT_U8 ? 1 : (fmt == AKZ_FMT_U16 ? 2 : 4);
         const size_t P0 = (size_t)w * h;
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n; ++i)
             if (!imgs[i]) return AKZ_E_INVALID;
-            AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
-                                     (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
+        // ---- input: rows gathered into the pinned block, one DMA ----
+        const size_t in_bytes = (size_t)n * P0 * esz;
+        const bool stage_in = in_bytes <= kAkzHostStageMax;
+        if (stage_in) {
+            AKZ_TRY(host_block(&c->h_in, &c->h_in_bytes, in_bytes));
+            for (int i = 0; i < n; ++i) {
+                char* dst = (char*)c->h_in + (size_t)i * P0 * esz;
+                const char* src = (const char*)imgs[i];
+                if (stride == w) memcpy(dst, src, P0 * esz);
+                else
+                    for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * w * esz, src + (size_t)y * stride * esz, (size_t)w * esz);
+            }
+            AKZ_HIP(hipMemcpyAsync(c->S().d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            for (int i = 0; i < n; ++i)
+                AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
+                                         (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
         }
         c->cur_n = n;
+        // ---- outputs: the last kernel writes them where the host can read them ----
+        const size_t K = c->max_kp;
+        const size_t head = 64 + (((size_t)n * sizeof(uint32_t) + 63) & ~(size_t)63);
+        const size_t out_bytes = head + (size_t)n * K * (sizeof(DevKp) + sizeof(akz_descriptor));
+        const bool stage_out = out_bytes <= kAkzHostStageMax;
         akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
+        int32_t status = AKZ_OK;
+        if (stage_out) {
+            AKZ_TRY(host_block(&c->h_out, &c->h_out_bytes, out_bytes));
+            uint32_t* h_err = (uint32_t*)c->h_out;
+            uint32_t* h_n = (uint32_t*)((char*)c->h_out + 64);
+            DevKp* h_kp = (DevKp*)((char*)c->h_out + head);
+            akz_descriptor* h_desc = (akz_descriptor*)((char*)c->h_out + head + (size_t)n * K * sizeof(DevKp));
+            AKZ_TRY(akz_run_keypoints(c, n, h_kp, h_desc, c->max_kp, h_n, h_err));
+            akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
+            // the keypoint stream waited for the scale-space stream: its end is the end of the call
+            AKZ_HIP(hipStreamSynchronize(c->stream_kp));
+            c->kp_pending[c->cur] = false;
+            if (*h_err & ~4u) {
+                AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+                return AKZ_E_INTERNAL;
+            }
+            for (int i = 0; i < n; ++i) {
+                const uint32_t cnt = h_n[i];
+                n_out[i] = cnt;
+                if (cnt > c->max_kp) return AKZ_E_INTERNAL;
+                if (cnt > cap_per_img) status = AKZ_E_CAPACITY;
+                const uint32_t m = cnt < cap_per_img ? cnt : cap_per_img;
+                if (m) {
+                    memcpy(kps + (size_t)i * cap_per_img, h_kp + (size_t)i * K, sizeof(akz_keypoint) * m);
+                    memcpy(descs + (size_t)i * cap_per_img, h_desc + (size_t)i * K, sizeof(akz_descriptor) * m);
+                }
+            }
+            return status;
+        }
         AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
         akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
         std::vector<uint32_t> cnt(n);
         AKZ_TRY(check_device_err(c));  // synchronises both streams
         AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-        int32_t status = AKZ_OK;
         for (int i = 0; i < n; ++i) {
             n_out[i] = cnt[i];
             if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;

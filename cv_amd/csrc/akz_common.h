@@ -36,6 +36,19 @@ constexpr uint32_t kAkzMaxKeypoints = 65536u;
 // Keys a per-frame / per-level sort keeps in LDS (128 KB of the CU's 160 KB); longer lists sort through global memory.
 constexpr uint32_t kAkzLdsSortKeys = 16384u;
 // Longest Gaussian kernel of the generic blur path (base_scale_offset up to 255.5)
+// scratch of the parallel suppression (akz_keypoints.hip: SupFrame), in 32-bit words
+constexpr int kAkzSupDeg = 24;         // neighbours kept per candidate (each direction)
+// chunk flags per frame (even, so that the uint2 array behind stays 8-byte aligned)
+__host__ __device__ __forceinline__ uint32_t sup_done_words(uint32_t cap) { return ((cap + 1023u) / 1024u + 2u) & ~1u; }
+// words of scratch per call of `nframes` frames; the first sup_zero_words() of them must be zero when k_sup_adj starts
+__host__ __device__ __forceinline__ size_t sup_scratch_words(uint32_t cap, uint32_t nframes)
+{
+    return (size_t)nframes * (sup_done_words(cap) + (size_t)cap * (7 + 2 * kAkzSupDeg));
+}
+__host__ __device__ __forceinline__ size_t sup_zero_words(uint32_t cap, uint32_t nframes)
+{
+    return (size_t)nframes * (sup_done_words(cap) + 2 * (size_t)cap);
+}
 constexpr int kAkzMaxTaps = 1023;
 
 // ---- host-side plan: what Akaze::allocate_evolutions computes (akaze/src/evolution.rs:80-126) ---

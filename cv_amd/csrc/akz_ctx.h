@@ -38,6 +38,8 @@ struct AkzSet {
     uint2* d_cand = nullptr;               // [B][32][max_cand] {x | y << 16, response bits}, raster-sorted per level
     DevKp* d_cache = nullptr;              // [B][max_kp]  suppression cache (scale_space_extrema.rs:15)
     uint32_t* d_ncache = nullptr;          // [B]
+    size_t zero_bytes = 0;                 // d_cmax .. end of d_fine: cleared by one memset at the start of a call
+    uint32_t* d_lvl_slot = nullptr;        // [B][kAkzMaxLevels + 1] first cache slot pushed at every level (+ the total)
     uint32_t* d_sup = nullptr;             // [B][sup_cap * (2 * 24 + 6)] scratch of the parallel suppression (k_sup_*)
     uint32_t* d_sup_flag = nullptr;        // [B] 1 = this frame takes the serial k_suppress
     DevKp* d_kp_a = nullptr;               // [B][max_kp]  stage-0 list (find_scale_space_extrema output)
@@ -89,6 +91,13 @@ struct akz_ctx {
     int cur = 0;               // set used by the most recent call
     uint64_t calls = 0;
     hipStream_t stream_kp = nullptr;
+    // The determinant / candidate kernel of a level reads only that level's {Lx, Ly}: it is a side branch of the
+    // Lt -> front -> FED -> Lt chain.  On its own stream it leaves that chain (a third of a single frame's launches)
+    // and joins again before the candidate sort.
+    hipStream_t stream_det = nullptr;
+    bool det_side_stream = true;        // AKZ_OPT_SERIAL_DET clears it
+    hipEvent_t ev_level[kAkzMaxLevels] = {};   // {Lx, Ly} of level l written (recorded on `stream`)
+    hipEvent_t ev_det_done = nullptr;          // every determinant kernel of the call finished (recorded on `stream_det`)
     bool sup_parallel = true;           // AKZ_SUP_PARALLEL=0: serial suppression only
     uint32_t sup_cap = 0;               // candidates per frame the parallel suppression is sized for
     void* d_color = nullptr;            // scratch of akz_sample_colors_rgb8 (image + keypoints + colours), grown on demand
@@ -98,6 +107,14 @@ struct akz_ctx {
     bool kp_pending[2] = {false, false};
     hipEvent_t ev_input = nullptr;                  // orders the caller's producer stream before our scale-space stream
     AkzSet& S() { return sets[cur]; }
+    // Host calls (akz_extract_batch & co): pinned, device-visible staging.  The input rows are gathered into h_in and
+    // go up as one DMA; the final compaction kernel writes keypoints, descriptors, counts and the overflow flag
+    // straight into h_out, so a call ends with ONE stream synchronisation instead of four blocking copies.  Used
+    // while the block stays below kAkzHostStageMax bytes; larger batches take the plain copies.
+    void* h_in = nullptr;
+    size_t h_in_bytes = 0;
+    void* h_out = nullptr;
+    size_t h_out_bytes = 0;
     uint32_t* d_err = nullptr;             // [1] sticky device-side overflow flag
     void* d_ori = nullptr;                 // OriTables (orientation sample/window tables)
     void* d_desc = nullptr;                // DescTables (M-LDB cell + comparison tables)
@@ -114,8 +131,9 @@ int32_t akz_ctx_prepare(akz_ctx* c, int w, int h);
 
 // Stage launchers (enqueue on c->stream).
 int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n);
+// h_err_copy (optional, host-visible): receives the sticky overflow flag together with the outputs
 int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
-                          uint32_t* d_n_out);
+                          uint32_t* d_n_out, uint32_t* h_err_copy = nullptr);
 
 // stand-alone image ops on device buffers (used by akz_horizontal_filter & co)
 int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel,

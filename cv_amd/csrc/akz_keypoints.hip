@@ -88,7 +88,8 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
                                                  const uint2* __restrict__ cand, uint32_t max_cand,
                                                  DevKp* __restrict__ cache, uint32_t max_kp,
                                                  uint32_t* __restrict__ ncache, uint32_t* __restrict__ err,
-                                                 const uint32_t* __restrict__ only_flagged)
+                                                 const uint32_t* __restrict__ only_flagged,
+                                                 uint32_t* __restrict__ lvl_slot)
 {
     if (only_flagged && !only_flagged[blockIdx.x]) return;   // the parallel path (k_sup_*) did this frame
     // LDS: the active list only.  A single wave executes its DS instructions in order, so a ds_write by
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
     float bmin0 = 3.0e38f, bmax0 = -3.0e38f, bmin1 = 3.0e38f, bmax1 = -3.0e38f;
     for (int e = 0; e < T.n; ++e) {
         const LevelDesc& L = T.L[e];
+        if (lane == 0) lvl_slot[(size_t)frame * (kMaxLevels + 1) + e] = nslots;   // first slot pushed at level e
         // ---- level change: keep only class e-1 entries (class e-2 can no longer match), in order ----
         {
             uint32_t kept = 0;
@@ -228,108 +230,112 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
             }
         }
     }
-    if (lane == 0) ncache[frame] = nslots;
+    if (lane == 0) {
+        ncache[frame] = nslots;
+        lvl_slot[(size_t)frame * (kMaxLevels + 1) + T.n] = nslots;
+    }
 }
 
 // second pass (scale_space_extrema.rs:121-140): drop i if a LATER cache entry of class i+1 lies within
-// size_i and has response >= response_i.  Thread per entry i.  Entries of one class sit (apart from
-// slots replaced in place) in one contiguous run of the cache, so every block first finds, per class,
-// the [first, last] slot holding that class and thread i only walks max(i+1, first[c+1]) .. last[c+1]:
-// about two levels' worth of slots instead of the whole tail.  Neighbouring threads walk nearly the
-// same range, so their loads coalesce into broadcasts.
+// size_i and has response >= response_i.  Thread per entry i.
+// Where such an entry can sit: a slot pushed by a level-e candidate starts with class e and is only ever
+// replaced by candidates of higher levels, so an entry of class c+1 lives in a slot pushed at level <= c+1, i.e.
+// before lvl_slot[c+2] (the first-pass kernels record the first slot of every level).  Entry i therefore walks
+// (i, lvl_slot[c+2]) only.  Slots are close to raster order, so the walk is pruned by the y range of every
+// 64-slot chunk (exact: a chunk is skipped only when no entry of it can be within size_i): the block tabulates the
+// ranges of the chunks its entries can need, then every wave loads the chunks that survive the test for at least
+// one of its lanes and broadcasts their entries lane by lane.  No barrier inside the walk.
 __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ cache, uint32_t max_kp,
                                                       const uint32_t* __restrict__ ncache,
+                                                      const uint32_t* __restrict__ lvl_slot, int nlev,
                                                       uint32_t* __restrict__ flag)
 {
-    __shared__ uint32_t s_lo[kMaxLevels + 1], s_hi[kMaxLevels + 1];
-    __shared__ float4 s_j[256];  // x, y, response, class bits of a tile of later entries
+    __shared__ uint32_t s_P[kMaxLevels + 2];
+    __shared__ float2 s_yr[kAkzMaxKeypoints / 64];   // {ymin, ymax} of chunk (rb / 64 + k)
     __shared__ uint32_t s_range[2];
-    __shared__ float s_ylo[4], s_yhi[4];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
     const uint32_t i0 = blockIdx.x * 256;
     if (i0 >= n) return;
     const DevKp* ch = cache + (size_t)frame * max_kp;
-    if (threadIdx.x <= kMaxLevels) {
-        s_lo[threadIdx.x] = 0xFFFFFFFFu;
-        s_hi[threadIdx.x] = 0u;
-    }
-    if (threadIdx.x == 0) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if ((int)tid <= nlev) s_P[tid] = min(lvl_slot[(size_t)frame * (kMaxLevels + 1) + tid], n);
+    if (tid == 0) {
         s_range[0] = 0xFFFFFFFFu;
         s_range[1] = 0u;
     }
     __syncthreads();
-    for (uint32_t j = i0 + threadIdx.x; j < n; j += 256) {  // only slots > i0 matter to this block
-        uint32_t c = min(ch[j].class_id, (uint32_t)kMaxLevels);
-        atomicMin(&s_lo[c], j);
-        atomicMax(&s_hi[c], j);
-    }
-    __syncthreads();
-    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t i = i0 + tid;
     const bool valid = i < n;
     DevKp ki;
     ki.x = ki.y = ki.response = ki.size = 0.0f;
     ki.class_id = kMaxLevels;
-    uint32_t jb = 1, je = 0;  // empty
-    if (valid) {
-        ki = ch[i];
-        const uint32_t cn = min(ki.class_id + 1u, (uint32_t)kMaxLevels);
-        if (s_lo[cn] != 0xFFFFFFFFu) {
-            jb = max(i + 1u, s_lo[cn]);
-            je = s_hi[cn];
-        }
-        if (jb <= je) {  // the union of the threads' ranges is what the block streams through LDS
-            atomicMin(&s_range[0], jb);
-            atomicMax(&s_range[1], je);
-        }
+    if (valid) ki = ch[i];
+    const uint32_t want = ki.class_id + 1u;
+    uint32_t jb = i + 1u, je = 0u;                            // [jb, je)
+    if (valid && (int)want < nlev) je = s_P[min(want + 1u, (uint32_t)nlev)];
+    const bool has = jb < je;
+    uint32_t lo = has ? jb : 0xFFFFFFFFu, hi = has ? je : 0u;   // becomes the wave's union
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
     }
+    if (lane == 0 && lo < hi) {
+        atomicMin(&s_range[0], lo);
+        atomicMax(&s_range[1], hi);
+    }
+    jb = has ? jb : 0xFFFFFFFFu;
+    je = has ? je : 0u;
     __syncthreads();
     const bool any_range = s_range[0] != 0xFFFFFFFFu;
-    const uint32_t rb = s_range[0] & ~63u, re = s_range[1];   // tiles start on a 64-slot boundary (chunk bounds)
     bool rep = false;
-    const float size2 = ki.size * ki.size;
-    const float margin = ki.size * 1.001f + 0.01f;           // conservative: |dy| > margin  =>  dist > size^2
-    const uint32_t want = ki.class_id + 1u;
     if (any_range) {
-        for (uint32_t t0 = rb; t0 <= re; t0 += 256) {
-            uint32_t j = t0 + threadIdx.x;
+        const uint32_t cb0 = s_range[0] >> 6, cb1 = (s_range[1] + 63u) >> 6;   // chunks [cb0, cb1)
+        for (uint32_t ck = cb0 + wv; ck < cb1; ck += 4) {
+            const uint32_t j = ck * 64u + lane;
             float ylo = 3.0e38f, yhi = -3.0e38f;
-            if (j <= re) {
-                const DevKp kj = ch[j];
-                s_j[threadIdx.x] = make_float4(kj.x, kj.y, kj.response, __uint_as_float(kj.class_id));
-                ylo = yhi = kj.y;
-            }
-            // y range of each 64-entry chunk: slots of a class are close to raster order, so most chunks lie
-            // entirely outside [y - size, y + size] of a given keypoint and are skipped without a distance test
+            if (j < n) ylo = yhi = ch[j].y;
             for (int off = 32; off > 0; off >>= 1) {
                 ylo = fminf(ylo, __shfl_xor(ylo, off));
                 yhi = fmaxf(yhi, __shfl_xor(yhi, off));
             }
-            if ((threadIdx.x & 63) == 0) {
-                s_ylo[threadIdx.x >> 6] = ylo;
-                s_yhi[threadIdx.x >> 6] = yhi;
-            }
-            __syncthreads();
-            if (!rep && jb <= je) {
-                const uint32_t lo = max(jb, t0), hi = min(je, min(re, t0 + 255u));
-                for (uint32_t cb = lo & ~63u; cb <= hi && lo <= hi && !rep; cb += 64u) {
-                    const uint32_t ck = (cb - t0) >> 6;    // t0 is a multiple of 64 past rb's chunk: see below
-                    if (ki.y + margin < s_ylo[ck] || ki.y - margin > s_yhi[ck]) continue;
-                    const uint32_t a = max(lo, cb), b = min(hi, cb + 63u);
-                    for (uint32_t jj = a; jj <= b; ++jj) {
-                        const float4 q = s_j[jj - t0];
-                        if (__float_as_uint(q.w) == want) {
-                            float dx = ki.x - q.x, dy = ki.y - q.y;
-                            float dist = dx * dx + dy * dy;
-                            if (dist <= size2 && ki.response <= q.z) {
-                                rep = true;
-                                break;
-                            }
-                        }
+            if (lane == 0) s_yr[ck - cb0] = make_float2(ylo, yhi);
+        }
+        __syncthreads();
+        const float size2 = ki.size * ki.size;
+        const float margin = ki.size * 1.001f + 0.01f;       // conservative: |dy| > margin  =>  dist > size^2
+        if (lo < hi) {                                        // wave-uniform: some lane of this wave has a range
+            for (uint32_t ck = lo >> 6; ck < ((hi + 63u) >> 6); ++ck) {
+                const float2 yr = s_yr[ck - cb0];
+                const uint32_t c_lo = ck * 64u, c_hi = c_lo + 64u;
+                const bool need = !rep && jb < c_hi && je > c_lo && ki.y + margin >= yr.x && ki.y - margin <= yr.y;
+                if (!__any(need)) continue;
+                const uint32_t j = c_lo + lane;
+                float ex = 0.f, ey = 0.f, er = 0.f;
+                uint32_t ec = 0xFFFFFFFFu;
+                if (j < n) {
+                    const DevKp kj = ch[j];
+                    ex = kj.x; ey = kj.y; er = kj.response; ec = kj.class_id;
+                }
+                // entries whose class some needing lane of the wave wants
+                uint32_t wmin = need ? want : 0xFFFFFFFFu, wmax = need ? want : 0u;
+                for (int off = 32; off > 0; off >>= 1) {
+                    wmin = min(wmin, (uint32_t)__shfl_xor((int)wmin, off));
+                    wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
+                }
+                unsigned long long m = __ballot(ec >= wmin && ec <= wmax);
+                while (m) {
+                    const uint32_t t = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1ull;
+                    const float qx = rl_f(ex, t), qy = rl_f(ey, t), qr = rl_f(er, t);
+                    const uint32_t qc = rl_u(ec, t), jj = c_lo + t;
+                    if (need && jj >= jb && jj < je && qc == want) {
+                        const float dx = ki.x - qx, dy = ki.y - qy;
+                        const float dist = dx * dx + dy * dy;
+                        if (dist <= size2 && ki.response <= qr) rep = true;
                     }
                 }
             }
-            __syncthreads();
         }
     }
     if (valid) flag[(size_t)frame * max_kp + i] = rep ? 0u : 1u;
@@ -341,10 +347,14 @@ __global__ __launch_bounds__(1024) void k_compact(const DevKp* __restrict__ in, 
                                                   const uint32_t* __restrict__ flag, const uint32_t* __restrict__ n_in,
                                                   uint32_t in_stride, DevKp* __restrict__ out,
                                                   akz_descriptor* __restrict__ dout, uint32_t out_stride,
-                                                  uint32_t* __restrict__ n_out, uint32_t* __restrict__ err)
+                                                  uint32_t* __restrict__ n_out, uint32_t* __restrict__ err,
+                                                  const uint32_t* __restrict__ err_src, uint32_t* __restrict__ err_dst)
 {
     __shared__ uint32_t s_wave[16];
     const int frame = blockIdx.x;
+    // the host calls read the sticky overflow flag from the same (host-visible) block as the outputs: every kernel
+    // that can raise it has completed before this one starts
+    if (err_dst && blockIdx.x == 0 && threadIdx.x == 0) *err_dst = *err_src;
     const uint32_t n = min(n_in[frame], in_stride);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t base = 0;
@@ -434,32 +444,38 @@ __device__ __forceinline__ float fast_atan2_equiv(float y, float x)
 //     data of its final occupant.
 // Frames whose lists overflow the fixed capacities (kSupDeg neighbours, kSupCap candidates) are flagged and
 // go through k_suppress instead, so the result is the same in every case.
-constexpr int kSupDeg = 24;            // neighbours kept per candidate (each direction)
+constexpr int kSupDeg = kAkzSupDeg;    // neighbours kept per candidate (each direction)
 constexpr uint32_t kSupNone = 0xFFFFFFFFu;
 
 struct SupFrame {                      // per-frame views of the scratch arrays
-    uint32_t* adj;    // [cap][kSupDeg]
-    uint32_t* nadj;   // [cap]
-    uint32_t* radj;   // [cap][kSupDeg]
+    uint32_t* done;   // [kd] chunk k resolved: pushes up to and including it, + 1 (chunk-parallel mode)
     uint32_t* nradj;  // [cap]
+    uint32_t* repl;   // [cap] a later candidate replaced this one in its slot
     uint2* state;     // [cap] {slot, target}
+    uint32_t* nadj;   // [cap]
     float* resp;      // [cap]
     uint32_t* rank;   // [cap] exclusive count of pushes before the candidate
+    uint32_t* adj;    // [cap][kSupDeg]
+    uint32_t* radj;   // [cap][kSupDeg]
 };
 
 __device__ __forceinline__ SupFrame sup_frame(uint32_t* base, uint32_t cap, int frame, uint32_t nframes)
 {
-    // array-major layout over the whole batch: nradj[B][cap] first (one memset clears the counters), then
-    // nadj, state(2), resp, rank, adj, radj
+    // array-major layout over the frames of the call (akz_common.h: sup_scratch_words): done[n][kd], nradj[n][cap],
+    // repl[n][cap] first (one memset clears them), then state(2), nadj, resp, rank, adj, radj
+    const size_t kd = sup_done_words(cap);
     const size_t fc = (size_t)frame * cap, bc = (size_t)nframes * cap;
+    uint32_t* p = base + (size_t)nframes * kd;
     SupFrame f;
-    f.nradj = base + fc;
-    f.nadj = base + bc + fc;
-    f.state = reinterpret_cast<uint2*>(base + 2 * bc) + fc;
-    f.resp = reinterpret_cast<float*>(base + 4 * bc) + fc;
-    f.rank = base + 5 * bc + fc;
-    f.adj = base + 6 * bc + fc * kSupDeg;
-    f.radj = base + (6 + (size_t)kSupDeg) * bc + fc * kSupDeg;
+    f.done = base + (size_t)frame * kd;
+    f.nradj = p + fc;
+    f.repl = p + bc + fc;
+    f.state = reinterpret_cast<uint2*>(p + 2 * bc) + fc;
+    f.nadj = p + 4 * bc + fc;
+    f.resp = reinterpret_cast<float*>(p + 5 * bc) + fc;
+    f.rank = p + 6 * bc + fc;
+    f.adj = p + 7 * bc + fc * kSupDeg;
+    f.radj = p + (7 + (size_t)kSupDeg) * bc + fc * kSupDeg;
     return f;
 }
 
@@ -541,16 +557,22 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
     if (over) fallback[frame] = 1u;
 }
 
+// CHUNK_PARALLEL: one workgroup per (chunk, frame) — blockIdx.x = chunk — chained through the frame's done[] flags
+// (a workgroup only ever waits for the chunk before it, which was dispatched before it); otherwise one workgroup per
+// frame walks the chunks itself.  Few frames take the first form (the chunks' list fetches overlap and only the part
+// that needs the earlier records is serial), a batch the second (every CU has a frame of its own).
+template <bool CHUNK_PARALLEL>
 __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32_t* __restrict__ ncand,
                                                       const uint2* __restrict__ cand, uint32_t max_cand,
                                                       uint32_t* scratch, uint32_t cap,
                                                       const uint32_t* __restrict__ fallback, DevKp* __restrict__ cache,
                                                       uint32_t max_kp, uint32_t* __restrict__ ncache,
-                                                      uint32_t* __restrict__ err)
+                                                      uint32_t* __restrict__ err, uint32_t* __restrict__ lvl_slot)
 {
     __shared__ uint32_t s_base[kMaxLevels + 1];
     __shared__ uint32_t s_scan[1024 / 64];
-    const int frame = blockIdx.x;
+    __shared__ uint32_t s_run;
+    const int frame = blockIdx.y;
     if (fallback[frame]) return;                 // k_suppress takes this frame
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
@@ -563,87 +585,200 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
     }
     __syncthreads();
     const uint32_t N = s_base[T.n];
-    const SupFrame F = sup_frame(scratch, cap, frame, gridDim.x);
-    for (uint32_t cb = 0; cb < N; cb += 1024) {
+    const uint32_t nchunks = (N + 1023u) / 1024u;
+    const uint32_t k0 = CHUNK_PARALLEL ? blockIdx.x : 0u;
+    const uint32_t k1 = CHUNK_PARALLEL ? min(k0 + 1u, nchunks) : nchunks;
+    if (N == 0) {
+        if (k0 == 0) {
+            if (tid == 0) ncache[frame] = 0u;
+            if ((int)tid <= T.n) lvl_slot[(size_t)frame * (kMaxLevels + 1) + tid] = 0u;
+        }
+        return;
+    }
+    if (k0 >= nchunks) return;
+    const SupFrame F = sup_frame(scratch, cap, frame, gridDim.y);
+    // The records of a 1024-candidate chunk live in LDS while the chunk iterates.  Everything a candidate reads that
+    // cannot change any more — its neighbour lists, the responses, and the records of candidates of EARLIER chunks,
+    // which are final — is fetched once per chunk into registers (rounds of independent loads); a sweep of the
+    // fixed-point iteration then touches LDS only.  Candidates with more than kSupRegN neighbours, kSupRegM reverse
+    // entries per neighbour or kSupRegT in-chunk threats per neighbour (rare) evaluate from the lists in memory.
+    constexpr int kSupRegN = 4, kSupRegM = 6, kSupRegT = 4;
+    __shared__ uint2 s_state[1024];
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    uint32_t running = 0;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t cb = k * 1024u;
         const uint32_t c = cb + tid;
         const bool on = c < N;
+        s_state[tid] = make_uint2(kSupNone, kSupNone);
         uint32_t nn = 0;
         float rc = 0.0f;
+        uint32_t nb[kSupRegN], nslot[kSupRegN], nth[kSupRegN], th[kSupRegN][kSupRegT], nr[kSupRegN], mm[kSupRegN][kSupRegM];
+        float nresp[kSupRegN];
+        bool rep_static[kSupRegN];
+        bool generic = false;
+#pragma unroll
+        for (int a = 0; a < kSupRegN; ++a) {
+            nb[a] = kSupNone; nslot[a] = kSupNone; nth[a] = 0u; nresp[a] = 0.0f; rep_static[a] = false; nr[a] = 0u;
+#pragma unroll
+            for (int q = 0; q < kSupRegT; ++q) th[a][q] = 0u;
+#pragma unroll
+            for (int q = 0; q < kSupRegM; ++q) mm[a][q] = kSupNone;
+        }
+        // ---- round A: the lists (nothing here depends on another chunk) ----
         if (on) {
             nn = F.nadj[c];
             rc = F.resp[c];
+            generic = nn > (uint32_t)kSupRegN;
+            if (!generic) {
+#pragma unroll
+                for (int a = 0; a < kSupRegN; ++a)
+                    if ((uint32_t)a < nn) nb[a] = F.adj[(size_t)c * kSupDeg + a];
+#pragma unroll
+                for (int a = 0; a < kSupRegN; ++a)
+                    if ((uint32_t)a < nn) {
+                        nresp[a] = F.resp[nb[a]];
+                        nr[a] = min(F.nradj[nb[a]], (uint32_t)kSupDeg);
+                    }
+#pragma unroll
+                for (int a = 0; a < kSupRegN; ++a) {
+                    if (nr[a] > (uint32_t)kSupRegM) generic = true;
+#pragma unroll
+                    for (int q = 0; q < kSupRegM; ++q)
+                        if ((uint32_t)q < nr[a]) mm[a][q] = F.radj[(size_t)nb[a] * kSupDeg + q];
+                }
+            }
         }
+        // ---- the chunk before this one is final (and with it every earlier one) ----
+        if (CHUNK_PARALLEL && k > 0) {
+            if (tid == 0) {
+                uint32_t v;
+                while ((v = __hip_atomic_load(&F.done[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                    __builtin_amdgcn_s_sleep(2);
+                s_run = v - 1u;
+            }
+            __syncthreads();
+            running = s_run;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        // ---- round B: the final records of earlier chunks ----
+        if (on && !generic) {
+#pragma unroll
+            for (int a = 0; a < kSupRegN; ++a)
+                if ((uint32_t)a < nn && nb[a] < cb) nslot[a] = F.state[nb[a]].x;
+#pragma unroll
+            for (int a = 0; a < kSupRegN; ++a) {
+#pragma unroll
+                for (int q = 0; q < kSupRegM; ++q) {
+                    const uint32_t m = mm[a][q];
+                    if (m >= c) continue;                             // (kSupNone included) later candidates cannot have replaced n yet
+                    if (m < cb) {
+                        if (F.state[m].y == nb[a]) rep_static[a] = true;
+                    } else if (nth[a] < (uint32_t)kSupRegT) {
+#pragma unroll
+                        for (int t = 0; t < kSupRegT; ++t)
+                            if ((uint32_t)t == nth[a]) th[a][t] = m - cb;
+                        ++nth[a];
+                    } else {
+                        generic = true;
+                    }
+                }
+            }
+        }
+        __syncthreads();
         for (;;) {
             bool changed = false;
             if (on) {
                 uint32_t best_slot = kSupNone, best_n = kSupNone;
-                for (uint32_t a = 0; a < nn; ++a) {
-                    const uint32_t n = F.adj[(size_t)c * kSupDeg + a];
-                    const uint32_t sl = F.state[n].x;
-                    if (sl == kSupNone || sl >= best_slot) continue;   // dropped, or not the first in slot order
-                    // still the occupant when c is processed?  not if an earlier-than-c candidate replaced it
-                    bool replaced = false;
-                    const uint32_t nr = min(F.nradj[n], (uint32_t)kSupDeg);
-                    for (uint32_t q = 0; q < nr; ++q) {
-                        const uint32_t m = F.radj[(size_t)n * kSupDeg + q];
-                        if (m < c && F.state[m].y == n) {
-                            replaced = true;
-                            break;
+                float best_resp = 0.0f;
+                if (!generic) {
+#pragma unroll
+                    for (int a = 0; a < kSupRegN; ++a) {
+                        if ((uint32_t)a >= nn) continue;
+                        const uint32_t n = nb[a];
+                        const uint32_t sl = n >= cb ? s_state[n - cb].x : nslot[a];
+                        if (sl == kSupNone || sl >= best_slot) continue;   // dropped, or not the first in slot order
+                        bool replaced = rep_static[a];
+#pragma unroll
+                        for (int t = 0; t < kSupRegT; ++t)
+                            if ((uint32_t)t < nth[a] && s_state[th[a][t]].y == n) replaced = true;
+                        if (!replaced) {
+                            best_slot = sl;
+                            best_n = n;
+                            best_resp = nresp[a];
                         }
                     }
-                    if (!replaced) {
-                        best_slot = sl;
-                        best_n = n;
+                } else {
+                    for (uint32_t a = 0; a < nn; ++a) {
+                        const uint32_t n = F.adj[(size_t)c * kSupDeg + a];
+                        const uint32_t sl = n >= cb ? s_state[n - cb].x : F.state[n].x;
+                        if (sl == kSupNone || sl >= best_slot) continue;
+                        // still the occupant when c is processed?  not if an earlier-than-c candidate replaced it
+                        bool replaced = false;
+                        const uint32_t nrn = min(F.nradj[n], (uint32_t)kSupDeg);
+                        for (uint32_t q = 0; q < nrn; ++q) {
+                            const uint32_t m = F.radj[(size_t)n * kSupDeg + q];
+                            if (m < c && (m >= cb ? s_state[m - cb].y : F.state[m].y) == n) {
+                                replaced = true;
+                                break;
+                            }
+                        }
+                        if (!replaced) {
+                            best_slot = sl;
+                            best_n = n;
+                            best_resp = F.resp[n];
+                        }
                     }
                 }
                 uint2 st;
                 if (best_n == kSupNone) st = make_uint2(c, kSupNone);                       // push
-                else if (rc > F.resp[best_n]) st = make_uint2(best_slot, best_n);           // is_repeated: in-place write
+                else if (rc > best_resp) st = make_uint2(best_slot, best_n);                // is_repeated: in-place write
                 else st = make_uint2(kSupNone, kSupNone);                                   // is_extremum = false
-                const uint2 old = F.state[c];
+                const uint2 old = s_state[tid];
                 if (old.x != st.x || old.y != st.y) {
-                    F.state[c] = st;
+                    s_state[tid] = st;
                     changed = true;
                 }
             }
             if (!__syncthreads_or(changed ? 1 : 0)) break;
         }
-    }
-    // pushed slots in pusher order -> cache positions
-    uint32_t running = 0;
-    for (uint32_t cb = 0; cb < N; cb += 1024) {
-        const uint32_t c = cb + tid;
-        const bool push = c < N && F.state[c].x == c;
+        // ---- the chunk is final: records to memory, replaced occupants marked, pushes numbered ----
+        const uint2 st = s_state[tid];
+        if (on) {
+            F.state[c] = st;
+            if (st.y != kSupNone) F.repl[st.y] = 1u;
+        }
+        const bool push = on && st.x == c;
         const unsigned long long bal = __ballot(push);
-        const uint32_t lane = tid & 63u, wv = tid >> 6;
         if (lane == 0) s_scan[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
-        uint32_t off = running;
-        for (uint32_t k = 0; k < wv; ++k) off += s_scan[k];
-        if (c < N) F.rank[c] = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        uint32_t tot = 0;
-        for (uint32_t k = 0; k < 1024 / 64; ++k) tot += s_scan[k];
+        uint32_t off = running, tot = 0;
+        for (uint32_t q = 0; q < 1024 / 64; ++q) {
+            if (q < wv) off += s_scan[q];
+            tot += s_scan[q];
+        }
+        if (on) F.rank[c] = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         running += tot;
-        __syncthreads();
+        if (CHUNK_PARALLEL) __threadfence();
+        else __threadfence_block();
+        __syncthreads();   // the next chunk reads these records from memory; s_state and s_scan are reused
+        if (CHUNK_PARALLEL && tid == 0) __hip_atomic_store(&F.done[k], running + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (k1 < nchunks) return;                    // the workgroup of the last chunk finishes the frame
     if (tid == 0) {
         if (running > max_kp || running >= (1u << 24)) *err = 2u;
         ncache[frame] = min(running, max_kp);
     }
+    // first slot pushed at every level (k_filter_upper bounds its walks with it): the pushes before the level's
+    // first candidate
+    if ((int)tid <= T.n) lvl_slot[(size_t)frame * (kMaxLevels + 1) + tid] = s_base[tid] < N ? F.rank[s_base[tid]] : running;
     // every slot's final occupant writes the entry
     const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
     for (uint32_t c = tid; c < N; c += 1024) {
         const uint2 st = F.state[c];
-        if (st.x == kSupNone) continue;
-        bool replaced = false;
-        const uint32_t nr = min(F.nradj[c], (uint32_t)kSupDeg);
-        for (uint32_t q = 0; q < nr; ++q)
-            if (F.state[F.radj[(size_t)c * kSupDeg + q]].y == c) {
-                replaced = true;
-                break;
-            }
-        if (replaced) continue;
+        const uint32_t rp = F.repl[c];
+        if (st.x == kSupNone || rp) continue;
         const uint32_t pos = F.rank[st.x];
         if (pos >= max_kp) continue;
         uint32_t i;
@@ -832,18 +967,24 @@ __device__ __forceinline__ unsigned long long rank_key(const DevKp& kp, uint32_t
     return ((unsigned long long)sk << 32) | (unsigned long long)i;
 }
 
+constexpr int kRankI = 32, kRankJ = 8;   // keypoints per block x slices of a key tile (kRankI * kRankJ = 256 threads)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
                                                    uint32_t stride, uint32_t max_features, int tile_shift,
                                                    DevKp* __restrict__ out, uint32_t* __restrict__ n_out,
                                                    uint32_t* __restrict__ perm)
 {
+    // a block ranks kRankI keypoints; its 256 threads split every 1024-key tile kRankJ ways, so a thread compares
+    // against n / kRankJ keys and the chip holds n / kRankI blocks per frame (single frame of 4 600 keypoints:
+    // 145 blocks x 577 compares per thread instead of 19 x 4 616)
     __shared__ unsigned long long s_key[1024];
+    __shared__ uint32_t s_part[kRankJ][kRankI];
     const int frame = blockIdx.y;
     const uint32_t n = min(n_in[frame], stride);
-    if (blockIdx.x * 256u >= n && !(blockIdx.x == 0 && MODE == RANK_RESPONSE)) return;    // whole block
+    if (blockIdx.x * (uint32_t)kRankI >= n && !(blockIdx.x == 0 && MODE == RANK_RESPONSE)) return;    // whole block
     const DevKp* src = in + (size_t)frame * stride;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ii = threadIdx.x & (kRankI - 1), js = threadIdx.x / kRankI;
+    const uint32_t i = blockIdx.x * (uint32_t)kRankI + ii;
     DevKp me;
     unsigned long long mine = ~0ull;
     if (i < n) {
@@ -851,16 +992,23 @@ __global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in,
         mine = rank_key<MODE>(me, i, tile_shift);
     }
     uint32_t rank = 0;
+    constexpr uint32_t kSlice = 1024 / kRankJ;
     for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < 1024; j += 256)
             s_key[j] = t0 + j < n ? rank_key<MODE>(src[t0 + j], t0 + j, tile_shift) : ~0ull;
         __syncthreads();
         const uint32_t m = min(1024u, n - t0);
+        const uint32_t j0 = js * kSlice, j1 = min(m, j0 + kSlice);
 #pragma unroll 8
-        for (uint32_t j = 0; j < m; ++j) rank += s_key[j] < mine ? 1u : 0u;
+        for (uint32_t j = j0; j < j1; ++j) rank += s_key[j] < mine ? 1u : 0u;
     }
-    if (i < n) {
+    s_part[js][ii] = rank;
+    __syncthreads();
+    if (js == 0 && i < n) {
+        rank = 0;
+#pragma unroll
+        for (int k = 0; k < kRankJ; ++k) rank += s_part[k][ii];
         if (MODE == RANK_RESPONSE) {
             if (rank < max_features) out[(size_t)frame * stride + rank] = me;
         } else {
@@ -1321,7 +1469,7 @@ int32_t akz_upload_tables(akz_ctx* c)
 }
 
 int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
-                          uint32_t* d_n_out)
+                          uint32_t* d_n_out, uint32_t* h_err_copy)
 {
     const AkzPlan& P = c->plan;
     AkzSet& S = c->S();
@@ -1344,25 +1492,33 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     AKZ_HIP(hipStreamWaitEvent(s, c->ev_ss_done[c->cur], 0));
     // A12b
     if (c->sup_parallel) {
-        AKZ_HIP(hipMemsetAsync(S.d_sup_flag, 0, sizeof(uint32_t) * n, s));
-        AKZ_HIP(hipMemsetAsync(S.d_sup, 0, sizeof(uint32_t) * (size_t)n * c->sup_cap, s));   // the reverse-list counters
+        // the fallback flags sit directly before the scratch, whose first words are the chunk flags, the reverse-list
+        // counters and the replaced marks
+        AKZ_HIP(hipMemsetAsync(S.d_sup_flag, 0, (size_t)((char*)S.d_sup - (char*)S.d_sup_flag) +
+                                                    sizeof(uint32_t) * sup_zero_words(c->sup_cap, (uint32_t)n), s));
         hipLaunchKernelGGL(k_sup_adj, dim3(akz_div_up((int)c->sup_cap, 256), n), dim3(256), 0, s, T, S.d_ncand, S.d_cand,
                            c->max_cand, S.d_sup, c->sup_cap, S.d_sup_flag);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sup_resolve, dim3(n), dim3(1024), 0, s, T, S.d_ncand, S.d_cand, c->max_cand, S.d_sup,
-                           c->sup_cap, S.d_sup_flag, S.d_cache, c->max_kp, S.d_ncache, c->d_err);
+        if (n <= 16)
+            hipLaunchKernelGGL((k_sup_resolve<true>), dim3(akz_div_up((int)c->sup_cap, 1024), n), dim3(1024), 0, s, T, S.d_ncand,
+                               S.d_cand, c->max_cand, S.d_sup, c->sup_cap, S.d_sup_flag, S.d_cache, c->max_kp, S.d_ncache,
+                               c->d_err, S.d_lvl_slot);
+        else
+            hipLaunchKernelGGL((k_sup_resolve<false>), dim3(1, n), dim3(1024), 0, s, T, S.d_ncand, S.d_cand, c->max_cand,
+                               S.d_sup, c->sup_cap, S.d_sup_flag, S.d_cache, c->max_kp, S.d_ncache, c->d_err, S.d_lvl_slot);
         AKZ_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T, S.d_ncand,
                        S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err,
-                       c->sup_parallel ? (const uint32_t*)S.d_sup_flag : (const uint32_t*)nullptr);
+                       c->sup_parallel ? (const uint32_t*)S.d_sup_flag : (const uint32_t*)nullptr, S.d_lvl_slot);
     AKZ_LAUNCH_CHECK();
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
-    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache, S.d_flag_b);
+    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache,
+                       (const uint32_t*)S.d_lvl_slot, T.n, S.d_flag_b);
     AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_cache, (const akz_descriptor*)nullptr,
                        S.d_flag_b, S.d_ncache, c->max_kp, S.d_kp_a, (akz_descriptor*)nullptr, c->max_kp, S.d_n_a,
-                       c->d_err);
+                       c->d_err, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
     // A13 + A14
     const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
@@ -1373,12 +1529,12 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     akz_timer_end(c, AKZ_T_REFINE, s, 1, (uint64_t)n);
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_kp_b, (const akz_descriptor*)nullptr,
                        S.d_flag_b, S.d_n_a, c->max_kp, S.d_kp_c, (akz_descriptor*)nullptr, c->max_kp, S.d_n_c,
-                       c->d_err);
+                       c->d_err, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
     // A15
     uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
     const bool rank_sorts = n <= 8;            // few frames: the chip-wide rank sort; many: one bitonic block per frame
-    const dim3 grid_rank((uint32_t)akz_div_up((int)c->max_kp, 256), n);
+    const dim3 grid_rank((uint32_t)akz_div_up((int)c->max_kp, kRankI), n);
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
     const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;   // longer lists: global key scratch
@@ -1408,7 +1564,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     AKZ_LAUNCH_CHECK();
     akz_timer_end(c, AKZ_T_DESCRIBE, s, 1, (uint64_t)n);
     hipLaunchKernelGGL((k_compact<true>), dim3(n), dim3(1024), 0, s, S.d_kp_d, S.d_desc_tmp, S.d_flag_d, S.d_n_d,
-                       c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr);
+                       c->max_kp, d_kps, d_descs, cap_per_img, d_n_out, (uint32_t*)nullptr, (const uint32_t*)c->d_err, h_err_copy);
     AKZ_LAUNCH_CHECK();
     AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
     c->kp_pending[c->cur] = true;

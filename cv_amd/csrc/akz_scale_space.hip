@@ -1937,16 +1937,13 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     }
     akz_timer_end(c, AKZ_T_FRONT0, s, 1, (uint64_t)P0 * n);
     // lib.rs:206-211 — contrast factor on the ORIGINAL image
-    AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, sizeof(unsigned long long) * n, s));
-    AKZ_HIP(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * (size_t)n * nbins, s));
-    AKZ_HIP(hipMemsetAsync(S.d_npoints, 0, sizeof(uint32_t) * n, s));
-    AKZ_HIP(hipMemsetAsync(S.d_ncand, 0, sizeof(uint32_t) * kAkzMaxLevels * (size_t)n, s));
+    // d_cmax, d_npoints, d_ncand, d_hist, d_fine: contiguous (carve_set)
+    AKZ_HIP(hipMemsetAsync(S.d_cmax, 0, S.zero_bytes, s));
     const bool pairc = (w & 3) == 0 && c->front_pair && nbins <= 510;
     akz_timer_begin(c, AKZ_T_CONTRAST, s);
     const bool fine = pairc && c->contrast_fine;
     if (pairc) {
         dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), kCTiles), (n + 1) / 2);
-        if (fine) AKZ_HIP(hipMemsetAsync(S.d_fine, 0, sizeof(uint32_t) * (size_t)n * kFineBins, s));
         hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
                            (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, fine ? S.d_fine : (uint32_t*)nullptr,
                            (const uint32_t*)nullptr);
@@ -1974,6 +1971,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     akz_timer_end(c, AKZ_T_CONTRAST, s, 2, (uint64_t)P0 * n);
 
     uint64_t fed_launches = 0, fed_units = 0;
+    const bool det_side = c->det_side_stream && c->stream_det != nullptr;
     for (int i = 0; i < nlev; ++i) {
         const AkzLevel& L = P.levels[i];
         const size_t fs = L.pixels();
@@ -2095,6 +2093,13 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             AKZ_LAUNCH_CHECK();
         }
         {
+            // {Lx, Ly} of this level are complete on `s_main`: the determinant / candidate kernel is a side branch
+            hipStream_t s_main = s;
+            if (det_side) {
+                AKZ_HIP(hipEventRecord(c->ev_level[i], s_main));
+                AKZ_HIP(hipStreamWaitEvent(c->stream_det, c->ev_level[i], 0));
+            }
+            hipStream_t s = det_side ? c->stream_det : s_main;
             CandParams cp;
             cp.thr = (float)c->cfg.detector_threshold;
             cp.border = L.cand_border;
@@ -2150,6 +2155,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             AKZ_LAUNCH_CHECK();
             if (t_det_on) akz_timer_end(c, AKZ_T_DET_SG2 + (int)L.deriv_sigma - 2, s, 1, (uint64_t)fs * n);
         }
+    }
+    if (det_side) {
+        AKZ_HIP(hipEventRecord(c->ev_det_done, c->stream_det));
+        AKZ_HIP(hipStreamWaitEvent(s, c->ev_det_done, 0));
     }
     {
         uint32_t np2 = 1;

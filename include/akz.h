@@ -99,7 +99,9 @@ enum {
     AKZ_OPT_STREAM_PRIORITY = 1u << 4,    /* scale-space stream at high, keypoint stream at low priority */
     AKZ_OPT_CONTRAST_EXACT = 1u << 5,     /* contrast factor always through the exact histogram pass */
     AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6, /* test knob: odd frames through the exact pass (mixed pairs) */
-    AKZ_OPT_TILE_KERNELS = 1u << 7        /* the LDS-tile determinant kernels of round 1 instead of the row-streaming one */
+    AKZ_OPT_TILE_KERNELS = 1u << 7,       /* the LDS-tile determinant kernels of round 1 instead of the row-streaming one */
+    AKZ_OPT_SERIAL_DET = 1u << 8          /* determinant / candidate kernels on the scale-space stream itself instead of
+                                           * the side stream that takes them off the Lt -> Lt dependency chain */
 };
 typedef struct akz_options {
     uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */

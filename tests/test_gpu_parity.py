@@ -1131,6 +1131,7 @@ OPTION_SETS = [
     ("serial suppression, no pipeline", dict(parallel_suppression=False, pipeline=False)),
     ("exact contrast, stream priorities", dict(contrast="exact", stream_priority=True)),
     ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
+    ("determinant kernels on the scale-space stream", dict(det_side_stream=False)),
 ]
 
 

@@ -22,3 +22,10 @@ for s, e, n in seg:
     agg[n][0] += 1; agg[n][1] += e - s
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f"{n[:60]:60s} {c:3d} {t/1e3:9.1f} us")
+# full timeline of the frame: offset of the start, duration, gap to the latest end seen so far
+print("--- timeline (us): start, dur, gap_since_prev_end, name")
+t0 = seg[0][0]; last_end = seg[0][0]
+for s_, e_, n_ in seg:
+    n_ = re.sub(r"\(anonymous namespace\)::", "", n_); n_ = re.sub(r"^void\s+", "", n_); n_ = re.sub(r"\(.*$", "", n_)
+    print(f"{(s_-t0)/1e3:9.1f} {(e_-s_)/1e3:7.1f} {(s_-last_end)/1e3:7.1f}  {n_[:70]}")
+    last_end = max(last_end, e_)

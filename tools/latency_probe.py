@@ -1,13 +1,18 @@
 import sys, time, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from cv_amd import build; build.build()
-from cv_amd import akaze
+from cv_amd import akaze, _lib
 from conftest import synth_frame
+kw = {}
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    kw[k] = bool(int(v)) if k in ("det_side_stream", "stream_kernels", "parallel_suppression", "pipeline") else int(v)
 img = synth_frame(1920, 1080, 4242, 200, 200)
 ak = akaze.Akaze.default()
-ctx = ak.context(1920, 1080, 1)
+ctx = ak.context(1920, 1080, 1, options=_lib.make_options(**kw))
 for _ in range(3): ctx.extract_batch([img])
-t=time.perf_counter(); N=10
+t=time.perf_counter(); N=20
 for _ in range(N): r = ctx.extract_batch([img])
-print("single 1080p frame extract (host in, host out): %.2f ms, %d keypoints" % ((time.perf_counter()-t)/N*1e3, len(r[0][0])))
+print("single 1080p frame extract (host in, host out) %s: %.3f ms, %d keypoints" % (kw, (time.perf_counter()-t)/N*1e3, len(r[0][0])))

@@ -39,7 +39,7 @@ def main():
     for kv in a.opt:
         key, val = kv.split("=")
         kw[key] = val if key == "contrast" else int(val)
-    for key in ("keep_all", "frame_pairs", "parallel_suppression", "stream_kernels", "stream_priority"):
+    for key in ("keep_all", "frame_pairs", "parallel_suppression", "stream_kernels", "stream_priority", "det_side_stream"):
         if key in kw:
             kw[key] = bool(kw[key])
     ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False, **kw))
