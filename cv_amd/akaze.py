@@ -190,8 +190,9 @@ class Context:
             imgs = [np.ascontiguousarray(im, dtype=np.float32) for im in imgs]
         assert all(im.shape == (h, w) and im.dtype == imgs[0].dtype for im in imgs)
         cap = self.max_kp
-        kps = np.zeros((n, cap), KP_DTYPE)
-        descs = np.zeros((n, cap, 64), np.uint8)
+        # (outputs are not cleared: the library writes cnt[i] entries per frame and only those are returned)
+        kps = np.empty((n, cap), KP_DTYPE)
+        descs = np.empty((n, cap, 64), np.uint8)
         cnt = np.zeros(n, np.uint32)
         ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         st = _lib.lib().akz_extract_batch(self._h, ptrs, fmt, n, w, h, w, kps.ctypes.data, descs.ctypes.data, cap,

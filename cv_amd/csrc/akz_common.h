@@ -49,6 +49,8 @@ __host__ __device__ __forceinline__ size_t sup_zero_words(uint32_t cap, uint32_t
 {
     return (size_t)nframes * (sup_done_words(cap) + 2 * (size_t)cap);
 }
+// calls of at most this many frames are treated as latency-bound chains of launches (longer FED blocks, ...)
+constexpr int kLatencyFrames = 4;
 constexpr int kAkzMaxTaps = 1023;
 
 // ---- host-side plan: what Akaze::allocate_evolutions computes (akaze/src/evolution.rs:80-126) ---

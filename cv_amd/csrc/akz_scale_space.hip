@@ -1030,9 +1030,10 @@ __global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src,
     dst[base] = v;
 }
 
-// the half-tau values of one temporally blocked launch (up to 8 steps)
+// the half-tau values of one temporally blocked launch (up to 16 steps)
+constexpr int kFedMaxBlock = 16;
 struct FedTaus {
-    float half_tau[8];
+    float half_tau[kFedMaxBlock];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1987,7 +1988,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // images, where fewer, longer launches win over the smaller useful tile
             // (measured, 256 x 1080p: 4 / 5 / 6 / 8 steps per launch below the first octave -> 5186 / 5216 / 5259 /
             // 5299 frames/s; a three-patch halo for up to 12 steps loses again)
-            const int fed_block = L.octave == 0 ? (c->fed_block < 4 ? c->fed_block : 4) : c->fed_block;
+            int fed_block = L.octave == 0 ? (c->fed_block < 4 ? c->fed_block : 4) : c->fed_block;
+            // a call of a few frames is a chain of dependent launches (~5 us each before any work): below the first
+            // octave it runs up to 16 steps per launch (three- and four-patch halos, 40 x 40 / 32 x 32 useful tiles),
+            // which a batch would lose on (see above) and a single frame wins on
+            if (n <= kLatencyFrames && L.octave > 0 && c->fed_block == 8) fed_block = kFedMaxBlock;
             const int nwrites = blocked ? (nsteps + fed_block - 1) / fed_block : nsteps;  // FED launches
             const float* init;
             if (L.new_octave) {
@@ -2052,20 +2057,23 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 for (int gi = 0; gi < ng; ++gi) {
                     float* dstb = ((ng - 1 - gi) % 2 == 0) ? bufA : bufB;
                     FedTaus ft;
-                    for (int q = 0; q < 8; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
+                    for (int q = 0; q < kFedMaxBlock; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
 #define AKZ_FED_CASE(TT)                                                                                              \
     case TT: {                                                                                                        \
         dim3 gridp(akz_div_up(L.w, fed_tile_edge(TT)), akz_div_up(L.h, fed_tile_edge(TT)), (n + 1) / 2);              \
         hipLaunchKernelGGL((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
     } break;
-                    akz_timer_begin(c, AKZ_T_FED_T1 + groups[gi] - 1, s);
+                    const int t_fed = AKZ_T_FED_T1 + (groups[gi] <= 8 ? groups[gi] : 8) - 1;   // (9..16 steps: single-frame calls only)
+                    akz_timer_begin(c, t_fed, s);
                     switch (groups[gi]) {
                         AKZ_FED_CASE(1) AKZ_FED_CASE(2) AKZ_FED_CASE(3) AKZ_FED_CASE(4)
                         AKZ_FED_CASE(5) AKZ_FED_CASE(6) AKZ_FED_CASE(7) AKZ_FED_CASE(8)
+                        AKZ_FED_CASE(9) AKZ_FED_CASE(10) AKZ_FED_CASE(11) AKZ_FED_CASE(12)
+                        AKZ_FED_CASE(13) AKZ_FED_CASE(14) AKZ_FED_CASE(15) AKZ_FED_CASE(16)
                     }
 #undef AKZ_FED_CASE
                     AKZ_LAUNCH_CHECK();
-                    akz_timer_end(c, AKZ_T_FED_T1 + groups[gi] - 1, s, 1, (uint64_t)fs * n);
+                    akz_timer_end(c, t_fed, s, 1, (uint64_t)fs * n);
                     j += groups[gi];
                     src = dstb;
                 }
