@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="one buffer set in the library (AKZ_OPT_NO_PIPELINE): "
                     "consecutive calls do not overlap; for counter passes and serial phase profiles")
+    ap.add_argument("--opt", action="append", default=[], help="akz_options field for the context, key=value (A/B runs; "
+                    "the defaults are what the headline is quoted on)")
     ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3])")
     ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
     ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
@@ -179,7 +181,13 @@ def main():
     ak = Akaze.default()
     ak.device = local_rank
     ak.max_keypoints = CAP
-    ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False) if args.no_pipeline else None)
+    okw = {}
+    for kv in args.opt:                       # A/B runs: akz_options fields by name (cv_amd._lib.make_options)
+        key, val = kv.split("=")
+        okw[key] = val if key == "contrast" else (bool(int(val)) if key in _lib.BOOL_OPTIONS else int(val))
+    if args.no_pipeline:
+        okw["pipeline"] = False
+    ctx = ak.context(W, H, MB, options=_lib.make_options(**okw) if okw else None)
     matcher = Matcher(CAP, device=local_rank)
     akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
     hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
@@ -364,7 +372,8 @@ def main():
                                    "Akaze::default() detect+describe, + symmetric better-by-24 BF Hamming match "
                                    "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
                        "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
-                       "mean_matches_per_pair": round(n_match, 1)},
+                       "mean_matches_per_pair": round(n_match, 1),
+                       "library_options": okw or "defaults"},
             "roofline": tops[0] if tops else None,
             "roofline_top": tops[:4],
             "phase_ms_per_step": {"fed": round(fed_ms / INSTR_STEPS, 2), "scale_space": round(ss_ms / INSTR_STEPS, 2),

@@ -125,7 +125,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
-            if (o.flags & ~((AKZ_OPT_SERIAL_DET << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
+            if (o.flags & ~((AKZ_OPT_SPLIT_FRONT_FED << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
         }
         {
@@ -160,6 +160,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->front_pair = !(o.flags & AKZ_OPT_NO_FRAME_PAIRS);
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
         c->det_side_stream = !(o.flags & AKZ_OPT_SERIAL_DET);
+        c->fuse_front_fed = !(o.flags & AKZ_OPT_SPLIT_FRONT_FED);
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
         if (o.stream_min_waves) c->stream_min_waves = (size_t)o.stream_min_waves;
         c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);

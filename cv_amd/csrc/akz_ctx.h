@@ -96,6 +96,7 @@ struct akz_ctx {
     // and joins again before the candidate sort.
     hipStream_t stream_det = nullptr;
     bool det_side_stream = true;        // AKZ_OPT_SERIAL_DET clears it
+    bool fuse_front_fed = true;         // k_front_fed where it applies (AKZ_OPT_SPLIT_FRONT_FED clears it)
     hipEvent_t ev_level[kAkzMaxLevels] = {};   // {Lx, Ly} of level l written (recorded on `stream`)
     hipEvent_t ev_det_done = nullptr;          // every determinant kernel of the call finished (recorded on `stream_det`)
     bool sup_parallel = true;           // AKZ_SUP_PARALLEL=0: serial suppression only

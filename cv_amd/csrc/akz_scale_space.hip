@@ -1178,6 +1178,326 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
 
 
 // ---------------------------------------------------------------------------------------------
+// Level front-end AND the first FED launch of the level in one kernel (two frames per block, w % 4 == 0).
+// lib.rs:230-256 does, for level i > 0:  Lt_i <- copy of Lt_{i-1};  Lsmooth = blur(Lt_i, 1.0);  Lflow = pm_g2(simple
+// Scharr(Lsmooth));  {Lx, Ly} = multiscale Scharr(Lsmooth);  then the FED steps on Lt_i with Lflow.  The front kernel
+// and the FED kernel above split that at Lflow: 16 B/pixel + 12 B/pixel per launch.  Here a block keeps the FED
+// kernel's organisation — a 64 x 64 window of 16 x 16 threads, each owning a 4 x 4 patch of both frames in registers —
+// and builds the conductivity of its patch itself, so Lflow never leaves the chip:
+//   1. the input window (+2 px: the blur radius) goes to LDS; every thread blurs ITS patch (horizontal then vertical,
+//      taps in the reference's lane order), the 64 x 64 blurred window replaces the input in LDS;
+//   2. from it every thread takes the simple Scharr gradient and pm_g2 of its patch (-> C[4][4], registers), and the
+//      threads of the useful region the multiscale Scharr {Lx, Ly} of theirs (-> HBM);
+//   3. the FED steps run exactly as in k_fed_pair (same exchange through LDS, same border rules).
+// HBM traffic: 4 B in (Lt), 4 B (Lt') + 8 B ({Lx, Ly}) out = 16 B/pixel for what took 28.
+// Validity: the conductivity needs the blurred ring around a pixel, so it is right on window pixels 1..62 and a launch
+// of T steps is right 1 + T pixels inside the window: HP halo patches serve T <= 4 HP - 1 steps (k_fed_pair: 4 HP).
+// Every value is computed by the same expression, in the same order, as in k_level_front2 / k_fed_pair.
+constexpr int kFFW = 64;                       // window edge
+constexpr int kFFIn = kFFW + 4;                // input rows (blur radius 2 either side)
+constexpr int kFFInC = kFFW + 8;               // input columns held (4 either side: whole 16-byte chunks)
+constexpr int kFFGS = kFFW + 4;                // row stride of the blurred window in LDS (2 apron columns either side)
+constexpr int front_fed_tile(int HP) { return kFFW - 8 * HP; }
+
+template <int SG, int HP, bool WRITE_FLOW>
+__global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
+                                                      GaussTaps taps, OffK k, FedTaus taus, int nsteps,
+                                                      float* __restrict__ out_lt, float* __restrict__ out_flow,
+                                                      float2* __restrict__ out_xy, const float* __restrict__ invk,
+                                                      int invk_off)
+{
+    // one block of LDS, three lives: input window [kFFIn][kFFInC], blurred window [kFFW + 2][kFFGS] (one apron row
+    // above and below), FED exchange buffers
+    __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC];
+    static_assert((kFFW + 2) * kFFGS <= kFFIn * kFFInC, "blurred window fits in the input window's space");
+    static_assert(4 * 256 * 2 * 2 <= kFFIn * kFFInC, "FED exchange buffers fit");
+    constexpr int U = front_fed_tile(HP);
+    const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int fa = 2 * (int)tile.z;
+    const bool has_b = fa + 1 < n;
+    const int fb = has_b ? fa + 1 : fa;
+    const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
+    const int wx0 = (int)tile.x * U - 4 * HP, wy0 = (int)tile.y * U - 4 * HP;   // window origin in the image
+    const float* srca = in + (size_t)fa * fs;
+    const float* srcb = in + (size_t)fb * fs;
+    // ---- 1a. input window: rows wy0 - 2 .., columns wx0 - 4 .., clamped coordinates outside the image ----
+    {
+        const bool inside = wx0 >= 4 && wx0 + kFFW + 4 <= w && wy0 >= 2 && wy0 + kFFW + 2 <= h;
+        if (inside) {
+            for (int idx = tid; idx < kFFIn * (kFFInC / 4); idx += 256) {
+                const int iy = idx / (kFFInC / 4), c4 = idx - iy * (kFFInC / 4);
+                const size_t o = (size_t)(wy0 - 2 + iy) * w + (wx0 - 4 + 4 * c4);
+                const float4 a = *reinterpret_cast<const float4*>(srca + o);
+                const float4 b = *reinterpret_cast<const float4*>(srcb + o);
+                float4* d = reinterpret_cast<float4*>(&s_buf[iy * kFFInC + 4 * c4]);
+                d[0] = make_float4(a.x, b.x, a.y, b.y);
+                d[1] = make_float4(a.z, b.z, a.w, b.w);
+            }
+        } else {
+            for (int idx = tid; idx < kFFIn * kFFInC; idx += 256) {
+                const int iy = idx / kFFInC, ix = idx - iy * kFFInC;
+                const int cx = clampi(wx0 - 4 + ix, 0, w - 1), cy = clampi(wy0 - 2 + iy, 0, h - 1);
+                const size_t o = (size_t)cy * w + cx;
+                s_buf[idx] = (v2f){srca[o], srcb[o]};
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 1b. Gaussian blur (sigma 1.0, 5 taps) of the thread's own patch ----
+    v2f g[4][4];
+    {
+        v2f hb[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            // window column X sits at input column X + 4; the patch needs columns 4 pc - 2 .. 4 pc + 5 of the window
+            const float4* row = reinterpret_cast<const float4*>(&s_buf[(4 * pr + r) * kFFInC + 4 * pc + 2]);
+            v2f v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v t = lds_chunk(row + q);
+                v[2 * q] = (v2f){t.x, t.y};
+                v[2 * q + 1] = (v2f){t.z, t.w};
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) hb[r][o] = lane4_dot_v<5>(v + o, taps.k);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const v2f col[5] = {hb[j][o], hb[j + 1][o], hb[j + 2][o], hb[j + 3][o], hb[j + 4][o]};
+                g[j][o] = lane4_dot_v<5>(col, taps.k);
+            }
+    }
+    __syncthreads();   // every thread has read its input: the blurred window takes the space
+    // blurred window: pixel (X, Y) of the window at s_g[(Y + 1) * kFFGS + X + 2]
+    v2f* s_g = s_buf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4* d = reinterpret_cast<float4*>(&s_g[(4 * pr + j + 1) * kFFGS + 4 * pc + 2]);
+        d[0] = make_float4(g[j][0].x, g[j][0].y, g[j][1].x, g[j][1].y);
+        d[1] = make_float4(g[j][2].x, g[j][2].y, g[j][3].x, g[j][3].y);
+    }
+    __syncthreads();
+    // positions outside the image take the blurred value at their clamped coordinate (the derivative filters clamp
+    // Lsmooth, image.rs:230-236 / :287-300): reads touch in-image positions only, writes out-of-image positions only
+    if (wx0 < 0 || wx0 + kFFW > w || wy0 < 0 || wy0 + kFFW > h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int x = wx0 + 4 * pc + o, y = wy0 + 4 * pr + j;
+                const int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
+                if (xc != x || yc != y) {
+                    const int X = clampi(xc - wx0, 0, kFFW - 1), Y = clampi(yc - wy0, 0, kFFW - 1);
+                    s_g[(4 * pr + j + 1) * kFFGS + 4 * pc + o + 2] = s_g[(Y + 1) * kFFGS + X + 2];
+                }
+            }
+        __syncthreads();
+    }
+    const int x0 = wx0 + 4 * pc, y0 = wy0 + 4 * pr;
+    const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
+    const bool useful = pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in;
+    // ---- 2a. conductivity of the patch: simple Scharr (derivatives.rs:3-11) + pm_g2 (nonlinear_diffusion.rs:80) ----
+    v2f C[4][4];
+    {
+        const v2f inverse_k = (v2f){invk[(size_t)fa * 8 + invk_off], invk[(size_t)fb * 8 + invk_off]};
+        // per source row: hx = v(+1) - v(-1), hy = (3 v(-1) + 10 v(0)) + 3 v(+1); a three-row window walks down
+        v2f hx[3][4], hy[3][4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            // source row 4 pr - 1 + r, window columns 4 pc - 2 .. 4 pc + 5 (two 16-byte chunks either side of the patch)
+            const float4* row = reinterpret_cast<const float4*>(&s_g[(4 * pr + r) * kFFGS + 4 * pc]);
+            v2f v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v t = lds_chunk(row + q);
+                v[2 * q] = (v2f){t.x, t.y};
+                v[2 * q + 1] = (v2f){t.z, t.w};
+            }
+            const int s = r % 3;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                hx[s][o] = v[o + 3] - v[o + 1];
+                hy[s][o] = (splat(3.0f) * v[o + 1] + splat(10.0f) * v[o + 2]) + splat(3.0f) * v[o + 3];
+            }
+            if (r >= 2) {
+                const int j = r - 2, sm = (r - 2) % 3, s0 = (r - 1) % 3, sp = r % 3;
+                v2f den[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const v2f lx = (splat(3.0f) * hx[sm][o] + splat(10.0f) * hx[s0][o]) + splat(3.0f) * hx[sp][o];
+                    const v2f ly = hy[sp][o] - hy[sm][o];
+                    den[o] = splat(1.0f) + inverse_k * (lx * lx + ly * ly);   // the denominator; inverted below
+                }
+                // (as in k_level_front2: the packed reciprocal unless some denominator of the wave is not finite)
+                bool odd = false;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) odd = odd || not_finite(den[o].x) || not_finite(den[o].y);
+                if (__any(odd)) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) C[j][o] = splat(1.0f) / den[o];
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) C[j][o] = rcp_pair_finite(den[o]);
+                }
+            }
+        }
+    }
+    if (WRITE_FLOW && useful) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + j;
+            if (y >= h) break;
+            const size_t o = (size_t)y * w + x0;
+            *reinterpret_cast<float4*>(out_flow + (size_t)fa * fs + o) = make_float4(C[j][0].x, C[j][1].x, C[j][2].x, C[j][3].x);
+            if (has_b)
+                *reinterpret_cast<float4*>(out_flow + (size_t)fb * fs + o) = make_float4(C[j][0].y, C[j][1].y, C[j][2].y, C[j][3].y);
+        }
+    }
+    // ---- 2b. multiscale Scharr first derivatives of the useful patches (derivatives.rs:23-49), taps at -SG, 0, +SG ----
+    if (useful) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + j;
+            if (y >= h) break;
+            // rows Y - SG, Y, Y + SG of the window, columns 4 pc - 4 .. 4 pc + 7
+            v2f m[12], z[12], p[12];
+            const int Y = 4 * pr + j;
+            const float4* rm = reinterpret_cast<const float4*>(&s_g[(Y - SG + 1) * kFFGS + 4 * pc - 2]);
+            const float4* rz = reinterpret_cast<const float4*>(&s_g[(Y + 1) * kFFGS + 4 * pc - 2]);
+            const float4* rp = reinterpret_cast<const float4*>(&s_g[(Y + SG + 1) * kFFGS + 4 * pc - 2]);
+            constexpr int Q0 = (4 - SG) / 2, Q1 = (7 + SG) / 2;   // 16-byte chunks that hold columns 4 - SG .. 7 + SG of the 12
+#pragma unroll
+            for (int q = Q0; q <= Q1; ++q) {
+                const f4v a = lds_chunk(rm + q), b = lds_chunk(rz + q), c = lds_chunk(rp + q);
+                m[2 * q] = (v2f){a.x, a.y}; m[2 * q + 1] = (v2f){a.z, a.w};
+                z[2 * q] = (v2f){b.x, b.y}; z[2 * q + 1] = (v2f){b.z, b.w};
+                p[2 * q] = (v2f){c.x, c.y}; p[2 * q + 1] = (v2f){c.z, c.w};
+            }
+            v2f rx[4], ry[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const v2f mm = m[4 + o - SG], m0 = m[4 + o], mp = m[4 + o + SG];
+                const v2f zm = z[4 + o - SG], zp = z[4 + o + SG];
+                const v2f pm = p[4 + o - SG], p0 = p[4 + o], pp = p[4 + o + SG];
+                rx[o] = off_combine_sg<SG>(k, mp - mm, zp - zm, pp - pm);
+                ry[o] = off_combine_sg<SG>(k, pm, p0, pp) - off_combine_sg<SG>(k, mm, m0, mp);
+            }
+            const size_t o = (size_t)y * w + x0;
+            {
+                float4* xy = reinterpret_cast<float4*>(out_xy + (size_t)fa * fs + o);
+                xy[0] = make_float4(rx[0].x, ry[0].x, rx[1].x, ry[1].x);
+                xy[1] = make_float4(rx[2].x, ry[2].x, rx[3].x, ry[3].x);
+            }
+            if (has_b) {
+                float4* xy = reinterpret_cast<float4*>(out_xy + (size_t)fb * fs + o);
+                xy[0] = make_float4(rx[0].y, ry[0].y, rx[1].y, ry[1].y);
+                xy[1] = make_float4(rx[2].y, ry[2].y, rx[3].y, ry[3].y);
+            }
+        }
+    }
+    // ---- 3. the FED steps, as k_fed_pair ----
+    v2f L[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + r;
+        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;
+        const bool in_img = col_in && y >= 0 && y < h;
+        if (in_img) {
+            const size_t o = (size_t)y * w + x0;
+            la = *reinterpret_cast<const float4*>(srca + o);
+            lb = *reinterpret_cast<const float4*>(srcb + o);
+        }
+        L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
+        if (!in_img) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) C[r][c] = splat(0.0f);
+        }
+    }
+    __syncthreads();   // the blurred window is dead: the exchange buffers take the space
+    float4* s_top = reinterpret_cast<float4*>(s_buf);            // [256 * 2]  [patch][4 px x 2 frames]
+    float4* s_bot = s_top + 256 * 2;
+    float4* s_ct = s_bot + 256 * 2;                              // top / bottom rows of C
+    float4* s_cb = s_ct + 256 * 2;
+    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+    s_cb[tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
+    s_cb[tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
+    const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
+    // flows that cross the image border are +0 (see k_fed_pair)
+    const bool z_left = x0 <= 0, z_right = x0 + 4 >= w, z_top = y0 <= 0;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        const v2f ht = splat(taus.half_tau[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));
+        s_top[tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
+        s_top[tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
+        s_bot[tid * 2] = make_float4(L[3][0].x, L[3][0].y, L[3][1].x, L[3][1].y);
+        s_bot[tid * 2 + 1] = make_float4(L[3][2].x, L[3][2].y, L[3][3].x, L[3][3].y);
+        __syncthreads();
+        v2f vu[4];
+        {
+            float4 a = s_bot[up * 2], b = s_bot[up * 2 + 1], c = s_cb[up * 2], d = s_cb[up * 2 + 1];
+            const v2f Lt[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
+            const v2f Ct[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                vu[cc] = fed_flow2(ht, Ct[cc], C[0][cc], Lt[cc], L[0][cc]);
+                if (z_top) vu[cc] = splat(0.0f);
+            }
+        }
+        v2f Lb[4], Cb[4];
+        {
+            float4 a = s_top[dn * 2], b = s_top[dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
+            Lb[0] = (v2f){a.x, a.y}; Lb[1] = (v2f){a.z, a.w}; Lb[2] = (v2f){b.x, b.y}; Lb[3] = (v2f){b.z, b.w};
+            Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const v2f Ll = dpp_row<0x111>(L[r][3]), Lr = dpp_row<0x101>(L[r][0]);
+            v2f hf[5];
+            const v2f Cl = dpp_row<0x111>(C[r][3]), Cr = dpp_row<0x101>(C[r][0]);
+            hf[0] = fed_flow2(ht, Cl, C[r][0], Ll, L[r][0]);
+            if (z_left) hf[0] = splat(0.0f);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
+            hf[4] = fed_flow2(ht, C[r][3], Cr, L[r][3], Lr);
+            if (z_right) hf[4] = splat(0.0f);
+            const bool z_down = y0 + r >= h - 1;
+            v2f vd[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vd[c] = r < 3 ? fed_flow2(ht, C[r][c], C[r + 1][c], L[r][c], L[r + 1][c])
+                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);
+                if (z_down) vd[c] = splat(0.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
+                vu[c] = vd[c];
+            }
+        }
+        if (t + 1 < nsteps) __syncthreads();
+    }
+    if (useful) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + r;
+            if (y >= h) break;
+            const size_t o = (size_t)y * w + x0;
+            *reinterpret_cast<float4*>(out_lt + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
+            if (has_b)
+                *reinterpret_cast<float4*>(out_lt + (size_t)fb * fs + o) =
+                    make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
 // {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
 // {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
@@ -1972,7 +2292,9 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     akz_timer_end(c, AKZ_T_CONTRAST, s, 2, (uint64_t)P0 * n);
 
     uint64_t fed_launches = 0, fed_units = 0;
-    const bool det_side = c->det_side_stream && c->stream_det != nullptr;
+    // the side stream shortens the dependency chain of a few-frame call; a batch fills the chip either way (measured:
+    // 6342 vs 6310 frames/s) and its kernels are easier to read in a profile when they do not overlap each other
+    const bool det_side = c->det_side_stream && c->stream_det != nullptr && n <= kLatencyFrames;
     for (int i = 0; i < nlev; ++i) {
         const AkzLevel& L = P.levels[i];
         const size_t fs = L.pixels();
@@ -2009,7 +2331,42 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
             fused_front = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
             const int t_front = AKZ_T_FRONT_SG2 + (int)L.deriv_sigma - 2;
-            if (fused_front) {
+            // the FED launches of the level: groups of up to fed_block steps, balanced sizes (5 -> 3 + 2)
+            std::vector<int> groups;
+            if (blocked)
+                for (int left = nsteps; left > 0;) {
+                    int ngr = (left + fed_block - 1) / fed_block;  // groups still to emit
+                    int g = (left + ngr - 1) / ngr;
+                    groups.push_back(g);
+                    left -= g;
+                }
+            // k_front_fed: front end + the first of those launches in one kernel (Lflow stays on chip unless a later
+            // launch of the level needs it).  First octave only: there a level is one or two launches, below it the
+            // 5 to 8 steps of a launch would need a three-patch halo.
+            const bool front_fed = c->fuse_front_fed && blocked && fused_front && !c->keep_all && !groups.empty() &&
+                                   groups[0] <= 7 && L.octave == 0;
+            if (front_fed) {
+                const int ng = (int)groups.size();
+                float* dst0 = ((ng - 1) % 2 == 0) ? bufA : bufB;
+                FedTaus ft;
+                for (int q = 0; q < kFedMaxBlock; ++q) ft.half_tau[q] = q < groups[0] ? 0.5f * (float)L.tau[q] : 0.0f;
+                OffK kk = make_offk(L.deriv_sigma);
+                const int t_ff = AKZ_T_FRONT_FED_SG2 + (int)L.deriv_sigma - 2;
+                akz_timer_begin(c, t_ff, s);
+#define AKZ_FF3(SGV, HPV, WFV)                                                                                           hipLaunchKernelGGL((k_front_fed<SGV, HPV, WFV>),                                                                                         dim3(akz_div_up(L.w, front_fed_tile(HPV)), akz_div_up(L.h, front_fed_tile(HPV)), (n + 1) / 2),                        dim3(256), 0, s, init, L.w, L.h, fs, n, t1, kk, ft, groups[0], dst0, S.Lflow[i], S.Lxy[i],                             (const float*)S.d_invk, (int)L.octave)
+#define AKZ_FF2(SGV, HPV)                                                                                                if (ng > 1) { AKZ_FF3(SGV, HPV, true); } else { AKZ_FF3(SGV, HPV, false); }
+#define AKZ_FF(SGV)                                                                                                      if (groups[0] <= 3) { AKZ_FF2(SGV, 1) } else { AKZ_FF2(SGV, 2) }
+                switch (L.deriv_sigma) {
+                case 2: AKZ_FF(2) break;
+                case 3: AKZ_FF(3) break;
+                default: AKZ_FF(4) break;
+                }
+#undef AKZ_FF
+#undef AKZ_FF2
+#undef AKZ_FF3
+                AKZ_LAUNCH_CHECK();
+                akz_timer_end(c, t_ff, s, 1, (uint64_t)fs * n);
+            } else if (fused_front) {
                 akz_timer_begin(c, t_front, s);
                 float* lsm_out = c->keep_all ? S.Lsm[i] : nullptr;  // Lsmooth stays on chip unless the taps want it
                 dim3 gridf(akz_div_up(L.w, kTW), akz_div_up(L.h, kTH), n);
@@ -2043,19 +2400,16 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             akz_timer_begin(c, AKZ_T_FED, s);
             const float* src = init;
             if (blocked) {
-                // temporally blocked: groups of up to fed_block steps per launch; the ping-pong parity is
-                // chosen per GROUP so that the last group lands in Lt[i]
-                std::vector<int> groups;
-                for (int left = nsteps; left > 0;) {
-                    int ngr = (left + fed_block - 1) / fed_block;  // groups still to emit
-                    int g = (left + ngr - 1) / ngr;                      // balanced sizes, e.g. 5 -> 3+2
-                    groups.push_back(g);
-                    left -= g;
-                }
+                // temporally blocked: the ping-pong parity is chosen per GROUP so that the last group lands in Lt[i]
                 const int ng = (int)groups.size();  // == nwrites
                 int j = 0;
                 for (int gi = 0; gi < ng; ++gi) {
                     float* dstb = ((ng - 1 - gi) % 2 == 0) ? bufA : bufB;
+                    if (gi == 0 && front_fed) {                    // k_front_fed did this launch
+                        j += groups[0];
+                        src = dstb;
+                        continue;
+                    }
                     FedTaus ft;
                     for (int q = 0; q < kFedMaxBlock; ++q) ft.half_tau[q] = q < groups[gi] ? 0.5f * (float)L.tau[j + q] : 0.0f;
 #define AKZ_FED_CASE(TT)                                                                                              \

@@ -100,8 +100,10 @@ enum {
     AKZ_OPT_CONTRAST_EXACT = 1u << 5,     /* contrast factor always through the exact histogram pass */
     AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6, /* test knob: odd frames through the exact pass (mixed pairs) */
     AKZ_OPT_TILE_KERNELS = 1u << 7,       /* the LDS-tile determinant kernels of round 1 instead of the row-streaming one */
-    AKZ_OPT_SERIAL_DET = 1u << 8          /* determinant / candidate kernels on the scale-space stream itself instead of
+    AKZ_OPT_SERIAL_DET = 1u << 8,         /* determinant / candidate kernels on the scale-space stream itself instead of
                                            * the side stream that takes them off the Lt -> Lt dependency chain */
+    AKZ_OPT_SPLIT_FRONT_FED = 1u << 9     /* level front end and first FED launch as two kernels (Lflow through HBM)
+                                           * instead of the fused k_front_fed */
 };
 typedef struct akz_options {
     uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */
@@ -418,7 +420,11 @@ enum {
     AKZ_T_REFINE = 12,    /* sub-pixel refinement + orientation (keypoint stream)              units: frames */
     AKZ_T_FED_PASS = 13,  /* = AKZ_T_FED with units = pixel-frames per launch */
     AKZ_T_FED_T1 = 14,    /* k_fed_pair<T> launches by T = 1..8 (ids 14..21), units = pixel-frames per launch */
-    AKZ_T_COUNT = 22
+    AKZ_T_FRONT_FED_SG2 = 22, /* fused level front end + first FED launch (k_front_fed), sigma 2..4: ids 22..24,
+                               * units = pixel-frames */
+    AKZ_T_FRONT_FED_SG3 = 23,
+    AKZ_T_FRONT_FED_SG4 = 24,
+    AKZ_T_COUNT = 25
 };
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);

@@ -20,7 +20,11 @@ MB = 128
 frames = bench.make_frames(torch, dev, 0, MB, 1)
 ak = Akaze.default()
 ak.max_keypoints = bench.CAP
-ctx = ak.context(bench.W, bench.H, MB)
+kw = {}
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    kw[k] = bool(int(v)) if k in ("det_side_stream", "stream_kernels", "frame_pairs") else int(v)
+ctx = ak.context(bench.W, bench.H, MB, options=_lib.make_options(**kw))
 best = 1e9
 for rep in range(6):
     torch.cuda.synchronize()
@@ -30,4 +34,4 @@ for rep in range(6):
     dt = time.perf_counter() - t
     if rep:
         best = min(best, dt)
-print(f"scale space: {MB / best:.1f} frames/s ({best * 1e3:.2f} ms per {MB} frames)")
+print(f"scale space {kw}: {MB / best:.1f} frames/s ({best * 1e3:.2f} ms per {MB} frames)")
