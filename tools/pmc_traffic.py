@@ -21,6 +21,9 @@ def family_key(name):
     if m:
         src = {"unsigned char": ",u8", "unsigned short": ",u16"}.get(m.group(3), "") if m.group(1) == "4" else ""
         return f"k_level_front2<{m.group(1)},{m.group(2)},..{src}>"
+    m = re.match(r"k_front_fed<(\d+),", n)
+    if m:
+        return f"k_front_fed<{m.group(1)},..>"
     m = re.match(r"k_det_stream<(\d+),", n)
     if m:
         return f"k_det_stream<{m.group(1)},..>"
