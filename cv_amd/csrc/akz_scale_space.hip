@@ -2344,7 +2344,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // launch of the level needs it).  First octave only: there a level is one or two launches, below it the
             // 5 to 8 steps of a launch would need a three-patch halo.
             const bool front_fed = c->fuse_front_fed && blocked && fused_front && !c->keep_all && !groups.empty() &&
-                                   groups[0] <= 7 && L.octave == 0;
+                                   groups[0] <= 7 && L.octave == 0;   // (octaves 1-3 measured: 9636 vs 9781 frames/s)
             if (front_fed) {
                 const int ng = (int)groups.size();
                 float* dst0 = ((ng - 1) % 2 == 0) ? bufA : bufB;
