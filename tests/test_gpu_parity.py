@@ -1132,6 +1132,7 @@ OPTION_SETS = [
     ("exact contrast, stream priorities", dict(contrast="exact", stream_priority=True)),
     ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
     ("determinant kernels on the scale-space stream", dict(det_side_stream=False)),
+    ("front end and FED as two kernels", dict(fuse_front_fed=False)),
 ]
 
 
@@ -1150,6 +1151,27 @@ def test_every_option_gives_the_same_bits(gpu, oracle, name, kw):
             _kp_eq(got[i][0], okp, f"{name} {w}x{h} frame {i}")
             _eq(got[i][1], od, f"{name} {w}x{h} frame {i} desc")
         ctx.close()
+
+
+@pytest.mark.parametrize("nfr", [1, 3, 4, 5, 16, 17])
+def test_call_size_selects_kernels_not_results(gpu, oracle, nfr):
+    """The library picks kernels by the number of frames of a call — up to 4: determinant kernels on the side stream and
+    up to 16 FED steps per launch; up to 8: rank sorts; up to 16: suppression chunks chained across workgroups; above:
+    one workgroup per frame, bitonic sorts.  Every frame of every call size equals the oracle byte for byte (832x480:
+    three octaves, more than one suppression chunk per frame)."""
+    akaze, _ = gpu
+    w, h = 832, 480
+    frames = [synth_frame(w, h, seed=5100 + (i % 3), n_rect=120, n_disc=120) for i in range(nfr)]
+    ctx = akaze.Context(akaze.Akaze.default(), w, h, nfr)
+    got = ctx.extract_batch(frames)
+    orc = oracle.Akaze(w, h, oracle.default_config())
+    want = [orc.extract(frames[i]) for i in range(min(nfr, 3))]
+    assert len(want[0][0]) > 1024                     # more than one suppression chunk of candidates
+    for i in range(nfr):
+        okp, od = want[i % 3]
+        _kp_eq(got[i][0], okp, f"call of {nfr} frames, frame {i}")
+        _eq(got[i][1], od, f"call of {nfr} frames, frame {i} desc")
+    ctx.close()
 
 
 def test_unknown_option_bits_are_refused(gpu):
