@@ -1245,6 +1245,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
     __syncthreads();
     // ---- 1b. Gaussian blur (sigma 1.0, 5 taps) of the thread's own patch ----
     v2f g[4][4];
+    v2f L[4][4];   // the patch itself: the FED steps start from it (taken here, the input window is about to be replaced)
     {
         v2f hb[8][4];
 #pragma unroll
@@ -1260,6 +1261,10 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o) hb[r][o] = lane4_dot_v<5>(v + o, taps.k);
+            if (r >= 2 && r < 6) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) L[r - 2][o] = v[o + 2];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1398,21 +1403,17 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
         }
     }
     // ---- 3. the FED steps, as k_fed_pair ----
-    v2f L[4][4];
+    // (k_fed_pair loads zeros outside the image: same here, for the image and the conductivity)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int y = y0 + r;
-        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;
         const bool in_img = col_in && y >= 0 && y < h;
-        if (in_img) {
-            const size_t o = (size_t)y * w + x0;
-            la = *reinterpret_cast<const float4*>(srca + o);
-            lb = *reinterpret_cast<const float4*>(srcb + o);
-        }
-        L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
         if (!in_img) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) C[r][c] = splat(0.0f);
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = splat(0.0f);
+                C[r][c] = splat(0.0f);
+            }
         }
     }
     __syncthreads();   // the blurred window is dead: the exchange buffers take the space
