@@ -1199,6 +1199,14 @@ constexpr int kFFInC = kFFW + 8;               // input columns held (4 either s
 constexpr int kFFGS = kFFW + 4;                // row stride of the blurred window in LDS (2 apron columns either side)
 constexpr int front_fed_tile(int HP) { return kFFW - 8 * HP; }
 
+// LDS rows of k_front_fed are stored like the two-frame tiles above: the 16-byte chunks ({col, a}, {col, b}, {col+1, a},
+// {col+1, b}) of a row in two planes, even chunks first, so that the sixteen threads of a patch row, which read chunks
+// two apart, touch consecutive 16-byte words.  RS = chunks per row (even).
+template <int RS>
+__device__ __forceinline__ int ff_chunk(int row, int ci) { return row * RS + ((ci & 1) ? RS / 2 : 0) + (ci >> 1); }
+template <int RS>
+__device__ __forceinline__ int ff_elem(int row, int col) { return 2 * ff_chunk<RS>(row, col >> 1) + (col & 1); }
+
 template <int SG, int HP, bool WRITE_FLOW>
 __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
                                                       GaussTaps taps, OffK k, FedTaus taus, int nsteps,
@@ -1229,16 +1237,16 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
                 const size_t o = (size_t)(wy0 - 2 + iy) * w + (wx0 - 4 + 4 * c4);
                 const float4 a = *reinterpret_cast<const float4*>(srca + o);
                 const float4 b = *reinterpret_cast<const float4*>(srcb + o);
-                float4* d = reinterpret_cast<float4*>(&s_buf[iy * kFFInC + 4 * c4]);
-                d[0] = make_float4(a.x, b.x, a.y, b.y);
-                d[1] = make_float4(a.z, b.z, a.w, b.w);
+                float4* d = reinterpret_cast<float4*>(s_buf);
+                d[ff_chunk<kFFInC / 2>(iy, 2 * c4)] = make_float4(a.x, b.x, a.y, b.y);
+                d[ff_chunk<kFFInC / 2>(iy, 2 * c4 + 1)] = make_float4(a.z, b.z, a.w, b.w);
             }
         } else {
             for (int idx = tid; idx < kFFIn * kFFInC; idx += 256) {
                 const int iy = idx / kFFInC, ix = idx - iy * kFFInC;
                 const int cx = clampi(wx0 - 4 + ix, 0, w - 1), cy = clampi(wy0 - 2 + iy, 0, h - 1);
                 const size_t o = (size_t)cy * w + cx;
-                s_buf[idx] = (v2f){srca[o], srcb[o]};
+                s_buf[ff_elem<kFFInC / 2>(iy, ix)] = (v2f){srca[o], srcb[o]};
             }
         }
     }
@@ -1251,11 +1259,11 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             // window column X sits at input column X + 4; the patch needs columns 4 pc - 2 .. 4 pc + 5 of the window
-            const float4* row = reinterpret_cast<const float4*>(&s_buf[(4 * pr + r) * kFFInC + 4 * pc + 2]);
+            const float4* tile = reinterpret_cast<const float4*>(s_buf);
             v2f v[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f4v t = lds_chunk(row + q);
+                const f4v t = lds_chunk(tile + ff_chunk<kFFInC / 2>(4 * pr + r, 2 * pc + 1 + q));
                 v[2 * q] = (v2f){t.x, t.y};
                 v[2 * q + 1] = (v2f){t.z, t.w};
             }
@@ -1275,13 +1283,13 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             }
     }
     __syncthreads();   // every thread has read its input: the blurred window takes the space
-    // blurred window: pixel (X, Y) of the window at s_g[(Y + 1) * kFFGS + X + 2]
+    // blurred window: pixel (X, Y) of the window is element (row Y + 1, column X + 2) of s_g
     v2f* s_g = s_buf;
+    float4* g4 = reinterpret_cast<float4*>(s_buf);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float4* d = reinterpret_cast<float4*>(&s_g[(4 * pr + j + 1) * kFFGS + 4 * pc + 2]);
-        d[0] = make_float4(g[j][0].x, g[j][0].y, g[j][1].x, g[j][1].y);
-        d[1] = make_float4(g[j][2].x, g[j][2].y, g[j][3].x, g[j][3].y);
+        g4[ff_chunk<kFFGS / 2>(4 * pr + j + 1, 2 * pc + 1)] = make_float4(g[j][0].x, g[j][0].y, g[j][1].x, g[j][1].y);
+        g4[ff_chunk<kFFGS / 2>(4 * pr + j + 1, 2 * pc + 2)] = make_float4(g[j][2].x, g[j][2].y, g[j][3].x, g[j][3].y);
     }
     __syncthreads();
     // positions outside the image take the blurred value at their clamped coordinate (the derivative filters clamp
@@ -1295,7 +1303,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
                 const int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
                 if (xc != x || yc != y) {
                     const int X = clampi(xc - wx0, 0, kFFW - 1), Y = clampi(yc - wy0, 0, kFFW - 1);
-                    s_g[(4 * pr + j + 1) * kFFGS + 4 * pc + o + 2] = s_g[(Y + 1) * kFFGS + X + 2];
+                    s_g[ff_elem<kFFGS / 2>(4 * pr + j + 1, 4 * pc + o + 2)] = s_g[ff_elem<kFFGS / 2>(Y + 1, X + 2)];
                 }
             }
         __syncthreads();
@@ -1312,11 +1320,10 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             // source row 4 pr - 1 + r, window columns 4 pc - 2 .. 4 pc + 5 (two 16-byte chunks either side of the patch)
-            const float4* row = reinterpret_cast<const float4*>(&s_g[(4 * pr + r) * kFFGS + 4 * pc]);
             v2f v[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f4v t = lds_chunk(row + q);
+                const f4v t = lds_chunk(g4 + ff_chunk<kFFGS / 2>(4 * pr + r, 2 * pc + q));
                 v[2 * q] = (v2f){t.x, t.y};
                 v[2 * q + 1] = (v2f){t.z, t.w};
             }
@@ -1369,13 +1376,12 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             // rows Y - SG, Y, Y + SG of the window, columns 4 pc - 4 .. 4 pc + 7
             v2f m[12], z[12], p[12];
             const int Y = 4 * pr + j;
-            const float4* rm = reinterpret_cast<const float4*>(&s_g[(Y - SG + 1) * kFFGS + 4 * pc - 2]);
-            const float4* rz = reinterpret_cast<const float4*>(&s_g[(Y + 1) * kFFGS + 4 * pc - 2]);
-            const float4* rp = reinterpret_cast<const float4*>(&s_g[(Y + SG + 1) * kFFGS + 4 * pc - 2]);
             constexpr int Q0 = (4 - SG) / 2, Q1 = (7 + SG) / 2;   // 16-byte chunks that hold columns 4 - SG .. 7 + SG of the 12
 #pragma unroll
             for (int q = Q0; q <= Q1; ++q) {
-                const f4v a = lds_chunk(rm + q), b = lds_chunk(rz + q), c = lds_chunk(rp + q);
+                const f4v a = lds_chunk(g4 + ff_chunk<kFFGS / 2>(Y - SG + 1, 2 * pc - 1 + q));
+                const f4v b = lds_chunk(g4 + ff_chunk<kFFGS / 2>(Y + 1, 2 * pc - 1 + q));
+                const f4v c = lds_chunk(g4 + ff_chunk<kFFGS / 2>(Y + SG + 1, 2 * pc - 1 + q));
                 m[2 * q] = (v2f){a.x, a.y}; m[2 * q + 1] = (v2f){a.z, a.w};
                 z[2 * q] = (v2f){b.x, b.y}; z[2 * q + 1] = (v2f){b.z, b.w};
                 p[2 * q] = (v2f){c.x, c.y}; p[2 * q + 1] = (v2f){c.z, c.w};
