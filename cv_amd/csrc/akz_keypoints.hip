@@ -1323,6 +1323,215 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe_fast(LevelTable T,
     if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A13 alone, one THREAD per keypoint: the sub-pixel fit needs nine determinant values the candidate list already
+// carries.  The orientation (A14) moves to the descriptor kernel below, where its arithmetic runs in the shadow of
+// the descriptor's gathers (k_refine with both is VALU-bound, k_describe_fast latency-bound: one after the other
+// they cost the sum, fused the larger of the two).
+__global__ __launch_bounds__(256) void k_refine_pos(LevelTable T, const DevKp* __restrict__ in,
+                                                    const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                    DevKp* __restrict__ out, uint32_t* __restrict__ flag,
+                                                    const float* __restrict__ cand_nb, uint32_t max_cand)
+{
+    const int frame = blockIdx.y;
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t ki = blockIdx.x * 256 + threadIdx.x;
+    if (ki >= n) return;
+    DevKp kp = in[(size_t)frame * stride + ki];
+    const LevelDesc* Lp = &T.L[kp.class_id];
+    // do_subpixel_refinement, :301-347
+    const float ratio = ldexpf(1.0f, (int)kp.octave);
+    int x = (int)sat_u32(roundf(kp.x / ratio));
+    int y = (int)sat_u32(roundf(kp.y / ratio));
+    const uint32_t cidx = __float_as_uint(kp.angle);   // the candidate's index inside its level (k_sup_resolve / k_suppress)
+    const float4* nbp = reinterpret_cast<const float4*>(cand_nb + (((size_t)frame * kAkzMaxLevels + kp.class_id) * max_cand + cidx) * 8);
+    const float4 n0 = nbp[0], n1 = nbp[1];
+    kp.angle = 0.0f;
+    float x_i = kp.response;   // Ldet at the pixel (> threshold > 0, so |v| = v)
+    float x_m_y_m = n0.x, y_m = n0.y, x_p_y_m = n0.z, x_m = n0.w, x_p = n1.x, x_m_y_p = n1.y, y_p = n1.z, x_p_y_p = n1.w;
+    float d_x = 0.5f * (x_p - x_m);
+    float d_y = 0.5f * (y_p - y_m);
+    float d_xx = x_p + x_m - 2.0f * x_i;
+    float d_yy = y_p + y_m - 2.0f * x_i;
+    float d_xy = 0.25f * (x_p_y_p + x_m_y_m) - 0.25f * (x_p_y_m + x_m_y_p);
+    float inv_det_a = 1.0f / (d_xx * d_yy - d_xy * d_xy);
+    float inv_a0 = inv_det_a * d_yy;
+    float inv_a1 = inv_det_a * -d_xy;
+    float inv_a2 = inv_det_a * -d_xy;
+    float inv_a3 = inv_det_a * d_xx;
+    float dst0 = -d_x * inv_a0 + -d_y * inv_a1;
+    float dst1 = -d_x * inv_a2 + -d_y * inv_a3;
+    const bool keep = fabsf(dst0) <= 1.0f && fabsf(dst1) <= 1.0f;
+    if (keep) {
+        float nx = (float)x + dst0, ny = (float)y + dst1;
+        float power = ldexpf(1.0f, (int)Lp->octave);
+        kp.x = nx * power + 0.5f * (power - 1.0f);
+        kp.y = ny * power + 0.5f * (power - 1.0f);
+        kp.size = kp.size * 2.0f;
+    }
+    out[(size_t)frame * stride + ki] = kp;
+    flag[(size_t)frame * stride + ki] = keep ? 1u : 0u;
+}
+
+// A14 + A16 + A17 for the default pattern: main orientation (as in k_refine), then the descriptor (as in
+// k_describe_fast), one wave per keypoint, four keypoints per block (the orientation tables are staged once per
+// block).  The wave's LDS segment is used twice: weighted gradients and window masks of the 109 orientation samples,
+// then the 441 lattice values of the descriptor.  The angle is written back into the keypoint list.
+constexpr int kODWaves = 4;
+__global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
+                                                                   const DescTables* __restrict__ desc_p,
+                                                                   DevKp* __restrict__ kps,
+                                                                   const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                                   const uint32_t* __restrict__ perm,
+                                                                   akz_descriptor* __restrict__ out,
+                                                                   uint32_t* __restrict__ flag, uint32_t* __restrict__ err)
+{
+    constexpr int LAT = 21, NS = LAT * LAT, NIT = (NS + 63) / 64, SMAX = 448;
+    __shared__ float s_bnd[128];
+    __shared__ uint2 s_mopen[128], s_meq[128];
+    __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 96];
+    const OriTables& c_ori = *ori_p;
+    const DescTables& c_desc = *desc_p;
+    if (threadIdx.x < 128) {
+        s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
+        s_mopen[threadIdx.x] = c_ori.m_open[threadIdx.x];
+        s_meq[threadIdx.x] = c_ori.m_eq[threadIdx.x];
+    }
+    __syncthreads();          // the only block-level barrier: waves are independent from here on
+    const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+    const int frame = (int)blk.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t vi = blk.x * kODWaves + wv;
+    if (vi >= n) return;  // whole wave
+    const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
+    DevKp kp = kps[(size_t)frame * stride + ki];
+    const LevelDesc& L = T.L[kp.class_id];
+    const float ratio = (float)(1u << kp.octave);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    const float2* LXY = L.Lxy + (size_t)frame * L.fs;
+    const int W = L.w, Hh = L.h;
+    // ---- compute_main_orientation, scale_space_extrema.rs:229-288 ----
+    {
+        float2* s_r = reinterpret_cast<float2*>(s_w[wv]);             // [112] weighted {Lx, Ly} of every sample
+        uint32_t* s_msk = reinterpret_cast<uint32_t*>(s_w[wv] + 224);   // [112][2] windows that contain its angle
+        const float s = roundf(0.5f * kp.size / ratio);
+        for (int idx = lane; idx < 109; idx += 64) {
+            unsigned iy = sat_u32(roundf(yf + (float)c_ori.dj[idx] * s));
+            unsigned ix = sat_u32(roundf(xf + (float)c_ori.di[idx] * s));
+            if (ix >= (unsigned)W || iy >= (unsigned)Hh) {  // the reference would panic here
+                atomicOr(err, 8u);
+                ix = min(ix, (unsigned)W - 1u);
+                iy = min(iy, (unsigned)Hh - 1u);
+            }
+            const float g = c_ori.gw[idx];
+            const float2 dxy = LXY[(size_t)iy * W + ix];
+            const float rx = g * dxy.x;
+            const float ry = g * dxy.y;
+            s_r[idx] = make_float2(rx, ry);
+            // window membership of this sample (:261-287) from the end-point table (see k_refine)
+            const float ang = fast_atan2_equiv(ry, rx);
+            int r = 0;
+#pragma unroll
+            for (int step = 64; step > 0; step >>= 1) r += s_bnd[r + step - 1] < ang ? step : 0;
+            const uint2 mm = (r < 128 && s_bnd[r & 127] == ang) ? s_meq[r & 127] : s_mopen[r & 127];
+            s_msk[idx * 2] = mm.x;
+            s_msk[idx * 2 + 1] = mm.y;
+        }
+        float val = -1.0f, sum_x = 0.0f, sum_y = 0.0f;
+        if (lane < c_ori.n_win) {
+            // branch-free: a sample outside the window adds +0.0, which leaves the sums bit-identical to skipping it
+            const int word = lane >> 5, bit = lane & 31;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
+#pragma unroll 4
+            for (int k = 0; k < 109; ++k) {
+                const bool in = (s_msk[k * 2 + word] >> bit) & 1u;
+                const float2 r = s_r[k];
+                sum += (v2f){in ? r.x : 0.0f, in ? r.y : 0.0f};
+            }
+            sum_x = sum.x;
+            sum_y = sum.y;
+            val = sum_x * sum_x + sum_y * sum_y;
+        }
+        // the serial loop keeps the FIRST window whose val exceeds every earlier one
+        float m = val;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        unsigned long long bal = __ballot(val == m && lane < c_ori.n_win);
+        int win = __ffsll((long long)bal) - 1;
+        float best_sx = __shfl(sum_x, win), best_sy = __shfl(sum_y, win);
+        kp.angle = (m > 0.0f) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
+        if (lane == 0) kps[(size_t)frame * stride + ki].angle = kp.angle;
+    }
+    // the segment changes hands: every LDS read above has returned before the writes below are issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- get_mldb_descriptor, descriptors.rs:66-72 (as k_describe_fast) ----
+    float* s_ri = s_w[wv];
+    float* s_dx = s_w[wv] + SMAX;
+    float* s_dy = s_w[wv] + 2 * SMAX;
+    float* s_val = s_w[wv] + 3 * SMAX;
+    const float scale = roundf(0.5f * kp.size / ratio);
+    const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
+    const float* LT = L.Lt + (size_t)frame * L.fs;
+    bool oob = false;
+    int idx[NIT], canon[NIT];
+    const bool k_fast = fabsf(co) > fabsf(si);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
+        const bool on = s < NS;
+        const int qa = s / LAT, qb = s - qa * LAT;
+        const int kq = k_fast ? qb : qa, lq = k_fast ? qa : qb;
+        canon[it] = kq * LAT + lq;                       // position in the (k outer, l inner) lattice the sums walk
+        const float kf = (float)(kq - 10), lf = (float)(lq - 10);
+        // descriptors.rs:127-128, exact expression order
+        float sample_y = yf + (lf * co * scale + kf * si * scale);
+        float sample_x = xf + (-lf * si * scale + kf * co * scale);
+        int y1 = sat_i32(roundf(sample_y));
+        int x1 = sat_i32(roundf(sample_x));
+        bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
+        oob |= on && bad;   // Error::SampleOutOfBounds in any grid drops the keypoint (descriptors.rs:28)
+        idx[it] = (on && !bad) ? y1 * W + x1 : 0;
+    }
+    float ri[NIT];
+    float2 dd[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        ri[it] = LT[idx[it]];
+        dd[it] = LXY[idx[it]];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = it * 64 + lane;
+        float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
+        float rrx = -dd[it].x * si + dd[it].y * co;
+        if (s < NS) {
+            s_ri[canon[it]] = ri[it];
+            s_dx[canon[it]] = rrx;
+            s_dy[canon[it]] = rry;
+        }
+    }
+    oob = __any(oob);
+    if (!oob) {
+        desc_cells<10, 2, 0>(s_ri, s_dx, s_dy, s_val, lane);
+        desc_cells<7, 3, 12>(s_ri, s_dx, s_dy, s_val, lane);
+        desc_cells<5, 4, 39>(s_ri, s_dx, s_dy, s_val, lane);
+    }
+    // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
+    uint32_t byte = 0;
+    if (!oob) {
+        for (int t = 0; t < 8; ++t) {
+            int b = lane * 8 + t;
+            if (b < c_desc.n_bits) {
+                float va = s_val[c_desc.cmp_a[b]], vb = s_val[c_desc.cmp_b[b]];
+                byte |= (va > vb ? 1u : 0u) << t;
+            }
+        }
+    }
+    out[(size_t)frame * stride + ki].bytes[lane] = (uint8_t)byte;
+    if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
+}
+
 void build_level_table(akz_ctx* c, LevelTable* T)
 {
     const AkzPlan& P = c->plan;
@@ -1523,8 +1732,16 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A13 + A14
     const uint32_t kw = (uint32_t)akz_div_up((int)c->max_kp, 4);
     akz_timer_begin(c, AKZ_T_REFINE, s);
-    hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, S.d_kp_a, S.d_n_a, c->max_kp, S.d_kp_b,
-                       S.d_flag_b, c->d_err, (const float*)S.d_cand_nb, c->max_cand);
+    // default pattern: the orientation is computed by the descriptor kernel (k_orient_describe); here only the fit
+    // (not with the parity taps on: akz_debug_get_keypoints stage 1 is the list after refinement AND orientation)
+    const bool fast_desc = c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3;
+    const bool orient_in_desc = fast_desc && !c->keep_all;
+    if (orient_in_desc)
+        hipLaunchKernelGGL(k_refine_pos, dim3((uint32_t)akz_div_up((int)c->max_kp, 256), n), dim3(256), 0, s, T, S.d_kp_a, S.d_n_a,
+                           c->max_kp, S.d_kp_b, S.d_flag_b, (const float*)S.d_cand_nb, c->max_cand);
+    else
+        hipLaunchKernelGGL(k_refine, dim3(kw, n), dim3(256), 0, s, T, (const OriTables*)c->d_ori, S.d_kp_a, S.d_n_a, c->max_kp, S.d_kp_b,
+                           S.d_flag_b, c->d_err, (const float*)S.d_cand_nb, c->max_cand);
     AKZ_LAUNCH_CHECK();
     akz_timer_end(c, AKZ_T_REFINE, s, 1, (uint64_t)n);
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_kp_b, (const akz_descriptor*)nullptr,
@@ -1555,8 +1772,13 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
             hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
                                S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
-                           S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);
+        if (orient_in_desc)
+            hipLaunchKernelGGL(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
+                               (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm,
+                               S.d_desc_tmp, S.d_flag_d, c->d_err);
+        else
+            hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T,
+                               (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);
     } else {
         hipLaunchKernelGGL(k_describe, dim3(kw, n), dim3(256), 0, s, T, (const DescTables*)c->d_desc, S.d_kp_d,
                            S.d_n_d, c->max_kp, S.d_desc_tmp, S.d_flag_d);
