@@ -1190,11 +1190,13 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
 //      threads of the useful region the multiscale Scharr {Lx, Ly} of theirs (-> HBM);
 //   3. the FED steps run exactly as in k_fed_pair (same exchange through LDS, same border rules).
 // HBM traffic: 4 B in (Lt), 4 B (Lt') + 8 B ({Lx, Ly}) out = 16 B/pixel for what took 28.
-// Validity: the conductivity needs the blurred ring around a pixel, so it is right on window pixels 1..62 and a launch
-// of T steps is right 1 + T pixels inside the window: HP halo patches serve T <= 4 HP - 1 steps (k_fed_pair: 4 HP).
+// Validity: the conductivity of the window's outermost pixels needs the blurred values one pixel outside it, so the
+// blur also covers that ring (260 pixels, one or two per thread) when RING is set; a launch of T steps is then right T
+// pixels inside the window, as in k_fed_pair: HP halo patches serve T <= 4 HP steps — without the ring (cheaper by
+// 6 %) the conductivity is right on window pixels 1..62 only and HP patches serve T <= 4 HP - 1.
 // Every value is computed by the same expression, in the same order, as in k_level_front2 / k_fed_pair.
 constexpr int kFFW = 64;                       // window edge
-constexpr int kFFIn = kFFW + 4;                // input rows (blur radius 2 either side)
+constexpr int kFFIn = kFFW + 6;                // input rows: the window, its one-pixel ring, the blur radius 2
 constexpr int kFFInC = kFFW + 8;               // input columns held (4 either side: whole 16-byte chunks)
 constexpr int kFFGS = kFFW + 4;                // row stride of the blurred window in LDS (2 apron columns either side)
 constexpr int front_fed_tile(int HP) { return kFFW - 8 * HP; }
@@ -1207,7 +1209,7 @@ __device__ __forceinline__ int ff_chunk(int row, int ci) { return row * RS + ((c
 template <int RS>
 __device__ __forceinline__ int ff_elem(int row, int col) { return 2 * ff_chunk<RS>(row, col >> 1) + (col & 1); }
 
-template <int SG, int HP, bool WRITE_FLOW>
+template <int SG, int HP, bool RING, bool WRITE_FLOW>
 __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
                                                       GaussTaps taps, OffK k, FedTaus taus, int nsteps,
                                                       float* __restrict__ out_lt, float* __restrict__ out_flow,
@@ -1228,13 +1230,13 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
     const int wx0 = (int)tile.x * U - 4 * HP, wy0 = (int)tile.y * U - 4 * HP;   // window origin in the image
     const float* srca = in + (size_t)fa * fs;
     const float* srcb = in + (size_t)fb * fs;
-    // ---- 1a. input window: rows wy0 - 2 .., columns wx0 - 4 .., clamped coordinates outside the image ----
+    // ---- 1a. input window: rows wy0 - 3 .., columns wx0 - 4 .., clamped coordinates outside the image ----
     {
-        const bool inside = wx0 >= 4 && wx0 + kFFW + 4 <= w && wy0 >= 2 && wy0 + kFFW + 2 <= h;
+        const bool inside = wx0 >= 4 && wx0 + kFFW + 4 <= w && wy0 >= 3 && wy0 + kFFW + 3 <= h;
         if (inside) {
             for (int idx = tid; idx < kFFIn * (kFFInC / 4); idx += 256) {
                 const int iy = idx / (kFFInC / 4), c4 = idx - iy * (kFFInC / 4);
-                const size_t o = (size_t)(wy0 - 2 + iy) * w + (wx0 - 4 + 4 * c4);
+                const size_t o = (size_t)(wy0 - 3 + iy) * w + (wx0 - 4 + 4 * c4);
                 const float4 a = *reinterpret_cast<const float4*>(srca + o);
                 const float4 b = *reinterpret_cast<const float4*>(srcb + o);
                 float4* d = reinterpret_cast<float4*>(s_buf);
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
         } else {
             for (int idx = tid; idx < kFFIn * kFFInC; idx += 256) {
                 const int iy = idx / kFFInC, ix = idx - iy * kFFInC;
-                const int cx = clampi(wx0 - 4 + ix, 0, w - 1), cy = clampi(wy0 - 2 + iy, 0, h - 1);
+                const int cx = clampi(wx0 - 4 + ix, 0, w - 1), cy = clampi(wy0 - 3 + iy, 0, h - 1);
                 const size_t o = (size_t)cy * w + cx;
                 s_buf[ff_elem<kFFInC / 2>(iy, ix)] = (v2f){srca[o], srcb[o]};
             }
@@ -1263,7 +1265,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             v2f v[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f4v t = lds_chunk(tile + ff_chunk<kFFInC / 2>(4 * pr + r, 2 * pc + 1 + q));
+                const f4v t = lds_chunk(tile + ff_chunk<kFFInC / 2>(4 * pr + r + 1, 2 * pc + 1 + q));
                 v[2 * q] = (v2f){t.x, t.y};
                 v[2 * q + 1] = (v2f){t.z, t.w};
             }
@@ -1282,6 +1284,32 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
                 g[j][o] = lane4_dot_v<5>(col, taps.k);
             }
     }
+    // the ring around the window: pixel t of (top row, bottom row, left column, right column), same two passes
+    v2f ring[2];
+    int ring_x[2], ring_y[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = tid + 256 * q;
+        int X = 0, Y = 0;
+        if (t < kFFW + 2) { X = t - 1; Y = -1; }
+        else if (t < 2 * (kFFW + 2)) { X = t - (kFFW + 2) - 1; Y = kFFW; }
+        else if (t < 2 * (kFFW + 2) + kFFW) { X = -1; Y = t - 2 * (kFFW + 2); }
+        else { X = kFFW; Y = t - 2 * (kFFW + 2) - kFFW; }
+        ring_x[q] = X;
+        ring_y[q] = Y;
+        ring[q] = splat(0.0f);
+        if (RING && t < 4 * kFFW + 4) {
+            v2f hr[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                v2f v[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) v[i] = s_buf[ff_elem<kFFInC / 2>(Y + 1 + r, X + 2 + i)];   // row Y - 2 + r, column X - 2 + i
+                hr[r] = lane4_dot_v<5>(v, taps.k);
+            }
+            ring[q] = lane4_dot_v<5>(hr, taps.k);
+        }
+    }
     __syncthreads();   // every thread has read its input: the blurred window takes the space
     // blurred window: pixel (X, Y) of the window is element (row Y + 1, column X + 2) of s_g
     v2f* s_g = s_buf;
@@ -1291,10 +1319,13 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
         g4[ff_chunk<kFFGS / 2>(4 * pr + j + 1, 2 * pc + 1)] = make_float4(g[j][0].x, g[j][0].y, g[j][1].x, g[j][1].y);
         g4[ff_chunk<kFFGS / 2>(4 * pr + j + 1, 2 * pc + 2)] = make_float4(g[j][2].x, g[j][2].y, g[j][3].x, g[j][3].y);
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (RING && tid + 256 * q < 4 * kFFW + 4) s_g[ff_elem<kFFGS / 2>(ring_y[q] + 1, ring_x[q] + 2)] = ring[q];
     __syncthreads();
     // positions outside the image take the blurred value at their clamped coordinate (the derivative filters clamp
     // Lsmooth, image.rs:230-236 / :287-300): reads touch in-image positions only, writes out-of-image positions only
-    if (wx0 < 0 || wx0 + kFFW > w || wy0 < 0 || wy0 + kFFW > h) {
+    if (wx0 < 1 || wx0 + kFFW + 1 > w || wy0 < 1 || wy0 + kFFW + 1 > h) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1302,8 +1333,18 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
                 const int x = wx0 + 4 * pc + o, y = wy0 + 4 * pr + j;
                 const int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
                 if (xc != x || yc != y) {
-                    const int X = clampi(xc - wx0, 0, kFFW - 1), Y = clampi(yc - wy0, 0, kFFW - 1);
+                    const int X = clampi(xc - wx0, -1, kFFW), Y = clampi(yc - wy0, -1, kFFW);
                     s_g[ff_elem<kFFGS / 2>(4 * pr + j + 1, 4 * pc + o + 2)] = s_g[ff_elem<kFFGS / 2>(Y + 1, X + 2)];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (RING && tid + 256 * q < 4 * kFFW + 4) {
+                const int x = wx0 + ring_x[q], y = wy0 + ring_y[q];
+                const int xc = clampi(x, 0, w - 1), yc = clampi(y, 0, h - 1);
+                if (xc != x || yc != y) {
+                    const int X = clampi(xc - wx0, -1, kFFW), Y = clampi(yc - wy0, -1, kFFW);
+                    s_g[ff_elem<kFFGS / 2>(ring_y[q] + 1, ring_x[q] + 2)] = s_g[ff_elem<kFFGS / 2>(Y + 1, X + 2)];
                 }
             }
         __syncthreads();
@@ -2351,7 +2392,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // launch of the level needs it).  First octave only: there a level is one or two launches, below it the
             // 5 to 8 steps of a launch would need a three-patch halo.
             const bool front_fed = c->fuse_front_fed && blocked && fused_front && !c->keep_all && !groups.empty() &&
-                                   groups[0] <= 7 && L.octave == 0;   // (octaves 1-3 measured: 9636 vs 9781 frames/s)
+                                   groups[0] <= 4 && L.octave == 0;   // (first-octave launches hold at most 4 steps; octaves 1-3 measured: 9636 vs 9781 frames/s)
             if (front_fed) {
                 const int ng = (int)groups.size();
                 float* dst0 = ((ng - 1) % 2 == 0) ? bufA : bufB;
@@ -2360,9 +2401,14 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 OffK kk = make_offk(L.deriv_sigma);
                 const int t_ff = AKZ_T_FRONT_FED_SG2 + (int)L.deriv_sigma - 2;
                 akz_timer_begin(c, t_ff, s);
-#define AKZ_FF3(SGV, HPV, WFV)                                                                                           hipLaunchKernelGGL((k_front_fed<SGV, HPV, WFV>),                                                                                         dim3(akz_div_up(L.w, front_fed_tile(HPV)), akz_div_up(L.h, front_fed_tile(HPV)), (n + 1) / 2),                        dim3(256), 0, s, init, L.w, L.h, fs, n, t1, kk, ft, groups[0], dst0, S.Lflow[i], S.Lxy[i],                             (const float*)S.d_invk, (int)L.octave)
-#define AKZ_FF2(SGV, HPV)                                                                                                if (ng > 1) { AKZ_FF3(SGV, HPV, true); } else { AKZ_FF3(SGV, HPV, false); }
-#define AKZ_FF(SGV)                                                                                                      if (groups[0] <= 3) { AKZ_FF2(SGV, 1) } else { AKZ_FF2(SGV, 2) }
+#define AKZ_FF3(SGV, HPV, RGV, WFV)                                                                                  \
+    hipLaunchKernelGGL((k_front_fed<SGV, HPV, RGV, WFV>),                                                             \
+                       dim3(akz_div_up(L.w, front_fed_tile(HPV)), akz_div_up(L.h, front_fed_tile(HPV)), (n + 1) / 2), \
+                       dim3(256), 0, s, init, L.w, L.h, fs, n, t1, kk, ft, groups[0], dst0, S.Lflow[i], S.Lxy[i],      \
+                       (const float*)S.d_invk, (int)L.octave)
+#define AKZ_FF2(SGV, HPV, RGV) if (ng > 1) { AKZ_FF3(SGV, HPV, RGV, true); } else { AKZ_FF3(SGV, HPV, RGV, false); }
+#define AKZ_FF(SGV)                                                                                                  \
+    if (groups[0] <= 3) { AKZ_FF2(SGV, 1, false) } else { AKZ_FF2(SGV, 1, true) }
                 switch (L.deriv_sigma) {
                 case 2: AKZ_FF(2) break;
                 case 3: AKZ_FF(3) break;
