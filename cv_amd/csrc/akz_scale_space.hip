@@ -53,11 +53,25 @@ __device__ __forceinline__ uint3 xcd_tile(uint3 bid, uint3 grid)
     return make_uint3(rem - y * grid.x, y, z);
 }
 
+// f32::from(v) / 255f32 and / 65535f32 (image.rs:54, :57-66) are true IEEE divisions per pixel.  For the integers
+// 0..255 over 255 and 0..65535 over 65535 the quotient is reproduced bit for bit by one multiply by the rounded
+// reciprocal and one Newton correction — q0 = v * r, q = fma(fma(-d, q0, v), r, q0) — checked exhaustively over both
+// ranges (tests/test_abi.py: test_pixel_normalisation_shortcut_is_exact); the compiler's division is ~11 instructions.
+__device__ __forceinline__ float px_over_255(float v)
+{
+    const float r = 1.0f / 255.0f, q0 = v * r;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, v), r, q0);
+}
+__device__ __forceinline__ float px_over_65535(float v)
+{
+    const float r = 1.0f / 65535.0f, q0 = v * r;
+    return __builtin_fmaf(__builtin_fmaf(-65535.0f, q0, v), r, q0);
+}
 __device__ __forceinline__ float load_px(const float* p, size_t i) { return p[i]; }
 // image.rs:54 — f32::from(v) / 255f32: a true IEEE division per pixel.
-__device__ __forceinline__ float load_px(const uint8_t* p, size_t i) { return (float)p[i] / 255.0f; }
+__device__ __forceinline__ float load_px(const uint8_t* p, size_t i) { return px_over_255((float)p[i]); }
 // image.rs:57-66 — Luma16: f32::from(v) / 65535f32
-__device__ __forceinline__ float load_px(const uint16_t* p, size_t i) { return (float)p[i] / 65535.0f; }
+__device__ __forceinline__ float load_px(const uint16_t* p, size_t i) { return px_over_65535((float)p[i]); }
 
 // wide::f32x4 accumulate + reduce_add as used by horizontal_filter/vertical_filter
 // (image.rs:242-247, :320-325): tap i goes to lane i&3, lanes accumulate in chunk order with an
@@ -213,8 +227,8 @@ __device__ __forceinline__ float4 load4_px(const float* p, size_t i) { return *r
 __device__ __forceinline__ float4 load4_px(const uint8_t* p, size_t i)
 {
     uint32_t u = *reinterpret_cast<const uint32_t*>(p + i);
-    return make_float4((float)(u & 0xFFu) / 255.0f, (float)((u >> 8) & 0xFFu) / 255.0f,
-                       (float)((u >> 16) & 0xFFu) / 255.0f, (float)(u >> 24) / 255.0f);
+    return make_float4(px_over_255((float)(u & 0xFFu)), px_over_255((float)((u >> 8) & 0xFFu)),
+                       px_over_255((float)((u >> 16) & 0xFFu)), px_over_255((float)(u >> 24)));
 }
 
 // k_level_front for two frames per block (requires w % 4 == 0 so that every 4-column strip is 16-byte
@@ -233,13 +247,13 @@ __device__ __forceinline__ uint2 load4_raw(const uint16_t* p, size_t i) { return
 __device__ __forceinline__ float4 raw_px(float4 r) { return r; }
 __device__ __forceinline__ float4 raw_px(uint2 u)     // image.rs:57-66 — f32::from(v) / 65535f32
 {
-    return make_float4((float)(u.x & 0xFFFFu) / 65535.0f, (float)(u.x >> 16) / 65535.0f,
-                       (float)(u.y & 0xFFFFu) / 65535.0f, (float)(u.y >> 16) / 65535.0f);
+    return make_float4(px_over_65535((float)(u.x & 0xFFFFu)), px_over_65535((float)(u.x >> 16)),
+                       px_over_65535((float)(u.y & 0xFFFFu)), px_over_65535((float)(u.y >> 16)));
 }
 __device__ __forceinline__ float4 raw_px(uint32_t u)   // image.rs:54 — f32::from(v) / 255f32
 {
-    return make_float4((float)(u & 0xFFu) / 255.0f, (float)((u >> 8) & 0xFFu) / 255.0f,
-                       (float)((u >> 16) & 0xFFu) / 255.0f, (float)(u >> 24) / 255.0f);
+    return make_float4(px_over_255((float)(u & 0xFFu)), px_over_255((float)((u >> 8) & 0xFFu)),
+                       px_over_255((float)((u >> 16) & 0xFFu)), px_over_255((float)(u >> 24)));
 }
 template <typename InT> struct RawOf { typedef float4 type; };
 template <> struct RawOf<uint8_t> { typedef uint32_t type; };

@@ -148,3 +148,23 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 2000.0          # BASELINE.json's target for one MI355X
+
+
+def test_pixel_normalisation_shortcut_is_exact():
+    """cv_amd/csrc/akz_scale_space.hip: px_over_255 / px_over_65535 replace the reference's per-pixel IEEE division
+    (image.rs:54, :57-66) by q0 = v * r, q = fma(fma(-d, q0, v), r, q0).  Exhaustive check over every u8 and u16 value
+    (the fma is emulated in f64: every product and sum here is exact in 53 bits, so one rounding to f32 remains)."""
+    import numpy as np
+
+    def fma(a, b, c):
+        return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    for d_, n in ((255.0, 256), (65535.0, 65536)):
+        d = np.float32(d_)
+        r = np.float32(np.float32(1.0) / d)
+        v = np.arange(n, dtype=np.float32)
+        want = (v / d).astype(np.float32)
+        q0 = (v * r).astype(np.float32)
+        got = np.array([fma(fma(-d, q0[i], v[i]), r, q0[i]) for i in range(n)], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert not np.array_equal(q0.view(np.uint32), want.view(np.uint32))      # the multiply alone is NOT enough
