@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
-    ap.add_argument("--micro-batch", type=int, default=128, help="frames per kernel launch")
+    ap.add_argument("--micro-batch", type=int, default=256, help="frames per library call (measured: 64 -> 6794, 128 -> 6912, 256 -> 6997 frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")

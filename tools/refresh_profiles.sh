@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): regenerates the raw material of profiles/ under gpurun_out/refresh/.
-# usage: bash tools/refresh_profiles.sh [round-tag, default r02] [micro-batch, default 128]
+# usage: bash tools/refresh_profiles.sh [round-tag, default r02] [micro-batch, default 256]
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-r02}
-MB=${2:-128}
+MB=${2:-256}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
