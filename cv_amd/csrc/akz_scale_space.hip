@@ -76,6 +76,9 @@ __device__ __forceinline__ float load_px(const uint16_t* p, size_t i) { return p
 // wide::f32x4 accumulate + reduce_add as used by horizontal_filter/vertical_filter
 // (image.rs:242-247, :320-325): tap i goes to lane i&3, lanes accumulate in chunk order with an
 // unfused multiply-then-add starting from +0, lanes are summed ((a0+a1)+a2)+a3.
+// The fold starts every lane from +0.  Only lane 0's start is observable: x + (+0) differs from x for x = -0 alone,
+// a0 = ... + (p0 + 0) can therefore never be -0, and a sum whose left operand is not -0 does not depend on the sign of
+// a zero on its right — so lanes 1..3 start from their first product (three adds fewer per filter tap group, same bits).
 template <int N>
 __device__ __forceinline__ float lane4_dot(const float* s, int stride, const float* k)
 {
@@ -84,9 +87,9 @@ __device__ __forceinline__ float lane4_dot(const float* s, int stride, const flo
     for (int i = 0; i < N; ++i) {
         float p = s[i * stride] * k[i];
         if ((i & 3) == 0) a0 = p + a0;
-        else if ((i & 3) == 1) a1 = p + a1;
-        else if ((i & 3) == 2) a2 = p + a2;
-        else a3 = p + a3;
+        else if ((i & 3) == 1) a1 = i == 1 ? p : p + a1;
+        else if ((i & 3) == 2) a2 = i == 2 ? p : p + a2;
+        else a3 = i == 3 ? p : p + a3;
     }
     return ((a0 + a1) + a2) + a3;
 }
@@ -207,9 +210,9 @@ __device__ __forceinline__ v2f lane4_dot_v(const v2f* v, const float* k)
     for (int i = 0; i < N; ++i) {
         v2f p = v[i] * splat(k[i]);
         if ((i & 3) == 0) a0 = p + a0;
-        else if ((i & 3) == 1) a1 = p + a1;
-        else if ((i & 3) == 2) a2 = p + a2;
-        else a3 = p + a3;
+        else if ((i & 3) == 1) a1 = i == 1 ? p : p + a1;      // (lanes 1..3 start from their first product: see lane4_dot)
+        else if ((i & 3) == 2) a2 = i == 2 ? p : p + a2;
+        else a3 = i == 3 ? p : p + a3;
     }
     return ((a0 + a1) + a2) + a3;
 }
