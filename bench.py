@@ -136,6 +136,7 @@ def main():
                     "consecutive calls do not overlap; for counter passes and serial phase profiles")
     ap.add_argument("--opt", action="append", default=[], help="akz_options field for the context, key=value (A/B runs; "
                     "the defaults are what the headline is quoted on)")
+    ap.add_argument("--matcher-low-priority", action="store_true", help="A/B: matcher stream at the lowest priority")
     ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3])")
     ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
     ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
@@ -192,7 +193,7 @@ def main():
     if args.no_pipeline:
         okw["pipeline"] = False
     ctx = ak.context(W, H, MB, options=_lib.make_options(**okw) if okw else None)
-    matcher = Matcher(CAP, device=local_rank)
+    matcher = Matcher(CAP, device=local_rank, low_priority=args.matcher_low_priority)
     akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
     hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
 

@@ -49,7 +49,7 @@ class Options(C.Structure):
 
 
 OPT_KEEP_ALL, OPT_NO_FRAME_PAIRS, OPT_SERIAL_SUPPRESSION, OPT_NO_PIPELINE = 1, 2, 4, 8
-OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED = 16, 32, 64, 128, 256, 512
+OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED, OPT_EQUAL_PRIORITY = 16, 32, 64, 128, 256, 512, 1024
 HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY = 1, 2, 4
 FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
 
@@ -58,7 +58,7 @@ BOOL_OPTIONS = ("keep_all", "frame_pairs", "parallel_suppression", "pipeline", "
                 "det_side_stream", "fuse_front_fed")
 
 
-def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=False,
+def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=True,
                  contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0, stream_kernels=True,
                  stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True):
     """Options with readable names.  contrast: "fine" (default), "exact", "force_odd"."""
@@ -66,7 +66,7 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
     o.struct_size = C.sizeof(Options)
     o.flags = ((OPT_KEEP_ALL if keep_all else 0) | (0 if frame_pairs else OPT_NO_FRAME_PAIRS)
                | (0 if parallel_suppression else OPT_SERIAL_SUPPRESSION) | (0 if pipeline else OPT_NO_PIPELINE)
-               | (OPT_STREAM_PRIORITY if stream_priority else 0) | (0 if stream_kernels else OPT_TILE_KERNELS)
+               | (0 if stream_priority else OPT_EQUAL_PRIORITY) | (0 if stream_kernels else OPT_TILE_KERNELS)
                | (0 if det_side_stream else OPT_SERIAL_DET) | (0 if fuse_front_fed else OPT_SPLIT_FRONT_FED)
                | {"fine": 0, "exact": OPT_CONTRAST_EXACT, "force_odd": OPT_CONTRAST_FORCE_ODD}[contrast])
     o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift

@@ -125,7 +125,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
-            if (o.flags & ~((AKZ_OPT_SPLIT_FRONT_FED << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
+            if (o.flags & ~((AKZ_OPT_EQUAL_PRIORITY << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
         }
         {
@@ -169,11 +169,12 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         if (o.fed_block) c->fed_block = (int)o.fed_block;
         if (o.desc_tile_shift) c->desc_tile_shift = (int)o.desc_tile_shift;
         int32_t st = AKZ_OK;
-        // Stream priorities (scale space urgent, keypoint stage filler) were measured without gain on MI355X
-        // (1982 vs 2029 fps): off unless asked for.
+        // Stream priorities: scale space urgent, keypoint stage filler.  Without gain in round 1 (1982 vs 2029 fps), worth
+        // +1 % now that the scale-space kernels are shorter (7 250-7 315 vs 7 205-7 225 frames/s): on unless
+        // AKZ_OPT_EQUAL_PRIORITY.
         int prio_lo = 0, prio_hi = 0;
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = numerically greatest = least urgent
-        const bool use_prio = (o.flags & AKZ_OPT_STREAM_PRIORITY) != 0;
+        const bool use_prio = !(o.flags & AKZ_OPT_EQUAL_PRIORITY);
         if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
             st = AKZ_E_HIP;

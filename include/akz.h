@@ -96,14 +96,16 @@ enum {
     AKZ_OPT_NO_FRAME_PAIRS = 1u << 1,     /* one-frame kernels even for widths divisible by 4 */
     AKZ_OPT_SERIAL_SUPPRESSION = 1u << 2, /* one-wave serial walk of scale_space_extrema.rs:61-118 for every frame */
     AKZ_OPT_NO_PIPELINE = 1u << 3,        /* one buffer set: consecutive calls do not overlap */
-    AKZ_OPT_STREAM_PRIORITY = 1u << 4,    /* scale-space stream at high, keypoint stream at low priority */
+    AKZ_OPT_STREAM_PRIORITY = 1u << 4,    /* (accepted, no effect: scale-space stream at high and keypoint stream at low
+                                           * priority is the default since it measured +1 % on the bench workload) */
     AKZ_OPT_CONTRAST_EXACT = 1u << 5,     /* contrast factor always through the exact histogram pass */
     AKZ_OPT_CONTRAST_FORCE_ODD = 1u << 6, /* test knob: odd frames through the exact pass (mixed pairs) */
     AKZ_OPT_TILE_KERNELS = 1u << 7,       /* the LDS-tile determinant kernels of round 1 instead of the row-streaming one */
     AKZ_OPT_SERIAL_DET = 1u << 8,         /* determinant / candidate kernels on the scale-space stream itself instead of
                                            * the side stream that takes them off the Lt -> Lt dependency chain */
-    AKZ_OPT_SPLIT_FRONT_FED = 1u << 9     /* level front end and first FED launch as two kernels (Lflow through HBM)
+    AKZ_OPT_SPLIT_FRONT_FED = 1u << 9,    /* level front end and first FED launch as two kernels (Lflow through HBM)
                                            * instead of the fused k_front_fed */
+    AKZ_OPT_EQUAL_PRIORITY = 1u << 10     /* all streams of the context at the default priority */
 };
 typedef struct akz_options {
     uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */

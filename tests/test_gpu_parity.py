@@ -1129,7 +1129,7 @@ OPTION_SETS = [
     ("one FED step per launch", dict(fed_block=1)),
     ("three FED steps per launch", dict(fed_block=3)),
     ("serial suppression, no pipeline", dict(parallel_suppression=False, pipeline=False)),
-    ("exact contrast, stream priorities", dict(contrast="exact", stream_priority=True)),
+    ("exact contrast, equal stream priorities", dict(contrast="exact", stream_priority=False)),
     ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
     ("determinant kernels on the scale-space stream", dict(det_side_stream=False)),
     ("front end and FED as two kernels", dict(fuse_front_fed=False)),
