@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in,
         for (int k = 0; k < kRankJ; ++k) rank += s_part[k][ii];
         if (MODE == RANK_RESPONSE) {
             if (rank < max_features) out[(size_t)frame * stride + rank] = me;
+            if (perm) perm[(size_t)frame * stride + i] = rank;    // pre-sort order as the descriptor stage's visiting order
         } else {
             perm[(size_t)frame * stride + rank] = i;
         }
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in,
 __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
                                                uint32_t stride, uint32_t max_features, DevKp* __restrict__ out,
                                                uint32_t* __restrict__ n_out, unsigned long long* __restrict__ gkeys,
-                                               uint32_t gstride, uint32_t lds_keys)
+                                               uint32_t gstride, uint32_t lds_keys, uint32_t* __restrict__ perm_raster)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* lds = reinterpret_cast<unsigned long long*>(smem);
@@ -1051,7 +1052,12 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
     if (big) bitonic_sort_big_u64<1024>(key, np2, lds, lds_keys);
     else bitonic_sort_lds_u64<1024>(key, np2);
     uint32_t m = n < max_features ? n : max_features;
-    for (uint32_t i = threadIdx.x; i < m; i += 1024) out[(size_t)frame * stride + i] = src[(uint32_t)(key[i] & 0xFFFFFFFFull)];
+    for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        const uint32_t from = (uint32_t)(key[i] & 0xFFFFFFFFull);
+        out[(size_t)frame * stride + i] = src[from];
+        // visiting order of the descriptor stage = the pre-sort order (level-major, close to raster): see akz_run_keypoints
+        if (perm_raster) perm_raster[(size_t)frame * stride + from] = i;
+    }
     if (threadIdx.x == 0) n_out[frame] = m;
 }
 
@@ -1751,21 +1757,29 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A15
     uint32_t maxf = c->cfg.maximum_features > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c->cfg.maximum_features;
     const bool rank_sorts = n <= 8;            // few frames: the chip-wide rank sort; many: one bitonic block per frame
+    // Visiting order of the descriptor stage.  The response-sorted list is spatially random; the list BEFORE the sort is
+    // in cache order (level-major, close to raster), and the sort knows where it sent every element — so when nothing is
+    // truncated the descriptor kernel walks the pre-sort order for free.  The (level, 32-px tile) order of
+    // k_spatial_order / k_rank_sort<RANK_SPATIAL> is better for the gathers (1 632 vs 1 708 us per 64 frames) but costs
+    // a second sort (153 us): it stays for calls that truncate to maximum_features.
+    const bool raster_visit = maxf >= c->max_kp;
     const dim3 grid_rank((uint32_t)akz_div_up((int)c->max_kp, kRankI), n);
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
     const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;   // longer lists: global key scratch
     if (rank_sorts)
         hipLaunchKernelGGL((k_rank_sort<RANK_RESPONSE>), grid_rank, dim3(256), 0, s, S.d_kp_c, S.d_n_c, c->max_kp, maxf, 0,
-                           S.d_kp_d, S.d_n_d, (uint32_t*)nullptr);
+                           S.d_kp_d, S.d_n_d, raster_visit ? S.d_perm : (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, S.d_kp_c, S.d_n_c,
-                           c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys);
+                           c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys,
+                           raster_visit ? S.d_perm : (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
     // A16 + A17
     akz_timer_begin(c, AKZ_T_DESCRIBE, s);
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
-        if (rank_sorts)
+        if (raster_visit) {
+        } else if (rank_sorts)
             hipLaunchKernelGGL((k_rank_sort<RANK_SPATIAL>), grid_rank, dim3(256), 0, s, S.d_kp_d, S.d_n_d, c->max_kp, 0u,
                                c->desc_tile_shift, (DevKp*)nullptr, (uint32_t*)nullptr, S.d_perm);
         else
