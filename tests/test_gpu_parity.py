@@ -1174,6 +1174,26 @@ def test_call_size_selects_kernels_not_results(gpu, oracle, nfr):
     ctx.close()
 
 
+def test_host_calls_with_and_without_pinned_staging(gpu, oracle):
+    """akz_extract_batch stages inputs and outputs through pinned blocks while they stay below 96 MB and falls back to
+    plain copies above (72 frames x 16 384 keypoint slots x 92 B = 108 MB): both give the oracle's bytes, and a second
+    call on the same context (staging blocks reused) too."""
+    akaze, _ = gpu
+    w, h = 160, 120
+    frames = [synth_frame(w, h, seed=6100 + (i % 4), n_rect=20, n_disc=20) for i in range(72)]
+    orc = oracle.Akaze(w, h, oracle.default_config())
+    want = [orc.extract(frames[i]) for i in range(4)]
+    for nfr in (3, 72):
+        ctx = akaze.Context(akaze.Akaze.default(), w, h, nfr)
+        for rep in range(2):
+            got = ctx.extract_batch(frames[:nfr])
+            for i in range(nfr):
+                okp, od = want[i % 4]
+                _kp_eq(got[i][0], okp, f"host call of {nfr} frames (call {rep}), frame {i}")
+                _eq(got[i][1], od, f"host call of {nfr} frames (call {rep}), frame {i} desc")
+        ctx.close()
+
+
 def test_unknown_option_bits_are_refused(gpu):
     import ctypes as C
     from cv_amd import _lib
