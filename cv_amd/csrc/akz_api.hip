@@ -492,14 +492,21 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
         const bool stage_in = in_bytes <= kAkzHostStageMax;
         if (stage_in) {
             AKZ_TRY(host_block(&c->h_in, &c->h_in_bytes, in_bytes));
+            // row blocks of ~512 KB: the DMA of a block runs while the next one is gathered
+            const int rows_per = (int)std::max<size_t>(1, ((size_t)512 << 10) / ((size_t)w * esz));
             for (int i = 0; i < n; ++i) {
                 char* dst = (char*)c->h_in + (size_t)i * P0 * esz;
                 const char* src = (const char*)imgs[i];
-                if (stride == w) memcpy(dst, src, P0 * esz);
-                else
-                    for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * w * esz, src + (size_t)y * stride * esz, (size_t)w * esz);
+                for (int y0 = 0; y0 < h; y0 += rows_per) {
+                    const int y1 = std::min(h, y0 + rows_per);
+                    if (stride == w) memcpy(dst + (size_t)y0 * w * esz, src + (size_t)y0 * w * esz, (size_t)(y1 - y0) * w * esz);
+                    else
+                        for (int y = y0; y < y1; ++y)
+                            memcpy(dst + (size_t)y * w * esz, src + (size_t)y * stride * esz, (size_t)w * esz);
+                    AKZ_HIP(hipMemcpyAsync((char*)c->S().d_in + (size_t)i * P0 * esz + (size_t)y0 * w * esz, dst + (size_t)y0 * w * esz,
+                                           (size_t)(y1 - y0) * w * esz, hipMemcpyHostToDevice, c->stream));
+                }
             }
-            AKZ_HIP(hipMemcpyAsync(c->S().d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
         } else {
             for (int i = 0; i < n; ++i)
                 AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
