@@ -1778,13 +1778,14 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // A16 + A17
     akz_timer_begin(c, AKZ_T_DESCRIBE, s);
     if (c->cfg.descriptor_pattern_size == 10 && c->cfg.descriptor_channels == 3) {
-        if (raster_visit) {
-        } else if (rank_sorts)
-            hipLaunchKernelGGL((k_rank_sort<RANK_SPATIAL>), grid_rank, dim3(256), 0, s, S.d_kp_d, S.d_n_d, c->max_kp, 0u,
-                               c->desc_tile_shift, (DevKp*)nullptr, (uint32_t*)nullptr, S.d_perm);
-        else
-            hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
-                               S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
+        if (!raster_visit) {
+            if (rank_sorts)
+                hipLaunchKernelGGL((k_rank_sort<RANK_SPATIAL>), grid_rank, dim3(256), 0, s, S.d_kp_d, S.d_n_d, c->max_kp, 0u,
+                                   c->desc_tile_shift, (DevKp*)nullptr, (uint32_t*)nullptr, S.d_perm);
+            else
+                hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
+                                   S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
+        }
         AKZ_LAUNCH_CHECK();
         if (orient_in_desc)
             hipLaunchKernelGGL(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
