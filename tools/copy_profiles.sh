@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the summaries a tools/gpu_job8.sh run merged into gpurun_out/ to profiles/ (tracked)
+# copies the summaries a tools/validate_job.sh run merged into gpurun_out/ to profiles/ (tracked)
 T=${1:-r02}
 cd "$(dirname "$0")/.."
 cp gpurun_out/refresh/${T}_bench.json profiles/${T}_bench.json
