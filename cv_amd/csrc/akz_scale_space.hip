@@ -321,14 +321,34 @@ __device__ __forceinline__ void pair_blur_tile(const InT* __restrict__ in, int w
         regs.commit(s_in);                                  // fetched by the caller / the previous tile
         if (next_ty0 >= 0) regs.fetch(in, w, h, fs, fa, fb, tx0, next_ty0);
     } else {
+        // tile columns on the image border: per-element clamped loads, eight per thread in flight (one load per round
+        // trip made these tiles several times as slow as the others; on the small octaves they are a quarter to half of all tiles)
         const InT* srca = in + (size_t)fa * fs;
         const InT* srcb = in + (size_t)fb * fs;
-        for (int idx = tid; idx < IH * CI; idx += NT) {
-            int iy = idx / CI, ix = idx - iy * CI;
-            int cx = clampi(tx0 - 8 + ix, 0, w - 1);
-            int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
-            size_t o = (size_t)cy * w + cx;
-            s_in[iy * CI + tile_col<CI>(ix)] = (v2f){load_px(srca, o), load_px(srcb, o)};
+        constexpr int BATCH = 8;
+        for (int base = 0; base < IH * CI; base += NT * BATCH) {
+            InT ea[BATCH], eb[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int idx = base + tid + NT * i;
+                ea[i] = eb[i] = InT(0);
+                if (idx < IH * CI) {
+                    int iy = idx / CI, ix = idx - iy * CI;
+                    int cx = clampi(tx0 - 8 + ix, 0, w - 1);
+                    int cy = clampi(ty0 - SG - R + iy, 0, h - 1);
+                    size_t o = (size_t)cy * w + cx;
+                    ea[i] = srca[o];
+                    eb[i] = srcb[o];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int idx = base + tid + NT * i;
+                if (idx < IH * CI) {
+                    int iy = idx / CI, ix = idx - iy * CI;
+                    s_in[iy * CI + tile_col<CI>(ix)] = (v2f){load_px(&ea[i], 0), load_px(&eb[i], 0)};
+                }
+            }
         }
     }
     __syncthreads();
