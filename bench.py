@@ -449,6 +449,7 @@ def roofline_entries(fam_pipe, fam_iso, mb):
     """Roofline objects of the timed kernel families, most expensive (inside the timed region) first."""
     iso = {f[0]: f for f in (fam_iso or [])}
     pmc = pmc_traffic(mb)
+    sq = sq_counters()
     out = []
     for name, ms, launches, units, bpu in sorted(fam_pipe, key=lambda f: -f[1]):
         gbs = units * bpu / (ms * 1e-3) / 1e9
@@ -469,6 +470,8 @@ def roofline_entries(fam_pipe, fam_iso, mb):
                          "is bound by packed-f32 VALU issue, not by HBM (profiles/: SQ counters); its HBM fraction is "
                          "reported because the contract asks for it, the time saved shows in `value`")
         key = name.split(" ")[0]
+        if key in sq:
+            e["issue_counters"] = sq[key]
         if pmc and key in pmc["kernels"]:
             k = pmc["kernels"][key]
             e["traffic"] = round(k["hbm_bytes_per_launch"])
@@ -697,6 +700,28 @@ def pmc_traffic(mb):
         return {"file": "profiles/" + name, "micro_batch": d["micro_batch"], "kernels": d["kernels"]}
     except Exception:
         return None
+
+
+def sq_counters():
+    """Issue-side counters of each kernel from the committed SQ passes (profiles/r02_pmc_sq_summary.txt, made by
+    tools/pmc_sq.sh over the serial phase profile at 64 frames per launch): what a kernel that is not HBM-bound is
+    bound by.  Keyed like the kernel families."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_traffic import family_key
+        out = {}
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.txt")) as f:
+            for line in f.read().splitlines()[1:]:
+                name, rest = line[:52].strip(), line[52:].split()
+                if len(rest) < 8:
+                    continue
+                key = family_key(name + ">") if name.count("<") > name.count(">") else family_key(name)
+                out.setdefault(key, {"file": "profiles/r02_pmc_sq_summary.txt", "valu_instructions_per_wave": int(rest[1]),
+                                     "valu_busy_pct": int(rest[2]), "lds_busy_pct": int(rest[3]),
+                                     "lds_bank_conflict_pct": int(rest[4]), "waves_parked_pct": int(rest[5])})
+        return out
+    except Exception:
+        return {}
 
 
 def cpu_baseline(frames, n):
