@@ -466,6 +466,10 @@ def roofline_entries(fam_pipe, fam_iso, mb):
             e["isolated"] = {"achieved": round(igbs, 1), "frac": round(igbs / HBM_PEAK_GBS, 4),
                              "avg_launch_us": round(ims * 1e3 / il, 2)}
         if name.startswith("k_front_fed"):
+            # what the same work cost as two kernels (k_level_front2 16 B + k_fed_pair 12 B per pixel): the fused kernel's
+            # time expressed against THOSE bytes, for comparison with round 1's front-end / FED fractions only
+            e["replaces"] = {"kernels": "k_level_front2<2,sigma,..> + k_fed_pair<T>", "bytes_per_pixel": 28.0,
+                             "equivalent_frac_of_peak": round(gbs * 28.0 / 16.0 / HBM_PEAK_GBS, 4)}
             e["note"] = ("fused kernel: moves 16 B/pixel where the split pair (k_level_front2 + k_fed_pair) moves 28, and "
                          "is bound by packed-f32 VALU issue, not by HBM (profiles/: SQ counters); its HBM fraction is "
                          "reported because the contract asks for it, the time saved shows in `value`")
