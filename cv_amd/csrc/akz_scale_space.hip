@@ -447,9 +447,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 3) void k_level_front2(const In
             }
             // a wave whose denominators are all finite (always, unless a frame has no gradient at all: then
             // inverse_k is infinite and the reference's quotient is NaN) takes the packed reciprocal
-            bool odd = false;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) odd = odd || not_finite(res_f[o].x) || not_finite(res_f[o].y);
+            // (one test on the sum of the four: it is not finite whenever one of them is not; a sum of finite values that
+            // overflows only sends the wave through the plain division, which is exact for every input)
+            const v2f dsum = (res_f[0] + res_f[1]) + (res_f[2] + res_f[3]);
+            const bool odd = not_finite(dsum.x) || not_finite(dsum.y);
             if (__any(odd)) {
 #pragma unroll
                 for (int o = 0; o < 4; ++o) res_f[o] = splat(1.0f) / res_f[o];
@@ -1456,9 +1457,8 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
                     den[o] = splat(1.0f) + inverse_k * (lx * lx + ly * ly);   // the denominator; inverted below
                 }
                 // (as in k_level_front2: the packed reciprocal unless some denominator of the wave is not finite)
-                bool odd = false;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) odd = odd || not_finite(den[o].x) || not_finite(den[o].y);
+                const v2f dsum = (den[0] + den[1]) + (den[2] + den[3]);   // (as in k_level_front2: one test for the four)
+                const bool odd = not_finite(dsum.x) || not_finite(dsum.y);
                 if (__any(odd)) {
 #pragma unroll
                     for (int o = 0; o < 4; ++o) C[j][o] = splat(1.0f) / den[o];
