@@ -1119,6 +1119,24 @@ def test_arrsac_refusals(gpu):
         cons.arrsac_model_inliers(a, b, 1e-6, n_hypotheses=120, block_size=64, estimations_per_block=4)   # 120 + 4 x 4 > 128
     assert e.value.status == -6                                # AKZ_E_TOO_LARGE
     assert cons.arrsac_model_inliers(a, b, 1e-6, n_hypotheses=112, block_size=64, estimations_per_block=4) is not None
+    # reserved field and unknown flag bits through the raw ABI
+    import ctypes as C
+    prm = _lib.ArrsacParams()
+    prm.struct_size = C.sizeof(_lib.ArrsacParams)
+    prm.n_hypotheses, prm.block_size, prm.init_blocks, prm.max_candidates = 64, 64, 1, 16
+    prm.flags, prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = 1, 1e-6, 0.05, 1e3, 0
+    pose = np.empty(12); best = C.c_uint32(); ninl = C.c_uint32(); inl = np.empty(256, np.uint32)
+
+    def call():
+        return _lib.lib().rs_essential_arrsac(cons._h, a.ctypes.data, b.ctypes.data, 256, None, C.byref(prm), pose.ctypes.data,
+                                              C.byref(best), inl.ctypes.data, 256, C.byref(ninl), None)
+    assert call() == 0
+    prm.reserved = 1
+    assert call() == -1
+    prm.reserved, prm.flags = 0, 1 << 7
+    assert call() == -1
+    prm.flags, prm.struct_size = 1, C.sizeof(_lib.ArrsacParams) - 8          # a caller built against the older struct
+    assert call() == -1
 
 
 OPTION_SETS = [
