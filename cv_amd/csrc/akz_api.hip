@@ -389,7 +389,11 @@ static int32_t host_block(void** p, size_t* have, size_t bytes)
         *have = 0;
     }
     const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    AKZ_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();     // not sticky: the caller falls back to plain copies
+        *p = nullptr;
+        return AKZ_E_OOM;
+    }
     *have = want;
     return AKZ_OK;
 }
@@ -489,9 +493,9 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
             if (!imgs[i]) return AKZ_E_INVALID;
         // ---- input: rows gathered into the pinned block, one DMA ----
         const size_t in_bytes = (size_t)n * P0 * esz;
-        const bool stage_in = in_bytes <= kAkzHostStageMax;
+        // (a host that cannot pin the block takes the plain copies: staging is an optimisation, never a requirement)
+        const bool stage_in = in_bytes <= kAkzHostStageMax && host_block(&c->h_in, &c->h_in_bytes, in_bytes) == AKZ_OK;
         if (stage_in) {
-            AKZ_TRY(host_block(&c->h_in, &c->h_in_bytes, in_bytes));
             // row blocks of ~512 KB: the DMA of a block runs while the next one is gathered
             const int rows_per = (int)std::max<size_t>(1, ((size_t)512 << 10) / ((size_t)w * esz));
             for (int i = 0; i < n; ++i) {
@@ -517,12 +521,11 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
         const size_t K = c->max_kp;
         const size_t head = 64 + (((size_t)n * sizeof(uint32_t) + 63) & ~(size_t)63);
         const size_t out_bytes = head + (size_t)n * K * (sizeof(DevKp) + sizeof(akz_descriptor));
-        const bool stage_out = out_bytes <= kAkzHostStageMax;
+        const bool stage_out = out_bytes <= kAkzHostStageMax && host_block(&c->h_out, &c->h_out_bytes, out_bytes) == AKZ_OK;
         akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
         int32_t status = AKZ_OK;
         if (stage_out) {
-            AKZ_TRY(host_block(&c->h_out, &c->h_out_bytes, out_bytes));
             uint32_t* h_err = (uint32_t*)c->h_out;
             uint32_t* h_n = (uint32_t*)((char*)c->h_out + 64);
             DevKp* h_kp = (DevKp*)((char*)c->h_out + head);
