@@ -136,6 +136,7 @@ def main():
                     "consecutive calls do not overlap; for counter passes and serial phase profiles")
     ap.add_argument("--opt", action="append", default=[], help="akz_options field for the context, key=value (A/B runs; "
                     "the defaults are what the headline is quoted on)")
+    ap.add_argument("--max-features", type=int, default=0, help="A/B: Akaze.maximum_features (0 = the reference's default, unlimited)")
     ap.add_argument("--matcher-low-priority", action="store_true", help="A/B: matcher stream at the lowest priority")
     ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3])")
     ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
@@ -186,6 +187,8 @@ def main():
     ak = Akaze.default()
     ak.device = local_rank
     ak.max_keypoints = CAP
+    if args.max_features:                     # A/B: a truncating call takes the (level, tile) visiting order + its sort
+        ak.maximum_features = args.max_features
     okw = {}
     for kv in args.opt:                       # A/B runs: akz_options fields by name (cv_amd._lib.make_options)
         key, val = kv.split("=")

@@ -1098,6 +1098,74 @@ __global__ __launch_bounds__(1024) void k_spatial_order(LevelTable T, const DevK
     for (uint32_t i = threadIdx.x; i < n; i += 1024) perm[(size_t)frame * stride + i] = (uint32_t)(key[i] & 0xFFFFFFFFull);
 }
 
+// The same (level, tile) grouping as a COUNTING sort: the tiles of all levels are a few thousand buckets (10 900 at
+// 1080p), so a block counts its frame's keypoints per bucket in LDS, scans the counts and scatters the indices — three
+// passes over the list instead of a bitonic network over padded 64-bit keys (153 -> ~20 us per 64 frames).  Inside a
+// tile the order is whatever the atomics produce: the permutation only decides in which order the descriptor kernel
+// visits keypoints, never what it writes where.  The host falls back to k_spatial_order when the bucket count does
+// not fit (kTileOrderMaxBuckets).
+constexpr uint32_t kTileOrderMaxBuckets = 15 * 1024;
+__global__ __launch_bounds__(1024) void k_tile_order(LevelTable T, const DevKp* __restrict__ in,
+                                                     const uint32_t* __restrict__ n_in, uint32_t stride,
+                                                     uint32_t* __restrict__ perm, int tile_shift)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);            // [nb]
+    __shared__ uint32_t s_lbase[kMaxLevels + 1], s_ntx[kMaxLevels], s_nty[kMaxLevels];
+    __shared__ uint32_t s_wave[16];
+    const int frame = blockIdx.x;
+    const uint32_t n = min(n_in[frame], stride);
+    const DevKp* src = in + (size_t)frame * stride;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) {
+        uint32_t base = 0;
+        for (int e = 0; e < T.n; ++e) {
+            const uint32_t ntx = ((uint32_t)(T.L[e].w - 1) >> tile_shift) + 1u, nty = ((uint32_t)(T.L[e].h - 1) >> tile_shift) + 1u;
+            s_lbase[e] = base;
+            s_ntx[e] = ntx;
+            s_nty[e] = nty;
+            base += ntx * nty;
+        }
+        s_lbase[T.n] = base;
+    }
+    __syncthreads();
+    const uint32_t nb = s_lbase[T.n];
+    for (uint32_t b = tid; b < nb; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    auto bucket = [&](const DevKp& kp) {
+        const uint32_t e = min(kp.class_id, (uint32_t)T.n - 1u);
+        const float ratio = (float)(1u << kp.octave);
+        const uint32_t tx = min((uint32_t)max(kp.x / ratio, 0.0f) >> tile_shift, s_ntx[e] - 1u);
+        const uint32_t ty = min((uint32_t)max(kp.y / ratio, 0.0f) >> tile_shift, s_nty[e] - 1u);
+        return s_lbase[e] + ty * s_ntx[e] + tx;
+    };
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&hist[bucket(src[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the counts: a contiguous run of buckets per thread, then the runs across the block
+    const uint32_t per = (nb + 1023u) / 1024u, b0 = tid * per, b1 = min(nb, b0 + per);
+    uint32_t run = 0;
+    for (uint32_t b = b0; b < b1; ++b) run += hist[b];
+    uint32_t incl = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - run;
+    for (uint32_t q = 0; q < wv; ++q) before += s_wave[q];
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t cnt = hist[b];
+        hist[b] = before;
+        before += cnt;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t pos = atomicAdd(&hist[bucket(src[i])], 1u);
+        perm[(size_t)frame * stride + pos] = i;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // A16 + A17: M-LDB descriptor, one wave per keypoint.  Lane c (< n_cells) accumulates cell c of the
 // three sampling grids sequentially in the reference's (k outer, l inner) order; the comparisons
@@ -1759,10 +1827,12 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     const bool rank_sorts = n <= 8;            // few frames: the chip-wide rank sort; many: one bitonic block per frame
     // Visiting order of the descriptor stage.  The response-sorted list is spatially random; the list BEFORE the sort is
     // in cache order (level-major, close to raster), and the sort knows where it sent every element — so when nothing is
-    // truncated the descriptor kernel walks the pre-sort order for free.  The (level, 32-px tile) order of
-    // k_spatial_order / k_rank_sort<RANK_SPATIAL> is better for the gathers (1 632 vs 1 708 us per 64 frames) but costs
-    // a second sort (153 us): it stays for calls that truncate to maximum_features.
-    const bool raster_visit = maxf >= c->max_kp;
+    // truncated the descriptor kernel can walk the pre-sort order for free.  The (level, 32-px tile) order of
+    // k_spatial_order is better for the gathers (84 vs 111 MB of HBM traffic per frame; 1 632 vs 1 708 us per 64 frames)
+    // and costs a second sort (153 us).  A few-frame call, where every launch is on the critical path, takes the free
+    // order; a batch takes the tile order (in the pipeline its sort hides and the lower traffic shows: 7 353-7 372 vs
+    // 7 301-7 321 frames/s).
+    const bool raster_visit = rank_sorts && maxf >= c->max_kp;
     const dim3 grid_rank((uint32_t)akz_div_up((int)c->max_kp, kRankI), n);
     uint32_t np2 = 1;
     while (np2 < c->max_kp) np2 <<= 1;
@@ -1782,9 +1852,17 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
             if (rank_sorts)
                 hipLaunchKernelGGL((k_rank_sort<RANK_SPATIAL>), grid_rank, dim3(256), 0, s, S.d_kp_d, S.d_n_d, c->max_kp, 0u,
                                    c->desc_tile_shift, (DevKp*)nullptr, (uint32_t*)nullptr, S.d_perm);
-            else
-                hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
-                                   S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
+            else {
+                uint32_t nbuckets = 0;
+                for (int e = 0; e < T.n; ++e)
+                    nbuckets += (((uint32_t)(T.L[e].w - 1) >> c->desc_tile_shift) + 1u) * (((uint32_t)(T.L[e].h - 1) >> c->desc_tile_shift) + 1u);
+                if (nbuckets <= kTileOrderMaxBuckets)
+                    hipLaunchKernelGGL(k_tile_order, dim3(n), dim3(1024), sizeof(uint32_t) * nbuckets, s, T, S.d_kp_d, S.d_n_d,
+                                       c->max_kp, S.d_perm, c->desc_tile_shift);
+                else
+                    hipLaunchKernelGGL(k_spatial_order, dim3(n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, T, S.d_kp_d,
+                                       S.d_n_d, c->max_kp, S.d_perm, c->desc_tile_shift, S.d_keys_kp, np2, lds_keys);
+            }
         }
         AKZ_LAUNCH_CHECK();
         if (orient_in_desc)
