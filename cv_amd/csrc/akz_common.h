@@ -109,6 +109,70 @@ static inline int32_t akz_guard(F&& f) noexcept
 static inline int akz_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t akz_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
+// Stable LSD radix sort of element ids by 32-bit keys, in LDS, for a 1024-thread block (16 waves): `rk[e]` is the key
+// of element e, `ia` holds the ids 0..n-1 in their initial order and `ib` is scratch of the same size; four 8-bit
+// digits (or only the `npass` lowest).  Returns the buffer that holds the sorted ids.  `wh` is [16][256] words, `tot`
+// [256].  A wave owns a contiguous range of positions, so "wave-major, then position" is the list order: per pass the
+// waves count their digits, a scan turns the counts into (digit, wave) offsets, and every wave scatters its range in
+// order — 64 elements at a time, rank inside the step by bit-sliced ballots.  Equal keys keep their order.
+constexpr uint32_t kRadixSortMax = 8192;   // elements per list the callers' LDS layouts hold (3 x 4 B each + 16 KB of counters)
+constexpr size_t kRadixSortLdsBytes = sizeof(uint32_t) * (3 * (size_t)kRadixSortMax + 16 * 256);
+__device__ __forceinline__ uint32_t* lds_radix_sort_ids(const uint32_t* rk, uint32_t* ia, uint32_t* ib, uint32_t* wh,
+                                                        uint32_t* tot, uint32_t n, int npass)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t per = (n + 15u) / 16u, r0 = min(n, wv * per), r1 = min(n, r0 + per);   // this wave's range
+    for (int pass = 0; pass < npass; ++pass) {
+        const int sh = 8 * pass;
+        for (uint32_t b = tid; b < 16 * 256; b += 1024) wh[b] = 0u;
+        __syncthreads();
+        for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            if (p < r1) atomicAdd(&wh[wv * 256 + ((rk[ia[p]] >> sh) & 255u)], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t t = 0;
+            for (int w = 0; w < 16; ++w) t += wh[w * 256 + tid];
+            tot[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t off = 0;
+            for (uint32_t b = 0; b < tid; ++b) off += tot[b];
+            for (int w = 0; w < 16; ++w) {
+                const uint32_t cnt = wh[w * 256 + tid];
+                wh[w * 256 + tid] = off;
+                off += cnt;
+            }
+        }
+        __syncthreads();
+        for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            const bool on = p < r1;
+            const uint32_t el = on ? ia[p] : 0u;
+            const uint32_t dig = on ? ((rk[el] >> sh) & 255u) : 0u;
+            unsigned long long same = __ballot(on);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long bal = __ballot((dig >> bit) & 1u);
+                same &= ((dig >> bit) & 1u) ? bal : ~bal;
+            }
+            if (on) {
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                const uint32_t base = wh[wv * 256 + dig];
+                ib[base + rank] = el;
+                if (rank == 0) wh[wv * 256 + dig] = base + (uint32_t)__popcll(same);   // the step's first lane of the digit
+            }
+        }
+        __syncthreads();
+        uint32_t* t = ia;
+        ia = ib;
+        ib = t;
+    }
+    return ia;
+}
+
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
 // Ascending bitonic sort of np2 (a power of two) 64-bit keys in LDS by one block of NT threads (NT a multiple of

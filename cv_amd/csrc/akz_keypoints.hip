@@ -1023,7 +1023,6 @@ __global__ __launch_bounds__(256) void k_rank_sort(const DevKp* __restrict__ in,
 // the frame's global key scratch, akz_common.h).  A batch of many frames keeps every CU busy with one block per
 // frame, and there the networks cost less than the n^2 comparisons (74 vs 190 us per 64 frames of ~5 000 keypoints):
 // akz_run_keypoints picks by batch size.
-constexpr uint32_t kRadixSortMax = 8192;   // keypoints per frame the LDS radix sort of k_sort holds (3 x 4 B each + 16 KB of counters)
 __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, const uint32_t* __restrict__ n_in,
                                                uint32_t stride, uint32_t max_features, DevKp* __restrict__ out,
                                                uint32_t* __restrict__ n_out, unsigned long long* __restrict__ gkeys,
@@ -1038,74 +1037,23 @@ __global__ __launch_bounds__(1024) void k_sort(const DevKp* __restrict__ in, con
     const DevKp* src = in + (size_t)frame * stride;
     // lists longer than the LDS buffer sort through the frame's global key scratch (akz_common.h)
     if (n <= kRadixSortMax) {
-        // Up to kRadixSortMax keypoints: a stable LSD radix sort of the 32-bit keys (four 8-bit digits) in LDS instead of
-        // the bitonic network over padded 64-bit keys (159 -> ~25 us per 64 frames of ~5 000 keypoints).  Stability does
-        // the tie-break: equal responses keep their pre-sort order, which is the (response desc, index asc) order.
-        // A wave owns a contiguous range of positions, so "wave-major, then position" is the list order: per pass the
-        // waves count their digits, a scan turns the counts into (digit, wave) offsets, and every wave scatters its
-        // range in order — 64 elements at a time, rank inside the step by bit-sliced ballots.
+        // Up to kRadixSortMax keypoints: a stable LSD radix sort of the 32-bit keys in LDS (akz_common.h) instead of the
+        // bitonic network over padded 64-bit keys (159 -> 38 us per 64 frames of ~5 000 keypoints).  Stability does the
+        // tie-break: equal responses keep their pre-sort order, which is the (response desc, index asc) order.
         uint32_t* rk = reinterpret_cast<uint32_t*>(smem);     // [kRadixSortMax] keys by element
         uint32_t* ia = rk + kRadixSortMax;                    // [kRadixSortMax] element ids, ping
         uint32_t* ib = ia + kRadixSortMax;                    // [kRadixSortMax] pong
         uint32_t* wh = ib + kRadixSortMax;                    // [16][256] per-wave digit counts / running offsets
         __shared__ uint32_t s_tot[256];
-        const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+        const uint32_t tid = threadIdx.x;
         for (uint32_t i = tid; i < n; i += 1024) {
             rk[i] = ~__float_as_uint(src[i].response);        // responses are |Ldet| > 0: the bit pattern is monotone
             ia[i] = i;
         }
-        const uint32_t per = (n + 15u) / 16u, r0 = min(n, wv * per), r1 = min(n, r0 + per);   // this wave's range
-        for (int pass = 0; pass < 4; ++pass) {
-            const int sh = 8 * pass;
-            for (uint32_t b = tid; b < 16 * 256; b += 1024) wh[b] = 0u;
-            __syncthreads();
-            for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
-                const uint32_t p = p0 + lane;
-                if (p < r1) atomicAdd(&wh[wv * 256 + ((rk[ia[p]] >> sh) & 255u)], 1u);
-            }
-            __syncthreads();
-            if (tid < 256) {
-                uint32_t t = 0;
-                for (int w = 0; w < 16; ++w) t += wh[w * 256 + tid];
-                s_tot[tid] = t;
-            }
-            __syncthreads();
-            if (tid < 256) {
-                uint32_t off = 0;
-                for (uint32_t b = 0; b < tid; ++b) off += s_tot[b];
-                for (int w = 0; w < 16; ++w) {
-                    const uint32_t cnt = wh[w * 256 + tid];
-                    wh[w * 256 + tid] = off;
-                    off += cnt;
-                }
-            }
-            __syncthreads();
-            for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
-                const uint32_t p = p0 + lane;
-                const bool on = p < r1;
-                const uint32_t el = on ? ia[p] : 0u;
-                const uint32_t dig = on ? ((rk[el] >> sh) & 255u) : 256u;
-                unsigned long long same = __ballot(on);
-#pragma unroll
-                for (int bit = 0; bit < 8; ++bit) {
-                    const unsigned long long bal = __ballot((dig >> bit) & 1u);
-                    same &= ((dig >> bit) & 1u) ? bal : ~bal;
-                }
-                if (on) {
-                    const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                    const uint32_t base = wh[wv * 256 + dig];
-                    ib[base + rank] = el;
-                    if (rank == 0) wh[wv * 256 + dig] = base + (uint32_t)__popcll(same);   // the step's first lane of the digit
-                }
-            }
-            __syncthreads();
-            uint32_t* t = ia;
-            ia = ib;
-            ib = t;
-        }
+        const uint32_t* sorted = lds_radix_sort_ids(rk, ia, ib, wh, s_tot, n, 4);   // (its first barrier orders the fill)
         const uint32_t m = n < max_features ? n : max_features;
         for (uint32_t i = tid; i < m; i += 1024) {
-            const uint32_t from = ia[i];
+            const uint32_t from = sorted[i];
             out[(size_t)frame * stride + i] = src[from];
             if (perm_raster) perm_raster[(size_t)frame * stride + from] = i;
         }
@@ -1918,7 +1866,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
                            S.d_kp_d, S.d_n_d, raster_visit ? S.d_perm : (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_sort, dim3(n), dim3(1024),
-                           std::max<size_t>(sizeof(unsigned long long) * lds_keys, sizeof(uint32_t) * (3 * kRadixSortMax + 16 * 256)), s, S.d_kp_c, S.d_n_c,
+                           std::max<size_t>(sizeof(unsigned long long) * lds_keys, kRadixSortLdsBytes), s, S.d_kp_c, S.d_n_c,
                            c->max_kp, maxf, S.d_kp_d, S.d_n_d, S.d_keys_kp, np2, lds_keys,
                            raster_visit ? S.d_perm : (uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();

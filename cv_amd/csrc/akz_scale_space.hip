@@ -2158,6 +2158,8 @@ __global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ L
 // Raster order (y, then x) of each (frame, level) candidate list: bitonic sort of 64-bit keys
 // (y << 48 | x << 32 | slot) in LDS ((x, y) is unique, so the order is total), then a gather of the unsorted
 // records into the sorted position / response list and the sorted neighbourhood list.
+constexpr uint32_t kCandRadixMax = 4096;
+constexpr size_t kCandRadixLdsBytes = sizeof(uint32_t) * (3 * (size_t)kCandRadixMax + 16 * 256);
 __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ cand_u, const uint32_t* __restrict__ ncand,
                                                     uint32_t cap, uint2* __restrict__ cand, float* __restrict__ cand_nb,
                                                     unsigned long long* __restrict__ gkeys, uint32_t gstride, uint32_t lds_keys)
@@ -2169,6 +2171,30 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
     if (n == 0) return;
     const size_t list = ((size_t)frame * kAkzMaxLevels + level) * cap;
     const CandU* seg = cand_u + list;
+    if (n <= kCandRadixMax) {
+        // positions inside a level are unique 32-bit keys (y << 16 | x): LSD radix sort of the ids in LDS (akz_common.h)
+        // instead of the bitonic network over padded 64-bit keys; lists of up to kCandRadixMax candidates (64 KB of LDS:
+        // two blocks per CU, as before)
+        uint32_t* rk = reinterpret_cast<uint32_t*>(smem);
+        uint32_t* ia = rk + kCandRadixMax;
+        uint32_t* ib = ia + kCandRadixMax;
+        uint32_t* wh = ib + kCandRadixMax;
+        __shared__ uint32_t s_tot[256];
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t xy = seg[i].xy;
+            rk[i] = ((xy >> 16) << 16) | (xy & 0xFFFFu);      // y in the high half: raster order
+            ia[i] = i;
+        }
+        const uint32_t* sorted = lds_radix_sort_ids(rk, ia, ib, wh, s_tot, n, 4);
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const CandU cu = seg[sorted[i]];
+            cand[list + i] = make_uint2(cu.xy, __float_as_uint(cu.v));
+            float4* nb = reinterpret_cast<float4*>(cand_nb + (list + i) * 8);
+            nb[0] = make_float4(cu.nb[0], cu.nb[1], cu.nb[2], cu.nb[3]);
+            nb[1] = make_float4(cu.nb[4], cu.nb[5], cu.nb[6], cu.nb[7]);
+        }
+        return;
+    }
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     // lists longer than the LDS buffer sort through the list's global key scratch (akz_common.h)
@@ -2708,7 +2734,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             hipLaunchKernelGGL(k_cand_rank, dim3(akz_div_up((int)c->max_cand, 32), nlev, n), dim3(256), 0, s, (const CandU*)S.d_cand_u,
                                S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
         else
-            hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024), sizeof(unsigned long long) * lds_keys, s, (const CandU*)S.d_cand_u,
+            hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024),
+                               std::max<size_t>(sizeof(unsigned long long) * lds_keys, kCandRadixLdsBytes), s, (const CandU*)S.d_cand_u,
                                S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb, S.d_keys_cand, np2, lds_keys);
         AKZ_LAUNCH_CHECK();
     }
