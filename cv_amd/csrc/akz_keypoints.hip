@@ -305,6 +305,13 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
         const float size2 = ki.size * ki.size;
         const float margin = ki.size * 1.001f + 0.01f;       // conservative: |dy| > margin  =>  dist > size^2
         if (lo < hi) {                                        // wave-uniform: some lane of this wave has a range
+            // the wave's own window in y (its 64 entries are neighbours in cache order: a few rows): an entry outside it
+            // cannot be within `size` of any lane's keypoint and is not broadcast
+            float wy_lo = has ? ki.y - margin : 3.0e38f, wy_hi = has ? ki.y + margin : -3.0e38f;
+            for (int off = 32; off > 0; off >>= 1) {
+                wy_lo = fminf(wy_lo, __shfl_xor(wy_lo, off));
+                wy_hi = fmaxf(wy_hi, __shfl_xor(wy_hi, off));
+            }
             for (uint32_t ck = lo >> 6; ck < ((hi + 63u) >> 6); ++ck) {
                 const float2 yr = s_yr[ck - cb0];
                 const uint32_t c_lo = ck * 64u, c_hi = c_lo + 64u;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
                     wmin = min(wmin, (uint32_t)__shfl_xor((int)wmin, off));
                     wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
                 }
-                unsigned long long m = __ballot(ec >= wmin && ec <= wmax);
+                unsigned long long m = __ballot(ec >= wmin && ec <= wmax && ey >= wy_lo && ey <= wy_hi);
                 while (m) {
                     const uint32_t t = (uint32_t)__ffsll((long long)m) - 1u;
                     m &= m - 1ull;
