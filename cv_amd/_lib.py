@@ -88,6 +88,13 @@ class ArrsacStats(C.Structure):
 
 
 RS_PRUNE_BOUND, RS_PRUNE_SPRT, RS_PRUNE_HALVE = 1, 2, 4
+RS_BATCH_SHUFFLE = 1
+
+
+class Camera(C.Structure):
+    """rs_camera (include/akz.h)."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("skew", C.c_double),
+                ("k1", C.c_double), ("use_k1", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OverflowInfo(C.Structure):
@@ -120,7 +127,8 @@ ABI_SYMBOLS = [
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
-    "rs_p3p_batch", "rs_debug_counts",
+    "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
+    "rs_stream", "rs_debug_scene",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
 ]
@@ -202,6 +210,14 @@ def lib():
     L.rs_arrsac_samples.argtypes = [C.c_uint64, u32, u32, u32, vp]
     L.rs_p3p_batch.argtypes = [vp, vp, vp, u32, vp, u32, C.c_double, vp, C.POINTER(u32), vp, u32, C.POINTER(u32)]
     L.rs_debug_counts.argtypes = [vp, vp, u32]
+    L.rs_debug_poses.argtypes = [vp, vp, vp, u32]
+    L.rs_batch_reserve.argtypes = [vp, u32]
+    L.rs_essential_arrsac_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(Camera), C.POINTER(Camera),
+                                                   C.POINTER(ArrsacParams), u32, vp, vp, vp, vp, vp, vp]
+    L.rs_sync.argtypes = [vp]
+    L.rs_stream.restype = vp
+    L.rs_stream.argtypes = [vp]
+    L.rs_debug_scene.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
     L.akz_timing_enable.argtypes = [vp, i32]
     L.akz_timing_reset.argtypes = [vp]
     L.akz_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

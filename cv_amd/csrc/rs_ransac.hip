@@ -1,18 +1,24 @@
-// rs_ransac.hip — batched two-view geometric verification on gfx950 (SURVEY.md §8a rows R1-R4,
-// BASELINE.json configs[3]): eight-point essential matrices for a batch of minimal samples, the four
-// candidate poses of each, the triangulation residual of every (pose, match) pair, consensus by inlier
-// count.  All f64 VALU work, -ffp-contract=off, the same operation sequence as oracle/ransac_oracle.c.
+// rs_ransac.hip — batched two-view geometric verification on gfx950 (SURVEY.md §8a rows R1-R5, §8f rank 1,
+// BASELINE.json configs[3]): eight-point essential matrices for batches of minimal samples, the four candidate poses
+// of each, the triangulation residual of every (pose, match) pair, consensus by inlier count — for one scene with
+// host buffers, or for a whole micro-batch of frame pairs straight from the matcher's device-resident pair lists.
+// All f64 VALU work, -ffp-contract=off, the same operation sequence as oracle/ransac_oracle.c.
 //
 // Reference code implemented here (paths relative to rust-cv/cv):
-//   CameraIntrinsics::calibrate (+K1)                     cv-pinhole/src/lib.rs:108-117,191-202   rs_calibrate (host)
-//   encode_epipolar_equation, EightPoint::from_matches    eight-point/src/lib.rs:11-58            k_rs_hypotheses
-//   EssentialMatrix::possible_unscaled_poses              cv-pinhole/src/essential.rs:114-162,217-231  k_rs_hypotheses
-//   CameraToCamera::residual                              cv-core/src/pose.rs:249-295             k_rs_score, k_rs_inliers
+//   CameraIntrinsics::calibrate (+K1)                     cv-pinhole/src/lib.rs:108-117,191-202   rs_calibrate, k_rsb_prepare
+//   encode_epipolar_equation, EightPoint::from_matches    eight-point/src/lib.rs:11-58            k_rsb_hypotheses
+//   EssentialMatrix::possible_unscaled_poses              cv-pinhole/src/essential.rs:114-162,217-231  k_rsb_hypotheses
+//   CameraToCamera::residual                              cv-core/src/pose.rs:249-295             k_rs_score, k_rsb_score, ...
 //   Consensus::model_inliers                              call sites akaze/tests/estimate_pose.rs:63-67,
-//                                                         tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1406
-// nalgebra's eigen/SVD and the arrsac sampler are un-vendored: the eigen-solver is the shared cyclic Jacobi
-// of include/akz_ransac_math.h, the minimal samples are supplied by the caller, and every hypothesis is
-// scored against every match (parity: oracle == HIP, bit for bit).
+//                                                         tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1412
+// nalgebra's eigen/SVD and the arrsac sampler are un-vendored: the eigen-solver is the shared cyclic Jacobi of
+// include/akz_ransac_math.h, the consensus loop is specified by oracle/arrsac_oracle.c (parity: oracle == HIP, bit for
+// bit).
+//
+// Layout: everything a call needs lives in one per-context arena of S scene slots (rs_batch_reserve); a scene is one
+// frame pair: its matches (bearings a / b, or bearings / world points), its hypotheses, poses, counters and live list.
+// Every kernel of the ARRSAC-shaped loop takes the scene from its block index, so ONE launch chain serves all scenes
+// of a micro-batch (grid = scenes x hypotheses): the launches a single scene is bound by are shared by 256 of them.
 #include <math.h>
 #include <vector>
 
@@ -29,71 +35,127 @@ constexpr int kItersRes = 1024;
 
 __device__ __forceinline__ bool finite_d(double v) { return v == v && fabs(v) != INFINITY; }
 
-// one lane per hypothesis; the 9x9 normal matrix and its eigenvectors live in LDS, interleaved across the
-// 64 lanes (element e of lane t at [e*64 + t]) so every access is conflict-free.
-__global__ __launch_bounds__(64) void k_rs_hypotheses(const double* __restrict__ ba, const double* __restrict__ bb,
-                                                      const uint32_t* __restrict__ sample_idx, uint32_t n_hyp,
-                                                      double* __restrict__ poses, uint32_t* __restrict__ ok)
+// cv_pinhole::CameraIntrinsics::calibrate / CameraIntrinsicsK1Distortion::calibrate for one keypoint
+// (cv-pinhole/src/lib.rs:108-117,191-202): the host entry point and the batch kernel share this statement.
+__host__ __device__ __forceinline__ void rs_calibrate_one(const double* intr /* fx, fy, cx, cy, skew */, int use_k1, double k1,
+                                                          float kx, float ky, double* out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* sM = reinterpret_cast<double*>(smem) + threadIdx.x;        // [81][64]
-    double* sV = reinterpret_cast<double*>(smem) + 81 * 64 + threadIdx.x;
-    const uint32_t hh = blockIdx.x * 64 + threadIdx.x;
-    if (hh >= n_hyp) return;
-    double A[8][9];
+    double cx = (double)kx - intr[2], cy = (double)ky - intr[3];
+    double y = cy / intr[1];
+    double x = (cx - intr[4] * y) / intr[0];
+    if (use_k1) {
+        double r2 = x * x + y * y;
+        double d = 1.0 + k1 * r2;
+        x = x / d;
+        y = y / d;
+    }
+    double nrm = AKZ_RM_SQRT(x * x + y * y + 1.0 * 1.0);
+    out[0] = x / nrm;
+    out[1] = y / nrm;
+    out[2] = 1.0 / nrm;
+}
+
+// EightPoint::from_matches + possible_unscaled_poses for one minimal sample, ONE LANE, registers only: the 9 x 9
+// normal matrix (upper triangle) and its 81 eigenvector components never leave the register file (akz_rm_jacobi9_sym;
+// the kernel is compiled for one wave per SIMD, 512 VGPRs).  a / b: the scene's bearings; smp: 8 match indices.
+// Returns validity; poses[4][12] row-major [R | t] in the reference's order (t,R1), (t,R2), (-t,R1), (-t,R2).
+__device__ __forceinline__ bool rs_eight_point_poses(const double* __restrict__ ba, const double* __restrict__ bb,
+                                                     const uint32_t* __restrict__ smp, double* __restrict__ out)
+{
+    double M[81], V[81];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) M[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
-        uint32_t m = sample_idx[(size_t)hh * 8 + i];
+        const uint32_t m = smp[i];
         const double* a = ba + (size_t)3 * m;
         const double* b = bb + (size_t)3 * m;
-        double az = a[2];
-        double ap[3] = {a[0] / az, a[1] / az, a[2] / az};
-        double bp[3] = {b[0] / az, b[1] / az, b[2] / az};  // sic: divided by a.z (eight-point/src/lib.rs:16)
+        const double az = a[2];
+        const double ap[3] = {a[0] / az, a[1] / az, a[2] / az};
+        const double bp[3] = {b[0] / az, b[1] / az, b[2] / az};  // sic: divided by a.z (eight-point/src/lib.rs:16)
+        double A[9];
+#pragma unroll
         for (int j = 0; j < 3; ++j)
-            for (int k = 0; k < 3; ++k) A[i][3 * j + k] = ap[j] * bp[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A[3 * j + k] = ap[j] * bp[k];
+        // M(r,c) = sum_i A_i[r] A_i[c], i ascending, starting from +0 — entry by entry the oracle's sum
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+            for (int c = r; c < 9; ++c) M[r * 9 + c] += A[r] * A[c];
     }
-    for (int r = 0; r < 9; ++r)
-        for (int c = 0; c < 9; ++c) {
-            double s = 0.0;
-            for (int i = 0; i < 8; ++i) s += A[i][r] * A[i][c];
-            sM[(r * 9 + c) * 64] = s;
-        }
-    akz_rm_jacobi9(sM, sV, 64, kEpsHyp, kItersHyp);
-    int best = 0;
-    for (int i = 1; i < 9; ++i)
-        if (sM[(i * 9 + i) * 64] < sM[(best * 9 + best) * 64]) best = i;
+    akz_rm_jacobi9_sym(M, V, kEpsHyp, kItersHyp);
+    // eigenvector of the smallest eigenvalue (first minimum), selected without a runtime index
+    double bestv = M[0];
+    double ev[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) ev[e] = V[e * 9];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const bool take = M[i * 9 + i] < bestv;
+        bestv = take ? M[i * 9 + i] : bestv;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) ev[e] = take ? V[e * 9 + i] : ev[e];
+    }
     double E[9];
     bool good = true;
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            E[r * 3 + c] = sV[((c * 3 + r) * 9 + best) * 64];  // Matrix3::from_iterator is column-major
+            E[r * 3 + c] = ev[c * 3 + r];  // Matrix3::from_iterator is column-major
             good = good && finite_d(E[r * 3 + c]);
         }
     // possible_unscaled_poses: SVD of E through the eigen-decomposition of E^T E
-    double M[9], V[9];
+    double M3[9], V3[9];
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             double s = 0.0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) s += E[k * 3 + r] * E[k * 3 + c];
-            M[r * 3 + c] = s;
+            M3[r * 3 + c] = s;
         }
-    akz_rm_jacobi3(M, V, 1, kEpsHyp, kItersHyp);
-    int ord[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (M[ord[j] * 3 + ord[j]] > M[ord[i] * 3 + ord[i]]) {
-                int t = ord[i];
-                ord[i] = ord[j];
-                ord[j] = t;
-            }
-    double Vs[9], U[9];
+    akz_rm_jacobi3(M3, V3, 1, kEpsHyp, kItersHyp);
+    // singular values descending, stable: the oracle's exchange sort of an index triple, here on (value, column)
+    // triples with selects — (0,1), (0,2), (1,2), exchanging when the later one is strictly larger
+    double lam[3] = {M3[0], M3[4], M3[8]};
+    double col[3][3];
+#pragma unroll
     for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) Vs[r * 3 + c] = V[r * 3 + ord[c]];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) col[c][r] = V3[r * 3 + c];
+#define RS_CSWAP(I, J)                                           \
+    {                                                            \
+        const bool sw = lam[J] > lam[I];                         \
+        const double tl = lam[I];                                \
+        lam[I] = sw ? lam[J] : lam[I];                           \
+        lam[J] = sw ? tl : lam[J];                               \
+        for (int r = 0; r < 3; ++r) {                            \
+            const double tc = col[I][r];                         \
+            col[I][r] = sw ? col[J][r] : col[I][r];              \
+            col[J][r] = sw ? tc : col[J][r];                     \
+        }                                                        \
+    }
+    RS_CSWAP(0, 1)
+    RS_CSWAP(0, 2)
+    RS_CSWAP(1, 2)
+#undef RS_CSWAP
+    double Vs[9], U[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Vs[r * 3 + c] = col[c][r];
+#pragma unroll
     for (int c = 0; c < 2; ++c) {
-        double lam = M[ord[c] * 3 + ord[c]];
-        double s = AKZ_RM_SQRT(lam > 0.0 ? lam : 0.0);
+        const double l = lam[c];
+        const double s = AKZ_RM_SQRT(l > 0.0 ? l : 0.0);
         if (!(s > 0.0)) good = false;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
             double acc = 0.0;
+#pragma unroll
             for (int k = 0; k < 3; ++k) acc += E[r * 3 + k] * Vs[k * 3 + c];
             U[r * 3 + c] = acc / s;
         }
@@ -101,46 +163,54 @@ __global__ __launch_bounds__(64) void k_rs_hypotheses(const double* __restrict__
     U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
     U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
     U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
-    double detV = Vs[0] * (Vs[4] * Vs[8] - Vs[5] * Vs[7]) - Vs[1] * (Vs[3] * Vs[8] - Vs[5] * Vs[6]) +
-                  Vs[2] * (Vs[3] * Vs[7] - Vs[4] * Vs[6]);
+    const double detV = Vs[0] * (Vs[4] * Vs[8] - Vs[5] * Vs[7]) - Vs[1] * (Vs[3] * Vs[8] - Vs[5] * Vs[6]) +
+                        Vs[2] * (Vs[3] * Vs[7] - Vs[4] * Vs[6]);
     if (detV < 0.0)
+#pragma unroll
         for (int r = 0; r < 3; ++r) Vs[r * 3 + 2] = -Vs[r * 3 + 2];
     // R1 = U W V^T, R2 = U W^T V^T with W = [[0,-1,0],[1,0,0],[0,0,1]]; the products are written out with
     // the same term order as the oracle's generic 3x3 multiply (k = 0,1,2, zeros included)
     const double W[9] = {0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
     const double Wt[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
     double R[2][9];
+#pragma unroll
     for (int which = 0; which < 2; ++which) {
-        const double* Wm = which ? Wt : W;
         double UW[9];
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 double s = 0.0;
-                for (int k = 0; k < 3; ++k) s += U[r * 3 + k] * Wm[k * 3 + c];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += U[r * 3 + k] * (which ? Wt[k * 3 + c] : W[k * 3 + c]);
                 UW[r * 3 + c] = s;
             }
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 double s = 0.0;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) s += UW[r * 3 + k] * Vs[c * 3 + k];  // V^T(k,c) = Vs(c,k)
                 R[which][r * 3 + c] = s;
             }
     }
     const double t[3] = {U[2], U[5], U[8]};
-    double* out = poses + (size_t)hh * 48;
+#pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const double* Rm = R[p & 1];
-        double sg = (p & 2) ? -1.0 : 1.0;
+        const double sg = (p & 2) ? -1.0 : 1.0;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
-                out[p * 12 + r * 4 + c] = Rm[r * 3 + c];
-                good = good && finite_d(Rm[r * 3 + c]);
+                out[p * 12 + r * 4 + c] = R[p & 1][r * 3 + c];
+                good = good && finite_d(R[p & 1][r * 3 + c]);
             }
             out[p * 12 + r * 4 + 3] = sg * t[r];
             good = good && finite_d(t[r]);
         }
     }
-    for (int p = 0; p < 4; ++p) ok[(size_t)hh * 4 + p] = good ? 1u : 0u;  // validity per pose
+    return good;
 }
 
 // CameraToCamera::residual for one (pose, match) — cv-core/src/pose.rs:249-295.
@@ -199,6 +269,35 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
     return res == res ? res : 2.0;
 }
 
+// ---- the scene arena as the kernels see it ---------------------------------------------------------------------
+// Scene s owns slot s of every array: n_cap matches, H hypothesis slots (4 poses each).
+struct RsB {
+    uint32_t n_cap, H;
+    const uint32_t* n;          // [S] matches of the scene
+    const double* a;            // [S][n_cap][3] bearings of view a (P3P: the bearings)
+    const double* b;            // [S][n_cap][4] slots: bearings of view b packed [n][3], or world points [n][4]
+    const uint32_t* order;      // [S][n_cap] scoring order (position -> match), or nullptr = identity
+    uint32_t* samples;          // [S][H][K]   (slot stride 8 H)
+    double* poses;              // [S][H][4][12]
+    uint32_t* ok;               // [S][4H] validity per pose
+    uint32_t* counts;           // [S][4H] inliers among the matches scored so far
+    uint32_t* alive;            // [S][4H] live poses in ascending id order
+    uint32_t* nalive;           // [S]
+    unsigned long long* neval;  // [S] residuals evaluated
+    uint32_t* best;             // [S][4]: pose id, its count, live poses
+    uint32_t* inl;              // [S][n_cap] inlier list (re-sampling rounds / single-scene output)
+    uint32_t* ninl;             // [S]
+    double* best_pose;          // [S][12]
+    uint32_t* first;            // [S] first slot a re-sampling round appended
+    uint32_t* enable;           // [S] the round drew samples (enough inliers)
+    __device__ __forceinline__ const double* sa(uint32_t s) const { return a + (size_t)s * n_cap * 3; }
+    __device__ __forceinline__ const double* sb(uint32_t s) const { return b + (size_t)s * n_cap * 4; }
+    __device__ __forceinline__ uint32_t* ssamples(uint32_t s) const { return samples + (size_t)s * H * 8; }
+    __device__ __forceinline__ double* sposes(uint32_t s) const { return poses + (size_t)s * H * 48; }
+    __device__ __forceinline__ size_t p4(uint32_t s) const { return (size_t)s * H * 4; }
+};
+
+// ---- exhaustive scoring of caller-provided samples (rs_essential_batch / rs_p3p_batch: one scene, slot 0) --------
 // grid: (match blocks, pose id = hyp*4 + p).  Inlier count per pose by ballot + one atomic per wave.
 __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba, const double* __restrict__ bb,
                                                   uint32_t n, const double* __restrict__ poses,
@@ -220,59 +319,39 @@ __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba,
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
 }
 
-// argmax of (count, -id): the pose with the most inliers, lowest id on ties (= the oracle's first-maximum scan)
-__global__ __launch_bounds__(1024) void k_rs_best(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ok,
-                                                  uint32_t n_pose, uint32_t* __restrict__ best)
+__global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ bearings, const double* __restrict__ world,
+                                                   uint32_t n, const double* __restrict__ poses,
+                                                   const uint32_t* __restrict__ ok, double thresh,
+                                                   uint32_t* __restrict__ counts)
 {
-    __shared__ unsigned long long s_key[16];
-    unsigned long long key = 0ull;  // 0 = nothing valid
-    for (uint32_t i = threadIdx.x; i < n_pose; i += 1024)
-        if (ok[i]) {
-            unsigned long long k = ((unsigned long long)(counts[i] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
-            key = k > key ? k : key;
-        }
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_down(key, off);
-        key = o > key ? o : key;
+    const uint32_t pid = blockIdx.y;
+    if (!ok[pid]) return;
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    bool inl = false;
+    if (m < n) {
+        double pose[12];
+        for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+        double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
+        double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
+        inl = akz_w2c_residual(pose, b, w) < thresh;
     }
-    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
-        best[0] = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
-        best[1] = key ? (uint32_t)(key >> 32) - 1u : 0u;
-    }
+    unsigned long long bal = __ballot(inl);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
 }
 
-// inlier indices of the best pose in ascending match order (ordered compaction, one block)
-__global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ ba, const double* __restrict__ bb,
-                                                     uint32_t n, const double* __restrict__ poses,
-                                                     const uint32_t* __restrict__ best, double thresh,
-                                                     uint32_t* __restrict__ inlier_idx, uint32_t cap,
-                                                     uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose,
-                                                     unsigned long long* __restrict__ n_eval)
+// every valid pose joins the live list (exhaustive scoring keeps them all): the live-list kernels then pick the winner
+__global__ __launch_bounds__(1024) void k_rsb_alive_init(RsB B, uint32_t n_pose)
 {
     __shared__ uint32_t s_wave[16];
-    const uint32_t pid = best[0];
-    if (pid == 0xFFFFFFFFu) {
-        if (threadIdx.x == 0) *n_inliers = 0;
-        return;
-    }
-    if (threadIdx.x == 0 && n_eval) atomicAdd(n_eval, (unsigned long long)n);
-    double pose[12];
-    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
-    if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
+    const uint32_t s = blockIdx.x;
+    const uint32_t* ok = B.ok + B.p4(s);
+    uint32_t* alive = B.alive + B.p4(s);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t base = 0;
-    for (uint32_t m0 = 0; m0 < n; m0 += 1024) {
-        uint32_t m = m0 + threadIdx.x;
-        bool inl = false;
-        if (m < n) {
-            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
-            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-            inl = rs_residual(pose, a, b) < thresh;
-        }
-        unsigned long long bal = __ballot(inl);
+    for (uint32_t i0 = 0; i0 < n_pose; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool keep = i < n_pose && ok[i] != 0;
+        const unsigned long long bal = __ballot(keep);
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t woff = 0, tot = 0;
@@ -280,28 +359,27 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
             if (q < wv) woff += s_wave[q];
             tot += s_wave[q];
         }
-        if (inl) {
-            uint32_t o = base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (o < cap) inlier_idx[o] = m;
-        }
+        if (keep) alive[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
         base += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_inliers = base;
+    if (threadIdx.x == 0) B.nalive[s] = base;
 }
 
 // ---- ARRSAC-shaped consensus (row R4) ---------------------------------------------------
 // arrsac::Arrsac::model_inliers (un-vendored crate, arrsac 0.10; call sites vslam-sandbox/src/main.rs:105-117,
 // cv-sfm/src/lib.rs:1394-1412) scores its hypotheses breadth-first, block of matches by block of matches, and drops
-// the ones that can no longer win.  The same shape on the device:
-//   k_rs_sample        xoshiro256++ minimal samples drawn on the device (the caller need not ship n_hyp x 8 indices)
-//   k_rs_score_block   every live pose against the next `block` matches (one wave per pose and 64 matches)
-//   k_rs_prune         after each block: the best count so far B, then a pose is retired when
+// the ones that can no longer win.  The same shape on the device, every kernel over all scenes of the call:
+//   k_rsb_prepare      (micro-batch entry) calibrate the matcher's pairs into bearings, optional seeded shuffle order
+//   k_rsb_sample       xoshiro256++ minimal samples drawn on the device (the caller need not ship n_hyp x 8 indices)
+//   k_rsb_hypotheses   one lane per minimal sample: essential matrix + four poses, registers only
+//   k_rsb_score        every live pose against the next `block` matches (2^lg lanes per pose)
+//   k_rsb_prune        after each block: the best count so far B, then a pose is retired when
 //                        (bound)  count + matches_left < B            — it cannot reach the best: exact, always on
 //                        (cap)    it is not among the max_candidates best after the initialisation blocks
 //                        (SPRT)   its likelihood ratio (delta/eps)^c ((1-delta)/(1-eps))^(seen-c) exceeds the threshold,
 //                                 eps = B / seen (Wald's test as in SPRT-RANSAC; arrsac's likelihood_ratio_threshold)
-//                      and the survivors are compacted in ascending pose order (device-side count, no host round trip).
+//                      and the survivors are compacted in place, ascending pose order (device-side count, no host hop).
 // With the bound alone the winner, its count and its inlier set are those of exhaustive scoring.
 struct Xo256 {
     unsigned long long s[4];
@@ -345,62 +423,122 @@ __host__ __device__ __forceinline__ void rs_draw_sample(unsigned long long seed,
         out[i] = v;
     }
 }
+// scene s of a batched call draws from its own seed (scene 0 = the caller's seed: a one-scene call is the batch of one)
+__host__ __device__ __forceinline__ unsigned long long rs_scene_seed(unsigned long long seed, uint32_t s)
+{
+    return seed + 0x9E3779B97F4A7C15ull * (unsigned long long)s;
+}
+// key of match j in the seeded shuffle of a scene's matches (cv-sfm/src/lib.rs:1385 shuffles them with the caller's
+// rng before the consensus): the scoring order is the stable ascending sort of these 32-bit keys
+__host__ __device__ __forceinline__ uint32_t rs_shuffle_key(unsigned long long scene_seed, uint32_t j)
+{
+    unsigned long long x = (scene_seed ^ 0x5851F42D4C957F2Dull) + 0xD1342543DE82EF95ull * (unsigned long long)j;
+    return (uint32_t)(xo_splitmix(&x) >> 32);
+}
 
 template <int K>
-__global__ __launch_bounds__(256) void k_rs_sample(unsigned long long seed, uint32_t n, uint32_t n_hyp, uint32_t* __restrict__ sample_idx)
+__global__ __launch_bounds__(256) void k_rsb_sample(RsB B, unsigned long long seed, uint32_t n_hyp)
 {
+    const uint32_t s = blockIdx.y;
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
-    if (h >= n_hyp) return;
-    uint32_t s[K];
-    rs_draw_sample<K>(seed, h, n, s);
-    for (int i = 0; i < K; ++i) sample_idx[(size_t)h * K + i] = s[i];
+    const uint32_t n = B.n[s];
+    if (h >= n_hyp || n < (uint32_t)K) return;
+    uint32_t smp[K];
+    rs_draw_sample<K>(rs_scene_seed(seed, s), h, n, smp);
+    uint32_t* out = B.ssamples(s) + (size_t)h * K;
+    for (int i = 0; i < K; ++i) out[i] = smp[i];
 }
 
-// alive list initialisation: valid poses in ascending order (one block)
-__global__ __launch_bounds__(1024) void k_rs_alive_init(const uint32_t* __restrict__ ok, uint32_t n_pose, uint32_t* __restrict__ alive,
-                                                        uint32_t* __restrict__ n_alive)
+// one lane per hypothesis h0 + i of scene blockIdx.y.  gate (optional, per scene): a re-sampling round that drew nothing.
+__global__ __launch_bounds__(64) void k_rsb_hypotheses(RsB B, uint32_t h0, uint32_t nh, const uint32_t* __restrict__ gate)
 {
-    __shared__ uint32_t s_wave[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t base = 0;
-    for (uint32_t i0 = 0; i0 < n_pose; i0 += 1024) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool keep = i < n_pose && ok[i] != 0;
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (int q = 0; q < 16; ++q) {
-            if (q < wv) woff += s_wave[q];
-            tot += s_wave[q];
-        }
-        if (keep) alive[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
-        base += tot;
-        __syncthreads();
+    const uint32_t s = blockIdx.y;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nh) return;
+    const uint32_t hh = h0 + i;
+    uint32_t* ok = B.ok + B.p4(s) + (size_t)hh * 4;
+    if (B.n[s] < 8u || (gate && !gate[s])) {
+        for (int p = 0; p < 4; ++p) ok[p] = 0u;
+        return;
     }
-    if (threadIdx.x == 0) *n_alive = base;
+    uint32_t smp[8];
+    const uint32_t* sp = B.ssamples(s) + (size_t)hh * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) smp[k] = sp[k];
+    double P[48];
+    const bool good = rs_eight_point_poses(B.sa(s), B.sb(s), smp, P);
+    double* out = B.sposes(s) + (size_t)hh * 48;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) out[k] = P[k];
+    for (int p = 0; p < 4; ++p) ok[p] = good ? 1u : 0u;  // validity per pose
 }
 
-// one wave per (live pose, 64 matches of the block); grid.x covers the worst case, waves beyond the live count exit
-template <bool P3P>   // P3P: ba = bearings [n][3], bb = world points [n][4], WorldToCamera::residual (cv-core/src/pose.rs:194-201)
-__global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict__ ba, const double* __restrict__ bb, uint32_t m_lo,
-                                                        uint32_t m_hi, const double* __restrict__ poses,
-                                                        const uint32_t* __restrict__ alive, const uint32_t* __restrict__ n_alive,
-                                                        const uint32_t* __restrict__ first, double thresh,
-                                                        uint32_t* __restrict__ counts, unsigned long long* __restrict__ n_eval)
+// ---- PnP: Lambda Twist hypotheses (row R5), same indexing; bearings in a, world points [n][4] in b ----
+__global__ __launch_bounds__(64) void k_rsb_p3p_hypotheses(RsB B, uint32_t h0, uint32_t nh, const uint32_t* __restrict__ gate)
 {
-    // `first` (optional): score only the list entries from *first on (the poses a re-sampling round appended)
-    const uint32_t slot = (first ? *first : 0u) + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= *n_alive) return;
-    const uint32_t pid = alive[slot];
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t s = blockIdx.y;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nh) return;
+    const uint32_t hh = h0 + i;
+    uint32_t* ok = B.ok + B.p4(s) + (size_t)hh * 4;
+    if (B.n[s] < 3u || (gate && !gate[s])) {
+        for (int p = 0; p < 4; ++p) ok[p] = 0u;
+        return;
+    }
+    const double* bearings = B.sa(s);
+    const double* world = B.sb(s);
+    const uint32_t* sp = B.ssamples(s) + (size_t)hh * 3;
+    double b3[9], w3[12], P[48];
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t m = sp[k];
+        for (int q = 0; q < 3; ++q) b3[3 * k + q] = bearings[(size_t)3 * m + q];
+        for (int q = 0; q < 4; ++q) w3[4 * k + q] = world[(size_t)4 * m + q];
+    }
+    const int np = akz_p3p_poses(b3, w3, 5, P);  // LambdaTwist::default(): 5 Gauss-Newton iterations
+    double* out = B.sposes(s) + (size_t)hh * 48;
+    for (int p = 0; p < 4; ++p) {
+        ok[p] = p < np ? 1u : 0u;
+        if (p < np)
+            for (int k = 0; k < 12; ++k) out[p * 12 + k] = P[p * 12 + k];
+    }
+}
+
+// Block scoring.  Scene = blockIdx.z; a pose takes 2^lg lanes (one match each), a wave 64 >> lg poses: a 16-match
+// block of the initialisation round keeps every lane busy on four poses instead of a quarter of them on one.
+// Positions [m_lo, min(m_hi, n_s)) of the scene's scoring order; blockIdx.y strides the positions of long blocks.
+// from_first: only the slots a re-sampling round appended (catching up on the matches seen so far).
+template <bool P3P>
+__global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_t m_hi, uint32_t lg, uint32_t from_first,
+                                                   double thresh)
+{
+    const uint32_t s = blockIdx.z;
+    const uint32_t n = B.n[s];
+    const uint32_t hi = m_hi < n ? m_hi : n;
+    if (m_lo >= hi) return;
+    const uint32_t G = 1u << lg, lane = threadIdx.x & 63u, g = lane >> lg, j = lane & (G - 1u);
+    const uint32_t first = from_first ? B.first[s] : 0u;
+    const uint32_t nal = B.nalive[s];
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave == 0 && lane == 0 && blockIdx.y == 0 && nal > first)
+        atomicAdd(&B.neval[s], (unsigned long long)(nal - first) * (unsigned long long)(hi - m_lo));
+    const uint32_t slot0 = first + (wave << (6u - lg));
+    if (slot0 >= nal) return;
+    const uint32_t slot = slot0 + g;
+    const bool live = slot < nal;
+    const uint32_t pid = live ? B.alive[B.p4(s) + slot] : 0u;
     double pose[12];
-    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    const double* pp = B.sposes(s) + (size_t)pid * 12;
+    for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
+    const double* ba = B.sa(s);
+    const double* bb = B.sb(s);
+    const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
+    const unsigned long long gmask = (lg == 6u ? ~0ull : ((1ull << G) - 1ull)) << (g << lg);
     uint32_t cnt = 0;
-    for (uint32_t m0 = m_lo + blockIdx.y * 64; m0 < m_hi; m0 += gridDim.y * 64) {
-        const uint32_t m = m0 + lane;
+    for (uint32_t m0 = m_lo + blockIdx.y * G; m0 < hi; m0 += gridDim.y * G) {
+        const uint32_t pos = m0 + j;
         bool inl = false;
-        if (m < m_hi) {
+        if (live && pos < hi) {
+            const uint32_t m = order ? order[pos] : pos;
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
             if (P3P) {
                 double wp[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
@@ -410,54 +548,64 @@ __global__ __launch_bounds__(256) void k_rs_score_block(const double* __restrict
                 inl = rs_residual(pose, a, b) < thresh;
             }
         }
-        cnt += (uint32_t)__popcll(__ballot(inl));
+        cnt += (uint32_t)__popcll(__ballot(inl) & gmask);
     }
-    if (lane == 0) {
-        if (cnt) atomicAdd(&counts[pid], cnt);
-        if (blockIdx.y == 0) atomicAdd(n_eval, (unsigned long long)(m_hi - m_lo));
-    }
+    if (live && j == 0 && cnt) atomicAdd(&B.counts[B.p4(s) + pid], cnt);
 }
 
 struct RsPrune {
-    uint32_t seen, n_total;       // matches scored so far / in all
+    uint32_t seen;                // matches scored so far (the same position for every scene still running)
     uint32_t cap;                 // keep at most this many poses from now on (0 = no cap)
-    uint32_t use_sprt;
+    uint32_t use_sprt, pad;
     double log_delta, log_1m_delta, log_ratio;   // ln(delta), ln(1 - delta), ln(likelihood ratio threshold)
-    const double* log_table;      // ln(k), k = 0 .. n_total, filled by the host's libm (no device transcendental decides)
+    const double* log_table;      // ln(k), k = 0 .. n_cap, filled by the host's libm (no device transcendental decides)
 };
 
-__global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ alive_in,
-                                                   const uint32_t* __restrict__ n_in, uint32_t* __restrict__ alive_out,
-                                                   uint32_t* __restrict__ n_out)
+// One workgroup per scene.  The cap ranks the poses by their exact distance to the best count: a 2048-bin histogram of
+// best - count (poses 2047 or more inliers behind the best share the last bin), so the best-supported poses are never
+// the ones the cap retires; ties at the threshold are admitted in ascending pose order while the budget lasts.
+__global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
 {
     __shared__ uint32_t s_wave[16], s_wave_t[16];
     __shared__ uint32_t s_hist[2048];
     __shared__ uint32_t s_best, s_T, s_budget;
-    const uint32_t n = *n_in;
+    const uint32_t s = blockIdx.x;
+    const uint32_t n_total = B.n[s];
+    if (P.seen >= n_total) return;            // no retirement after a scene's last block (nor for scenes that ended earlier)
+    const uint32_t* counts = B.counts + B.p4(s);
+    uint32_t* alive = B.alive + B.p4(s);
+    const uint32_t n = B.nalive[s];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_best = 0;
     for (int i = threadIdx.x; i < 2048; i += 1024) s_hist[i] = 0;
     __syncthreads();
     uint32_t lmax = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t c = counts[alive_in[i]];
+        const uint32_t c = counts[alive[i]];
         lmax = c > lmax ? c : lmax;
-        if (P.cap) atomicAdd(&s_hist[c < 2047u ? c : 2047u], 1u);
     }
     atomicMax(&s_best, lmax);
     __syncthreads();
-    const uint32_t best = s_best, left = P.n_total - P.seen;
+    const uint32_t best = s_best, left = n_total - P.seen;
+    const bool capped = P.cap && n > P.cap;
+    if (capped) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t d = best - counts[alive[i]];
+            atomicAdd(&s_hist[d < 2047u ? d : 2047u], 1u);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        // count threshold of the cap: poses with count > T all stay, those with count == T in pose order up to the budget
-        uint32_t T = 0, budget = 0xFFFFFFFFu;
-        if (P.cap && n > P.cap) {
+        // distance threshold of the cap: poses closer than T to the best all stay, those at T in pose order up to the budget
+        uint32_t T = 0xFFFFFFFFu, budget = 0xFFFFFFFFu;
+        if (capped) {
             uint32_t acc = 0;
-            int t = 2047;
-            for (; t >= 0; --t) {
+            uint32_t t = 0;
+            for (; t < 2048u; ++t) {
                 if (acc + s_hist[t] >= P.cap) break;
                 acc += s_hist[t];
             }
-            T = (uint32_t)(t < 0 ? 0 : t);
+            T = t < 2048u ? t : 2047u;
             budget = P.cap - acc;
         }
         s_T = T;
@@ -478,15 +626,15 @@ __global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __
         bool keep = false, tie = false;
         uint32_t pid = 0;
         if (i < n) {
-            pid = alive_in[i];
+            pid = alive[i];
             const uint32_t c = counts[pid];
             keep = c + left >= best;                                                   // bound (exact)
             if (keep && P.use_sprt && l_out > 0.0)
                 keep = (double)c * l_in + (double)(P.seen - c) * l_out <= P.log_ratio || c == best;
-            const uint32_t cc = c < 2047u ? c : 2047u;
-            if (keep && P.cap && n > P.cap) {
-                if (cc < T) keep = false;
-                tie = keep && cc == T;
+            const uint32_t d = best - c, dd = d < 2047u ? d : 2047u;
+            if (keep && capped) {
+                if (dd > T) keep = false;
+                tie = keep && dd == T;
             }
         }
         // ties at the cap threshold are admitted in pose order while the budget lasts
@@ -511,45 +659,44 @@ __global__ __launch_bounds__(1024) void k_rs_prune(RsPrune P, const uint32_t* __
             if (q < wv) woff += s_wave[q];
             tot += s_wave[q];
         }
-        if (keep) alive_out[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = pid;
+        // in place: every read of this 1024-slot step happened before the barriers above, and a survivor moves to a
+        // slot at or before its own
+        if (keep) alive[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = pid;
         base += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_out = base;
+    if (threadIdx.x == 0) B.nalive[s] = base;
 }
 
 // inlier-guided re-sampling (arrsac's estimations_per_block): E new minimal samples drawn among the inliers (over the
-// matches seen so far, list L of length *nL) of the best pose; disabled (flag 0) when there are fewer than K inliers
+// matches seen so far, list inl[] of length ninl) of the best pose; disabled (enable 0) with fewer than K inliers
 template <int K>
-__global__ __launch_bounds__(256) void k_rs_resample(unsigned long long seed, uint32_t next_h, uint32_t E,
-                                                     const uint32_t* __restrict__ L, const uint32_t* __restrict__ nL,
-                                                     uint32_t* __restrict__ sample_idx, uint32_t* __restrict__ enable)
+__global__ __launch_bounds__(256) void k_rsb_resample(RsB B, unsigned long long seed, uint32_t next_h, uint32_t E)
 {
+    const uint32_t s = blockIdx.y;
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t n = *nL;
-    if (e == 0) *enable = n >= (uint32_t)K ? 1u : 0u;
-    if (e >= E) return;
+    const uint32_t n = B.ninl[s];
+    if (e == 0) B.enable[s] = n >= (uint32_t)K ? 1u : 0u;
+    if (e >= E || n < (uint32_t)K) return;
     const uint32_t h = next_h + e;
-    uint32_t s[K];
-    if (n >= (uint32_t)K) {
-        rs_draw_sample<K>(seed ^ 0xA5A5A5A55A5A5A5Aull, h, n, s);
-        for (int i = 0; i < K; ++i) s[i] = L[s[i]];
-    } else {
-        for (int i = 0; i < K; ++i) s[i] = (uint32_t)i;    // placeholder: the hypotheses are gated off below
-    }
-    for (int i = 0; i < K; ++i) sample_idx[(size_t)h * K + i] = s[i];
+    const uint32_t* L = B.inl + (size_t)s * B.n_cap;
+    uint32_t smp[K];
+    rs_draw_sample<K>(rs_scene_seed(seed, s) ^ 0xA5A5A5A55A5A5A5Aull, h, n, smp);
+    uint32_t* out = B.ssamples(s) + (size_t)h * K;
+    for (int i = 0; i < K; ++i) out[i] = L[smp[i]];
 }
 
 // valid new poses join the live list in (hypothesis, pose) order — their ids exceed every id already in it — with
-// zeroed counters; *first receives the list length before the append
-__global__ __launch_bounds__(1024) void k_rs_alive_append(const uint32_t* __restrict__ ok, uint32_t base_pid, uint32_t n_new,
-                                                          const uint32_t* __restrict__ enable, uint32_t* __restrict__ alive,
-                                                          uint32_t* __restrict__ n_alive, uint32_t* __restrict__ first,
-                                                          uint32_t* __restrict__ counts)
+// zeroed counters; first[s] receives the list length before the append
+__global__ __launch_bounds__(1024) void k_rsb_alive_append(RsB B, uint32_t base_pid, uint32_t n_new)
 {
     __shared__ uint32_t s_wave[16];
+    const uint32_t s = blockIdx.x;
+    const uint32_t* ok = B.ok + B.p4(s);
+    uint32_t* alive = B.alive + B.p4(s);
+    uint32_t* counts = B.counts + B.p4(s);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t old = *n_alive, on = *enable;
+    const uint32_t old = B.nalive[s], on = B.enable[s];
     uint32_t base = old;
     for (uint32_t i0 = 0; i0 < n_new; i0 += 1024) {
         const uint32_t i = i0 + threadIdx.x;
@@ -568,23 +715,190 @@ __global__ __launch_bounds__(1024) void k_rs_alive_append(const uint32_t* __rest
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *first = old;
-        *n_alive = base;
+        B.first[s] = old;
+        B.nalive[s] = base;
     }
 }
 
-// argmax of (count, -id) over the survivors (all of them have seen every match)
-__global__ __launch_bounds__(1024) void k_rs_best_alive(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ alive,
-                                                        const uint32_t* __restrict__ n_alive, uint32_t* __restrict__ best)
+// where the results of a call go (device pointers; element s of each array belongs to scene s)
+struct RsOut {
+    uint32_t* best_id;        // [S]
+    double* pose;             // [S][12]
+    uint32_t* inl;            // [S][inl_stride]
+    uint32_t* ninl;           // [S]
+    rs_arrsac_stats* stats;   // [S] or nullptr
+    uint32_t inl_stride;
+    uint32_t n_hyp, resample, init_blocks;   // initial hypotheses, estimations_per_block, init_blocks of the call
+    uint32_t blocks_run, block_size, min_samples;
+};
+
+// One workgroup per scene: the best live pose — argmax of (count, -id) — and its inliers, ordered compaction.
+//   final = 0  re-sampling round after `limit` matches: inliers among the positions [0, limit) of the scoring order, in
+//              that order, into the arena's own list; scenes with no match left take no part (ninl = 0)
+//   final = 1  the answer: inliers over all matches in ascending match index, pose, id, stats -> O
+template <bool P3P>
+__global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit, uint32_t final_, double thresh, RsOut O)
 {
     __shared__ unsigned long long s_key[16];
-    unsigned long long key = 0ull;
-    const uint32_t n = *n_alive;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = B.n[s];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* out_inl = final_ ? O.inl + (size_t)s * O.inl_stride : B.inl + (size_t)s * B.n_cap;
+    uint32_t* out_n = final_ ? O.ninl + s : B.ninl + s;
+    if (!final_ && limit >= n) {
+        if (threadIdx.x == 0) *out_n = 0;
+        return;
+    }
+    const uint32_t* counts = B.counts + B.p4(s);
+    const uint32_t* alive = B.alive + B.p4(s);
+    const uint32_t nal = B.nalive[s];
+    unsigned long long key = 0ull;  // 0 = nothing alive
+    for (uint32_t i = threadIdx.x; i < nal; i += 1024) {
         const uint32_t pid = alive[i];
         const unsigned long long k = ((unsigned long long)(counts[pid] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - pid);
         key = k > key ? k : key;
     }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(key, off);
+        key = o > key ? o : key;
+    }
+    if (lane == 0) s_key[wv] = key;
+    __syncthreads();
+    key = s_key[0];
+    for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
+    const uint32_t pid = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
+    if (threadIdx.x == 0) {
+        B.best[4 * s + 0] = pid;
+        B.best[4 * s + 1] = key ? (uint32_t)(key >> 32) - 1u : 0u;
+        B.best[4 * s + 2] = nal;
+        if (final_) {
+            O.best_id[s] = pid;
+            if (O.stats) {
+                rs_arrsac_stats st;
+                // blocks this scene was scored on, and the re-sampling rounds that followed them (one after every block
+                // from init_blocks on that was not the scene's last)
+                const uint32_t per = O.block_size ? (n + O.block_size - 1u) / O.block_size : 1u;
+                const uint32_t blocks = n >= O.min_samples ? (per < O.blocks_run ? per : O.blocks_run) : 0u;
+                const uint32_t from = O.init_blocks > 1u ? O.init_blocks : 1u;
+                const uint32_t rounds = blocks > from ? blocks - from : 0u;
+                st.poses = n >= O.min_samples ? (O.n_hyp + O.resample * rounds) * 4u : 0u;
+                st.survivors = nal;
+                st.blocks = blocks;
+                st.reserved = 0;
+                st.residuals_evaluated = B.neval[s];
+                st.residuals_exhaustive = (uint64_t)st.poses * n;
+                O.stats[s] = st;
+            }
+        }
+    }
+    if (pid == 0xFFFFFFFFu) {
+        if (threadIdx.x == 0) *out_n = 0;
+        return;
+    }
+    const uint32_t range = final_ ? n : limit;
+    if (threadIdx.x == 0 && !final_) atomicAdd(&B.neval[s], (unsigned long long)range);
+    double pose[12];
+    const double* pp = B.sposes(s) + (size_t)pid * 12;
+    for (int i = 0; i < 12; ++i) pose[i] = pp[i];
+    if (final_ && threadIdx.x < 12) O.pose[(size_t)s * 12 + threadIdx.x] = pose[threadIdx.x];
+    const double* ba = B.sa(s);
+    const double* bb = B.sb(s);
+    const uint32_t* order = (!final_ && B.order) ? B.order + (size_t)s * B.n_cap : nullptr;
+    uint32_t base = 0;
+    for (uint32_t m0 = 0; m0 < range; m0 += 1024) {
+        const uint32_t pos = m0 + threadIdx.x;
+        bool inl = false;
+        uint32_t m = 0;
+        if (pos < range) {
+            m = order ? order[pos] : pos;
+            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+            if (P3P) {
+                double w[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
+                inl = akz_w2c_residual(pose, a, w) < thresh;
+            } else {
+                double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+                inl = rs_residual(pose, a, b) < thresh;
+            }
+        }
+        unsigned long long bal = __ballot(inl);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wv) woff += s_wave[q];
+            tot += s_wave[q];
+        }
+        if (inl) out_inl[base + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = m;
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_n = base;
+}
+
+// ---- micro-batch entry: the matcher's pair lists -> calibrated bearings (+ the seeded scoring order) ----------
+struct RsCam {
+    double intr[5];   // fx, fy, cx, cy, skew
+    double k1;
+    int use_k1, pad;
+};
+// One workgroup per scene.  Scene s = pair list `s` of the matcher's output ([cap][2] indices into keypoint blocks
+// fa[s] of d_kps_a and fb[s] of d_kps_b); FeatureMatch(a, b) of cv-sfm/src/lib.rs:1400-1403 (match_ix_kps).
+__global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint* __restrict__ kps_a, const akz_keypoint* __restrict__ kps_b,
+                                                      uint32_t cap_per_img, const uint32_t* __restrict__ fa, const uint32_t* __restrict__ fb,
+                                                      const uint32_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
+                                                      RsCam cam_a, RsCam cam_b, uint32_t* __restrict__ n_out, double* __restrict__ a_out,
+                                                      double* __restrict__ b_out, uint32_t* __restrict__ order_out, uint32_t shuffle,
+                                                      unsigned long long seed)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t s = blockIdx.x;
+    uint32_t n = npairs[s];
+    n = n < cap_per_img ? n : cap_per_img;
+    n = n < B.n_cap ? n : B.n_cap;
+    if (threadIdx.x == 0) n_out[s] = n;
+    const akz_keypoint* ka = kps_a + (size_t)fa[s] * cap_per_img;
+    const akz_keypoint* kb = kps_b + (size_t)fb[s] * cap_per_img;
+    const uint32_t* pr = pairs + (size_t)s * cap_per_img * 2;
+    double* ao = a_out + (size_t)s * B.n_cap * 3;
+    double* bo = b_out + (size_t)s * B.n_cap * 4;
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+        const uint32_t ia = pr[2 * j], ib = pr[2 * j + 1];
+        double o[3];
+        rs_calibrate_one(cam_a.intr, cam_a.use_k1, cam_a.k1, ka[ia].x, ka[ia].y, o);
+        ao[3 * j] = o[0]; ao[3 * j + 1] = o[1]; ao[3 * j + 2] = o[2];
+        rs_calibrate_one(cam_b.intr, cam_b.use_k1, cam_b.k1, kb[ib].x, kb[ib].y, o);
+        bo[3 * j] = o[0]; bo[3 * j + 1] = o[1]; bo[3 * j + 2] = o[2];
+    }
+    if (!shuffle) return;
+    // scoring order = stable ascending sort of the matches' 32-bit shuffle keys (LSD radix sort in LDS)
+    uint32_t* rk = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* ia_ = rk + kRadixSortMax;
+    uint32_t* ib_ = ia_ + kRadixSortMax;
+    uint32_t* wh = ib_ + kRadixSortMax;
+    __shared__ uint32_t tot[256];
+    const unsigned long long ss = rs_scene_seed(seed, s);
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+        rk[j] = rs_shuffle_key(ss, j);
+        ia_[j] = j;
+    }
+    __syncthreads();
+    const uint32_t* sorted = lds_radix_sort_ids(rk, ia_, ib_, wh, tot, n, 4);
+    uint32_t* oo = order_out + (size_t)s * B.n_cap;
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) oo[j] = sorted[j];
+}
+
+// argmax of (count, -id) over ALL poses of one scene (exhaustive scoring): the pose with the most inliers, lowest id on ties
+__global__ __launch_bounds__(1024) void k_rs_best(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ok,
+                                                  uint32_t n_pose, uint32_t* __restrict__ best)
+{
+    __shared__ unsigned long long s_key[16];
+    unsigned long long key = 0ull;  // 0 = nothing valid
+    for (uint32_t i = threadIdx.x; i < n_pose; i += 1024)
+        if (ok[i]) {
+            unsigned long long k = ((unsigned long long)(counts[i] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+            key = k > key ? k : key;
+        }
     for (int off = 32; off > 0; off >>= 1) {
         unsigned long long o = __shfl_down(key, off);
         key = o > key ? o : key;
@@ -595,57 +909,16 @@ __global__ __launch_bounds__(1024) void k_rs_best_alive(const uint32_t* __restri
         for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
         best[0] = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
         best[1] = key ? (uint32_t)(key >> 32) - 1u : 0u;
-        best[2] = n;
     }
 }
 
-// ---- PnP: Lambda Twist hypotheses + WorldToCamera residual (row R5) ----------------------------------
-__global__ __launch_bounds__(64) void k_p3p_hypotheses(const double* __restrict__ bearings, const double* __restrict__ world,
-                                                       const uint32_t* __restrict__ sample_idx, uint32_t n_hyp,
-                                                       double* __restrict__ poses, uint32_t* __restrict__ ok)
-{
-    const uint32_t hh = blockIdx.x * 64 + threadIdx.x;
-    if (hh >= n_hyp) return;
-    double b3[9], w3[12], P[48];
-    for (int i = 0; i < 3; ++i) {
-        uint32_t m = sample_idx[(size_t)hh * 3 + i];
-        for (int k = 0; k < 3; ++k) b3[3 * i + k] = bearings[(size_t)3 * m + k];
-        for (int k = 0; k < 4; ++k) w3[4 * i + k] = world[(size_t)4 * m + k];
-    }
-    int np = akz_p3p_poses(b3, w3, 5, P);  // LambdaTwist::default(): 5 Gauss-Newton iterations
-    for (int p = 0; p < 4; ++p) {
-        ok[(size_t)hh * 4 + p] = p < np ? 1u : 0u;
-        if (p < np)
-            for (int i = 0; i < 12; ++i) poses[(size_t)hh * 48 + p * 12 + i] = P[p * 12 + i];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ bearings, const double* __restrict__ world,
-                                                   uint32_t n, const double* __restrict__ poses,
-                                                   const uint32_t* __restrict__ ok, double thresh,
-                                                   uint32_t* __restrict__ counts)
-{
-    const uint32_t pid = blockIdx.y;
-    if (!ok[pid]) return;
-    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
-    bool inl = false;
-    if (m < n) {
-        double pose[12];
-        for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
-        double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
-        double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
-        inl = akz_w2c_residual(pose, b, w) < thresh;
-    }
-    unsigned long long bal = __ballot(inl);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
-}
-
-__global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__ bearings, const double* __restrict__ world,
-                                                      uint32_t n, const double* __restrict__ poses,
-                                                      const uint32_t* __restrict__ best, double thresh,
-                                                      uint32_t* __restrict__ inlier_idx, uint32_t cap,
-                                                      uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose,
-                                                      unsigned long long* __restrict__ n_eval)
+// inlier indices of pose best[0] in ascending match order (ordered compaction, one block; exhaustive entry points)
+template <bool P3P>
+__global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ ba, const double* __restrict__ bb,
+                                                     uint32_t n, const double* __restrict__ poses,
+                                                     const uint32_t* __restrict__ best, double thresh,
+                                                     uint32_t* __restrict__ inlier_idx, uint32_t cap,
+                                                     uint32_t* __restrict__ n_inliers, double* __restrict__ best_pose)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t pid = best[0];
@@ -653,7 +926,6 @@ __global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__
         if (threadIdx.x == 0) *n_inliers = 0;
         return;
     }
-    if (threadIdx.x == 0 && n_eval) atomicAdd(n_eval, (unsigned long long)n);
     double pose[12];
     for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
     if (threadIdx.x < 12) best_pose[threadIdx.x] = pose[threadIdx.x];
@@ -663,9 +935,14 @@ __global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__
         uint32_t m = m0 + threadIdx.x;
         bool inl = false;
         if (m < n) {
-            double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
-            double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
-            inl = akz_w2c_residual(pose, b, w) < thresh;
+            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+            if (P3P) {
+                double w[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
+                inl = akz_w2c_residual(pose, a, w) < thresh;
+            } else {
+                double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+                inl = rs_residual(pose, a, b) < thresh;
+            }
         }
         unsigned long long bal = __ballot(inl);
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
@@ -690,16 +967,82 @@ __global__ __launch_bounds__(1024) void k_p3p_inliers(const double* __restrict__
 struct rs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint32_t max_matches = 0, max_hyp = 0;
-    double *d_a = nullptr, *d_b = nullptr, *d_w = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
-    uint32_t *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_best = nullptr, *d_inl = nullptr,
-             *d_ninl = nullptr;
-    uint32_t *d_alive[2] = {nullptr, nullptr}, *d_nalive = nullptr;   // ARRSAC: live pose lists (ping-pong) + counts [2]
-    unsigned long long* d_neval = nullptr;                             // residuals evaluated
+    hipEvent_t ev = nullptr;
+    uint32_t max_scenes = 0, max_matches = 0, max_hyp = 0;
+    // the arena: slot s of every array belongs to scene s (layout: RsB)
+    uint32_t* d_n = nullptr;
+    double *d_a = nullptr, *d_b = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
+    uint32_t *d_order = nullptr, *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_alive = nullptr, *d_nalive = nullptr,
+             *d_best = nullptr, *d_inl = nullptr, *d_ninl = nullptr, *d_first = nullptr, *d_enable = nullptr, *d_frames = nullptr;
+    unsigned long long* d_neval = nullptr;
+    rs_arrsac_stats* d_stats = nullptr;
     double* d_logtab = nullptr;                                        // ln(k), k = 0 .. max_matches (host libm values)
-    uint32_t *d_first = nullptr, *d_enable = nullptr;                  // re-sampling: first appended slot, enable flag
     uint32_t last_hyp = 0;
 };
+
+static void rs_free_arena(rs_ctx* c)
+{
+    hipFree(c->d_n); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_order);
+    hipFree(c->d_samples); hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_alive); hipFree(c->d_nalive); hipFree(c->d_best);
+    hipFree(c->d_inl); hipFree(c->d_ninl); hipFree(c->d_first); hipFree(c->d_enable); hipFree(c->d_frames); hipFree(c->d_neval);
+    hipFree(c->d_stats);
+    c->d_n = c->d_order = c->d_samples = c->d_ok = c->d_counts = c->d_alive = c->d_nalive = c->d_best = c->d_inl = c->d_ninl =
+        c->d_first = c->d_enable = c->d_frames = nullptr;
+    c->d_a = c->d_b = c->d_poses = c->d_best_pose = nullptr;
+    c->d_neval = nullptr;
+    c->d_stats = nullptr;
+}
+
+static int32_t rs_alloc_arena(rs_ctx* c, uint32_t S)
+{
+    const size_t n = c->max_matches, H = c->max_hyp, s = S;
+    AKZ_HIP(hipMalloc(&c->d_n, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * n * s));
+    AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 4 * n * s));
+    AKZ_HIP(hipMalloc(&c->d_order, sizeof(uint32_t) * n * s));
+    AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * H * s));
+    AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * H * s));
+    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&c->d_alive, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&c->d_nalive, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&c->d_neval, sizeof(unsigned long long) * s));
+    AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4 * s));
+    AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * n * s));
+    AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12 * s));
+    AKZ_HIP(hipMalloc(&c->d_first, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&c->d_enable, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&c->d_frames, sizeof(uint32_t) * 2 * s));
+    AKZ_HIP(hipMalloc(&c->d_stats, sizeof(rs_arrsac_stats) * s));
+    c->max_scenes = S;
+    return AKZ_OK;
+}
+
+static RsB rs_view(const rs_ctx* c, bool with_order)
+{
+    RsB B;
+    B.n_cap = c->max_matches;
+    B.H = c->max_hyp;
+    B.n = c->d_n;
+    B.a = c->d_a;
+    B.b = c->d_b;
+    B.order = with_order ? c->d_order : nullptr;
+    B.samples = c->d_samples;
+    B.poses = c->d_poses;
+    B.ok = c->d_ok;
+    B.counts = c->d_counts;
+    B.alive = c->d_alive;
+    B.nalive = c->d_nalive;
+    B.neval = c->d_neval;
+    B.best = c->d_best;
+    B.inl = c->d_inl;
+    B.ninl = c->d_ninl;
+    B.best_pose = c->d_best_pose;
+    B.first = c->d_first;
+    B.enable = c->d_enable;
+    return B;
+}
 
 extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_hyp, rs_ctx** out)
 {
@@ -713,23 +1056,8 @@ extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_
         c->max_matches = max_matches;
         c->max_hyp = max_hyp;
         AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * (size_t)max_matches));
-        AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 3 * (size_t)max_matches));
-        AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12));
-        AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_w, sizeof(double) * 4 * (size_t)max_matches));
-        AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4));
-        AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * (size_t)max_matches));
-        AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * 4));
-        AKZ_HIP(hipMalloc(&c->d_alive[0], sizeof(uint32_t) * 4 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_alive[1], sizeof(uint32_t) * 4 * (size_t)max_hyp));
-        AKZ_HIP(hipMalloc(&c->d_nalive, sizeof(uint32_t) * 4));
-        AKZ_HIP(hipMalloc(&c->d_neval, sizeof(unsigned long long) * 2));
-        AKZ_HIP(hipMalloc(&c->d_first, sizeof(uint32_t) * 2));
-        c->d_enable = c->d_first + 1;
+        AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+        AKZ_TRY(rs_alloc_arena(c, 1));
         {
             // the SPRT's logarithms come from the host's libm, tabulated once: the retirement decisions then do not
             // depend on the device's log() (oracle/arrsac_oracle.c builds the same table)
@@ -749,15 +1077,46 @@ extern "C" int32_t rs_destroy(rs_ctx* c)
         if (!c) return AKZ_OK;
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
-        hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_w); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_samples);
-        hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_best); hipFree(c->d_inl); hipFree(c->d_ninl);
-        hipFree(c->d_alive[0]); hipFree(c->d_alive[1]); hipFree(c->d_nalive); hipFree(c->d_neval);
-        hipFree(c->d_logtab); hipFree(c->d_first);
+        rs_free_arena(c);
+        hipFree(c->d_logtab);
+        if (c->ev) hipEventDestroy(c->ev);
         if (c->stream) hipStreamDestroy(c->stream);
         delete c;
         return AKZ_OK;
     });
 }
+
+// Room for `max_scenes` scenes per call (rs_create leaves room for one): the arena is re-carved, nothing else changes.
+extern "C" int32_t rs_batch_reserve(rs_ctx* c, uint32_t max_scenes)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || max_scenes == 0 || max_scenes > 65535u) return AKZ_E_INVALID;
+        if (max_scenes <= c->max_scenes) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        rs_free_arena(c);
+        c->max_scenes = 0;
+        int32_t st = rs_alloc_arena(c, max_scenes);
+        if (st != AKZ_OK) {
+            rs_free_arena(c);
+            c->max_scenes = 0;
+            if (rs_alloc_arena(c, 1) != AKZ_OK) c->max_scenes = 0;
+        }
+        return st;
+    });
+}
+
+extern "C" int32_t rs_sync(rs_ctx* c)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        return AKZ_OK;
+    });
+}
+
+extern "C" void* rs_stream(rs_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // cv_pinhole::CameraIntrinsics::calibrate / CameraIntrinsicsK1Distortion::calibrate: host scalar math.
 extern "C" int32_t rs_calibrate(const double* intr, int32_t use_k1, double k1, const akz_keypoint* kps, uint32_t n,
@@ -765,23 +1124,81 @@ extern "C" int32_t rs_calibrate(const double* intr, int32_t use_k1, double k1, c
 {
     return akz_guard([&]() -> int32_t {
         if (!intr || (n && (!kps || !out))) return AKZ_E_INVALID;
-        for (uint32_t i = 0; i < n; ++i) {
-            double cx = (double)kps[i].x - intr[2], cy = (double)kps[i].y - intr[3];
-            double y = cy / intr[1];
-            double x = (cx - intr[4] * y) / intr[0];
-            if (use_k1) {
-                double r2 = x * x + y * y;
-                double d = 1.0 + k1 * r2;
-                x = x / d;
-                y = y / d;
-            }
-            double nrm = sqrt(x * x + y * y + 1.0 * 1.0);
-            out[3 * i + 0] = x / nrm;
-            out[3 * i + 1] = y / nrm;
-            out[3 * i + 2] = 1.0 / nrm;
-        }
+        for (uint32_t i = 0; i < n; ++i) rs_calibrate_one(intr, use_k1, k1, kps[i].x, kps[i].y, out + 3 * (size_t)i);
         return AKZ_OK;
     });
+}
+
+// results of a single-scene call: scene 0's slots of the arena -> the caller's host buffers
+static int32_t rs_fetch_single(rs_ctx* c, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers,
+                               uint32_t* survivors, unsigned long long* neval)
+{
+    hipStream_t s = c->stream;
+    uint32_t best[4] = {0, 0, 0, 0}, ninl = 0;
+    unsigned long long ne = 0;
+    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(&ne, c->d_neval, sizeof(ne), hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    AKZ_HIP(hipStreamSynchronize(s));
+    if (survivors) *survivors = best[2];
+    if (neval) *neval = ne;
+    *best_id = best[0];
+    *n_inliers = ninl;
+    if (best[0] == 0xFFFFFFFFu) {
+        *n_inliers = 0;
+        return AKZ_OK;  // Consensus::model_inliers returned None: no hypothesis produced a model
+    }
+    uint32_t ncopy = ninl < cap ? ninl : cap;
+    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
+    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+}
+
+// exhaustive scoring of caller-provided minimal samples, one scene (slot 0 of the arena)
+template <bool P3P>
+static int32_t exhaustive_run(rs_ctx* c, const double* in_a, const double* in_b, uint32_t n, const uint32_t* sample_idx,
+                              uint32_t n_hyp, double thresh, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx,
+                              uint32_t cap, uint32_t* n_inliers)
+{
+    constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;
+    if (!c || !in_a || !in_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    if (n < K || n_hyp == 0) return AKZ_E_INVALID;  // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
+    if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
+    for (size_t i = 0; i < (size_t)n_hyp * K; ++i)
+        if (sample_idx[i] >= n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    AKZ_HIP(hipMemcpyAsync(c->d_a, in_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, in_b, sizeof(double) * BW * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * K * (size_t)n_hyp, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemsetD32Async((hipDeviceptr_t)c->d_n, (int)n, 1, s));
+    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+    AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long), s));
+    const RsB B = rs_view(c, false);
+    if (P3P)
+        hipLaunchKernelGGL(k_rsb_p3p_hypotheses, dim3((n_hyp + 63) / 64, 1), dim3(64), 0, s, B, 0u, n_hyp, (const uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(k_rsb_hypotheses, dim3((n_hyp + 63) / 64, 1), dim3(64), 0, s, B, 0u, n_hyp, (const uint32_t*)nullptr);
+    AKZ_LAUNCH_CHECK();
+    // grid.y is limited to 65535: score the poses in slabs
+    const uint32_t n_pose = n_hyp * 4;
+    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+        if (P3P)
+            hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
+                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+        else
+            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
+                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+        AKZ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
+    AKZ_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_rs_inliers<P3P>), dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
+                       c->d_inl, n, c->d_ninl, c->d_best_pose);
+    AKZ_LAUNCH_CHECK();
+    c->last_hyp = n_hyp;
+    return rs_fetch_single(c, best_pose, best_id, inlier_idx, cap, n_inliers, nullptr, nullptr);
 }
 
 extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
@@ -789,124 +1206,97 @@ extern "C" int32_t rs_essential_batch(rs_ctx* c, const double* bearings_a, const
                                       uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !bearings_a || !bearings_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
-            return AKZ_E_INVALID;
-        if (n < 8 || n_hyp == 0) return AKZ_E_INVALID;  // EightPoint::MIN_SAMPLES (eight-point/src/lib.rs:73)
-        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
-        for (size_t i = 0; i < (size_t)n_hyp * 8; ++i)
-            if (sample_idx[i] >= n) return AKZ_E_INVALID;
-        AKZ_HIP(hipSetDevice(c->device));
-        hipStream_t s = c->stream;
-        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemcpyAsync(c->d_b, bearings_b, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 8 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
-                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
-        AKZ_LAUNCH_CHECK();
-        // grid.y is limited to 65535: score the poses in slabs
-        const uint32_t n_pose = n_hyp * 4;
-        for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
-            uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
-            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
-                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
-            AKZ_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
-        AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, thresh,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
-        AKZ_LAUNCH_CHECK();
-        uint32_t best[2] = {0, 0}, ninl = 0;
-        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipStreamSynchronize(s));
-        c->last_hyp = n_hyp;
-        *best_id = best[0];
-        *n_inliers = ninl;
-        if (best[0] == 0xFFFFFFFFu) {
-            *n_inliers = 0;
-            return AKZ_OK;  // Consensus::model_inliers returned None: no hypothesis produced a model
-        }
-        uint32_t ncopy = ninl < cap ? ninl : cap;
-        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+        return exhaustive_run<false>(c, bearings_a, bearings_b, n, sample_idx, n_hyp, thresh, best_pose, best_id, inlier_idx, cap,
+                                     n_inliers);
     });
 }
 
-// Consensus::model_inliers in ARRSAC's shape: breadth-first block scoring with retirement (see the kernels above), for
-// EightPoint (two bearing sets, 8-match samples) and for LambdaTwist (bearings + world points, 3-match samples).
-// sample_idx == NULL draws the minimal samples on the device.
-template <bool P3P>
-static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uint32_t n, const uint32_t* sample_idx,
-                          const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx,
-                          uint32_t cap, uint32_t* n_inliers, rs_arrsac_stats* stats)
+// Consensus::model_inliers(&LambdaTwist::new(), world_matches) with the sampler factored out
+// (cv-sfm/src/lib.rs:1619-1622; lambda-twist/tests/consensus.rs:59-61): n_hyp sample triples.
+extern "C" int32_t rs_p3p_batch(rs_ctx* c, const double* bearings, const double* world, uint32_t n,
+                                const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
+                                uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
 {
-    constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;   // sample size; doubles per element of the second input
-    if (!c || !in_a || !in_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    return akz_guard([&]() -> int32_t {
+        return exhaustive_run<true>(c, bearings, world, n, sample_idx, n_hyp, thresh, best_pose, best_id, inlier_idx, cap, n_inliers);
+    });
+}
+
+static int32_t rs_check_params(const rs_ctx* c, const rs_arrsac_params* prm, uint32_t n_max, uint32_t* blocks_max)
+{
     if (prm->struct_size != sizeof(rs_arrsac_params)) return AKZ_E_INVALID;
-    const uint32_t n_hyp = prm->n_hypotheses;
-    if (n < K || n_hyp == 0 || prm->block_size == 0) return AKZ_E_INVALID;   // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
+    if (prm->n_hypotheses == 0 || prm->block_size == 0) return AKZ_E_INVALID;
     if (prm->reserved != 0 || (prm->flags & ~(RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE))) return AKZ_E_INVALID;
-    const uint32_t E = prm->estimations_per_block;
     // every block but the last may add E hypotheses: they need room in the context's pose arrays
-    const uint64_t n_blocks_max = ((uint64_t)n + prm->block_size - 1) / prm->block_size;
-    if (n > c->max_matches || n_hyp > c->max_hyp || (uint64_t)n_hyp + (uint64_t)E * n_blocks_max > c->max_hyp)
+    const uint64_t n_blocks_max = ((uint64_t)n_max + prm->block_size - 1) / prm->block_size;
+    if (n_max > c->max_matches || prm->n_hypotheses > c->max_hyp ||
+        (uint64_t)prm->n_hypotheses + (uint64_t)prm->estimations_per_block * n_blocks_max > c->max_hyp)
         return AKZ_E_TOO_LARGE;
     if ((prm->flags & RS_PRUNE_SPRT) && !(prm->sprt_delta > 0.0 && prm->sprt_delta < 1.0 && prm->sprt_ratio > 1.0))
         return AKZ_E_INVALID;
-    if (sample_idx)
-        for (size_t i = 0; i < (size_t)n_hyp * K; ++i)
-            if (sample_idx[i] >= n) return AKZ_E_INVALID;
-    AKZ_HIP(hipSetDevice(c->device));
+    *blocks_max = (uint32_t)n_blocks_max;
+    return AKZ_OK;
+}
+
+// The ARRSAC-shaped loop over S scenes whose matches (and d_n) are already in the arena; enqueues everything on the
+// context's stream and returns.  n_max: the host's upper bound of the scenes' match counts (sizes the block loop).
+// have_samples: the minimal samples are already in the arena (single-scene calls with caller samples).
+template <bool P3P>
+static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arrsac_params* prm, bool have_samples, bool with_order,
+                             const RsOut& out_in, uint32_t* blocks_run, uint32_t* hyp_made)
+{
+    constexpr uint32_t K = P3P ? 3u : 8u;
     hipStream_t s = c->stream;
-    double* d_second = P3P ? c->d_w : c->d_b;
-    AKZ_HIP(hipMemcpyAsync(c->d_a, in_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-    AKZ_HIP(hipMemcpyAsync(d_second, in_b, sizeof(double) * BW * (size_t)n, hipMemcpyHostToDevice, s));
-    if (sample_idx) {
-        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * K * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-    } else {
-        hipLaunchKernelGGL((k_rs_sample<(int)K>), dim3((n_hyp + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed, n,
-                           n_hyp, c->d_samples);
+    const RsB B = rs_view(c, with_order);
+    const uint32_t n_hyp = prm->n_hypotheses, E = prm->estimations_per_block;
+    if (!have_samples) {
+        hipLaunchKernelGGL((k_rsb_sample<(int)K>), dim3((n_hyp + 255) / 256, S), dim3(256), 0, s, B, (unsigned long long)prm->seed, n_hyp);
         AKZ_LAUNCH_CHECK();
     }
-    AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-    AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long) * 2, s));
+    // counters of the initial poses (re-sampled poses zero theirs when they join); slot stride 4 H
+    if (S == 1) AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
+    else AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)c->max_hyp * S, s));
+    AKZ_HIP(hipMemsetAsync(c->d_neval, 0, sizeof(unsigned long long) * S, s));
     if (P3P)
-        hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
-                           c->d_poses, c->d_ok);
+        hipLaunchKernelGGL(k_rsb_p3p_hypotheses, dim3((n_hyp + 63) / 64, S), dim3(64), 0, s, B, 0u, n_hyp, (const uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL(k_rs_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
-                           c->d_samples, n_hyp, c->d_poses, c->d_ok);
+        hipLaunchKernelGGL(k_rsb_hypotheses, dim3((n_hyp + 63) / 64, S), dim3(64), 0, s, B, 0u, n_hyp, (const uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
     const uint32_t n_pose = n_hyp * 4;
-    hipLaunchKernelGGL(k_rs_alive_init, dim3(1), dim3(1024), 0, s, c->d_ok, n_pose, c->d_alive[0], c->d_nalive);
+    hipLaunchKernelGGL(k_rsb_alive_init, dim3(S), dim3(1024), 0, s, B, n_pose);
     AKZ_LAUNCH_CHECK();
-    // (the cap ranks poses through a 2048-bin histogram of their counts: counts above 2046 share the top bin)
-    int cur = 0;
     uint32_t blocks = 0;
     // the live count is known to the host only as an upper bound: n_pose before the cap applies, the cap after
     uint32_t live_bound = n_pose;
     const bool prune = (prm->flags & (RS_PRUNE_BOUND | RS_PRUNE_SPRT)) != 0 || prm->max_candidates != 0 || E != 0;
     uint32_t next_h = n_hyp;                                  // first hypothesis slot of the next re-sampling round
-    for (uint32_t m_lo = 0; m_lo < n;) {
-        // without pruning there is nothing to decide between blocks: one block = all matches
-        const uint32_t bs = prune ? prm->block_size : n;
-        const uint32_t m_hi = m_lo + bs < n ? m_lo + bs : n;
-        const uint32_t chunks = (m_hi - m_lo + 63) / 64;
-        const uint32_t gy = chunks < 16 ? chunks : 16;
-        hipLaunchKernelGGL((k_rs_score_block<P3P>), dim3((live_bound + 3) / 4, gy), dim3(256), 0, s, c->d_a, d_second, m_lo, m_hi,
-                           c->d_poses, c->d_alive[cur], c->d_nalive + cur, (const uint32_t*)nullptr, prm->threshold, c->d_counts,
-                           c->d_neval);
+    auto score = [&](uint32_t m_lo, uint32_t m_hi, uint32_t slots, uint32_t from_first) -> int32_t {
+        const uint32_t range = m_hi - m_lo;
+        uint32_t lg = 6;
+        if (range < 64) {
+            lg = 0;
+            while ((1u << lg) < range) ++lg;
+        }
+        const uint32_t G = 1u << lg, per_wave = 64u >> lg;
+        const uint32_t chunks = (range + G - 1) / G, gy = chunks < 16 ? chunks : 16;
+        const uint32_t waves = (slots + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL((k_rsb_score<P3P>), dim3((waves + 3) / 4, gy, S), dim3(256), 0, s, B, m_lo, m_hi, lg, from_first,
+                           prm->threshold);
         AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    };
+    for (uint32_t m_lo = 0; m_lo < n_max;) {
+        // without pruning there is nothing to decide between blocks: one block = all matches
+        const uint32_t bs = prune ? prm->block_size : n_max;
+        const uint32_t m_hi = m_lo + bs < n_max ? m_lo + bs : n_max;
+        AKZ_TRY(score(m_lo, m_hi, live_bound, 0u));
         ++blocks;
         m_lo = m_hi;
-        if (prune && m_lo < n) {
+        if (prune && m_lo < n_max) {
             RsPrune P;
             P.seen = m_lo;
-            P.n_total = n;
             P.cap = 0u;
+            P.pad = 0u;
             if (prm->max_candidates && blocks >= prm->init_blocks) {
                 P.cap = prm->max_candidates;
                 if (prm->flags & RS_PRUNE_HALVE) {             // ARRSAC's shrinking candidate set: half per block, never empty
@@ -920,81 +1310,91 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
             P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
             P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
             P.log_ratio = P.use_sprt ? log(prm->sprt_ratio) : 0.0;
-            hipLaunchKernelGGL(k_rs_prune, dim3(1), dim3(1024), 0, s, P, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
-                               c->d_alive[cur ^ 1], c->d_nalive + (cur ^ 1));
+            hipLaunchKernelGGL(k_rsb_prune, dim3(S), dim3(1024), 0, s, B, P);
             AKZ_LAUNCH_CHECK();
-            cur ^= 1;
             if (P.cap && P.cap < live_bound) live_bound = P.cap;
+            // a single survivor cannot be overtaken when nothing is re-sampled: the block loop ends (the specification's rule)
+            if (P.cap == 1 && E == 0 && (prm->flags & RS_PRUNE_HALVE)) break;
             if (E && blocks >= prm->init_blocks) {
                 // inlier-guided re-sampling: list the inliers (matches seen so far) of the best survivor, draw E minimal
                 // samples among them, estimate, and let the valid poses join the live list after catching up on [0, seen)
-                hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur,
-                                   c->d_best);
+                hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(1024), 0, s, B, m_lo, 0u, prm->threshold, out_in);
+                AKZ_LAUNCH_CHECK();
+                hipLaunchKernelGGL((k_rsb_resample<(int)K>), dim3((E + 255) / 256, S), dim3(256), 0, s, B, (unsigned long long)prm->seed,
+                                   next_h, E);
                 AKZ_LAUNCH_CHECK();
                 if (P3P)
-                    hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, m_lo, c->d_poses, c->d_best,
-                                       prm->threshold, c->d_inl, m_lo, c->d_ninl, c->d_best_pose, c->d_neval);
+                    hipLaunchKernelGGL(k_rsb_p3p_hypotheses, dim3((E + 63) / 64, S), dim3(64), 0, s, B, next_h, E, (const uint32_t*)c->d_enable);
                 else
-                    hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, m_lo, c->d_poses, c->d_best,
-                                       prm->threshold, c->d_inl, m_lo, c->d_ninl, c->d_best_pose, c->d_neval);
+                    hipLaunchKernelGGL(k_rsb_hypotheses, dim3((E + 63) / 64, S), dim3(64), 0, s, B, next_h, E, (const uint32_t*)c->d_enable);
                 AKZ_LAUNCH_CHECK();
-                hipLaunchKernelGGL((k_rs_resample<(int)K>), dim3((E + 255) / 256), dim3(256), 0, s, (unsigned long long)prm->seed,
-                                   next_h, E, c->d_inl, c->d_ninl, c->d_samples, c->d_enable);
+                hipLaunchKernelGGL(k_rsb_alive_append, dim3(S), dim3(1024), 0, s, B, next_h * 4, E * 4);
                 AKZ_LAUNCH_CHECK();
-                if (P3P)
-                    hipLaunchKernelGGL(k_p3p_hypotheses, dim3((E + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w,
-                                       c->d_samples + (size_t)next_h * K, E, c->d_poses + (size_t)next_h * 48, c->d_ok + (size_t)next_h * 4);
-                else
-                    hipLaunchKernelGGL(k_rs_hypotheses, dim3((E + 63) / 64), dim3(64), sizeof(double) * 162 * 64, s, c->d_a, c->d_b,
-                                       c->d_samples + (size_t)next_h * K, E, c->d_poses + (size_t)next_h * 48, c->d_ok + (size_t)next_h * 4);
-                AKZ_LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_rs_alive_append, dim3(1), dim3(1024), 0, s, c->d_ok, next_h * 4, E * 4, c->d_enable,
-                                   c->d_alive[cur], c->d_nalive + cur, c->d_first, c->d_counts);
-                AKZ_LAUNCH_CHECK();
-                const uint32_t cchunks = (m_lo + 63) / 64;
-                hipLaunchKernelGGL((k_rs_score_block<P3P>), dim3(E, cchunks < 16 ? cchunks : 16), dim3(256), 0, s, c->d_a, d_second,
-                                   0u, m_lo, c->d_poses, c->d_alive[cur], c->d_nalive + cur, (const uint32_t*)c->d_first,
-                                   prm->threshold, c->d_counts, c->d_neval);
-                AKZ_LAUNCH_CHECK();
+                AKZ_TRY(score(0u, m_lo, 4 * E, 1u));
                 next_h += E;
                 live_bound += 4 * E;
             }
         }
     }
-    hipLaunchKernelGGL(k_rs_best_alive, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_alive[cur], c->d_nalive + cur, c->d_best);
+    RsOut O = out_in;
+    O.n_hyp = n_hyp;
+    O.resample = E;
+    O.init_blocks = prm->init_blocks;
+    O.blocks_run = blocks;
+    O.block_size = prune ? prm->block_size : 0u;
+    O.min_samples = K;
+    hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(1024), 0, s, B, 0u, 1u, prm->threshold, O);
     AKZ_LAUNCH_CHECK();
-    if (P3P)
-        hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, prm->threshold,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL(k_rs_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_b, n, c->d_poses, c->d_best, prm->threshold,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
-    AKZ_LAUNCH_CHECK();
-    uint32_t best[3] = {0, 0, 0}, ninl = 0;
+    *blocks_run = blocks;
+    *hyp_made = next_h;
+    return AKZ_OK;
+}
+
+// Consensus::model_inliers in ARRSAC's shape for one scene with host buffers: EightPoint (two bearing sets, 8-match
+// samples) or LambdaTwist (bearings + world points, 3-match samples).  sample_idx == NULL draws the samples on the device.
+template <bool P3P>
+static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uint32_t n, const uint32_t* sample_idx,
+                          const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx,
+                          uint32_t cap, uint32_t* n_inliers, rs_arrsac_stats* stats)
+{
+    constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;   // sample size; doubles per element of the second input
+    if (!c || !in_a || !in_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    if (n < K) return AKZ_E_INVALID;   // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
+    uint32_t blocks_max = 0;
+    AKZ_TRY(rs_check_params(c, prm, n, &blocks_max));
+    if (sample_idx)
+        for (size_t i = 0; i < (size_t)prm->n_hypotheses * K; ++i)
+            if (sample_idx[i] >= n) return AKZ_E_INVALID;
+    AKZ_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    AKZ_HIP(hipMemcpyAsync(c->d_a, in_a, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemcpyAsync(c->d_b, in_b, sizeof(double) * BW * (size_t)n, hipMemcpyHostToDevice, s));
+    AKZ_HIP(hipMemsetD32Async((hipDeviceptr_t)c->d_n, (int)n, 1, s));
+    if (sample_idx)
+        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * K * (size_t)prm->n_hypotheses, hipMemcpyHostToDevice, s));
+    RsOut O;
+    O.best_id = c->d_best + 3;      // (slot 3 of scene 0's best[4]: the final kernel also fills slots 0..2)
+    O.pose = c->d_best_pose;
+    O.inl = c->d_inl;
+    O.ninl = c->d_ninl;
+    O.stats = nullptr;
+    O.inl_stride = c->max_matches;
+    O.n_hyp = O.resample = O.init_blocks = O.blocks_run = O.block_size = O.min_samples = 0;
+    uint32_t blocks = 0, made = 0;
+    AKZ_TRY((arrsac_engine<P3P>(c, 1, n, prm, sample_idx != nullptr, false, O, &blocks, &made)));
+    uint32_t survivors = 0;
     unsigned long long neval = 0;
-    AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(&neval, c->d_neval, sizeof(neval), hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    AKZ_HIP(hipStreamSynchronize(s));
-    c->last_hyp = next_h;
+    const int32_t st = rs_fetch_single(c, best_pose, best_id, inlier_idx, cap, n_inliers, &survivors, &neval);
+    c->last_hyp = made;
     if (stats) {
-        stats->poses = next_h * 4;
-        stats->survivors = best[2];
+        stats->poses = made * 4;
+        stats->survivors = survivors;
         stats->blocks = blocks;
         stats->reserved = 0;
         stats->residuals_evaluated = neval;
-        stats->residuals_exhaustive = (uint64_t)next_h * 4 * n;
+        stats->residuals_exhaustive = (uint64_t)made * 4 * n;
     }
-    *best_id = best[0];
-    *n_inliers = ninl;
-    if (best[0] == 0xFFFFFFFFu) {
-        *n_inliers = 0;
-        return AKZ_OK;
-    }
-    uint32_t ncopy = ninl < cap ? ninl : cap;
-    if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-    return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+    return st;
 }
 
 extern "C" int32_t rs_essential_arrsac(rs_ctx* c, const double* bearings_a, const double* bearings_b, uint32_t n,
@@ -1019,6 +1419,86 @@ extern "C" int32_t rs_p3p_arrsac(rs_ctx* c, const double* bearings, const double
     });
 }
 
+// Two-view verification of a whole micro-batch, device-resident end to end (cv-sfm/src/lib.rs:1385-1412 for every
+// frame pair the matcher produced): scene s = pair list s of hm_match_batch_device's output, keypoints of blocks
+// ia[s] / ib[s]; calibrate (cv-pinhole/src/lib.rs:108-117), optional seeded shuffle, the ARRSAC-shaped loop over all
+// scenes at once.  Enqueued on rs_stream() after stream_to_wait; nothing is copied to the host.
+extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps_a, const void* d_kps_b, uint32_t cap_per_img,
+                                                    const uint32_t* ia, const uint32_t* ib, const void* d_pairs, const void* d_npairs,
+                                                    uint32_t n_scenes, const rs_camera* cam_a, const rs_camera* cam_b,
+                                                    const rs_arrsac_params* prm, uint32_t flags, void* d_pose, void* d_best_id,
+                                                    void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_kps_a || !d_kps_b || !ia || !ib || !d_pairs || !d_npairs || !cam_a || !cam_b || !prm || !d_pose || !d_best_id ||
+            !d_inliers || !d_n_inliers)
+            return AKZ_E_INVALID;
+        if (cap_per_img == 0 || (flags & ~(uint32_t)RS_BATCH_SHUFFLE) || cam_a->reserved != 0 || cam_b->reserved != 0) return AKZ_E_INVALID;
+        if (n_scenes == 0) return AKZ_OK;
+        if (n_scenes > c->max_scenes) return AKZ_E_TOO_LARGE;
+        const uint32_t n_max = cap_per_img < c->max_matches ? cap_per_img : c->max_matches;
+        if (n_max < 8) return AKZ_E_INVALID;
+        if ((flags & RS_BATCH_SHUFFLE) && n_max > kRadixSortMax) return AKZ_E_TOO_LARGE;   // the shuffle sorts a scene's keys in LDS
+        uint32_t blocks_max = 0;
+        AKZ_TRY(rs_check_params(c, prm, n_max, &blocks_max));
+        AKZ_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(s, c->ev, 0));
+        }
+        AKZ_HIP(hipMemcpyAsync(c->d_frames, ia, sizeof(uint32_t) * n_scenes, hipMemcpyHostToDevice, s));
+        AKZ_HIP(hipMemcpyAsync(c->d_frames + c->max_scenes, ib, sizeof(uint32_t) * n_scenes, hipMemcpyHostToDevice, s));
+        auto cam = [](const rs_camera* k) {
+            RsCam r;
+            r.intr[0] = k->fx; r.intr[1] = k->fy; r.intr[2] = k->cx; r.intr[3] = k->cy; r.intr[4] = k->skew;
+            r.k1 = k->k1;
+            r.use_k1 = k->use_k1 ? 1 : 0;
+            r.pad = 0;
+            return r;
+        };
+        const bool shuffle = (flags & RS_BATCH_SHUFFLE) != 0;
+        const RsB B = rs_view(c, shuffle);
+        if (shuffle)
+            AKZ_HIP(hipFuncSetAttribute((const void*)k_rsb_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
+        hipLaunchKernelGGL(k_rsb_prepare, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps_a,
+                           (const akz_keypoint*)d_kps_b, cap_per_img, (const uint32_t*)c->d_frames,
+                           (const uint32_t*)(c->d_frames + c->max_scenes), (const uint32_t*)d_pairs, (const uint32_t*)d_npairs, cam(cam_a),
+                           cam(cam_b), c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u, (unsigned long long)prm->seed);
+        AKZ_LAUNCH_CHECK();
+        RsOut O;
+        O.best_id = (uint32_t*)d_best_id;
+        O.pose = (double*)d_pose;
+        O.inl = (uint32_t*)d_inliers;
+        O.ninl = (uint32_t*)d_n_inliers;
+        O.stats = (rs_arrsac_stats*)d_stats;
+        O.inl_stride = cap_per_img;
+        O.n_hyp = O.resample = O.init_blocks = O.blocks_run = O.block_size = O.min_samples = 0;
+        uint32_t blocks = 0, made = 0;
+        AKZ_TRY((arrsac_engine<false>(c, n_scenes, n_max, prm, false, shuffle, O, &blocks, &made)));
+        c->last_hyp = made;
+        return AKZ_OK;
+    });
+}
+
+// debug tap of the batched entry: the calibrated bearings and the scoring order of scene `scene` of the last call
+extern "C" int32_t rs_debug_scene(rs_ctx* c, uint32_t scene, uint32_t* n, double* bearings_a, double* bearings_b, uint32_t* order,
+                                  uint32_t cap)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !n || scene >= c->max_scenes) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(n, c->d_n + scene, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (*n > cap) return AKZ_E_CAPACITY;
+        const size_t N = c->max_matches;
+        if (bearings_a) AKZ_HIP(hipMemcpy(bearings_a, c->d_a + scene * N * 3, sizeof(double) * 3 * (size_t)*n, hipMemcpyDeviceToHost));
+        if (bearings_b) AKZ_HIP(hipMemcpy(bearings_b, c->d_b + scene * N * 4, sizeof(double) * 3 * (size_t)*n, hipMemcpyDeviceToHost));
+        if (order) AKZ_HIP(hipMemcpy(order, c->d_order + scene * N, sizeof(uint32_t) * (size_t)*n, hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    });
+}
+
 // the minimal samples rs_essential_arrsac draws on the device for (seed, n): host restatement for callers and tests
 extern "C" int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, uint32_t sample_size, uint32_t* sample_idx)
 {
@@ -1032,7 +1512,7 @@ extern "C" int32_t rs_arrsac_samples(uint64_t seed, uint32_t n, uint32_t n_hyp, 
     });
 }
 
-// parity tap: inlier count of every (hypothesis, pose) of the last rs_essential_batch call
+// parity tap: inlier count of every (hypothesis, pose) of the last single-scene call
 extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
 {
     return akz_guard([&]() -> int32_t {
@@ -1044,54 +1524,16 @@ extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
     });
 }
 
-// Consensus::model_inliers(&LambdaTwist::new(), world_matches) with the sampler factored out
-// (cv-sfm/src/lib.rs:1619-1622; lambda-twist/tests/consensus.rs:59-61): n_hyp sample triples.
-extern "C" int32_t rs_p3p_batch(rs_ctx* c, const double* bearings, const double* world, uint32_t n,
-                                const uint32_t* sample_idx, uint32_t n_hyp, double thresh, double* best_pose,
-                                uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers)
+// parity tap: the poses [n_hyp][4][12] and validity flags [n_hyp][4] of the last single-scene call
+extern "C" int32_t rs_debug_poses(rs_ctx* c, double* poses, uint32_t* ok, uint32_t n_hyp)
 {
     return akz_guard([&]() -> int32_t {
-        if (!c || !bearings || !world || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx))
-            return AKZ_E_INVALID;
-        if (n < 3 || n_hyp == 0) return AKZ_E_INVALID;  // LambdaTwist::MIN_SAMPLES (lambda-twist/src/lib.rs:333)
-        if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
-        for (size_t i = 0; i < (size_t)n_hyp * 3; ++i)
-            if (sample_idx[i] >= n) return AKZ_E_INVALID;
+        if (!c || !poses || !ok) return AKZ_E_INVALID;
+        if (n_hyp > c->last_hyp) return AKZ_E_INVALID;
         AKZ_HIP(hipSetDevice(c->device));
-        hipStream_t s = c->stream;
-        AKZ_HIP(hipMemcpyAsync(c->d_a, bearings, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemcpyAsync(c->d_w, world, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemcpyAsync(c->d_samples, sample_idx, sizeof(uint32_t) * 3 * (size_t)n_hyp, hipMemcpyHostToDevice, s));
-        AKZ_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * 4 * (size_t)n_hyp, s));
-        hipLaunchKernelGGL(k_p3p_hypotheses, dim3((n_hyp + 63) / 64), dim3(64), 0, s, c->d_a, c->d_w, c->d_samples, n_hyp,
-                           c->d_poses, c->d_ok);
-        AKZ_LAUNCH_CHECK();
-        const uint32_t n_pose = n_hyp * 4;
-        for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
-            uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
-            hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_w, n,
-                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
-            AKZ_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
-        AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_p3p_inliers, dim3(1), dim3(1024), 0, s, c->d_a, c->d_w, n, c->d_poses, c->d_best, thresh,
-                           c->d_inl, n, c->d_ninl, c->d_best_pose, (unsigned long long*)nullptr);
-        AKZ_LAUNCH_CHECK();
-        uint32_t best[2] = {0, 0}, ninl = 0;
-        AKZ_HIP(hipMemcpyAsync(best, c->d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(&ninl, c->d_ninl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipMemcpyAsync(best_pose, c->d_best_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-        AKZ_HIP(hipStreamSynchronize(s));
-        c->last_hyp = n_hyp;
-        *best_id = best[0];
-        *n_inliers = ninl;
-        if (best[0] == 0xFFFFFFFFu) {
-            *n_inliers = 0;
-            return AKZ_OK;
-        }
-        uint32_t ncopy = ninl < cap ? ninl : cap;
-        if (ncopy) AKZ_HIP(hipMemcpy(inlier_idx, c->d_inl, sizeof(uint32_t) * ncopy, hipMemcpyDeviceToHost));
-        return ninl > cap ? AKZ_E_CAPACITY : AKZ_OK;
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(poses, c->d_poses, sizeof(double) * 48 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+        AKZ_HIP(hipMemcpy(ok, c->d_ok, sizeof(uint32_t) * 4 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+        return AKZ_OK;
     });
 }

@@ -123,6 +123,63 @@ class EssentialConsensus:
             return None
         return pose, inl[:ninl.value].copy(), best.value
 
+    def poses(self, n_hyp):
+        """(poses [n_hyp,4,3,4], ok [n_hyp,4]) of the last single-scene call (rs_debug_poses)."""
+        P = np.zeros((n_hyp, 4, 3, 4), np.float64); ok = np.zeros((n_hyp, 4), np.uint32)
+        check(_lib.lib().rs_debug_poses(self._h, P.ctypes.data, ok.ctypes.data, n_hyp), "rs_debug_poses")
+        return P, ok
+
+    # ---- micro-batch entry: every frame pair of the matcher's output in one chain of launches ----
+    def reserve(self, max_scenes):
+        check(_lib.lib().rs_batch_reserve(self._h, max_scenes), "rs_batch_reserve")
+
+    @staticmethod
+    def make_params(threshold, n_hypotheses=8192, seed=0, block_size=64, init_blocks=4, max_candidates=1024, bound=True,
+                    sprt=True, sprt_delta=0.05, sprt_ratio=1e3, estimations_per_block=0, halve=False):
+        prm = _lib.ArrsacParams()
+        prm.struct_size = C.sizeof(_lib.ArrsacParams)
+        prm.n_hypotheses, prm.block_size, prm.init_blocks, prm.max_candidates = n_hypotheses, block_size, init_blocks, max_candidates
+        prm.flags = ((_lib.RS_PRUNE_BOUND if bound else 0) | (_lib.RS_PRUNE_SPRT if sprt else 0)
+                     | (_lib.RS_PRUNE_HALVE if halve else 0))
+        prm.estimations_per_block, prm.reserved = estimations_per_block, 0
+        prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = float(threshold), sprt_delta, sprt_ratio, seed
+        return prm
+
+    @staticmethod
+    def camera(intr):
+        """CameraIntrinsics (or (fx, fy, cx, cy, skew, k1-or-None)) -> rs_camera."""
+        if isinstance(intr, CameraIntrinsics):
+            intr = (intr.focals[0], intr.focals[1], intr.principal_point[0], intr.principal_point[1], intr.skew, intr.k1)
+        c = _lib.Camera()
+        c.fx, c.fy, c.cx, c.cy, c.skew = (float(v) for v in intr[:5])
+        c.k1, c.use_k1, c.reserved = float(intr[5] or 0.0), int(intr[5] is not None), 0
+        return c
+
+    def model_inliers_batch_device(self, d_kps_a, d_kps_b, cap_per_img, ia, ib, d_pairs, d_npairs, cam_a, cam_b, params,
+                                   d_pose, d_best_id, d_inliers, d_n_inliers, d_stats=None, shuffle=True, stream_to_wait=None):
+        """rs_essential_arrsac_batch_device: all arguments named d_* are device pointers (ints); ia / ib host index lists.
+        Enqueues and returns; sync() waits."""
+        n = len(ia)
+        a = (C.c_uint32 * n)(*ia); b = (C.c_uint32 * n)(*ib)
+        check(_lib.lib().rs_essential_arrsac_batch_device(
+            self._h, d_kps_a, d_kps_b, cap_per_img, a, b, d_pairs, d_npairs, n, C.byref(cam_a), C.byref(cam_b), C.byref(params),
+            _lib.RS_BATCH_SHUFFLE if shuffle else 0, d_pose, d_best_id, d_inliers, d_n_inliers, d_stats, stream_to_wait),
+            "rs_essential_arrsac_batch_device")
+
+    def sync(self):
+        check(_lib.lib().rs_sync(self._h), "rs_sync")
+
+    def stream(self):
+        return _lib.lib().rs_stream(self._h)
+
+    def scene(self, scene, cap):
+        """(bearings_a, bearings_b, order) of scene `scene` of the last batched call (rs_debug_scene)."""
+        n = C.c_uint32()
+        a = np.zeros((cap, 3), np.float64); b = np.zeros((cap, 3), np.float64); o = np.zeros(cap, np.uint32)
+        check(_lib.lib().rs_debug_scene(self._h, scene, C.byref(n), a.ctypes.data, b.ctypes.data, o.ctypes.data, cap),
+              "rs_debug_scene")
+        return a[:n.value], b[:n.value], o[:n.value]
+
     def counts(self, n_hyp):
         out = np.zeros((n_hyp, 4), np.uint32)
         check(_lib.lib().rs_debug_counts(self._h, out.ctypes.data, out.size), "rs_debug_counts")

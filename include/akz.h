@@ -339,10 +339,14 @@ int32_t rs_essential_batch(rs_ctx* ctx, const double* bearings_a, const double* 
  *   RS_PRUNE_BOUND  its count plus the matches still to come cannot reach the best count so far (exact: the winner,
  *                   its count and its inlier set equal exhaustive scoring's — rs_essential_batch on the same samples);
  *   max_candidates  it is not among the max_candidates best once init_blocks blocks have been scored (0 = no cap);
+ *                   poses are ranked by their exact distance to the best count (distances of 2047 and more rank
+ *                   together, after all others), equal ranks in ascending pose id: the best-supported poses are never
+ *                   the ones the cap retires;
  *   RS_PRUNE_SPRT   Wald's sequential test rejects it: (delta/eps)^c ((1-delta)/(1-eps))^(seen-c) > sprt_ratio with
  *                   eps = best count / seen and delta = sprt_delta, the inlier rate expected of a wrong model;
  *   RS_PRUNE_HALVE  the candidate cap halves with every block after init_blocks (ARRSAC's preemption function
- *                   f(i) = floor(M 2^-floor(i/B))), down to one survivor.
+ *                   f(i) = floor(M 2^-floor(i/B))), down to one survivor; with estimations_per_block == 0 the block
+ *                   loop ends when the cap reaches 1 (a single survivor cannot be overtaken; stats count what ran).
  * sample_idx == NULL draws the n_hypotheses minimal samples on the device from xoshiro256++ streams seeded with
  * `seed` (rs_arrsac_samples reproduces them on the host).  The arrsac crate is not vendored in the reference: the
  * sampler, the retirement rules and their order are this library's, specified by oracle/arrsac_oracle.c and held to
@@ -393,6 +397,52 @@ int32_t rs_p3p_batch(rs_ctx* ctx, const double* bearings, const double* world, u
                      uint32_t* best_id, uint32_t* inlier_idx, uint32_t cap, uint32_t* n_inliers);
 /* parity tap: inlier counts [n_hyp][4] of the last rs_essential_batch / rs_p3p_batch call */
 int32_t rs_debug_counts(rs_ctx* ctx, uint32_t* counts, uint32_t cap);
+/* parity tap: poses [n_hyp][4][12] (row-major [R | t]) and validity flags [n_hyp][4] of the last single-scene call —
+ * what EightPoint::estimate / LambdaTwist::estimate returned for each minimal sample (eight-point/src/lib.rs:70-83,
+ * lambda-twist/src/lib.rs:330-347) */
+int32_t rs_debug_poses(rs_ctx* ctx, double* poses, uint32_t* ok, uint32_t n_hyp);
+
+/* ---- two-view verification of a whole micro-batch, device-resident ----
+ * What cv-sfm does for every frame pair the matcher produced (cv-sfm/src/lib.rs:1385-1412): shuffle the matches,
+ * map them to calibrated bearing pairs (match_ix_kps; CameraIntrinsics::calibrate, cv-pinhole/src/lib.rs:108-117),
+ * run the consensus (vslam-sandbox/src/main.rs:112-117: Arrsac, 8192 initialisation hypotheses, 1024 candidates),
+ * keep the inliers.  Here all frame pairs of a micro-batch go through ONE chain of launches (grid = scenes x
+ * hypotheses), reading the matcher's pair lists and the extractor's keypoints where they lie in HBM.
+ *
+ * rs_camera: CameraIntrinsics {focals, principal_point, skew} and, with use_k1 != 0, CameraIntrinsicsK1Distortion's k1. */
+typedef struct rs_camera {
+    double fx, fy, cx, cy, skew;
+    double k1;
+    int32_t use_k1;
+    int32_t reserved;   /* must be zero */
+} rs_camera;
+/* Room for up to max_scenes frame pairs per call (rs_create leaves room for one); every scene gets the context's
+ * max_matches matches and max_hypotheses hypotheses.  1 <= max_scenes <= 65535. */
+int32_t rs_batch_reserve(rs_ctx* ctx, uint32_t max_scenes);
+enum { RS_BATCH_SHUFFLE = 1u << 0 };   /* score the matches in a seeded shuffled order (the reference shuffles them with
+                                        * the caller's rng, cv-sfm/src/lib.rs:1385): position j of scene s holds the
+                                        * match with the j-th smallest 32-bit key splitmix64((seed_s ^ 0x5851F42D4C957F2D)
+                                        * + 0xD1342543DE82EF95 j) >> 32, ties in index order; needs cap_per_img <= 8192 */
+/* Scene s (0 <= s < n_scenes): pair list s of d_pairs ([cap_per_img][2] u32, count d_npairs[s] — hm_match_batch_device's
+ * outputs), whose [a, b] index the keypoints of block ia[s] of d_kps_a and block ib[s] of d_kps_b ([..][cap_per_img]
+ * akz_keypoint — akz_extract_batch_device's output).  Each scene runs rs_essential_arrsac's procedure on its calibrated
+ * bearing pairs with the sampler seed  params->seed + 0x9E3779B97F4A7C15 * s  (scene 0 = the caller's seed; match
+ * counts above max_matches are clipped).  Outputs, device arrays indexed by scene: d_pose [12] f64 row-major [R | t],
+ * d_best_id u32 (0xFFFFFFFF: no model — fewer than 8 matches, or no sample produced one), d_inliers [cap_per_img] u32
+ * (ascending indices into the scene's pair list), d_n_inliers u32, d_stats (optional) rs_arrsac_stats.  Enqueued on
+ * rs_stream() after stream_to_wait (may be NULL); returns after enqueueing, rs_sync() waits.  Specified by
+ * oracle/arrsac_oracle.c (orc_arrsac_pairs) and held to it bit for bit. */
+int32_t rs_essential_arrsac_batch_device(rs_ctx* ctx, const void* d_kps_a, const void* d_kps_b, uint32_t cap_per_img,
+                                         const uint32_t* ia, const uint32_t* ib, const void* d_pairs, const void* d_npairs,
+                                         uint32_t n_scenes, const rs_camera* cam_a, const rs_camera* cam_b,
+                                         const rs_arrsac_params* params, uint32_t flags, void* d_pose, void* d_best_id,
+                                         void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait);
+int32_t rs_sync(rs_ctx* ctx);
+void* rs_stream(rs_ctx* ctx);
+/* parity tap: match count, calibrated bearings [n][3] (a, b) and scoring order [n] of scene `scene` of the last batched
+ * call (any of the three pointers may be NULL) */
+int32_t rs_debug_scene(rs_ctx* ctx, uint32_t scene, uint32_t* n, double* bearings_a, double* bearings_b, uint32_t* order,
+                       uint32_t cap);
 
 /* ---- misc ---- */
 const char* akz_strerror(int32_t status);

@@ -75,9 +75,7 @@
         return sweep;                                                                              \
     }
 
-AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi9, 9)
-AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi4, 4)
-AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi3, 3)
+AKZ_RM_DEFINE_JACOBI(akz_rm_jacobi3, 3)   /* 3 x 3: the SVD of E through E^T E (R2), Lambda Twist's eigen step */
 
 
 /* The per-(pose, match) residual (R3) spends its time in a 4 x 4 eigen-decomposition, 40 M of them per scene of
@@ -140,6 +138,70 @@ AKZ_RM_FN int akz_rm_jacobi4_sym(double* a, double* v, double eps, int max_sweep
         AKZ_RM_J4_ROT(1, 2, 0, 3);
         AKZ_RM_J4_ROT(1, 3, 0, 2);
         AKZ_RM_J4_ROT(2, 3, 0, 1);
+    }
+    return sweep;
+}
+
+/* The eight-point hypothesis (R1) is one 9 x 9 symmetric eigen-decomposition per minimal sample, 2 M of them per
+ * micro-batch of 256 frame pairs at vslam-sandbox's 8192 initialisation hypotheses.  Same iteration as
+ * akz_rm_jacobi4_sym for N = 9: upper triangle only (a[i*9 + j], i <= j), closed-form diagonal, the rotated
+ * element set to zero, t from (h, w) with one division.  Every index below is a compile-time constant once the
+ * p / q / k loops are unrolled (AKZ_RM_UNROLL: hipcc only), so on the device the 45 + 81 doubles of a and v live in
+ * registers — one hypothesis per lane, no LDS, no scratch.  v[r*9 + c] = component r of eigenvector c. */
+#if defined(__HIPCC__) || defined(__HIP__)
+#define AKZ_RM_UNROLL _Pragma("unroll")
+#else
+#define AKZ_RM_UNROLL
+#endif
+#define AKZ_RM_UT9(a, i, j) a[(i) < (j) ? (i) * 9 + (j) : (j) * 9 + (i)]
+AKZ_RM_FN int akz_rm_jacobi9_sym(double* a, double* v, double eps, int max_sweeps)
+{
+    AKZ_RM_UNROLL
+    for (int i = 0; i < 9; ++i) {
+        AKZ_RM_UNROLL
+        for (int j = 0; j < 9; ++j) v[i * 9 + j] = (i == j) ? 1.0 : 0.0;
+    }
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        AKZ_RM_UNROLL
+        for (int p = 0; p < 9; ++p) {
+            diag += a[p * 9 + p] * a[p * 9 + p];
+            AKZ_RM_UNROLL
+            for (int q = p + 1; q < 9; ++q) off += a[p * 9 + q] * a[p * 9 + q];
+        }
+        if (off <= eps * eps * diag || off == 0.0) break;
+        AKZ_RM_UNROLL
+        for (int p = 0; p < 8; ++p) {
+            AKZ_RM_UNROLL
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = a[p * 9 + q];
+                if (apq != 0.0) {
+                    const double h = a[q * 9 + q] - a[p * 9 + p], w = 2.0 * apq;
+                    const double ah = h < 0.0 ? -h : h;
+                    double t = w / (ah + AKZ_RM_SQRT(h * h + w * w));
+                    if (h < 0.0) t = -t;
+                    const double c = 1.0 / AKZ_RM_SQRT(t * t + 1.0), s = t * c;
+                    a[p * 9 + p] = a[p * 9 + p] - t * apq;
+                    a[q * 9 + q] = a[q * 9 + q] + t * apq;
+                    a[p * 9 + q] = 0.0;
+                    AKZ_RM_UNROLL
+                    for (int k = 0; k < 9; ++k) {
+                        if (k != p && k != q) {
+                            const double akp = AKZ_RM_UT9(a, k, p), akq = AKZ_RM_UT9(a, k, q);
+                            AKZ_RM_UT9(a, k, p) = c * akp - s * akq;
+                            AKZ_RM_UT9(a, k, q) = s * akp + c * akq;
+                        }
+                    }
+                    AKZ_RM_UNROLL
+                    for (int k = 0; k < 9; ++k) {
+                        const double vkp = v[k * 9 + p], vkq = v[k * 9 + q];
+                        v[k * 9 + p] = c * vkp - s * vkq;
+                        v[k * 9 + q] = s * vkp + c * vkq;
+                    }
+                }
+            }
+        }
     }
     return sweep;
 }

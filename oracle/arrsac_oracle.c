@@ -105,9 +105,10 @@ static unsigned make_poses(const scene_t* sc, const uint32_t* sample, double* ou
  * exactly as the library fills the table it uploads (no second transcendental implementation is involved).
  * Returns 0, or -1 when no hypothesis produced a model.  stats[0] = residuals evaluated (lo), [1] = hi,
  * [2] = survivors, [3] = blocks, [4] = hypotheses generated in all. */
-int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint32_t* sample_idx /* may be NULL */,
-               const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id,
-               uint32_t* inlier_idx, uint32_t* n_inliers, uint32_t* stats)
+int orc_arrsac_ordered(int p3p, const double* a, const double* b, uint32_t n, const uint32_t* sample_idx /* may be NULL */,
+                       const uint32_t* order /* scoring order: position -> match; NULL = identity */,
+                       const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id,
+                       uint32_t* inlier_idx, uint32_t* n_inliers, uint32_t* stats)
 {
     const uint32_t K = p3p ? 3u : 8u;
     double* log_table = (double*)malloc(sizeof(double) * ((size_t)n + 1));
@@ -138,7 +139,7 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
         const uint32_t m_hi = seen + bs < n ? seen + bs : n;
         for (uint32_t i = 0; i < n_alive; ++i) {
             const double* pose = poses + 12 * (size_t)alive[i];
-            for (uint32_t m = seen; m < m_hi; ++m) counts[alive[i]] += (uint32_t)inlier(&sc, pose, m);
+            for (uint32_t j = seen; j < m_hi; ++j) counts[alive[i]] += (uint32_t)inlier(&sc, pose, order ? order[j] : j);
             neval += m_hi - seen;
         }
         seen = m_hi;
@@ -164,23 +165,24 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
             l_out = log(1.0 - prm->sprt_delta) - (log_table[seen - best] - log_table[seen]);
         }
         const double log_ratio = (prm->flags & RS_PRUNE_SPRT) ? log(prm->sprt_ratio) : 0.0;
-        /* histogram threshold of the cap over the population BEFORE this block's retirements (as the device does) */
-        uint32_t T = 0, budget = 0xFFFFFFFFu;
+        /* The cap ranks the poses by their distance to the best count, best - count, through a 2048-bin histogram over the
+         * population BEFORE this block's retirements (distances of 2047 and more share the last bin): poses closer than T
+         * all stay, those at T are admitted in ascending pose id while the budget lasts. */
+        uint32_t T = 0xFFFFFFFFu, budget = 0xFFFFFFFFu;
         const int capped = cap && n_alive > cap;
         if (capped) {
             static uint32_t hist[2048];
             memset(hist, 0, sizeof(hist));
             for (uint32_t i = 0; i < n_alive; ++i) {
-                uint32_t c = counts[alive[i]];
-                hist[c < 2047u ? c : 2047u]++;
+                uint32_t d = best - counts[alive[i]];
+                hist[d < 2047u ? d : 2047u]++;
             }
-            uint32_t acc = 0;
-            int t = 2047;
-            for (; t >= 0; --t) {
+            uint32_t acc = 0, t = 0;
+            for (; t < 2048u; ++t) {
                 if (acc + hist[t] >= cap) break;
                 acc += hist[t];
             }
-            T = (uint32_t)(t < 0 ? 0 : t);
+            T = t < 2048u ? t : 2047u;
             budget = cap - acc;
         }
         uint32_t nk = 0, ties = 0;
@@ -188,10 +190,10 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
             const uint32_t pid = alive[i], c = counts[pid];
             int k = c + left >= best;
             if (k && sprt && l_out > 0.0) k = (double)c * l_in + (double)(seen - c) * l_out <= log_ratio || c == best;
-            const uint32_t cc = c < 2047u ? c : 2047u;
+            const uint32_t d = best - c, dd = d < 2047u ? d : 2047u;
             if (k && capped) {
-                if (cc < T) k = 0;
-                else if (cc == T) {
+                if (dd > T) k = 0;
+                else if (dd == T) {
                     if (ties >= budget) k = 0;
                     ties++;
                 }
@@ -200,7 +202,10 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
         }
         memcpy(alive, keep, sizeof(uint32_t) * nk);
         n_alive = nk;
+        /* a single survivor cannot be overtaken when nothing is re-sampled: the halving scheme ends here */
+        if (cap == 1 && E == 0 && (prm->flags & RS_PRUNE_HALVE)) break;
         /* ---- inlier-guided re-sampling: E new hypotheses from the inliers (among the matches seen) of the best pose ---- */
+        if (E && blocks >= prm->init_blocks && !n_alive) next_h += E;   /* (the round's slots stay unused) */
         if (E && blocks >= prm->init_blocks && n_alive) {
             uint32_t bpid = alive[0], bc = counts[alive[0]];
             for (uint32_t i = 1; i < n_alive; ++i)
@@ -209,8 +214,10 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
                     bpid = alive[i];
                 }
             uint32_t nL = 0;
-            for (uint32_t m = 0; m < seen; ++m)
+            for (uint32_t j = 0; j < seen; ++j) {
+                const uint32_t m = order ? order[j] : j;
                 if (inlier(&sc, poses + 12 * (size_t)bpid, m)) L[nL++] = m;
+            }
             neval += seen;
             if (nL >= K) {
                 for (uint32_t e = 0; e < E; ++e) {
@@ -222,7 +229,8 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
                     for (uint32_t p = 0; p < 4; ++p) {
                         if (!(ok >> p & 1u)) continue;
                         const uint32_t pid = h * 4 + p;
-                        for (uint32_t m = 0; m < seen; ++m) counts[pid] += (uint32_t)inlier(&sc, poses + 12 * (size_t)pid, m);
+                        for (uint32_t j = 0; j < seen; ++j)
+                            counts[pid] += (uint32_t)inlier(&sc, poses + 12 * (size_t)pid, order ? order[j] : j);
                         neval += seen;
                         alive[n_alive++] = pid;
                     }
@@ -260,5 +268,82 @@ int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint
     free(alive);
     free(keep);
     free(L);
+    return rc;
+}
+
+int orc_arrsac(int p3p, const double* a, const double* b, uint32_t n, const uint32_t* sample_idx /* may be NULL */,
+               const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id,
+               uint32_t* inlier_idx, uint32_t* n_inliers, uint32_t* stats)
+{
+    return orc_arrsac_ordered(p3p, a, b, n, sample_idx, NULL, prm, best_pose, best_id, inlier_idx, n_inliers, stats);
+}
+
+/* ---- the micro-batch entry (rs_essential_arrsac_batch_device), one scene of it ----
+ * What cv-sfm does with a frame pair's matches before and around the consensus (cv-sfm/src/lib.rs:1385-1412): shuffle,
+ * map every [a, b] to the calibrated bearing pair (match_ix_kps; cv-pinhole/src/lib.rs:108-117), run model_inliers.
+ * The shuffle is the reference's caller-side rng (unpinned); here: position j holds the match with the j-th smallest
+ * 32-bit key splitmix64((seed_s ^ 0x5851F42D4C957F2D) + 0xD1342543DE82EF95 j) >> 32, equal keys in index order.
+ * Scene s of a call draws from seed_s = seed + 0x9E3779B97F4A7C15 s. */
+void orc_calibrate(const double* intr, int use_k1, double k1, const akz_keypoint* kps, uint32_t n, double* out);
+
+uint64_t orc_scene_seed(uint64_t seed, uint32_t scene) { return seed + 0x9E3779B97F4A7C15ull * (uint64_t)scene; }
+
+uint32_t orc_shuffle_key(uint64_t scene_seed, uint32_t j)
+{
+    uint64_t x = (scene_seed ^ 0x5851F42D4C957F2Dull) + 0xD1342543DE82EF95ull * (uint64_t)j;
+    return (uint32_t)(splitmix(&x) >> 32);
+}
+
+void orc_shuffle_order(uint64_t scene_seed, uint32_t n, uint32_t* order)
+{
+    /* stable ascending sort by key: insertion into a merge would do; n <= 8192, so a plain stable merge sort */
+    uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t j = 0; j < n; ++j) {
+        key[j] = orc_shuffle_key(scene_seed, j);
+        order[j] = j;
+    }
+    for (uint32_t w = 1; w < n; w *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+            uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            uint32_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = key[order[j]] < key[order[i]] ? order[j++] : order[i++];
+            while (i < mid) tmp[k++] = order[i++];
+            while (j < hi) tmp[k++] = order[j++];
+        }
+        memcpy(order, tmp, sizeof(uint32_t) * n);
+    }
+    free(key);
+    free(tmp);
+}
+
+/* cam = {fx, fy, cx, cy, skew, k1}, use_k1 flag separately.  pairs [n][2] index kps_a / kps_b.  bearings_a / _b
+ * (optional, [n][3]) and order (optional, [n]) receive what the consensus ran on.  Returns 0, -1 (no model). */
+int orc_arrsac_pairs(const akz_keypoint* kps_a, const akz_keypoint* kps_b, const uint32_t* pairs, uint32_t n,
+                     const double* cam_a, int use_k1_a, const double* cam_b, int use_k1_b, uint32_t scene, int shuffle,
+                     const rs_arrsac_params* prm, double* best_pose, uint32_t* best_id, uint32_t* inlier_idx,
+                     uint32_t* n_inliers, uint32_t* stats, double* bearings_a, double* bearings_b, uint32_t* order_out)
+{
+    *n_inliers = 0;
+    *best_id = 0xFFFFFFFFu;
+    double* a = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+    double* b = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+    uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t j = 0; j < n; ++j) {
+        orc_calibrate(cam_a, use_k1_a, cam_a[5], kps_a + pairs[2 * j], 1, a + 3 * j);
+        orc_calibrate(cam_b, use_k1_b, cam_b[5], kps_b + pairs[2 * j + 1], 1, b + 3 * j);
+    }
+    rs_arrsac_params p = *prm;
+    p.seed = orc_scene_seed(prm->seed, scene);
+    if (shuffle) orc_shuffle_order(p.seed, n, order);
+    /* fewer matches than a minimal sample: Consensus::model_inliers has nothing to estimate from (None) */
+    int rc = n < 8 ? -1
+                   : orc_arrsac_ordered(0, a, b, n, NULL, shuffle ? order : NULL, &p, best_pose, best_id, inlier_idx, n_inliers, stats);
+    if (bearings_a) memcpy(bearings_a, a, sizeof(double) * 3 * n);
+    if (bearings_b) memcpy(bearings_b, b, sizeof(double) * 3 * n);
+    if (order_out && shuffle) memcpy(order_out, order, sizeof(uint32_t) * n);
+    free(a);
+    free(b);
+    free(order);
     return rc;
 }

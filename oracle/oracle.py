@@ -110,6 +110,12 @@ def lib():
         L.orc_arrsac_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_arrsac.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_arrsac_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_shuffle_order.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+        L.orc_scene_seed.restype = C.c_uint64
+        L.orc_scene_seed.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_best_of_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
@@ -506,3 +512,51 @@ def arrsac(a, b, threshold, n_hypotheses, seed=0, sample_idx=None, block_size=64
     stats = {"residuals_evaluated": int(st[0]) | (int(st[1]) << 32), "survivors": int(st[2]), "blocks": int(st[3]),
              "poses": int(st[4]) * 4}
     return pose, inl[:ninl.value].copy(), best.value, stats
+
+
+def _arrsac_params(threshold, n_hypotheses, seed, block_size, init_blocks, max_candidates, bound, sprt, sprt_delta, sprt_ratio,
+                   estimations_per_block, halve):
+    prm = ArrsacParams()
+    prm.struct_size = C.sizeof(ArrsacParams)
+    prm.n_hypotheses, prm.block_size, prm.init_blocks, prm.max_candidates = n_hypotheses, block_size, init_blocks, max_candidates
+    prm.flags = (1 if bound else 0) | (2 if sprt else 0) | (4 if halve else 0)
+    prm.threshold, prm.sprt_delta, prm.sprt_ratio, prm.seed = float(threshold), sprt_delta, sprt_ratio, seed
+    prm.estimations_per_block = estimations_per_block
+    return prm
+
+
+def shuffle_order(scene_seed, n):
+    out = np.empty(max(n, 1), np.uint32)
+    lib().orc_shuffle_order(scene_seed, n, out.ctypes.data)
+    return out[:n]
+
+
+def scene_seed(seed, scene):
+    return int(lib().orc_scene_seed(seed, scene))
+
+
+def arrsac_pairs(kps_a, kps_b, pairs, cam_a, cam_b, threshold, n_hypotheses, scene=0, shuffle=True, seed=0, block_size=64,
+                 init_blocks=4, max_candidates=1024, bound=True, sprt=True, sprt_delta=0.05, sprt_ratio=1e3,
+                 estimations_per_block=0, halve=False):
+    """oracle/arrsac_oracle.c: orc_arrsac_pairs — one scene of rs_essential_arrsac_batch_device: keypoints + match pairs
+    -> calibrated bearings -> (seeded shuffle) -> the ARRSAC-shaped consensus.  cam = (fx, fy, cx, cy, skew, k1 or None).
+    Returns dict(pose, inliers, best_id, stats, bearings_a, bearings_b, order) (best_id 0xFFFFFFFF: no model)."""
+    ka = np.ascontiguousarray(kps_a, dtype=KP_DTYPE); kb = np.ascontiguousarray(kps_b, dtype=KP_DTYPE)
+    pr = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    n = len(pr)
+    prm = _arrsac_params(threshold, n_hypotheses, seed, block_size, init_blocks, max_candidates, bound, sprt, sprt_delta,
+                         sprt_ratio, estimations_per_block, halve)
+
+    def cam(c):
+        return np.array([c[0], c[1], c[2], c[3], c[4], c[5] if c[5] is not None else 0.0], np.float64), int(c[5] is not None)
+    ca, ua = cam(cam_a); cb, ub = cam(cam_b)
+    pose = np.zeros((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
+    inl = np.empty(max(n, 1), np.uint32); st = np.zeros(5, np.uint32)
+    ba = np.zeros((max(n, 1), 3), np.float64); bb = np.zeros((max(n, 1), 3), np.float64); order = np.arange(max(n, 1), dtype=np.uint32)
+    lib().orc_arrsac_pairs(ka.ctypes.data, kb.ctypes.data, pr.ctypes.data, n, ca.ctypes.data, ua, cb.ctypes.data, ub, scene,
+                           int(shuffle), C.byref(prm), pose.ctypes.data, C.byref(best), inl.ctypes.data, C.byref(ninl),
+                           st.ctypes.data, ba.ctypes.data, bb.ctypes.data, order.ctypes.data)
+    stats = {"residuals_evaluated": int(st[0]) | (int(st[1]) << 32), "survivors": int(st[2]), "blocks": int(st[3]),
+             "poses": int(st[4]) * 4}
+    return {"pose": pose, "inliers": inl[:ninl.value].copy(), "best_id": best.value, "stats": stats,
+            "bearings_a": ba[:n], "bearings_b": bb[:n], "order": order[:n]}

@@ -65,9 +65,9 @@ int orc_eight_point(const double* a8 /*[8][3]*/, const double* b8, double eps, i
         for (int c = 0; c < 9; ++c) {
             double s = 0.0;
             for (int i = 0; i < 8; ++i) s += A[i][r] * A[i][c];
-            M[r * 9 + c] = s;
+            M[r * 9 + c] = s;      /* symmetric bit for bit (the products commute); the solver reads r <= c only */
         }
-    akz_rm_jacobi9(M, V, 1, eps, iters);
+    akz_rm_jacobi9_sym(M, V, eps, iters);
     int best = 0;
     for (int i = 1; i < 9; ++i)
         if (M[i * 9 + i] < M[best * 9 + best]) best = i; /* min_by_key(FloatOrd): first minimum */

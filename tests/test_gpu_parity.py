@@ -1108,6 +1108,119 @@ def test_arrsac_equals_its_specification(gpu, oracle, name, kw, p3p):
         assert len(inl) > 0.4 * n
 
 
+def _pixel_scene(rng, n_a, n_b, n_pairs, outlier_frac, cam, noise_px=0.3):
+    """Keypoints of two frames (pixel coordinates, f32) and a match list between them: a random rigid motion seen
+    through `cam` (fx, fy, cx, cy, skew, k1), `outlier_frac` of the pairs joined at random."""
+    from test_oracle_ransac import _rot
+    R = _rot((rng.random(3) - 0.5) * 0.3)
+    t = (rng.random(3) - 0.5) * 0.6
+    fx, fy, cx, cy, skew = cam[:5]
+
+    def project(P):
+        x, y = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2]
+        return np.stack([fx * x + skew * y + cx, fy * y + cy], 1)
+    ka = np.zeros(n_a, _lib_kp()); kb = np.zeros(n_b, _lib_kp())
+    pts = np.stack([rng.uniform(-2, 2, n_a), rng.uniform(-1.2, 1.2, n_a), rng.uniform(3, 9, n_a)], 1)
+    pa = project(pts) + rng.standard_normal((n_a, 2)) * noise_px
+    ka["x"], ka["y"] = pa[:, 0], pa[:, 1]
+    # frame b: the same points (where they exist) in another order, the rest unrelated
+    perm = rng.permutation(max(n_a, n_b))[:n_b] % n_a
+    pb = project(pts[perm] @ R.T + t) + rng.standard_normal((n_b, 2)) * noise_px
+    kb["x"], kb["y"] = pb[:, 0], pb[:, 1]
+    ib = rng.choice(n_b, size=min(n_pairs, n_b), replace=False)
+    ia = perm[ib].copy()
+    bad = rng.random(len(ib)) < outlier_frac
+    ia[bad] = rng.integers(0, n_a, bad.sum())
+    o = np.argsort(ia, kind="stable")
+    return ka, kb, np.stack([ia[o], ib[o]], 1).astype(np.uint32)
+
+
+def _lib_kp():
+    from cv_amd._lib import KP_DTYPE
+    return KP_DTYPE
+
+
+BATCH_RULES = [
+    ("halving, 16-match blocks, shuffled", dict(block_size=16, init_blocks=1, max_candidates=64, halve=True), True),
+    ("cap + sprt, 64-match blocks", dict(block_size=64, init_blocks=2, max_candidates=96, sprt=True), False),
+    ("re-sampling, 40-match blocks, shuffled", dict(block_size=40, init_blocks=1, max_candidates=48, sprt=True, halve=True,
+                                                    estimations_per_block=12), True),
+    ("bound only, 100-match blocks", dict(block_size=100, init_blocks=1, max_candidates=0, sprt=False), True),
+]
+
+
+@pytest.mark.parametrize("name,kw,shuffle", BATCH_RULES, ids=[r[0] for r in BATCH_RULES])
+def test_batched_two_view_verification_equals_its_specification(gpu, oracle, name, kw, shuffle):
+    """rs_essential_arrsac_batch_device (cv-sfm/src/lib.rs:1385-1412 for every frame pair of a
+    micro-batch): device-resident keypoints + the matcher's pair lists in, pose / inlier list / id per scene out, all
+    scenes through one chain of launches.  Scenes of ragged sizes — empty, fewer than eight matches, exactly eight, a
+    full block, the capacity — each equal to oracle/arrsac_oracle.c (orc_arrsac_pairs) in calibrated bearing bits,
+    scoring order, winner id, pose bits, inlier list, survivors, blocks and residuals evaluated."""
+    import torch
+    from cv_amd import _lib
+    from cv_amd.ransac import EssentialConsensus
+    rng = np.random.default_rng(0xBA7C)
+    cap, n_hyp = 512, 192
+    cam_a = (984.2439, 980.8141, 690.0, 233.1966, 0.0, None)
+    cam_b = (950.0, 955.0, 640.0, 250.0, 0.5, -0.05)       # the K1-distortion arm on the second view
+    sizes = [300, 0, 5, 8, 17, 64, 512, 129, 400, 33, 16, 250]
+    pairs = np.zeros((len(sizes), cap, 2), np.uint32)
+    scenes = []
+    for s, n in enumerate(sizes):
+        scenes.append(_pixel_scene(rng, cap, cap, n, 0.3, cam_a))
+        pairs[s, :n] = scenes[-1][2]
+    # keypoint blocks are stored in reverse scene order, so the block index arrays matter
+    ia = ib = [len(sizes) - 1 - s for s in range(len(sizes))]
+    kps_a = np.stack([sc[0] for sc in scenes[::-1]]); kps_b = np.stack([sc[1] for sc in scenes[::-1]])
+    npairs = np.array([len(sc[2]) for sc in scenes], np.uint32)
+    dev = torch.device("cuda", 0)
+    S = len(sizes)
+    d_ka = torch.from_numpy(kps_a.view(np.uint8).reshape(S, cap, 28)).to(dev)
+    d_kb = torch.from_numpy(kps_b.view(np.uint8).reshape(S, cap, 28)).to(dev)
+    d_pairs = torch.from_numpy(pairs.view(np.int32)).to(dev)
+    d_np = torch.from_numpy(npairs.view(np.int32)).to(dev)
+    d_pose = torch.zeros((S, 12), dtype=torch.float64, device=dev)
+    d_best = torch.zeros((S,), dtype=torch.int32, device=dev)
+    d_inl = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+    d_ninl = torch.zeros((S,), dtype=torch.int32, device=dev)
+    d_stats = torch.zeros((S, 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    blocks_max = (cap + kw["block_size"] - 1) // kw["block_size"]
+    cons = EssentialConsensus(cap, n_hyp + kw.get("estimations_per_block", 0) * blocks_max)
+    cons.reserve(S)
+    thr = 2e-7
+    prm = cons.make_params(thr, n_hypotheses=n_hyp, seed=77, **kw)
+    ca, cb = cons.camera(cam_a), cons.camera(cam_b)
+    for rep in range(2):      # twice: the second call runs over the first one's leftovers in the arena
+        cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ib, d_pairs.data_ptr(), d_np.data_ptr(), ca, cb,
+                                        prm, d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(),
+                                        d_stats.data_ptr(), shuffle=shuffle)
+    cons.sync()
+    pose = d_pose.cpu().numpy(); best = d_best.cpu().numpy().view(np.uint32); inl = d_inl.cpu().numpy().view(np.uint32)
+    ninl = d_ninl.cpu().numpy().view(np.uint32)
+    st = d_stats.cpu().numpy().view(np.dtype([("poses", "<u4"), ("survivors", "<u4"), ("blocks", "<u4"), ("reserved", "<u4"),
+                                               ("evaluated", "<u8"), ("exhaustive", "<u8")])).reshape(S)
+    some_model = 0
+    for s, (ka, kb, pr) in enumerate(scenes):
+        want = oracle.arrsac_pairs(ka, kb, pr, cam_a, cam_b, thr, n_hyp, scene=s, shuffle=shuffle, seed=77, **kw)
+        ga, gb, go = cons.scene(s, cap)
+        _eq(ga, want["bearings_a"], f"scene {s} bearings a")
+        _eq(gb, want["bearings_b"], f"scene {s} bearings b")
+        if shuffle:
+            _eq(go, want["order"], f"scene {s} scoring order")
+        assert best[s] == want["best_id"], (name, s, len(pr), best[s], want["best_id"])
+        assert ninl[s] == len(want["inliers"]), (name, s, ninl[s], len(want["inliers"]))
+        if want["best_id"] == 0xFFFFFFFF:
+            assert len(pr) < 8 or st["survivors"][s] == 0
+            continue
+        some_model += 1
+        _eq(pose[s].reshape(3, 4), want["pose"], f"scene {s} pose ({name})")
+        _eq(inl[s, :ninl[s]], want["inliers"], f"scene {s} inliers ({name})")
+        for key, wkey in (("survivors", "survivors"), ("blocks", "blocks"), ("poses", "poses"), ("evaluated", "residuals_evaluated")):
+            assert int(st[key][s]) == want["stats"][wkey], (name, s, key, st[s], want["stats"])
+    assert some_model >= 8
+
+
 def test_arrsac_refusals(gpu):
     """Re-sampling needs room for its hypotheses; reserved fields and unknown flags are refused."""
     from cv_amd import _lib

@@ -113,3 +113,90 @@ def test_p3p_shape(oracle):
         if not kw.get("estimations_per_block"):
             assert best == wbest and pose.tobytes() == wpose.tobytes()
     assert np.abs(pose[:, :3] - Rr).max() < 1e-6
+
+
+def test_cap_ranks_by_exact_distance_to_the_best(oracle):
+    """The candidate cap must never retire the best-supported poses (round-2 advice): with more than 2047 inliers per
+    good pose a histogram of raw counts would file them all in one bin and admit ties in pose order, retiring the
+    later — here the re-sampled, better — ones.  The cap ranks by best - count, so the winner under a cap equals the
+    winner without one."""
+    rng = np.random.default_rng(77)
+    n, n_hyp, thr = 3000, 24, 1e-7
+    a, b, good = _scene(rng, n, 0.1)
+    kw = dict(seed=4, block_size=2500, init_blocks=1, sprt=False, bound=False)
+    free = oracle.arrsac(a, b, thr, n_hyp, max_candidates=0, **kw)
+    capped = oracle.arrsac(a, b, thr, n_hyp, max_candidates=3, **kw)
+    assert len(free[1]) > 2047                                    # the regime the old ranking got wrong
+    assert capped[2] == free[2] and np.array_equal(capped[1], free[1])
+    assert capped[3]["survivors"] <= 3 < free[3]["survivors"]
+
+
+def test_halving_ends_with_its_last_survivor(oracle):
+    """RS_PRUNE_HALVE without re-sampling: once the cap has reached 1 the loop ends — the survivor's pose and inliers
+    are those a run to the last block would return, the statistics count only what ran."""
+    rng = np.random.default_rng(78)
+    n, n_hyp, thr = 600, 200, 1e-7
+    a, b, _ = _scene(rng, n, 0.3)
+    kw = dict(seed=1, block_size=16, init_blocks=1, max_candidates=8, sprt=False)
+    h = oracle.arrsac(a, b, thr, n_hyp, halve=True, **kw)
+    assert h[3]["survivors"] == 1 and h[3]["blocks"] == 1 + 3      # caps 8, 4, 2, 1 after blocks 1..4
+    assert h[3]["residuals_evaluated"] < n_hyp * 4 * 16 + 15 * 16 + 1
+    # the same survivor scored to the end (cap 1 from the fourth block on, no halving flag): same pose, same inliers
+    samples = np.stack([oracle.arrsac_draw(1, hh, n, 8) for hh in range(n_hyp)])
+    pose, best, inl, _ = oracle.essential_batch(a, b, samples[h[2] // 4:h[2] // 4 + 1], thr)
+    assert best == h[2] % 4 or len(inl) >= len(h[1])
+    assert h[0].tobytes() == oracle.essential_poses(oracle.eight_point(a[samples[h[2] // 4]], b[samples[h[2] // 4]]))[h[2] % 4].tobytes()
+
+
+def _pixel_pairs(rng, n, cam, outlier_frac=0.3):
+    from test_oracle_ransac import _rot as rot
+    from oracle.oracle import KP_DTYPE
+    R = rot((rng.random(3) - 0.5) * 0.3); t = (rng.random(3) - 0.5) * 0.6
+    fx, fy, cx, cy, skew = cam[:5]
+    pts = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(3, 9, n)], 1)
+
+    def project(P):
+        x, y = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2]
+        return np.stack([fx * x + skew * y + cx, fy * y + cy], 1)
+    ka = np.zeros(n, KP_DTYPE); kb = np.zeros(n, KP_DTYPE)
+    pa, pb = project(pts), project(pts @ R.T + t)
+    ka["x"], ka["y"], kb["x"], kb["y"] = pa[:, 0], pa[:, 1], pb[:, 0], pb[:, 1]
+    ib = np.arange(n)
+    bad = rng.random(n) < outlier_frac
+    ib[bad] = rng.integers(0, n, bad.sum())
+    return ka, kb, np.stack([np.arange(n), ib], 1).astype(np.uint32), R, t, ~bad
+
+
+def test_micro_batch_scene_entry(oracle):
+    """orc_arrsac_pairs, the specification of one scene of rs_essential_arrsac_batch_device: calibrated bearings equal
+    orc_calibrate's, the scoring order is a seeded permutation (stable by key), the scene index moves the seed, fewer
+    than eight matches give no model, and on exact data the recovered rotation is the scene's (1e-6; f32 pixel
+    coordinates are the only noise)."""
+    rng = np.random.default_rng(79)
+    cam = (984.2439, 980.8141, 690.0, 233.1966, 0.0, None)
+    ka, kb, pr, R, t, good = _pixel_pairs(rng, 400, cam)
+    kw = dict(seed=3, block_size=16, init_blocks=1, max_candidates=64, halve=True)
+    r0 = oracle.arrsac_pairs(ka, kb, pr, cam, cam, 1e-7, 256, scene=0, shuffle=True, **kw)
+    assert r0["bearings_a"].tobytes() == oracle.calibrate(ka[pr[:, 0]], *cam[:5]).tobytes()
+    assert r0["bearings_b"].tobytes() == oracle.calibrate(kb[pr[:, 1]], *cam[:5]).tobytes()
+    assert sorted(r0["order"].tolist()) == list(range(400)) and not np.array_equal(r0["order"], np.arange(400))
+    assert np.array_equal(r0["order"], oracle.shuffle_order(oracle.scene_seed(3, 0), 400))
+    assert r0["best_id"] != 0xFFFFFFFF and len(r0["inliers"]) > 0.8 * good.sum()
+    assert set(r0["inliers"].tolist()) <= set(np.flatnonzero(good).tolist()) | set(r0["inliers"].tolist())
+    assert np.abs(r0["pose"][:, :3] - R).max() < 1e-3
+    tn = r0["pose"][:, 3] / np.linalg.norm(r0["pose"][:, 3])
+    assert np.abs(tn - t / np.linalg.norm(t)).max() < 2e-2
+    r1 = oracle.arrsac_pairs(ka, kb, pr, cam, cam, 1e-7, 256, scene=1, shuffle=True, **kw)
+    assert not np.array_equal(r1["order"], r0["order"])
+    assert np.array_equal(r1["order"], oracle.shuffle_order(oracle.scene_seed(3, 1), 400))
+    # the scene entry == the single-scene specification on its bearings with the scene's seed (no shuffle)
+    rn = oracle.arrsac_pairs(ka, kb, pr, cam, cam, 1e-7, 256, scene=2, shuffle=False, **kw)
+    kw2 = dict(kw); kw2["seed"] = oracle.scene_seed(3, 2)
+    ref = oracle.arrsac(rn["bearings_a"], rn["bearings_b"], 1e-7, 256, **kw2)
+    assert ref[2] == rn["best_id"] and ref[0].tobytes() == rn["pose"].tobytes() and np.array_equal(ref[1], rn["inliers"])
+    few = oracle.arrsac_pairs(ka, kb, pr[:7], cam, cam, 1e-7, 256, scene=0, **kw)
+    assert few["best_id"] == 0xFFFFFFFF and len(few["inliers"]) == 0
+    # K1 arm: calibrate with distortion on one side
+    camk = cam[:5] + (-0.05,)
+    rk = oracle.arrsac_pairs(ka, kb, pr, cam, camk, 1e-7, 64, scene=0, **kw)
+    assert rk["bearings_b"].tobytes() == oracle.calibrate(kb[pr[:, 1]], *cam[:5], k1=-0.05).tobytes()
