@@ -138,7 +138,11 @@ def main():
                     "the defaults are what the headline is quoted on)")
     ap.add_argument("--max-features", type=int, default=0, help="A/B: Akaze.maximum_features (0 = the reference's default, unlimited)")
     ap.add_argument("--matcher-low-priority", action="store_true", help="A/B: matcher stream at the lowest priority")
-    ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3])")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3], pipeline+verify)")
+    ap.add_argument("--verify-steps", type=int, default=4, help="timed steps of the pipeline+verify leg (extract + match + "
+                    "two-view ARRSAC of every frame pair, device-resident); 0 = skip")
+    ap.add_argument("--verify-block", type=int, default=16, help="pipeline+verify: matches per scoring block")
+    ap.add_argument("--verify-check", type=int, default=16, help="pipeline+verify: scenes compared with oracle/arrsac_oracle.c")
     ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
     ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
@@ -229,6 +233,8 @@ def main():
     # cv_amd/sharding.py
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
 
+    verify = {"on": None}            # pipeline+verify leg: a callable(p, m0, js, prev_js) that enqueues the consensus
+
     def step():
         cur = torch.cuda.current_stream()
         p = step_no[0] & 1
@@ -238,6 +244,8 @@ def main():
             cur.wait_event(match_done[p])
             if world > 1:
                 comm.wait_event(match_done[p])
+            if verify["on"] is not None and verify.get("armed"):
+                cur.wait_event(verify["done"][p])   # ... and its keypoints / pair lists by the consensus
         for m0 in range(0, NF, MB):
             tA = time.perf_counter()
             _lib.check(L.akz_extract_batch_device(
@@ -260,6 +268,8 @@ def main():
                 matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib,
                 len(js), RULE_STRICT, 24, 0.0, 1, pairs[m0:].data_ptr(), npairs[m0:].data_ptr(), wait.cuda_stream),
                 "match")
+            if verify["on"] is not None:
+                verify["on"](p, m0, js, [(j - 1) % NF for j in js])
             if host_trace is not None:
                 host_trace.append((step_no[0], m0, round((tB - tA) * 1e3, 2), round((time.perf_counter() - tB) * 1e3, 2)))
         match_done[p].record(hm_stream)
@@ -427,6 +437,9 @@ def main():
         if world == 1 and not args.no_extras:
             out["configs_extra"] = {"configs[2]": extra_match(torch, dev, L, _lib, args.extra_frames),
                                     "configs[3]": extra_ransac(args.extra_hyp)}
+            if args.verify_steps > 0:
+                out["configs_extra"]["pipeline+verify"] = extra_pipeline_verify(
+                    torch, dev, L, _lib, args, step, step_no, barrier, verify, match_done, hm_stream, kps2, pairs2, npairs2, NF, MB)
             for v in out["configs_extra"].values():
                 if v.get("parity", {}).get("mismatches"):
                     rc = 1
@@ -584,6 +597,99 @@ def extra_match(torch, dev, L, _lib, n_frames):
            "parity": {"pairs_checked": len(sample), "mismatches": bad,
                       "what": "match pair lists of the sampled frame pairs vs oracle/match_oracle.c"}}
     m.close()
+    return out
+
+
+def extra_pipeline_verify(torch, dev, L, _lib, args, step, step_no, barrier, verify, match_done, hm_stream, kps2, pairs2, npairs2,
+                          NF, MB):
+    """The headline pipeline with the stage that consumes its match lists attached: every frame pair of every
+    micro-batch goes from the matcher straight into rs_essential_arrsac_batch_device (calibrate -> seeded shuffle ->
+    8192 eight-point hypotheses -> block scoring with a halving candidate set of 1024, SPRT; vslam-sandbox/src/main.rs:
+    112-117, cv-sfm/src/lib.rs:1385-1412), nothing leaves the device.  value = verified frame pairs per second of the
+    whole pipeline; a sample of scenes from different micro-batch positions is held to oracle/arrsac_oracle.c."""
+    from cv_amd.ransac import EssentialConsensus
+    from oracle import oracle as O
+    cam = (1000.0, 1000.0, W / 2.0, H / 2.0, 0.0, None)     # a pinhole camera for the synthetic frames
+    n_hyp, thr = 8192, 1e-7                                  # initialization_hypotheses, two_view_consensus_threshold
+    kw = dict(block_size=args.verify_block, init_blocks=1, max_candidates=1024, halve=True, sprt=True)
+    cons = EssentialConsensus(CAP, n_hyp)
+    cons.reserve(MB + 1)
+    prm = cons.make_params(thr, n_hypotheses=n_hyp, seed=0, **kw)
+    c = cons.camera(cam)
+    rs_stream = torch.cuda.ExternalStream(cons.stream(), device=dev)
+    z = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=dev) for _ in range(2)]
+    pose2, best2, inl2, ninl2 = z((NF + 2, 12), torch.float64), z((NF + 2,), torch.int32), z((NF + 2, CAP), torch.int32), z((NF + 2,), torch.int32)
+    stats2 = z((NF + 2, 32), torch.uint8)
+    verify_done = [torch.cuda.Event(), torch.cuda.Event()]
+    calls = {}
+
+    def enqueue(p, m0, js, prev_js):
+        cons.model_inliers_batch_device(kps2[p].data_ptr(), kps2[p].data_ptr(), CAP, js, prev_js, pairs2[p][m0:].data_ptr(),
+                                        npairs2[p][m0:].data_ptr(), c, c, prm, pose2[p][m0:].data_ptr(), best2[p][m0:].data_ptr(),
+                                        inl2[p][m0:].data_ptr(), ninl2[p][m0:].data_ptr(), stats2[p][m0:].data_ptr(),
+                                        shuffle=True, stream_to_wait=hm_stream.cuda_stream)
+        calls[(p, m0)] = (list(js), list(prev_js))
+        if m0 + MB >= NF:
+            verify_done[p].record(rs_stream)
+            if p == 1:
+                verify["armed"] = True          # both events have been recorded once
+    barrier()
+    verify["done"] = verify_done
+    verify["on"] = enqueue
+    step(); step()                                  # warm-up: both output sets
+    cons.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.verify_steps):
+        step()
+    cons.sync()
+    barrier()
+    dt = (time.perf_counter() - t0) / args.verify_steps
+    verify["on"] = None
+    last = (step_no[0] - 1) & 1
+    kps, pairs, npairs = kps2[last], pairs2[last], npairs2[last]
+    hbest = best2[last].cpu().numpy().view(np.uint32); hninl = ninl2[last].cpu().numpy().view(np.uint32)
+    hst = stats2[last].cpu().numpy().view(np.dtype([("poses", "<u4"), ("survivors", "<u4"), ("blocks", "<u4"), ("reserved", "<u4"),
+                                                      ("evaluated", "<u8"), ("exhaustive", "<u8")])).reshape(-1)
+    hn = npairs.cpu().numpy()
+    # parity: scenes spread over the micro-batches of the last step (first, last, odd positions)
+    slots = []
+    for m0 in range(0, NF, MB):
+        js, prev_js = calls[(last, m0)]
+        per = max(1, args.verify_check // max(1, NF // MB))
+        q = sorted({0, len(js) - 1} | {min(len(js) - 1, (k * len(js) // per) | 1) for k in range(per)})
+        slots += [(m0, qq, js[qq], prev_js[qq]) for qq in q if qq < len(js)]
+    slots = slots if args.verify_check else []
+    bad, detail = 0, []
+    t0 = time.perf_counter()
+    for m0, q, ja, jb in slots:
+        n = int(hn[m0 + q])
+        ka = kps[ja].cpu().numpy().view(_lib.KP_DTYPE).reshape(-1)
+        kb = kps[jb].cpu().numpy().view(_lib.KP_DTYPE).reshape(-1)
+        pr = pairs[m0 + q, :n].cpu().numpy().astype(np.uint32)
+        w = O.arrsac_pairs(ka, kb, pr, cam, cam, thr, n_hyp, scene=q, shuffle=True, seed=0, **kw)
+        g_inl = inl2[last][m0 + q, :hninl[m0 + q]].cpu().numpy().view(np.uint32)
+        g_pose = pose2[last][m0 + q].cpu().numpy()
+        ok = (hbest[m0 + q] == w["best_id"] and np.array_equal(g_inl, w["inliers"])
+              and (w["best_id"] == 0xFFFFFFFF or g_pose.tobytes() == w["pose"].tobytes()))
+        if not ok:
+            bad += 1
+            detail.append(f"pair ({ja},{jb}): id {int(hbest[m0 + q])} vs {w['best_id']}, inliers {len(g_inl)} vs {len(w['inliers'])}")
+    cpu_s = time.perf_counter() - t0
+    valid = hn[:NF] >= 8
+    out = {"workload": f"configs[1] batch ({NF} frames of 1920x1080 per step) -> extract -> symmetric better-by-24 match of consecutive "
+                       f"frames -> two-view ARRSAC of every pair on the device ({n_hyp} eight-point hypotheses, threshold {thr:g}, "
+                       f"{kw['block_size']}-match blocks, candidates 1024 halving per block, SPRT, seeded shuffle)",
+           "verified_pairs_per_s": round(NF / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.verify_steps,
+           "mean_matches_per_pair": round(float(hn[:NF].mean()), 1),
+           "mean_inliers_per_pair": round(float(hninl[:NF].mean()), 1),
+           "pairs_with_a_model": int((hbest[:NF] != 0xFFFFFFFF).sum()),
+           "residuals_evaluated_frac": round(float(hst["evaluated"][:NF][valid].sum()) / max(1.0, float(hst["exhaustive"][:NF][valid].sum())), 5),
+           "parity": {"scenes_checked": len(slots), "mismatches": bad, "detail": detail[:4], "cpu_s_per_scene": round(cpu_s / max(1, len(slots)), 2),
+                      "what": "winner id, pose bits and inlier list of scenes taken from the first / last / odd positions of "
+                              "the last step's micro-batches vs oracle/arrsac_oracle.c (orc_arrsac_pairs) on the GPU's own "
+                              "keypoints and pair lists"}}
+    cons.close()
     return out
 
 

@@ -214,24 +214,47 @@ __device__ __forceinline__ bool rs_eight_point_poses(const double* __restrict__ 
 }
 
 // CameraToCamera::residual for one (pose, match) — cv-core/src/pose.rs:249-295.
+// The design matrix is sum over the two views of (P - b b^T P)^T (P - b b^T P).  The oracle evaluates both views with
+// the generic expression; for the first view P = [I | 0], whose zeros and ones make most of that arithmetic vacuous:
+//   term(r,c) = delta_rc - a_r a_c (c < 3), +0 (c = 3)  — (x*1 = x, sums of signed zeros start from +0, and
+//   0 - (+-0) = +0 either way), so its contribution is the 3 x 3 block sum_k term(k,r) term(k,c) and +0 elsewhere.
+// Dropping the leading "0.0 +" of that block's sums cannot change the final entry: it could only turn a -0 partial
+// sum into +0, and the second view's sum — which keeps its own leading +0 and is therefore never -0 — is added on top
+// (x + s1 is the same for x = +-0).  Only the upper triangle is built: akz_rm_jacobi4_sym reads nothing else.
 __device__ double rs_residual(const double* __restrict__ pose, const double* a, const double* b)
 {
     double design[16], V[16];
-    for (int i = 0; i < 16; ++i) design[i] = 0.0;
-    for (int view = 0; view < 2; ++view) {
-        double P[12];
-        for (int i = 0; i < 12; ++i) P[i] = view == 0 ? ((i == 0 || i == 5 || i == 10) ? 1.0 : 0.0) : pose[i];
-        const double* br = view == 0 ? a : b;
-        double term[12];
+    {
+        double t0[9];
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t0[r * 3 + c] = (r == c ? 1.0 : 0.0) - a[r] * a[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = r; c < 3; ++c)
+                design[r * 4 + c] = (t0[0 * 3 + r] * t0[0 * 3 + c] + t0[1 * 3 + r] * t0[1 * 3 + c]) + t0[2 * 3 + r] * t0[2 * 3 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) design[r * 4 + 3] = 0.0;
+    }
+    {
+        double term[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double s = 0.0;
-                for (int k = 0; k < 3; ++k) s += (br[r] * br[k]) * P[k * 4 + c];
-                term[r * 4 + c] = P[r * 4 + c] - s;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += (b[r] * b[k]) * pose[k * 4 + c];
+                term[r * 4 + c] = pose[r * 4 + c] - s;
             }
+#pragma unroll
         for (int r = 0; r < 4; ++r)
-            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int c = r; c < 4; ++c) {
                 double s = 0.0;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) s += term[k * 4 + r] * term[k * 4 + c];
                 design[r * 4 + c] += s;
             }
