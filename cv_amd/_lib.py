@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
 ]
@@ -218,6 +218,7 @@ def lib():
     L.rs_stream.restype = vp
     L.rs_stream.argtypes = [vp]
     L.rs_debug_scene.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
+    L.rs_debug_residuals.argtypes = [vp, vp, u32, vp, vp, u32, i32, vp]
     L.akz_timing_enable.argtypes = [vp, i32]
     L.akz_timing_reset.argtypes = [vp]
     L.akz_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -221,7 +221,22 @@ __device__ __forceinline__ bool rs_eight_point_poses(const double* __restrict__ 
 // Dropping the leading "0.0 +" of that block's sums cannot change the final entry: it could only turn a -0 partial
 // sum into +0, and the second view's sum — which keeps its own leading +0 and is therefore never -0 — is added on top
 // (x + s1 is the same for x = +-0).  Only the upper triangle is built: akz_rm_jacobi4_sym reads nothing else.
-__device__ double rs_residual(const double* __restrict__ pose, const double* a, const double* b)
+//
+// The mirrored pose comes for free.  possible_unscaled_poses returns (t,R1), (t,R2), (-t,R1), (-t,R2): poses p and
+// p + 2 differ in the sign of t only.  With S = diag(1,1,1,-1) the design matrix of [R | -t] is S D S entry by entry
+// (negation commutes with every rounding), the Jacobi iteration on it is the mirror image of the one on D — same
+// h, same c, t and s negated in the rotations that involve index 3, same sweeps — and its eigenvectors are S V S.
+// The normalised triangulated point of the mirrored pose is therefore (-x, -y, -z, w) / |xyz| where the pose's own
+// is (x, y, z, w) / |xyz|, its image in the second camera is the negated one, and
+//     residual(-t) = 0.5 (1 + a.p + 1 + b.q)      next to      residual(t) = 0.5 (1 - a.p + 1 - b.q).
+// Exactness: every mirrored quantity is the exact negation of its counterpart or a zero of either sign, and a zero's
+// sign can reach a result through one place only — signbit(p[3]) when the eigenvector's last component is exactly
+// zero.  Those lanes (a point exactly at infinity) evaluate the mirrored pose directly in a second pass of the same
+// code; for all others the two residuals of a pair cost one eigen-decomposition.
+// (NOT force-inlined: with always_inline the sweep loop of the eigen-solver is optimised after inlining into the kernels'
+// own loops and comes out with twice the registers — 249 instead of 122 VGPRs — and a third more instructions)
+__device__ void rs_residual_core(const double* __restrict__ pose, double tsign, const double* a, const double* b,
+                                                 double* res_out, double* res_mirror, double* w_raw)
 {
     double design[16], V[16];
     {
@@ -238,6 +253,13 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) design[r * 4 + 3] = 0.0;
     }
+    double P[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[r * 4 + c] = pose[r * 4 + c];
+        P[r * 4 + 3] = tsign * pose[r * 4 + 3];      // tsign = +-1: exact
+    }
     {
         double term[12];
 #pragma unroll
@@ -246,8 +268,8 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
             for (int c = 0; c < 4; ++c) {
                 double s = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s += (b[r] * b[k]) * pose[k * 4 + c];
-                term[r * 4 + c] = pose[r * 4 + c] - s;
+                for (int k = 0; k < 3; ++k) s += (b[r] * b[k]) * P[k * 4 + c];
+                term[r * 4 + c] = P[r * 4 + c] - s;
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -272,24 +294,53 @@ __device__ double rs_residual(const double* __restrict__ pose, const double* a, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = take ? V[r * 4 + i] : p[r];
     }
+    *w_raw = p[3];
     if (__builtin_signbit(p[3]))
         for (int i = 0; i < 4; ++i) p[i] = -p[i];
     double nrm = AKZ_RM_SQRT(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
     for (int i = 0; i < 4; ++i) p[i] = p[i] / nrm;
-    for (int i = 0; i < 4; ++i)
-        if (!finite_d(p[i])) return 2.0;
+    bool fin = true;
+    for (int i = 0; i < 4; ++i) fin = fin && finite_d(p[i]);
     double q[4];
     for (int r = 0; r < 3; ++r)
-        q[r] = ((pose[r * 4 + 0] * p[0] + pose[r * 4 + 1] * p[1]) + pose[r * 4 + 2] * p[2]) + pose[r * 4 + 3] * p[3];
+        q[r] = ((P[r * 4 + 0] * p[0] + P[r * 4 + 1] * p[1]) + P[r * 4 + 2] * p[2]) + P[r * 4 + 3] * p[3];
     q[3] = p[3];
     if (__builtin_signbit(q[3]))
         for (int i = 0; i < 4; ++i) q[i] = -q[i];
     double qn = AKZ_RM_SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
     for (int i = 0; i < 4; ++i) q[i] = q[i] / qn;
-    double ad = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
-    double bd = (b[0] * q[0] + b[1] * q[1]) + b[2] * q[2];
-    double res = 0.5 * (1.0 - ad + 1.0 - bd);
-    return res == res ? res : 2.0;
+    const double ad = (a[0] * p[0] + a[1] * p[1]) + a[2] * p[2];
+    const double bd = (b[0] * q[0] + b[1] * q[1]) + b[2] * q[2];
+    const double res = 0.5 * (1.0 - ad + 1.0 - bd);
+    const double adm = -ad, bdm = -bd;
+    const double resm = 0.5 * (1.0 - adm + 1.0 - bdm);
+    *res_out = (fin && res == res) ? res : 2.0;
+    *res_mirror = (fin && resm == resm) ? resm : 2.0;
+}
+
+__device__ double rs_residual(const double* __restrict__ pose, const double* a, const double* b)
+{
+    double r, rm, w;
+    rs_residual_core(pose, 1.0, a, b, &r, &rm, &w);
+    return r;
+}
+
+// residuals of [R | t] (r0) and [R | -t] (r1) — poses p and p + 2 of a hypothesis — from one eigen-decomposition
+__device__ void rs_residual_pair(const double* __restrict__ pose, const double* a, const double* b, double* r0, double* r1)
+{
+    double tsign = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double r, rm, w;
+        rs_residual_core(pose, tsign, a, b, &r, &rm, &w);
+        if (pass == 0) {
+            *r0 = r;
+            *r1 = rm;
+            if (w != 0.0) break;       // (a NaN component is no zero either: both residuals are 2.0 then)
+            tsign = -1.0;              // the eigenvector's last component is exactly zero: the mirrored pose directly
+        } else {
+            *r1 = r;
+        }
+    }
 }
 
 // ---- the scene arena as the kernels see it ---------------------------------------------------------------------
@@ -321,25 +372,32 @@ struct RsB {
 };
 
 // ---- exhaustive scoring of caller-provided samples (rs_essential_batch / rs_p3p_batch: one scene, slot 0) --------
-// grid: (match blocks, pose id = hyp*4 + p).  Inlier count per pose by ballot + one atomic per wave.
+// grid: (match blocks, 2 hyp + which).  A block scores poses 4 hyp + which and 4 hyp + which + 2 — [R | t] and
+// [R | -t] — together (rs_residual_pair).  Inlier count per pose by ballot + one atomic per wave.
 __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba, const double* __restrict__ bb,
                                                   uint32_t n, const double* __restrict__ poses,
                                                   const uint32_t* __restrict__ ok, double thresh,
                                                   uint32_t* __restrict__ counts)
 {
-    const uint32_t pid = blockIdx.y;
+    const uint32_t pid = (blockIdx.y >> 1) * 4u + (blockIdx.y & 1u);
     if (!ok[pid]) return;
     const uint32_t m = blockIdx.x * 256 + threadIdx.x;
-    bool inl = false;
+    bool inl0 = false, inl1 = false;
     if (m < n) {
         double pose[12];
         for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
         double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
         double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-        inl = rs_residual(pose, a, b) < thresh;
+        double r0, r1;
+        rs_residual_pair(pose, a, b, &r0, &r1);
+        inl0 = r0 < thresh;
+        inl1 = r1 < thresh;
     }
-    unsigned long long bal = __ballot(inl);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
+    const unsigned long long bal0 = __ballot(inl0), bal1 = __ballot(inl1);
+    if ((threadIdx.x & 63) == 0) {
+        if (bal0) atomicAdd(&counts[pid], (uint32_t)__popcll(bal0));
+        if (bal1) atomicAdd(&counts[pid + 2], (uint32_t)__popcll(bal1));
+    }
 }
 
 __global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ bearings, const double* __restrict__ world,
@@ -574,6 +632,54 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
         cnt += (uint32_t)__popcll(__ballot(inl) & gmask);
     }
     if (live && j == 0 && cnt) atomicAdd(&B.counts[B.p4(s) + pid], cnt);
+}
+
+// The first block of a call: nothing has been retired yet, so the live list is every valid pose and the four poses of
+// a hypothesis are all in it.  Units of work are (hypothesis, R1 | R2): 2^lg lanes score [R | t] and [R | -t] of
+// the unit against one match each, one eigen-decomposition per lane for the two residuals (rs_residual_pair) — half
+// the arithmetic of scoring the four poses one by one, which is three quarters of a micro-batch's verification time.
+__global__ __launch_bounds__(256) void k_rsb_score_first(RsB B, uint32_t m_hi, uint32_t lg, uint32_t n_hyp, double thresh)
+{
+    const uint32_t s = blockIdx.z;
+    const uint32_t n = B.n[s];
+    const uint32_t hi = m_hi < n ? m_hi : n;
+    if (hi == 0) return;
+    const uint32_t G = 1u << lg, lane = threadIdx.x & 63u, g = lane >> lg, j = lane & (G - 1u);
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t nal = B.nalive[s];
+    if (wave == 0 && lane == 0 && blockIdx.y == 0 && nal) atomicAdd(&B.neval[s], (unsigned long long)nal * (unsigned long long)hi);
+    const uint32_t unit0 = wave << (6u - lg);
+    if (unit0 >= 2u * n_hyp) return;
+    const uint32_t unit = unit0 + g;
+    const uint32_t pid = (unit >> 1) * 4u + (unit & 1u);
+    const bool live = unit < 2u * n_hyp && B.ok[B.p4(s) + pid] != 0;
+    double pose[12];
+    const double* pp = B.sposes(s) + (size_t)pid * 12;
+    for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
+    const double* ba = B.sa(s);
+    const double* bb = B.sb(s);
+    const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
+    const unsigned long long gmask = (lg == 6u ? ~0ull : ((1ull << G) - 1ull)) << (g << lg);
+    uint32_t cnt0 = 0, cnt1 = 0;
+    for (uint32_t m0 = blockIdx.y * G; m0 < hi; m0 += gridDim.y * G) {
+        const uint32_t pos = m0 + j;
+        bool inl0 = false, inl1 = false;
+        if (live && pos < hi) {
+            const uint32_t m = order ? order[pos] : pos;
+            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+            double r0, r1;
+            rs_residual_pair(pose, a, b, &r0, &r1);
+            inl0 = r0 < thresh;
+            inl1 = r1 < thresh;
+        }
+        cnt0 += (uint32_t)__popcll(__ballot(inl0) & gmask);
+        cnt1 += (uint32_t)__popcll(__ballot(inl1) & gmask);
+    }
+    if (live && j == 0) {
+        if (cnt0) atomicAdd(&B.counts[B.p4(s) + pid], cnt0);
+        if (cnt1) atomicAdd(&B.counts[B.p4(s) + pid + 2], cnt1);
+    }
 }
 
 struct RsPrune {
@@ -985,6 +1091,26 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
     if (threadIdx.x == 0) *n_inliers = base;
 }
 
+// parity tap: the residual of every (pose, match), directly or through the (t, -t) pair path
+__global__ __launch_bounds__(256) void k_rs_debug_residuals(const double* __restrict__ poses, uint32_t n_pose, const double* __restrict__ ba,
+                                                            const double* __restrict__ bb, uint32_t n, int paired, double* __restrict__ out)
+{
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x, pid = blockIdx.y;
+    if (m >= n) return;
+    double pose[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+    double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+    if (paired) {
+        double r0, r1;
+        rs_residual_pair(pose, a, b, &r0, &r1);
+        out[((size_t)pid * 2 + 0) * n + m] = r0;
+        out[((size_t)pid * 2 + 1) * n + m] = r1;
+    } else {
+        out[(size_t)pid * n + m] = rs_residual(pose, a, b);
+    }
+}
+
 }  // namespace
 
 struct rs_ctx {
@@ -1206,12 +1332,12 @@ static int32_t exhaustive_run(rs_ctx* c, const double* in_a, const double* in_b,
     // grid.y is limited to 65535: score the poses in slabs
     const uint32_t n_pose = n_hyp * 4;
     for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
-        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;
+        uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;     // (65532: whole hypotheses per slab)
         if (P3P)
             hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
                                c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
-        else
-            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
+        else    // two poses per block: [R | t] and [R | -t] share their eigen-decomposition
+            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np / 2), dim3(256), 0, s, c->d_a, c->d_b, n,
                                c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
         AKZ_LAUNCH_CHECK();
     }
@@ -1308,11 +1434,25 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     };
+    auto score_first = [&](uint32_t m_hi) -> int32_t {     // block 0 of the two-view consensus: poses in (t, -t) pairs
+        uint32_t lg = 6;
+        if (m_hi < 64) {
+            lg = 0;
+            while ((1u << lg) < m_hi) ++lg;
+        }
+        const uint32_t G = 1u << lg, per_wave = 64u >> lg;
+        const uint32_t chunks = (m_hi + G - 1) / G, gy = chunks < 16 ? chunks : 16;
+        const uint32_t waves = (2 * n_hyp + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL(k_rsb_score_first, dim3((waves + 3) / 4, gy, S), dim3(256), 0, s, B, m_hi, lg, n_hyp, prm->threshold);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    };
     for (uint32_t m_lo = 0; m_lo < n_max;) {
         // without pruning there is nothing to decide between blocks: one block = all matches
         const uint32_t bs = prune ? prm->block_size : n_max;
         const uint32_t m_hi = m_lo + bs < n_max ? m_lo + bs : n_max;
-        AKZ_TRY(score(m_lo, m_hi, live_bound, 0u));
+        if (!P3P && m_lo == 0) AKZ_TRY(score_first(m_hi));
+        else AKZ_TRY(score(m_lo, m_hi, live_bound, 0u));
         ++blocks;
         m_lo = m_hi;
         if (prune && m_lo < n_max) {
@@ -1557,6 +1697,32 @@ extern "C" int32_t rs_debug_poses(rs_ctx* c, double* poses, uint32_t* ok, uint32
         AKZ_HIP(hipStreamSynchronize(c->stream));
         AKZ_HIP(hipMemcpy(poses, c->d_poses, sizeof(double) * 48 * (size_t)n_hyp, hipMemcpyDeviceToHost));
         AKZ_HIP(hipMemcpy(ok, c->d_ok, sizeof(uint32_t) * 4 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    });
+}
+
+// parity tap: CameraToCamera::residual of every (pose, match) as the device evaluates it (host buffers in and out)
+extern "C" int32_t rs_debug_residuals(rs_ctx* c, const double* poses, uint32_t n_pose, const double* bearings_a, const double* bearings_b,
+                                      uint32_t n, int32_t paired, double* out)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !poses || !bearings_a || !bearings_b || !out || n_pose == 0 || n == 0 || n_pose > 65535u) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        double *d_p = nullptr, *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+        const size_t no = (size_t)n_pose * n * (paired ? 2 : 1);
+        AKZ_HIP(hipMalloc(&d_p, sizeof(double) * 12 * n_pose));
+        AKZ_HIP(hipMalloc(&d_a, sizeof(double) * 3 * n));
+        AKZ_HIP(hipMalloc(&d_b, sizeof(double) * 3 * n));
+        AKZ_HIP(hipMalloc(&d_o, sizeof(double) * no));
+        AKZ_HIP(hipMemcpy(d_p, poses, sizeof(double) * 12 * n_pose, hipMemcpyHostToDevice));
+        AKZ_HIP(hipMemcpy(d_a, bearings_a, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+        AKZ_HIP(hipMemcpy(d_b, bearings_b, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_rs_debug_residuals, dim3((n + 255) / 256, n_pose), dim3(256), 0, c->stream, d_p, n_pose, d_a, d_b, n,
+                           paired ? 1 : 0, d_o);
+        AKZ_LAUNCH_CHECK();
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(out, d_o, sizeof(double) * no, hipMemcpyDeviceToHost));
+        hipFree(d_p); hipFree(d_a); hipFree(d_b); hipFree(d_o);
         return AKZ_OK;
     });
 }

@@ -180,6 +180,16 @@ class EssentialConsensus:
               "rs_debug_scene")
         return a[:n.value], b[:n.value], o[:n.value]
 
+    def residuals(self, poses, bearings_a, bearings_b, paired=False):
+        """CameraToCamera::residual of every (pose, match) as the device evaluates it (rs_debug_residuals): [n_pose, n],
+        or [n_pose, 2, n] (the pose and its mirror [R | -t]) with paired=True."""
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        a = np.ascontiguousarray(bearings_a, np.float64); b = np.ascontiguousarray(bearings_b, np.float64)
+        out = np.zeros((len(P), 2, len(a)) if paired else (len(P), len(a)), np.float64)
+        check(_lib.lib().rs_debug_residuals(self._h, P.ctypes.data, len(P), a.ctypes.data, b.ctypes.data, len(a), int(paired),
+                                            out.ctypes.data), "rs_debug_residuals")
+        return out
+
     def counts(self, n_hyp):
         out = np.zeros((n_hyp, 4), np.uint32)
         check(_lib.lib().rs_debug_counts(self._h, out.ctypes.data, out.size), "rs_debug_counts")

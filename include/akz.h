@@ -402,6 +402,13 @@ int32_t rs_debug_counts(rs_ctx* ctx, uint32_t* counts, uint32_t cap);
  * lambda-twist/src/lib.rs:330-347) */
 int32_t rs_debug_poses(rs_ctx* ctx, double* poses, uint32_t* ok, uint32_t n_hyp);
 
+/* parity tap: CameraToCamera::residual (cv-core/src/pose.rs:249-295) of every (pose, match) as the device evaluates it.
+ * poses [n_pose][12] row-major [R | t], bearings [n][3], host buffers.  paired == 0: out [n_pose][n].  paired != 0: out
+ * [n_pose][2][n] — the pose and its mirror image [R | -t] (poses p and p + 2 of a hypothesis) through the path that
+ * shares one eigen-decomposition between the two. */
+int32_t rs_debug_residuals(rs_ctx* ctx, const double* poses, uint32_t n_pose, const double* bearings_a, const double* bearings_b,
+                           uint32_t n, int32_t paired, double* out);
+
 /* ---- two-view verification of a whole micro-batch, device-resident ----
  * What cv-sfm does for every frame pair the matcher produced (cv-sfm/src/lib.rs:1385-1412): shuffle the matches,
  * map them to calibrated bearing pairs (match_ix_kps; CameraIntrinsics::calibrate, cv-pinhole/src/lib.rs:108-117),
