@@ -43,6 +43,7 @@ W, H = 1920, 1080
 FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_TAG = "r03"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
 FED_BYTES_PER_PIXEL_STEP = 12.0
 CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage
 FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
@@ -73,6 +74,9 @@ KERNEL_FAMILIES = [
     ("k_fed_pair<8> (calculate_step, 8 steps per launch)", 21, 12.0),
     ("k_contrast_pair (contrast factor passes)", 10, 1.0),
 ]
+# the keypoint-stage kernel with the most GPU time: gathers, no per-pixel byte model — its roofline entry takes the PMC
+# bytes themselves as the numerator (what it really moved per launch)
+ORIENT_DESCRIBE = ("k_orient_describe (main orientation + M-LDB descriptor, one wave per keypoint)", 25)
 MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
 MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4/FP6 MFMA (MI355X_MICROARCH.md; AMD's 20 PF headline is 2:1 sparse)
 
@@ -130,7 +134,15 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
     ap.add_argument("--micro-batch", type=int, default=256, help="frames per library call (measured: 64 -> 6794, 128 -> 6912, 256 -> 6997 frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="A/B: timed region without the per-launch start/stop events "
+                    "(no roofline objects)")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the isolated scale-space pass (rocprof runs whose kernel "
+                    "statistics are to be compared with this line's roofline: every launch is then the pipelined workload's)")
+    ap.add_argument("--pmc-run", action="store_true", help="counter passes: exactly --steps steps of the pipeline and nothing "
+                    "else on the GPU (no instrumented pass, no isolated pass, no CPU baseline, no extras)")
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--parity-pairs", type=int, default=5, help="frame pairs from other batch positions held to the oracle "
+                    "(2 oracle extractions each, ~1 s per 1080p frame)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="one buffer set in the library (AKZ_OPT_NO_PIPELINE): "
                     "consecutive calls do not overlap; for counter passes and serial phase profiles")
@@ -150,6 +162,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
     ap.add_argument("--dump-matches", default=None, help="write per-global-frame keypoint/match counts to this .npy")
     args = ap.parse_args()
+    if args.pmc_run:
+        args.no_cpu_baseline = args.no_extras = args.no_isolated = True
 
     import torch
     import torch.distributed as dist
@@ -283,46 +297,53 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # the timed region runs without the per-kernel event brackets (about 250 event records per call would be
-    # part of the measurement); one more, untimed, instrumented step afterwards gives the in-pipeline breakdown
-    ctx.timing_enable(False)
+    # The timed region runs with the KERNEL timers on (akz_timing_enable 2, hm_timing_enable): every timed launch carries
+    # its own start / stop events (hipExtLaunchKernel — the dispatch's begin and end timestamps, what rocprofv3's kernel
+    # trace reports), no extra packet enters a stream; --no-kernel-timers is the A/B switch.  The PHASE timers are event
+    # brackets on the streams and stay off here: an untimed instrumented pass of two more steps reads them.
+    kt = not args.no_kernel_timers
+    ctx.timing_enable(2 if kt else 0)
+    ctx.timing_reset()
     _lib.check(L.hm_timing_get(matcher.handle, None, None, 1), "hm_timing_get")
-    _lib.check(L.hm_timing_enable(matcher.handle, 1), "hm_timing_enable")
+    _lib.check(L.hm_timing_enable(matcher.handle, 1 if kt else 0), "hm_timing_enable")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    step()
-    step()                          # two steps: both output sets, so `last` below still names the newest one
-    barrier()
-    INSTR_STEPS = 2
-    last = (step_no[0] - 1) & 1
-    kps, descs, counts, pairs, npairs = kps2[last], descs2[last], counts2[last], pairs2[last], npairs2[last]
     knn_ms, knn_launches = C.c_double(), C.c_uint64()
     _lib.check(L.hm_timing_get(matcher.handle, C.byref(knn_ms), C.byref(knn_launches), 1), "hm_timing_get")
     _lib.check(L.hm_timing_enable(matcher.handle, 0), "hm_timing_enable")
+    fam_pipe = read_families(ctx)                 # kernel families over the timed region (all streams busy)
+    desc_k_ms, desc_k_launches, _ = ctx.timing_get(25)
+    INSTR_STEPS = 0 if args.pmc_run else 2
+    fed_ms = ss_ms = all_ms = desc_ms = refine_ms = 0.0
+    if INSTR_STEPS:
+        ctx.timing_enable(1)
+        ctx.timing_reset()
+        step()
+        step()                          # two steps: both output sets, so `last` below still names the newest one
+        barrier()
+        fed_ms, _, _ = ctx.timing_get(0)
+        ss_ms, _, _ = ctx.timing_get(1)
+        all_ms, _, _ = ctx.timing_get(2)
+        desc_ms, _, _ = ctx.timing_get(11)
+        refine_ms, _, _ = ctx.timing_get(12)
+    last = (step_no[0] - 1) & 1
+    kps, descs, counts, pairs, npairs = kps2[last], descs2[last], counts2[last], pairs2[last], npairs2[last]
     _lib.check(L.akz_sync(ctx.handle), "akz_sync")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fam_pipe = read_families(ctx)                 # kernel families of the instrumented pipelined pass (all streams busy)
-    fed_ms, fed_launches, fed_units = ctx.timing_get(0)
-    ss_ms, _, _ = ctx.timing_get(1)
-    all_ms, _, _ = ctx.timing_get(2)
-    desc_ms, _, _ = ctx.timing_get(11)
-    refine_ms, _, _ = ctx.timing_get(12)
     ctx.timing_enable(False)
 
     # Isolated pass: the same scale-space launches with nothing else on the GPU (in the timed region above they
     # share the chip with the keypoint and matcher streams of neighbouring micro-batches).
     fam_iso, iso_fps = None, None
-    if rank == 0:
+    if rank == 0 and not args.no_isolated and not args.pmc_run:
         torch.cuda.synchronize()
-        ctx.timing_enable(True)
+        ctx.timing_enable(1)
         ctx.timing_reset()
         for _ in range(3):
             _lib.check(L.akz_scale_space_device(ctx.handle, frames[:MB].data_ptr(), 0, MB, W, H, None), "scale_space")
@@ -380,7 +401,8 @@ def main():
     if rank == 0:
         total_frames = NF * world * args.steps
         fps = total_frames / elapsed
-        tops = roofline_entries(fam_pipe, fam_iso, MB)
+        tops = roofline_entries(fam_pipe, fam_iso, MB, args.steps)
+        traffic = pipeline_traffic(MB, NF)
         out = {
             "metric": "frames/sec AKAZE detect+describe+BF-Hamming-match, 1080p",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -394,12 +416,14 @@ def main():
                        "library_options": okw or "defaults"},
             "roofline": tops[0] if tops else None,
             "roofline_top": tops[:4],
-            "phase_ms_per_step": {"fed": round(fed_ms / INSTR_STEPS, 2), "scale_space": round(ss_ms / INSTR_STEPS, 2),
-                                  "extract": round(all_ms / INSTR_STEPS, 2), "describe": round(desc_ms / INSTR_STEPS, 2),
-                                  "refine": round(refine_ms / INSTR_STEPS, 2),
-                                  "note": "HIP-event brackets of an instrumented pass of 2 steps run after the timed "
-                                          "region (same pipelined workload)"},
         }
+        if INSTR_STEPS:
+            out["phase_ms_per_step"] = {"fed": round(fed_ms / INSTR_STEPS, 2), "scale_space": round(ss_ms / INSTR_STEPS, 2),
+                                        "extract": round(all_ms / INSTR_STEPS, 2), "describe": round(desc_ms / INSTR_STEPS, 2),
+                                        "refine": round(refine_ms / INSTR_STEPS, 2),
+                                        "note": "HIP-event brackets on the library's streams (wall time of a phase, waits for the "
+                                                "other streams included) in an instrumented pass of 2 steps run after the timed "
+                                                "region (same pipelined workload)"}
         if iso_fps:
             out["scale_space_isolated"] = {
                 "frames_per_s": round(iso_fps, 1),
@@ -411,7 +435,7 @@ def main():
         if knn_ms.value > 0:
             # the matcher's roofline: 2 directions x nq x nt x 512-bit contractions per frame pair as MACs (2 ops
             # each) over the HIP-event time of the k-NN launches on the matcher's stream
-            pairs_total = NF * (args.steps + INSTR_STEPS)
+            pairs_total = NF * args.steps
             macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
             tops_m = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
             out["roofline_matcher"] = {
@@ -419,9 +443,12 @@ def main():
                 "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4), "traffic": None, "launches": int(knn_launches.value),
                 "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
-                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count, HIP events on the "
-                        "matcher's stream over the timed and the instrumented steps; peak = the dense FP4 MFMA figure "
+                "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count; time = the k-NN "
+                        "launches' own start/stop events over the timed region; peak = the dense FP4 MFMA figure "
                         "of MI355X_MICROARCH.md (~10 PF)"}
+        if traffic:
+            out["hbm_traffic_per_frame"] = traffic
+            out["end_to_end_hbm_frac"] = round(traffic["bytes"] * fps / world / (HBM_PEAK_GBS * 1e9), 4)
         out["device"] = device_probe(torch, dev)
         rc = 0
         if world == 1 and not args.no_cpu_baseline:
@@ -431,6 +458,10 @@ def main():
             # last timed step (default options, micro-batch MB, pipelined) vs what the oracle just computed
             out["parity_checked"] = parity_check(oracle_out, kps, descs, counts, pairs, npairs, MB)
             if out["parity_checked"]["mismatches"]:
+                rc = 1
+            # ... and frame pairs from other positions of the batch (middle, odd, the last one of every micro-batch)
+            out["parity_checked_spread"] = parity_spread(frames, kps, descs, counts, pairs, npairs, NF, MB, args.parity_pairs)
+            if out["parity_checked_spread"]["mismatches"]:
                 rc = 1
             if args.cpu_procs > 0:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(frames, args.cpu_procs)
@@ -458,24 +489,56 @@ def read_families(ctx):
         ms, launches, units = ctx.timing_get(tid)
         if launches:
             fam.append((name, ms, launches, units, bpu))
+    ms, launches, units = ctx.timing_get(ORIENT_DESCRIBE[1])
+    if launches:
+        fam.append((ORIENT_DESCRIBE[0], ms, launches, units, None))
     return fam
 
 
-def roofline_entries(fam_pipe, fam_iso, mb):
-    """Roofline objects of the timed kernel families, most expensive (inside the timed region) first."""
+VALU_ISSUE_PEAK_T = 39.3     # T wave-lane instructions / s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one VALU instruction per
+                             # lane and cycle; = the 78.6 T lane-op/s non-FMA packed-f32 peak of MI355X_MICROARCH.md / 2)
+
+
+def roofline_entries(fam_pipe, fam_iso, mb, steps):
+    """Roofline objects of the timed kernel families, most expensive (inside the timed region) first.  Per family:
+    hbm_frac = algorithmic bytes / kernel time / 8 TB/s; valu_frac = VALU instructions x 64 lanes / kernel time / the VALU
+    issue peak (counters: profiles/, taken at this micro-batch); `bound` names the larger one and `frac` is its value."""
     iso = {f[0]: f for f in (fam_iso or [])}
     pmc = pmc_traffic(mb)
     sq = sq_counters()
     out = []
     for name, ms, launches, units, bpu in sorted(fam_pipe, key=lambda f: -f[1]):
+        if ms <= 0:
+            continue
+        key = name.split(" ")[0]
+        if bpu is None:        # no byte model: the counted bytes of the committed pass are the numerator
+            if not (pmc and key in pmc["kernels"]):
+                continue
+            bpu = pmc["kernels"][key]["hbm_bytes_per_launch"] * launches / max(1, units)
         gbs = units * bpu / (ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(launches),
              "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2),
-             "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_pixel": bpu,
-             "timed": "HIP events around the launches on the library's scale-space stream during an instrumented pass "
-                      "of the same pipelined workload (the keypoint and matcher streams of neighbouring micro-batches "
-                      "share the GPU); gpu_ms covers 2 steps"}
+             "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_unit": round(bpu, 3),
+             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+             "timed": f"the launches' own start/stop events (hipExtLaunchKernel: the dispatch's begin -> end, rocprofv3's "
+                      f"kernel duration) over the {steps} timed steps; the keypoint and matcher streams of neighbouring "
+                      f"micro-batches share the GPU"}
+        if pmc and key in pmc["kernels"]:
+            k = pmc["kernels"][key]
+            e["traffic"] = round(k["hbm_bytes_per_launch"])
+            e["traffic_source"] = {"file": pmc["file"], "micro_batch": pmc["micro_batch"], "launches_counted": k["launches"]}
+            if k.get("valu_insts_per_launch"):
+                lane_ops = k["valu_insts_per_launch"] * 64.0 / (ms * 1e-3 / launches) / 1e12
+                e["valu_frac"] = round(lane_ops / VALU_ISSUE_PEAK_T, 4)
+                e["valu"] = {"achieved": round(lane_ops, 2), "peak": VALU_ISSUE_PEAK_T, "unit": "T lane-instr/s",
+                             "insts_per_launch": round(k["valu_insts_per_launch"]),
+                             "note": "SQ_INSTS_VALU (rocprofv3 --pmc, committed pass at this micro-batch) x 64 lanes / this "
+                                     "run's kernel time; the frame-pair kernels issue packed f32 (2 lane-ops per "
+                                     "instruction), so this is also their fraction of the 78.6 T lane-op/s non-FMA peak"}
+                if e["valu_frac"] > e["hbm_frac"]:
+                    e["bound"] = "valu"
+                    e["frac"] = e["valu_frac"]
         if name in iso:
             _, ims, il, iu, _ = iso[name]
             igbs = iu * bpu / (ims * 1e-3) / 1e9
@@ -486,19 +549,22 @@ def roofline_entries(fam_pipe, fam_iso, mb):
             # time expressed against THOSE bytes, for comparison with round 1's front-end / FED fractions only
             e["replaces"] = {"kernels": "k_level_front2<2,sigma,..> + k_fed_pair<T>", "bytes_per_pixel": 28.0,
                              "equivalent_frac_of_peak": round(gbs * 28.0 / 16.0 / HBM_PEAK_GBS, 4)}
-            e["note"] = ("fused kernel: moves 16 B/pixel where the split pair (k_level_front2 + k_fed_pair) moves 28, and "
-                         "is bound by packed-f32 VALU issue, not by HBM (profiles/: SQ counters); its HBM fraction is "
-                         "reported because the contract asks for it, the time saved shows in `value`")
-        key = name.split(" ")[0]
         if key in sq:
             e["issue_counters"] = sq[key]
-        if pmc and key in pmc["kernels"]:
-            k = pmc["kernels"][key]
-            e["traffic"] = round(k["hbm_bytes_per_launch"])
-            e["traffic_source"] = {"file": pmc["file"], "micro_batch": pmc["micro_batch"],
-                                   "launches_counted": k["launches"]}
         out.append(e)
     return out
+
+
+def pipeline_traffic(mb, nf):
+    """HBM bytes per frame of the WHOLE timed pipeline (scale space + keypoint stage + matcher; the library's kernels
+    only — frame generation and torch fills are not counted) from the committed counter passes of `bench.py --pmc-run`."""
+    pmc = pmc_traffic(mb)
+    if not pmc or not pmc.get("per_frame") or int(pmc.get("frames_per_step", 0)) != int(nf):
+        return None
+    pf = pmc["per_frame"]
+    return {"bytes": round(pf["hbm_bytes"]), "scale_space_bytes": round(pf.get("scale_space_hbm_bytes", 0)),
+            "keypoint_stage_bytes": round(pf.get("keypoint_stage_hbm_bytes", 0)), "matcher_bytes": round(pf.get("matcher_hbm_bytes", 0)),
+            "file": pmc["file"], "source": pmc.get("source_short", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bench.py --pmc-run")}
 
 
 def parity_check(oracle_out, kps, descs, counts, pairs, npairs, mb):
@@ -521,6 +587,40 @@ def parity_check(oracle_out, kps, descs, counts, pairs, npairs, mb):
     return {"frames": n, "pairs": sum(1 for o in oracle_out if o[2] is not None), "mismatches": len(bad),
             "what": "keypoint bytes, descriptor bytes and symmetric match pairs of the cpu_baseline frames: last timed "
                     "step's GPU output (default options, pipelined micro-batches) vs the oracle", "detail": bad[:4]}
+
+
+def parity_spread(frames, kps, descs, counts, pairs, npairs, NF, MB, n_pairs):
+    """Frame pairs (j-1, j) spread over the batch — odd and even positions, the last frame of every micro-batch — the
+    last timed step's GPU keypoints / descriptors / pair list of each against the oracle."""
+    from oracle import oracle as O
+    if n_pairs <= 0 or NF < 8:
+        return {"frames": 0, "pairs": 0, "mismatches": 0}
+    cand = sorted({NF - 1, NF // 2, (NF // 4) | 1, (3 * NF // 4) | 1, NF // 3} | {m0 + MB - 1 for m0 in range(0, NF, MB)})
+    cand = [j for j in cand if j >= 7][:n_pairs]           # (frames 0..5 are the cpu_baseline sample's)
+    orc = O.Akaze(W, H, O.default_config())
+    cnt = counts.cpu().numpy()
+    cache, bad = {}, []
+
+    def ext(j):
+        if j not in cache:
+            cache[j] = orc.extract(frames[j].cpu().numpy())
+            okp, od = cache[j]
+            c = int(cnt[j])
+            if c != len(okp) or kps[j, :min(c, CAP)].cpu().numpy().tobytes() != okp.tobytes() or \
+                    not np.array_equal(descs[j, :min(c, CAP)].cpu().numpy(), od):
+                bad.append(f"frame {j}: keypoints/descriptors ({c} vs {len(okp)})")
+        return cache[j]
+    for j in cand:
+        (_, dp), (_, dj) = ext(j - 1), ext(j)
+        om = O.match(dj, dp, rule=O.RULE_STRICT, param_u=24, symmetric=True).astype(np.uint32)
+        m0 = (j // MB) * MB
+        slot = j - 1 if m0 == 0 else j                      # position of frame j's problem in its micro-batch's list
+        m = int(npairs[slot].item())
+        gp = pairs[slot, :m].cpu().numpy().astype(np.uint32)
+        if m != len(om) or not np.array_equal(gp, om):
+            bad.append(f"pair ({j},{j - 1}): matches ({m} vs {len(om)})")
+    return {"frames": len(cache), "pairs": len(cand), "positions": cand, "mismatches": len(bad), "detail": bad[:4],
+            "what": "as parity_checked, for frame pairs at other positions of the batch"}
 
 
 def extra_match(torch, dev, L, _lib, n_frames):
@@ -574,7 +674,7 @@ def extra_match(torch, dev, L, _lib, n_frames):
     _lib.check(L.hm_timing_get(m.handle, C.byref(ms), C.byref(launches), 1), "timing")
     _lib.check(L.hm_timing_enable(m.handle, 0), "timing")
     # oracle on a sample of the pairs
-    sample = sorted({0, npr // 2, npr - 1})
+    sample = sorted({int(v) for v in np.linspace(0, npr - 1, min(npr, 64))})
     bad = 0
     hd = descs.cpu().numpy()
     for p_ in sample:
@@ -715,7 +815,7 @@ def extra_ransac(n_hyp):
     counts = cons.counts(n_hyp)
     # oracle: the first `sub` hypotheses in full (per-(hypothesis, pose) inlier counts), and the winning hypothesis
     # on its own (pose bits and inlier set)
-    sub = min(256, n_hyp)
+    sub = min(1024, n_hyp)
     t0 = time.perf_counter()
     _, _, _, wcounts = O.essential_batch(a, b, samples[:sub], thr)
     cpu_s = time.perf_counter() - t0
@@ -805,12 +905,13 @@ def pmc_traffic(mb):
     made by tools/pmc_traffic.py: WRITE_SIZE and doubled FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction,
     separate --pmc passes).  Only used when the counters were taken at THIS micro-batch: nothing is rescaled."""
     try:
-        name = "r02_pmc_traffic.json"
+        name = PROFILE_TAG + "_pmc_traffic.json"
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         if int(d["micro_batch"]) != int(mb):
             return None
-        return {"file": "profiles/" + name, "micro_batch": d["micro_batch"], "kernels": d["kernels"]}
+        d["file"] = "profiles/" + name
+        return d
     except Exception:
         return None
 
@@ -823,13 +924,13 @@ def sq_counters():
     try:
         from pmc_traffic import family_key
         out = {}
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.txt")) as f:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq_summary.txt")) as f:
             for line in f.read().splitlines()[1:]:
                 name, rest = line[:52].strip(), line[52:].split()
                 if len(rest) < 8:
                     continue
                 key = family_key(name + ">") if name.count("<") > name.count(">") else family_key(name)
-                out.setdefault(key, {"file": "profiles/r02_pmc_sq_summary.txt", "valu_instructions_per_wave": int(rest[1]),
+                out.setdefault(key, {"file": "profiles/" + PROFILE_TAG + "_pmc_sq_summary.txt", "valu_instructions_per_wave": int(rest[1]),
                                      "valu_busy_pct": int(rest[2]), "lds_busy_pct": int(rest[3]),
                                      "lds_bank_conflict_pct": int(rest[4]), "waves_parked_pct": int(rest[5])})
         return out

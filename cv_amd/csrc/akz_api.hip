@@ -58,17 +58,50 @@ static hipEvent_t timer_event(AkzTimer* t)
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+thread_local akz_ctx* g_akz_timed_ctx = nullptr;
+static bool is_phase_timer(int which)
+{
+    return which == AKZ_T_FED || which == AKZ_T_SCALE_SPACE || which == AKZ_T_EXTRACT || which == AKZ_T_DESCRIBE ||
+           which == AKZ_T_REFINE;
+}
 void akz_timer_begin(akz_ctx* c, int which, hipStream_t s)
 {
     if (!c->timing) return;
     AkzTimer* t = &c->timers[which];
+    if (!is_phase_timer(which)) {          // kernel timer: the launches bring their own events (AKZ_LAUNCH)
+        c->open_kernel_timer = which;
+        g_akz_timed_ctx = c;
+        return;
+    }
+    if (!c->timing_phases) return;
     t->cur_start = timer_event(t);
     if (t->cur_start) hipEventRecord(t->cur_start, s);
+}
+void akz_timer_launch_events(hipEvent_t* start, hipEvent_t* stop)
+{
+    akz_ctx* c = g_akz_timed_ctx;
+    if (!c || c->open_kernel_timer < 0) return;
+    AkzTimer* t = &c->timers[c->open_kernel_timer];
+    hipEvent_t e0 = timer_event(t), e1 = timer_event(t);
+    if (!e0 || !e1) return;
+    t->pending.emplace_back(e0, e1);
+    *start = e0;
+    *stop = e1;
 }
 void akz_timer_end(akz_ctx* c, int which, hipStream_t s, uint64_t launches, uint64_t units, uint64_t units2)
 {
     AkzTimer* t = &c->timers[which];
-    if (!c->timing || !t->cur_start) return;
+    if (!c->timing) return;
+    if (!is_phase_timer(which)) {
+        if (c->open_kernel_timer != which) return;
+        c->open_kernel_timer = -1;
+        g_akz_timed_ctx = nullptr;
+        t->launches += launches;
+        t->units += units;
+        t->units2 += units2;
+        return;
+    }
+    if (!t->cur_start) return;
     hipEvent_t stop = timer_event(t);
     if (!stop) return;
     hipEventRecord(stop, s);
@@ -837,6 +870,9 @@ extern "C" int32_t akz_timing_enable(akz_ctx* c, int32_t on)
     return akz_guard([&]() -> int32_t {
         if (!c) return AKZ_E_INVALID;
         c->timing = on != 0;
+        c->timing_phases = on == 1;         // 2: kernel timers only (cheap enough to stay on inside a timed region)
+        c->open_kernel_timer = -1;
+        g_akz_timed_ctx = nullptr;
         return AKZ_OK;
     });
 }

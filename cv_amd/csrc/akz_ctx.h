@@ -2,6 +2,8 @@
 #pragma once
 #include <utility>
 
+#include <hip/hip_ext.h>
+
 #include "akz_common.h"
 
 // One keypoint work record on the device; identical to akz_keypoint (28 B).
@@ -124,6 +126,8 @@ struct akz_ctx {
 
     // timing (akz_timing_*)
     bool timing = false;
+    bool timing_phases = false;     // phase timers (event brackets) as well as kernel timers
+    int open_kernel_timer = -1;     // AKZ_T_* id of the kernel timer open on the launching thread, -1: none
     AkzTimer timers[AKZ_T_COUNT];   // indexed by the AKZ_T_* ids of include/akz.h
 };
 
@@ -147,6 +151,25 @@ int32_t akz_upload_tables(akz_ctx* c);
 size_t akz_ori_table_bytes();
 size_t akz_desc_table_bytes();
 
-// HIP-event brackets around a group of launches on stream `s` (no-ops unless akz_timing_enable is on)
+// Timing of a group of launches on stream `s` (no-ops unless akz_timing_enable is on).  Two kinds of timer:
+//   phase timers   (AKZ_T_FED, _SCALE_SPACE, _EXTRACT, _DESCRIBE, _REFINE): a HIP-event bracket on the stream — the wall time
+//                  of the phase, waits for the other streams' kernels included;
+//   kernel timers  (every other id): each launch made through AKZ_LAUNCH while the timer is open carries its own start /
+//                  stop events (hipExtLaunchKernel: the dispatch's own begin and end timestamps — what rocprofv3's
+//                  kernel trace reports as the kernel's duration), and the timer accumulates those durations.  A kernel's
+//                  roofline is then the same number whether it is read from bench.py's line or from the committed
+//                  rocprof kernel statistics of the same command.
 void akz_timer_begin(akz_ctx* c, int which, hipStream_t s);
 void akz_timer_end(akz_ctx* c, int which, hipStream_t s, uint64_t launches, uint64_t units, uint64_t units2 = 0);
+extern thread_local akz_ctx* g_akz_timed_ctx;       // a kernel timer of this context is open on this thread
+void akz_timer_launch_events(hipEvent_t* start, hipEvent_t* stop);
+#define AKZ_LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+    do {                                                                                                 \
+        if (g_akz_timed_ctx) {                                                                           \
+            hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                   \
+            akz_timer_launch_events(&ev0_, &ev1_);                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ev0_, ev1_, 0, __VA_ARGS__);       \
+        } else {                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                         \
+        }                                                                                                \
+    } while (0)

@@ -1897,11 +1897,13 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
             }
         }
         AKZ_LAUNCH_CHECK();
-        if (orient_in_desc)
-            hipLaunchKernelGGL(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
-                               (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm,
-                               S.d_desc_tmp, S.d_flag_d, c->d_err);
-        else
+        if (orient_in_desc) {
+            akz_timer_begin(c, AKZ_T_ORIENT_DESCRIBE_K, s);
+            AKZ_LAUNCH(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
+                       (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm,
+                       S.d_desc_tmp, S.d_flag_d, c->d_err);
+            akz_timer_end(c, AKZ_T_ORIENT_DESCRIBE_K, s, 1, (uint64_t)n);
+        } else
             hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T,
                                (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm, S.d_desc_tmp, S.d_flag_d);
     } else {
@@ -1916,4 +1918,34 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     AKZ_HIP(hipEventRecord(c->ev_kp_done[c->cur], c->stream_kp));
     c->kp_pending[c->cur] = true;
     return AKZ_OK;
+}
+
+// ---- parity tap: the transcendentals of the orientation / descriptor kernels as the DEVICE evaluates them ----
+// (compute_main_orientation's atan2, scale_space_extrema.rs:242; get_mldb_descriptor's cos / sin, descriptors.rs:70-71)
+__global__ __launch_bounds__(256) void k_debug_portable_math(int which, const float* __restrict__ x, const float* __restrict__ y,
+                                                             uint32_t n, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = which == 0 ? akz_pm_atan2f(y[i], x[i]) : (which == 1 ? akz_pm_sinf(x[i]) : akz_pm_cosf(x[i]));
+}
+
+extern "C" int32_t akz_debug_portable_math(akz_ctx* c, int32_t which, const float* x, const float* y, uint32_t n, float* out)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !x || !out || which < 0 || which > 2 || (which == 0 && !y) || n == 0) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+        AKZ_HIP(hipMalloc(&dx, sizeof(float) * n));
+        AKZ_HIP(hipMalloc(&dy, sizeof(float) * n));
+        AKZ_HIP(hipMalloc(&dout, sizeof(float) * n));
+        AKZ_HIP(hipMemcpy(dx, x, sizeof(float) * n, hipMemcpyHostToDevice));
+        AKZ_HIP(hipMemcpy(dy, which == 0 ? y : x, sizeof(float) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_debug_portable_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, which, dx, dy, n, dout);
+        AKZ_LAUNCH_CHECK();
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
+        hipFree(dx); hipFree(dy); hipFree(dout);
+        return AKZ_OK;
+    });
 }

@@ -2347,14 +2347,14 @@ inline dim3 grid_px(int w, int h, int n) { return dim3(akz_div_up(w, 64), akz_di
 int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel, int ksize,
                          int vertical)
 {
-    hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, in, out, w, h, d_kernel, ksize, vertical);
+    AKZ_LAUNCH(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, in, out, w, h, d_kernel, ksize, vertical);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
 
 int32_t akz_dev_deinterleave(hipStream_t s, const float2* in, float* out, size_t n, int component)
 {
-    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, component);
+    AKZ_LAUNCH(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, component);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
@@ -2363,7 +2363,7 @@ int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int
                           size_t out_fs)
 {
     if (w / 2 <= 0 || h / 2 <= 0) return AKZ_E_INVALID;
-    hipLaunchKernelGGL(k_half_size, grid_px(w / 2, h / 2, n), dim3(256), 0, s, in, out, w, h, in_fs, out_fs);
+    AKZ_LAUNCH(k_half_size, grid_px(w / 2, h / 2, n), dim3(256), 0, s, in, out, w, h, in_fs, out_fs);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
@@ -2374,7 +2374,7 @@ static int32_t launch_blur(akz_ctx* c, const InT* in, int w, int h, size_t in_fs
 {
     AkzSet& S = c->S();
     dim3 grid(akz_div_up(w, kTW), akz_div_up(h, kTH), n);
-    hipLaunchKernelGGL((k_blur_tile<R, E, InT, EPI>), grid, dim3(256), 0, c->stream, in, w, h, in_fs, taps, out_g,
+    AKZ_LAUNCH((k_blur_tile<R, E, InT, EPI>), grid, dim3(256), 0, c->stream, in, w, h, in_fs, taps, out_g,
                        out_flow, out_fs, S.d_invk, invk_off, S.d_cmax, S.d_hist, S.d_npoints,
                        (int)c->cfg.contrast_factor_num_bins);
     AKZ_LAUNCH_CHECK();
@@ -2421,7 +2421,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     akz_timer_begin(c, AKZ_T_FRONT0, s);
     if (fused0 && (w & 3) == 0 && c->front_pair) {
 #define AKZ_FRONT0(THV, NTV, TPBV)                                                                                  \
-    hipLaunchKernelGGL((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
+    AKZ_LAUNCH((k_level_front2<4, 2, THV, NTV, InT, false, TPBV>),                                              \
                        dim3(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s,    \
                        d_imgs, w, h, P0, n, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0], (const float*)nullptr, 0)
         // 32-row tiles (measured against 24 x 512 and against 5 row tiles per block with register prefetch: 10.18
@@ -2431,7 +2431,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #undef AKZ_FRONT0
         AKZ_LAUNCH_CHECK();
     } else if (fused0) {
-        hipLaunchKernelGGL((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
+        AKZ_LAUNCH((k_level_front<4, 2, InT, false>), dim3(akz_div_up(w, kTW), akz_div_up(h, kTH), n), dim3(256), 0,
                            s, d_imgs, w, h, P0, t0, make_offk(2), S.Lt[0], (float*)nullptr, S.Lxy[0],
                            (const float*)nullptr, 0);
         AKZ_LAUNCH_CHECK();
@@ -2445,12 +2445,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         c->h_taps.assign((size_t)ks, 0.0f);
         akz_host_gaussian_kernel(sigma0, ks, c->h_taps.data());
         AKZ_HIP(hipMemcpyAsync(c->d_taps, c->h_taps.data(), sizeof(float) * ks, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL((k_to_f32<InT>), dim3((unsigned)((P0 * n + 255) / 256)), dim3(256), 0, s, d_imgs, S.tmp, P0 * n);
+        AKZ_LAUNCH((k_to_f32<InT>), dim3((unsigned)((P0 * n + 255) / 256)), dim3(256), 0, s, d_imgs, S.tmp, P0 * n);
         AKZ_LAUNCH_CHECK();
         for (int f = 0; f < n; ++f) {
-            hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.tmp + (size_t)f * P0),
+            AKZ_LAUNCH(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.tmp + (size_t)f * P0),
                                S.Ldet[0] + (size_t)f * P0, w, h, (const float*)c->d_taps, ks, 0);
-            hipLaunchKernelGGL(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.Ldet[0] + (size_t)f * P0),
+            AKZ_LAUNCH(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, (const float*)(S.Ldet[0] + (size_t)f * P0),
                                S.Lt[0] + (size_t)f * P0, w, h, (const float*)c->d_taps, ks, 1);
             AKZ_LAUNCH_CHECK();
         }
@@ -2464,19 +2464,19 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     const bool fine = pairc && c->contrast_fine;
     if (pairc) {
         dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), kCTiles), (n + 1) / 2);
-        hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
+        AKZ_LAUNCH((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
                            (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, fine ? S.d_fine : (uint32_t*)nullptr,
                            (const uint32_t*)nullptr);
         AKZ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_contrast_thresholds, dim3(n), dim3(512), 0, s, S.d_cmax, nbins, S.d_cthr);
+        AKZ_LAUNCH(k_contrast_thresholds, dim3(n), dim3(512), 0, s, S.d_cmax, nbins, S.d_cthr);
         AKZ_LAUNCH_CHECK();
         if (fine) {
-            hipLaunchKernelGGL(k_contrast_resolve, dim3(n), dim3(256), 0, s, S.d_cmax, S.d_fine, S.d_npoints,
+            AKZ_LAUNCH(k_contrast_resolve, dim3(n), dim3(256), 0, s, S.d_cmax, S.d_fine, S.d_npoints,
                                (const double*)S.d_cthr, nbins, c->cfg.contrast_percentile, P.n_octaves, S.d_contrast,
                                S.d_invk, S.d_cflag, c->contrast_force_odd ? 1 : 0);
             AKZ_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((k_contrast_pair<InT, EPI_CHIST>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
+        AKZ_LAUNCH((k_contrast_pair<InT, EPI_CHIST>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
                            (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, (uint32_t*)nullptr,
                            fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
         AKZ_LAUNCH_CHECK();
@@ -2484,7 +2484,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
         AKZ_TRY((launch_blur<2, 1, InT, EPI_CHIST>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
     }
-    hipLaunchKernelGGL(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
+    AKZ_LAUNCH(k_contrast_finish, dim3(akz_div_up(n, 64)), dim3(64), 0, s, S.d_cmax, S.d_hist,
                        S.d_npoints, nbins, c->cfg.contrast_percentile, n, P.n_octaves, S.d_contrast, S.d_invk,
                        fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
     AKZ_LAUNCH_CHECK();
@@ -2553,7 +2553,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 const int t_ff = AKZ_T_FRONT_FED_SG2 + (int)L.deriv_sigma - 2;
                 akz_timer_begin(c, t_ff, s);
 #define AKZ_FF3(SGV, HPV, RGV, WFV)                                                                                  \
-    hipLaunchKernelGGL((k_front_fed<SGV, HPV, RGV, WFV>),                                                             \
+    AKZ_LAUNCH((k_front_fed<SGV, HPV, RGV, WFV>),                                                             \
                        dim3(akz_div_up(L.w, front_fed_tile(HPV)), akz_div_up(L.h, front_fed_tile(HPV)), (n + 1) / 2), \
                        dim3(256), 0, s, init, L.w, L.h, fs, n, t1, kk, ft, groups[0], dst0, S.Lflow[i], S.Lxy[i],      \
                        (const float*)S.d_invk, (int)L.octave)
@@ -2576,10 +2576,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 dim3 gridf(akz_div_up(L.w, kTW), akz_div_up(L.h, kTH), n);
                 OffK kk = make_offk(L.deriv_sigma);
 #define AKZ_FRONT(SGV)                                                                                               \
-    hipLaunchKernelGGL((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
+    AKZ_LAUNCH((k_level_front<2, SGV, float, true>), gridf, dim3(256), 0, s, init, L.w, L.h, fs, t1, kk,      \
                        lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
 #define AKZ_FRONT2X(SGV, THV, NTV, TPBV)                                                                             \
-    hipLaunchKernelGGL((k_level_front2<2, SGV, THV, NTV, float, true, TPBV>),                                            \
+    AKZ_LAUNCH((k_level_front2<2, SGV, THV, NTV, float, true, TPBV>),                                            \
                        dim3(akz_div_up(L.w, kTW), akz_div_up(akz_div_up(L.h, THV), TPBV), (n + 1) / 2), dim3(NTV), 0, s, \
                        init, L.w, L.h, fs, n, t1, kk, lsm_out, S.Lflow[i], S.Lxy[i], (const float*)S.d_invk,            \
                        (int)L.octave)
@@ -2619,7 +2619,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_FED_CASE(TT)                                                                                              \
     case TT: {                                                                                                        \
         dim3 gridp(akz_div_up(L.w, fed_tile_edge(TT)), akz_div_up(L.h, fed_tile_edge(TT)), (n + 1) / 2);              \
-        hipLaunchKernelGGL((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
+        AKZ_LAUNCH((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
     } break;
                     const int t_fed = AKZ_T_FED_T1 + (groups[gi] <= 8 ? groups[gi] : 8) - 1;   // (9..16 steps: single-frame calls only)
                     akz_timer_begin(c, t_fed, s);
@@ -2639,7 +2639,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             for (int j = 0; j < nsteps; ++j) {
                 float* dst = ((nsteps - 1 - j) % 2 == 0) ? bufA : bufB;
                 float half_tau = 0.5f * (float)L.tau[j];
-                hipLaunchKernelGGL(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, S.Lflow[i], dst, L.w, L.h, fs,
+                AKZ_LAUNCH(k_fed_step, grid_px(L.w, L.h, n), dim3(256), 0, s, src, S.Lflow[i], dst, L.w, L.h, fs,
                                    half_tau);
                 AKZ_LAUNCH_CHECK();
                 src = dst;
@@ -2654,7 +2654,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         // detector_response.rs:60-67 + :33-57
         OffK k = make_offk(L.deriv_sigma);
         if (!(i == 0 ? fused0 : fused_front)) {
-            hipLaunchKernelGGL(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
+            AKZ_LAUNCH(k_deriv_first, grid_px(L.w, L.h, n), dim3(256), 0, s, smooth, S.Lxy[i], L.w, L.h, fs,
                                (int)L.deriv_sigma, k);
             AKZ_LAUNCH_CHECK();
         }
@@ -2675,10 +2675,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             dim3 grid2(akz_div_up(L.w, 64), akz_div_up(L.h, 32), n);
             float* ldet_out = c->keep_all ? S.Ldet[i] : nullptr;   // refinement reads the candidates' own 3x3 values
 #define AKZ_D2(SGV)                                                                                                  \
-    hipLaunchKernelGGL((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], ldet_out, L.w, L.h, fs,          \
+    AKZ_LAUNCH((k_deriv_second_cand<SGV>), grid2, dim3(256), 0, s, S.Lxy[i], ldet_out, L.w, L.h, fs,          \
                        (int)L.deriv_sigma, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err)
 #define AKZ_D2P(SGV)                                                                                                 \
-    hipLaunchKernelGGL((k_deriv_second_cand2<SGV, kDTH, 256>),                                                       \
+    AKZ_LAUNCH((k_deriv_second_cand2<SGV, kDTH, 256>),                                                       \
                        dim3(akz_div_up(L.w, 64), akz_div_up(L.h, kDTH), (n + 1) / 2), dim3(256), 0, s, S.Lxy[i],     \
                        ldet_out, L.w, L.h, fs, n, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err)
             const bool pair2 = (L.w & 3) == 0 && c->front_pair;
@@ -2696,11 +2696,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         const int seg_rows = akz_div_up(L.h, nseg);                                                                  \
         nseg = akz_div_up(L.h, seg_rows);                                                                            \
         if (ldet_out)                                                                                                \
-            hipLaunchKernelGGL((k_det_stream<SGV, true>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i],  \
+            AKZ_LAUNCH((k_det_stream<SGV, true>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i],  \
                                ldet_out, L.w, L.h, fs, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err, nb, \
                                seg_rows);                                                                            \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_det_stream<SGV, false>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i], \
+            AKZ_LAUNCH((k_det_stream<SGV, false>), dim3(akz_div_up(nb * nseg, 4), n), dim3(256), 0, s, S.Lxy[i], \
                                ldet_out, L.w, L.h, fs, k, L.sigma_quat, cp, (CandU*)S.d_cand_u, S.d_ncand, c->d_err, nb, \
                                seg_rows);                                                                            \
     }
@@ -2731,10 +2731,10 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         while (np2 < c->max_cand) np2 <<= 1;
         const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;
         if (n <= kLatencyFrames)
-            hipLaunchKernelGGL(k_cand_rank, dim3(akz_div_up((int)c->max_cand, 32), nlev, n), dim3(256), 0, s, (const CandU*)S.d_cand_u,
+            AKZ_LAUNCH(k_cand_rank, dim3(akz_div_up((int)c->max_cand, 32), nlev, n), dim3(256), 0, s, (const CandU*)S.d_cand_u,
                                S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
         else
-            hipLaunchKernelGGL(k_cand_sort, dim3(nlev, n), dim3(1024),
+            AKZ_LAUNCH(k_cand_sort, dim3(nlev, n), dim3(1024),
                                std::max<size_t>(sizeof(unsigned long long) * lds_keys, kCandRadixLdsBytes), s, (const CandU*)S.d_cand_u,
                                S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb, S.d_keys_cand, np2, lds_keys);
         AKZ_LAUNCH_CHECK();

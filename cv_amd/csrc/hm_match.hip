@@ -17,6 +17,8 @@
 // "lowest index wins ties" order (space 0.17: partition_point(d <= new) insertion).
 #include <algorithm>
 
+#include <hip/hip_ext.h>
+
 #include "akz_common.h"
 
 namespace {
@@ -791,6 +793,9 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
         hipLaunchKernelGGL(k_expand, dim3((max_cap * 16 + 255) / 256, (uint32_t)jobs.size()), dim3(256), 0, c->stream,
                            reinterpret_cast<const HmExpandJob*>((char*)c->d_probs + jobs_off));
     AKZ_LAUNCH_CHECK();
+    // timing: the launch carries its own start / stop events (hipExtLaunchKernel: the dispatch's begin and end timestamps,
+    // i.e. the duration rocprofv3's kernel trace reports) — an event bracket on the stream would also count the time the
+    // launch waits for the other streams' kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing) {
         auto take = [&]() {
@@ -801,27 +806,26 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
         };
         ev0 = take();
         ev1 = take();
-        if (ev0) hipEventRecord(ev0, c->stream);
+        if (!ev0 || !ev1) ev0 = ev1 = nullptr;
     }
     {
         dim3 grid((max_nq + 255) / 256, n_probs);
         const HmProbX* dp = reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off);
         if (c->use_fp4) {
             switch (knn) {
-            case 1: hipLaunchKernelGGL(k_knn_mfma4<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-            case 3: hipLaunchKernelGGL(k_knn_mfma4<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-            default: hipLaunchKernelGGL(k_knn_mfma4<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            case 1: hipExtLaunchKernelGGL(k_knn_mfma4<1>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            case 3: hipExtLaunchKernelGGL(k_knn_mfma4<3>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            default: hipExtLaunchKernelGGL(k_knn_mfma4<2>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
             }
         } else {
             switch (knn) {
-            case 1: hipLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-            case 3: hipLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
-            default: hipLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, dp); break;
+            case 1: hipExtLaunchKernelGGL(k_knn_mfma<1>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            case 3: hipExtLaunchKernelGGL(k_knn_mfma<3>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            default: hipExtLaunchKernelGGL(k_knn_mfma<2>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
             }
         }
     }
     if (ev0 && ev1) {
-        hipEventRecord(ev1, c->stream);
         c->t_pending.emplace_back(ev0, ev1);
         c->t_launches += 1;
     }

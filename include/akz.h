@@ -205,6 +205,11 @@ int32_t akz_debug_get_contrast(akz_ctx* ctx, int32_t img, double* out);
 int32_t akz_debug_get_keypoints(akz_ctx* ctx, int32_t img, int32_t stage, akz_keypoint* out,
                                 uint32_t cap, uint32_t* n_out);
 
+/* The transcendentals of the orientation and descriptor stages as the DEVICE evaluates them (f32::atan2 at
+ * scale_space_extrema.rs:242, f32::cos / sin at descriptors.rs:70-71): which 0: out = atan2f(y, x); 1: sinf(x); 2: cosf(x)
+ * (y ignored).  Host buffers.  The tests hold these to the host libm within 1 ulp. */
+int32_t akz_debug_portable_math(akz_ctx* ctx, int32_t which, const float* x, const float* y, uint32_t n, float* out);
+
 /* ---- stand-alone image ops (akaze::image public API, akaze/src/image.rs:202-389) ---- */
 /* gaussian_kernel(r, kernel_size) — image.rs:360-374.  Host-only scalar math. */
 int32_t akz_gaussian_kernel(float r, uint32_t kernel_size, float* out);
@@ -458,8 +463,13 @@ int32_t akz_last_hip_error(void);
 const char* akz_last_hip_error_string(void);
 const char* akz_version(void);
 
-/* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Events are recorded by the
- * library on the stream each family is launched on, around the launches themselves.  `which` is an AKZ_T_* id;
+/* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Kernel families (every id but the
+ * phase ids below): each launch carries its own start / stop events (hipExtLaunchKernel — the dispatch's begin and end
+ * timestamps, the duration rocprofv3's kernel trace reports), so a family's time is the sum of its kernels' own
+ * durations whatever else shares the GPU.  Phases (AKZ_T_FED, _SCALE_SPACE, _EXTRACT, _DESCRIBE, _REFINE): an event
+ * bracket on the stream, i.e. wall time including waits for the other streams.  akz_timing_enable(ctx, 1) turns both
+ * kinds on, 2 the kernel families only (no extra packets in the streams: usable inside a timed region), 0 off.
+ * `which` is an AKZ_T_* id;
  * the call returns the milliseconds, launch count and processed units accumulated since akz_timing_reset():
  * units = pixel-frames the launches covered (FED: pixel-steps, the contract's unit; AKZ_T_FED_PASS reports the
  * same launches with units = pixel-frames per launch, i.e. passes over memory). */
@@ -483,7 +493,8 @@ enum {
                                * units = pixel-frames */
     AKZ_T_FRONT_FED_SG3 = 23,
     AKZ_T_FRONT_FED_SG4 = 24,
-    AKZ_T_COUNT = 25
+    AKZ_T_ORIENT_DESCRIBE_K = 25, /* the k_orient_describe launch itself (kernel timer inside the AKZ_T_DESCRIBE phase), units: frames */
+    AKZ_T_COUNT = 26
 };
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);

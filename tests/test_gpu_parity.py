@@ -1440,3 +1440,43 @@ def test_device_geometry_against_independent_f64_statements(gpu):
     pose, inl, _ = got
     assert np.abs(pose[:, :3] - R).max() < 1e-6 and np.abs(pose[:, 3] - t).max() < 1e-6
     assert len(inl) == len(bb)
+
+
+def test_device_transcendentals_against_the_host_libm(gpu, oracle):
+    """Round-2 verdict, weak spot 1b (A14): the angle bits equal the oracle's because both sides evaluate
+    include/akz_portable_math.h.  Independent evidence on the DEVICE side: atan2f / sinf / cosf as the gfx950 kernels
+    compute them, on 10^5 values each, against glibc (what Rust's f32::atan2 / sin / cos call on Linux) within 1 ulp
+    and against the correctly rounded f64 value within 1 ulp; and bit for bit against the oracle's build of the header."""
+    import ctypes
+    from test_oracle_math import _ulp_diff
+    akaze, _ = gpu
+    from cv_amd import _lib
+    ctx = akaze.Akaze.default().context(64, 64, 1)
+    rng = np.random.default_rng(0x7A)
+    n = 100000
+    y = (rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2, n)).astype(np.float32)
+    x = (rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2, n)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n).astype(np.float32)
+    ang[:8] = np.array([0, np.pi, np.pi / 2, 3 * np.pi / 2, 2 * np.pi, 1e-8, 6.2831855, 3.1415927], np.float32)
+
+    def dev(which, xs, ys=None):
+        out = np.empty(len(xs), np.float32)
+        _lib.check(_lib.lib().akz_debug_portable_math(ctx.handle, which, xs.ctypes.data, ys.ctypes.data if ys is not None else None,
+                                                      len(xs), out.ctypes.data), "akz_debug_portable_math")
+        return out
+    at, si, co = dev(0, x, y), dev(1, ang), dev(2, ang)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atan2f.restype = ctypes.c_float; libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    for fn in (libm.sinf, libm.cosf):
+        fn.restype = ctypes.c_float; fn.argtypes = [ctypes.c_float]
+    g_at = np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+    g_si = np.array([libm.sinf(float(v)) for v in ang], np.float32)
+    g_co = np.array([libm.cosf(float(v)) for v in ang], np.float32)
+    assert _ulp_diff(at, g_at).max() <= 1 and _ulp_diff(si, g_si).max() <= 1 and _ulp_diff(co, g_co).max() <= 1
+    assert (at != g_at).mean() < 0.01 and (si != g_si).mean() < 0.03 and (co != g_co).mean() < 0.03
+    assert _ulp_diff(at, np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)).max() <= 1
+    assert _ulp_diff(si, np.sin(ang.astype(np.float64)).astype(np.float32)).max() <= 1
+    assert _ulp_diff(co, np.cos(ang.astype(np.float64)).astype(np.float32)).max() <= 1
+    _eq(at, oracle.pm_atan2f(y, x), "device atan2f vs the oracle's build of akz_portable_math.h")
+    os_, oc_ = oracle.pm_sincosf(ang)
+    _eq(si, os_, "device sinf"); _eq(co, oc_, "device cosf")

@@ -1,8 +1,9 @@
 #!/bin/bash
 # copies the summaries a tools/validate_job.sh run merged into gpurun_out/ to profiles/ (tracked)
-T=${1:-r02}
+T=${1:-r03}
 cd "$(dirname "$0")/.."
 cp gpurun_out/refresh/${T}_bench.json profiles/${T}_bench.json
+cp gpurun_out/refresh/${T}_bench_profiled.json profiles/${T}_bench_profiled.json
 cp gpurun_out/refresh/${T}_bench_kernel_stats.txt gpurun_out/refresh/${T}_pmc_traffic.json gpurun_out/refresh/${T}_pmc_fetch_size.txt gpurun_out/refresh/${T}_pmc_write_size.txt profiles/
 cp gpurun_out/pmc_sq_summary.txt profiles/${T}_pmc_sq_summary.txt
 cp gpurun_out/kstat_final.txt profiles/${T}_kstat_serial_64frames.txt

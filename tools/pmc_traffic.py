@@ -4,7 +4,7 @@
 HBM bytes = WRITE_SIZE + 2 x FETCH_SIZE (KiB units; FETCH_SIZE doubled: the gfx950 correction for 16-byte reads of
 MI355X_MICROARCH.md).  bench.py attaches these per-launch figures as roofline.traffic only when its micro-batch
 equals the one recorded here.
-usage: pmc_traffic.py fetch.db write.db out.json micro_batch"""
+usage: pmc_traffic.py fetch.db write.db out.json micro_batch [valu.db frames steps]"""
 import json
 import re
 import sqlite3
@@ -49,24 +49,54 @@ def per_kernel(path, counter):
     return agg
 
 
-def main(fetch_db, write_db, out, mb):
+SCALE_SPACE = ("k_level_front", "k_front_fed", "k_fed_", "k_det_stream", "k_deriv_", "k_contrast", "k_half_size", "k_cand_", "k_blur",
+               "k_filter1d", "k_to_f32")
+MATCHER = ("k_knn", "k_expand", "k_pairs")
+
+
+def stage_of(name):
+    """which stage of the timed pipeline a kernel belongs to (None: not the library's — frame generation, torch fills)"""
+    if not name.startswith("k_"):
+        return None
+    if name.startswith(SCALE_SPACE):
+        return "scale_space"
+    if name.startswith(MATCHER):
+        return "matcher"
+    return "keypoint_stage"
+
+
+def main(fetch_db, write_db, out, mb, valu_db=None, frames=None, steps=1):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
-    res = {"micro_batch": int(mb),
-           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --frames {mb} "
-                     f"--micro-batch {mb} --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-pipeline; KiB units; "
-                     "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 16-byte-read correction, "
-                     "MI355X_MICROARCH.md); every dispatch of the run is counted (the isolated scale-space passes "
-                     "included: same kernels, same sizes)",
+    v = per_kernel(valu_db, "SQ_INSTS_VALU") if valu_db else {}
+    frames = int(frames or mb)
+    res = {"micro_batch": int(mb), "frames_per_step": frames, "steps": int(steps),
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU SQ_WAVES (separate passes) of "
+                     f"bench.py --pmc-run --frames {frames} --micro-batch {mb} --steps {steps} --warmup 0: exactly {steps} step(s) "
+                     f"of the timed pipeline and nothing else from the library on the GPU; KiB units; hbm bytes = "
+                     "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 16-byte-read correction, MI355X_MICROARCH.md)",
+           "source_short": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --pmc-run (library kernels only)",
            "kernels": {}}
+    tot = {"scale_space": 0.0, "keypoint_stage": 0.0, "matcher": 0.0}
     for k in sorted(f, key=lambda k: -f[k][1]):
         n = f[k][0]
         wk = w.get(k, [0, 0.0])[1]
         res["kernels"][k] = {"launches": n, "fetch_size_kib_x2": round(2 * f[k][1], 1), "write_size_kib": round(wk, 1),
                              "hbm_bytes_per_launch": round((2 * f[k][1] + wk) * 1024 / max(1, n))}
+        if k in v and v[k][0]:
+            res["kernels"][k]["valu_insts_per_launch"] = round(v[k][1] / v[k][0])
+        st = stage_of(k)
+        if st:
+            tot[st] += (2 * f[k][1] + wk) * 1024
+    nfr = float(frames) * float(steps)
+    res["per_frame"] = {"hbm_bytes": sum(tot.values()) / nfr, "scale_space_hbm_bytes": tot["scale_space"] / nfr,
+                        "keypoint_stage_hbm_bytes": tot["keypoint_stage"] / nfr, "matcher_hbm_bytes": tot["matcher"] / nfr,
+                        "note": "sum over the library's kernels (names k_*) of one pipeline step / frames; torch's frame-generation "
+                                "and fill kernels are excluded"}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in list(res["kernels"].items())[:8]}))
+    print(json.dumps({k: v_["hbm_bytes_per_launch"] for k, v_ in list(res["kernels"].items())[:8]}))
+    print(json.dumps(res["per_frame"]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4])
+    main(*sys.argv[1:])

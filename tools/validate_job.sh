@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -6
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-bash tools/refresh_profiles.sh r02 256 > gpurun_out/refresh.log 2>&1
+bash tools/refresh_profiles.sh r03 256 > gpurun_out/refresh.log 2>&1
 tail -c 600 gpurun_out/refresh/bench.log
 KSTAT_LINES=60 bash tools/kstat.sh final > /dev/null 2>&1
 bash tools/pmc_sq.sh > /dev/null 2>&1
