@@ -159,6 +159,15 @@ def main():
     ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU smoke test of the multi-rank path)")
+    ap.add_argument("--recent", type=int, default=1, help="every frame is matched against its K predecessors g-1 .. g-K "
+                    "(cv-sfm tracking_recent_frames: up to 32); 1 = the headline workload (symmetric match with g-1), "
+                    "K > 1: LinearKnn::knn(., 2) of every feature against each of the K views (hm_knn_views_device)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "shift", "allgather"], help="how descriptor blocks reach the "
+                    "ranks that match against them: ring shift (K = 1) or all-gather of the fixed-capacity blocks (K > 1)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "akz", "torch"], help="akz: the library's own RCCL exchange "
+                    "(akz_comm_*, C ABI); torch: torch.distributed.  auto = akz with the nccl backend, torch otherwise")
+    ap.add_argument("--force-exchange", action="store_true", help="run the exchange code path even with one rank (a rank "
+                    "then sends to itself): the single-GPU test of the N > 1 path's collectives")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
     ap.add_argument("--dump-matches", default=None, help="write per-global-frame keypoint/match counts to this .npy")
     args = ap.parse_args()
@@ -178,8 +187,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_exchange      # the exchange step runs (with one rank: to itself)
+    comm_kind = args.comm if args.comm != "auto" else ("akz" if args.backend == "nccl" else "torch")
+    K = max(1, args.recent)
+    use_allgather = args.exchange == "allgather" or (args.exchange == "auto" and K > 1)
+    if world > 1 or (sharded and comm_kind == "torch"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -195,7 +209,7 @@ def main():
     from cv_amd import _lib
     from cv_amd.akaze import Akaze
     from cv_amd.knn import Matcher, RULE_STRICT
-    from cv_amd.sharding import exchange_predecessors, pred_row
+    from cv_amd.sharding import AkzExchange, TorchExchange, exchange_predecessors, gathered_block, pred_row, window_views
     L = _lib.lib()
 
     NF, MB = args.frames, min(args.micro_batch, args.frames)
@@ -228,8 +242,13 @@ def main():
     counts2 = zeros2((NF,), torch.int32)
     # predecessor descriptor blocks: prev[j] = descriptors of global frame g-1 for local frame j
     # (row NF holds the predecessor of local frame 0 on rank 0: cv_amd/sharding.py)
-    prev_descs2 = zeros2((NF + 1, CAP, 64), torch.uint8) if world > 1 else [None, None]
-    prev_counts2 = zeros2((NF + 1,), torch.int32) if world > 1 else [None, None]
+    shift_mode = sharded and not use_allgather
+    prev_descs2 = zeros2((NF + 1, CAP, 64), torch.uint8) if shift_mode else [None, None]
+    prev_counts2 = zeros2((NF + 1,), torch.int32) if shift_mode else [None, None]
+    # all-gather mode: gathered[m][r][i] = block of local frame m*MB + i of rank r (cv_amd/sharding.py: gathered_block)
+    gath_descs2 = zeros2((NF // MB, world, MB, CAP, 64), torch.uint8) if (sharded and use_allgather) else [None, None]
+    gath_counts2 = zeros2((NF // MB, world, MB), torch.int32) if (sharded and use_allgather) else [None, None]
+    knn_out2 = zeros2((NF, K, CAP, 2, 2), torch.int32) if K > 1 else [None, None]     # [frame][view][query][k]{index, distance}
     pairs2 = zeros2((NF + 2, CAP, 2), torch.int32)   # +2: a micro-batch can carry mb+1 pairs
     npairs2 = zeros2((NF + 2,), torch.int32)
     match_done = [torch.cuda.Event(), torch.cuda.Event()]   # the matcher finished reading output set p
@@ -245,7 +264,11 @@ def main():
     # predecessor's straight into the rows the matcher reads) runs on its own stream, so that the next micro-batch's
     # scale space (which waits on the caller's stream only) does not queue behind it; ordering contract in
     # cv_amd/sharding.py
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if sharded else None
+    exchange = None
+    if sharded:
+        exchange = AkzExchange(dist, rank, world, local_rank) if comm_kind == "akz" else TorchExchange(dist, rank, world)
+        flush_c_stdio()
 
     verify = {"on": None}            # pipeline+verify leg: a callable(p, m0, js, prev_js) that enqueues the consensus
 
@@ -256,7 +279,7 @@ def main():
         prev_descs, prev_counts = prev_descs2[p], prev_counts2[p]
         if step_no[0] >= 2:          # set p was last read by the matcher two steps ago (long finished)
             cur.wait_event(match_done[p])
-            if world > 1:
+            if sharded:
                 comm.wait_event(match_done[p])
             if verify["on"] is not None and verify.get("armed"):
                 cur.wait_event(verify["done"][p])   # ... and its keypoints / pair lists by the consensus
@@ -269,12 +292,31 @@ def main():
             js = [j for j in range(m0, m0 + MB) if j > 0]
             if m0 + MB == NF:
                 js.append(0)
-            if world > 1:
+            if K > 1:
+                # window mode: the micro-batch's blocks go to every rank (all-gather); matching follows the step's last one
+                if sharded:
+                    comm.wait_stream(akz_stream)
+                    with torch.cuda.stream(comm):
+                        exchange.allgather(descs[m0:m0 + MB], counts[m0:m0 + MB], gath_descs2[p][m0 // MB], gath_counts2[p][m0 // MB])
+                continue
+            if shift_mode:
                 comm.wait_stream(akz_stream)
                 with torch.cuda.stream(comm):
                     js = exchange_predecessors(dist, rank, world, m0, MB, NF, descs[m0:m0 + MB],
-                                               counts[m0:m0 + MB], prev_descs, prev_counts)
+                                               counts[m0:m0 + MB], prev_descs, prev_counts, exchange)
                 ia, ib, tb, nb, wait = idx(js), idx([pred_row(rank, j, NF) for j in js]), prev_descs, prev_counts, comm
+            elif sharded:
+                # K = 1 through the all-gather: the predecessor's block is looked up in the gathered array
+                comm.wait_stream(akz_stream)
+                with torch.cuda.stream(comm):
+                    exchange.allgather(descs[m0:m0 + MB], counts[m0:m0 + MB], gath_descs2[p][m0 // MB], gath_counts2[p][m0 // MB])
+                if m0 + MB < NF:
+                    continue             # (frame 0's predecessor is the step's last frame: match once everything is gathered)
+                js = list(range(NF))
+                ia = idx(js)
+                ib = idx([gathered_block(window_views(rank, j, world, NF, 1)[0], world, NF, MB) for j in js])
+                tb, nb, wait = gath_descs2[p], gath_counts2[p], comm
+                m0 = 0                   # the pair lists of all frames, slot = frame
             else:
                 ia, ib, tb, nb, wait = idx(js), idx([(j - 1) % NF for j in js]), descs, counts, akz_stream
             # problem p writes pairs/npairs block p of the view starting at js[0]'s slot; keep them per frame
@@ -286,6 +328,17 @@ def main():
                 verify["on"](p, m0, js, [(j - 1) % NF for j in js])
             if host_trace is not None:
                 host_trace.append((step_no[0], m0, round((tB - tA) * 1e3, 2), round((time.perf_counter() - tB) * 1e3, 2)))
+        if K > 1:
+            # every feature of frame j against each of its K recent views (cv-sfm/src/lib.rs:1468-1486), 2 neighbours each
+            views_d = gath_descs2[p] if sharded else descs
+            views_n = gath_counts2[p] if sharded else counts
+            wait = comm if sharded else akz_stream
+            for j in range(NF):
+                gv = window_views(rank, j, world, NF, K)
+                vi = idx([gathered_block(g, world, NF, MB) for g in gv]) if sharded else idx(gv)
+                _lib.check(L.hm_knn_views_device(matcher.handle, descs[j].data_ptr(), counts[j:].data_ptr(), views_d.data_ptr(),
+                                                 views_n.data_ptr(), CAP, vi, K, 2, knn_out2[p][j].data_ptr(),
+                                                 wait.cuda_stream if j == 0 else None), "knn_views")
         match_done[p].record(hm_stream)
         step_no[0] += 1
 
@@ -306,11 +359,15 @@ def main():
     ctx.timing_reset()
     _lib.check(L.hm_timing_get(matcher.handle, None, None, 1), "hm_timing_get")
     _lib.check(L.hm_timing_enable(matcher.handle, 1 if kt else 0), "hm_timing_enable")
+    if exchange is not None:
+        exchange.exposed()               # reset the exchange's own timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+    exch = exchange.exposed() if exchange is not None else None
     knn_ms, knn_launches = C.c_double(), C.c_uint64()
     _lib.check(L.hm_timing_get(matcher.handle, C.byref(knn_ms), C.byref(knn_launches), 1), "hm_timing_get")
     _lib.check(L.hm_timing_enable(matcher.handle, 0), "hm_timing_enable")
@@ -332,10 +389,13 @@ def main():
     last = (step_no[0] - 1) & 1
     kps, descs, counts, pairs, npairs = kps2[last], descs2[last], counts2[last], pairs2[last], npairs2[last]
     _lib.check(L.akz_sync(ctx.handle), "akz_sync")
+    per_rank = [my_elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
     ctx.timing_enable(False)
 
     # Isolated pass: the same scale-space launches with nothing else on the GPU (in the timed region above they
@@ -358,19 +418,23 @@ def main():
     if args.dump_matches:
         # per GLOBAL frame g = j*world + rank: [keypoints, matches of (g, g-1)]; problem order follows `js`
         # within each micro-batch, so the match count of local frame j is looked up through the same schedule
+        slot_of = {}
+        for m0 in range(0, NF, MB):
+            if sharded and not shift_mode:
+                js, base = list(range(m0, m0 + MB)), None        # all-gather route: slot = frame
+            elif sharded and rank > 0:
+                js, base = list(range(m0, m0 + MB)), m0
+            elif sharded:
+                js, base = list(range(m0 + 1, m0 + MB)) + ([m0] if m0 > 0 else []) + ([0] if m0 + MB == NF else []), m0
+            else:
+                js, base = [j for j in range(m0, m0 + MB) if j > 0] + ([0] if m0 + MB == NF else []), m0
+            for q, j in enumerate(js):
+                slot_of[j] = j if base is None else base + q
         per_frame = torch.zeros((NF, 2), dtype=torch.int32, device=dev)
         per_frame[:, 0] = counts
-        slot = 0
-        for m0 in range(0, NF, MB):
-            if world > 1:
-                if rank > 0:
-                    js = list(range(m0, m0 + MB))
-                else:
-                    js = list(range(m0 + 1, m0 + MB)) + ([m0] if m0 > 0 else []) + ([0] if m0 + MB == NF else [])
-            else:
-                js = [j for j in range(m0, m0 + MB) if j > 0] + ([0] if m0 + MB == NF else [])
-            for q, j in enumerate(js):
-                per_frame[j, 1] = npairs[m0 + q]
+        if K == 1:
+            for j in range(NF):
+                per_frame[j, 1] = npairs[slot_of[j]]
         allf = [torch.zeros_like(per_frame) for _ in range(world)] if world > 1 else [per_frame]
         if world > 1:
             dist.all_gather(allf, per_frame)
@@ -379,20 +443,15 @@ def main():
             for r in range(world):
                 glob[r::world] = allf[r].cpu().numpy()
             np.save(args.dump_matches, glob)
-        # the pair lists themselves, one file per rank, keyed by GLOBAL frame (variable lengths)
-        slot_of = {}
-        for m0 in range(0, NF, MB):
-            if world > 1 and rank > 0:
-                js = list(range(m0, m0 + MB))
-            elif world > 1:
-                js = list(range(m0 + 1, m0 + MB)) + ([m0] if m0 > 0 else []) + ([0] if m0 + MB == NF else [])
-            else:
-                js = [j for j in range(m0, m0 + MB) if j > 0] + ([0] if m0 + MB == NF else [])
-            for q, j in enumerate(js):
-                slot_of[j] = m0 + q
-        hp, hn = pairs.cpu().numpy(), npairs.cpu().numpy()
-        np.savez(f"{args.dump_matches}.r{rank}.npz",
-                 **{f"g{j * world + rank}": hp[slot_of[j], :hn[slot_of[j]]].copy() for j in range(NF)})
+        # the pair lists (K = 1) or the neighbour lists against the K views, one file per rank, keyed by GLOBAL frame
+        if K == 1:
+            hp, hn = pairs.cpu().numpy(), npairs.cpu().numpy()
+            np.savez(f"{args.dump_matches}.r{rank}.npz",
+                     **{f"g{j * world + rank}": hp[slot_of[j], :hn[slot_of[j]]].copy() for j in range(NF)})
+        else:
+            hk, hc = knn_out2[last].cpu().numpy(), counts.cpu().numpy()
+            np.savez(f"{args.dump_matches}.r{rank}.npz",
+                     **{f"g{j * world + rank}": hk[j, :, :hc[j]].copy() for j in range(NF)})
 
     n_kp = counts.float().mean().item()
     n_match = npairs[:NF].float().mean().item()
@@ -446,6 +505,20 @@ def main():
                 "note": "ops = 2 x 512 MACs per (query, target) pair with the mean keypoint count; time = the k-NN "
                         "launches' own start/stop events over the timed region; peak = the dense FP4 MFMA figure "
                         "of MI355X_MICROARCH.md (~10 PF)"}
+        if sharded:
+            out["multi_gpu"] = {
+                "per_rank_frames_per_s": [round(NF * args.steps / t_, 1) for t_ in per_rank],
+                "recent_views": K, "exchange": "all-gather of fixed-capacity descriptor blocks" if use_allgather else "ring shift",
+                "comm": "akz_comm_* (libakz -> librccl.so.1)" if comm_kind == "akz" else f"torch.distributed ({args.backend})",
+                "block_bytes_per_rank_per_step": NF * (CAP * 64 + 4)}
+            if exch:
+                out["multi_gpu"]["exchange_ms_per_step"] = round(exch[0] / args.steps, 3)
+                out["multi_gpu"]["exchange_bytes_per_step"] = int(exch[2] // max(1, args.steps))
+                out["multi_gpu"]["note"] = ("exchange_ms_per_step = HIP-event time of the transfers on the exchange stream (rank 0); "
+                                            "they overlap the next micro-batch's scale space, so ms_per_step loses less than that")
+        if K > 1:
+            out["config"]["recent_views"] = K
+            out["config"]["workload"] += f"; WINDOW MODE: 2-NN of every feature against each of the {K} preceding frames instead of the symmetric match"
         if traffic:
             out["hbm_traffic_per_frame"] = traffic
             out["end_to_end_hbm_frac"] = round(traffic["bytes"] * fps / world / (HBM_PEAK_GBS * 1e9), 4)
@@ -474,12 +547,20 @@ def main():
             for v in out["configs_extra"].values():
                 if v.get("parity", {}).get("mismatches"):
                     rc = 1
+        flush_c_stdio()                     # (RCCL writes a version banner through C stdio: it must not follow the line)
         print(json.dumps(out), flush=True)
         if rc:
             print("bench.py: GPU output differs from the oracle (see parity_checked / configs_extra)", file=sys.stderr)
             sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
+
+
+def flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def read_families(ctx):

@@ -131,6 +131,8 @@ ABI_SYMBOLS = [
     "rs_stream", "rs_debug_scene", "rs_debug_residuals",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
+    "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
+    "akz_comm_stream", "akz_comm_rank", "akz_comm_world", "akz_comm_timing", "akz_comm_last_error_string",
 ]
 
 _lib = None
@@ -220,6 +222,18 @@ def lib():
     L.rs_stream.argtypes = [vp]
     L.rs_debug_scene.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
     L.rs_debug_residuals.argtypes = [vp, vp, u32, vp, vp, u32, i32, vp]
+    L.akz_comm_unique_id.argtypes = [vp]
+    L.akz_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.akz_comm_destroy.argtypes = [vp]
+    L.akz_comm_shift_blocks.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+    L.akz_comm_allgather_blocks.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+    L.akz_comm_sync.argtypes = [vp]
+    L.akz_comm_stream.restype = vp
+    L.akz_comm_stream.argtypes = [vp]
+    L.akz_comm_rank.argtypes = [vp]
+    L.akz_comm_world.argtypes = [vp]
+    L.akz_comm_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32]
+    L.akz_comm_last_error_string.restype = C.c_char_p
     L.akz_timing_enable.argtypes = [vp, i32]
     L.akz_timing_reset.argtypes = [vp]
     L.akz_timing_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libakz.so")
-SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_color.hip", "akz_plan.cpp"]
+SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_color.hip", "akz_comm.hip", "akz_plan.cpp"]
 HEADERS = ["akz_common.h", "akz_ctx.h", "../../include/akz.h", "../../include/akz_portable_math.h", "../../include/akz_ransac_math.h", "../../include/akz_p3p_math.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
             sys.stderr.write(f"hipcc failed on {s}\n")
     if failed:
         raise RuntimeError("libakz build failed")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

@@ -23,6 +23,7 @@ extern "C" const char* akz_strerror(int32_t s)
     case AKZ_E_HIP: return "HIP runtime error";
     case AKZ_E_TOO_LARGE: return "image or batch larger than the context was created for";
     case AKZ_E_INTERNAL: return "device-side overflow of an internal work list (create the context with a larger max_keypoints / akz_options.max_candidates)";
+    case AKZ_E_COMM: return "RCCL call failed or librccl.so.1 could not be loaded (akz_comm_last_error_string())";
     default: return "unknown status";
     }
 }

@@ -75,7 +75,7 @@ def _ring_shift(dist, rank, world, send_tensors, recv_tensors):
         torch.cuda.synchronize()
 
 
-def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, prev_descs, prev_counts):
+def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, prev_descs, prev_counts, exchange=None):
     """After the local frames [m0, m0+mb) of every rank have been extracted, pass their descriptor blocks one
     rank up the ring so that every rank holds the predecessors (global frame g-1, wrapping inside the step of
     nf*world frames) of its own frames.
@@ -84,7 +84,10 @@ def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, pr
     the predecessor of frame j is row pred_row(rank, j, nf).  Tensors: descs_mb [mb,cap,64] u8, counts_mb
     [mb] i32 (views of the rank's own outputs), prev_descs [nf+1,cap,64], prev_counts [nf+1]."""
     lo = m0 if rank > 0 else m0 + 1                    # rank 0 receives (world-1, j-1): one row further down
-    _ring_shift(dist, rank, world, [descs_mb, counts_mb], [prev_descs[lo:lo + mb], prev_counts[lo:lo + mb]])
+    if exchange is None:
+        _ring_shift(dist, rank, world, [descs_mb, counts_mb], [prev_descs[lo:lo + mb], prev_counts[lo:lo + mb]])
+    else:
+        exchange.shift(descs_mb, counts_mb, prev_descs[lo:lo + mb], prev_counts[lo:lo + mb])
     if rank > 0:
         return list(range(m0, m0 + mb))                # predecessor of (rank, j) is (rank-1, j): this micro-batch
     ready = list(range(m0 + 1, m0 + mb))               # (0, j) <- (world-1, j-1) for the frames after the first
@@ -93,3 +96,115 @@ def exchange_predecessors(dist, rank, world, m0, mb, nf, descs_mb, counts_mb, pr
     if m0 + mb == nf:
         ready.append(0)                                # row nf: the step's last global frame
     return ready
+
+
+# ---- matching against a window of recent frames (g-1 .. g-k): the all-gather of SURVEY.md §8e -------------------
+# cv-sfm matches a new frame against up to tracking_recent_frames = 32 recent views (cv-sfm/src/settings.rs:449-450, the
+# loop at cv-sfm/src/lib.rs:1462-1486).  With frame g on rank g % world the views g-1 .. g-k live on the other ranks, all
+# of them once k >= world - 1: every micro-batch's blocks are all-gathered, rank-major, into one slab per micro-batch,
+#     gathered[m][r][i]  =  block of local frame m*mb + i of rank r  =  global frame (m*mb + i) * world + r
+# and a view is addressed by its block index in that array (hm_knn_views_device's view_idx).
+
+def gathered_block(g, world, nf, mb):
+    """Index, in the [nf // mb][world][mb] array of gathered blocks, of global frame g (0 <= g < nf * world)."""
+    r, j = g % world, g // world
+    return ((j // mb) * world + r) * mb + (j % mb)
+
+
+def window_views(rank, j, world, nf, k):
+    """Global frames g-1 .. g-k of local frame j (g = j * world + rank), wrapping inside the step's nf * world frames."""
+    total = nf * world
+    g = j * world + rank
+    return [(g - d) % total for d in range(1, k + 1)]
+
+
+class TorchExchange:
+    """The exchange through torch.distributed (nccl = RCCL on device tensors; gloo stages device tensors through the host)."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def shift(self, descs, counts, recv_descs, recv_counts):
+        _ring_shift(self.dist, self.rank, self.world, [descs, counts], [recv_descs, recv_counts])
+
+    def allgather(self, descs, counts, all_descs, all_counts):
+        """descs [mb,cap,64], counts [mb] -> all_descs [world,mb,cap,64], all_counts [world,mb] (rank-major)."""
+        dist = self.dist
+        staged = descs.is_cuda and dist.get_backend() != "nccl"
+        if staged:
+            import torch
+            torch.cuda.synchronize()
+            for src, dst in ((descs, all_descs), (counts, all_counts)):
+                host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.world)]
+                dist.all_gather(host, src.cpu())
+                for r in range(self.world):
+                    dst[r].copy_(host[r])
+            torch.cuda.synchronize()
+            return
+        if descs.is_cuda:
+            w1 = dist.all_gather_into_tensor(all_descs, descs.contiguous(), async_op=True)
+            w2 = dist.all_gather_into_tensor(all_counts, counts.contiguous(), async_op=True)
+            w1.wait(); w2.wait()              # NCCL: orders the current stream after the collectives
+        else:
+            dist.all_gather([all_descs[r] for r in range(self.world)], descs.contiguous())
+            dist.all_gather([all_counts[r] for r in range(self.world)], counts.contiguous())
+
+    def exposed(self):
+        return None
+
+    def close(self):
+        pass
+
+
+class AkzExchange:
+    """The exchange through the library's own C ABI (akz_comm_*: RCCL loaded by libakz, its own stream).  The unique id
+    is made by rank 0 and handed round through torch.distributed's store — the host application's part of the job."""
+
+    def __init__(self, dist, rank, world, device):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self._lib, self._C, self._torch = _lib, C, torch
+        self.rank, self.world = rank, world
+        L = _lib.lib()
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(L.akz_comm_unique_id(buf), "akz_comm_unique_id")
+            ident[0] = bytes(buf)
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self._h = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        _lib.check(L.akz_comm_create(idb, rank, world, device, C.byref(self._h)), "akz_comm_create")
+        self.stream = torch.cuda.ExternalStream(L.akz_comm_stream(self._h), device=torch.device("cuda", device))
+        _lib.check(L.akz_comm_timing(self._h, 1, None, None, None, 1), "akz_comm_timing")
+
+    def _after(self):
+        self._torch.cuda.current_stream().wait_stream(self.stream)    # what follows on the caller's stream sees the rows
+
+    def shift(self, descs, counts, recv_descs, recv_counts):
+        cur = self._torch.cuda.current_stream()
+        self._lib.check(self._lib.lib().akz_comm_shift_blocks(
+            self._h, descs.data_ptr(), counts.data_ptr(), descs.shape[0], descs.shape[1], recv_descs.data_ptr(),
+            recv_counts.data_ptr(), cur.cuda_stream), "akz_comm_shift_blocks")
+        self._after()
+
+    def allgather(self, descs, counts, all_descs, all_counts):
+        cur = self._torch.cuda.current_stream()
+        self._lib.check(self._lib.lib().akz_comm_allgather_blocks(
+            self._h, descs.data_ptr(), counts.data_ptr(), descs.shape[0], descs.shape[1], all_descs.data_ptr(),
+            all_counts.data_ptr(), cur.cuda_stream), "akz_comm_allgather_blocks")
+        self._after()
+
+    def exposed(self):
+        """(milliseconds of transfers on the comm stream, calls, bytes) since the last call."""
+        C = self._C
+        ms, calls, nbytes = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._lib.check(self._lib.lib().akz_comm_timing(self._h, 1, C.byref(ms), C.byref(calls), C.byref(nbytes), 1), "akz_comm_timing")
+        return ms.value, calls.value, nbytes.value
+
+    def close(self):
+        if self._h:
+            self._lib.lib().akz_comm_destroy(self._h)
+            self._h = self._C.c_void_p()

@@ -32,7 +32,8 @@ typedef enum akz_status {
     AKZ_E_CAPACITY = -4,   /* caller buffer too small; *n_out = required */
     AKZ_E_HIP = -5,        /* a HIP runtime call failed (akz_last_hip_error()) */
     AKZ_E_TOO_LARGE = -6,  /* image or batch exceeds what the context was created for */
-    AKZ_E_INTERNAL = -7    /* device-side overflow of an internal work list */
+    AKZ_E_INTERNAL = -7,   /* device-side overflow of an internal work list */
+    AKZ_E_COMM = -8        /* an RCCL call failed, or librccl.so.1 could not be loaded (akz_comm_*) */
 } akz_status;
 
 /* akaze::Akaze — akaze/src/lib.rs:109-142 (fields), :169-185 (Default), :147-166 (new/sparse/dense).
@@ -455,6 +456,36 @@ void* rs_stream(rs_ctx* ctx);
  * call (any of the three pointers may be NULL) */
 int32_t rs_debug_scene(rs_ctx* ctx, uint32_t scene, uint32_t* n, double* bearings_a, double* bearings_b, uint32_t* order,
                        uint32_t cap);
+
+/* ---- the exchange step of the frame-sharded front-end ----
+ * Frames shard over the GPUs of a node as frame g -> rank g mod N (extraction is stateless per frame: akaze::Akaze is
+ * Copy, akaze/src/lib.rs:108).  A new frame is matched against its recent predecessors g-1 .. g-k (cv-sfm/src/lib.rs:
+ * 1462-1486; tracking_recent_frames = 32, cv-sfm/src/settings.rs:449-450), which live on the other ranks: the
+ * descriptor blocks a rank has extracted — fixed capacity, [n_frames][cap_per_img][64] bytes + [n_frames] u32 counts,
+ * exactly akz_extract_batch_device's outputs — travel by a ring shift (k = 1: a rank needs its predecessor's block) or
+ * by an all-gather (k >= N - 1).  RCCL directly (ncclSend/ncclRecv/ncclAllGather on akz_comm_stream()), loaded with
+ * dlopen("librccl.so.1") on first use.  One process per GPU; rank 0 makes the id, the host application hands it to the
+ * other ranks by its own means, every rank creates its communicator.  Calls enqueue and return; they wait for
+ * stream_to_wait (the producer of the send rows and last reader of the receive rows; may be NULL), consumers take
+ * akz_comm_stream() as their stream_to_wait. */
+typedef struct akz_comm akz_comm;
+int32_t akz_comm_unique_id(uint8_t* id128);                    /* 128 bytes (ncclUniqueId) */
+int32_t akz_comm_create(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, akz_comm** out);
+int32_t akz_comm_destroy(akz_comm* comm);
+/* this rank's blocks -> rank + 1; the blocks of rank - 1 -> d_recv_descs / d_recv_counts (same shapes) */
+int32_t akz_comm_shift_blocks(akz_comm* comm, const void* d_descs, const void* d_counts, uint32_t n_frames, uint32_t cap_per_img,
+                              void* d_recv_descs, void* d_recv_counts, void* stream_to_wait);
+/* every rank's blocks -> every rank: d_all_descs [world][n_frames][cap_per_img][64], d_all_counts [world][n_frames] */
+int32_t akz_comm_allgather_blocks(akz_comm* comm, const void* d_descs, const void* d_counts, uint32_t n_frames, uint32_t cap_per_img,
+                                  void* d_all_descs, void* d_all_counts, void* stream_to_wait);
+int32_t akz_comm_sync(akz_comm* comm);
+void* akz_comm_stream(akz_comm* comm);
+int32_t akz_comm_rank(akz_comm* comm);
+int32_t akz_comm_world(akz_comm* comm);
+/* HIP-event time of the transfers on akz_comm_stream() (their exposed time is what a step loses to them), call and byte
+ * counts since the last reset; `enable` switches the brackets on or off for the calls that follow. */
+int32_t akz_comm_timing(akz_comm* comm, int32_t enable, double* ms, uint64_t* calls, uint64_t* bytes, int32_t reset);
+const char* akz_comm_last_error_string(void);
 
 /* ---- misc ---- */
 const char* akz_strerror(int32_t status);

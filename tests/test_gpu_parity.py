@@ -2,6 +2,7 @@
 on the same inputs.  Bit-exact for every pyramid buffer, keypoint field, descriptor byte and match
 index (SURVEY.md §8d "Tolerances"; the angle is bit-exact too because both sides evaluate
 include/akz_portable_math.h)."""
+import json
 import os
 
 import numpy as np
@@ -1473,10 +1474,114 @@ def test_device_transcendentals_against_the_host_libm(gpu, oracle):
     g_si = np.array([libm.sinf(float(v)) for v in ang], np.float32)
     g_co = np.array([libm.cosf(float(v)) for v in ang], np.float32)
     assert _ulp_diff(at, g_at).max() <= 1 and _ulp_diff(si, g_si).max() <= 1 and _ulp_diff(co, g_co).max() <= 1
-    assert (at != g_at).mean() < 0.01 and (si != g_si).mean() < 0.03 and (co != g_co).mean() < 0.03
-    assert _ulp_diff(at, np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)).max() <= 1
+    # (glibc 2.35's atan2f / sinf / cosf are 0.5x-ulp functions, not correctly rounded: ~13 % / ~1 % of inputs are 1 ulp off
+    # the correctly rounded value, which is what the device returns in all but a handful of cases)
+    assert (si != g_si).mean() < 0.03 and (co != g_co).mean() < 0.03
+    cr_at = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    assert _ulp_diff(at, cr_at).max() <= 1 and (at != cr_at).mean() < 1e-4
     assert _ulp_diff(si, np.sin(ang.astype(np.float64)).astype(np.float32)).max() <= 1
     assert _ulp_diff(co, np.cos(ang.astype(np.float64)).astype(np.float32)).max() <= 1
     _eq(at, oracle.pm_atan2f(y, x), "device atan2f vs the oracle's build of akz_portable_math.h")
     os_, oc_ = oracle.pm_sincosf(ang)
     _eq(si, os_, "device sinf"); _eq(co, oc_, "device cosf")
+
+
+def test_comm_c_abi_on_one_rank(gpu):
+    """akz_comm_* (include/akz.h: the exchange step through the library itself, RCCL loaded with dlopen): a communicator of
+    ONE rank on the GPU — the ring shift is a send to oneself, the all-gather a copy — so the RCCL branch of the N > 1
+    path has executed on hardware before a multi-GPU run needs it: received rows byte-equal to the sent ones, rows outside
+    the transfer untouched, stream ordering through akz_comm_stream(), the timing bracket counts the bytes."""
+    import ctypes as C
+    import torch
+    from cv_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    ident = (C.c_uint8 * 128)()
+    _lib.check(L.akz_comm_unique_id(ident), "akz_comm_unique_id")
+    h = C.c_void_p()
+    _lib.check(L.akz_comm_create(ident, 0, 1, 0, C.byref(h)), "akz_comm_create")
+    try:
+        assert L.akz_comm_rank(h) == 0 and L.akz_comm_world(h) == 1
+        n, cap = 5, 512
+        g = torch.Generator(device=dev).manual_seed(3)
+        descs = torch.randint(0, 256, (n, cap, 64), generator=g, device=dev, dtype=torch.uint8)
+        counts = torch.arange(100, 100 + n, device=dev, dtype=torch.int32)
+        rd = torch.full((n + 2, cap, 64), 7, dtype=torch.uint8, device=dev)
+        rc = torch.full((n + 2,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(L.akz_comm_timing(h, 1, None, None, None, 1), "timing")
+        cur = torch.cuda.current_stream()
+        _lib.check(L.akz_comm_shift_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, rd[1:].data_ptr(), rc[1:].data_ptr(),
+                                           cur.cuda_stream), "akz_comm_shift_blocks")
+        ad = torch.zeros((1, n, cap, 64), dtype=torch.uint8, device=dev)
+        ac = torch.zeros((1, n), dtype=torch.int32, device=dev)
+        _lib.check(L.akz_comm_allgather_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, ad.data_ptr(), ac.data_ptr(), None),
+                   "akz_comm_allgather_blocks")
+        _lib.check(L.akz_comm_sync(h), "akz_comm_sync")
+        assert torch.equal(rd[1:n + 1], descs) and torch.equal(rc[1:n + 1], counts)
+        assert bool((rd[0] == 7).all()) and bool((rd[n + 1] == 7).all()) and int(rc[0]) == -1 and int(rc[n + 1]) == -1
+        assert torch.equal(ad[0], descs) and torch.equal(ac[0], counts)
+        ms, calls, nbytes = C.c_double(), C.c_uint64(), C.c_uint64()
+        _lib.check(L.akz_comm_timing(h, 0, C.byref(ms), C.byref(calls), C.byref(nbytes), 1), "timing")
+        assert calls.value == 2 and nbytes.value == 2 * n * (cap * 64 + 4) and ms.value > 0.0
+        # refusals
+        assert L.akz_comm_shift_blocks(h, None, counts.data_ptr(), n, cap, rd.data_ptr(), rc.data_ptr(), None) == -1
+        assert L.akz_comm_create(ident, 1, 1, 0, C.byref(C.c_void_p())) == -1
+    finally:
+        _lib.check(L.akz_comm_destroy(h), "akz_comm_destroy")
+
+
+@pytest.mark.parametrize("comm,exchange", [("akz", "shift"), ("akz", "allgather"), ("torch", "shift"), ("torch", "allgather")])
+def test_exchange_code_paths_on_one_rank(gpu, tmp_path, comm, exchange):
+    """bench.py's N > 1 code path with ONE rank on the real backends (--force-exchange: the rank sends to itself): the
+    library's own RCCL exchange (akz_comm_*) and torch.distributed's NCCL, ring shift and all-gather — the pair lists of
+    every frame must equal the plain single-rank run's.  (Two NCCL ranks cannot share a GPU, so this is as far as the
+    RCCL branches can be executed on a one-GPU box.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m1, m2 = tmp_path / "m1.npy", tmp_path / "m2.npy"
+    common = ["--frames", "16", "--micro-batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-isolated"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-matches", str(m1)] + common,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dump-matches", str(m2), "--force-exchange", "--comm", comm,
+                        "--exchange", exchange] + common, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert "multi_gpu" in line and line["multi_gpu"]["per_rank_frames_per_s"][0] > 0
+    assert np.array_equal(np.load(m1), np.load(m2))
+    a, b = np.load(str(m1) + ".r0.npz"), np.load(str(m2) + ".r0.npz")
+    for g in range(16):
+        assert np.array_equal(a[f"g{g}"], b[f"g{g}"]), f"pairs of frame {g} differ ({comm}, {exchange})"
+        assert len(a[f"g{g}"]) > 500
+
+
+def test_window_of_recent_views_two_ranks_equals_single_rank(gpu, tmp_path):
+    """Windowed matching across ranks (cv-sfm/src/lib.rs:1462-1486, tracking_recent_frames): every frame's features against
+    each of its K = 4 predecessors.  Two ranks (gloo, both on cuda:0) shard 24 global frames, all-gather their descriptor
+    blocks per micro-batch and search the gathered views; the neighbour lists of every global frame — [view][query][2]
+    {index, distance} — must equal, byte for byte, the single-rank run over the same frames."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m1, m2 = tmp_path / "w1.npy", tmp_path / "w2.npy"
+    common = ["--micro-batch", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-isolated", "--recent", "4"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "24", "--dump-matches", str(m1)] + common,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--frames", "12", "--backend", "gloo", "--share-device",
+                        "--dump-matches", str(m2)] + common,
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    single = np.load(str(m1) + ".r0.npz")
+    ranks = [np.load(str(m2) + f".r{r}.npz") for r in range(2)]
+    for g in range(24):
+        want, got = single[f"g{g}"], ranks[g % 2][f"g{g}"]
+        assert want.shape == got.shape and want.shape[0] == 4 and want.shape[1] > 1000, (g, want.shape, got.shape)
+        assert np.array_equal(want, got), f"neighbour lists of global frame {g} differ"
+    # the window really reaches back: view k of frame g is frame g - k (its first neighbour distances differ per view)
+    assert not np.array_equal(single["g10"][0], single["g10"][3])
