@@ -143,7 +143,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--parity-pairs", type=int, default=5, help="frame pairs from other batch positions held to the oracle "
                     "(2 oracle extractions each, ~1 s per 1080p frame)")
-    ap.add_argument("--cpu-procs", type=int, default=64, help="host processes of the all-cores CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=64, help="OpenMP threads of the all-cores CPU baseline (0 = skip; each "
+                    "thread holds a ~0.4 GB pyramid)")
     ap.add_argument("--no-pipeline", action="store_true", help="one buffer set in the library (AKZ_OPT_NO_PIPELINE): "
                     "consecutive calls do not overlap; for counter passes and serial phase profiles")
     ap.add_argument("--opt", action="append", default=[], help="akz_options field for the context, key=value (A/B runs; "
@@ -1020,56 +1021,50 @@ def sq_counters():
 
 
 def cpu_baseline(frames, n):
-    """The CPU oracle (a C restatement of the reference's akaze crate + BF matcher; kind 'port') on the
-    first n frames of the same workload, single thread, on this box's host cores.  Also returns what it computed
-    (keypoints, descriptors, match pairs per frame) so the caller can hold the GPU's output against it."""
+    """The CPU oracle (a C restatement of the reference's akaze crate + BF matcher; kind 'port') on the first n frames of
+    the same workload, single thread, on this box's host cores.  Two builds of the same sources: the -O2 CHECKER computes
+    what the GPU output is held to (returned: keypoints, descriptors, match pairs per frame); the -O3 -march=native build
+    (oracle/Makefile `fast`) is the one that is TIMED, after its outputs have been found bit-identical to the
+    checker's on these frames."""
     from oracle import oracle as O
     n = max(2, min(n, frames.shape[0]))
     host = frames[:n].cpu().numpy()
-    orc = O.Akaze(W, H, O.default_config())
     t0 = time.perf_counter()
-    prev = None
-    nk = 0
-    results = []
-    for i in range(n):
-        kp, d = orc.extract(host[i])
-        nk += len(d)
-        m = O.match(d, prev, rule=O.RULE_STRICT, param_u=24, symmetric=True) if prev is not None else None
-        results.append((kp, d, m))
-        prev = d
+    results = O.extract_match_many(host, threads=1, fast=False)
+    dt_checker = time.perf_counter() - t0
+    O.fast_lib()                                            # (build outside the timed region)
+    t0 = time.perf_counter()
+    fast = O.extract_match_many(host, threads=1, fast=True)
     dt = time.perf_counter() - t0
+    same = all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+               and ((a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])) for a, b in zip(results, fast))
+    if not same:
+        raise SystemExit("bench.py: the -O3 -march=native oracle build differs from the -O2 checker")
+    nk = sum(len(r[1]) for r in results)
     return ({"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
              "host_cores_available": os.cpu_count(),
+             "build": "oracle/Makefile fast: gcc -O3 -march=native -fopenmp -ffp-contract=off (no fast-math); outputs "
+                      "bit-identical to the -O2 checker on this sample (asserted before timing)",
+             "checker_frames_per_s": round(n / dt_checker, 3),
              "sample": f"first {n} frames of the bench batch: Akaze::default() extract + symmetric match vs previous "
                        f"frame, single thread, {dt:.1f} s, {nk // n} keypoints/frame"}, results)
 
 
-def _cpu_worker(args):
-    """One frame pair on one core: extract both frames with the oracle, match them symmetrically."""
-    a, b = args
+def cpu_baseline_all_cores(frames, threads):
+    """The same -O3 -march=native build with OpenMP over frames (one pyramid per thread, dynamic schedule): what the
+    reference's per-frame parallelism (cv-sfm extracts frame by frame; rayon inside a frame) could reach on this host."""
     from oracle import oracle as O
-    orc = O.Akaze(W, H, O.default_config())
-    _, da = orc.extract(a)
-    _, db = orc.extract(b)
-    O.match(db, da, rule=O.RULE_STRICT, param_u=24, symmetric=True)
-    return len(da) + len(db)
-
-
-def cpu_baseline_all_cores(frames, procs):
-    """The same oracle on `procs` host cores at once (one process per frame pair, nothing shared): what the
-    reference's per-frame parallelism (cv-sfm processes frames independently) could reach on this host."""
-    import multiprocessing as mp
-    procs = max(1, min(procs, os.cpu_count() or 1, frames.shape[0] // 2))
-    host = frames[:2 * procs].cpu().numpy()
-    tasks = [(host[2 * i], host[2 * i + 1]) for i in range(procs)]
-    ctx = mp.get_context("spawn")            # the parent holds a HIP context: never fork it
-    with ctx.Pool(procs) as pool:
-        pool.map(_cpu_worker, tasks[:1])     # warm the workers' imports (oracle build check, page-in)
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, tasks, chunksize=1)
-        dt = time.perf_counter() - t0
-    return {"value": round(2 * procs / dt, 2), "unit": "frames/s", "cores": procs, "kind": "port",
-            "sample": f"{procs} processes x 2 frames (extract both, one symmetric match), {dt:.1f} s"}
+    avail = O.threads_available()
+    threads = max(1, min(threads if threads > 0 else avail, avail, os.cpu_count() or 1))
+    n = min(frames.shape[0], 2 * threads)
+    host = frames[:n].cpu().numpy()
+    O.extract_match_many(host[:min(n, threads)], threads=threads, fast=True, match=False)     # page the workers' pyramids in
+    t0 = time.perf_counter()
+    O.extract_match_many(host, threads=threads, fast=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames, OpenMP over frames on {threads} threads (extract + symmetric match vs previous frame), {dt:.1f} s; "
+                      f"host reports {os.cpu_count()} logical CPUs"}
 
 
 if __name__ == "__main__":

@@ -157,10 +157,18 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             // a caller built against an older (shorter) struct passes its own size; unknown tail = defaults
             if (opts->struct_size < 2 * sizeof(uint32_t) || opts->struct_size > 4096) return AKZ_E_INVALID;
             memcpy(&o, opts, opts->struct_size < sizeof(o) ? opts->struct_size : sizeof(o));
+            // a caller built against a NEWER (longer) struct: fields this library does not know must be at their defaults
+            // (zero) — anything else would be dropped silently
+            for (uint32_t i = (uint32_t)sizeof(o); i < opts->struct_size; ++i)
+                if (reinterpret_cast<const unsigned char*>(opts)[i]) return AKZ_E_INVALID;
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
             if (o.flags & ~((AKZ_OPT_EQUAL_PRIORITY << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
+            // sizes that would only surface as an opaque allocation failure (or wrap in an int) otherwise
+            if (o.sup_capacity > (1u << 24) || o.max_candidates > kAkzMaxKeypoints || o.stream_waves > (1u << 24) ||
+                o.stream_min_waves > (1u << 24))
+                return AKZ_E_INVALID;
         }
         {
             // every per-frame table has kAkzMaxLevels slots per frame: refuse before anything is launched
@@ -445,6 +453,9 @@ static int32_t sync_all(akz_ctx* c)
 {
     AKZ_HIP(hipStreamSynchronize(c->stream));
     AKZ_HIP(hipStreamSynchronize(c->stream_kp));
+    // the determinant side stream joins the main stream at the end of a call's level loop only: a call that left that
+    // loop early (an error return) may still have kernels there that write this buffer set's candidate lists
+    if (c->stream_det) AKZ_HIP(hipStreamSynchronize(c->stream_det));
     c->kp_pending[0] = c->kp_pending[1] = false;
     return AKZ_OK;
 }
@@ -554,7 +565,10 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
         // ---- outputs: the last kernel writes them where the host can read them ----
         const size_t K = c->max_kp;
         const size_t head = 64 + (((size_t)n * sizeof(uint32_t) + 63) & ~(size_t)63);
-        const size_t out_bytes = head + (size_t)n * K * (sizeof(DevKp) + sizeof(akz_descriptor));
+        // (the descriptor block starts on a 64-byte boundary: the compaction kernel writes it with 16-byte stores and
+        // n * K * sizeof(DevKp) — 28-byte records — is a multiple of 16 only by accident)
+        const size_t kp_bytes = akz_align_up((size_t)n * K * sizeof(DevKp), 64);
+        const size_t out_bytes = head + kp_bytes + (size_t)n * K * sizeof(akz_descriptor);
         const bool stage_out = out_bytes <= kAkzHostStageMax && host_block(&c->h_out, &c->h_out_bytes, out_bytes) == AKZ_OK;
         akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
@@ -563,7 +577,7 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
             uint32_t* h_err = (uint32_t*)c->h_out;
             uint32_t* h_n = (uint32_t*)((char*)c->h_out + 64);
             DevKp* h_kp = (DevKp*)((char*)c->h_out + head);
-            akz_descriptor* h_desc = (akz_descriptor*)((char*)c->h_out + head + (size_t)n * K * sizeof(DevKp));
+            akz_descriptor* h_desc = (akz_descriptor*)((char*)c->h_out + head + kp_bytes);
             AKZ_TRY(akz_run_keypoints(c, n, h_kp, h_desc, c->max_kp, h_n, h_err));
             akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
             // the keypoint stream waited for the scale-space stream: its end is the end of the call
@@ -788,7 +802,7 @@ extern "C" int32_t akz_last_overflow(akz_ctx* c, akz_overflow_info* per_frame, u
             per_frame[f].needed_candidates = mx;               // the counters keep counting past the capacity
             per_frame[f].candidate_capacity = c->max_cand;
             per_frame[f].keypoint_capacity = c->max_kp;
-            per_frame[f].flags = (mx > c->max_cand ? 1u : 0u) | (ncache[f] >= c->max_kp ? 2u : 0u);
+            per_frame[f].flags = (mx > c->max_cand ? 1u : 0u) | (ncache[f] > c->max_kp ? 2u : 0u);
         }
         return AKZ_OK;
     });

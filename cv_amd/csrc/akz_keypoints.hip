@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
     const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
     DevKp* ch = cache + (size_t)frame * max_kp;
     uint32_t nact = 0, nslots = 0;  // wave-uniform
+    bool overflowed = false;        // wave-uniform: a list ran out of room (the call then fails with AKZ_E_INTERNAL)
     // chunk bounds live in registers: lane l holds [ymin, ymax] of chunks l and l + 64
     float bmin0 = 3.0e38f, bmax0 = -3.0e38f, bmin1 = 3.0e38f, bmax1 = -3.0e38f;
     for (int e = 0; e < T.n; ++e) {
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
                     slot = nslots;
                     if (!(slot < max_kp && ai < (uint32_t)kActCap && slot < (1u << 24))) {
                         if (lane == 0) *err = 2u;
+                        overflowed = true;
                         continue;
                     }
                     nact = ai + 1;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void k_suppress(LevelTable T, const uint32_t* _
         }
     }
     if (lane == 0) {
-        ncache[frame] = nslots;
+        ncache[frame] = overflowed ? max_kp + 1u : nslots;   // (> max_kp = "did not fit": akz_last_overflow; readers clip)
         lvl_slot[(size_t)frame * (kMaxLevels + 1) + T.n] = nslots;
     }
 }
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
     if (k1 < nchunks) return;                    // the workgroup of the last chunk finishes the frame
     if (tid == 0) {
         if (running > max_kp || running >= (1u << 24)) *err = 2u;
-        ncache[frame] = min(running, max_kp);
+        ncache[frame] = running;     // unclipped (every reader takes min(., max_kp)): akz_last_overflow reports what was needed
     }
     // first slot pushed at every level (k_filter_upper bounds its walks with it): the pushes before the level's
     // first candidate

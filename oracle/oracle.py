@@ -51,7 +51,7 @@ BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5, "Lxx": 6,
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "match_oracle.c", "ransac_oracle.c", "p3p_oracle.c", "color_oracle.c", "lsh_oracle.c", "arrsac_oracle.c",
-                                        "Makefile")]
+                                        "batch_oracle.c", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -560,3 +560,67 @@ def arrsac_pairs(kps_a, kps_b, pairs, cam_a, cam_b, threshold, n_hypotheses, sce
              "poses": int(st[4]) * 4}
     return {"pose": pose, "inliers": inl[:ninl.value].copy(), "best_id": best.value, "stats": stats,
             "bearings_a": ba[:n], "bearings_b": bb[:n], "order": order[:n]}
+
+
+# ---- the CPU baseline build (bench.py's cpu_baseline legs only) ----------------------------------------------------
+_FAST_PATH = os.path.join(_HERE, "liboracle_fast.so")
+_fast = None
+
+
+def _host_signature():
+    """-march=native code must run on the host it was built on: the build is keyed by the CPU's feature flags."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = sorted({ln for ln in f if ln.startswith(("flags", "model name"))})
+    except OSError:
+        flags = []
+    return hashlib.sha1("".join(flags).encode()).hexdigest()
+
+
+def fast_lib():
+    """liboracle_fast.so: the same sources at -O3 -march=native -fopenmp (oracle/Makefile, target `fast`), rebuilt when the
+    sources or the host CPU changed.  Only its batch entry is bound."""
+    global _fast
+    if _fast is None:
+        sig_path = _FAST_PATH + ".host"
+        src = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c") or f == "Makefile"]
+        stale = (not os.path.exists(_FAST_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_FAST_PATH) for s in src)
+                 or not os.path.exists(sig_path) or open(sig_path).read() != _host_signature())
+        if stale:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "fast"])
+            with open(sig_path, "w") as f:
+                f.write(_host_signature())
+        L = C.CDLL(_FAST_PATH)
+        _bind_batch(L)
+        _fast = L
+    return _fast
+
+
+def _bind_batch(L):
+    L.orc_threads_available.restype = C.c_int
+    L.orc_extract_match_many_u8.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+
+
+def extract_match_many(frames, threads=1, cap=8192, match=True, param_u=24, cfg=None, fast=True):
+    """oracle/batch_oracle.c: extract every frame ([n,h,w] u8) and match frame i symmetrically (d0 + param_u < d1) against
+    frame i-1, on `threads` OpenMP threads of the fast build (fast=False: the -O2 checker, single thread).  Returns a list
+    of (keypoints, descriptors, pairs-or-None) per frame."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    L = fast_lib() if fast else lib()
+    if not fast:
+        _bind_batch(L)
+    cfg = cfg if cfg is not None else default_config()
+    kps = np.zeros((n, cap), KP_DTYPE); descs = np.zeros((n, cap, 64), np.uint8); counts = np.zeros(n, np.uint32)
+    pairs = np.zeros((n, cap, 2), np.uint32); npairs = np.zeros(n, np.uint32)
+    r = L.orc_extract_match_many_u8(C.byref(cfg), w, h, frames.ctypes.data, n, int(threads), cap, kps.ctypes.data, descs.ctypes.data,
+                                    counts.ctypes.data, int(match), param_u, pairs.ctypes.data, npairs.ctypes.data)
+    assert r == 0, "a frame has more keypoints than cap"
+    return [(kps[i, :counts[i]].copy(), descs[i, :counts[i]].copy(), pairs[i, :npairs[i]].copy() if (match and i > 0) else None)
+            for i in range(n)]
+
+
+def threads_available():
+    return int(fast_lib().orc_threads_available())

@@ -207,3 +207,21 @@ def test_knn_general_k_matches_linear_knn_semantics(oracle):
         assert np.array_equal(g["distance"], np.take_along_axis(bits, order, 1).astype(np.uint32))
     short = O.knn(q, t[:2], 3)
     assert (short["index"][:, 2] == 0xFFFFFFFF).all() and (short["index"][:, :2] < 2).all()
+
+
+def test_cpu_baseline_build_is_the_checker_bit_for_bit(oracle):
+    """bench.py times a second build of the oracle's sources (-O3 -march=native -fopenmp, SURVEY.md 8d) as the CPU baseline;
+    it must be the same function: keypoints, descriptors and match pairs bit-identical to the -O2 checker, single- and
+    multi-threaded (OpenMP over frames only re-orders whole frames)."""
+    from conftest import synth_frame
+    frames = np.stack([synth_frame(480, 272, 40 + s) for s in range(5)])
+    want = oracle.extract_match_many(frames, threads=1, fast=False)
+    for threads in (1, 3):
+        got = oracle.extract_match_many(frames, threads=threads, fast=True)
+        for i, (a, b) in enumerate(zip(want, got)):
+            assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]), (threads, i)
+            assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2]), (threads, i)
+    single = oracle.Akaze(480, 272, oracle.default_config())
+    kp, d = single.extract(frames[2])
+    assert kp.tobytes() == want[2][0].tobytes() and np.array_equal(d, want[2][1])
+    assert len(kp) > 100
