@@ -119,7 +119,7 @@ assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "akz_config_default", "akz_create", "akz_create_ex", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_u16",
-    "akz_extract_gray_f32",
+    "akz_extract_gray_f32", "akz_extract_color",
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_last_overflow", "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
@@ -167,6 +167,7 @@ def lib():
     L.akz_extract_gray_u16.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_gray_f32.argtypes = [vp, vp, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
+    L.akz_extract_color.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, u32, C.POINTER(u32)]
     L.akz_extract_batch.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, vp, u32, vp]
     L.akz_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, u32, vp, vp]
     L.akz_scale_space_device.argtypes = [vp, vp, i32, i32, i32, i32, vp]

@@ -138,17 +138,35 @@ class Akaze:
             return self.extract(np.asarray(im))
         if im.mode == "LA":
             return self.extract(np.asarray(im)[..., 0])
-        return self.extract(grayscale(np.asarray(im.convert("RGB") if im.mode not in ("RGB", "RGBA") else im)))
+        return self.extract(np.asarray(im.convert("RGB") if im.mode not in ("RGB", "RGBA") else im))
 
     def extract_arrays(self, image):
-        """extract() returning the raw structured keypoint array instead of KeyPoint objects."""
+        """extract() returning the raw structured keypoint array instead of KeyPoint objects.  HxW images are the gray
+        arms of GrayFloatImage::from_dynamic; HxWx3 / HxWx4 images (uint8, uint16, float32) the colour ones —
+        DynamicImage::grayscale() runs on the device (akz_extract_color).
+
+        The reference's lists are unbounded (maximum_features = usize::MAX, lib.rs:172); the library's have a capacity fixed
+        at context creation.  A call that overflows it (AKZ_E_INTERNAL + akz_last_overflow) is repeated with a context of
+        twice the capacity, up to the library's 65 536 per frame — the caller sees the reference's behaviour, not the cap."""
         img = np.asarray(image)
-        if img.ndim != 2:
-            raise ValueError("expected a single-channel HxW image")
-        if img.dtype not in (np.uint8, np.uint16):   # Luma8 / Luma16 go to the device as they are (image.rs:47-66)
-            img = np.ascontiguousarray(img, dtype=np.float32)
-        h, w = img.shape
-        return self.context(w, h, 1).extract_batch([img])[0]
+        if img.ndim == 3 and img.shape[2] in (3, 4):
+            if img.dtype not in (np.uint8, np.uint16):
+                img = np.ascontiguousarray(img, dtype=np.float32)
+            run = lambda ctx: ctx.extract_color(img)
+        elif img.ndim == 2:
+            if img.dtype not in (np.uint8, np.uint16):   # Luma8 / Luma16 go to the device as they are (image.rs:47-66)
+                img = np.ascontiguousarray(img, dtype=np.float32)
+            run = lambda ctx: ctx.extract_batch([img])[0]
+        else:
+            raise ValueError("expected an HxW (gray) or HxWx3/4 (colour) image")
+        h, w = img.shape[:2]
+        while True:
+            try:
+                return run(self.context(w, h, 1))
+            except AkzError as e:
+                if e.status != -7 or self.max_keypoints >= MAX_KEYPOINTS:
+                    raise
+                self.max_keypoints = min(MAX_KEYPOINTS, 2 * int(self.max_keypoints))   # context() re-creates for the new key
 
 
 class Context:
@@ -201,6 +219,20 @@ class Context:
             raise AkzError(st, "akz_extract_batch: " + self.overflow_report())
         check(st, "akz_extract_batch")
         return [(kps[i, :cnt[i]].copy(), descs[i, :cnt[i]].copy()) for i in range(n)]
+
+    def extract_color(self, image):
+        """One HxWx3/4 uint8 / uint16 / float32 image through akz_extract_color.  Returns (kp_array, desc[n,64])."""
+        img = np.ascontiguousarray(image)
+        h, w, ch = img.shape
+        fmt = {np.dtype(np.uint8): _lib.FMT_U8, np.dtype(np.uint16): _lib.FMT_U16, np.dtype(np.float32): _lib.FMT_F32}[img.dtype]
+        cap = self.max_kp
+        kps = np.empty(cap, KP_DTYPE); descs = np.empty((cap, 64), np.uint8); cnt = C.c_uint32()
+        st = _lib.lib().akz_extract_color(self._h, img.ctypes.data, fmt, ch, w, h, w * ch, kps.ctypes.data, descs.ctypes.data, cap,
+                                          C.byref(cnt))
+        if st == -7:
+            raise AkzError(st, "akz_extract_color: " + self.overflow_report())
+        check(st, "akz_extract_color")
+        return kps[:cnt.value].copy(), descs[:cnt.value].copy()
 
     def overflow_report(self):
         """akz_last_overflow as text: which frame's internal list overflowed and what it needed."""

@@ -489,7 +489,7 @@ extern "C" int32_t akz_scale_space_device(akz_ctx* c, const void* d_imgs, int32_
         AKZ_TRY(akz_ctx_prepare(c, w, h));
         AKZ_TRY(begin_call(c));
         AKZ_TRY(wait_for(c, stream_to_wait));
-        c->cur_n = n;
+    c->cur_n = n;
         AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
         // completion is observable on akz_stream() like every other call
         AKZ_HIP(hipEventRecord(c->ev_ss_done[c->cur], c->stream));
@@ -512,13 +512,76 @@ extern "C" int32_t akz_extract_batch_device(akz_ctx* c, const void* d_imgs, int3
         AKZ_TRY(akz_ctx_prepare(c, w, h));
         AKZ_TRY(begin_call(c));
         AKZ_TRY(wait_for(c, stream_to_wait));
-        c->cur_n = n;
+    c->cur_n = n;
         akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
         AKZ_TRY(akz_run_scale_space(c, d_imgs, fmt, n));
         AKZ_TRY(akz_run_keypoints(c, n, (DevKp*)d_kps, (akz_descriptor*)d_descs, cap_per_img, (uint32_t*)d_n_out));
         akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
         return AKZ_OK;
     });
+}
+
+// second half of a host call: the frames are in S().d_in (fmt = their pixel format); run, and hand the outputs back
+static int32_t host_extract_finish(akz_ctx* c, int32_t fmt, int32_t n, akz_keypoint* kps, akz_descriptor* descs, uint32_t cap_per_img,
+                                   uint32_t* n_out)
+{
+    c->cur_n = n;
+    // ---- outputs: the last kernel writes them where the host can read them ----
+    const size_t K = c->max_kp;
+    const size_t head = 64 + (((size_t)n * sizeof(uint32_t) + 63) & ~(size_t)63);
+    // (the descriptor block starts on a 64-byte boundary: the compaction kernel writes it with 16-byte stores and
+    // n * K * sizeof(DevKp) — 28-byte records — is a multiple of 16 only by accident)
+    const size_t kp_bytes = akz_align_up((size_t)n * K * sizeof(DevKp), 64);
+    const size_t out_bytes = head + kp_bytes + (size_t)n * K * sizeof(akz_descriptor);
+    const bool stage_out = out_bytes <= kAkzHostStageMax && host_block(&c->h_out, &c->h_out_bytes, out_bytes) == AKZ_OK;
+    akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
+    AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
+    int32_t status = AKZ_OK;
+    if (stage_out) {
+        uint32_t* h_err = (uint32_t*)c->h_out;
+        uint32_t* h_n = (uint32_t*)((char*)c->h_out + 64);
+        DevKp* h_kp = (DevKp*)((char*)c->h_out + head);
+        akz_descriptor* h_desc = (akz_descriptor*)((char*)c->h_out + head + kp_bytes);
+        AKZ_TRY(akz_run_keypoints(c, n, h_kp, h_desc, c->max_kp, h_n, h_err));
+        akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
+        // the keypoint stream waited for the scale-space stream: its end is the end of the call
+        AKZ_HIP(hipStreamSynchronize(c->stream_kp));
+        c->kp_pending[c->cur] = false;
+        if (*h_err & ~4u) {
+            AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+            return AKZ_E_INTERNAL;
+        }
+        for (int i = 0; i < n; ++i) {
+            const uint32_t cnt = h_n[i];
+            n_out[i] = cnt;
+            if (cnt > c->max_kp) return AKZ_E_INTERNAL;
+            if (cnt > cap_per_img) status = AKZ_E_CAPACITY;
+            const uint32_t m = cnt < cap_per_img ? cnt : cap_per_img;
+            if (m) {
+                memcpy(kps + (size_t)i * cap_per_img, h_kp + (size_t)i * K, sizeof(akz_keypoint) * m);
+                memcpy(descs + (size_t)i * cap_per_img, h_desc + (size_t)i * K, sizeof(akz_descriptor) * m);
+            }
+        }
+        return status;
+    }
+    AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
+    akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
+    std::vector<uint32_t> cnt(n);
+    AKZ_TRY(check_device_err(c));  // synchronises both streams
+    AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        n_out[i] = cnt[i];
+        if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;
+        if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
+        uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
+        if (m) {
+            AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->S().d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
+                              hipMemcpyDeviceToHost));
+            AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->S().d_desc_out + (size_t)i * c->max_kp,
+                              sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
+        }
+    }
+    return status;
 }
 
 extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_t fmt, int32_t n, int32_t w, int32_t h,
@@ -561,63 +624,26 @@ extern "C" int32_t akz_extract_batch(akz_ctx* c, const void* const* imgs, int32_
                 AKZ_HIP(hipMemcpy2DAsync((char*)c->S().d_in + (size_t)i * P0 * esz, (size_t)w * esz, imgs[i], (size_t)stride * esz,
                                          (size_t)w * esz, (size_t)h, hipMemcpyHostToDevice, c->stream));
         }
-        c->cur_n = n;
-        // ---- outputs: the last kernel writes them where the host can read them ----
-        const size_t K = c->max_kp;
-        const size_t head = 64 + (((size_t)n * sizeof(uint32_t) + 63) & ~(size_t)63);
-        // (the descriptor block starts on a 64-byte boundary: the compaction kernel writes it with 16-byte stores and
-        // n * K * sizeof(DevKp) — 28-byte records — is a multiple of 16 only by accident)
-        const size_t kp_bytes = akz_align_up((size_t)n * K * sizeof(DevKp), 64);
-        const size_t out_bytes = head + kp_bytes + (size_t)n * K * sizeof(akz_descriptor);
-        const bool stage_out = out_bytes <= kAkzHostStageMax && host_block(&c->h_out, &c->h_out_bytes, out_bytes) == AKZ_OK;
-        akz_timer_begin(c, AKZ_T_EXTRACT, c->stream);
-        AKZ_TRY(akz_run_scale_space(c, c->S().d_in, fmt, n));
-        int32_t status = AKZ_OK;
-        if (stage_out) {
-            uint32_t* h_err = (uint32_t*)c->h_out;
-            uint32_t* h_n = (uint32_t*)((char*)c->h_out + 64);
-            DevKp* h_kp = (DevKp*)((char*)c->h_out + head);
-            akz_descriptor* h_desc = (akz_descriptor*)((char*)c->h_out + head + kp_bytes);
-            AKZ_TRY(akz_run_keypoints(c, n, h_kp, h_desc, c->max_kp, h_n, h_err));
-            akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
-            // the keypoint stream waited for the scale-space stream: its end is the end of the call
-            AKZ_HIP(hipStreamSynchronize(c->stream_kp));
-            c->kp_pending[c->cur] = false;
-            if (*h_err & ~4u) {
-                AKZ_HIP(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
-                return AKZ_E_INTERNAL;
-            }
-            for (int i = 0; i < n; ++i) {
-                const uint32_t cnt = h_n[i];
-                n_out[i] = cnt;
-                if (cnt > c->max_kp) return AKZ_E_INTERNAL;
-                if (cnt > cap_per_img) status = AKZ_E_CAPACITY;
-                const uint32_t m = cnt < cap_per_img ? cnt : cap_per_img;
-                if (m) {
-                    memcpy(kps + (size_t)i * cap_per_img, h_kp + (size_t)i * K, sizeof(akz_keypoint) * m);
-                    memcpy(descs + (size_t)i * cap_per_img, h_desc + (size_t)i * K, sizeof(akz_descriptor) * m);
-                }
-            }
-            return status;
-        }
-        AKZ_TRY(akz_run_keypoints(c, n, c->S().d_kp_out, c->S().d_desc_out, c->max_kp, c->S().d_n_out));
-        akz_timer_end(c, AKZ_T_EXTRACT, c->stream_kp, 0, (uint64_t)n);   // closes where the outputs complete
-        std::vector<uint32_t> cnt(n);
-        AKZ_TRY(check_device_err(c));  // synchronises both streams
-        AKZ_HIP(hipMemcpy(cnt.data(), c->S().d_n_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) {
-            n_out[i] = cnt[i];
-            if (cnt[i] > c->max_kp) return AKZ_E_INTERNAL;
-            if (cnt[i] > cap_per_img) status = AKZ_E_CAPACITY;
-            uint32_t m = cnt[i] < cap_per_img ? cnt[i] : cap_per_img;
-            if (m) {
-                AKZ_HIP(hipMemcpy(kps + (size_t)i * cap_per_img, c->S().d_kp_out + (size_t)i * c->max_kp, sizeof(akz_keypoint) * m,
-                                  hipMemcpyDeviceToHost));
-                AKZ_HIP(hipMemcpy(descs + (size_t)i * cap_per_img, c->S().d_desc_out + (size_t)i * c->max_kp,
-                                  sizeof(akz_descriptor) * m, hipMemcpyDeviceToHost));
-            }
-        }
-        return status;
+        return host_extract_finish(c, fmt, n, kps, descs, cap_per_img, n_out);
+    });
+}
+
+// Akaze::extract on a colour DynamicImage (ImageRgb8 / Rgba8 / Rgb16 / Rgba16 / Rgb32F / Rgba32F): akaze/src/image.rs:45-46
+// grayscale() first, then the matching gray arm.  pixels: h rows of `stride` ELEMENTS, `channels` (3 or 4) interleaved
+// samples per pixel; alpha is ignored, as grayscale() drops it.
+int32_t akz_color_to_input(akz_ctx* c, const void* pixels, int32_t fmt, int32_t channels, int32_t w, int32_t h, int32_t stride);
+extern "C" int32_t akz_extract_color(akz_ctx* c, const void* pixels, int32_t fmt, int32_t channels, int32_t w, int32_t h,
+                                     int32_t stride, akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !pixels || !n_out || (fmt < 0 || fmt > 2) || (channels != 3 && channels != 4) || stride < w * channels)
+            return AKZ_E_INVALID;
+        if (cap && (!kps || !descs)) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(akz_ctx_prepare(c, w, h));
+        AKZ_TRY(begin_call(c));
+        AKZ_TRY(akz_color_to_input(c, pixels, fmt, channels, w, h, stride));
+        return host_extract_finish(c, fmt, 1, kps, descs, cap, n_out);
     });
 }
 

@@ -86,3 +86,53 @@ extern "C" int32_t akz_sample_colors_rgb8(akz_ctx* c, const uint8_t* rgb, int32_
         return AKZ_OK;
     });
 }
+
+// ---- colour inputs: the arms of GrayFloatImage::from_dynamic that go through DynamicImage::grayscale() -------------
+// akaze/src/image.rs:45-46: `match input_image.grayscale()`.  For 8/16-bit RGB(A) the `image` crate (0.24, un-vendored:
+// [3P-unverified]) computes an integer Rec. 709 luma, (2126 R + 7152 G + 722 B) / 10000 in the next larger integer
+// type, truncating; the result is the Luma8 / Luma16 arm (image.rs:47-66).  Rgb32F / Rgba32F stay float through
+// grayscale() and take `to_luma()` per pixel (image.rs:87-106): the same weights in f64, narrowed to f32.
+// The conversion runs on the device into the context's input plane; everything after is the gray path.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void k_to_luma(const T* __restrict__ px, int channels, int w, int h, size_t stride, T* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)w * h) return;
+    const int y = (int)(i / (size_t)w), x = (int)(i - (size_t)y * w);
+    const T* p = px + (size_t)y * stride + (size_t)x * channels;
+    if (sizeof(T) == 4) {
+        const double l = ((2126.0 * (double)p[0] + 7152.0 * (double)p[1]) + 722.0 * (double)p[2]) / 10000.0;
+        out[i] = (T)l;
+    } else {
+        const unsigned long long l = (2126ull * (unsigned long long)p[0] + 7152ull * (unsigned long long)p[1] + 722ull * (unsigned long long)p[2]) / 10000ull;
+        out[i] = (T)l;
+    }
+}
+}  // namespace
+
+// device side of akz_extract_color: n = 1 interleaved image (host) -> luma plane in the context's input buffer
+int32_t akz_color_to_input(akz_ctx* c, const void* pixels, int32_t fmt, int32_t channels, int32_t w, int32_t h, int32_t stride)
+{
+    const size_t esz = fmt == AKZ_FMT_U8 ? 1 : (fmt == AKZ_FMT_U16 ? 2 : 4);
+    const size_t row = (size_t)w * channels * esz, bytes = row * h;
+    if (bytes > c->color_bytes) {
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_color) AKZ_HIP(hipFree(c->d_color));
+        c->d_color = nullptr;
+        c->color_bytes = 0;
+        AKZ_HIP(hipMalloc(&c->d_color, bytes));
+        c->color_bytes = bytes;
+    }
+    AKZ_HIP(hipMemcpy2DAsync(c->d_color, row, pixels, (size_t)stride * esz, row, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)(((size_t)w * h + 255) / 256));
+    const size_t st = (size_t)w * channels;
+    if (fmt == AKZ_FMT_U8)
+        hipLaunchKernelGGL(k_to_luma<uint8_t>, grid, dim3(256), 0, c->stream, (const uint8_t*)c->d_color, channels, w, h, st, (uint8_t*)c->S().d_in);
+    else if (fmt == AKZ_FMT_U16)
+        hipLaunchKernelGGL(k_to_luma<uint16_t>, grid, dim3(256), 0, c->stream, (const uint16_t*)c->d_color, channels, w, h, st, (uint16_t*)c->S().d_in);
+    else
+        hipLaunchKernelGGL(k_to_luma<float>, grid, dim3(256), 0, c->stream, (const float*)c->d_color, channels, w, h, st, (float*)c->S().d_in);
+    AKZ_LAUNCH_CHECK();
+    return AKZ_OK;
+}

@@ -19,7 +19,9 @@
 
 #include <array>
 #include <cstdint>
+#include <cstring>
 #include <limits>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -63,6 +65,82 @@ struct GrayFloatImage {
     int width, height, stride;
 };
 
+// A colour image view (DynamicImage::ImageRgb8 / Rgba8: what image.rs:45-46 sends through grayscale() first).
+struct ColorImageU8 {
+    const uint8_t* data;
+    int width, height, stride;   // stride in bytes
+    int channels;                // 3 (RGB) or 4 (RGBA)
+};
+
+namespace detail {
+// Device contexts are not part of akaze::Akaze (a Copy struct of eleven fields whose methods take &self and keep no
+// state, lib.rs:108-142): they live in a small per-thread cache keyed by everything a context is created from, so that
+// a loop of extract() calls — cv-sfm/src/lib.rs:2200-2204 — re-uses one pyramid instead of allocating ~0.2 GB per frame.
+struct CtxKey {
+    akz_config cfg;
+    int device, w, h;
+    uint32_t max_keypoints;
+    bool same(const CtxKey& o) const
+    {
+        return cfg.maximum_features == o.cfg.maximum_features && cfg.num_sublevels == o.cfg.num_sublevels &&
+               cfg.max_octave_evolution == o.cfg.max_octave_evolution && cfg.base_scale_offset == o.cfg.base_scale_offset &&
+               cfg.initial_contrast == o.cfg.initial_contrast && cfg.contrast_percentile == o.cfg.contrast_percentile &&
+               cfg.contrast_factor_num_bins == o.cfg.contrast_factor_num_bins && cfg.derivative_factor == o.cfg.derivative_factor &&
+               cfg.detector_threshold == o.cfg.detector_threshold && cfg.descriptor_channels == o.cfg.descriptor_channels &&
+               cfg.descriptor_pattern_size == o.cfg.descriptor_pattern_size && device == o.device && max_keypoints == o.max_keypoints;
+    }
+};
+struct CtxCache {
+    static constexpr int kSlots = 2;
+    struct Slot {
+        CtxKey key;
+        akz_ctx* ctx = nullptr;
+        uint64_t used = 0;
+    } slots[kSlots];
+    uint64_t tick = 0;
+    ~CtxCache()
+    {
+        for (Slot& s : slots)
+            if (s.ctx) akz_destroy(s.ctx);
+    }
+    akz_ctx* get(const CtxKey& k)
+    {
+        for (Slot& s : slots)
+            if (s.ctx && s.key.same(k) && k.w <= s.key.w && k.h <= s.key.h) {
+                s.used = ++tick;
+                return s.ctx;
+            }
+        Slot* victim = &slots[0];
+        for (Slot& s : slots) {
+            if (!s.ctx) {
+                victim = &s;
+                break;
+            }
+            if (s.used < victim->used) victim = &s;
+        }
+        if (victim->ctx) akz_destroy(victim->ctx);
+        victim->ctx = nullptr;
+        check(akz_create(&k.cfg, k.device, k.w, k.h, 1, k.max_keypoints, &victim->ctx), "akz_create");
+        victim->key = k;
+        victim->used = ++tick;
+        return victim->ctx;
+    }
+    void drop(akz_ctx* c)
+    {
+        for (Slot& s : slots)
+            if (s.ctx == c) {
+                akz_destroy(c);
+                s.ctx = nullptr;
+            }
+    }
+};
+inline CtxCache& ctx_cache()
+{
+    static thread_local CtxCache cache;
+    return cache;
+}
+}  // namespace detail
+
 class Akaze {
 public:
     // the reference's 11 public fields, same names and defaults (lib.rs:109-185)
@@ -79,19 +157,9 @@ public:
     std::size_t descriptor_pattern_size = 10;
     // placement (not part of the reference struct)
     int device = 0;
-    uint32_t max_keypoints = 16384;
-
-    Akaze() = default;
-    Akaze(const Akaze& o) { copy_fields(o); }
-    Akaze& operator=(const Akaze& o)
-    {
-        if (this != &o) {
-            release();
-            copy_fields(o);
-        }
-        return *this;
-    }
-    ~Akaze() { release(); }
+    // first capacity of the device's per-frame lists.  The reference's Vecs are unbounded; a call that overflows the
+    // capacity is repeated with twice as much (up to the library's 65 536 per frame), so this is a starting point only.
+    uint32_t initial_keypoint_capacity = 16384;
 
     static Akaze new_(double threshold)  // Akaze::new (lib.rs:147-152); `new` is reserved in C++
     {
@@ -102,27 +170,28 @@ public:
     static Akaze sparse() { return new_(0.01); }    // lib.rs:157-159
     static Akaze dense() { return new_(0.0001); }   // lib.rs:164-166
 
+    using Features = std::pair<std::vector<KeyPoint>, std::vector<BitArray64>>;
+
     // Akaze::extract on a Luma8 image (lib.rs:295)
-    std::pair<std::vector<KeyPoint>, std::vector<BitArray64>> extract(const GrayImageU8& img)
+    Features extract(const GrayImageU8& img) const
     {
-        ensure(img.width, img.height);
-        std::vector<akz_keypoint> k(max_keypoints);
-        std::vector<akz_descriptor> d(max_keypoints);
-        uint32_t n = 0;
-        check(akz_extract_gray_u8(ctx_, img.data, img.width, img.height, img.stride, k.data(), d.data(), max_keypoints, &n),
-              "akz_extract_gray_u8");
-        return convert(k, d, n);
+        return run(img.width, img.height, [&](akz_ctx* c, akz_keypoint* k, akz_descriptor* d, uint32_t cap, uint32_t* n) {
+            return akz_extract_gray_u8(c, img.data, img.width, img.height, img.stride, k, d, cap, n);
+        });
+    }
+    // Akaze::extract on a colour image: DynamicImage::grayscale() first (image.rs:45-46), on the device
+    Features extract(const ColorImageU8& img) const
+    {
+        return run(img.width, img.height, [&](akz_ctx* c, akz_keypoint* k, akz_descriptor* d, uint32_t cap, uint32_t* n) {
+            return akz_extract_color(c, img.data, AKZ_FMT_U8, img.channels, img.width, img.height, img.stride, k, d, cap, n);
+        });
     }
     // Akaze::extract_from_gray_float_image (lib.rs:309)
-    std::pair<std::vector<KeyPoint>, std::vector<BitArray64>> extract_from_gray_float_image(const GrayFloatImage& img)
+    Features extract_from_gray_float_image(const GrayFloatImage& img) const
     {
-        ensure(img.width, img.height);
-        std::vector<akz_keypoint> k(max_keypoints);
-        std::vector<akz_descriptor> d(max_keypoints);
-        uint32_t n = 0;
-        check(akz_extract_gray_f32(ctx_, img.data, img.width, img.height, img.stride, k.data(), d.data(), max_keypoints, &n),
-              "akz_extract_gray_f32");
-        return convert(k, d, n);
+        return run(img.width, img.height, [&](akz_ctx* c, akz_keypoint* k, akz_descriptor* d, uint32_t cap, uint32_t* n) {
+            return akz_extract_gray_f32(c, img.data, img.width, img.height, img.stride, k, d, cap, n);
+        });
     }
 
     akz_config config() const
@@ -143,44 +212,33 @@ public:
     }
 
 private:
-    akz_ctx* ctx_ = nullptr;
-    int ctx_w_ = 0, ctx_h_ = 0;
-
-    void copy_fields(const Akaze& o)
+    // one call, with growth: AKZ_E_INTERNAL (a device list overflowed) and AKZ_E_CAPACITY (more keypoints than the output
+    // arrays hold) both mean "not enough room" — the reference has no such thing, so the call is repeated with more
+    template <typename Call>
+    Features run(int w, int h, Call call) const
     {
-        maximum_features = o.maximum_features;
-        num_sublevels = o.num_sublevels;
-        max_octave_evolution = o.max_octave_evolution;
-        base_scale_offset = o.base_scale_offset;
-        initial_contrast = o.initial_contrast;
-        contrast_percentile = o.contrast_percentile;
-        contrast_factor_num_bins = o.contrast_factor_num_bins;
-        derivative_factor = o.derivative_factor;
-        detector_threshold = o.detector_threshold;
-        descriptor_channels = o.descriptor_channels;
-        descriptor_pattern_size = o.descriptor_pattern_size;
-        device = o.device;
-        max_keypoints = o.max_keypoints;
+        constexpr uint32_t kLibraryMax = 65536;
+        uint32_t cap = initial_keypoint_capacity < 64 ? 64 : (initial_keypoint_capacity > kLibraryMax ? kLibraryMax : initial_keypoint_capacity);
+        if ((uint64_t)maximum_features < cap) cap = (uint32_t)(maximum_features < 64 ? 64 : maximum_features);
+        for (;;) {
+            detail::CtxKey key{config(), device, w, h, cap};
+            akz_ctx* c = detail::ctx_cache().get(key);
+            std::vector<akz_keypoint> k(cap);
+            std::vector<akz_descriptor> d(cap);
+            uint32_t n = 0;
+            const int32_t st = call(c, k.data(), d.data(), cap, &n);
+            if (st == AKZ_OK) return convert(k, d, n);
+            if ((st == AKZ_E_INTERNAL || st == AKZ_E_CAPACITY) && cap < kLibraryMax) {
+                detail::ctx_cache().drop(c);
+                cap = cap * 2 > kLibraryMax ? kLibraryMax : cap * 2;
+                continue;
+            }
+            check(st, "akz_extract");
+        }
     }
-    void release()
+    static Features convert(const std::vector<akz_keypoint>& k, const std::vector<akz_descriptor>& d, uint32_t n)
     {
-        if (ctx_) akz_destroy(ctx_);
-        ctx_ = nullptr;
-    }
-    void ensure(int w, int h)
-    {
-        if (ctx_ && w <= ctx_w_ && h <= ctx_h_) return;
-        release();
-        akz_config c = config();
-        check(akz_create(&c, device, w, h, 1, max_keypoints, &ctx_), "akz_create");
-        ctx_w_ = w;
-        ctx_h_ = h;
-    }
-    static std::pair<std::vector<KeyPoint>, std::vector<BitArray64>> convert(const std::vector<akz_keypoint>& k,
-                                                                             const std::vector<akz_descriptor>& d,
-                                                                             uint32_t n)
-    {
-        std::pair<std::vector<KeyPoint>, std::vector<BitArray64>> out;
+        Features out;
         out.first.reserve(n);
         out.second.reserve(n);
         for (uint32_t i = 0; i < n; ++i) {
@@ -287,6 +345,164 @@ inline std::vector<std::array<std::size_t, 2>> match_descriptors(Matcher& m, con
 }
 
 }  // namespace space
+
+// ---- two-view / registration consensus: the sample_consensus::Consensus surface over rs_* -------------------------
+//   cv_core::FeatureMatch(a, b) / FeatureWorldMatch(bearing, world)        cv-core/src/matches.rs
+//   cv_pinhole::CameraIntrinsics::calibrate                                 cv-pinhole/src/lib.rs:108-117
+//   eight_point::EightPoint, lambda_twist::LambdaTwist (Estimator)          eight-point/src/lib.rs:60-83, lambda-twist/src/lib.rs:330-347
+//   arrsac::Arrsac::{new, initialization_hypotheses, max_candidate_hypotheses, estimations_per_block, block_size,
+//                    likelihood_ratio_threshold} + Consensus::{model, model_inliers}
+//                                                                           call sites akaze/tests/estimate_pose.rs:63-75,
+//                                                                           vslam-sandbox/src/main.rs:105-117, cv-sfm/src/lib.rs:1394-1412
+// The arrsac crate is not vendored in the reference: what runs is this library's ARRSAC-shaped procedure (include/akz.h:
+// rs_essential_arrsac / rs_p3p_arrsac, specified by oracle/arrsac_oracle.c); the builder names are the crate's.
+namespace cv_core {
+struct FeatureMatch {
+    std::array<double, 3> a, b;       // unit bearings of the two views
+};
+struct FeatureWorldMatch {
+    std::array<double, 3> bearing;    // unit bearing in the camera
+    std::array<double, 4> world;      // homogeneous world point (Projective form: xyz normalised, w = 1 / distance)
+};
+struct CameraToCamera {
+    std::array<double, 12> rt;        // row-major 3 x 4 [R | t]
+};
+struct WorldToCamera {
+    std::array<double, 12> rt;
+};
+}  // namespace cv_core
+
+namespace cv_pinhole {
+struct CameraIntrinsics {
+    std::array<double, 2> focals, principal_point;
+    double skew = 0.0;
+    // CameraModel::calibrate (lib.rs:108-117): pixel keypoint -> unit bearing
+    std::array<double, 3> calibrate(const akaze::KeyPoint& kp) const
+    {
+        const double intr[5] = {focals[0], focals[1], principal_point[0], principal_point[1], skew};
+        akz_keypoint k{};
+        k.x = kp.point.first;
+        k.y = kp.point.second;
+        std::array<double, 3> out{};
+        akaze::check(rs_calibrate(intr, 0, 0.0, &k, 1, out.data()), "rs_calibrate");
+        return out;
+    }
+};
+}  // namespace cv_pinhole
+
+namespace eight_point {
+struct EightPoint {
+    static constexpr std::size_t MIN_SAMPLES = 8;   // eight-point/src/lib.rs:73
+};
+}  // namespace eight_point
+namespace lambda_twist {
+struct LambdaTwist {
+    static constexpr std::size_t MIN_SAMPLES = 3;   // lambda-twist/src/lib.rs:333
+};
+}  // namespace lambda_twist
+
+namespace arrsac {
+
+class Arrsac {
+public:
+    // Arrsac::new(inlier_threshold, rng): the rng is a seed here (the sampler is the library's xoshiro256++ streams)
+    Arrsac(double inlier_threshold, uint64_t seed = 0, int device = 0) : device_(device)
+    {
+        std::memset(&p_, 0, sizeof(p_));
+        p_.struct_size = sizeof(p_);
+        p_.n_hypotheses = 256;
+        p_.block_size = 64;
+        p_.init_blocks = 1;
+        p_.max_candidates = 64;
+        p_.flags = RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE;
+        p_.threshold = inlier_threshold;
+        p_.sprt_delta = 0.05;
+        p_.sprt_ratio = 1e3;
+        p_.seed = seed;
+        p_.estimations_per_block = 0;
+    }
+    ~Arrsac()
+    {
+        if (ctx_) rs_destroy(ctx_);
+    }
+    Arrsac(const Arrsac&) = delete;
+    Arrsac& operator=(const Arrsac&) = delete;
+    Arrsac(Arrsac&& o) noexcept : p_(o.p_), device_(o.device_), ctx_(o.ctx_), cap_m_(o.cap_m_), cap_h_(o.cap_h_) { o.ctx_ = nullptr; }
+
+    // the crate's builder methods (vslam-sandbox/src/main.rs:105-117)
+    Arrsac&& initialization_hypotheses(uint32_t n) && { p_.n_hypotheses = n; return std::move(*this); }
+    Arrsac&& max_candidate_hypotheses(uint32_t n) && { p_.max_candidates = n; return std::move(*this); }
+    Arrsac&& estimations_per_block(uint32_t n) && { p_.estimations_per_block = n; return std::move(*this); }
+    Arrsac&& block_size(uint32_t n) && { p_.block_size = n; return std::move(*this); }
+    Arrsac&& initialization_blocks(uint32_t n) && { p_.init_blocks = n; return std::move(*this); }
+    Arrsac&& likelihood_ratio_threshold(double r) && { p_.sprt_ratio = r; return std::move(*this); }
+
+    // Consensus<EightPoint, FeatureMatch>::model_inliers (eight-point/src/lib.rs:70-83 estimates, cv-core/src/pose.rs:249-295 scores)
+    std::optional<std::pair<cv_core::CameraToCamera, std::vector<std::size_t>>> model_inliers(const eight_point::EightPoint&,
+                                                                                              const std::vector<cv_core::FeatureMatch>& data)
+    {
+        if (data.size() < eight_point::EightPoint::MIN_SAMPLES) return std::nullopt;
+        std::vector<double> a(3 * data.size()), b(3 * data.size());
+        for (std::size_t i = 0; i < data.size(); ++i)
+            for (int k = 0; k < 3; ++k) {
+                a[3 * i + k] = data[i].a[k];
+                b[3 * i + k] = data[i].b[k];
+            }
+        cv_core::CameraToCamera pose{};
+        std::vector<std::size_t> inl;
+        if (!run(false, a.data(), b.data(), (uint32_t)data.size(), pose.rt.data(), &inl)) return std::nullopt;
+        return std::make_pair(pose, std::move(inl));
+    }
+    std::optional<cv_core::CameraToCamera> model(const eight_point::EightPoint& e, const std::vector<cv_core::FeatureMatch>& data)
+    {
+        auto r = model_inliers(e, data);
+        if (!r) return std::nullopt;
+        return r->first;
+    }
+    // Consensus<LambdaTwist, FeatureWorldMatch>::model_inliers (lambda-twist/src/lib.rs:330-347, cv-core/src/pose.rs:194-201)
+    std::optional<std::pair<cv_core::WorldToCamera, std::vector<std::size_t>>> model_inliers(const lambda_twist::LambdaTwist&,
+                                                                                             const std::vector<cv_core::FeatureWorldMatch>& data)
+    {
+        if (data.size() < lambda_twist::LambdaTwist::MIN_SAMPLES) return std::nullopt;
+        std::vector<double> a(3 * data.size()), w(4 * data.size());
+        for (std::size_t i = 0; i < data.size(); ++i) {
+            for (int k = 0; k < 3; ++k) a[3 * i + k] = data[i].bearing[k];
+            for (int k = 0; k < 4; ++k) w[4 * i + k] = data[i].world[k];
+        }
+        cv_core::WorldToCamera pose{};
+        std::vector<std::size_t> inl;
+        if (!run(true, a.data(), w.data(), (uint32_t)data.size(), pose.rt.data(), &inl)) return std::nullopt;
+        return std::make_pair(pose, std::move(inl));
+    }
+
+private:
+    bool run(bool p3p, const double* a, const double* b, uint32_t n, double* pose, std::vector<std::size_t>* inl)
+    {
+        const uint32_t blocks = (n + p_.block_size - 1) / p_.block_size;
+        const uint32_t need_h = p_.n_hypotheses + p_.estimations_per_block * blocks;
+        if (!ctx_ || n > cap_m_ || need_h > cap_h_) {
+            if (ctx_) rs_destroy(ctx_);
+            ctx_ = nullptr;
+            cap_m_ = n < 64 ? 64 : n;
+            cap_h_ = need_h;
+            akaze::check(rs_create(device_, cap_m_, cap_h_, &ctx_), "rs_create");
+        }
+        std::vector<uint32_t> idx(n);
+        uint32_t best = 0, ninl = 0;
+        const int32_t st = p3p ? rs_p3p_arrsac(ctx_, a, b, n, nullptr, &p_, pose, &best, idx.data(), n, &ninl, nullptr)
+                               : rs_essential_arrsac(ctx_, a, b, n, nullptr, &p_, pose, &best, idx.data(), n, &ninl, nullptr);
+        akaze::check(st, p3p ? "rs_p3p_arrsac" : "rs_essential_arrsac");
+        if (best == 0xFFFFFFFFu) return false;     // Consensus::model_inliers returned None
+        inl->assign(idx.begin(), idx.begin() + ninl);
+        return true;
+    }
+    rs_arrsac_params p_;
+    int device_;
+    rs_ctx* ctx_ = nullptr;
+    uint32_t cap_m_ = 0, cap_h_ = 0;
+};
+
+}  // namespace arrsac
 
 // hamming_lsh::HammingHasher<64, H> and the lsh_to_frame map of cv-sfm (cv-sfm/src/lib.rs:205-217, 672, 622-624) over
 // hm_hash_bag / hm_hash_knn.  The hashing crate is not vendored in the reference: see oracle/lsh_oracle.c for what

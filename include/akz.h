@@ -139,6 +139,15 @@ int32_t akz_extract_gray_u16(akz_ctx* ctx, const uint16_t* img, int32_t w, int32
 int32_t akz_extract_gray_f32(akz_ctx* ctx, const float* img, int32_t w, int32_t h, int32_t stride,
                              akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
 
+/* Akaze::extract on a COLOUR DynamicImage (akaze/src/image.rs:45-46: `input_image.grayscale()` first): 8- and 16-bit
+ * RGB(A) become Luma8 / Luma16 by the `image` crate's integer Rec. 709 luma, (2126 R + 7152 G + 722 B) / 10000
+ * truncating, and take the arms of image.rs:47-66; Rgb32F / Rgba32F keep their floats and take `to_luma()` per pixel
+ * (image.rs:87-106: the same weights in f64, narrowed to f32).  The `image` crate is not vendored in the reference:
+ * colour-input parity is unpinned (oracle/color_oracle.c restates the published formula).  pixels: host memory, h rows
+ * of `stride` ELEMENTS, `channels` = 3 or 4 interleaved samples per pixel (alpha ignored); fmt = AKZ_FMT_* of a sample. */
+int32_t akz_extract_color(akz_ctx* ctx, const void* pixels, int32_t fmt, int32_t channels, int32_t w, int32_t h, int32_t stride,
+                          akz_keypoint* kps, akz_descriptor* descs, uint32_t cap, uint32_t* n_out);
+
 /* Pixel formats of the batched / device entry points: the arms of GrayFloatImage::from_dynamic
  * (akaze/src/image.rs:45-109) that need no colour conversion. */
 enum { AKZ_FMT_U8 = 0 /* Luma8: v / 255 */, AKZ_FMT_F32 = 1 /* GrayFloatImage, [0,1] */, AKZ_FMT_U16 = 2 /* Luma16: v / 65535 */ };

@@ -54,3 +54,26 @@ int orc_sample_colors_rgb8(const uint8_t* rgb, int w, int h, const akz_keypoint*
     }
     return 0;
 }
+
+/* DynamicImage::grayscale() of a colour image, then the sample type's arm of GrayFloatImage::from_dynamic
+ * (akaze/src/image.rs:45-109).  The `image` crate (0.24) is not vendored: its published conversion is
+ *   rgb_to_luma: l = 2126 R + 7152 G + 722 B in the next larger type (u32 / u64 / f64), l / 10000, narrowed
+ * — integer division truncates; f32 pixels go through f64.  PARITY UNPINNED [3P].  fmt: AKZ_FMT_*; channels 3 or 4
+ * (alpha ignored); stride in elements; out: w*h samples of the same type. */
+void orc_luma(const void* in, int fmt, int channels, int w, int h, int stride, void* out)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t i = (size_t)y * stride + (size_t)x * channels, o = (size_t)y * w + x;
+            if (fmt == AKZ_FMT_U8) {
+                const uint8_t* p = (const uint8_t*)in + i;
+                ((uint8_t*)out)[o] = (uint8_t)((2126u * p[0] + 7152u * p[1] + 722u * p[2]) / 10000u);
+            } else if (fmt == AKZ_FMT_U16) {
+                const uint16_t* p = (const uint16_t*)in + i;
+                ((uint16_t*)out)[o] = (uint16_t)((2126ull * p[0] + 7152ull * p[1] + 722ull * p[2]) / 10000ull);
+            } else {
+                const float* p = (const float*)in + i;
+                ((float*)out)[o] = (float)(((2126.0 * (double)p[0] + 7152.0 * (double)p[1]) + 722.0 * (double)p[2]) / 10000.0);
+            }
+        }
+}

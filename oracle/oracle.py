@@ -116,6 +116,7 @@ def lib():
         L.orc_shuffle_order.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
         L.orc_scene_seed.restype = C.c_uint64
         L.orc_scene_seed.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_best_of_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_match.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
@@ -624,3 +625,13 @@ def extract_match_many(frames, threads=1, cap=8192, match=True, param_u=24, cfg=
 
 def threads_available():
     return int(fast_lib().orc_threads_available())
+
+
+def luma(img):
+    """DynamicImage::grayscale() restated (oracle/color_oracle.c: orc_luma): HxWx3/4 uint8 / uint16 / float32 -> HxW."""
+    a = np.ascontiguousarray(img)
+    fmt = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2}[a.dtype]
+    h, w, ch = a.shape
+    out = np.empty((h, w), a.dtype)
+    lib().orc_luma(a.ctypes.data, fmt, ch, w, h, w * ch, out.ctypes.data)
+    return out

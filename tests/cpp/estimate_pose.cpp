@@ -2,7 +2,9 @@
 // against the C++ host-side mirror (include/akaze.hpp), i.e. through the C ABI of libakz.so:
 //   Akaze::sparse().extract x2 on the two KITTI frames -> exactly 399 and 343 descriptors,
 //   space::LinearKnn{Hamming}.knn(d, 2) + Lowe ratio 0.5 -> exactly 11 matches.
-// (The ARRSAC + eight-point stage of the reference test is the second-phase path, see DESIGN.md.)
+//   calibrate with K_00 -> Arrsac::new(0.1, rng) + EightPoint::new() -> model_inliers -> exactly 11 inliers (:63-75).
+// Also checked here, because only a native caller can: the per-thread context cache (a second extract of the same size
+// re-uses the pyramid) and the growth of the device lists (a first capacity far too small still gives 399 descriptors).
 // usage: estimate_pose frame0.raw frame14.raw width height
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +69,37 @@ int main(int argc, char** argv)
             if (matches[i].first != batched[i][0] || matches[i].second != batched[i][1]) return 1;
         auto sym = space::symmetric_matching(m, r1.second, r2.second);
         printf("symmetric better-by-24 matches %zu\n", sym.size());
+        // estimate_pose.rs:28-32, 61-75: K_00 of the KITTI sequence, Arrsac::new(0.1, ..) + EightPoint::new()
+        cv_pinhole::CameraIntrinsics intrinsics{{9.842439e+02, 9.808141e+02}, {6.900000e+02, 2.331966e+02}, 0.0};
+        std::vector<cv_core::FeatureMatch> fm;
+        for (auto& mt : matches)
+            fm.push_back(cv_core::FeatureMatch{intrinsics.calibrate(r1.first[mt.first]), intrinsics.calibrate(r2.first[mt.second])});
+        arrsac::Arrsac consensus(0.1, 1);
+        auto res = consensus.model_inliers(eight_point::EightPoint{}, fm);
+        if (!res) return 1;
+        printf("inliers %zu\n", res->second.size());
+        if (res->second.size() != 11) return 1;                              // estimate_pose.rs:75
+        for (size_t i = 0; i < 11; ++i)
+            if (res->second[i] != i) return 1;
+        // R of the recovered pose is a rotation
+        const auto& rt = res->first.rt;
+        double det = rt[0] * (rt[5] * rt[10] - rt[6] * rt[9]) - rt[1] * (rt[4] * rt[10] - rt[6] * rt[8]) + rt[2] * (rt[4] * rt[9] - rt[5] * rt[8]);
+        if (det < 0.999999 || det > 1.000001) return 1;
+        // fewer matches than a minimal sample: None
+        std::vector<cv_core::FeatureMatch> few(fm.begin(), fm.begin() + 7);
+        if (consensus.model_inliers(eight_point::EightPoint{}, few)) return 1;
+        // growth: a first capacity of 64 keypoints per frame still ends with the reference's 399
+        akaze::Akaze tiny = akaze::Akaze::sparse();
+        tiny.initial_keypoint_capacity = 64;
+        auto rg = tiny.extract(akaze::GrayImageU8{f0.data(), w, h, w});
+        printf("grown %zu\n", rg.second.size());
+        if (rg.second.size() != 399 || rg.second != r1.second) return 1;
+        // a colour view of the same frame (R = G = B = the gray value: integer Rec. 709 luma gives it back exactly)
+        std::vector<uint8_t> rgb((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; ++i) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = f0[i];
+        auto rc = akaze::Akaze::sparse().extract(akaze::ColorImageU8{rgb.data(), w, h, 3 * w, 3});
+        printf("colour %zu\n", rc.second.size());
+        if (rc.second != r1.second) return 1;
     } catch (const akaze::Error& e) {
         fprintf(stderr, "akaze error: %s\n", e.what());
         return 3;

@@ -617,8 +617,9 @@ def test_tutorial_ch5_symmetric_matching(gpu, oracle, kitti, kitti_golden):
 
 
 def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
-    """The reference's integration test (akaze/tests/estimate_pose.rs:24-59) restated in C++ against
-    include/akaze.hpp and run as a separate native process linked to libakz.so."""
+    """The reference's integration test (akaze/tests/estimate_pose.rs:24-76: extract, match, calibrate, Arrsac + EightPoint
+    consensus -> 11 inliers) restated in C++ against include/akaze.hpp — the twin of the Rust shim — and run as a separate
+    native process linked to libakz.so; plus the context cache, list growth and the colour arm from a native caller."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "estimate_pose"
@@ -632,6 +633,7 @@ def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
     r = subprocess.run([str(exe), str(f0), str(f1), str(w), str(h)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "descriptors 399 343" in r.stdout and "matches 11" in r.stdout
+    assert "inliers 11" in r.stdout and "grown 399" in r.stdout and "colour 399" in r.stdout and "estimate_pose ok" in r.stdout
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1585,3 +1587,64 @@ def test_window_of_recent_views_two_ranks_equals_single_rank(gpu, tmp_path):
         assert np.array_equal(want, got), f"neighbour lists of global frame {g} differ"
     # the window really reaches back: view k of frame g is frame g - k (its first neighbour distances differ per view)
     assert not np.array_equal(single["g10"][0], single["g10"][3])
+
+
+@pytest.mark.parametrize("dtype,channels", [(np.uint8, 3), (np.uint8, 4), (np.uint16, 3), (np.float32, 3), (np.float32, 4)])
+def test_colour_input_arms(gpu, oracle, dtype, channels):
+    """The colour arms of GrayFloatImage::from_dynamic (akaze/src/image.rs:45-46, 87-106) on the C ABI (akz_extract_color):
+    DynamicImage::grayscale() on the device, then the gray path — keypoints and descriptors equal the oracle's on the
+    oracle's luma plane (oracle/color_oracle.c: orc_luma), and the luma plane itself is what the numpy restatement of the
+    `image` crate's formula gives."""
+    akaze, _ = gpu
+    rng = np.random.default_rng(0xC0 + channels)
+    h, w = 200, 336
+    base = synth_frame(w, h, 91).astype(np.float64)
+    planes = [np.clip(base * f + rng.uniform(-12, 12, (h, w)), 0, 255) for f in (1.0, 0.8, 1.15)]
+    if channels == 4:
+        planes.append(rng.uniform(0, 255, (h, w)))
+    img = np.stack(planes, 2)
+    if dtype == np.uint8:
+        img = img.astype(np.uint8)
+    elif dtype == np.uint16:
+        img = (img * 257.0).astype(np.uint16)
+    else:
+        img = (img / 255.0).astype(np.float32)
+    luma = oracle.luma(img)
+    if dtype == np.float32:
+        want_l = ((2126.0 * img[..., 0].astype(np.float64) + 7152.0 * img[..., 1].astype(np.float64))
+                  + 722.0 * img[..., 2].astype(np.float64)) / 10000.0
+        assert np.array_equal(luma, want_l.astype(np.float32))
+    else:
+        want_l = (2126 * img[..., 0].astype(np.uint64) + 7152 * img[..., 1].astype(np.uint64) + 722 * img[..., 2].astype(np.uint64)) // 10000
+        assert np.array_equal(luma, want_l.astype(dtype))
+    ak = akaze.Akaze.default()
+    kp, d = ak.extract_arrays(img)
+    okp, od = oracle.Akaze(w, h, oracle.default_config()).extract(luma)
+    assert len(kp) == len(okp) > 50
+    _eq(kp.view(np.uint8), okp.view(np.uint8), f"colour arm keypoints ({dtype.__name__} x{channels})")
+    _eq(d, od, "colour arm descriptors")
+    # the same luma plane through the gray entry gives the same result
+    kp2, d2 = ak.extract_arrays(luma)
+    assert kp2.tobytes() == kp.tobytes() and np.array_equal(d2, d)
+
+
+def test_capacity_grows_instead_of_failing(gpu, oracle):
+    """The reference's keypoint Vecs are unbounded (maximum_features = usize::MAX, akaze/src/lib.rs:172).  The library's
+    lists have a capacity fixed at context creation; the host mirror repeats a call that overflowed it with twice the
+    capacity (AKZ_E_INTERNAL + akz_last_overflow -> a larger context), so a caller sees the reference's result."""
+    akaze, _ = gpu
+    img = synth_frame(640, 360, 17)
+    want_kp, want_d = oracle.Akaze(640, 360, oracle.default_config()).extract(img)
+    assert len(want_kp) > 500
+    ak = akaze.Akaze.default()
+    ak.max_keypoints = 128                       # far too small: every list overflows
+    kp, d = ak.extract_arrays(img)
+    assert ak.max_keypoints >= len(want_kp) and ak.max_keypoints <= 4096
+    _eq(kp.view(np.uint8), want_kp.view(np.uint8), "keypoints after growth")
+    _eq(d, want_d, "descriptors after growth")
+    # the raw context still reports the overflow honestly
+    small = akaze.Akaze.default(); small.max_keypoints = 128
+    ctx = small.context(640, 360, 1)
+    with pytest.raises(akaze.AkzError) as e:
+        ctx.extract_batch([img])
+    assert e.value.status == -7 and "max_keypoints" in str(e.value)
