@@ -1,15 +1,20 @@
 //! `akaze`-compatible front-end over the MI355X library (C ABI declared in `include/akz.h`).
 //!
 //! NOT BUILT in this repository (no Rust toolchain in the build image); kept as the reference-side
-//! binding of INTEGRATION.md.  The public surface is the one rust-cv callers use
+//! binding of INTEGRATION.md.  Its C++ twin, include/akaze.hpp, has the same structure (per-thread context cache, capacity
+//! growth, consensus layer) and IS built and run against the GPU by tests/cpp/estimate_pose.cpp.  The public surface is the one rust-cv callers use
 //! (`akaze/src/lib.rs:69-185,295-366` of rust-cv/cv): `Akaze` with its 11 public fields,
 //! `Akaze::{new, sparse, dense, extract, extract_from_gray_float_image, extract_path}`, `KeyPoint`, the `image`
 //! module (`GrayFloatImage`, the separable filters, `gaussian_kernel`), a `space::Knn` implementor, the two-view
 //! consensus and the place-recognition hasher.
 use bitarray::BitArray;
-use cv_core::{nalgebra::Point2, ImagePoint};
+use cv_core::{
+    nalgebra::{IsometryMatrix3, Matrix3, Point2, Rotation3, Translation3, UnitVector3, Vector3},
+    sample_consensus::{Consensus, Estimator},
+    CameraToCamera, FeatureMatch, FeatureWorldMatch, ImagePoint, Projective, WorldToCamera,
+};
 use ::image::{DynamicImage, ImageResult};
-use std::{os::raw::c_void, path::Path, ptr};
+use std::{cell::RefCell, os::raw::c_void, path::Path, ptr};
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -54,6 +59,8 @@ extern "C" {
                            descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
     fn akz_extract_gray_f32(ctx: *mut c_void, img: *const f32, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
                             descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
+    fn akz_extract_color(ctx: *mut c_void, pixels: *const c_void, fmt: i32, channels: i32, w: i32, h: i32, stride: i32,
+                         kps: *mut AkzKeypoint, descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
     fn akz_gaussian_kernel(r: f32, kernel_size: u32, out: *mut f32) -> i32;
     fn akz_horizontal_filter(ctx: *mut c_void, img: *const f32, w: i32, h: i32, kernel: *const f32, ksize: u32,
                              out: *mut f32) -> i32;
@@ -65,6 +72,12 @@ extern "C" {
     fn rs_essential_batch(ctx: *mut c_void, bearings_a: *const f64, bearings_b: *const f64, n: u32,
                           sample_idx: *const u32, n_hyp: u32, thresh: f64, best_pose: *mut f64, best_id: *mut u32,
                           inlier_idx: *mut u32, cap: u32, n_inliers: *mut u32) -> i32;
+    fn rs_essential_arrsac(ctx: *mut c_void, bearings_a: *const f64, bearings_b: *const f64, n: u32, sample_idx: *const u32,
+                           params: *const RsArrsacParams, best_pose: *mut f64, best_id: *mut u32, inlier_idx: *mut u32,
+                           cap: u32, n_inliers: *mut u32, stats: *mut c_void) -> i32;
+    fn rs_p3p_arrsac(ctx: *mut c_void, bearings: *const f64, world: *const f64, n: u32, sample_idx: *const u32,
+                     params: *const RsArrsacParams, best_pose: *mut f64, best_id: *mut u32, inlier_idx: *mut u32, cap: u32,
+                     n_inliers: *mut u32, stats: *mut c_void) -> i32;
     fn hm_create(device: i32, max_q: u32, max_t: u32, out: *mut *mut c_void) -> i32;
     fn hm_destroy(ctx: *mut c_void) -> i32;
     fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
@@ -125,7 +138,79 @@ impl Default for Akaze {
     }
 }
 
-const MAX_KP: u32 = 16384;
+/// `rs_arrsac_params` (include/akz.h).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RsArrsacParams {
+    struct_size: u32,
+    n_hypotheses: u32,
+    block_size: u32,
+    init_blocks: u32,
+    max_candidates: u32,
+    flags: u32,
+    threshold: f64,
+    sprt_delta: f64,
+    sprt_ratio: f64,
+    seed: u64,
+    estimations_per_block: u32,
+    reserved: u32,
+}
+
+const AKZ_E_CAPACITY: i32 = -4;
+const AKZ_E_INTERNAL: i32 = -7;
+const FMT_U8: i32 = 0;
+const FMT_F32: i32 = 1;
+const FMT_U16: i32 = 2;
+/// First capacity of the device's per-frame lists.  The reference's `Vec`s are unbounded (`maximum_features` is
+/// `usize::MAX`, lib.rs:172): a call that overflows the capacity is repeated with twice as much, up to the library's
+/// 65 536 keypoints per frame — a caller never sees the cap, only (beyond 65 536) a panic naming it.
+const INITIAL_KP: u32 = 16384;
+const LIBRARY_MAX_KP: u32 = 65536;
+
+/// One device pyramid per (config, size, capacity), per thread.  `Akaze` itself stays the reference's `Copy` struct
+/// with `&self` methods and no state (lib.rs:108): a loop of `extract` calls (cv-sfm/src/lib.rs:2200-2204) re-uses the
+/// pyramid instead of allocating ~0.2 GB per frame.
+struct CachedCtx {
+    cfg: AkzConfig,
+    w: u32,
+    h: u32,
+    cap: u32,
+    ctx: *mut c_void,
+}
+impl Drop for CachedCtx {
+    fn drop(&mut self) {
+        unsafe { akz_destroy(self.ctx) };
+    }
+}
+thread_local! {
+    static CTX: RefCell<Option<CachedCtx>> = RefCell::new(None);
+    static MATCHER: RefCell<Option<(u32, *mut c_void)>> = RefCell::new(None);
+}
+fn same_cfg(a: &AkzConfig, b: &AkzConfig) -> bool {
+    a.maximum_features == b.maximum_features && a.num_sublevels == b.num_sublevels
+        && a.max_octave_evolution == b.max_octave_evolution && a.base_scale_offset == b.base_scale_offset
+        && a.initial_contrast == b.initial_contrast && a.contrast_percentile == b.contrast_percentile
+        && a.contrast_factor_num_bins == b.contrast_factor_num_bins && a.derivative_factor == b.derivative_factor
+        && a.detector_threshold == b.detector_threshold && a.descriptor_channels == b.descriptor_channels
+        && a.descriptor_pattern_size == b.descriptor_pattern_size
+}
+/// The thread's matcher context, grown to hold `n` descriptors a side.
+fn with_matcher<R>(n: u32, f: impl FnOnce(*mut c_void) -> R) -> R {
+    MATCHER.with(|m| {
+        let mut m = m.borrow_mut();
+        if m.map_or(true, |(cap, _)| cap < n) {
+            if let Some((_, old)) = m.take() {
+                unsafe { hm_destroy(old) };
+            }
+            let cap = n.max(4096).next_power_of_two();
+            let mut ctx: *mut c_void = ptr::null_mut();
+            let st = unsafe { hm_create(0, cap, cap, &mut ctx) };
+            assert_eq!(st, 0, "hm_create failed with status {st} (there is no CPU fallback)");
+            *m = Some((cap, ctx));
+        }
+        f(m.unwrap().1)
+    })
+}
 
 impl Akaze {
     pub fn new(threshold: f64) -> Self {
@@ -154,69 +239,101 @@ impl Akaze {
         }
     }
 
-    fn run<F: FnOnce(*mut c_void, *mut AkzKeypoint, *mut [u8; 64], *mut u32) -> i32>(
+    /// One extraction through the thread's cached context, with growth: `AKZ_E_INTERNAL` (a device list overflowed) and
+    /// `AKZ_E_CAPACITY` (more keypoints than the output arrays hold) both mean "not enough room"; the reference has no
+    /// such condition, so the call is repeated with twice the capacity.
+    fn run<F: Fn(*mut c_void, *mut AkzKeypoint, *mut [u8; 64], u32, *mut u32) -> i32>(
         &self, w: u32, h: u32, f: F,
     ) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
-        // `Akaze` is Copy and stateless in the reference, so the device context is created per call here;
-        // a production shim would cache one context per (config, size) in a thread-local.
         let cfg = self.config();
-        let mut ctx: *mut c_void = ptr::null_mut();
-        let st = unsafe { akz_create(&cfg, 0, w as i32, h as i32, 1, MAX_KP, &mut ctx) };
-        assert_eq!(st, 0, "akz_create failed with status {st} (there is no CPU fallback)");
-        let mut kps = vec![AkzKeypoint::default(); MAX_KP as usize];
-        let mut descs = vec![[0u8; 64]; MAX_KP as usize];
-        let mut n = 0u32;
-        let st = f(ctx, kps.as_mut_ptr(), descs.as_mut_ptr(), &mut n);
-        unsafe { akz_destroy(ctx) };
-        assert_eq!(st, 0, "akz_extract failed with status {st}");
-        let n = n as usize;
-        let keypoints = kps[..n]
-            .iter()
-            .map(|k| KeyPoint {
-                point: (k.x, k.y),
-                response: k.response,
-                size: k.size,
-                octave: k.octave as usize,
-                class_id: k.class_id as usize,
-                angle: k.angle,
-            })
-            .collect();
-        let descriptors = descs[..n].iter().map(|d| BitArray::new(*d)).collect();
-        (keypoints, descriptors)
+        let mut cap = INITIAL_KP.min((self.maximum_features as u64).max(64).min(LIBRARY_MAX_KP as u64) as u32);
+        loop {
+            let (st, kps, descs, n) = CTX.with(|slot| {
+                let mut slot = slot.borrow_mut();
+                let fits = slot.as_ref().map_or(false, |c| same_cfg(&c.cfg, &cfg) && c.cap == cap && w <= c.w && h <= c.h);
+                if !fits {
+                    *slot = None; // drops (and destroys) the previous context first
+                    let mut ctx: *mut c_void = ptr::null_mut();
+                    let st = unsafe { akz_create(&cfg, 0, w as i32, h as i32, 1, cap, &mut ctx) };
+                    assert_eq!(st, 0, "akz_create failed with status {st} (there is no CPU fallback)");
+                    *slot = Some(CachedCtx { cfg, w, h, cap, ctx });
+                }
+                let ctx = slot.as_ref().unwrap().ctx;
+                let mut kps = vec![AkzKeypoint::default(); cap as usize];
+                let mut descs = vec![[0u8; 64]; cap as usize];
+                let mut n = 0u32;
+                let st = f(ctx, kps.as_mut_ptr(), descs.as_mut_ptr(), cap, &mut n);
+                (st, kps, descs, n)
+            });
+            if (st == AKZ_E_INTERNAL || st == AKZ_E_CAPACITY) && cap < LIBRARY_MAX_KP {
+                cap = (cap * 2).min(LIBRARY_MAX_KP);
+                continue;
+            }
+            assert_eq!(st, 0, "akz_extract failed with status {st} (capacity {cap} keypoints per frame)");
+            let n = n as usize;
+            let keypoints = kps[..n]
+                .iter()
+                .map(|k| KeyPoint {
+                    point: (k.x, k.y),
+                    response: k.response,
+                    size: k.size,
+                    octave: k.octave as usize,
+                    class_id: k.class_id as usize,
+                    angle: k.angle,
+                })
+                .collect();
+            let descriptors = descs[..n].iter().map(|d| BitArray::new(*d)).collect();
+            return (keypoints, descriptors);
+        }
     }
 
-    /// `Akaze::extract` (akaze/src/lib.rs:295).
+    /// `Akaze::extract` (akaze/src/lib.rs:295).  Every arm of `GrayFloatImage::from_dynamic` (image.rs:45-109) runs on the
+    /// device: the gray ones as they are, the colour ones through `akz_extract_color` (`DynamicImage::grayscale()` there).
     pub fn extract(&self, image: &DynamicImage) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
-        match image.grayscale() {
-            DynamicImage::ImageLuma8(g) => {
-                let (w, h) = (g.width(), g.height());
-                self.run(w, h, |ctx, k, d, n| unsafe {
-                    akz_extract_gray_u8(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
-                })
-            }
-            DynamicImage::ImageLuma16(g) => {
+        let (w, h) = (image.width(), image.height());
+        let colour = |pixels: *const c_void, fmt: i32, channels: i32| {
+            self.run(w, h, move |ctx, k, d, cap, n| unsafe {
+                akz_extract_color(ctx, pixels, fmt, channels, w as i32, h as i32, w as i32 * channels, k, d, cap, n)
+            })
+        };
+        match image {
+            DynamicImage::ImageLuma8(g) => self.run(w, h, |ctx, k, d, cap, n| unsafe {
+                akz_extract_gray_u8(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, cap, n)
+            }),
+            DynamicImage::ImageLuma16(g) => self.run(w, h, |ctx, k, d, cap, n| unsafe {
                 // image.rs:57-66: f32::from(v) / 65535f32, done on the device
-                let (w, h) = (g.width(), g.height());
-                self.run(w, h, |ctx, k, d, n| unsafe {
-                    akz_extract_gray_u16(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
-                })
-            }
-            other => {
-                // remaining arms of GrayFloatImage::from_dynamic (image.rs:67-106): convert on the host
-                let f = other.to_luma32f();
-                let (w, h) = (f.width(), f.height());
-                self.run(w, h, |ctx, k, d, n| unsafe {
-                    akz_extract_gray_f32(ctx, f.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
-                })
-            }
+                akz_extract_gray_u16(ctx, g.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, cap, n)
+            }),
+            DynamicImage::ImageRgb8(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_U8, 3),
+            DynamicImage::ImageRgba8(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_U8, 4),
+            DynamicImage::ImageRgb16(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_U16, 3),
+            DynamicImage::ImageRgba16(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_U16, 4),
+            DynamicImage::ImageRgb32F(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_F32, 3),
+            DynamicImage::ImageRgba32F(c) => colour(c.as_raw().as_ptr() as *const c_void, FMT_F32, 4),
+            // LumaA8 / LumaA16 (image.rs:67-86: the luma sample of every pixel): drop the alpha on the host
+            other => match other.grayscale() {
+                DynamicImage::ImageLumaA8(g) => {
+                    let l: Vec<u8> = g.pixels().map(|p| p[0]).collect();
+                    self.run(w, h, |ctx, k, d, cap, n| unsafe {
+                        akz_extract_gray_u8(ctx, l.as_ptr(), w as i32, h as i32, w as i32, k, d, cap, n)
+                    })
+                }
+                DynamicImage::ImageLumaA16(g) => {
+                    let l: Vec<u16> = g.pixels().map(|p| p[0]).collect();
+                    self.run(w, h, |ctx, k, d, cap, n| unsafe {
+                        akz_extract_gray_u16(ctx, l.as_ptr(), w as i32, h as i32, w as i32, k, d, cap, n)
+                    })
+                }
+                _ => panic!("DynamicImage::grayscale() returned unexpected type"), // image.rs:107
+            },
         }
     }
 
     /// `Akaze::extract_from_gray_float_image` (akaze/src/lib.rs:309).
     pub fn extract_from_gray_float_image(&self, img: &crate::image::GrayFloatImage) -> (Vec<KeyPoint>, Vec<BitArray<64>>) {
         let (w, h) = (img.width() as u32, img.height() as u32);
-        self.run(w, h, |ctx, k, d, n| unsafe {
-            akz_extract_gray_f32(ctx, img.0.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, MAX_KP, n)
+        self.run(w, h, |ctx, k, d, cap, n| unsafe {
+            akz_extract_gray_f32(ctx, img.0.as_raw().as_ptr(), w as i32, h as i32, w as i32, k, d, cap, n)
         })
     }
 
@@ -238,15 +355,12 @@ impl<'a> space::Knn for Mi355xLinearKnn<'a> {
     fn knn(&self, query: &BitArray<64>, num: usize) -> Self::KnnIter {
         // cv-sfm asks for 2 when matching frame pairs (lib.rs:3103) and 3 when registering a frame (lib.rs:1474)
         assert!((1..=3).contains(&num), "the MI355X matcher implements knn(query, k) for k <= 3");
-        let mut ctx: *mut c_void = ptr::null_mut();
         let n = self.targets.len() as u32;
-        assert_eq!(unsafe { hm_create(0, 1, n.max(2), &mut ctx) }, 0);
         let mut out = [AkzNeighbor { index: 0, distance: 0 }; 3];
-        let st = unsafe {
+        let st = with_matcher(n, |ctx| unsafe {
             hm_knn(ctx, query.bytes() as *const [u8; 64], 1, self.targets.as_ptr() as *const [u8; 64], n, num as u32,
                    out.as_mut_ptr())
-        };
-        unsafe { hm_destroy(ctx) };
+        });
         assert_eq!(st, 0);
         // LinearKnn returns min(num, len) neighbours
         out.iter().take(num.min(self.targets.len()))
@@ -270,16 +384,13 @@ impl Mi355xHammingHasher {
     }
     pub fn hash_bag<'a>(&self, features: impl IntoIterator<Item = &'a BitArray<64>>) -> BitArray<512> {
         let feats: Vec<BitArray<64>> = features.into_iter().cloned().collect();
-        let mut ctx: *mut c_void = ptr::null_mut();
         let cap = (feats.len() as u32).max(self.codewords.len() as u32);
-        assert_eq!(unsafe { hm_create(0, cap, cap, &mut ctx) }, 0);
         let mut hash = [0u8; 512];
-        let st = unsafe {
+        let st = with_matcher(cap, |ctx| unsafe {
             hm_hash_bag(ctx, feats.as_ptr() as *const [u8; 64], feats.len() as u32,
                         self.codewords.as_ptr() as *const [u8; 64], self.codewords.len() as u32, hash.as_mut_ptr(),
                         ptr::null_mut())
-        };
-        unsafe { hm_destroy(ctx) };
+        });
         assert_eq!(st, 0);
         BitArray::new(hash)
     }
@@ -288,15 +399,12 @@ impl Mi355xHammingHasher {
 /// `lsh_to_frame.knn_values(&lsh, num)` (cv-sfm/src/lib.rs:622-624) as an exact search over the stored hashes:
 /// (index into `hashes`, distance), ascending (distance, index).
 pub fn nearest_hashes(query: &BitArray<512>, hashes: &[BitArray<512>], num: usize) -> Vec<(usize, u32)> {
-    let mut ctx: *mut c_void = ptr::null_mut();
-    assert_eq!(unsafe { hm_create(0, 2, 2, &mut ctx) }, 0);
     let mut out = vec![AkzNeighbor { index: 0, distance: 0 }; num.max(1)];
     let mut n: u32 = 0;
-    let st = unsafe {
+    let st = with_matcher(2, |ctx| unsafe {
         hm_hash_knn(ctx, query.bytes().as_ptr(), hashes.as_ptr() as *const u8, hashes.len() as u32, 512, num as u32,
                     out.as_mut_ptr(), &mut n)
-    };
-    unsafe { hm_destroy(ctx) };
+    });
     assert_eq!(st, 0);
     out.iter().take(n as usize).map(|o| (o.index as usize, o.distance)).collect()
 }
@@ -386,35 +494,135 @@ pub mod image {
     }
 }
 
-/// Two-view consensus on the MI355X: what `Consensus::model_inliers(&EightPoint::new(), matches)` computes
-/// (akaze/tests/estimate_pose.rs:63-67, tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1406), with the
-/// minimal samples drawn by the caller's RNG (`arrsac` draws them inside; the crate is not part of this
-/// repository).  `bearings_a[i]` / `bearings_b[i]` are the unit bearings of match i; `samples` holds 8 match
-/// indices per hypothesis.  Returns the winning pose as a row-major 3x4 `[R | t]` and the inlier indices.
-pub struct Mi355xEssentialConsensus {
-    pub inlier_threshold: f64,
+/// `arrsac::Arrsac` over the MI355X library: the `sample_consensus::Consensus` the reference's callers hand their
+/// estimators to (akaze/tests/estimate_pose.rs:63-75, vslam-sandbox/src/main.rs:105-117, cv-sfm/src/lib.rs:1394-1412 and
+/// 1619-1622), for the two estimators of the hot path — `EightPoint` over `FeatureMatch` and `LambdaTwist` over
+/// `FeatureWorldMatch`.  The estimator argument selects the device procedure (`rs_essential_arrsac` / `rs_p3p_arrsac`);
+/// its own `estimate` is not called: hypotheses, scoring and consensus all run on the GPU.  The `arrsac` crate is not
+/// vendored in rust-cv/cv; what runs is this library's ARRSAC-shaped procedure (include/akz.h, specified by
+/// oracle/arrsac_oracle.c) under the crate's builder names, seeded with a `u64` where the crate takes an `Rng`.
+pub struct Arrsac {
+    params: RsArrsacParams,
+    ctx: Option<(u32, u32, *mut c_void)>, // (matches, hypotheses) the context holds
 }
-impl Mi355xEssentialConsensus {
-    pub fn model_inliers(&mut self, bearings_a: &[[f64; 3]], bearings_b: &[[f64; 3]], samples: &[[u32; 8]])
-        -> Option<([f64; 12], Vec<usize>)> {
-        assert_eq!(bearings_a.len(), bearings_b.len());
-        let n = bearings_a.len() as u32;
-        let mut ctx: *mut c_void = ptr::null_mut();
-        assert_eq!(unsafe { rs_create(0, n.max(8), samples.len().max(1) as u32, &mut ctx) }, 0);
+impl Arrsac {
+    pub fn new(inlier_threshold: f64, seed: u64) -> Self {
+        Self {
+            params: RsArrsacParams {
+                struct_size: std::mem::size_of::<RsArrsacParams>() as u32,
+                n_hypotheses: 256,
+                block_size: 64,
+                init_blocks: 1,
+                max_candidates: 64,
+                flags: 1 | 2 | 4, // RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE
+                threshold: inlier_threshold,
+                sprt_delta: 0.05,
+                sprt_ratio: 1e3,
+                seed,
+                estimations_per_block: 0,
+                reserved: 0,
+            },
+            ctx: None,
+        }
+    }
+    pub fn initialization_hypotheses(mut self, n: usize) -> Self { self.params.n_hypotheses = n as u32; self }
+    pub fn max_candidate_hypotheses(mut self, n: usize) -> Self { self.params.max_candidates = n as u32; self }
+    pub fn estimations_per_block(mut self, n: usize) -> Self { self.params.estimations_per_block = n as u32; self }
+    pub fn block_size(mut self, n: usize) -> Self { self.params.block_size = n as u32; self }
+    pub fn initialization_blocks(mut self, n: usize) -> Self { self.params.init_blocks = n as u32; self }
+    pub fn likelihood_ratio_threshold(mut self, r: f64) -> Self { self.params.sprt_ratio = r; self }
+
+    fn context(&mut self, n: u32) -> *mut c_void {
+        let blocks = (n + self.params.block_size - 1) / self.params.block_size;
+        let need_h = self.params.n_hypotheses + self.params.estimations_per_block * blocks;
+        if self.ctx.map_or(true, |(m, h, _)| m < n || h < need_h) {
+            if let Some((_, _, old)) = self.ctx.take() {
+                unsafe { rs_destroy(old) };
+            }
+            let mut ctx: *mut c_void = ptr::null_mut();
+            let st = unsafe { rs_create(0, n.max(64), need_h, &mut ctx) };
+            assert_eq!(st, 0, "rs_create failed with status {st} (there is no CPU fallback)");
+            self.ctx = Some((n.max(64), need_h, ctx));
+        }
+        self.ctx.unwrap().2
+    }
+    /// (row-major 3x4 `[R | t]`, inlier indices) or `None`
+    fn run(&mut self, p3p: bool, a: &[f64], b: &[f64], n: u32) -> Option<([f64; 12], Vec<usize>)> {
+        let ctx = self.context(n);
         let mut pose = [0f64; 12];
         let (mut best, mut n_inl) = (0u32, 0u32);
         let mut inl = vec![0u32; n as usize];
         let st = unsafe {
-            rs_essential_batch(ctx, bearings_a.as_ptr() as *const f64, bearings_b.as_ptr() as *const f64, n,
-                               samples.as_ptr() as *const u32, samples.len() as u32, self.inlier_threshold,
-                               pose.as_mut_ptr(), &mut best, inl.as_mut_ptr(), n, &mut n_inl)
+            if p3p {
+                rs_p3p_arrsac(ctx, a.as_ptr(), b.as_ptr(), n, ptr::null(), &self.params, pose.as_mut_ptr(), &mut best,
+                              inl.as_mut_ptr(), n, &mut n_inl, ptr::null_mut())
+            } else {
+                rs_essential_arrsac(ctx, a.as_ptr(), b.as_ptr(), n, ptr::null(), &self.params, pose.as_mut_ptr(), &mut best,
+                                    inl.as_mut_ptr(), n, &mut n_inl, ptr::null_mut())
+            }
         };
-        unsafe { rs_destroy(ctx) };
-        assert_eq!(st, 0);
+        assert_eq!(st, 0, "consensus failed with status {st}");
         if best == u32::MAX {
-            return None;
+            return None; // Consensus::model_inliers -> None: no sample produced a model
         }
         Some((pose, inl[..n_inl as usize].iter().map(|&i| i as usize).collect()))
     }
 }
-
+impl Drop for Arrsac {
+    fn drop(&mut self) {
+        if let Some((_, _, ctx)) = self.ctx.take() {
+            unsafe { rs_destroy(ctx) };
+        }
+    }
+}
+fn isometry(rt: &[f64; 12]) -> IsometryMatrix3<f64> {
+    let r = Matrix3::new(rt[0], rt[1], rt[2], rt[4], rt[5], rt[6], rt[8], rt[9], rt[10]);
+    IsometryMatrix3::from_parts(Translation3::from(Vector3::new(rt[3], rt[7], rt[11])), Rotation3::from_matrix_unchecked(r))
+}
+/// `Consensus<EightPoint, FeatureMatch>` — eight-point/src/lib.rs:70-83 estimates, cv-core/src/pose.rs:249-295 scores.
+impl Consensus<eight_point::EightPoint, FeatureMatch> for Arrsac {
+    type Inliers = Vec<usize>;
+    fn model<I>(&mut self, estimator: &eight_point::EightPoint, data: I) -> Option<CameraToCamera>
+    where I: Iterator<Item = FeatureMatch> + Clone {
+        self.model_inliers(estimator, data).map(|(m, _)| m)
+    }
+    fn model_inliers<I>(&mut self, _estimator: &eight_point::EightPoint, data: I) -> Option<(CameraToCamera, Vec<usize>)>
+    where I: Iterator<Item = FeatureMatch> + Clone {
+        let (mut a, mut b) = (Vec::new(), Vec::new());
+        for FeatureMatch(fa, fb) in data {
+            a.extend_from_slice(fa.as_ref().as_slice());
+            b.extend_from_slice(fb.as_ref().as_slice());
+        }
+        let n = (a.len() / 3) as u32;
+        if (n as usize) < <eight_point::EightPoint as Estimator<FeatureMatch>>::MIN_SAMPLES {
+            return None;
+        }
+        self.run(false, &a, &b, n).map(|(rt, inl)| (CameraToCamera(isometry(&rt)), inl))
+    }
+}
+/// `Consensus<LambdaTwist, FeatureWorldMatch>` — lambda-twist/src/lib.rs:330-347 estimates, cv-core/src/pose.rs:194-201 scores.
+impl Consensus<lambda_twist::LambdaTwist, FeatureWorldMatch> for Arrsac {
+    type Inliers = Vec<usize>;
+    fn model<I>(&mut self, estimator: &lambda_twist::LambdaTwist, data: I) -> Option<WorldToCamera>
+    where I: Iterator<Item = FeatureWorldMatch> + Clone {
+        self.model_inliers(estimator, data).map(|(m, _)| m)
+    }
+    fn model_inliers<I>(&mut self, _estimator: &lambda_twist::LambdaTwist, data: I) -> Option<(WorldToCamera, Vec<usize>)>
+    where I: Iterator<Item = FeatureWorldMatch> + Clone {
+        let (mut a, mut w) = (Vec::new(), Vec::new());
+        for FeatureWorldMatch(bearing, world) in data {
+            a.extend_from_slice(bearing.as_ref().as_slice());
+            w.extend_from_slice(world.homogeneous().as_slice()); // Projective form: xyz normalised, w = 1 / distance
+        }
+        let n = (a.len() / 3) as u32;
+        if (n as usize) < <lambda_twist::LambdaTwist as Estimator<FeatureWorldMatch>>::MIN_SAMPLES {
+            return None;
+        }
+        self.run(true, &a, &w, n).map(|(rt, inl)| (WorldToCamera(isometry(&rt)), inl))
+    }
+}
+/// `UnitVector3` bearings of a match list, for callers that hold keypoints: `CameraIntrinsics::calibrate` is the reference's
+/// own (cv-pinhole/src/lib.rs:108-117) and stays on the host — it is a handful of flops per keypoint.
+pub fn bearing(v: [f64; 3]) -> UnitVector3<f64> {
+    UnitVector3::new_unchecked(Vector3::new(v[0], v[1], v[2]))
+}
