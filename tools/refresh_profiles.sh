@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): regenerates the raw material of profiles/ under gpurun_out/refresh/.
 # usage: bash tools/refresh_profiles.sh [round-tag, default r03] [micro-batch, default 256]
-#   <tag>_bench_kernel_stats.txt  rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5 --no-isolated --no-extras
+#   <tag>_bench_kernel_stats.txt  rocprofv3 --kernel-trace of `bench.py --steps 30 --warmup 2 --no-isolated --no-extras
 #                                 --no-cpu-baseline` — every launch of that run is the pipelined workload's, so a kernel's
 #                                 average duration here is what the same run's JSON line (<tag>_bench_profiled.json) reports as
 #                                 roofline.avg_launch_us
@@ -18,15 +18,17 @@ B="python $R/bench.py --pmc-run --frames $MB --micro-batch $MB --steps 1 --warmu
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o $T -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o $T -- $B > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d $O/pmc_valu -o $T -- $B > $O/pmc_valu.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/trace -o $T -- python $R/bench.py --steps 20 --warmup 5 --no-isolated --no-extras --no-cpu-baseline > $O/trace.log 2> $O/trace.err
-tail -1 $O/trace.log > $O/${T}_bench_profiled.json
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch/${T}_results.db $O/pmc_write/${T}_results.db $O/${T}_pmc_traffic.json $MB $O/pmc_valu/${T}_results.db $MB 1
+cp $O/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json   # bench.py reads it for roofline.traffic / valu_frac
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/trace -o $T -- python $R/bench.py --steps 30 --warmup 2 --no-isolated --no-extras --no-cpu-baseline > $O/trace.log 2> $O/trace.err
+grep '^{' $O/trace.log | tail -1 > $O/${T}_bench_profiled.json
+cd $R
 python tools/rocpd_pmc.py $O/pmc_fetch/${T}_results.db $O/${T}_pmc_fetch_size.txt > /dev/null
 python tools/rocpd_pmc.py $O/pmc_write/${T}_results.db $O/${T}_pmc_write_size.txt > /dev/null
 python tools/rocpd_stats.py $O/trace/${T}_results.db $O/${T}_bench_kernel_stats.txt > /dev/null
-cp $O/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json   # bench.py reads it for roofline.traffic / valu_frac
 python bench.py > $O/bench.log 2> $O/bench.err
-tail -1 $O/bench.log > $O/${T}_bench.json
+grep '^{' $O/bench.log | tail -1 > $O/${T}_bench.json
 tail -c 1500 $O/bench.log
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/trace   # raw databases are large: only the summaries travel back
