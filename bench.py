@@ -267,8 +267,31 @@ def main():
     # cv_amd/sharding.py
     comm = torch.cuda.Stream(device=dev) if sharded else None
     exchange = None
+    comm_note = None
     if sharded:
-        exchange = AkzExchange(dist, rank, world, local_rank) if comm_kind == "akz" else TorchExchange(dist, rank, world)
+        if comm_kind == "akz":
+            # every rank must end up on the same route: agree on whether the library's own RCCL exchange came up everywhere
+            try:
+                exchange = AkzExchange(dist, rank, world, local_rank)
+                ok = 1
+            except Exception as e:          # librccl not loadable, communicator refused ...
+                exchange, ok, comm_note = None, 0, f"akz_comm unavailable ({e}); torch.distributed used instead"
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                if exchange is not None:
+                    exchange.close()
+                comm_note = comm_note or "akz_comm unavailable on another rank; torch.distributed used instead"
+                comm_kind = "torch"
+                if not dist.is_initialized():
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29511")
+                    dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if args.backend == "nccl" else {}))
+                exchange = TorchExchange(dist, rank, world)
+        else:
+            exchange = TorchExchange(dist, rank, world)
         flush_c_stdio()
 
     verify = {"on": None}            # pipeline+verify leg: a callable(p, m0, js, prev_js) that enqueues the consensus
@@ -512,6 +535,8 @@ def main():
                 "recent_views": K, "exchange": "all-gather of fixed-capacity descriptor blocks" if use_allgather else "ring shift",
                 "comm": "akz_comm_* (libakz -> librccl.so.1)" if comm_kind == "akz" else f"torch.distributed ({args.backend})",
                 "block_bytes_per_rank_per_step": NF * (CAP * 64 + 4)}
+            if comm_note:
+                out["multi_gpu"]["comm_note"] = comm_note
             if exch:
                 out["multi_gpu"]["exchange_ms_per_step"] = round(exch[0] / args.steps, 3)
                 out["multi_gpu"]["exchange_bytes_per_step"] = int(exch[2] // max(1, args.steps))
