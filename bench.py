@@ -1079,8 +1079,10 @@ def cpu_baseline_all_cores(frames, threads):
     """The same -O3 -march=native build with OpenMP over frames (one pyramid per thread, dynamic schedule): what the
     reference's per-frame parallelism (cv-sfm extracts frame by frame; rayon inside a frame) could reach on this host."""
     from oracle import oracle as O
-    avail = O.threads_available()
-    threads = max(1, min(threads if threads > 0 else avail, avail, os.cpu_count() or 1))
+    # (the CPUs this process may run on — not omp_get_max_threads(), which an inherited OMP_NUM_THREADS=1 pins to one;
+    # the thread count is set explicitly for the call)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads if threads > 0 else avail, avail))
     n = min(frames.shape[0], 2 * threads)
     host = frames[:n].cpu().numpy()
     O.extract_match_many(host[:min(n, threads)], threads=threads, fast=True, match=False)     # page the workers' pyramids in
