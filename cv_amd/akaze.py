@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import KP_DTYPE, AkzError, Config, LevelInfo, Options, check, make_options  # noqa: F401
 
 USIZE_MAX = 2 ** 64 - 1
-MAX_KEYPOINTS = 65536   # kAkzMaxKeypoints (cv_amd/csrc/akz_common.h)
+MAX_KEYPOINTS = 262144   # kAkzMaxKeypoints (cv_amd/csrc/akz_common.h)
 BUF = {"Lt": 0, "Lsmooth": 1, "Lx": 2, "Ly": 3, "Ldet": 4, "Lflow": 5}
 
 
@@ -147,7 +147,7 @@ class Akaze:
 
         The reference's lists are unbounded (maximum_features = usize::MAX, lib.rs:172); the library's have a capacity fixed
         at context creation.  A call that overflows it (AKZ_E_INTERNAL + akz_last_overflow) is repeated with a context of
-        twice the capacity, up to the library's 65 536 per frame — the caller sees the reference's behaviour, not the cap."""
+        twice the capacity, up to the library's 262 144 per frame — the caller sees the reference's behaviour, not the cap."""
         img = np.asarray(image)
         if img.ndim == 3 and img.shape[2] in (3, 4):
             if img.dtype not in (np.uint8, np.uint16):

