@@ -1665,3 +1665,65 @@ def test_dense_full_hd_noise_beyond_the_old_limit(gpu, oracle):
     assert ak.max_keypoints == 131072
     _kp_eq(kp, okp, "dense 1080p noise keypoints")
     _eq(d, od, "dense 1080p noise descriptors")
+
+
+def test_new_entry_points_refuse_what_they_cannot_do(gpu):
+    """Round-3 entry points answer with a status, never with a wrong result: the batched consensus (scenes beyond the
+    reservation, unknown flags, a shuffle that would not fit its LDS sort, a stale parameter struct), the colour arm
+    (two channels, a stride shorter than a row), the exchange (rank outside the world)."""
+    import ctypes as C
+    import torch
+    akaze, _ = gpu
+    from cv_amd import _lib
+    from cv_amd.ransac import EssentialConsensus
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    cons = EssentialConsensus(512, 64)
+    cons.reserve(2)
+    cam = cons.camera((1000.0, 1000.0, 320.0, 240.0, 0.0, None))
+    prm = cons.make_params(1e-6, n_hypotheses=64, block_size=32)
+    kp = torch.zeros((4, 512, 28), dtype=torch.uint8, device=dev)
+    pairs = torch.zeros((4, 512, 2), dtype=torch.int32, device=dev)
+    npairs = torch.zeros((4,), dtype=torch.int32, device=dev)
+    out = [torch.zeros((4, 12), dtype=torch.float64, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
+           torch.zeros((4, 512), dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)]
+
+    def call(n_scenes, flags=0, cap=512, p=prm, camera=cam):
+        ia = (C.c_uint32 * max(1, n_scenes))(*range(n_scenes))
+        return L.rs_essential_arrsac_batch_device(cons._h, kp.data_ptr(), kp.data_ptr(), cap, ia, ia, pairs.data_ptr(), npairs.data_ptr(),
+                                                  n_scenes, C.byref(camera), C.byref(camera), C.byref(p), flags, out[0].data_ptr(),
+                                                  out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), None, None)
+    assert call(2) == 0 and call(0) == 0
+    cons.sync()
+    assert out[1].cpu().numpy().view(np.uint32)[0] == 0xFFFFFFFF          # no matches: no model
+    assert call(3) == -6                                                   # AKZ_E_TOO_LARGE: beyond rs_batch_reserve
+    assert call(2, flags=2) == -1                                          # unknown flag
+    bad = cons.make_params(1e-6, n_hypotheses=64, block_size=32); bad.struct_size = 8
+    assert call(2, p=bad) == -1
+    big = cons.make_params(1e-6, n_hypotheses=65, block_size=32)
+    assert call(2, p=big) == -6                                            # more hypotheses than the context holds
+    cam2 = cons.camera((1000.0, 1000.0, 320.0, 240.0, 0.0, None)); cam2.reserved = 1
+    assert call(2, camera=cam2) == -1
+    wide = EssentialConsensus(16384, 16)
+    wide.reserve(1)
+    kpw = torch.zeros((1, 16384, 28), dtype=torch.uint8, device=dev)
+    prw = torch.zeros((1, 16384, 2), dtype=torch.int32, device=dev)
+    one = (C.c_uint32 * 1)(0)
+    pw = wide.make_params(1e-6, n_hypotheses=16, block_size=64)
+    st = L.rs_essential_arrsac_batch_device(wide._h, kpw.data_ptr(), kpw.data_ptr(), 16384, one, one, prw.data_ptr(), npairs.data_ptr(), 1,
+                                            C.byref(cam), C.byref(cam), C.byref(pw), _lib.RS_BATCH_SHUFFLE, out[0].data_ptr(),
+                                            out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), None, None)
+    assert st == -6                                                        # the seeded shuffle sorts at most 8192 keys in LDS
+    # colour arm
+    ctx = akaze.Akaze.default().context(64, 48, 1)
+    img = np.zeros((48, 64, 3), np.uint8)
+    k = np.zeros(16, _lib.KP_DTYPE); d = np.zeros((16, 64), np.uint8); n = C.c_uint32()
+    assert L.akz_extract_color(ctx.handle, img.ctypes.data, 0, 2, 64, 48, 128, k.ctypes.data, d.ctypes.data, 16, C.byref(n)) == -1
+    assert L.akz_extract_color(ctx.handle, img.ctypes.data, 0, 3, 64, 48, 100, k.ctypes.data, d.ctypes.data, 16, C.byref(n)) == -1
+    assert L.akz_extract_color(ctx.handle, img.ctypes.data, 5, 3, 64, 48, 192, k.ctypes.data, d.ctypes.data, 16, C.byref(n)) == -1
+    assert L.akz_extract_color(ctx.handle, img.ctypes.data, 0, 3, 64, 48, 192, k.ctypes.data, d.ctypes.data, 16, C.byref(n)) == 0 and n.value == 0
+    # exchange
+    ident = (C.c_uint8 * 128)()
+    assert L.akz_comm_create(ident, 2, 2, 0, C.byref(C.c_void_p())) == -1
+    assert L.akz_comm_create(ident, 0, 0, 0, C.byref(C.c_void_p())) == -1
+    assert L.akz_comm_unique_id(None) == -1
