@@ -548,6 +548,8 @@ def main():
         if traffic:
             out["hbm_traffic_per_frame"] = traffic
             out["end_to_end_hbm_frac"] = round(traffic["bytes"] * fps / world / (HBM_PEAK_GBS * 1e9), 4)
+            # the same for the VALU: wave-instructions of the library's kernels per frame x 64 lanes x frames/s against the issue peak
+            out["end_to_end_valu_frac"] = round(traffic["valu_insts"] * 64.0 * fps / world / (VALU_ISSUE_PEAK_T * 1e12), 4)
         out["device"] = device_probe(torch, dev)
         rc = 0
         if world == 1 and not args.no_cpu_baseline:
@@ -669,7 +671,9 @@ def pipeline_traffic(mb, nf):
     if not pmc or not pmc.get("per_frame") or int(pmc.get("frames_per_step", 0)) != int(nf):
         return None
     pf = pmc["per_frame"]
-    return {"bytes": round(pf["hbm_bytes"]), "scale_space_bytes": round(pf.get("scale_space_hbm_bytes", 0)),
+    valu = sum(k.get("valu_insts_per_launch", 0) * k["launches"] for name, k in pmc["kernels"].items() if name.startswith("k_"))
+    return {"valu_insts": round(valu / (float(pmc["frames_per_step"]) * float(pmc.get("steps", 1)))),
+            "bytes": round(pf["hbm_bytes"]), "scale_space_bytes": round(pf.get("scale_space_hbm_bytes", 0)),
             "keypoint_stage_bytes": round(pf.get("keypoint_stage_hbm_bytes", 0)), "matcher_bytes": round(pf.get("matcher_hbm_bytes", 0)),
             "file": pmc["file"], "source": pmc.get("source_short", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bench.py --pmc-run")}
 
