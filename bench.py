@@ -162,7 +162,7 @@ def main():
                     "single-GPU smoke test of the multi-rank path)")
     ap.add_argument("--recent", type=int, default=1, help="every frame is matched against its K predecessors g-1 .. g-K "
                     "(cv-sfm tracking_recent_frames: up to 32); 1 = the headline workload (symmetric match with g-1), "
-                    "K > 1: LinearKnn::knn(., 2) of every feature against each of the K views (hm_knn_views_device)")
+                    "K > 1: LinearKnn::knn(., 2) of every feature against each of the K views (hm_knn_batch_device: one call per step)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "shift", "allgather"], help="how descriptor blocks reach the "
                     "ranks that match against them: ring shift (K = 1) or all-gather of the fixed-capacity blocks (K > 1)")
     ap.add_argument("--comm", default="auto", choices=["auto", "akz", "torch"], help="akz: the library's own RCCL exchange "
@@ -357,12 +357,17 @@ def main():
             views_d = gath_descs2[p] if sharded else descs
             views_n = gath_counts2[p] if sharded else counts
             wait = comm if sharded else akz_stream
+            iq, it = [], []
             for j in range(NF):
                 gv = window_views(rank, j, world, NF, K)
-                vi = idx([gathered_block(g, world, NF, MB) for g in gv]) if sharded else idx(gv)
-                _lib.check(L.hm_knn_views_device(matcher.handle, descs[j].data_ptr(), counts[j:].data_ptr(), views_d.data_ptr(),
-                                                 views_n.data_ptr(), CAP, vi, K, 2, knn_out2[p][j].data_ptr(),
-                                                 wait.cuda_stream if j == 0 else None), "knn_views")
+                iq += [j] * K
+                it += [gathered_block(g, world, NF, MB) for g in gv] if sharded else gv
+            for p0 in range(0, len(iq), 32768):          # (a call takes up to 65 535 problems)
+                p1 = min(len(iq), p0 + 32768)
+                _lib.check(L.hm_knn_batch_device(matcher.handle, descs.data_ptr(), counts.data_ptr(), views_d.data_ptr(),
+                                                 views_n.data_ptr(), CAP, idx(iq[p0:p1]), idx(it[p0:p1]), p1 - p0, 2,
+                                                 knn_out2[p].view(-1, CAP, 2, 2)[p0:].data_ptr(),
+                                                 wait.cuda_stream if p0 == 0 else None), "knn_batch")
         match_done[p].record(hm_stream)
         step_no[0] += 1
 

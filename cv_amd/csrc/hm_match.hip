@@ -19,6 +19,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <unordered_map>
+
 #include "akz_common.h"
 
 namespace {
@@ -756,9 +758,11 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     std::vector<HmProbX> px(n_probs);
     size_t words = 0;
     const size_t ew = c->use_fp4 ? 64 : 128;   // words of recoded descriptor
+    std::unordered_map<const void*, size_t> seen;   // block -> its job (a window call has thousands of problems over few blocks)
     auto expanded = [&](const uint4* src, const uint32_t* cnt, uint32_t cap) -> size_t {
-        for (size_t i = 0; i < jobs.size(); ++i)
-            if (jobs[i].src == (const uint32_t*)src) return job_off[i];
+        auto it = seen.find((const void*)src);
+        if (it != seen.end()) return job_off[it->second];
+        seen.emplace((const void*)src, jobs.size());
         jobs.push_back(HmExpandJob{(const uint32_t*)src, cnt, cap, nullptr});
         job_off.push_back(words);
         words += (size_t)cap * ew;
@@ -918,6 +922,32 @@ extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d
                            (const uint32_t*)d_nviews + view_idx[v], cap_per_img,
                            (akz_neighbor*)d_out + (size_t)v * cap_per_img * k};
         return launch_knn2(c, hp.data(), n_views, cap_per_img, 0, (int)k);
+    });
+}
+
+// The batched form of the same search: problem p = every feature of query block iq[p] (of d_q) against target block
+// it[p] (of d_t), k neighbours each — a whole step's window of recent views (cv-sfm/src/lib.rs:1462-1486 for every
+// frame of a micro-batch: n_frames x K problems) in ONE call; every distinct block is recoded once.  d_out [n_probs][cap][k].
+extern "C" int32_t hm_knn_batch_device(hm_ctx* c, const void* d_q, const void* d_nq, const void* d_t, const void* d_nt,
+                                       uint32_t cap_per_img, const uint32_t* iq, const uint32_t* it, uint32_t n_probs,
+                                       uint32_t k, void* d_out, void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_q || !d_nq || !d_t || !d_nt || !iq || !it || !d_out || k < 1 || k > 3) return AKZ_E_INVALID;
+        if (cap_per_img == 0 || cap_per_img >= (1u << (kIdxBits - 1)) || n_probs > 65535u) return AKZ_E_INVALID;
+        if (n_probs == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_probs)));
+        std::vector<HmProb> hp(n_probs);
+        for (uint32_t p = 0; p < n_probs; ++p)
+            hp[p] = HmProb{(const uint4*)d_q + (size_t)iq[p] * cap_per_img * 4, (const uint32_t*)d_nq + iq[p], cap_per_img,
+                           (const uint4*)d_t + (size_t)it[p] * cap_per_img * 4, (const uint32_t*)d_nt + it[p], cap_per_img,
+                           (akz_neighbor*)d_out + (size_t)p * cap_per_img * k};
+        return launch_knn2(c, hp.data(), n_probs, cap_per_img, 0, (int)k);
     });
 }
 

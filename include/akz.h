@@ -266,6 +266,13 @@ int32_t hm_knn(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_desc
 int32_t hm_knn_views_device(hm_ctx* ctx, const void* d_q, const void* d_nq, const void* d_views,
                             const void* d_nviews, uint32_t cap_per_img, const uint32_t* view_idx,
                             uint32_t n_views, uint32_t k, void* d_out, void* stream_to_wait);
+/* The batched form: problem p = every feature of query block iq[p] (of d_q, count d_nq[iq[p]]) against target block it[p]
+ * (of d_t), k neighbours each — the window of recent views of every frame of a micro-batch (n_frames x K problems) in one
+ * call; every distinct block is recoded once.  iq / it host index arrays, n_probs <= 65535; d_out [n_probs][cap][k], slots past
+ * a target block's count as in hm_knn. */
+int32_t hm_knn_batch_device(hm_ctx* ctx, const void* d_q, const void* d_nq, const void* d_t, const void* d_nt,
+                            uint32_t cap_per_img, const uint32_t* iq, const uint32_t* it, uint32_t n_probs, uint32_t k,
+                            void* d_out, void* stream_to_wait);
 /* What follows hm_knn_views_device in the reference (cv-sfm/src/lib.rs:1489-1542): per feature, the best distance of
  * every distinct landmark among its n_views x k neighbours, the three best landmarks (ascending (distance, landmark
  * key): the reference's HashMap leaves the order of equal distances unspecified), and the decision of :1516-1532 —

@@ -425,6 +425,62 @@ def test_knn_views_device(gpu, oracle):
         assert set(np.unique(wdec)) <= {0, 1, 2} and (wdec == 1).any()
 
 
+@pytest.mark.gpu
+def test_knn_batch_device(gpu, oracle):
+    """hm_knn_batch_device: (query block, target block) problems of one call — the windows of several frames at once —
+    each equal to the oracle's knn of that pair; blocks repeat as queries and as targets, one block is empty."""
+    import ctypes as C
+    import torch
+    _, knn = gpu
+    from cv_amd import _lib
+    rng = np.random.default_rng(78)
+    cap = 512
+    qn = np.array([512, 77, 0, 300], np.int32)
+    tn = np.array([1, 512, 200, 0, 45, 333], np.int32)
+    qs = np.zeros((len(qn), cap, 64), np.uint8)
+    ts = np.zeros((len(tn), cap, 64), np.uint8)
+    for b in range(len(qn)):
+        qs[b, :qn[b]] = _rand_desc(rng, int(qn[b]))
+    for b in range(len(tn)):
+        ts[b, :tn[b]] = _rand_desc(rng, int(tn[b]))
+    ts[1, :50] = qs[0, :50]                                    # exact hits and ties
+    ts[2, :50] = qs[0, :50]
+    dev = torch.device("cuda", 0)
+    d_q, d_nq = torch.from_numpy(qs).to(dev), torch.from_numpy(qn).to(dev)
+    d_t, d_nt = torch.from_numpy(ts).to(dev), torch.from_numpy(tn).to(dev)
+    iq = [0, 0, 0, 1, 1, 2, 3, 3, 3, 0]
+    it = [1, 2, 5, 1, 0, 1, 3, 4, 1, 1]
+    L = _lib.lib()
+    m = knn.Matcher(cap)
+    for k in (2, 3):
+        out = torch.full((len(iq), cap, k, 2), -1, dtype=torch.int32, device=dev)
+        _lib.check(L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap,
+                                         (C.c_uint32 * len(iq))(*iq), (C.c_uint32 * len(it))(*it), len(iq), k, out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "knn_batch")
+        _lib.check(L.hm_sync(m.handle), "hm_sync")
+        got = out.cpu().numpy()
+        for p, (a, b) in enumerate(zip(iq, it)):
+            if qn[a] == 0:
+                continue
+            want = oracle.knn(qs[a, :qn[a]], ts[b, :tn[b]], k)
+            absent = want["index"] == 0xFFFFFFFF                 # slots past the target count: {2^22 - 1, 1023} (akz.h, hm_knn)
+            assert absent[:, min(k, tn[b]):].all() and not absent[:, :min(k, tn[b])].any()
+            _eq(got[p, :qn[a], :, 0].astype(np.uint32), np.where(absent, (1 << 22) - 1, want["index"]), f"k {k} problem {p} idx")
+            _eq(got[p, :qn[a], :, 1].astype(np.uint32), np.where(absent, 1023, want["distance"]), f"k {k} problem {p} dist")
+    # a view call is the batch call with one query block
+    o1 = torch.zeros((3, cap, 2, 2), dtype=torch.int32, device=dev)
+    o2 = torch.zeros((3, cap, 2, 2), dtype=torch.int32, device=dev)
+    sel = (C.c_uint32 * 3)(5, 1, 2)
+    _lib.check(L.hm_knn_views_device(m.handle, d_q[3:].data_ptr(), d_nq[3:].data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap,
+                                     sel, 3, 2, o1.data_ptr(), None), "knn_views")
+    _lib.check(L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap,
+                                     (C.c_uint32 * 3)(3, 3, 3), sel, 3, 2, o2.data_ptr(), None), "knn_batch")
+    _lib.check(L.hm_sync(m.handle), "hm_sync")
+    _eq(o1.cpu().numpy()[:, :300], o2.cpu().numpy()[:, :300], "views == batch")
+    assert L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap,
+                                 sel, sel, 3, 4, o2.data_ptr(), None) == -1                       # AKZ_E_INVALID: k > 3
+
+
 def test_place_recognition_hash_and_search(gpu, oracle, kitti_golden):
     """hm_hash_bag / hm_hash_bag_device / hm_hash_knn == oracle/lsh_oracle.c (cv-sfm/src/lib.rs:672, :622-624):
     nearest-codeword bag hash over a 4096-word codebook with duplicate words (tie -> lowest index), an empty
