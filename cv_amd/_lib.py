@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene", "rs_debug_residuals",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "rs_debug_scene_world",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
     "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
@@ -219,6 +219,9 @@ def lib():
     L.rs_batch_reserve.argtypes = [vp, u32]
     L.rs_essential_arrsac_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(Camera), C.POINTER(Camera),
                                                    C.POINTER(ArrsacParams), u32, vp, vp, vp, vp, vp, vp]
+    L.rs_p3p_arrsac_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, C.POINTER(Camera), C.POINTER(ArrsacParams), u32,
+                                             vp, vp, vp, vp, vp, vp]
+    L.rs_debug_scene_world.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
     L.rs_sync.argtypes = [vp]
     L.rs_stream.restype = vp
     L.rs_stream.argtypes = [vp]

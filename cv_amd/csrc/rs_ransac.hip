@@ -55,6 +55,34 @@ __host__ __device__ __forceinline__ void rs_calibrate_one(const double* intr /* 
     out[2] = 1.0 / nrm;
 }
 
+// `WorldToCamera::residual(pose, match) < thresh` (cv-core/src/pose.rs:194-201) — the boolean only.  The exact statement
+// (akz_w2c_residual) spends most of its instructions on three f64 divisions and a square root; almost every (pose, match)
+// pair is far from the threshold, so the test is first made on  1 - (a . q) rsqrt(q . q)  (reciprocal square root by the
+// hardware estimate + two Newton steps: relative error < 1e-12 whatever the estimate's accuracy above 2^-10) and the exact
+// statement decides only inside a band 1000 times wider than that error around the threshold, or when q . q is not an
+// ordinary number.  The result is the exact statement's for every input.
+__device__ __forceinline__ bool rs_w2c_inlier(const double* __restrict__ pose, const double* __restrict__ a,
+                                              const double* __restrict__ w, double thresh)
+{
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = ((pose[r * 4 + 0] * w[0] + pose[r * 4 + 1] * w[1]) + pose[r * 4 + 2] * w[2]) + pose[r * 4 + 3] * w[3];
+    const double sgn = __builtin_signbit(w[3]) ? -1.0 : 1.0;
+    const double s2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    const double c = sgn * ((a[0] * q[0] + a[1] * q[1]) + a[2] * q[2]);
+    if (s2 > 1e-200 && s2 < 1e200 && fabs(c) < 1e200) {
+        double y = __builtin_amdgcn_rsq(s2);
+        y = y * (1.5 - (0.5 * s2) * (y * y));
+        y = y * (1.5 - (0.5 * s2) * (y * y));
+        const double cy = c * y;
+        const double r = 1.0 - cy;
+        const double band = 1e-9 * (1.0 + fabs(cy));
+        if (r < thresh - band) return true;
+        if (r > thresh + band) return false;
+    }
+    return akz_w2c_residual(pose, a, w) < thresh;
+}
+
 // EightPoint::from_matches + possible_unscaled_poses for one minimal sample, ONE LANE, registers only: the 9 x 9
 // normal matrix (upper triangle) and its 81 eigenvector components never leave the register file (akz_rm_jacobi9_sym;
 // the kernel is compiled for one wave per SIMD, 512 VGPRs).  a / b: the scene's bearings; smp: 8 match indices.
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ be
         for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
         double b[3] = {bearings[3 * (size_t)m], bearings[3 * (size_t)m + 1], bearings[3 * (size_t)m + 2]};
         double w[4] = {world[4 * (size_t)m], world[4 * (size_t)m + 1], world[4 * (size_t)m + 2], world[4 * (size_t)m + 3]};
-        inl = akz_w2c_residual(pose, b, w) < thresh;
+        inl = rs_w2c_inlier(pose, b, w, thresh);
     }
     unsigned long long bal = __ballot(inl);
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[pid], (uint32_t)__popcll(bal));
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
             if (P3P) {
                 double wp[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
-                inl = akz_w2c_residual(pose, a, wp) < thresh;
+                inl = rs_w2c_inlier(pose, a, wp, thresh);
             } else {
                 double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
                 inl = rs_residual(pose, a, b) < thresh;
@@ -632,6 +660,66 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
         cnt += (uint32_t)__popcll(__ballot(inl) & gmask);
     }
     if (live && j == 0 && cnt) atomicAdd(&B.counts[B.p4(s) + pid], cnt);
+}
+
+// Block scoring of the registration consensus.  WorldToCamera::residual is a dozen multiplications per (pose, match), so
+// the match-per-lane organisation above spends its time gathering 56 bytes of match per lane; here a LANE is a live pose
+// (its 12 values in registers), the workgroup stages the matches of its part of [m_lo, m_hi) in LDS once and every lane
+// walks them (broadcast reads), counting in a register: one atomic per pose and launch.  blockIdx.y splits long ranges.
+constexpr uint32_t kP3PTile = 256;   // matches staged per pass (8 doubles each: bearing, world point, pad)
+__global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uint32_t m_hi, uint32_t from_first, double thresh)
+{
+    __shared__ __attribute__((aligned(16))) double s_m[kP3PTile][8];
+    const uint32_t s = blockIdx.z;
+    const uint32_t n = B.n[s];
+    const uint32_t hi = m_hi < n ? m_hi : n;
+    if (m_lo >= hi) return;
+    const uint32_t first = from_first ? B.first[s] : 0u;
+    const uint32_t nal = B.nalive[s];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nal > first)
+        atomicAdd(&B.neval[s], (unsigned long long)(nal - first) * (unsigned long long)(hi - m_lo));
+    const uint32_t slot0 = first + blockIdx.x * 256u;
+    if (slot0 >= nal) return;   // whole workgroup
+    const uint32_t part = (hi - m_lo + gridDim.y - 1) / gridDim.y;
+    const uint32_t lo = m_lo + blockIdx.y * part;
+    const uint32_t hi_p = lo + part < hi ? lo + part : hi;
+    if (lo >= hi_p) return;
+    const uint32_t slot = slot0 + threadIdx.x;
+    const bool live = slot < nal;
+    const uint32_t pid = live ? B.alive[B.p4(s) + slot] : 0u;
+    double pose[12];
+    const double* pp = B.sposes(s) + (size_t)pid * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
+    const double* ba = B.sa(s);
+    const double* bb = B.sb(s);
+    const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
+    uint32_t cnt = 0;
+    for (uint32_t t0 = lo; t0 < hi_p; t0 += kP3PTile) {
+        const uint32_t tn = hi_p - t0 < kP3PTile ? hi_p - t0 : kP3PTile;
+        __syncthreads();   // the previous tile has been read
+        if (threadIdx.x < tn) {
+            const uint32_t m = order ? order[t0 + threadIdx.x] : t0 + threadIdx.x;
+            double* d = s_m[threadIdx.x];
+            d[0] = ba[3 * (size_t)m]; d[1] = ba[3 * (size_t)m + 1]; d[2] = ba[3 * (size_t)m + 2];
+            d[3] = 0.0;
+            d[4] = bb[4 * (size_t)m]; d[5] = bb[4 * (size_t)m + 1]; d[6] = bb[4 * (size_t)m + 2]; d[7] = bb[4 * (size_t)m + 3];
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll 2
+            for (uint32_t i = 0; i < tn; ++i) {
+                const double2 a01 = *reinterpret_cast<const double2*>(&s_m[i][0]);
+                const double2 a2x = *reinterpret_cast<const double2*>(&s_m[i][2]);
+                const double2 w01 = *reinterpret_cast<const double2*>(&s_m[i][4]);
+                const double2 w23 = *reinterpret_cast<const double2*>(&s_m[i][6]);
+                const double a[3] = {a01.x, a01.y, a2x.x};
+                const double w[4] = {w01.x, w01.y, w23.x, w23.y};
+                cnt += rs_w2c_inlier(pose, a, w, thresh) ? 1u : 0u;
+            }
+        }
+    }
+    if (live && cnt) atomicAdd(&B.counts[B.p4(s) + pid], cnt);
 }
 
 // The first block of a call: nothing has been retired yet, so the live list is every valid pose and the four poses of
@@ -944,7 +1032,7 @@ __global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
             if (P3P) {
                 double w[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
-                inl = akz_w2c_residual(pose, a, w) < thresh;
+                inl = rs_w2c_inlier(pose, a, w, thresh);
             } else {
                 double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
                 inl = rs_residual(pose, a, b) < thresh;
@@ -973,7 +1061,10 @@ struct RsCam {
 };
 // One workgroup per scene.  Scene s = pair list `s` of the matcher's output ([cap][2] indices into keypoint blocks
 // fa[s] of d_kps_a and fb[s] of d_kps_b); FeatureMatch(a, b) of cv-sfm/src/lib.rs:1400-1403 (match_ix_kps).
-__global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint* __restrict__ kps_a, const akz_keypoint* __restrict__ kps_b,
+// P3P: scene s = a list of (feature of keypoint block fa[s], world point) index pairs — FeatureWorldMatch(bearing, point) of
+// cv-sfm/src/lib.rs:1571-1590; kps_b is the table of homogeneous world points ([..][4] f64) and cam_b / fb are unused.
+template <bool P3P>
+__global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint* __restrict__ kps_a, const void* __restrict__ kps_b_or_world,
                                                       uint32_t cap_per_img, const uint32_t* __restrict__ fa, const uint32_t* __restrict__ fb,
                                                       const uint32_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
                                                       RsCam cam_a, RsCam cam_b, uint32_t* __restrict__ n_out, double* __restrict__ a_out,
@@ -987,7 +1078,6 @@ __global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint*
     n = n < B.n_cap ? n : B.n_cap;
     if (threadIdx.x == 0) n_out[s] = n;
     const akz_keypoint* ka = kps_a + (size_t)fa[s] * cap_per_img;
-    const akz_keypoint* kb = kps_b + (size_t)fb[s] * cap_per_img;
     const uint32_t* pr = pairs + (size_t)s * cap_per_img * 2;
     double* ao = a_out + (size_t)s * B.n_cap * 3;
     double* bo = b_out + (size_t)s * B.n_cap * 4;
@@ -996,8 +1086,14 @@ __global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint*
         double o[3];
         rs_calibrate_one(cam_a.intr, cam_a.use_k1, cam_a.k1, ka[ia].x, ka[ia].y, o);
         ao[3 * j] = o[0]; ao[3 * j + 1] = o[1]; ao[3 * j + 2] = o[2];
-        rs_calibrate_one(cam_b.intr, cam_b.use_k1, cam_b.k1, kb[ib].x, kb[ib].y, o);
-        bo[3 * j] = o[0]; bo[3 * j + 1] = o[1]; bo[3 * j + 2] = o[2];
+        if (P3P) {
+            const double* wp = (const double*)kps_b_or_world + (size_t)4 * ib;
+            bo[4 * j] = wp[0]; bo[4 * j + 1] = wp[1]; bo[4 * j + 2] = wp[2]; bo[4 * j + 3] = wp[3];
+        } else {
+            const akz_keypoint* kb = (const akz_keypoint*)kps_b_or_world + (size_t)fb[s] * cap_per_img;
+            rs_calibrate_one(cam_b.intr, cam_b.use_k1, cam_b.k1, kb[ib].x, kb[ib].y, o);
+            bo[3 * j] = o[0]; bo[3 * j + 1] = o[1]; bo[3 * j + 2] = o[2];
+        }
     }
     if (!shuffle) return;
     // scoring order = stable ascending sort of the matches' 32-bit shuffle keys (LSD radix sort in LDS)
@@ -1067,7 +1163,7 @@ __global__ __launch_bounds__(1024) void k_rs_inliers(const double* __restrict__ 
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
             if (P3P) {
                 double w[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
-                inl = akz_w2c_residual(pose, a, w) < thresh;
+                inl = rs_w2c_inlier(pose, a, w, thresh);
             } else {
                 double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
                 inl = rs_residual(pose, a, b) < thresh;
@@ -1421,6 +1517,13 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
     uint32_t next_h = n_hyp;                                  // first hypothesis slot of the next re-sampling round
     auto score = [&](uint32_t m_lo, uint32_t m_hi, uint32_t slots, uint32_t from_first) -> int32_t {
         const uint32_t range = m_hi - m_lo;
+        if (P3P) {
+            uint32_t gy = range / 64;
+            gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
+            hipLaunchKernelGGL(k_rsb_score_p3p, dim3((slots + 255) / 256, gy, S), dim3(256), 0, s, B, m_lo, m_hi, from_first, prm->threshold);
+            AKZ_LAUNCH_CHECK();
+            return AKZ_OK;
+        }
         uint32_t lg = 6;
         if (range < 64) {
             lg = 0;
@@ -1623,9 +1726,9 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
         const bool shuffle = (flags & RS_BATCH_SHUFFLE) != 0;
         const RsB B = rs_view(c, shuffle);
         if (shuffle)
-            AKZ_HIP(hipFuncSetAttribute((const void*)k_rsb_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
-        hipLaunchKernelGGL(k_rsb_prepare, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps_a,
-                           (const akz_keypoint*)d_kps_b, cap_per_img, (const uint32_t*)c->d_frames,
+            AKZ_HIP(hipFuncSetAttribute((const void*)k_rsb_prepare<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
+        hipLaunchKernelGGL(k_rsb_prepare<false>, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps_a,
+                           d_kps_b, cap_per_img, (const uint32_t*)c->d_frames,
                            (const uint32_t*)(c->d_frames + c->max_scenes), (const uint32_t*)d_pairs, (const uint32_t*)d_npairs, cam(cam_a),
                            cam(cam_b), c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u, (unsigned long long)prm->seed);
         AKZ_LAUNCH_CHECK();
@@ -1644,6 +1747,62 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
     });
 }
 
+// The registration path's consensus for a whole micro-batch (cv-sfm/src/lib.rs:1571-1622 for every new frame): scene s =
+// a list of (feature of keypoint block ik[s], world point) index pairs; bearing = calibrate(keypoint), point = d_world[idx]
+// (homogeneous, [n_world][4] f64: the control plane's triangulated landmarks); Lambda Twist hypotheses from 3-match
+// samples, WorldToCamera::residual, the same ARRSAC-shaped loop over all scenes at once.
+extern "C" int32_t rs_p3p_arrsac_batch_device(rs_ctx* c, const void* d_kps, uint32_t cap_per_img, const uint32_t* ik, const void* d_pairs,
+                                              const void* d_npairs, uint32_t n_scenes, const void* d_world, const rs_camera* cam,
+                                              const rs_arrsac_params* prm, uint32_t flags, void* d_pose, void* d_best_id,
+                                              void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_kps || !ik || !d_pairs || !d_npairs || !d_world || !cam || !prm || !d_pose || !d_best_id || !d_inliers || !d_n_inliers)
+            return AKZ_E_INVALID;
+        if (cap_per_img == 0 || (flags & ~(uint32_t)RS_BATCH_SHUFFLE) || cam->reserved != 0) return AKZ_E_INVALID;
+        if (n_scenes == 0) return AKZ_OK;
+        if (n_scenes > c->max_scenes) return AKZ_E_TOO_LARGE;
+        const uint32_t n_max = cap_per_img < c->max_matches ? cap_per_img : c->max_matches;
+        if (n_max < 3) return AKZ_E_INVALID;
+        if ((flags & RS_BATCH_SHUFFLE) && n_max > kRadixSortMax) return AKZ_E_TOO_LARGE;
+        uint32_t blocks_max = 0;
+        AKZ_TRY(rs_check_params(c, prm, n_max, &blocks_max));
+        AKZ_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(s, c->ev, 0));
+        }
+        AKZ_HIP(hipMemcpyAsync(c->d_frames, ik, sizeof(uint32_t) * n_scenes, hipMemcpyHostToDevice, s));
+        RsCam k;
+        k.intr[0] = cam->fx; k.intr[1] = cam->fy; k.intr[2] = cam->cx; k.intr[3] = cam->cy; k.intr[4] = cam->skew;
+        k.k1 = cam->k1;
+        k.use_k1 = cam->use_k1 ? 1 : 0;
+        k.pad = 0;
+        const bool shuffle = (flags & RS_BATCH_SHUFFLE) != 0;
+        const RsB B = rs_view(c, shuffle);
+        if (shuffle)
+            AKZ_HIP(hipFuncSetAttribute((const void*)k_rsb_prepare<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
+        hipLaunchKernelGGL(k_rsb_prepare<true>, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps,
+                           d_world, cap_per_img, (const uint32_t*)c->d_frames, (const uint32_t*)c->d_frames, (const uint32_t*)d_pairs,
+                           (const uint32_t*)d_npairs, k, k, c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u,
+                           (unsigned long long)prm->seed);
+        AKZ_LAUNCH_CHECK();
+        RsOut O;
+        O.best_id = (uint32_t*)d_best_id;
+        O.pose = (double*)d_pose;
+        O.inl = (uint32_t*)d_inliers;
+        O.ninl = (uint32_t*)d_n_inliers;
+        O.stats = (rs_arrsac_stats*)d_stats;
+        O.inl_stride = cap_per_img;
+        O.n_hyp = O.resample = O.init_blocks = O.blocks_run = O.block_size = O.min_samples = 0;
+        uint32_t blocks = 0, made = 0;
+        AKZ_TRY((arrsac_engine<true>(c, n_scenes, n_max, prm, false, shuffle, O, &blocks, &made)));
+        c->last_hyp = made;
+        return AKZ_OK;
+    });
+}
+
 // debug tap of the batched entry: the calibrated bearings and the scoring order of scene `scene` of the last call
 extern "C" int32_t rs_debug_scene(rs_ctx* c, uint32_t scene, uint32_t* n, double* bearings_a, double* bearings_b, uint32_t* order,
                                   uint32_t cap)
@@ -1657,6 +1816,24 @@ extern "C" int32_t rs_debug_scene(rs_ctx* c, uint32_t scene, uint32_t* n, double
         const size_t N = c->max_matches;
         if (bearings_a) AKZ_HIP(hipMemcpy(bearings_a, c->d_a + scene * N * 3, sizeof(double) * 3 * (size_t)*n, hipMemcpyDeviceToHost));
         if (bearings_b) AKZ_HIP(hipMemcpy(bearings_b, c->d_b + scene * N * 4, sizeof(double) * 3 * (size_t)*n, hipMemcpyDeviceToHost));
+        if (order) AKZ_HIP(hipMemcpy(order, c->d_order + scene * N, sizeof(uint32_t) * (size_t)*n, hipMemcpyDeviceToHost));
+        return AKZ_OK;
+    });
+}
+
+// the same tap after rs_p3p_arrsac_batch_device: bearings [n][3], world points [n][4]
+extern "C" int32_t rs_debug_scene_world(rs_ctx* c, uint32_t scene, uint32_t* n, double* bearings, double* world, uint32_t* order,
+                                        uint32_t cap)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !n || scene >= c->max_scenes) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(n, c->d_n + scene, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (*n > cap) return AKZ_E_CAPACITY;
+        const size_t N = c->max_matches;
+        if (bearings) AKZ_HIP(hipMemcpy(bearings, c->d_a + scene * N * 3, sizeof(double) * 3 * (size_t)*n, hipMemcpyDeviceToHost));
+        if (world) AKZ_HIP(hipMemcpy(world, c->d_b + scene * N * 4, sizeof(double) * 4 * (size_t)*n, hipMemcpyDeviceToHost));
         if (order) AKZ_HIP(hipMemcpy(order, c->d_order + scene * N, sizeof(uint32_t) * (size_t)*n, hipMemcpyDeviceToHost));
         return AKZ_OK;
     });

@@ -166,6 +166,17 @@ class EssentialConsensus:
             _lib.RS_BATCH_SHUFFLE if shuffle else 0, d_pose, d_best_id, d_inliers, d_n_inliers, d_stats, stream_to_wait),
             "rs_essential_arrsac_batch_device")
 
+    def p3p_model_inliers_batch_device(self, d_kps, cap_per_img, ik, d_pairs, d_npairs, d_world, cam, params, d_pose, d_best_id,
+                                       d_inliers, d_n_inliers, d_stats=None, shuffle=True, stream_to_wait=None):
+        """rs_p3p_arrsac_batch_device: scene s = (feature of keypoint block ik[s], world point index) pairs; d_world
+        [..][4] f64.  Enqueues and returns; sync() waits."""
+        n = len(ik)
+        k = (C.c_uint32 * n)(*ik)
+        check(_lib.lib().rs_p3p_arrsac_batch_device(
+            self._h, d_kps, cap_per_img, k, d_pairs, d_npairs, n, d_world, C.byref(cam), C.byref(params),
+            _lib.RS_BATCH_SHUFFLE if shuffle else 0, d_pose, d_best_id, d_inliers, d_n_inliers, d_stats, stream_to_wait),
+            "rs_p3p_arrsac_batch_device")
+
     def sync(self):
         check(_lib.lib().rs_sync(self._h), "rs_sync")
 
@@ -178,6 +189,14 @@ class EssentialConsensus:
         a = np.zeros((cap, 3), np.float64); b = np.zeros((cap, 3), np.float64); o = np.zeros(cap, np.uint32)
         check(_lib.lib().rs_debug_scene(self._h, scene, C.byref(n), a.ctypes.data, b.ctypes.data, o.ctypes.data, cap),
               "rs_debug_scene")
+        return a[:n.value], b[:n.value], o[:n.value]
+
+    def scene_world(self, scene, cap):
+        """(bearings, world points [n][4], order) of scene `scene` of the last rs_p3p_arrsac_batch_device call."""
+        n = C.c_uint32()
+        a = np.zeros((cap, 3), np.float64); b = np.zeros((cap, 4), np.float64); o = np.zeros(cap, np.uint32)
+        check(_lib.lib().rs_debug_scene_world(self._h, scene, C.byref(n), a.ctypes.data, b.ctypes.data, o.ctypes.data, cap),
+              "rs_debug_scene_world")
         return a[:n.value], b[:n.value], o[:n.value]
 
     def residuals(self, poses, bearings_a, bearings_b, paired=False):

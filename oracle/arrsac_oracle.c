@@ -347,3 +347,35 @@ int orc_arrsac_pairs(const akz_keypoint* kps_a, const akz_keypoint* kps_b, const
     free(order);
     return rc;
 }
+
+/* One scene of rs_p3p_arrsac_batch_device (cv-sfm/src/lib.rs:1571-1622): pairs [n][2] = {feature index into kps, index
+ * into world ([..][4] homogeneous points)}; bearing = calibrate(keypoint).  bearings ([n][3]), world_out ([n][4]) and
+ * order ([n]) optionally receive what the consensus ran on.  Returns 0, -1 (no model). */
+int orc_p3p_arrsac_pairs(const akz_keypoint* kps, const uint32_t* pairs, uint32_t n, const double* cam, int use_k1,
+                         const double* world, uint32_t scene, int shuffle, const rs_arrsac_params* prm, double* best_pose,
+                         uint32_t* best_id, uint32_t* inlier_idx, uint32_t* n_inliers, uint32_t* stats, double* bearings,
+                         double* world_out, uint32_t* order_out)
+{
+    *n_inliers = 0;
+    *best_id = 0xFFFFFFFFu;
+    double* a = (double*)malloc(sizeof(double) * 3 * (n ? n : 1));
+    double* b = (double*)malloc(sizeof(double) * 4 * (n ? n : 1));
+    uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t j = 0; j < n; ++j) {
+        orc_calibrate(cam, use_k1, cam[5], kps + pairs[2 * j], 1, a + 3 * j);
+        memcpy(b + 4 * j, world + (size_t)4 * pairs[2 * j + 1], sizeof(double) * 4);
+    }
+    rs_arrsac_params p = *prm;
+    p.seed = orc_scene_seed(prm->seed, scene);
+    if (shuffle) orc_shuffle_order(p.seed, n, order);
+    /* fewer matches than a minimal sample (LambdaTwist::MIN_SAMPLES = 3): None */
+    int rc = n < 3 ? -1
+                   : orc_arrsac_ordered(1, a, b, n, NULL, shuffle ? order : NULL, &p, best_pose, best_id, inlier_idx, n_inliers, stats);
+    if (bearings) memcpy(bearings, a, sizeof(double) * 3 * n);
+    if (world_out) memcpy(world_out, b, sizeof(double) * 4 * n);
+    if (order_out && shuffle) memcpy(order_out, order, sizeof(uint32_t) * n);
+    free(a);
+    free(b);
+    free(order);
+    return rc;
+}

@@ -113,6 +113,9 @@ def lib():
         L.orc_arrsac_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_p3p_arrsac_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         L.orc_shuffle_order.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
         L.orc_scene_seed.restype = C.c_uint64
         L.orc_scene_seed.argtypes = [C.c_uint64, C.c_uint32]
@@ -561,6 +564,31 @@ def arrsac_pairs(kps_a, kps_b, pairs, cam_a, cam_b, threshold, n_hypotheses, sce
              "poses": int(st[4]) * 4}
     return {"pose": pose, "inliers": inl[:ninl.value].copy(), "best_id": best.value, "stats": stats,
             "bearings_a": ba[:n], "bearings_b": bb[:n], "order": order[:n]}
+
+
+def p3p_arrsac_pairs(kps, pairs, world, cam, threshold, n_hypotheses, scene=0, shuffle=True, seed=0, block_size=64,
+                     init_blocks=4, max_candidates=1024, bound=True, sprt=True, sprt_delta=0.05, sprt_ratio=1e3,
+                     estimations_per_block=0, halve=False):
+    """oracle/arrsac_oracle.c: orc_p3p_arrsac_pairs — one scene of rs_p3p_arrsac_batch_device: keypoints + (feature, world
+    point) index pairs + homogeneous world points [..][4] -> bearings / points -> (seeded shuffle) -> the ARRSAC-shaped
+    consensus over Lambda Twist hypotheses.  Returns dict(pose, inliers, best_id, stats, bearings, world, order)."""
+    k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    pr = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    W = np.ascontiguousarray(world, np.float64).reshape(-1, 4)
+    n = len(pr)
+    prm = _arrsac_params(threshold, n_hypotheses, seed, block_size, init_blocks, max_candidates, bound, sprt, sprt_delta,
+                         sprt_ratio, estimations_per_block, halve)
+    c = np.array([cam[0], cam[1], cam[2], cam[3], cam[4], cam[5] if cam[5] is not None else 0.0], np.float64)
+    pose = np.zeros((3, 4), np.float64); best = C.c_uint32(); ninl = C.c_uint32()
+    inl = np.empty(max(n, 1), np.uint32); st = np.zeros(5, np.uint32)
+    ba = np.zeros((max(n, 1), 3), np.float64); wo = np.zeros((max(n, 1), 4), np.float64); order = np.arange(max(n, 1), dtype=np.uint32)
+    lib().orc_p3p_arrsac_pairs(k.ctypes.data, pr.ctypes.data, n, c.ctypes.data, int(cam[5] is not None), W.ctypes.data, scene,
+                               int(shuffle), C.byref(prm), pose.ctypes.data, C.byref(best), inl.ctypes.data, C.byref(ninl),
+                               st.ctypes.data, ba.ctypes.data, wo.ctypes.data, order.ctypes.data)
+    stats = {"residuals_evaluated": int(st[0]) | (int(st[1]) << 32), "survivors": int(st[2]), "blocks": int(st[3]),
+             "poses": int(st[4]) * 4}
+    return {"pose": pose, "inliers": inl[:ninl.value].copy(), "best_id": best.value, "stats": stats,
+            "bearings": ba[:n], "world": wo[:n], "order": order[:n]}
 
 
 # ---- the CPU baseline build (bench.py's cpu_baseline legs only) ----------------------------------------------------

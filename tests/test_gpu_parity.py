@@ -790,6 +790,45 @@ def test_p3p_bit_exact(gpu, oracle):
     assert len(inl) > 0.5 * n and np.abs(pose[:, :3] - Rr).max() < 1e-6
 
 
+def test_p3p_inlier_test_is_exact_at_the_threshold(gpu, oracle):
+    """The device decides `WorldToCamera::residual < thresh` on a cheap estimate and falls back to the exact statement
+    near the threshold (rs_w2c_inlier).  Thresholds placed EXACTLY on residuals of the winning pose, one ulp above and
+    one ulp below, negative homogeneous weights, huge and tiny point scales: the inlier set is always the oracle's."""
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import _projective, _rot
+    rng = np.random.default_rng(0x7E57)
+    n = 400
+    Rr = _rot(rng.random(3) * 0.8); tr = rng.random(3)
+    pts = rng.random((n, 3)) * 4.0 - 2.0
+    pts[:, 2] += 6.0
+    cam = pts @ Rr.T + tr
+    bb = cam / np.linalg.norm(cam, axis=1, keepdims=True)
+    bb += rng.standard_normal(bb.shape) * 1e-4
+    bb /= np.linalg.norm(bb, axis=1, keepdims=True)
+    world = _projective(pts)
+    world[::3] *= -1.0                      # signbit(w) arm: the point is negated, not the result
+    world[1::7] *= 1e-150                   # q . q far outside the ordinary range: the exact statement decides
+    world[2::7] *= 1e120
+    samples = np.stack([rng.choice(n, 3, replace=False) for _ in range(64)]).astype(np.uint32)
+    cons = EssentialConsensus(1024, 1024)
+    wpose, wbest, winl, _ = oracle.p3p_batch(bb, world, samples, 1e-6)
+    res = np.array([oracle.w2c_residual(wpose, bb[i], world[i]) for i in range(n)])
+    assert np.isfinite(res).all() and (res > 0).sum() > n // 2
+    checked = 0
+    for k in np.argsort(res)[n // 4::n // 16][:10]:
+        for thr in (res[k], np.nextafter(res[k], np.inf), np.nextafter(res[k], -np.inf)):
+            want = oracle.p3p_batch(bb, world, samples, float(thr))
+            got = cons.p3p_model_inliers(bb, world, samples, float(thr))
+            assert (got is None) == (want is None)
+            if want is None:
+                continue
+            _eq(cons.counts(len(samples)), want[3], f"counts at thr {thr!r}")
+            assert got[2] == want[1]
+            _eq(got[1], want[2], f"inliers at thr {thr!r}")
+            checked += 1
+    assert checked >= 24
+
+
 def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     """The N>1 path of bench.py end to end on ONE GPU: two ranks (gloo, both on cuda:0) shard 32 global frames
     g -> rank g % 2, pass their descriptor blocks one rank up the ring and match every frame against its
@@ -1277,6 +1316,91 @@ def test_batched_two_view_verification_equals_its_specification(gpu, oracle, nam
         _eq(inl[s, :ninl[s]], want["inliers"], f"scene {s} inliers ({name})")
         for key, wkey in (("survivors", "survivors"), ("blocks", "blocks"), ("poses", "poses"), ("evaluated", "residuals_evaluated")):
             assert int(st[key][s]) == want["stats"][wkey], (name, s, key, st[s], want["stats"])
+    assert some_model >= 8
+
+
+REG_RULES = [
+    ("halving, 16-match blocks, shuffled", dict(block_size=16, init_blocks=1, max_candidates=64, halve=True), True),
+    ("cap + sprt, 64-match blocks", dict(block_size=64, init_blocks=2, max_candidates=96, sprt=True), False),
+    ("re-sampling, 40-match blocks, shuffled", dict(block_size=40, init_blocks=1, max_candidates=48, sprt=True, halve=True,
+                                                    estimations_per_block=12), True),
+    ("bound only, 100-match blocks", dict(block_size=100, init_blocks=1, max_candidates=0, sprt=False), False),
+]
+
+
+@pytest.mark.parametrize("name,kw,shuffle", REG_RULES, ids=[r[0] for r in REG_RULES])
+def test_batched_registration_consensus_equals_its_specification(gpu, oracle, name, kw, shuffle):
+    """rs_p3p_arrsac_batch_device (cv-sfm/src/lib.rs:1571-1622 for every new frame of a micro-batch):
+    device-resident keypoints, (feature, world point) pair lists and the world-point table in, WorldToCamera pose /
+    inlier list / id per scene out.  Ragged scenes — empty, two matches, exactly three, a full block, the capacity — each
+    equal to oracle/arrsac_oracle.c (orc_p3p_arrsac_pairs) in bearing and point bits, scoring order, winner id, pose
+    bits, inlier list, survivors, blocks and residuals evaluated."""
+    import torch
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_arrsac import _registration_scene
+    rng = np.random.default_rng(0x9E6)
+    cap, n_hyp, n_world = 512, 160, 700
+    cam = (950.0, 955.0, 640.0, 250.0, 0.5, -0.05)       # skew + the K1-distortion arm
+    sizes = [300, 0, 2, 3, 17, 64, 512, 129, 400, 4, 16, 250]
+    S = len(sizes)
+    pairs = np.zeros((S, cap, 2), np.uint32)
+    scenes = []
+    worlds = []
+    for s, n in enumerate(sizes):
+        kps, world, pr, R, t, good = _registration_scene(rng, cap, n_world, n, 0.3, cam)
+        pr = pr.copy(); pr[:, 1] += s * n_world            # one table for all scenes
+        scenes.append((kps, pr, R, t))
+        worlds.append(world)
+        pairs[s, :n] = pr
+    world_all = np.concatenate(worlds)
+    ik = [S - 1 - s for s in range(S)]                      # keypoint blocks stored in reverse scene order
+    kps_all = np.stack([sc[0] for sc in scenes[::-1]])
+    npairs = np.array(sizes, np.uint32)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(kps_all.view(np.uint8).reshape(S, cap, 28)).to(dev)
+    d_pairs = torch.from_numpy(pairs.view(np.int32)).to(dev)
+    d_np = torch.from_numpy(npairs.view(np.int32)).to(dev)
+    d_world = torch.from_numpy(world_all).to(dev)
+    d_pose = torch.zeros((S, 12), dtype=torch.float64, device=dev)
+    d_best = torch.zeros((S,), dtype=torch.int32, device=dev)
+    d_inl = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+    d_ninl = torch.zeros((S,), dtype=torch.int32, device=dev)
+    d_stats = torch.zeros((S, 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    blocks_max = (cap + kw["block_size"] - 1) // kw["block_size"]
+    cons = EssentialConsensus(cap, n_hyp + kw.get("estimations_per_block", 0) * blocks_max)
+    cons.reserve(S)
+    thr = 1e-6
+    prm = cons.make_params(thr, n_hypotheses=n_hyp, seed=41, **kw)
+    for rep in range(2):
+        cons.p3p_model_inliers_batch_device(d_k.data_ptr(), cap, ik, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(),
+                                            cons.camera(cam), prm, d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(),
+                                            d_ninl.data_ptr(), d_stats.data_ptr(), shuffle=shuffle)
+    cons.sync()
+    pose = d_pose.cpu().numpy(); best = d_best.cpu().numpy().view(np.uint32); inl = d_inl.cpu().numpy().view(np.uint32)
+    ninl = d_ninl.cpu().numpy().view(np.uint32)
+    st = d_stats.cpu().numpy().view(np.dtype([("poses", "<u4"), ("survivors", "<u4"), ("blocks", "<u4"), ("reserved", "<u4"),
+                                               ("evaluated", "<u8"), ("exhaustive", "<u8")])).reshape(S)
+    some_model = 0
+    for s, (kps, pr, R, t) in enumerate(scenes):
+        want = oracle.p3p_arrsac_pairs(kps, pr, world_all, cam, thr, n_hyp, scene=s, shuffle=shuffle, seed=41, **kw)
+        ga, gw, go = cons.scene_world(s, cap)
+        _eq(ga, want["bearings"], f"scene {s} bearings")
+        _eq(gw, want["world"], f"scene {s} world points")
+        if shuffle:
+            _eq(go, want["order"], f"scene {s} scoring order")
+        assert best[s] == want["best_id"], (name, s, len(pr), best[s], want["best_id"])
+        assert ninl[s] == len(want["inliers"]), (name, s, ninl[s], len(want["inliers"]))
+        if want["best_id"] == 0xFFFFFFFF:
+            assert len(pr) < 3 or st["survivors"][s] == 0
+            continue
+        some_model += 1
+        _eq(pose[s].reshape(3, 4), want["pose"], f"scene {s} pose ({name})")
+        _eq(inl[s, :ninl[s]], want["inliers"], f"scene {s} inliers ({name})")
+        for key, wkey in (("survivors", "survivors"), ("blocks", "blocks"), ("poses", "poses"), ("evaluated", "residuals_evaluated")):
+            assert int(st[key][s]) == want["stats"][wkey], (name, s, key, st[s], want["stats"])
+        if len(pr) >= 64:
+            assert np.abs(pose[s].reshape(3, 4)[:, :3] - R).max() < 1e-2, (s, len(pr))
     assert some_model >= 8
 
 

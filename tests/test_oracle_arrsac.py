@@ -200,3 +200,55 @@ def test_micro_batch_scene_entry(oracle):
     camk = cam[:5] + (-0.05,)
     rk = oracle.arrsac_pairs(ka, kb, pr, cam, camk, 1e-7, 64, scene=0, **kw)
     assert rk["bearings_b"].tobytes() == oracle.calibrate(kb[pr[:, 1]], *cam[:5], k1=-0.05).tobytes()
+
+
+def _registration_scene(rng, n_kp, n_world, n_pairs, outlier_frac, cam, noise_px=0.2):
+    """One new frame against a landmark table: keypoints (pixel coordinates, f32), homogeneous world points and a
+    (feature, world point) pair list, `outlier_frac` of it joined at random.  Returns kps, world, pairs, R, t, good."""
+    from test_oracle_ransac import _rot
+    from oracle.oracle import KP_DTYPE
+    R = _rot((rng.random(3) - 0.5) * 0.6)
+    t = (rng.random(3) - 0.5) * 1.0
+    fx, fy, cx, cy, skew = cam[:5]
+    pts = np.stack([rng.uniform(-2, 2, n_world), rng.uniform(-1.2, 1.2, n_world), rng.uniform(4, 9, n_world)], 1)
+    world = np.concatenate([pts, np.ones((n_world, 1))], 1) * rng.uniform(0.5, 2.0, (n_world, 1))   # any projective scale
+    camp = pts @ R.T + t
+    x, y = camp[:, 0] / camp[:, 2], camp[:, 1] / camp[:, 2]
+    kps = np.zeros(n_kp, KP_DTYPE)
+    which = rng.integers(0, n_world, n_kp)                       # keypoint i observes world point which[i]
+    kps["x"] = fx * x[which] + skew * y[which] + cx + rng.standard_normal(n_kp) * noise_px
+    kps["y"] = fy * y[which] + cy + rng.standard_normal(n_kp) * noise_px
+    feat = rng.choice(n_kp, size=min(n_pairs, n_kp), replace=False)
+    wi = which[feat].copy()
+    bad = rng.random(len(feat)) < outlier_frac
+    wi[bad] = rng.integers(0, n_world, bad.sum())
+    good = wi == which[feat]
+    o = np.argsort(feat, kind="stable")
+    return kps, world, np.stack([feat[o], wi[o]], 1).astype(np.uint32), R, t, good[o]
+
+
+def test_registration_scene_entry(oracle):
+    """orc_p3p_arrsac_pairs, the specification of one scene of rs_p3p_arrsac_batch_device: bearings = orc_calibrate of the
+    paired keypoints, points = the paired rows of the world table, the scene entry equals the single-scene P3P
+    specification on them with the scene's seed, fewer than three matches give no model, and the pose of the scene comes
+    back (WorldToCamera; 1e-3: f32 pixel coordinates + 0.2 px noise)."""
+    rng = np.random.default_rng(80)
+    cam = (984.2439, 980.8141, 690.0, 233.1966, 0.0, None)
+    kps, world, pr, R, t, good = _registration_scene(rng, 600, 900, 500, 0.3, cam)
+    kw = dict(seed=5, block_size=32, init_blocks=1, max_candidates=64, halve=True)
+    r0 = oracle.p3p_arrsac_pairs(kps, pr, world, cam, 1e-6, 512, scene=0, shuffle=True, **kw)
+    assert r0["bearings"].tobytes() == oracle.calibrate(kps[pr[:, 0]], *cam[:5]).tobytes()
+    assert r0["world"].tobytes() == np.ascontiguousarray(world[pr[:, 1]]).tobytes()
+    assert np.array_equal(r0["order"], oracle.shuffle_order(oracle.scene_seed(5, 0), len(pr)))
+    assert r0["best_id"] != 0xFFFFFFFF and len(r0["inliers"]) > 0.7 * good.sum()
+    assert good[r0["inliers"]].mean() > 0.98
+    assert np.abs(r0["pose"][:, :3] - R).max() < 1e-3 and np.abs(r0["pose"][:, 3] - t).max() < 1e-2
+    rn = oracle.p3p_arrsac_pairs(kps, pr, world, cam, 1e-6, 512, scene=3, shuffle=False, **kw)
+    kw2 = dict(kw); kw2["seed"] = oracle.scene_seed(5, 3)
+    ref = oracle.arrsac(rn["bearings"], rn["world"], 1e-6, 512, p3p=True, **kw2)
+    assert ref[2] == rn["best_id"] and ref[0].tobytes() == rn["pose"].tobytes() and np.array_equal(ref[1], rn["inliers"])
+    few = oracle.p3p_arrsac_pairs(kps, pr[:2], world, cam, 1e-6, 64, scene=0, **kw)
+    assert few["best_id"] == 0xFFFFFFFF and len(few["inliers"]) == 0
+    camk = cam[:5] + (-0.05,)
+    rk = oracle.p3p_arrsac_pairs(kps, pr, world, camk, 1e-6, 64, scene=0, **kw)
+    assert rk["bearings"].tobytes() == oracle.calibrate(kps[pr[:, 0]], *cam[:5], k1=-0.05).tobytes()

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Throughput of rs_essential_arrsac_batch_device alone: S synthetic frame pairs (pixel keypoints of a rigid motion
+"""Throughput of rs_essential_arrsac_batch_device (or, with --registration, rs_p3p_arrsac_batch_device) alone: S synthetic frame pairs (pixel keypoints of a rigid motion
 seen through a pinhole camera, `--matches` pairs each, a fraction joined at random), vslam-sandbox's consensus
 parameters (8192 initialisation hypotheses, 1024 candidates; vslam-sandbox/src/main.rs:112-117).  Prints one JSON line.
 
   python tools/bench_verify.py [--scenes 256] [--matches 4400] [--hyp 8192] [--block 16] [--check 2]
+  python tools/bench_verify.py --registration --cap 2048 --matches 1500 --hyp 16384 --block 64 --resample 256 --thr 1e-5
+      (the single-view consensus of vslam-sandbox/src/main.rs:104-110: 16 384 hypotheses, 1 024 candidates, 256 estimations
+       per block, threshold cv-sfm/src/settings.rs:352-355)
 """
 import argparse
 import json
@@ -59,6 +62,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=2, help="scenes compared with oracle/arrsac_oracle.c")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic scenes (repeated to fill --scenes)")
+    ap.add_argument("--registration", action="store_true", help="the P3P registration consensus instead of the two-view one")
+    ap.add_argument("--resample", type=int, default=0, help="estimations_per_block")
     args = ap.parse_args()
 
     import torch
@@ -70,7 +75,19 @@ def main():
     cam = (1000.0, 1000.0, 960.0, 540.0, 0.0, None)
     rng = np.random.default_rng(0xFE11)
     nd = min(args.distinct, S)
-    base = [make_scene(rng, cap, args.matches, args.outliers, cam, args.noise) for _ in range(nd)]
+    n_world = 4 * cap
+    if args.registration:
+        from test_oracle_arrsac import _registration_scene
+        base, worlds = [], []
+        for i in range(nd):
+            kps, world, pr, _, _, _ = _registration_scene(rng, cap, n_world, args.matches, args.outliers, cam, args.noise)
+            pr = pr.copy(); pr[:, 1] += i * n_world
+            base.append((kps, kps, pr))
+            worlds.append(world)
+        world_all = np.concatenate(worlds)
+        d_world = torch.from_numpy(world_all).to(dev)
+    else:
+        base = [make_scene(rng, cap, args.matches, args.outliers, cam, args.noise) for _ in range(nd)]
     kps_a = np.stack([b[0] for b in base]); kps_b = np.stack([b[1] for b in base])
     pairs = np.zeros((S, cap, 2), np.uint32)
     for s in range(S):
@@ -86,14 +103,19 @@ def main():
     d_ninl = torch.zeros((S,), dtype=torch.int32, device=dev)
     d_stats = torch.zeros((S, 32), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    cons = EssentialConsensus(cap, args.hyp)
+    cons = EssentialConsensus(cap, args.hyp + args.resample * ((cap + args.block - 1) // args.block))
     cons.reserve(S)
     kw = dict(block_size=args.block, init_blocks=args.init_blocks, max_candidates=args.candidates, halve=not args.no_halve,
-              sprt=not args.no_sprt)
+              sprt=not args.no_sprt, estimations_per_block=args.resample)
     prm = cons.make_params(args.thr, n_hypotheses=args.hyp, seed=0, **kw)
     c = cons.camera(cam)
 
     def run():
+        if args.registration:
+            cons.p3p_model_inliers_batch_device(d_ka.data_ptr(), cap, ia, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(), c, prm,
+                                                d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(),
+                                                d_stats.data_ptr(), shuffle=True)
+            return
         cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ib, d_pairs.data_ptr(), d_np.data_ptr(), c, c, prm,
                                         d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(), d_stats.data_ptr(),
                                         shuffle=True)
@@ -107,7 +129,7 @@ def main():
     ninl = d_ninl.cpu().numpy().view(np.uint32)
     st = d_stats.cpu().numpy().view(np.dtype([("poses", "<u4"), ("survivors", "<u4"), ("blocks", "<u4"), ("reserved", "<u4"),
                                                ("evaluated", "<u8"), ("exhaustive", "<u8")])).reshape(S)
-    out = {"scenes": S, "matches": args.matches, "hypotheses": args.hyp, "params": kw, "ms_per_call": round(dt * 1e3, 3),
+    out = {"what": "registration (P3P)" if args.registration else "two-view (eight-point)", "scenes": S, "matches": args.matches, "hypotheses": args.hyp, "params": kw, "ms_per_call": round(dt * 1e3, 3),
            "pairs_per_s": round(S / dt, 1), "hypotheses_per_s": round(S * args.hyp / dt, 1),
            "residuals_per_s": round(float(st["evaluated"].sum()) / dt, 1),
            "mean_inliers": round(float(ninl.mean()), 1), "mean_blocks": float(st["blocks"].mean()),
@@ -119,7 +141,10 @@ def main():
         t0 = time.perf_counter()
         for s in np.linspace(0, S - 1, args.check).astype(int):
             ka, kb, pr = base[s % nd]
-            w = O.arrsac_pairs(ka, kb, pr, cam, cam, args.thr, args.hyp, scene=int(s), shuffle=True, seed=0, **kw)
+            if args.registration:
+                w = O.p3p_arrsac_pairs(ka, pr, world_all, cam, args.thr, args.hyp, scene=int(s), shuffle=True, seed=0, **kw)
+            else:
+                w = O.arrsac_pairs(ka, kb, pr, cam, cam, args.thr, args.hyp, scene=int(s), shuffle=True, seed=0, **kw)
             bad += int(best[s] != w["best_id"] or pose[s].tobytes() != w["pose"].tobytes()
                        or not np.array_equal(inl[s, :ninl[s]], w["inliers"]))
         out["parity"] = {"scenes_checked": int(args.check), "mismatches": bad, "cpu_s_per_scene": round((time.perf_counter() - t0) / args.check, 2)}

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the batched two-view verification (GPU box): random scene counts and sizes, outlier
-fractions, cameras, thresholds and ARRSAC rule sets — rs_essential_arrsac_batch_device vs oracle/arrsac_oracle.c
-(orc_arrsac_pairs): bearings, scoring order, winner id, pose bits, inlier list, survivors / blocks / poses /
+"""Randomised parity sweep of the batched two-view verification and (every third call) the batched registration
+consensus (GPU box): random scene counts and sizes, outlier fractions, cameras, thresholds and ARRSAC rule sets —
+rs_essential_arrsac_batch_device / rs_p3p_arrsac_batch_device vs oracle/arrsac_oracle.c (orc_arrsac_pairs /
+orc_p3p_arrsac_pairs): bearings, scoring order, winner id, pose bits, inlier list, survivors / blocks / poses /
 residuals evaluated must all be equal.  The oracle runs in a process pool.
 usage: python tools/stress_verify.py [--rounds 12] [--seed 1] [--procs 32]"""
 import argparse
@@ -44,14 +45,34 @@ def make_round(r, seed):
         n = min(n, cap)
         scenes.append(_pixel_scene(rng, cap, cap, n, float(rng.choice([0.0, 0.3, 0.7])), cam_a,
                                    noise_px=float(rng.choice([0.0, 0.3, 2.0]))))
+    reg = None
+    if r % 3 == 2:
+        # every third call is the registration path: (feature, world point) pairs against one table of landmarks
+        from test_oracle_arrsac import _registration_scene
+        n_world = int(rng.integers(50, 1500))
+        reg, worlds = [], []
+        for s in range(S):
+            n = min(int(rng.choice([0, 2, 3, 4, bs, bs + 1, cap, int(rng.integers(0, cap + 1))])), cap)
+            kps, world, pr, _, _, _ = _registration_scene(rng, cap, n_world, n, float(rng.choice([0.0, 0.3, 0.7])), cam_b,
+                                                          noise_px=float(rng.choice([0.0, 0.2, 2.0])))
+            pr = pr.copy(); pr[:, 1] += s * n_world
+            reg.append((kps, pr))
+            worlds.append(world)
+        reg = dict(scenes=reg, world=np.concatenate(worlds))
+        thr = float(rng.choice([1e-7, 1e-6, 1e-4]))
     return dict(cap=cap, cam_a=cam_a, cam_b=cam_b, kw=kw, n_hyp=n_hyp, thr=thr, shuffle=shuffle, scenes=scenes,
-                seed=int(rng.integers(1 << 40)))
+                seed=int(rng.integers(1 << 40)), reg=reg)
 
 
 def oracle_scene(args):
     r, seed, s = args
     from oracle import oracle as O
     R = make_round(r, seed)
+    if R["reg"] is not None:
+        kps, pr = R["reg"]["scenes"][s]
+        w = O.p3p_arrsac_pairs(kps, pr, R["reg"]["world"], R["cam_b"], R["thr"], R["n_hyp"], scene=s, shuffle=R["shuffle"],
+                               seed=R["seed"], **R["kw"])
+        return r, s, w
     ka, kb, pr = R["scenes"][s]
     w = O.arrsac_pairs(ka, kb, pr, R["cam_a"], R["cam_b"], R["thr"], R["n_hyp"], scene=s, shuffle=R["shuffle"], seed=R["seed"],
                        **R["kw"])
@@ -79,11 +100,18 @@ def main():
     models = 0
     for r, R in enumerate(rounds):
         cap, kw, S = R["cap"], R["kw"], len(R["scenes"])
+        reg = R["reg"]
         pairs = np.zeros((S, cap, 2), np.uint32)
-        for s, sc in enumerate(R["scenes"]):
-            pairs[s, :len(sc[2])] = sc[2]
-        kps_a = np.stack([sc[0] for sc in R["scenes"]]); kps_b = np.stack([sc[1] for sc in R["scenes"]])
-        npairs = np.array([len(sc[2]) for sc in R["scenes"]], np.uint32)
+        if reg is not None:
+            for s, (kps, pr) in enumerate(reg["scenes"]):
+                pairs[s, :len(pr)] = pr
+            kps_a = kps_b = np.stack([sc[0] for sc in reg["scenes"]])
+            npairs = np.array([len(sc[1]) for sc in reg["scenes"]], np.uint32)
+        else:
+            for s, sc in enumerate(R["scenes"]):
+                pairs[s, :len(sc[2])] = sc[2]
+            kps_a = np.stack([sc[0] for sc in R["scenes"]]); kps_b = np.stack([sc[1] for sc in R["scenes"]])
+            npairs = np.array([len(sc[2]) for sc in R["scenes"]], np.uint32)
         d_ka = torch.from_numpy(kps_a.view(np.uint8).reshape(S, cap, 28)).to(dev)
         d_kb = torch.from_numpy(kps_b.view(np.uint8).reshape(S, cap, 28)).to(dev)
         d_pairs = torch.from_numpy(pairs.view(np.int32)).to(dev)
@@ -99,10 +127,16 @@ def main():
         cons.reserve(S)
         prm = cons.make_params(R["thr"], n_hypotheses=R["n_hyp"], seed=R["seed"], **kw)
         ia = list(range(S))
-        cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ia, d_pairs.data_ptr(), d_np.data_ptr(),
-                                        cons.camera(R["cam_a"]), cons.camera(R["cam_b"]), prm, d_pose.data_ptr(),
-                                        d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(), d_stats.data_ptr(),
-                                        shuffle=R["shuffle"])
+        if reg is not None:
+            d_world = torch.from_numpy(reg["world"]).to(dev)
+            cons.p3p_model_inliers_batch_device(d_ka.data_ptr(), cap, ia, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(),
+                                                cons.camera(R["cam_b"]), prm, d_pose.data_ptr(), d_best.data_ptr(),
+                                                d_inl.data_ptr(), d_ninl.data_ptr(), d_stats.data_ptr(), shuffle=R["shuffle"])
+        else:
+            cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ia, d_pairs.data_ptr(), d_np.data_ptr(),
+                                            cons.camera(R["cam_a"]), cons.camera(R["cam_b"]), prm, d_pose.data_ptr(),
+                                            d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(), d_stats.data_ptr(),
+                                            shuffle=R["shuffle"])
         cons.sync()
         pose = d_pose.cpu().numpy(); best = d_best.cpu().numpy().view(np.uint32)
         inl = d_inl.cpu().numpy().view(np.uint32); ninl = d_ninl.cpu().numpy().view(np.uint32)
@@ -110,8 +144,12 @@ def main():
         rbad = 0
         for s in range(S):
             w = want[(r, s)]
-            ga, gb, go = cons.scene(s, cap)
-            ok = ga.tobytes() == w["bearings_a"].tobytes() and gb.tobytes() == w["bearings_b"].tobytes()
+            if reg is not None:
+                ga, gb, go = cons.scene_world(s, cap)
+                ok = ga.tobytes() == w["bearings"].tobytes() and gb.tobytes() == w["world"].tobytes()
+            else:
+                ga, gb, go = cons.scene(s, cap)
+                ok = ga.tobytes() == w["bearings_a"].tobytes() and gb.tobytes() == w["bearings_b"].tobytes()
             if R["shuffle"]:
                 ok = ok and np.array_equal(go, w["order"])
             ok = ok and best[s] == w["best_id"] and ninl[s] == len(w["inliers"])
@@ -125,7 +163,7 @@ def main():
                 print(f"MISMATCH round {r} scene {s}: n {npairs[s]} best {best[s]} / {w['best_id']} inliers {ninl[s]} / {len(w['inliers'])}",
                       flush=True)
         bad += rbad
-        print(f"round {r}: {S} scenes cap {cap} hyp {R['n_hyp']} thr {R['thr']:g} shuffle {int(R['shuffle'])} {kw} -> "
+        print(f"round {r}{' (registration)' if reg is not None else ''}: {S} scenes cap {cap} hyp {R['n_hyp']} thr {R['thr']:g} shuffle {int(R['shuffle'])} {kw} -> "
               f"{'ok' if not rbad else str(rbad) + ' BAD'}", flush=True)
     print(f"stress_verify seed {a.seed}: {len(jobs)} scenes in {a.rounds} calls, {models} with a model, {bad} mismatches")
     return 1 if bad else 0
