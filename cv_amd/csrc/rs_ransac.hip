@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_rsb_alive_init(RsB B, uint32_t n_pose)
 //   k_rsb_prepare      (micro-batch entry) calibrate the matcher's pairs into bearings, optional seeded shuffle order
 //   k_rsb_sample       xoshiro256++ minimal samples drawn on the device (the caller need not ship n_hyp x 8 indices)
 //   k_rsb_hypotheses   one lane per minimal sample: essential matrix + four poses, registers only
-//   k_rsb_score        every live pose against the next `block` matches (2^lg lanes per pose)
+//   k_rsb_score        every live pose against the next `block` matches (2^lg lanes per pose; k_rsb_score_p3p: a lane per pose)
 //   k_rsb_prune        after each block: the best count so far B, then a pose is retired when
 //                        (bound)  count + matches_left < B            — it cannot reach the best: exact, always on
 //                        (cap)    it is not among the max_candidates best after the initialisation blocks
@@ -612,11 +612,10 @@ __global__ __launch_bounds__(64) void k_rsb_p3p_hypotheses(RsB B, uint32_t h0, u
     }
 }
 
-// Block scoring.  Scene = blockIdx.z; a pose takes 2^lg lanes (one match each), a wave 64 >> lg poses: a 16-match
+// Block scoring of the two-view consensus.  Scene = blockIdx.z; a pose takes 2^lg lanes (one match each), a wave 64 >> lg poses: a 16-match
 // block of the initialisation round keeps every lane busy on four poses instead of a quarter of them on one.
 // Positions [m_lo, min(m_hi, n_s)) of the scene's scoring order; blockIdx.y strides the positions of long blocks.
 // from_first: only the slots a re-sampling round appended (catching up on the matches seen so far).
-template <bool P3P>
 __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_t m_hi, uint32_t lg, uint32_t from_first,
                                                    double thresh)
 {
@@ -649,13 +648,8 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
         if (live && pos < hi) {
             const uint32_t m = order ? order[pos] : pos;
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
-            if (P3P) {
-                double wp[4] = {bb[4 * (size_t)m], bb[4 * (size_t)m + 1], bb[4 * (size_t)m + 2], bb[4 * (size_t)m + 3]};
-                inl = rs_w2c_inlier(pose, a, wp, thresh);
-            } else {
-                double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-                inl = rs_residual(pose, a, b) < thresh;
-            }
+            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+            inl = rs_residual(pose, a, b) < thresh;
         }
         cnt += (uint32_t)__popcll(__ballot(inl) & gmask);
     }
@@ -1517,23 +1511,21 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
     uint32_t next_h = n_hyp;                                  // first hypothesis slot of the next re-sampling round
     auto score = [&](uint32_t m_lo, uint32_t m_hi, uint32_t slots, uint32_t from_first) -> int32_t {
         const uint32_t range = m_hi - m_lo;
-        if (P3P) {
+        if constexpr (P3P) {
             uint32_t gy = range / 64;
             gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
             hipLaunchKernelGGL(k_rsb_score_p3p, dim3((slots + 255) / 256, gy, S), dim3(256), 0, s, B, m_lo, m_hi, from_first, prm->threshold);
-            AKZ_LAUNCH_CHECK();
-            return AKZ_OK;
+        } else {
+            uint32_t lg = 6;
+            if (range < 64) {
+                lg = 0;
+                while ((1u << lg) < range) ++lg;
+            }
+            const uint32_t G = 1u << lg, per_wave = 64u >> lg;
+            const uint32_t chunks = (range + G - 1) / G, gy = chunks < 16 ? chunks : 16;
+            const uint32_t waves = (slots + per_wave - 1) / per_wave;
+            hipLaunchKernelGGL(k_rsb_score, dim3((waves + 3) / 4, gy, S), dim3(256), 0, s, B, m_lo, m_hi, lg, from_first, prm->threshold);
         }
-        uint32_t lg = 6;
-        if (range < 64) {
-            lg = 0;
-            while ((1u << lg) < range) ++lg;
-        }
-        const uint32_t G = 1u << lg, per_wave = 64u >> lg;
-        const uint32_t chunks = (range + G - 1) / G, gy = chunks < 16 ? chunks : 16;
-        const uint32_t waves = (slots + per_wave - 1) / per_wave;
-        hipLaunchKernelGGL((k_rsb_score<P3P>), dim3((waves + 3) / 4, gy, S), dim3(256), 0, s, B, m_lo, m_hi, lg, from_first,
-                           prm->threshold);
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     };

@@ -6,7 +6,7 @@
 #                                 average duration here is what the same run's JSON line (<tag>_bench_profiled.json) reports as
 #                                 roofline.avg_launch_us
 #   <tag>_pmc_traffic.json        counter passes of `bench.py --pmc-run` (one pipeline step, nothing else)
-#   <tag>_bench.json              the default `python bench.py` line (what the driver runs)
+#   <tag>_bench.json              the line of `python bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-r03}
@@ -28,7 +28,7 @@ cd $R
 python tools/rocpd_pmc.py $O/pmc_fetch/${T}_results.db $O/${T}_pmc_fetch_size.txt > /dev/null
 python tools/rocpd_pmc.py $O/pmc_write/${T}_results.db $O/${T}_pmc_write_size.txt > /dev/null
 python tools/rocpd_stats.py $O/trace/${T}_results.db $O/${T}_bench_kernel_stats.txt > /dev/null
-python bench.py > $O/bench.log 2> $O/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.log 2> $O/bench.err   # the command the driver runs
 grep '^{' $O/bench.log | tail -1 > $O/${T}_bench.json
 tail -c 1500 $O/bench.log
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/trace   # raw databases are large: only the summaries travel back
