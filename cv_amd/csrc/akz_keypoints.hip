@@ -841,7 +841,6 @@ __global__ __launch_bounds__(256) void k_refine(LevelTable T, const OriTables* _
     const uint32_t n = min(n_in[frame], stride);
     const uint32_t ki = blk.x * 4 + wv;
     const bool active = ki < n;  // wave-uniform; inactive waves still join the block barriers
-    const float PI_F = 3.14159274101257324219f;
     DevKp kp;
     bool keep = false;
     const LevelDesc* Lp = &T.L[0];

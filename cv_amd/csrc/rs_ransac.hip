@@ -346,6 +346,48 @@ __device__ void rs_residual_core(const double* __restrict__ pose, double tsign, 
     *res_mirror = (fin && resm == resm) ? resm : 2.0;
 }
 
+// A (pose, match) pair that cannot be an inlier, decided without the eigen-decomposition.  Whatever point p a
+// triangulation returns, the rays to p from the two cameras and the baseline t lie in one plane through t, so the angular
+// errors alpha (view a) and beta (view b) are at least the angles of f0 = R a and f1 = b to that plane, and over all planes
+// through t that sum is smallest at one of the rays' own epipolar planes:
+//     alpha + beta >= S,   sin S = |t . (f0 x f1)| / max(|f0 x t|, |f1 x t|)
+// (Lee & Civera's closed-form L1 triangulation).  CameraToCamera::residual = ((1 - cos alpha) + (1 - cos beta)) / 2
+// >= 1 - cos(S / 2) >= 0.122 sin^2 S  on [0, pi / 2].  So 0.122 num^2 > thresh' den^2 proves residual >= thresh for [R | t]
+// AND its mirror [R | -t] (S does not see the sign of t); thresh' carries a margin of 1e-6 relative + 1e-13 absolute, a
+// thousand times the rounding of either side, and the bound is used only for bearings that are unit vectors to 4e-15
+// (calibrated ones are) and poses whose R is orthonormal to 1e-9.  A NaN anywhere makes the comparison false: the exact
+// statement decides.
+__device__ __forceinline__ bool rs_pair_far(const double* __restrict__ pose, const double* a, const double* b, double thresh)
+{
+    const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2], nb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    if (!(fabs(na - 1.0) <= 4e-15 && fabs(nb - 1.0) <= 4e-15)) return false;
+    double f[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) f[r] = (pose[r * 4 + 0] * a[0] + pose[r * 4 + 1] * a[1]) + pose[r * 4 + 2] * a[2];
+    const double t[3] = {pose[3], pose[7], pose[11]};
+    const double c[3] = {f[1] * b[2] - f[2] * b[1], f[2] * b[0] - f[0] * b[2], f[0] * b[1] - f[1] * b[0]};
+    const double num = (t[0] * c[0] + t[1] * c[1]) + t[2] * c[2];
+    const double u[3] = {f[1] * t[2] - f[2] * t[1], f[2] * t[0] - f[0] * t[2], f[0] * t[1] - f[1] * t[0]};
+    const double v[3] = {b[1] * t[2] - b[2] * t[1], b[2] * t[0] - b[0] * t[2], b[0] * t[1] - b[1] * t[0]};
+    const double d0 = (u[0] * u[0] + u[1] * u[1]) + u[2] * u[2], d1 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    const double den2 = d0 > d1 ? d0 : d1;
+    // (the caller has checked that R preserves angles to 1e-9: rs_rotation_checked, bit 1 of the pose's ok word)
+    return 0.122 * (num * num) > (thresh * (1.0 + 1e-6) + 1e-13) * den2;
+}
+
+__device__ __forceinline__ bool rs_rotation_checked(const double* pose)
+{
+    bool fine = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            const double d = (pose[i] * pose[j] + pose[4 + i] * pose[4 + j]) + pose[8 + i] * pose[8 + j];   // (R^T R)(i, j)
+            fine = fine && fabs(d - (i == j ? 1.0 : 0.0)) <= 1e-9;
+        }
+    return fine;
+}
+
 __device__ double rs_residual(const double* __restrict__ pose, const double* a, const double* b)
 {
     double r, rm, w;
@@ -408,7 +450,8 @@ __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba,
                                                   uint32_t* __restrict__ counts)
 {
     const uint32_t pid = (blockIdx.y >> 1) * 4u + (blockIdx.y & 1u);
-    if (!ok[pid]) return;
+    const uint32_t okw = ok[pid];
+    if (!okw) return;
     const uint32_t m = blockIdx.x * 256 + threadIdx.x;
     bool inl0 = false, inl1 = false;
     if (m < n) {
@@ -416,10 +459,12 @@ __global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba,
         for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
         double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
         double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-        double r0, r1;
-        rs_residual_pair(pose, a, b, &r0, &r1);
-        inl0 = r0 < thresh;
-        inl1 = r1 < thresh;
+        if (!((okw & 2u) && rs_pair_far(pose, a, b, thresh))) {
+            double r0, r1;
+            rs_residual_pair(pose, a, b, &r0, &r1);
+            inl0 = r0 < thresh;
+            inl1 = r1 < thresh;
+        }
     }
     const unsigned long long bal0 = __ballot(inl0), bal1 = __ballot(inl1);
     if ((threadIdx.x & 63) == 0) {
@@ -579,7 +624,9 @@ __global__ __launch_bounds__(64) void k_rsb_hypotheses(RsB B, uint32_t h0, uint3
     double* out = B.sposes(s) + (size_t)hh * 48;
 #pragma unroll
     for (int k = 0; k < 48; ++k) out[k] = P[k];
-    for (int p = 0; p < 4; ++p) ok[p] = good ? 1u : 0u;  // validity per pose
+    // validity per pose; bit 1: the pose's R is orthonormal to 1e-9 (what rs_pair_far's angle argument needs: a product of
+    // Jacobi rotations is, but nothing here depends on the SVD's third column having come out that way)
+    for (int p = 0; p < 4; ++p) ok[p] = good ? (rs_rotation_checked(P + p * 12) ? 3u : 1u) : 0u;
 }
 
 // ---- PnP: Lambda Twist hypotheses (row R5), same indexing; bearings in a, world points [n][4] in b ----
@@ -634,6 +681,7 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
     const uint32_t slot = slot0 + g;
     const bool live = slot < nal;
     const uint32_t pid = live ? B.alive[B.p4(s) + slot] : 0u;
+    const bool rot_ok = live && (B.ok[B.p4(s) + pid] & 2u);
     double pose[12];
     const double* pp = B.sposes(s) + (size_t)pid * 12;
     for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
@@ -649,7 +697,7 @@ __global__ __launch_bounds__(256) void k_rsb_score(RsB B, uint32_t m_lo, uint32_
             const uint32_t m = order ? order[pos] : pos;
             double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
             double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-            inl = rs_residual(pose, a, b) < thresh;
+            inl = !(rot_ok && rs_pair_far(pose, a, b, thresh)) && rs_residual(pose, a, b) < thresh;
         }
         cnt += (uint32_t)__popcll(__ballot(inl) & gmask);
     }
@@ -717,50 +765,105 @@ __global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uin
 }
 
 // The first block of a call: nothing has been retired yet, so the live list is every valid pose and the four poses of
-// a hypothesis are all in it.  Units of work are (hypothesis, R1 | R2): 2^lg lanes score [R | t] and [R | -t] of
-// the unit against one match each, one eigen-decomposition per lane for the two residuals (rs_residual_pair) — half
-// the arithmetic of scoring the four poses one by one, which is three quarters of a micro-batch's verification time.
-__global__ __launch_bounds__(256) void k_rsb_score_first(RsB B, uint32_t m_hi, uint32_t lg, uint32_t n_hyp, double thresh)
+// a hypothesis are all in it.  Units of work are (hypothesis, R1 | R2): [R | t] and [R | -t] of a unit are scored from one
+// eigen-decomposition per match (rs_residual_pair) — half the arithmetic of scoring the four poses one by one.
+// Most units are poses of contaminated samples, for which rs_pair_far discards nearly every match; a lane-per-pair layout
+// would leave those lanes idle beside the few that do need the eigen-decomposition.  A workgroup therefore owns 256 units
+// and works in two phases per tile of 16 matches (staged in LDS):
+//   1. lane <-> unit (pose in registers, matches by broadcast reads): the far test of the unit against the 16 matches
+//      -> a 16-bit mask; the surviving (unit, match) pairs are queued in LDS (positions by a workgroup prefix sum);
+//   2. lane <-> queued pair: the eigen-decomposition, with every lane busy; inliers counted in LDS per unit.
+// One atomic per pose at the end.  With vslam-sandbox's parameters on a 10 %-outlier batch 43 % of the pairs reach phase 2,
+// with 30 % outliers 6 %.
+constexpr uint32_t kFirstUnits = 256, kFirstTile = 16;
+__global__ __launch_bounds__(256) void k_rsb_score_first(RsB B, uint32_t m_hi, uint32_t n_hyp, double thresh)
 {
+    __shared__ __attribute__((aligned(16))) double s_pose[kFirstUnits][12];
+    __shared__ __attribute__((aligned(16))) double s_m[kFirstTile][6];
+    __shared__ unsigned short s_pair[kFirstUnits * kFirstTile];
+    __shared__ uint32_t s_cnt[kFirstUnits][2];
+    __shared__ uint32_t s_wsum[4];
     const uint32_t s = blockIdx.z;
     const uint32_t n = B.n[s];
     const uint32_t hi = m_hi < n ? m_hi : n;
     if (hi == 0) return;
-    const uint32_t G = 1u << lg, lane = threadIdx.x & 63u, g = lane >> lg, j = lane & (G - 1u);
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t nal = B.nalive[s];
-    if (wave == 0 && lane == 0 && blockIdx.y == 0 && nal) atomicAdd(&B.neval[s], (unsigned long long)nal * (unsigned long long)hi);
-    const uint32_t unit0 = wave << (6u - lg);
-    if (unit0 >= 2u * n_hyp) return;
-    const uint32_t unit = unit0 + g;
+    if (blockIdx.x == 0 && tid == 0 && nal) atomicAdd(&B.neval[s], (unsigned long long)nal * (unsigned long long)hi);
+    const uint32_t unit = blockIdx.x * kFirstUnits + tid;
     const uint32_t pid = (unit >> 1) * 4u + (unit & 1u);
-    const bool live = unit < 2u * n_hyp && B.ok[B.p4(s) + pid] != 0;
+    const uint32_t okw = unit < 2u * n_hyp ? B.ok[B.p4(s) + pid] : 0u;
     double pose[12];
-    const double* pp = B.sposes(s) + (size_t)pid * 12;
-    for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
+    {
+        const double* pp = B.sposes(s) + (size_t)pid * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            pose[i] = okw ? pp[i] : 0.0;
+            s_pose[tid][i] = pose[i];
+        }
+    }
+    s_cnt[tid][0] = 0u;
+    s_cnt[tid][1] = 0u;
     const double* ba = B.sa(s);
     const double* bb = B.sb(s);
     const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
-    const unsigned long long gmask = (lg == 6u ? ~0ull : ((1ull << G) - 1ull)) << (g << lg);
-    uint32_t cnt0 = 0, cnt1 = 0;
-    for (uint32_t m0 = blockIdx.y * G; m0 < hi; m0 += gridDim.y * G) {
-        const uint32_t pos = m0 + j;
-        bool inl0 = false, inl1 = false;
-        if (live && pos < hi) {
-            const uint32_t m = order ? order[pos] : pos;
-            double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
-            double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-            double r0, r1;
-            rs_residual_pair(pose, a, b, &r0, &r1);
-            inl0 = r0 < thresh;
-            inl1 = r1 < thresh;
+    for (uint32_t t0 = 0; t0 < hi; t0 += kFirstTile) {
+        const uint32_t tn = hi - t0 < kFirstTile ? hi - t0 : kFirstTile;
+        __syncthreads();   // the previous tile's pairs have been scored; s_pose / s_cnt initialised
+        if (tid < tn) {
+            const uint32_t m = order ? order[t0 + tid] : t0 + tid;
+            s_m[tid][0] = ba[3 * (size_t)m]; s_m[tid][1] = ba[3 * (size_t)m + 1]; s_m[tid][2] = ba[3 * (size_t)m + 2];
+            s_m[tid][3] = bb[3 * (size_t)m]; s_m[tid][4] = bb[3 * (size_t)m + 1]; s_m[tid][5] = bb[3 * (size_t)m + 2];
         }
-        cnt0 += (uint32_t)__popcll(__ballot(inl0) & gmask);
-        cnt1 += (uint32_t)__popcll(__ballot(inl1) & gmask);
+        __syncthreads();
+        // ---- phase 1: which of the tile's matches can be inliers of this lane's unit at all ----
+        uint32_t mask = 0u;
+        if (okw & 2u) {
+            for (uint32_t i = 0; i < tn; ++i) {
+                const double a[3] = {s_m[i][0], s_m[i][1], s_m[i][2]};
+                const double b[3] = {s_m[i][3], s_m[i][4], s_m[i][5]};
+                mask |= rs_pair_far(pose, a, b, thresh) ? 0u : (1u << i);
+            }
+        } else if (okw) {
+            mask = (1u << tn) - 1u;   // a valid pose whose R was not certified: every match goes to the exact statement
+        }
+        // queue positions: exclusive prefix sum of the lanes' pair counts over the workgroup
+        const uint32_t mine = (uint32_t)__popc(mask);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        if (lane == 63u) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            base += w < wv ? s_wsum[w] : 0u;
+            total += s_wsum[w];
+        }
+        uint32_t at = base + incl - mine;
+        for (uint32_t mk = mask; mk; mk &= mk - 1u) s_pair[at++] = (unsigned short)((tid << 4) | (uint32_t)(__ffs((int)mk) - 1));
+        __syncthreads();
+        // ---- phase 2: the eigen-decomposition of every queued pair, one per lane ----
+        for (uint32_t q = tid; q < total; q += 256) {
+            const uint32_t e = s_pair[q], ul = e >> 4, i = e & 15u;
+            double ps[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ps[k] = s_pose[ul][k];
+            const double a[3] = {s_m[i][0], s_m[i][1], s_m[i][2]};
+            const double b[3] = {s_m[i][3], s_m[i][4], s_m[i][5]};
+            double r0, r1;
+            rs_residual_pair(ps, a, b, &r0, &r1);
+            if (r0 < thresh) atomicAdd(&s_cnt[ul][0], 1u);
+            if (r1 < thresh) atomicAdd(&s_cnt[ul][1], 1u);
+        }
     }
-    if (live && j == 0) {
-        if (cnt0) atomicAdd(&B.counts[B.p4(s) + pid], cnt0);
-        if (cnt1) atomicAdd(&B.counts[B.p4(s) + pid + 2], cnt1);
+    __syncthreads();
+    if (okw) {
+        if (s_cnt[tid][0]) atomicAdd(&B.counts[B.p4(s) + pid], s_cnt[tid][0]);
+        if (s_cnt[tid][1]) atomicAdd(&B.counts[B.p4(s) + pid + 2], s_cnt[tid][1]);
     }
 }
 
@@ -1530,15 +1633,8 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
         return AKZ_OK;
     };
     auto score_first = [&](uint32_t m_hi) -> int32_t {     // block 0 of the two-view consensus: poses in (t, -t) pairs
-        uint32_t lg = 6;
-        if (m_hi < 64) {
-            lg = 0;
-            while ((1u << lg) < m_hi) ++lg;
-        }
-        const uint32_t G = 1u << lg, per_wave = 64u >> lg;
-        const uint32_t chunks = (m_hi + G - 1) / G, gy = chunks < 16 ? chunks : 16;
-        const uint32_t waves = (2 * n_hyp + per_wave - 1) / per_wave;
-        hipLaunchKernelGGL(k_rsb_score_first, dim3((waves + 3) / 4, gy, S), dim3(256), 0, s, B, m_hi, lg, n_hyp, prm->threshold);
+        hipLaunchKernelGGL(k_rsb_score_first, dim3((2 * n_hyp + kFirstUnits - 1) / kFirstUnits, 1, S), dim3(256), 0, s, B, m_hi, n_hyp,
+                           prm->threshold);
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     };

@@ -734,6 +734,41 @@ def test_ransac_bit_exact(gpu, oracle):
             assert len(inl) > 0.5 * n
 
 
+def test_far_pair_rejection_never_changes_a_count(gpu, oracle):
+    """Before the 4x4 eigen-decomposition the device discards (pose, match) pairs whose residual provably exceeds the
+    threshold (rs_pair_far: the rays' angle to each other's epipolar plane bounds the residual from below).  Counts of
+    every (hypothesis, pose), winner and inlier list against the oracle, which knows no such shortcut, for thresholds
+    from 1e-12 to 0.5 — through the decade where the bound and the threshold meet for most pairs — on a noisy scene, on
+    non-unit bearings (the shortcut must stand aside) and on degenerate geometry (rays along the baseline)."""
+    from cv_amd.ransac import EssentialConsensus
+    rng = np.random.default_rng(0xFA12)
+    cons = EssentialConsensus(2048, 4096)
+    n, n_hyp = 300, 96
+    a, b = _two_view_scene(rng, n, 0.3)
+    b = b + rng.standard_normal(b.shape) * 3e-3
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    samples = np.stack([rng.choice(n, 8, replace=False) for _ in range(n_hyp)]).astype(np.uint32)
+    scenes = [("noisy", a, b)]
+    scenes.append(("non-unit bearings", a * 1.0000001, b * (1.0 + 1e-12)))
+    a2 = a.copy(); b2 = b.copy()
+    a2[::5] = a2[0]; b2[::5] = b2[0]                     # repeated matches: rank-deficient samples, rays along one direction
+    scenes.append(("degenerate", a2, b2))
+    checked = 0
+    for name, sa, sb in scenes:
+        for thr in (1e-12, 1e-9, 1e-7, 3e-6, 1e-4, 2e-3, 0.05, 0.2, 0.5):
+            want = oracle.essential_batch(sa, sb, samples, thr)
+            got = cons.model_inliers(sa, sb, samples, thr)
+            assert (got is None) == (want is None), (name, thr)
+            if want is None:
+                continue
+            _eq(cons.counts(n_hyp), want[3], f"{name}: counts at thr {thr}")
+            assert got[2] == want[1], (name, thr)
+            _eq(got[0], want[0], f"{name}: pose at thr {thr}")
+            _eq(got[1], want[2], f"{name}: inliers at thr {thr}")
+            checked += 1
+    assert checked >= 20
+
+
 def test_ransac_estimate_pose_pin(gpu, kitti, oracle):
     """akaze/tests/estimate_pose.rs:24-76 end to end on the device: 399/343 descriptors -> 11 matches ->
     calibrate with K_00 -> consensus at 0.1 -> 11 inliers."""
