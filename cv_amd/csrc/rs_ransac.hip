@@ -351,7 +351,8 @@ __device__ void rs_residual_core(const double* __restrict__ pose, double tsign, 
 // errors alpha (view a) and beta (view b) are at least the angles of f0 = R a and f1 = b to that plane, and over all planes
 // through t that sum is smallest at one of the rays' own epipolar planes:
 //     alpha + beta >= S,   sin S = |t . (f0 x f1)| / max(|f0 x t|, |f1 x t|)
-// (Lee & Civera's closed-form L1 triangulation).  CameraToCamera::residual = ((1 - cos alpha) + (1 - cos beta)) / 2
+// (the closed-form L1-optimal two-view triangulation of Lee & Civera, ICCV 2019; DESIGN.md 7 has the three-line proof).
+// CameraToCamera::residual = ((1 - cos alpha) + (1 - cos beta)) / 2
 // >= 1 - cos(S / 2) >= 0.122 sin^2 S  on [0, pi / 2].  So 0.122 num^2 > thresh' den^2 proves residual >= thresh for [R | t]
 // AND its mirror [R | -t] (S does not see the sign of t); thresh' carries a margin of 1e-6 relative + 1e-13 absolute, a
 // thousand times the rounding of either side, and the bound is used only for bearings that are unit vectors to 4e-15
