@@ -981,7 +981,7 @@ def extra_ransac(n_hyp):
                        "host buffers in and out",
            "hypotheses_per_s": round(n_hyp / dt, 1), "residuals_per_s": round(n_hyp * 4 * n / dt, 1),
            "ms_per_scene": round(dt * 1e3, 3), "inliers": int(len(inl)), "best_id": int(best),
-           "roofline": {"bound": "fp64-valu", "kernel": "k_rs_score (CameraToCamera::residual < threshold per (pose, match): a "
+           "roofline": {"bound": "fp64-valu", "kernel": "k_rsb_score_first over all matches (CameraToCamera::residual < threshold per (pose, match): a "
                                                         "lower bound first, the 4x4 Jacobi where it does not decide)",
                         "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                         "exhaustive_equivalent_tflops": round(2400.0 * n_hyp * 4 * n / dt / 1e12, 2),

@@ -8,7 +8,7 @@
 //   CameraIntrinsics::calibrate (+K1)                     cv-pinhole/src/lib.rs:108-117,191-202   rs_calibrate, k_rsb_prepare
 //   encode_epipolar_equation, EightPoint::from_matches    eight-point/src/lib.rs:11-58            k_rsb_hypotheses
 //   EssentialMatrix::possible_unscaled_poses              cv-pinhole/src/essential.rs:114-162,217-231  k_rsb_hypotheses
-//   CameraToCamera::residual                              cv-core/src/pose.rs:249-295             k_rs_score, k_rsb_score, ...
+//   CameraToCamera::residual                              cv-core/src/pose.rs:249-295             k_rsb_score_first, k_rsb_score
 //   Consensus::model_inliers                              call sites akaze/tests/estimate_pose.rs:63-67,
 //                                                         tutorial ch5 main.rs:70-72, cv-sfm/src/lib.rs:1394-1412
 // nalgebra's eigen/SVD and the arrsac sampler are un-vendored: the eigen-solver is the shared cyclic Jacobi of
@@ -442,38 +442,8 @@ struct RsB {
     __device__ __forceinline__ size_t p4(uint32_t s) const { return (size_t)s * H * 4; }
 };
 
-// ---- exhaustive scoring of caller-provided samples (rs_essential_batch / rs_p3p_batch: one scene, slot 0) --------
-// grid: (match blocks, 2 hyp + which).  A block scores poses 4 hyp + which and 4 hyp + which + 2 — [R | t] and
-// [R | -t] — together (rs_residual_pair).  Inlier count per pose by ballot + one atomic per wave.
-__global__ __launch_bounds__(256) void k_rs_score(const double* __restrict__ ba, const double* __restrict__ bb,
-                                                  uint32_t n, const double* __restrict__ poses,
-                                                  const uint32_t* __restrict__ ok, double thresh,
-                                                  uint32_t* __restrict__ counts)
-{
-    const uint32_t pid = (blockIdx.y >> 1) * 4u + (blockIdx.y & 1u);
-    const uint32_t okw = ok[pid];
-    if (!okw) return;
-    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
-    bool inl0 = false, inl1 = false;
-    if (m < n) {
-        double pose[12];
-        for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
-        double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
-        double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
-        if (!((okw & 2u) && rs_pair_far(pose, a, b, thresh))) {
-            double r0, r1;
-            rs_residual_pair(pose, a, b, &r0, &r1);
-            inl0 = r0 < thresh;
-            inl1 = r1 < thresh;
-        }
-    }
-    const unsigned long long bal0 = __ballot(inl0), bal1 = __ballot(inl1);
-    if ((threadIdx.x & 63) == 0) {
-        if (bal0) atomicAdd(&counts[pid], (uint32_t)__popcll(bal0));
-        if (bal1) atomicAdd(&counts[pid + 2], (uint32_t)__popcll(bal1));
-    }
-}
-
+// ---- exhaustive scoring of caller-provided samples (rs_p3p_batch: one scene, slot 0; rs_essential_batch runs
+// k_rsb_score_first over all matches) --------
 __global__ __launch_bounds__(256) void k_p3p_score(const double* __restrict__ bearings, const double* __restrict__ world,
                                                    uint32_t n, const double* __restrict__ poses,
                                                    const uint32_t* __restrict__ ok, double thresh,
@@ -790,7 +760,12 @@ __global__ __launch_bounds__(256) void k_rsb_score_first(RsB B, uint32_t m_hi, u
     if (hi == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t nal = B.nalive[s];
-    if (blockIdx.x == 0 && tid == 0 && nal) atomicAdd(&B.neval[s], (unsigned long long)nal * (unsigned long long)hi);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nal) atomicAdd(&B.neval[s], (unsigned long long)nal * (unsigned long long)hi);
+    // blockIdx.y takes a share of the tiles (long match lists of a single scene: rs_essential_batch)
+    const uint32_t n_tiles = (hi + kFirstTile - 1) / kFirstTile, part = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const uint32_t m_begin = blockIdx.y * part * kFirstTile;
+    const uint32_t m_end = m_begin + part * kFirstTile < hi ? m_begin + part * kFirstTile : hi;
+    if (m_begin >= m_end) return;
     const uint32_t unit = blockIdx.x * kFirstUnits + tid;
     const uint32_t pid = (unit >> 1) * 4u + (unit & 1u);
     const uint32_t okw = unit < 2u * n_hyp ? B.ok[B.p4(s) + pid] : 0u;
@@ -808,8 +783,8 @@ __global__ __launch_bounds__(256) void k_rsb_score_first(RsB B, uint32_t m_hi, u
     const double* ba = B.sa(s);
     const double* bb = B.sb(s);
     const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
-    for (uint32_t t0 = 0; t0 < hi; t0 += kFirstTile) {
-        const uint32_t tn = hi - t0 < kFirstTile ? hi - t0 : kFirstTile;
+    for (uint32_t t0 = m_begin; t0 < m_end; t0 += kFirstTile) {
+        const uint32_t tn = m_end - t0 < kFirstTile ? m_end - t0 : kFirstTile;
         __syncthreads();   // the previous tile's pairs have been scored; s_pose / s_cnt initialised
         if (tid < tn) {
             const uint32_t m = order ? order[t0 + tid] : t0 + tid;
@@ -1525,14 +1500,21 @@ static int32_t exhaustive_run(rs_ctx* c, const double* in_a, const double* in_b,
     AKZ_LAUNCH_CHECK();
     // grid.y is limited to 65535: score the poses in slabs
     const uint32_t n_pose = n_hyp * 4;
-    for (uint32_t p0 = 0; p0 < n_pose; p0 += 65532) {
+    for (uint32_t p0 = 0; P3P && p0 < n_pose; p0 += 65532) {
         uint32_t np = n_pose - p0 < 65532 ? n_pose - p0 : 65532;     // (65532: whole hypotheses per slab)
         if (P3P)
             hipLaunchKernelGGL(k_p3p_score, dim3((n + 255) / 256, np), dim3(256), 0, s, c->d_a, c->d_b, n,
                                c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
-        else    // two poses per block: [R | t] and [R | -t] share their eigen-decomposition
-            hipLaunchKernelGGL(k_rs_score, dim3((n + 255) / 256, np / 2), dim3(256), 0, s, c->d_a, c->d_b, n,
-                               c->d_poses + (size_t)p0 * 12, c->d_ok + p0, thresh, c->d_counts + p0);
+        AKZ_LAUNCH_CHECK();
+    }
+    if (!P3P) {
+        // the first-block kernel of the ARRSAC-shaped loop over ALL matches: far pairs are discarded by the bound, the rest
+        // are dealt to full waves; blockIdx.y splits the match list so that one scene still fills the chip
+        AKZ_HIP(hipMemsetAsync(c->d_nalive, 0, sizeof(uint32_t), s));   // (no residual count is kept here)
+        const uint32_t gx = (2 * n_hyp + kFirstUnits - 1) / kFirstUnits, n_tiles = (n + kFirstTile - 1) / kFirstTile;
+        uint32_t gy = gx >= 1024 ? 1 : 1024 / gx;
+        gy = gy > n_tiles ? n_tiles : gy;
+        hipLaunchKernelGGL(k_rsb_score_first, dim3(gx, gy, 1), dim3(256), 0, s, B, n, n_hyp, thresh);
         AKZ_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rs_best, dim3(1), dim3(1024), 0, s, c->d_counts, c->d_ok, n_pose, c->d_best);
