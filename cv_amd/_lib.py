@@ -123,7 +123,7 @@ ABI_SYMBOLS = [
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_last_overflow", "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
     "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
-    "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_knn_batch_device", "hm_best_of_views_device", "hm_match",
+    "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_knn_batch_device", "hm_best_of_views_device", "hm_best_of_views_batch_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
@@ -194,6 +194,7 @@ def lib():
     L.hm_knn.argtypes = [vp, vp, u32, vp, u32, u32, vp]
     L.hm_knn_views_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, vp, vp]
     L.hm_knn_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, u32, vp, vp]
+    L.hm_best_of_views_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp]
     L.hm_best_of_views_device.argtypes = [vp, vp, vp, u32, vp, u32, u32, vp, vp, u32, vp, vp, vp]
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]

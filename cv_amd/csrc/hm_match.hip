@@ -965,8 +965,16 @@ __global__ __launch_bounds__(256) void k_best_of_views(const akz_neighbor* __res
                                                        uint32_t cap, uint32_t n_views, uint32_t k,
                                                        const uint32_t* __restrict__ landmarks, const uint32_t* __restrict__ view_idx,
                                                        const uint32_t* __restrict__ nviews, uint32_t better_by,
-                                                       uint2* __restrict__ best, uint32_t* __restrict__ decision)
+                                                       uint2* __restrict__ best, uint32_t* __restrict__ decision,
+                                                       const uint32_t* __restrict__ q_block)
 {
+    // blockIdx.y = frame of a batched call: its slab of the k-NN output, its row of view indices, its count
+    const uint32_t f = blockIdx.y;
+    knn += (size_t)f * n_views * cap * k;
+    view_idx += (size_t)f * n_views;
+    best += (size_t)f * cap * 3;
+    decision += (size_t)f * cap;
+    if (q_block) nq += q_block[f];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*nq, cap)) return;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -1021,7 +1029,37 @@ extern "C" int32_t hm_best_of_views_device(hm_ctx* c, const void* d_knn, const v
         hipLaunchKernelGGL(k_best_of_views, dim3((cap_per_img + 255) / 256), dim3(256), 0, c->stream, (const akz_neighbor*)d_knn,
                            (const uint32_t*)d_nq, cap_per_img, n_views, k, (const uint32_t*)d_landmarks,
                            (const uint32_t*)c->d_probs, (const uint32_t*)d_nviews, better_by, (uint2*)d_best,
-                           (uint32_t*)d_decision);
+                           (uint32_t*)d_decision, (const uint32_t*)nullptr);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    });
+}
+
+// The same for every frame of a micro-batch in one launch: frame f's neighbours are slab f of hm_knn_batch_device's output
+// laid out [n_frames][n_views][cap][k] (problem f * n_views + v = frame f against its v-th view), its count d_nq[iq[f]], its
+// views view_idx[f][0..n_views); d_best [n_frames][cap][3], d_decision [n_frames][cap].
+extern "C" int32_t hm_best_of_views_batch_device(hm_ctx* c, const void* d_knn, const void* d_nq, const uint32_t* iq, uint32_t cap_per_img,
+                                                 const uint32_t* view_idx, uint32_t n_frames, uint32_t n_views, uint32_t k,
+                                                 const void* d_landmarks, const void* d_nviews, uint32_t better_by, void* d_best,
+                                                 void* d_decision, void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_knn || !d_nq || !iq || !view_idx || !d_landmarks || !d_nviews || !d_best || !d_decision) return AKZ_E_INVALID;
+        if (k < 1 || k > 3 || n_views == 0 || n_views > 64 || cap_per_img == 0 || n_frames > 65535u) return AKZ_E_INVALID;
+        if (n_frames == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        const size_t vi_bytes = akz_align_up(sizeof(uint32_t) * (size_t)n_frames * n_views, 64);
+        AKZ_TRY(hm_ensure_probs(c, vi_bytes + sizeof(uint32_t) * n_frames + 64));
+        AKZ_TRY(hm_push_probs(c, 0, view_idx, sizeof(uint32_t) * (size_t)n_frames * n_views));
+        AKZ_TRY(hm_push_probs(c, vi_bytes, iq, sizeof(uint32_t) * n_frames));
+        hipLaunchKernelGGL(k_best_of_views, dim3((cap_per_img + 255) / 256, n_frames), dim3(256), 0, c->stream,
+                           (const akz_neighbor*)d_knn, (const uint32_t*)d_nq, cap_per_img, n_views, k, (const uint32_t*)d_landmarks,
+                           (const uint32_t*)c->d_probs, (const uint32_t*)d_nviews, better_by, (uint2*)d_best, (uint32_t*)d_decision,
+                           (const uint32_t*)((const char*)c->d_probs + vi_bytes));
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     });

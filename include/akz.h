@@ -285,6 +285,13 @@ int32_t hm_best_of_views_device(hm_ctx* ctx, const void* d_knn, const void* d_nq
                                 const uint32_t* view_idx, uint32_t n_views, uint32_t k, const void* d_landmarks,
                                 const void* d_nviews, uint32_t better_by, void* d_best, void* d_decision,
                                 void* stream_to_wait);
+/* The same for every frame of a micro-batch in one launch: d_knn = hm_knn_batch_device's output laid out
+ * [n_frames][n_views][cap][k] (problem f * n_views + v = frame f against its v-th view), frame f's count d_nq[iq[f]], its views
+ * view_idx[f * n_views + v]; d_best [n_frames][cap][3], d_decision [n_frames][cap].  n_frames <= 65535. */
+int32_t hm_best_of_views_batch_device(hm_ctx* ctx, const void* d_knn, const void* d_nq, const uint32_t* iq, uint32_t cap_per_img,
+                                      const uint32_t* view_idx, uint32_t n_frames, uint32_t n_views, uint32_t k,
+                                      const void* d_landmarks, const void* d_nviews, uint32_t better_by, void* d_best,
+                                      void* d_decision, void* stream_to_wait);
 /* matching()/symmetric_matching() of tutorial ch5 main.rs:154-200 and cv-sfm/src/lib.rs:3097-3133,
  * and match_descriptors() of akaze/tests/estimate_pose.rs:78-97.
  *   rule 0: accept iff d0 + param_u <  d1   (tutorial, param_u = 24)

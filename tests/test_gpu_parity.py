@@ -481,6 +481,75 @@ def test_knn_batch_device(gpu, oracle):
                                  sel, sel, 3, 4, o2.data_ptr(), None) == -1                       # AKZ_E_INVALID: k > 3
 
 
+def test_registration_matching_of_a_micro_batch(gpu, oracle):
+    """The registration path's matching for several new frames at once (cv-sfm/src/lib.rs:1462-1532): hm_knn_batch_device
+    (k = 3, every frame against its own window of stored views) + hm_best_of_views_batch_device == the oracle's knn and
+    best-of-views per frame, and == the single-frame entry points."""
+    import ctypes as C
+    import torch
+    _, knn = gpu
+    from cv_amd import _lib
+    rng = np.random.default_rng(79)
+    cap, F, V, NB, k = 384, 5, 4, 9, 3
+    qn = np.array([384, 100, 0, 257, 31], np.int32)
+    tn = rng.integers(3, cap + 1, NB).astype(np.int32)
+    qs = np.zeros((F, cap, 64), np.uint8); ts = np.zeros((NB, cap, 64), np.uint8)
+    for b in range(F):
+        qs[b, :qn[b]] = _rand_desc(rng, int(qn[b]))
+    for b in range(NB):
+        ts[b, :tn[b]] = _rand_desc(rng, int(tn[b]))
+    ts[2, :20] = qs[0, :20]; ts[5, :20] = qs[0, :20]                      # equal distances in two views
+    landmarks = rng.integers(0, 700, (NB, cap), dtype=np.uint32)           # few distinct landmarks: repeats across views
+    views = np.stack([rng.choice(NB, V, replace=False) for _ in range(F)]).astype(np.uint32)
+    views[1] = [7, 0, 3, 8]
+    ts[7, :10] = qs[1, :10]; tn[7] = max(tn[7], 10)                        # exact hits in one view only: unique matches
+    dev = torch.device("cuda", 0)
+    d_q, d_nq = torch.from_numpy(qs).to(dev), torch.from_numpy(qn).to(dev)
+    d_t, d_nt = torch.from_numpy(ts).to(dev), torch.from_numpy(tn).to(dev)
+    d_lm = torch.from_numpy(landmarks.view(np.int32)).to(dev)
+    iq = np.repeat(np.arange(F, dtype=np.uint32), V)
+    it = views.reshape(-1)
+    d_knn = torch.zeros((F, V, cap, k, 2), dtype=torch.int32, device=dev)
+    d_best = torch.zeros((F, cap, 3, 2), dtype=torch.int32, device=dev)
+    d_dec = torch.full((F, cap), 9, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    m = knn.Matcher(cap)
+    u32p = lambda a: np.ascontiguousarray(a, np.uint32).ctypes.data_as(C.c_void_p)
+    _lib.check(L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap, u32p(iq), u32p(it),
+                                     F * V, k, d_knn.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn_batch")
+    fr = np.arange(F, dtype=np.uint32)
+    for better_by in (24, 1):
+        _lib.check(L.hm_best_of_views_batch_device(m.handle, d_knn.data_ptr(), d_nq.data_ptr(), u32p(fr), cap, u32p(views), F, V, k,
+                                                   d_lm.data_ptr(), d_nt.data_ptr(), better_by, d_best.data_ptr(), d_dec.data_ptr(), None),
+                   "best_of_views_batch")
+        _lib.check(L.hm_sync(m.handle), "hm_sync")
+        gk = d_knn.cpu().numpy(); gb = d_best.cpu().numpy(); gd = d_dec.cpu().numpy()
+        some = 0
+        for f in range(F):
+            n = int(qn[f])
+            if n == 0:
+                assert (gd[f] == 9).all()                                  # an empty frame is left alone
+                continue
+            gnb = np.zeros((V, cap, k), _lib.NB_DTYPE)
+            gnb["index"] = gk[f, ..., 0]; gnb["distance"] = gk[f, ..., 1]
+            for v in range(V):
+                want = oracle.knn(qs[f, :n], ts[views[f, v], :tn[views[f, v]]], k)
+                _eq(gnb["index"][v, :n], want["index"], f"frame {f} view {v} idx")
+                _eq(gnb["distance"][v, :n], want["distance"], f"frame {f} view {v} dist")
+            wbest, wdec = oracle.best_of_views(gnb, n, landmarks, views[f], tn, better_by)
+            _eq(gb[f, :n].astype(np.uint32), wbest, f"frame {f} best of views (better_by {better_by})")
+            _eq(gd[f, :n].astype(np.uint32), wdec, f"frame {f} decisions (better_by {better_by})")
+            some += int((wdec == 1).sum())
+            # the single-frame entry on the same slab
+            d_b1 = torch.zeros((cap, 3, 2), dtype=torch.int32, device=dev); d_d1 = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            _lib.check(L.hm_best_of_views_device(m.handle, d_knn[f].data_ptr(), d_nq[f:].data_ptr(), cap, u32p(views[f]), V, k,
+                                                 d_lm.data_ptr(), d_nt.data_ptr(), better_by, d_b1.data_ptr(), d_d1.data_ptr(), None), "best")
+            _lib.check(L.hm_sync(m.handle), "hm_sync")
+            _eq(d_b1.cpu().numpy()[:n], gb[f, :n], "single == batch (best)")
+            _eq(d_d1.cpu().numpy()[:n], gd[f, :n], "single == batch (decision)")
+        assert some >= 10
+
+
 def test_place_recognition_hash_and_search(gpu, oracle, kitti_golden):
     """hm_hash_bag / hm_hash_bag_device / hm_hash_knn == oracle/lsh_oracle.c (cv-sfm/src/lib.rs:672, :622-624):
     nearest-codeword bag hash over a 4096-word codebook with duplicate words (tie -> lowest index), an empty

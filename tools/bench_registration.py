@@ -2,7 +2,9 @@
 """SURVEY.md §8f rank 2 (the registration path of cv-sfm, cv-sfm/src/lib.rs:1452-1542,1619-1622): one new frame's
 descriptors against 32 recent views with knn(., 3), device-resident, then Lambda Twist consensus over 8192 minimal
 samples on 1000 landmark matches (30 % outliers).  Prints one JSON line; both stages checked against the oracle
-on a sample."""
+on a sample.  --batch F adds the same matching for F new frames in one call chain (hm_knn_batch_device +
+hm_best_of_views_batch_device: frame f against the 32 blocks before it)."""
+import argparse
 import ctypes as C
 import json
 import os
@@ -81,7 +83,48 @@ wpose, wbest, winl, _ = O.p3p_batch(b, w, samples[:sub], thr)
 cpu_s = time.perf_counter() - t0
 g = cons.p3p_model_inliers(b, w, samples[:sub], thr)
 assert g[2] == wbest and np.array_equal(g[1], winl) and g[0].tobytes() == wpose.tobytes()
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64, help="frames of the batched leg (0: skip)")
+args = ap.parse_args()
+batch = None
+if args.batch:
+    F = args.batch
+    NB = F + nviews
+    bc = rng.integers(4700, 5300, NB).astype(np.int32)
+    d_blocks = torch.randint(0, 256, (NB, cap, 64), dtype=torch.uint8, device=dev)
+    d_bc = torch.from_numpy(bc).to(dev)
+    d_lm = torch.randint(0, 200000, (NB, cap), dtype=torch.int32, device=dev)
+    iq = np.repeat(np.arange(nviews, NB, dtype=np.uint32), nviews)                       # frame f = block nviews + f
+    it = (np.arange(F, dtype=np.uint32)[:, None] + np.arange(nviews, dtype=np.uint32)[None, :]).reshape(-1)
+    fr = np.arange(nviews, NB, dtype=np.uint32)
+    d_knn = torch.zeros((F, nviews, cap, k, 2), dtype=torch.int32, device=dev)
+    d_best = torch.zeros((F, cap, 3, 2), dtype=torch.int32, device=dev)
+    d_dec = torch.zeros((F, cap), dtype=torch.int32, device=dev)
+    p = lambda a: np.ascontiguousarray(a, np.uint32).ctypes.data_as(C.c_void_p)
+
+    def run_batch():
+        _lib.check(L.hm_knn_batch_device(m.handle, d_blocks.data_ptr(), d_bc.data_ptr(), d_blocks.data_ptr(), d_bc.data_ptr(), cap,
+                                         p(iq), p(it), F * nviews, k, d_knn.data_ptr(), None), "knn_batch")
+        _lib.check(L.hm_best_of_views_batch_device(m.handle, d_knn.data_ptr(), d_bc.data_ptr(), p(fr), cap, p(it), F, nviews, k,
+                                                   d_lm.data_ptr(), d_bc.data_ptr(), 24, d_best.data_ptr(), d_dec.data_ptr(), None), "bov")
+    run_batch()
+    _lib.check(L.hm_sync(m.handle), "sync")
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run_batch()
+    _lib.check(L.hm_sync(m.handle), "sync")
+    bs = (time.perf_counter() - t0) / 3
+    # one (frame, view) against the oracle
+    f, v = F // 2, 5
+    blk = d_blocks.cpu().numpy()
+    want = O.knn(blk[nviews + f, :100], blk[f + v, :bc[f + v]], 3)
+    got = d_knn[f, v].cpu().numpy()
+    assert (got[:100, :, 0].astype(np.uint32) == want["index"]).all() and (got[:100, :, 1].astype(np.uint32) == want["distance"]).all()
+    dist = float(sum(int(bc[nviews + f_]) * int(bc[f_:f_ + nviews].sum()) for f_ in range(F)))
+    batch = {"frames": F, "ms": round(bs * 1e3, 2), "frames_per_s": round(F / bs, 1), "knn_distances_per_s": round(dist / bs, 1),
+             "what": f"hm_knn_batch_device (k = 3, {F} x {nviews} problems) + hm_best_of_views_batch_device, one call each"}
 print(json.dumps({
+    "batched_matching": batch,
     "workload": f"registration: {nq} descriptors x {nviews} views of ~{int(counts.mean())} (knn 3, device-resident) + "
                 f"Lambda Twist consensus, {n_hyp} samples x {n} matches (30% outliers), host buffers in/out",
     "knn3_views_ms": round(knn_s * 1e3, 3), "knn_distances_per_s": round(nq * float(counts.sum()) / knn_s, 1),
