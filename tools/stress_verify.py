@@ -36,8 +36,8 @@ def make_round(r, seed):
               estimations_per_block=int(rng.choice([0, 0, 5, 16])))
     if rng.random() < 0.3:
         kw.update(sprt_delta=0.02, sprt_ratio=200.0)
-    n_hyp = int(rng.choice([8, 64, 192, 500]))
-    thr = float(rng.choice([1e-7, 2e-7, 1e-6, 1e-4]))
+    n_hyp = int(rng.choice([8, 64, 192, 500, 1500]))
+    thr = float(rng.choice([1e-9, 1e-7, 2e-7, 1e-6, 1e-4, 3e-3, 0.05, 0.2]))
     shuffle = bool(rng.integers(2))
     scenes = []
     for s in range(S):
