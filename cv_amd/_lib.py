@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "rs_debug_scene_world",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "rs_debug_scene_world", "rs_debug_far",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
     "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
@@ -228,6 +228,7 @@ def lib():
     L.rs_stream.argtypes = [vp]
     L.rs_debug_scene.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
     L.rs_debug_residuals.argtypes = [vp, vp, u32, vp, vp, u32, i32, vp]
+    L.rs_debug_far.argtypes = [vp, vp, u32, vp, vp, u32, C.c_double, vp]
     L.akz_comm_unique_id.argtypes = [vp]
     L.akz_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.akz_comm_destroy.argtypes = [vp]

@@ -1280,6 +1280,19 @@ __global__ __launch_bounds__(256) void k_rs_debug_residuals(const double* __rest
     }
 }
 
+// parity tap: rs_pair_far of every (pose, match) — 1 where the bound alone decides "not an inlier" (with the pose's rotation check)
+__global__ __launch_bounds__(256) void k_rs_debug_far(const double* __restrict__ poses, uint32_t n_pose, const double* __restrict__ ba,
+                                                      const double* __restrict__ bb, uint32_t n, double thresh, unsigned char* __restrict__ out)
+{
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x, pid = blockIdx.y;
+    if (m >= n) return;
+    double pose[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(size_t)pid * 12 + i];
+    const double a[3] = {ba[3 * (size_t)m], ba[3 * (size_t)m + 1], ba[3 * (size_t)m + 2]};
+    const double b[3] = {bb[3 * (size_t)m], bb[3 * (size_t)m + 1], bb[3 * (size_t)m + 2]};
+    out[(size_t)pid * n + m] = (rs_rotation_checked(pose) && rs_pair_far(pose, a, b, thresh)) ? 1 : 0;
+}
+
 }  // namespace
 
 struct rs_ctx {
@@ -1970,6 +1983,33 @@ extern "C" int32_t rs_debug_residuals(rs_ctx* c, const double* poses, uint32_t n
         AKZ_LAUNCH_CHECK();
         AKZ_HIP(hipStreamSynchronize(c->stream));
         AKZ_HIP(hipMemcpy(out, d_o, sizeof(double) * no, hipMemcpyDeviceToHost));
+        hipFree(d_p); hipFree(d_a); hipFree(d_b); hipFree(d_o);
+        return AKZ_OK;
+    });
+}
+
+// parity tap of the shortcut in front of the eigen-decomposition: out[pose][match] = 1 where rs_pair_far (and the pose's
+// rotation check) decides "residual >= thresh" on its own.  Tests hold it to the residuals of rs_debug_residuals.
+extern "C" int32_t rs_debug_far(rs_ctx* c, const double* poses, uint32_t n_pose, const double* bearings_a, const double* bearings_b,
+                                uint32_t n, double thresh, uint8_t* out)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !poses || !bearings_a || !bearings_b || !out || n_pose == 0 || n == 0 || n_pose > 65535u) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        double *d_p = nullptr, *d_a = nullptr, *d_b = nullptr;
+        unsigned char* d_o = nullptr;
+        const size_t no = (size_t)n_pose * n;
+        AKZ_HIP(hipMalloc(&d_p, sizeof(double) * 12 * n_pose));
+        AKZ_HIP(hipMalloc(&d_a, sizeof(double) * 3 * n));
+        AKZ_HIP(hipMalloc(&d_b, sizeof(double) * 3 * n));
+        AKZ_HIP(hipMalloc(&d_o, no));
+        AKZ_HIP(hipMemcpy(d_p, poses, sizeof(double) * 12 * n_pose, hipMemcpyHostToDevice));
+        AKZ_HIP(hipMemcpy(d_a, bearings_a, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+        AKZ_HIP(hipMemcpy(d_b, bearings_b, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_rs_debug_far, dim3((n + 255) / 256, n_pose), dim3(256), 0, c->stream, d_p, n_pose, d_a, d_b, n, thresh, d_o);
+        AKZ_LAUNCH_CHECK();
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        AKZ_HIP(hipMemcpy(out, d_o, no, hipMemcpyDeviceToHost));
         hipFree(d_p); hipFree(d_a); hipFree(d_b); hipFree(d_o);
         return AKZ_OK;
     });

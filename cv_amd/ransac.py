@@ -199,6 +199,15 @@ class EssentialConsensus:
               "rs_debug_scene_world")
         return a[:n.value], b[:n.value], o[:n.value]
 
+    def far(self, poses, bearings_a, bearings_b, thresh):
+        """[n_pose, n] bool: where the device's epipolar-plane bound alone rules a match out (rs_debug_far)."""
+        P = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        a = np.ascontiguousarray(bearings_a, np.float64).reshape(-1, 3); b = np.ascontiguousarray(bearings_b, np.float64).reshape(-1, 3)
+        out = np.zeros((len(P), len(a)), np.uint8)
+        check(_lib.lib().rs_debug_far(self._h, P.ctypes.data, len(P), a.ctypes.data, b.ctypes.data, len(a), float(thresh),
+                                      out.ctypes.data), "rs_debug_far")
+        return out.astype(bool)
+
     def residuals(self, poses, bearings_a, bearings_b, paired=False):
         """CameraToCamera::residual of every (pose, match) as the device evaluates it (rs_debug_residuals): [n_pose, n],
         or [n_pose, 2, n] (the pose and its mirror [R | -t]) with paired=True."""

@@ -437,6 +437,10 @@ int32_t rs_debug_poses(rs_ctx* ctx, double* poses, uint32_t* ok, uint32_t n_hyp)
  * shares one eigen-decomposition between the two. */
 int32_t rs_debug_residuals(rs_ctx* ctx, const double* poses, uint32_t n_pose, const double* bearings_a, const double* bearings_b,
                            uint32_t n, int32_t paired, double* out);
+/* parity tap of the shortcut in front of the eigen-decomposition (rs_pair_far): out[pose * n + match] = 1 where
+ * the epipolar-plane bound alone proves residual >= thresh for [R | t] and [R | -t]; tests hold it to rs_debug_residuals. */
+int32_t rs_debug_far(rs_ctx* ctx, const double* poses, uint32_t n_pose, const double* bearings_a, const double* bearings_b,
+                     uint32_t n, double thresh, uint8_t* out);
 
 /* ---- two-view verification of a whole micro-batch, device-resident ----
  * What cv-sfm does for every frame pair the matcher produced (cv-sfm/src/lib.rs:1385-1412): shuffle the matches,

@@ -838,6 +838,49 @@ def test_far_pair_rejection_never_changes_a_count(gpu, oracle):
     assert checked >= 20
 
 
+def test_far_bound_is_a_lower_bound_of_the_device_residual(gpu):
+    """rs_pair_far against the residuals the device itself evaluates (rs_debug_residuals, no shortcut): wherever the bound
+    says "far" at threshold T, the residual of [R | t] AND of its mirror [R | -t] is >= T — for random rotations and
+    baselines, matches from exact to unrelated, rays along the baseline, thresholds over nine decades; the bound must also
+    do its job (most unrelated pairs are far at small thresholds) and stand aside for a matrix that is not a rotation and
+    for bearings that are not unit vectors."""
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import _rot
+    rng = np.random.default_rng(0xB0D)
+    cons = EssentialConsensus(2048, 64)
+    n, n_pose = 1500, 24
+    poses = np.zeros((n_pose, 3, 4))
+    for p in range(n_pose):
+        poses[p, :, :3] = _rot(rng.standard_normal(3) * rng.uniform(0.01, 1.5))
+        poses[p, :, 3] = rng.standard_normal(3) * rng.uniform(0.01, 2.0)
+    a = rng.standard_normal((n, 3)); a[:, 2] = np.abs(a[:, 2]) + 0.3
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.standard_normal((n, 3)); b[:, 2] = np.abs(b[:, 2]) + 0.3
+    # a third of the matches agree with pose 0 up to noise of three magnitudes, a few rays point along its baseline
+    R0, t0 = poses[0, :, :3], poses[0, :, 3]
+    k = n // 3
+    X = a[:k] * rng.uniform(2, 9, (k, 1))
+    b[:k] = X @ R0.T + t0 + rng.standard_normal((k, 3)) * rng.choice([0.0, 1e-4, 1e-2], (k, 1))
+    b[k:k + 20] = t0 + rng.standard_normal((20, 3)) * 1e-3
+    a[k:k + 20] = (R0.T @ t0) + rng.standard_normal((20, 3)) * 1e-3
+    a /= np.linalg.norm(a, axis=1, keepdims=True); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    res = cons.residuals(poses, a, b, paired=True)              # [pose, {t, -t}, match]
+    lo = res.min(axis=1)
+    for thr in (1e-12, 1e-9, 1e-7, 1e-5, 1e-3, 0.03, 0.1, 0.12, 0.5):
+        far = cons.far(poses, a, b, thr)
+        assert (lo[far] >= thr).all(), (thr, float(lo[far].min()))
+        if thr <= 1e-5:
+            assert far[1:].mean() > 0.9                             # unrelated poses: nearly every pair is ruled out ...
+            assert not far[0, :k][lo[0, :k] < thr].any()            # ... and no inlier of the true pose ever is
+        if thr >= 0.1225:
+            assert not far.any()                                    # beyond what the bound can prove
+    # not a rotation (scaled, sheared): the bound must not be used
+    bad = poses.copy(); bad[:, :, :3] *= 1.0 + 1e-6; bad[3, 0, 1] += 0.2
+    assert not cons.far(bad, a, b, 1e-7).any()
+    # bearings that are not unit vectors
+    assert not cons.far(poses, a * (1 + 1e-9), b, 1e-7).any() and not cons.far(poses, a, b * 0.5, 1e-7).any()
+
+
 def test_ransac_estimate_pose_pin(gpu, kitti, oracle):
     """akaze/tests/estimate_pose.rs:24-76 end to end on the device: 399/343 descriptors -> 11 matches ->
     calibrate with K_00 -> consensus at 0.1 -> 11 inliers."""
