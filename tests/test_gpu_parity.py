@@ -761,6 +761,29 @@ def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
     assert "inliers 11" in r.stdout and "grown 399" in r.stdout and "colour 399" in r.stdout and "estimate_pose ok" in r.stdout
 
 
+def test_native_host_drives_the_device_pipeline(gpu, kitti, tmp_path):
+    """INTEGRATION.md 4 from a native process with no Python and no PyTorch in it (tests/cpp/device_pipeline.cpp): hipMalloc'd
+    buffers, akz_extract_batch_device -> hm_match_batch_device -> rs_essential_arrsac_batch_device chained by their streams,
+    nothing copied back in between: 399 / 343 descriptors, 11 matches, 11 inliers, and the device API's keypoints and
+    descriptors byte-equal to the host API's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "device_pipeline"
+    lib_dir = os.path.join(root, "cv_amd", "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "device_pipeline.cpp"),
+                           "-o", str(exe), "-L", lib_dir, "-lakz", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                           f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"])
+    f0, f1 = tmp_path / "f0.raw", tmp_path / "f14.raw"
+    kitti[0].tofile(f0); kitti[1].tofile(f1)
+    h, w = kitti[0].shape
+    r = subprocess.run([str(exe), str(f0), str(f1), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "descriptors 399 343" in r.stdout and "matches 11" in r.stdout and "inliers 11" in r.stdout
+    assert "host api == device api" in r.stdout and "device_pipeline ok" in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------
 def _two_view_scene(rng, n, outlier_frac):
     """the scene of eight-point/tests/random.rs:38-75 with uniformly random outlier
