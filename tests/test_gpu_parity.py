@@ -2077,3 +2077,32 @@ def test_new_entry_points_refuse_what_they_cannot_do(gpu):
     assert L.akz_comm_create(ident, 2, 2, 0, C.byref(C.c_void_p())) == -1
     assert L.akz_comm_create(ident, 0, 0, 0, C.byref(C.c_void_p())) == -1
     assert L.akz_comm_unique_id(None) == -1
+    # the registration consensus: the same refusals, and its own minimum (three matches)
+    world = torch.zeros((8, 4), dtype=torch.float64, device=dev)
+
+    def reg(n_scenes, flags=0, cap=512, p=prm, camera=cam, w=world):
+        ik = (C.c_uint32 * max(1, n_scenes))(*range(n_scenes))
+        return L.rs_p3p_arrsac_batch_device(cons._h, kp.data_ptr(), cap, ik, pairs.data_ptr(), npairs.data_ptr(), n_scenes,
+                                            w.data_ptr() if w is not None else None, C.byref(camera), C.byref(p), flags,
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), None, None)
+    assert reg(2) == 0 and reg(0) == 0
+    cons.sync()
+    assert out[1].cpu().numpy().view(np.uint32)[1] == 0xFFFFFFFF
+    assert reg(3) == -6 and reg(2, flags=4) == -1 and reg(2, p=bad) == -1 and reg(2, camera=cam2) == -1 and reg(2, w=None) == -1
+    assert reg(2, cap=2) == -1                                             # fewer than a minimal sample can ever hold
+    # the batched matcher entries
+    from cv_amd import knn as knn_mod
+    m = knn_mod.Matcher(512)
+    dsc = torch.zeros((2, 512, 64), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbr = torch.zeros((2, 512, 3, 2), dtype=torch.int32, device=dev)
+    two = (C.c_uint32 * 2)(0, 1)
+    kb = lambda n_probs, k: L.hm_knn_batch_device(m.handle, dsc.data_ptr(), cnt.data_ptr(), dsc.data_ptr(), cnt.data_ptr(), 512, two, two,
+                                                  n_probs, k, nbr.data_ptr(), None)
+    assert kb(2, 3) == 0 and kb(0, 2) == 0 and kb(2, 4) == -1 and kb(2, 0) == -1 and kb(70000, 2) == -1
+    bov = lambda n_views, k, n_frames=1: L.hm_best_of_views_batch_device(
+        m.handle, nbr.data_ptr(), cnt.data_ptr(), two, 512, two, n_frames, n_views, k, pairs.data_ptr(), cnt.data_ptr(), 24,
+        nbr.data_ptr(), pairs.data_ptr(), None)
+    assert bov(2, 3) == 0 and bov(0, 3) == -1 and bov(65, 3) == -1 and bov(2, 4) == -1 and bov(2, 3, 70000) == -1
+    _lib.check(L.hm_sync(m.handle), "hm_sync")
+    assert L.rs_debug_far(cons._h, None, 1, None, None, 1, 1e-7, None) == -1
