@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def make_case(i, seed):
+def make_case(i, seed, arms=False):
     from conftest import synth_frame
     rng = np.random.default_rng(seed * 7919 + i)
     w = int(rng.integers(40, 230)) * 4 if i % 3 else int(rng.integers(120, 900))
@@ -27,13 +27,30 @@ def make_case(i, seed):
         img = synth_frame(w, h, seed=int(rng.integers(1 << 30)), n_rect=int(rng.integers(5, 60)), n_disc=int(rng.integers(5, 60)))
     if kind == 2:
         img = (img.astype(np.int16) // 16 * 16).astype(np.uint8)      # plateaus: exact ties
+    # the input arm (GrayFloatImage::from_dynamic, akaze/src/image.rs:45-109): Luma8 most of the time, else Luma16, f32 gray,
+    # RGB8, RGBA16, RGB32F
+    arm = int(rng.integers(0, 10)) if arms else 0
+    if arm == 5:
+        img = (img.astype(np.uint16) * 257 + rng.integers(0, 200, img.shape, dtype=np.uint16) * (img < 255)).astype(np.uint16)
+    elif arm == 6:
+        img = (img.astype(np.float32) / 255.0 + rng.uniform(-1e-3, 1e-3, img.shape).astype(np.float32)).clip(0, 1).astype(np.float32)
+    elif arm == 7:
+        img = np.stack([img, np.roll(img, 3, 1), 255 - img], 2)
+    elif arm == 8:
+        b = img.astype(np.uint16) * 257
+        img = np.stack([b, np.roll(b, 5, 0), b // 2, rng.integers(0, 65535, b.shape, dtype=np.uint16)], 2)
+    elif arm == 9:
+        f = img.astype(np.float32) / 255.0
+        img = np.stack([f, f * 0.7, np.roll(f, 2, 1)], 2)
     return w, h, thr, img
 
 
 def oracle_case(args):
-    i, seed = args
+    i, seed, arms = args
     from oracle import oracle as O
-    w, h, thr, img = make_case(i, seed)
+    w, h, thr, img = make_case(i, seed, arms)
+    if img.ndim == 3:
+        img = O.luma(img)                       # DynamicImage::grayscale(), then the gray arm of its type
     kp, d = O.Akaze(w, h, O.default_config(threshold=thr)).extract(img)
     return i, kp.tobytes(), d.tobytes(), len(d)
 
@@ -43,6 +60,7 @@ def main():
     ap.add_argument("--n", type=int, default=48)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--procs", type=int, default=32)
+    ap.add_argument("--arms", action="store_true", help="also draw the input arm: Luma16, f32, RGB8, RGBA16, RGB32F")
     ap.add_argument("--opt", action="append", default=[], help="akz_options field, key=value (make_options keywords)")
     a = ap.parse_args()
     kw = {k: int(v) for k, v in (kv.split("=") for kv in a.opt)}
@@ -50,22 +68,25 @@ def main():
     O.build()
     ctx = mp.get_context("spawn")
     with ctx.Pool(a.procs) as pool:
-        want = {r[0]: r[1:] for r in pool.map(oracle_case, [(i, a.seed) for i in range(a.n)], chunksize=1)}
+        want = {r[0]: r[1:] for r in pool.map(oracle_case, [(i, a.seed, a.arms) for i in range(a.n)], chunksize=1)}
     from cv_amd import build
     build.build()
     from cv_amd import _lib, akaze
     bad = 0
     total = 0
     for i in range(a.n):
-        w, h, thr, img = make_case(i, a.seed)
-        c = akaze.Context(akaze.Akaze.new(thr), w, h, 1, _lib.make_options(**kw) if kw else None)
-        (kp, d), = c.extract_batch([img])
-        c.close()
+        w, h, thr, img = make_case(i, a.seed, a.arms)
+        if img.dtype == np.uint8 and img.ndim == 2:
+            c = akaze.Context(akaze.Akaze.new(thr), w, h, 1, _lib.make_options(**kw) if kw else None)
+            (kp, d), = c.extract_batch([img])
+            c.close()
+        else:
+            kp, d = akaze.Akaze.new(thr).extract_arrays(img)       # the host mirror's dispatch on dtype / channels
         okp, od, n = want[i]
         total += n
         if kp.tobytes() != okp or d.tobytes() != od:
             bad += 1
-            print(f"MISMATCH case {i}: {w}x{h} thr {thr}: gpu {len(d)} vs oracle {n} keypoints")
+            print(f"MISMATCH case {i}: {w}x{h} {img.dtype} {img.shape[2:] or ''} thr {thr}: gpu {len(d)} vs oracle {n} keypoints")
     print(f"{a.n} cases, {total} keypoints, {bad} mismatches")
     sys.exit(1 if bad else 0)
 
