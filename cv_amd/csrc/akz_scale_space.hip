@@ -1101,13 +1101,104 @@ __device__ __forceinline__ v2f dpp_row(v2f v)   // value of the lane CTRL select
     return (v2f){__int_as_float(x), __int_as_float(y)};
 }
 
+// The FED steps of a launch on the register-resident patches (shared by k_fed_pair and k_front_fed).  Every flow is
+// evaluated by ONE thread and handed to the other pixel it belongs to: the flow through a patch's right edge goes to the
+// right-hand neighbour lane by a DPP row shift (it is that patch's left-edge flow: same operands, same expression),
+// the flow through its bottom edge goes to the patch below through LDS (s_vd).  Per step a thread exchanges its top
+// image row (s_top: the patch above needs it for its bottom-edge flow) and its four bottom-edge flows; the top
+// conductivity rows are static (s_ct).  Rows are updated bottom-up, so row r - 1 is still the pre-update image when the
+// flow between rows r - 1 and r is taken, and the flow from the patch above is needed last (the second barrier of the
+// step sits in front of row 0's update only).
+// Flows across the image border: nonlinear_diffusion.rs:31-52 skips those terms.  Here the thread that EVALUATES such a
+// flow takes a zero step size for it, (0 * (ca + cb)) * (b - a) = +-0 — a zero of either sign leaves every value it
+// is added to or subtracted from unchanged, because no term of the update is ever -0 (k_fed_pair's header; the data
+// are finite: pixels are finite and c is in [0, 1]).  Which flows those are is fixed per thread: the one through the
+// patch's right edge (z_right: that edge is an image border; patches are wholly inside or outside horizontally) and
+// the ones below its rows (z_below(r): row y0 + r is the image's last row or lies above its first) — five selects on
+// the step size per step instead of one on every flow (56 of the 312 vector instructions of a step).
+__device__ __forceinline__ void fed_steps(v2f (&L)[4][4], v2f (&C)[4][4], float4* __restrict__ s_top,
+                                          float4* __restrict__ s_ct, float4* __restrict__ s_vd, const FedTaus& taus,
+                                          int nsteps, int tid, int up, int dn, int x0, int y0, int w, int h)
+{
+    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+    const bool z_right = x0 + 4 <= 0 || x0 + 4 >= w;
+    bool z_below[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z_below[r] = y0 + r < 0 || y0 + r >= h - 1;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        const float htf = taus.half_tau[t];
+        const v2f ht = splat(htf);
+        // an unrolled step loop lets the compiler keep every c(x) + c(x+1) sum and every neighbour's c across the
+        // steps (190 VGPRs); the empty asm makes C opaque per step so they are recomputed instead
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));
+        s_top[tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
+        s_top[tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
+        __syncthreads();   // (also: every reader of the previous step's s_vd is done before this step's writes below)
+        v2f vd[4];         // flow through the bottom edge of the row being updated
+        {
+            const float4 a = s_top[dn * 2], b = s_top[dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
+            const v2f Lb[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
+            const v2f Cb[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
+            const v2f ht3 = splat(z_below[3] ? 0.0f : htf);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) vd[cc] = fed_flow2(ht3, C[3][cc], Cb[cc], L[3][cc], Lb[cc]);
+            s_vd[tid * 2] = make_float4(vd[0].x, vd[0].y, vd[1].x, vd[1].y);
+            s_vd[tid * 2 + 1] = make_float4(vd[2].x, vd[2].y, vd[3].x, vd[3].y);
+        }
+        const v2f htr = splat(z_right ? 0.0f : htf);
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+            const v2f Lr = dpp_row<0x101>(L[r][0]), Cr = dpp_row<0x101>(C[r][0]);   // the right-hand neighbour's first column
+            v2f hf[5];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
+            hf[4] = fed_flow2(htr, C[r][3], Cr, L[r][3], Lr);
+            hf[0] = dpp_row<0x111>(hf[4]);                                            // the left-hand neighbour's hf[4]
+            v2f vu[4];
+            if (r > 0) {
+                const v2f htu = splat(z_below[r > 0 ? r - 1 : 0] ? 0.0f : htf);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vu[c] = fed_flow2(htu, C[r - (r > 0)][c], C[r][c], L[r - (r > 0)][c], L[r][c]);
+            } else {
+                __syncthreads();   // the bottom-edge flows of the patch above are in s_vd
+                const float4 a = s_vd[up * 2], b = s_vd[up * 2 + 1];
+                vu[0] = (v2f){a.x, a.y}; vu[1] = (v2f){a.z, a.w}; vu[2] = (v2f){b.x, b.y}; vu[3] = (v2f){b.z, b.w};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
+                vd[c] = vu[c];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void fed_store_patch(const v2f (&L)[4][4], float* __restrict__ dst, int fa, int fb, bool has_b,
+                                                size_t fs, int w, int h, int x0, int y0)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        const size_t o = (size_t)y * w + x0;
+        *reinterpret_cast<float4*>(dst + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
+        if (has_b)
+            *reinterpret_cast<float4*>(dst + (size_t)fb * fs + o) = make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
+    }
+}
+
 template <int T>
-__global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src, const float* __restrict__ cnd,
+__global__ __launch_bounds__(256, 4) void k_fed_pair(const float* __restrict__ src, const float* __restrict__ cnd,
                                                   float* __restrict__ dst, int w, int h, size_t fs, int n, FedTaus taus)
 {
-    __shared__ __attribute__((aligned(16))) float4 s_top[1][256 * 2];   // [patch][4 px x 2 frames]
-    __shared__ __attribute__((aligned(16))) float4 s_bot[1][256 * 2];
-    __shared__ __attribute__((aligned(16))) float4 s_ct[256 * 2], s_cb[256 * 2];   // top / bottom rows of C
+    __shared__ __attribute__((aligned(16))) float4 s_top[256 * 2];   // [patch][4 px x 2 frames]: top image rows
+    __shared__ __attribute__((aligned(16))) float4 s_vd[256 * 2];    // bottom-edge flows
+    __shared__ __attribute__((aligned(16))) float4 s_ct[256 * 2];    // top rows of C (fixed for the whole launch)
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
     const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
@@ -1131,87 +1222,10 @@ __global__ __launch_bounds__(256) void k_fed_pair(const float* __restrict__ src,
         L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
         C[r][0] = (v2f){ca.x, cb.x}; C[r][1] = (v2f){ca.y, cb.y}; C[r][2] = (v2f){ca.z, cb.z}; C[r][3] = (v2f){ca.w, cb.w};
     }
-    // conductivity of the facing edges: fixed for the whole launch.  Left/right are re-fetched from the
-    // neighbouring lanes each step and top/bottom re-read from a static LDS copy: holding all four in registers
-    // costs 32 VGPRs, which is the difference between two and three waves per SIMD for this kernel.
-    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
-    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
-    s_cb[tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
-    s_cb[tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
-    // flows that cross the image border are +0 (see above)
-    const bool z_left = x0 <= 0, z_right = x0 + 4 >= w, z_top = y0 <= 0;
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-        const v2f ht = splat(taus.half_tau[t]);
-        const int par = 0;
-        // an unrolled step loop lets the compiler keep every c(x) + c(x+1) sum and every neighbour's c across the
-        // steps (190 VGPRs); the empty asm makes C opaque per step so they are recomputed instead
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));
-        s_top[par][tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
-        s_top[par][tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
-        s_bot[par][tid * 2] = make_float4(L[3][0].x, L[3][0].y, L[3][1].x, L[3][1].y);
-        s_bot[par][tid * 2 + 1] = make_float4(L[3][2].x, L[3][2].y, L[3][3].x, L[3][3].y);
-        __syncthreads();   // also orders this step's reads after the previous-but-one step's (same parity) writes
-        v2f vu[4];
-        {
-            float4 a = s_bot[par][up * 2], b = s_bot[par][up * 2 + 1], c = s_cb[up * 2], d = s_cb[up * 2 + 1];
-            const v2f Lt[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
-            const v2f Ct[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                vu[cc] = fed_flow2(ht, Ct[cc], C[0][cc], Lt[cc], L[0][cc]);
-                if (z_top) vu[cc] = splat(0.0f);
-            }
-        }
-        v2f Lb[4], Cb[4];
-        {
-            float4 a = s_top[par][dn * 2], b = s_top[par][dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
-            Lb[0] = (v2f){a.x, a.y}; Lb[1] = (v2f){a.z, a.w}; Lb[2] = (v2f){b.x, b.y}; Lb[3] = (v2f){b.z, b.w};
-            Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const v2f Ll = dpp_row<0x111>(L[r][3]), Lr = dpp_row<0x101>(L[r][0]);
-            v2f hf[5];
-            const v2f Cl = dpp_row<0x111>(C[r][3]), Cr = dpp_row<0x101>(C[r][0]);
-            hf[0] = fed_flow2(ht, Cl, C[r][0], Ll, L[r][0]);
-            if (z_left) hf[0] = splat(0.0f);
-#pragma unroll
-            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
-            hf[4] = fed_flow2(ht, C[r][3], Cr, L[r][3], Lr);
-            if (z_right) hf[4] = splat(0.0f);
-            const bool z_down = y0 + r >= h - 1;
-            v2f vd[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                vd[c] = r < 3 ? fed_flow2(ht, C[r][c], C[r + 1][c], L[r][c], L[r + 1][c])
-                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);   // Lb / Cb: loaded below for r == 3
-                if (z_down) vd[c] = splat(0.0f);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
-                vu[c] = vd[c];
-            }
-        }
-        if (t + 1 < T) __syncthreads();   // single exchange buffer: every reader is done before the next step's writes
-    }
-    if (pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = y0 + r;
-            if (y >= h) break;
-            const size_t o = (size_t)y * w + x0;
-            *reinterpret_cast<float4*>(dst + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
-            if (has_b)
-                *reinterpret_cast<float4*>(dst + (size_t)fb * fs + o) =
-                    make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
-        }
-    }
+    const bool useful = pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in;
+    fed_steps(L, C, s_top, s_ct, s_vd, taus, T, tid, up, dn, x0, y0, w, h);
+    if (useful) fed_store_patch(L, dst, fa, fb, has_b, fs, w, h, x0, y0);
 }
 
 
@@ -1258,7 +1272,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
     // above and below), FED exchange buffers
     __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC];
     static_assert((kFFW + 2) * kFFGS <= kFFIn * kFFInC, "blurred window fits in the input window's space");
-    static_assert(4 * 256 * 2 * 2 <= kFFIn * kFFInC, "FED exchange buffers fit");
+    static_assert(3 * 256 * 2 * 2 <= kFFIn * kFFInC, "FED exchange buffers fit");
     constexpr int U = front_fed_tile(HP);
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
     const int fa = 2 * (int)tile.z;
@@ -1536,85 +1550,12 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
         }
     }
     __syncthreads();   // the blurred window is dead: the exchange buffers take the space
-    float4* s_top = reinterpret_cast<float4*>(s_buf);            // [256 * 2]  [patch][4 px x 2 frames]
-    float4* s_bot = s_top + 256 * 2;
-    float4* s_ct = s_bot + 256 * 2;                              // top / bottom rows of C
-    float4* s_cb = s_ct + 256 * 2;
-    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
-    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
-    s_cb[tid * 2] = make_float4(C[3][0].x, C[3][0].y, C[3][1].x, C[3][1].y);
-    s_cb[tid * 2 + 1] = make_float4(C[3][2].x, C[3][2].y, C[3][3].x, C[3][3].y);
+    float4* s_top = reinterpret_cast<float4*>(s_buf);            // [256 * 2]  [patch][4 px x 2 frames]: top image rows
+    float4* s_vd = s_top + 256 * 2;                              // bottom-edge flows
+    float4* s_ct = s_vd + 256 * 2;                               // top rows of C
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
-    // flows that cross the image border are +0 (see k_fed_pair)
-    const bool z_left = x0 <= 0, z_right = x0 + 4 >= w, z_top = y0 <= 0;
-#pragma unroll 1
-    for (int t = 0; t < nsteps; ++t) {
-        const v2f ht = splat(taus.half_tau[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));
-        s_top[tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
-        s_top[tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
-        s_bot[tid * 2] = make_float4(L[3][0].x, L[3][0].y, L[3][1].x, L[3][1].y);
-        s_bot[tid * 2 + 1] = make_float4(L[3][2].x, L[3][2].y, L[3][3].x, L[3][3].y);
-        __syncthreads();
-        v2f vu[4];
-        {
-            float4 a = s_bot[up * 2], b = s_bot[up * 2 + 1], c = s_cb[up * 2], d = s_cb[up * 2 + 1];
-            const v2f Lt[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
-            const v2f Ct[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                vu[cc] = fed_flow2(ht, Ct[cc], C[0][cc], Lt[cc], L[0][cc]);
-                if (z_top) vu[cc] = splat(0.0f);
-            }
-        }
-        v2f Lb[4], Cb[4];
-        {
-            float4 a = s_top[dn * 2], b = s_top[dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
-            Lb[0] = (v2f){a.x, a.y}; Lb[1] = (v2f){a.z, a.w}; Lb[2] = (v2f){b.x, b.y}; Lb[3] = (v2f){b.z, b.w};
-            Cb[0] = (v2f){c.x, c.y}; Cb[1] = (v2f){c.z, c.w}; Cb[2] = (v2f){d.x, d.y}; Cb[3] = (v2f){d.z, d.w};
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const v2f Ll = dpp_row<0x111>(L[r][3]), Lr = dpp_row<0x101>(L[r][0]);
-            v2f hf[5];
-            const v2f Cl = dpp_row<0x111>(C[r][3]), Cr = dpp_row<0x101>(C[r][0]);
-            hf[0] = fed_flow2(ht, Cl, C[r][0], Ll, L[r][0]);
-            if (z_left) hf[0] = splat(0.0f);
-#pragma unroll
-            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
-            hf[4] = fed_flow2(ht, C[r][3], Cr, L[r][3], Lr);
-            if (z_right) hf[4] = splat(0.0f);
-            const bool z_down = y0 + r >= h - 1;
-            v2f vd[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                vd[c] = r < 3 ? fed_flow2(ht, C[r][c], C[r + 1][c], L[r][c], L[r + 1][c])
-                              : fed_flow2(ht, C[3][c], Cb[c], L[3][c], Lb[c]);
-                if (z_down) vd[c] = splat(0.0f);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
-                vu[c] = vd[c];
-            }
-        }
-        if (t + 1 < nsteps) __syncthreads();
-    }
-    if (useful) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = y0 + r;
-            if (y >= h) break;
-            const size_t o = (size_t)y * w + x0;
-            *reinterpret_cast<float4*>(out_lt + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
-            if (has_b)
-                *reinterpret_cast<float4*>(out_lt + (size_t)fb * fs + o) =
-                    make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
-        }
-    }
+    fed_steps(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
+    if (useful) fed_store_patch(L, out_lt, fa, fb, has_b, fs, w, h, x0, y0);
 }
 
 // ---------------------------------------------------------------------------------------------
