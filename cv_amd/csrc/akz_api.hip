@@ -187,6 +187,10 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         if (!c) return AKZ_E_OOM;
         c->cfg = *cfg;
         c->device = device;
+        {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+        }
         c->max_w = max_w;
         c->max_h = max_h;
         c->max_batch = max_batch;

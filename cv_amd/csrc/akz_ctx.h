@@ -66,6 +66,7 @@ struct AkzSet {
 struct akz_ctx {
     akz_config cfg;
     int device = 0;
+    int n_cu = 256;           // compute units of the device (sizes the grids of the tile-walking kernels)
     hipStream_t stream = nullptr;
     int max_w = 0, max_h = 0, max_batch = 0;
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list

@@ -42,10 +42,16 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // speed choice only), and each XCD has its own L2.  Tiles that share halo rows / columns should therefore have
 // ids that are congruent mod 8: the bijective remap below hands XCD x the x-th contiguous eighth of the tile
 // sequence (x fastest, then y, then frame pair), so a tile's neighbours hit the L2 that already holds the halo.
+__device__ __forceinline__ uint3 xcd_tile_linear(uint32_t orig, uint3 grid);
 __device__ __forceinline__ uint3 xcd_tile(uint3 bid, uint3 grid)
 {
+    return xcd_tile_linear(bid.x + grid.x * (bid.y + grid.y * bid.z), grid);
+}
+// the same for a linear workgroup number (kernels that walk a virtual grid: the number's low three bits must be the XCD
+// the workgroup runs on, i.e. the walk's stride a multiple of 8)
+__device__ __forceinline__ uint3 xcd_tile_linear(uint32_t orig, uint3 grid)
+{
     const uint32_t nwg = grid.x * grid.y * grid.z;
-    const uint32_t orig = bid.x + grid.x * (bid.y + grid.y * bid.z);
     const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
     const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
     const uint32_t z = t / (grid.x * grid.y), rem = t - z * (grid.x * grid.y);
@@ -1178,6 +1184,85 @@ __device__ __forceinline__ void fed_steps(v2f (&L)[4][4], v2f (&C)[4][4], float4
     }
 }
 
+// The same steps with the conductivity sums c(x) + c(x+1), c(y) + c(y+1) of every flow held in registers for the whole
+// launch (64 VGPRs instead of the 32 of the conductivities themselves): a step is 32 additions, the eight row shifts of
+// the neighbours' conductivities and two LDS reads shorter.  For kernels that run at three waves per SIMD anyway
+// (k_front_fed); k_fed_pair keeps four waves with the form above.
+__device__ __forceinline__ void fed_steps_sums(v2f (&L)[4][4], const v2f (&C)[4][4], float4* __restrict__ s_top,
+                                               float4* __restrict__ s_ct, float4* __restrict__ s_vd, const FedTaus& taus,
+                                               int nsteps, int tid, int up, int dn, int x0, int y0, int w, int h)
+{
+    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+    v2f SH[4][4], SV[4][4];   // SH[r][c]: columns c, c + 1 of row r (c = 3: with the right-hand neighbour); SV[r][c]: rows r, r + 1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const v2f Cr = dpp_row<0x101>(C[r][0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) SH[r][c] = C[r][c] + C[r][c + 1];
+        SH[r][3] = C[r][3] + Cr;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) SV[r][c] = C[r][c] + C[r + 1][c];
+    __syncthreads();
+    {
+        const float4 c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
+        SV[3][0] = C[3][0] + (v2f){c.x, c.y};
+        SV[3][1] = C[3][1] + (v2f){c.z, c.w};
+        SV[3][2] = C[3][2] + (v2f){d.x, d.y};
+        SV[3][3] = C[3][3] + (v2f){d.z, d.w};
+    }
+    const bool z_right = x0 + 4 <= 0 || x0 + 4 >= w;
+    bool z_below[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z_below[r] = y0 + r < 0 || y0 + r >= h - 1;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        const float htf = taus.half_tau[t];
+        const v2f ht = splat(htf);
+        s_top[tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
+        s_top[tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
+        __syncthreads();
+        v2f vd[4];
+        {
+            const float4 a = s_top[dn * 2], b = s_top[dn * 2 + 1];
+            const v2f Lb[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
+            const v2f ht3 = splat(z_below[3] ? 0.0f : htf);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) vd[cc] = (ht3 * SV[3][cc]) * (Lb[cc] - L[3][cc]);
+            s_vd[tid * 2] = make_float4(vd[0].x, vd[0].y, vd[1].x, vd[1].y);
+            s_vd[tid * 2 + 1] = make_float4(vd[2].x, vd[2].y, vd[3].x, vd[3].y);
+        }
+        const v2f htr = splat(z_right ? 0.0f : htf);
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+            const v2f Lr = dpp_row<0x101>(L[r][0]);
+            v2f hf[5];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) hf[c] = (ht * SH[r][c - 1]) * (L[r][c] - L[r][c - 1]);
+            hf[4] = (htr * SH[r][3]) * (Lr - L[r][3]);
+            hf[0] = dpp_row<0x111>(hf[4]);
+            v2f vu[4];
+            if (r > 0) {
+                const v2f htu = splat(z_below[r > 0 ? r - 1 : 0] ? 0.0f : htf);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vu[c] = (htu * SV[r - (r > 0)][c]) * (L[r][c] - L[r - (r > 0)][c]);
+            } else {
+                __syncthreads();
+                const float4 a = s_vd[up * 2], b = s_vd[up * 2 + 1];
+                vu[0] = (v2f){a.x, a.y}; vu[1] = (v2f){a.z, a.w}; vu[2] = (v2f){b.x, b.y}; vu[3] = (v2f){b.z, b.w};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
+                vd[c] = vu[c];
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void fed_store_patch(const v2f (&L)[4][4], float* __restrict__ dst, int fa, int fb, bool has_b,
                                                 size_t fs, int w, int h, int x0, int y0)
 {
@@ -1261,8 +1346,61 @@ __device__ __forceinline__ int ff_chunk(int row, int ci) { return row * RS + ((c
 template <int RS>
 __device__ __forceinline__ int ff_elem(int row, int col) { return 2 * ff_chunk<RS>(row, col >> 1) + (col & 1); }
 
+// Experiment builds only (-DAKZ_FF_PROF, tools/build_variant.sh; never in the product library): thread 0 of every
+// 8th block of k_front_fed records the shader clock at its phase boundaries, tools/ff_prof.py reads them back.
+#ifdef AKZ_FF_PROF
+constexpr int kFFProfStamps = 12, kFFProfCap = 1 << 16;
+__device__ unsigned long long g_ff_prof[(size_t)kFFProfCap * kFFProfStamps];
+__device__ unsigned int g_ff_prof_n;
+#define FF_STAMP(i)                                                                              \
+    do {                                                                                         \
+        if (ff_slot >= 0 && threadIdx.x == 0) g_ff_prof[(size_t)ff_slot * kFFProfStamps + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int32_t akz_debug_ff_prof(unsigned long long* out, uint32_t cap_blocks, uint32_t* n, int32_t reset)
+{
+    unsigned int cnt = 0;
+    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_ff_prof_n), sizeof(cnt)) != hipSuccess) return AKZ_E_HIP;
+    if (cnt > (unsigned)kFFProfCap) cnt = kFFProfCap;
+    if (cnt > cap_blocks) cnt = cap_blocks;
+    if (out && cnt && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_prof), (size_t)cnt * kFFProfStamps * 8) != hipSuccess) return AKZ_E_HIP;
+    if (n) *n = cnt;
+    if (reset) {
+        unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ff_prof_n), &z, sizeof(z)) != hipSuccess) return AKZ_E_HIP;
+    }
+    return AKZ_OK;
+}
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
+
+// the interior input window of k_front_fed (rows wy0 - 3 .., columns wx0 - 4 .., all inside the image) as ITEMS float4 per
+// thread and frame; every load is issued before any is consumed
+template <int ITEMS>
+__device__ __forceinline__ void front_fed_fetch(float4 (&ra)[ITEMS], float4 (&rb)[ITEMS], const float* __restrict__ srca,
+                                                const float* __restrict__ srcb, int w, int wx0, int wy0, int tid)
+{
+    constexpr int NCH = kFFIn * (kFFInC / 4);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < NCH) {
+            const int iy = idx / (kFFInC / 4), c4 = idx - iy * (kFFInC / 4);
+            const size_t o = (size_t)(wy0 - 3 + iy) * w + (wx0 - 4 + 4 * c4);
+            ra[i] = *reinterpret_cast<const float4*>(srca + o);
+            rb[i] = *reinterpret_cast<const float4*>(srcb + o);
+        }
+    }
+}
+
+#ifndef AKZ_FF_WAVES
+#define AKZ_FF_WAVES 3
+#endif
+#ifndef AKZ_FF_SUMS
+#define AKZ_FF_SUMS 1
+#endif
 template <int SG, int HP, bool RING, bool WRITE_FLOW>
-__global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
+__global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
                                                       GaussTaps taps, OffK k, FedTaus taus, int nsteps,
                                                       float* __restrict__ out_lt, float* __restrict__ out_flow,
                                                       float2* __restrict__ out_xy, const float* __restrict__ invk,
@@ -1270,18 +1408,42 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
 {
     // one block of LDS, three lives: input window [kFFIn][kFFInC], blurred window [kFFW + 2][kFFGS] (one apron row
     // above and below), FED exchange buffers
+#ifdef AKZ_FF_PAD_LDS
+    __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC + AKZ_FF_PAD_LDS / 8];   // occupancy experiment
+#else
     __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC];
+#endif
     static_assert((kFFW + 2) * kFFGS <= kFFIn * kFFInC, "blurred window fits in the input window's space");
     static_assert(3 * 256 * 2 * 2 <= kFFIn * kFFInC, "FED exchange buffers fit");
     constexpr int U = front_fed_tile(HP);
     const uint3 tile = xcd_tile(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+    const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
     const int fa = 2 * (int)tile.z;
     const bool has_b = fa + 1 < n;
     const int fb = has_b ? fa + 1 : fa;
-    const int tid = threadIdx.x, pc = tid & 15, pr = tid >> 4;
     const int wx0 = (int)tile.x * U - 4 * HP, wy0 = (int)tile.y * U - 4 * HP;   // window origin in the image
     const float* srca = in + (size_t)fa * fs;
     const float* srcb = in + (size_t)fb * fs;
+#ifdef AKZ_FF_PROF
+    __shared__ int ff_slot_s;
+    if (threadIdx.x == 0) {
+        int sl = -1;
+        if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u) == 0) {
+            const unsigned q = atomicAdd(&g_ff_prof_n, 1u);
+            if (q < (unsigned)kFFProfCap) sl = (int)q;
+        }
+        ff_slot_s = sl;
+        if (sl >= 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_ff_prof[(size_t)sl * kFFProfStamps + 11] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+    __syncthreads();
+    const int ff_slot = ff_slot_s;
+#endif
+    FF_STAMP(0);
     // ---- 1a. input window: rows wy0 - 3 .., columns wx0 - 4 .., clamped coordinates outside the image ----
     {
         const bool inside = wx0 >= 4 && wx0 + kFFW + 4 <= w && wy0 >= 3 && wy0 + kFFW + 3 <= h;
@@ -1290,16 +1452,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             // item is five dependent round trips to HBM: 8.5 us of a 21 us block, measured)
             constexpr int NCH = kFFIn * (kFFInC / 4), ITEMS = (NCH + 255) / 256;
             float4 ra[ITEMS], rb[ITEMS];
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const int idx = tid + 256 * i;
-                if (idx < NCH) {
-                    const int iy = idx / (kFFInC / 4), c4 = idx - iy * (kFFInC / 4);
-                    const size_t o = (size_t)(wy0 - 3 + iy) * w + (wx0 - 4 + 4 * c4);
-                    ra[i] = *reinterpret_cast<const float4*>(srca + o);
-                    rb[i] = *reinterpret_cast<const float4*>(srcb + o);
-                }
-            }
+            front_fed_fetch<ITEMS>(ra, rb, srca, srcb, w, wx0, wy0, tid);
             float4* d = reinterpret_cast<float4*>(s_buf);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -1340,36 +1493,39 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
         }
     }
     __syncthreads();
+    FF_STAMP(1);
     // ---- 1b. Gaussian blur (sigma 1.0, 5 taps) of the thread's own patch ----
+    // Horizontal pass: every window row once — a thread takes the four rows of its own patch, and the four rows the
+    // vertical pass needs above and below the window (rows -2, -1, 64, 65) are dealt one pixel per thread; the rows go
+    // through LDS to the threads that need them (a thread blurring rows -2 .. +5 of its patch by itself evaluates every
+    // row twice: 320 packed operations instead of 170).
     v2f g[4][4];
     v2f L[4][4];   // the patch itself: the FED steps start from it (taken here, the input window is about to be replaced)
+    v2f hown[4][4], hhalo;
+    const int halo_row = (tid >> 6) < 2 ? (tid >> 6) - 2 : kFFW - 2 + (tid >> 6), halo_col = tid & 63;   // window coordinates
     {
-        v2f hb[8][4];
+        const float4* tile = reinterpret_cast<const float4*>(s_buf);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            // window column X sits at input column X + 4; the patch needs columns 4 pc - 2 .. 4 pc + 5 of the window
-            const float4* tile = reinterpret_cast<const float4*>(s_buf);
+        for (int j = 0; j < 4; ++j) {
+            // window row 4 pr + j is input row 4 pr + j + 3; window column X sits at input column X + 4, the patch
+            // needs columns 4 pc - 2 .. 4 pc + 5 of the window
             v2f v[8];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f4v t = lds_chunk(tile + ff_chunk<kFFInC / 2>(4 * pr + r + 1, 2 * pc + 1 + q));
+                const f4v t = lds_chunk(tile + ff_chunk<kFFInC / 2>(4 * pr + j + 3, 2 * pc + 1 + q));
                 v[2 * q] = (v2f){t.x, t.y};
                 v[2 * q + 1] = (v2f){t.z, t.w};
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) hb[r][o] = lane4_dot_v<5>(v + o, taps.k);
-            if (r >= 2 && r < 6) {
-#pragma unroll
-                for (int o = 0; o < 4; ++o) L[r - 2][o] = v[o + 2];
+            for (int o = 0; o < 4; ++o) {
+                hown[j][o] = lane4_dot_v<5>(v + o, taps.k);
+                L[j][o] = v[o + 2];
             }
         }
+        v2f v[5];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const v2f col[5] = {hb[j][o], hb[j + 1][o], hb[j + 2][o], hb[j + 3][o], hb[j + 4][o]};
-                g[j][o] = lane4_dot_v<5>(col, taps.k);
-            }
+        for (int i = 0; i < 5; ++i) v[i] = s_buf[ff_elem<kFFInC / 2>(halo_row + 3, halo_col + 2 + i)];
+        hhalo = lane4_dot_v<5>(v, taps.k);
     }
     // the ring around the window: pixel t of (top row, bottom row, left column, right column), same two passes
     v2f ring[2];
@@ -1397,7 +1553,44 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             ring[q] = lane4_dot_v<5>(hr, taps.k);
         }
     }
-    __syncthreads();   // every thread has read its input: the blurred window takes the space
+    __syncthreads();   // every thread has read its input: the horizontally blurred rows take the space
+    FF_STAMP(2);
+    {
+        // row Y of the window (-2 .. 65) is row Y + 2 of s_h, 64 columns = 32 chunks in the two-plane layout
+        constexpr int HR = kFFW / 2;
+        static_assert((kFFW + 4) * kFFW <= kFFIn * kFFInC, "horizontally blurred rows fit in the input window's space");
+        float4* h4 = reinterpret_cast<float4*>(s_buf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h4[ff_chunk<HR>(4 * pr + j + 2, 2 * pc)] = make_float4(hown[j][0].x, hown[j][0].y, hown[j][1].x, hown[j][1].y);
+            h4[ff_chunk<HR>(4 * pr + j + 2, 2 * pc + 1)] = make_float4(hown[j][2].x, hown[j][2].y, hown[j][3].x, hown[j][3].y);
+        }
+        s_buf[ff_elem<HR>(halo_row + 2, halo_col)] = hhalo;
+        __syncthreads();
+        // vertical pass: rows 4 pr - 2 .. 4 pr + 5 of the patch's own columns; the middle four are the thread's own
+        v2f hb[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r >= 2 && r < 6) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) hb[r][o] = hown[r - 2][o];
+            } else {
+                const f4v t0 = lds_chunk(h4 + ff_chunk<HR>(4 * pr + r, 2 * pc));
+                const f4v t1 = lds_chunk(h4 + ff_chunk<HR>(4 * pr + r, 2 * pc + 1));
+                hb[r][0] = (v2f){t0.x, t0.y}; hb[r][1] = (v2f){t0.z, t0.w};
+                hb[r][2] = (v2f){t1.x, t1.y}; hb[r][3] = (v2f){t1.z, t1.w};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const v2f col[5] = {hb[j][o], hb[j + 1][o], hb[j + 2][o], hb[j + 3][o], hb[j + 4][o]};
+                g[j][o] = lane4_dot_v<5>(col, taps.k);
+            }
+    }
+    __syncthreads();   // every thread has read its rows: the blurred window takes the space
+    FF_STAMP(3);
     // blurred window: pixel (X, Y) of the window is element (row Y + 1, column X + 2) of s_g
     v2f* s_g = s_buf;
     float4* g4 = reinterpret_cast<float4*>(s_buf);
@@ -1436,6 +1629,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             }
         __syncthreads();
     }
+    FF_STAMP(4);
     const int x0 = wx0 + 4 * pc, y0 = wy0 + 4 * pr;
     const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
     const bool useful = pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in;
@@ -1483,6 +1677,7 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             }
         }
     }
+    FF_STAMP(5);
     if (WRITE_FLOW && useful) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1549,16 +1744,23 @@ __global__ __launch_bounds__(256, 3) void k_front_fed(const float* __restrict__ 
             }
         }
     }
+    FF_STAMP(6);
     __syncthreads();   // the blurred window is dead: the exchange buffers take the space
+    FF_STAMP(7);
     float4* s_top = reinterpret_cast<float4*>(s_buf);            // [256 * 2]  [patch][4 px x 2 frames]: top image rows
     float4* s_vd = s_top + 256 * 2;                              // bottom-edge flows
     float4* s_ct = s_vd + 256 * 2;                               // top rows of C
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
+#if AKZ_FF_SUMS
+    fed_steps_sums(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
+#else
     fed_steps(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
+#endif
+    FF_STAMP(8);
     if (useful) fed_store_patch(L, out_lt, fa, fb, has_b, fs, w, h, x0, y0);
+    FF_STAMP(9);
 }
 
-// ---------------------------------------------------------------------------------------------
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
 // {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
 // {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
