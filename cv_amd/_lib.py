@@ -220,7 +220,7 @@ def lib():
     L.rs_batch_reserve.argtypes = [vp, u32]
     L.rs_essential_arrsac_batch_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, u32, C.POINTER(Camera), C.POINTER(Camera),
                                                    C.POINTER(ArrsacParams), u32, vp, vp, vp, vp, vp, vp]
-    L.rs_p3p_arrsac_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, C.POINTER(Camera), C.POINTER(ArrsacParams), u32,
+    L.rs_p3p_arrsac_batch_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, C.POINTER(Camera), C.POINTER(ArrsacParams), u32,
                                              vp, vp, vp, vp, vp, vp]
     L.rs_debug_scene_world.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, u32]
     L.rs_sync.argtypes = [vp]

@@ -254,6 +254,7 @@ extern "C" int32_t akz_destroy(akz_ctx* c)
 {
     return akz_guard([&]() -> int32_t {
         if (!c) return AKZ_OK;
+        if (g_akz_timed_ctx == c) g_akz_timed_ctx = nullptr;   // (a timer left open by a failed call on this thread)
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
         if (c->stream_kp) hipStreamSynchronize(c->stream_kp);

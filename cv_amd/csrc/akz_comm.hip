@@ -43,32 +43,35 @@ struct RcclApi {
     bool ok = false;
 };
 
+// Loaded once, on first use, by whichever thread gets there first (function-local static: the C++11 runtime serialises
+// the initialisation, every other caller waits and then sees the finished table or the recorded failure).
 RcclApi* rccl()
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.ok ? &api : nullptr;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (api.handle) break;
-    }
-    if (!api.handle) return nullptr;
-#define RCCL_SYM(field, sym)                                                   \
-    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
-    if (!api.field) return nullptr;
-    RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
-    RCCL_SYM(CommInitRank, "ncclCommInitRank")
-    RCCL_SYM(CommDestroy, "ncclCommDestroy")
-    RCCL_SYM(GroupStart, "ncclGroupStart")
-    RCCL_SYM(GroupEnd, "ncclGroupEnd")
-    RCCL_SYM(Send, "ncclSend")
-    RCCL_SYM(Recv, "ncclRecv")
-    RCCL_SYM(AllGather, "ncclAllGather")
-    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+    static const RcclApi api = []() {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) return a;
+        bool all = true;
+#define RCCL_SYM(field, sym)                                               \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, sym));   \
+    all = all && a.field != nullptr;
+        RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+        RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        RCCL_SYM(Send, "ncclSend")
+        RCCL_SYM(Recv, "ncclRecv")
+        RCCL_SYM(AllGather, "ncclAllGather")
+        RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RCCL_SYM
-    api.ok = true;
-    return &api;
+        a.ok = all;
+        return a;
+    }();
+    return api.ok ? const_cast<RcclApi*>(&api) : nullptr;
 }
 
 thread_local int g_last_rccl = 0;
@@ -83,6 +86,25 @@ thread_local int g_last_rccl = 0;
             return AKZ_E_COMM;       \
         }                            \
     } while (0)
+
+// Between ncclGroupStart and ncclGroupEnd (inside a transfer function: c, e0, e1 in scope): a failing call must not
+// leave the group open (every later RCCL call of the process would join it) — close it, keep the first error, hand the
+// timing events back.
+#define AKZ_RCCL_IN_GROUP(R, call)                 \
+    do {                                           \
+        int r_ = (call);                           \
+        if (r_ != 0) {                             \
+            g_last_rccl = r_;                      \
+            (R)->GroupEnd();                       \
+            if (e0) c->pool.push_back(e0);         \
+            if (e1) c->pool.push_back(e1);         \
+            return AKZ_E_COMM;                     \
+        }                                          \
+    } while (0)
+
+// most event pairs kept un-resolved when timing is on and akz_comm_timing() is never called: beyond it the oldest are
+// resolved (their transfers are long finished) before another pair is added
+constexpr size_t kCommMaxPending = 256;
 
 struct akz_comm {
     int device = 0, rank = 0, world = 1;
@@ -119,7 +141,18 @@ extern "C" int32_t akz_comm_create(const uint8_t* id128, int32_t rank, int32_t w
         RcclApi* R = rccl();
         if (!R) return AKZ_E_COMM;
         AKZ_HIP(hipSetDevice(device));
-        akz_comm* c = new akz_comm();
+        // (owned until the communicator is complete: every failure below frees the half-built object, its stream and event)
+        struct Undo {
+            akz_comm* c;
+            ~Undo()
+            {
+                if (!c) return;
+                if (c->ev) hipEventDestroy(c->ev);
+                if (c->stream) hipStreamDestroy(c->stream);
+                delete c;
+            }
+        } undo{new akz_comm()};
+        akz_comm* c = undo.c;
         c->device = device;
         c->rank = rank;
         c->world = world;
@@ -128,6 +161,7 @@ extern "C" int32_t akz_comm_create(const uint8_t* id128, int32_t rank, int32_t w
         rccl_unique_id id;
         memcpy(id.internal, id128, 128);
         AKZ_RCCL(R->CommInitRank(&c->comm, world, id, rank));
+        undo.c = nullptr;
         *out = c;
         return AKZ_OK;
     });
@@ -167,6 +201,19 @@ extern "C" int32_t akz_comm_sync(akz_comm* c)
     });
 }
 
+static void comm_resolve(akz_comm* c, size_t keep)
+{
+    size_t n = c->pending.size() > keep ? c->pending.size() - keep : 0;
+    for (size_t i = 0; i < n; ++i) {
+        auto& pr = c->pending[i];
+        float t = 0.0f;
+        hipEventSynchronize(pr.second);
+        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) c->ms += (double)t;
+        c->pool.push_back(pr.first);
+        c->pool.push_back(pr.second);
+    }
+    c->pending.erase(c->pending.begin(), c->pending.begin() + (long)n);
+}
 static int32_t comm_begin(akz_comm* c, void* stream_to_wait, hipEvent_t* e0, hipEvent_t* e1)
 {
     AKZ_HIP(hipSetDevice(c->device));
@@ -176,6 +223,7 @@ static int32_t comm_begin(akz_comm* c, void* stream_to_wait, hipEvent_t* e0, hip
     }
     *e0 = *e1 = nullptr;
     if (c->timing) {
+        if (c->pending.size() >= kCommMaxPending) comm_resolve(c, kCommMaxPending / 2);
         auto take = [&]() {
             hipEvent_t e = nullptr;
             if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
@@ -214,10 +262,10 @@ extern "C" int32_t akz_comm_shift_blocks(akz_comm* c, const void* d_descs, const
         const size_t db = (size_t)n_frames * cap_per_img * 64, cb = (size_t)n_frames;
         const int nxt = (c->rank + 1) % c->world, prv = (c->rank + c->world - 1) % c->world;
         AKZ_RCCL(R->GroupStart());
-        AKZ_RCCL(R->Send(d_descs, db, kRcclUint8, nxt, c->comm, c->stream));
-        AKZ_RCCL(R->Send(d_counts, cb, kRcclUint32, nxt, c->comm, c->stream));
-        AKZ_RCCL(R->Recv(d_recv_descs, db, kRcclUint8, prv, c->comm, c->stream));
-        AKZ_RCCL(R->Recv(d_recv_counts, cb, kRcclUint32, prv, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->Send(d_descs, db, kRcclUint8, nxt, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->Send(d_counts, cb, kRcclUint32, nxt, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->Recv(d_recv_descs, db, kRcclUint8, prv, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->Recv(d_recv_counts, cb, kRcclUint32, prv, c->comm, c->stream));
         AKZ_RCCL(R->GroupEnd());
         return comm_end(c, e0, e1, db + 4 * cb);
     });
@@ -238,8 +286,8 @@ extern "C" int32_t akz_comm_allgather_blocks(akz_comm* c, const void* d_descs, c
         AKZ_TRY(comm_begin(c, stream_to_wait, &e0, &e1));
         const size_t db = (size_t)n_frames * cap_per_img * 64, cb = (size_t)n_frames;
         AKZ_RCCL(R->GroupStart());
-        AKZ_RCCL(R->AllGather(d_descs, d_all_descs, db, kRcclUint8, c->comm, c->stream));
-        AKZ_RCCL(R->AllGather(d_counts, d_all_counts, cb, kRcclUint32, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->AllGather(d_descs, d_all_descs, db, kRcclUint8, c->comm, c->stream));
+        AKZ_RCCL_IN_GROUP(R, R->AllGather(d_counts, d_all_counts, cb, kRcclUint32, c->comm, c->stream));
         AKZ_RCCL(R->GroupEnd());
         return comm_end(c, e0, e1, (db + 4 * cb) * (size_t)c->world);
     });
@@ -250,14 +298,7 @@ extern "C" int32_t akz_comm_timing(akz_comm* c, int32_t enable, double* ms, uint
     return akz_guard([&]() -> int32_t {
         if (!c) return AKZ_E_INVALID;
         AKZ_HIP(hipSetDevice(c->device));
-        for (auto& pr : c->pending) {
-            float t = 0.0f;
-            hipEventSynchronize(pr.second);
-            if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) c->ms += (double)t;
-            c->pool.push_back(pr.first);
-            c->pool.push_back(pr.second);
-        }
-        c->pending.clear();
+        comm_resolve(c, 0);
         if (ms) *ms = c->ms;
         if (calls) *calls = c->calls;
         if (bytes) *bytes = c->bytes;

@@ -164,6 +164,20 @@ void akz_timer_begin(akz_ctx* c, int which, hipStream_t s);
 void akz_timer_end(akz_ctx* c, int which, hipStream_t s, uint64_t launches, uint64_t units, uint64_t units2 = 0);
 extern thread_local akz_ctx* g_akz_timed_ctx;       // a kernel timer of this context is open on this thread
 void akz_timer_launch_events(hipEvent_t* start, hipEvent_t* stop);
+// A stage launcher holds one of these: whatever path it returns by (every AKZ_TRY / AKZ_LAUNCH_CHECK between an
+// akz_timer_begin and its akz_timer_end is an early return), no kernel timer of the context stays open on the thread —
+// an open one would book the next launch of ANY context to this context's timer, or to a freed one.
+struct AkzTimerScope {
+    akz_ctx* c;
+    explicit AkzTimerScope(akz_ctx* ctx) : c(ctx) {}
+    ~AkzTimerScope()
+    {
+        if (g_akz_timed_ctx == c) g_akz_timed_ctx = nullptr;
+        c->open_kernel_timer = -1;
+    }
+    AkzTimerScope(const AkzTimerScope&) = delete;
+    AkzTimerScope& operator=(const AkzTimerScope&) = delete;
+};
 #define AKZ_LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
     do {                                                                                                 \
         if (g_akz_timed_ctx) {                                                                           \

@@ -1786,6 +1786,7 @@ int32_t akz_upload_tables(akz_ctx* c)
 int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
                           uint32_t* d_n_out, uint32_t* h_err_copy)
 {
+    AkzTimerScope timer_scope(c);
     const AkzPlan& P = c->plan;
     AkzSet& S = c->S();
     hipStream_t s = c->stream;  // candidate detection streams Ldet: it stays on the scale-space stream

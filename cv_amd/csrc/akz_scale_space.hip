@@ -2890,6 +2890,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 
 int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n)
 {
+    AkzTimerScope timer_scope(c);
     if (fmt == AKZ_FMT_U8) return scale_space_impl<uint8_t>(c, (const uint8_t*)d_imgs, n);
     if (fmt == AKZ_FMT_U16) return scale_space_impl<uint16_t>(c, (const uint16_t*)d_imgs, n);
     return scale_space_impl<float>(c, (const float*)d_imgs, n);

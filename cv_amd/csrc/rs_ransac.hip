@@ -1142,18 +1142,24 @@ __global__ __launch_bounds__(1024) void k_rsb_prepare(RsB B, const akz_keypoint*
                                                       const uint32_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
                                                       RsCam cam_a, RsCam cam_b, uint32_t* __restrict__ n_out, double* __restrict__ a_out,
                                                       double* __restrict__ b_out, uint32_t* __restrict__ order_out, uint32_t shuffle,
-                                                      unsigned long long seed)
+                                                      unsigned long long seed, uint32_t limit_b)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t s = blockIdx.x;
     uint32_t n = npairs[s];
     n = n < cap_per_img ? n : cap_per_img;
     n = n < B.n_cap ? n : B.n_cap;
-    if (threadIdx.x == 0) n_out[s] = n;
     const akz_keypoint* ka = kps_a + (size_t)fa[s] * cap_per_img;
     const uint32_t* pr = pairs + (size_t)s * cap_per_img * 2;
     double* ao = a_out + (size_t)s * B.n_cap * 3;
     double* bo = b_out + (size_t)s * B.n_cap * 4;
+    // A pair list is the caller's device data (normally hm_match_batch_device's output): an entry that points outside
+    // the keypoint block (>= cap_per_img) or the world table (>= limit_b) refuses the whole scene — it ends with "no
+    // model", nothing is read out of bounds (oracle/arrsac_oracle.c has the same rule).
+    bool bad = false;
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) bad = bad || pr[2 * j] >= cap_per_img || pr[2 * j + 1] >= limit_b;
+    if (__syncthreads_or(bad)) n = 0;
+    if (threadIdx.x == 0) n_out[s] = n;
     for (uint32_t j = threadIdx.x; j < n; j += 1024) {
         const uint32_t ia = pr[2 * j], ib = pr[2 * j + 1];
         double o[3];
@@ -1295,60 +1301,79 @@ __global__ __launch_bounds__(256) void k_rs_debug_far(const double* __restrict__
 
 }  // namespace
 
-struct rs_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
-    uint32_t max_scenes = 0, max_matches = 0, max_hyp = 0;
-    // the arena: slot s of every array belongs to scene s (layout: RsB)
+// The per-scene work arrays: slot s of every array belongs to scene s (layout: RsB).  An arena is either complete
+// (max_scenes > 0, every pointer valid) or empty (max_scenes == 0, every pointer null) — never half-built: it is
+// allocated into a temporary and swapped in only when every allocation succeeded.
+struct RsArena {
+    uint32_t max_scenes = 0;
     uint32_t* d_n = nullptr;
     double *d_a = nullptr, *d_b = nullptr, *d_poses = nullptr, *d_best_pose = nullptr;
     uint32_t *d_order = nullptr, *d_samples = nullptr, *d_ok = nullptr, *d_counts = nullptr, *d_alive = nullptr, *d_nalive = nullptr,
              *d_best = nullptr, *d_inl = nullptr, *d_ninl = nullptr, *d_first = nullptr, *d_enable = nullptr, *d_frames = nullptr;
     unsigned long long* d_neval = nullptr;
     rs_arrsac_stats* d_stats = nullptr;
+};
+struct rs_ctx : RsArena {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    uint32_t max_matches = 0, max_hyp = 0;
     double* d_logtab = nullptr;                                        // ln(k), k = 0 .. max_matches (host libm values)
     uint32_t last_hyp = 0;
 };
 
-static void rs_free_arena(rs_ctx* c)
+static void rs_free_arena(RsArena* c)
 {
     hipFree(c->d_n); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_poses); hipFree(c->d_best_pose); hipFree(c->d_order);
     hipFree(c->d_samples); hipFree(c->d_ok); hipFree(c->d_counts); hipFree(c->d_alive); hipFree(c->d_nalive); hipFree(c->d_best);
     hipFree(c->d_inl); hipFree(c->d_ninl); hipFree(c->d_first); hipFree(c->d_enable); hipFree(c->d_frames); hipFree(c->d_neval);
     hipFree(c->d_stats);
-    c->d_n = c->d_order = c->d_samples = c->d_ok = c->d_counts = c->d_alive = c->d_nalive = c->d_best = c->d_inl = c->d_ninl =
-        c->d_first = c->d_enable = c->d_frames = nullptr;
-    c->d_a = c->d_b = c->d_poses = c->d_best_pose = nullptr;
-    c->d_neval = nullptr;
-    c->d_stats = nullptr;
+    *c = RsArena();
 }
 
-static int32_t rs_alloc_arena(rs_ctx* c, uint32_t S)
+static int32_t rs_alloc_arena_into(RsArena* A, size_t n, size_t H, uint32_t S)
 {
-    const size_t n = c->max_matches, H = c->max_hyp, s = S;
-    AKZ_HIP(hipMalloc(&c->d_n, sizeof(uint32_t) * s));
-    AKZ_HIP(hipMalloc(&c->d_a, sizeof(double) * 3 * n * s));
-    AKZ_HIP(hipMalloc(&c->d_b, sizeof(double) * 4 * n * s));
-    AKZ_HIP(hipMalloc(&c->d_order, sizeof(uint32_t) * n * s));
-    AKZ_HIP(hipMalloc(&c->d_samples, sizeof(uint32_t) * 8 * H * s));
-    AKZ_HIP(hipMalloc(&c->d_poses, sizeof(double) * 48 * H * s));
-    AKZ_HIP(hipMalloc(&c->d_ok, sizeof(uint32_t) * 4 * H * s));
-    AKZ_HIP(hipMalloc(&c->d_counts, sizeof(uint32_t) * 4 * H * s));
-    AKZ_HIP(hipMalloc(&c->d_alive, sizeof(uint32_t) * 4 * H * s));
-    AKZ_HIP(hipMalloc(&c->d_nalive, sizeof(uint32_t) * s));
-    AKZ_HIP(hipMalloc(&c->d_neval, sizeof(unsigned long long) * s));
-    AKZ_HIP(hipMalloc(&c->d_best, sizeof(uint32_t) * 4 * s));
-    AKZ_HIP(hipMalloc(&c->d_inl, sizeof(uint32_t) * n * s));
-    AKZ_HIP(hipMalloc(&c->d_ninl, sizeof(uint32_t) * s));
-    AKZ_HIP(hipMalloc(&c->d_best_pose, sizeof(double) * 12 * s));
-    AKZ_HIP(hipMalloc(&c->d_first, sizeof(uint32_t) * s));
-    AKZ_HIP(hipMalloc(&c->d_enable, sizeof(uint32_t) * s));
-    AKZ_HIP(hipMalloc(&c->d_frames, sizeof(uint32_t) * 2 * s));
-    AKZ_HIP(hipMalloc(&c->d_stats, sizeof(rs_arrsac_stats) * s));
-    c->max_scenes = S;
+    const size_t s = S;
+    AKZ_HIP(hipMalloc(&A->d_n, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&A->d_a, sizeof(double) * 3 * n * s));
+    AKZ_HIP(hipMalloc(&A->d_b, sizeof(double) * 4 * n * s));
+    AKZ_HIP(hipMalloc(&A->d_order, sizeof(uint32_t) * n * s));
+    AKZ_HIP(hipMalloc(&A->d_samples, sizeof(uint32_t) * 8 * H * s));
+    AKZ_HIP(hipMalloc(&A->d_poses, sizeof(double) * 48 * H * s));
+    AKZ_HIP(hipMalloc(&A->d_ok, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&A->d_counts, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&A->d_alive, sizeof(uint32_t) * 4 * H * s));
+    AKZ_HIP(hipMalloc(&A->d_nalive, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&A->d_neval, sizeof(unsigned long long) * s));
+    AKZ_HIP(hipMalloc(&A->d_best, sizeof(uint32_t) * 4 * s));
+    AKZ_HIP(hipMalloc(&A->d_inl, sizeof(uint32_t) * n * s));
+    AKZ_HIP(hipMalloc(&A->d_ninl, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&A->d_best_pose, sizeof(double) * 12 * s));
+    AKZ_HIP(hipMalloc(&A->d_first, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&A->d_enable, sizeof(uint32_t) * s));
+    AKZ_HIP(hipMalloc(&A->d_frames, sizeof(uint32_t) * 2 * s));
+    AKZ_HIP(hipMalloc(&A->d_stats, sizeof(rs_arrsac_stats) * s));
+    A->max_scenes = S;
     return AKZ_OK;
 }
+// A complete arena for S scenes in `*out`, or an error and nothing allocated.
+static int32_t rs_alloc_arena(const rs_ctx* c, uint32_t S, RsArena* out)
+{
+    RsArena A;
+    const int32_t st = rs_alloc_arena_into(&A, c->max_matches, c->max_hyp, S);
+    if (st != AKZ_OK) {
+        rs_free_arena(&A);
+        return st;
+    }
+    *out = A;
+    return AKZ_OK;
+}
+// every entry point that touches the arena starts with this: a context whose arena could not be rebuilt after a failed
+// rs_batch_reserve answers AKZ_E_OOM instead of launching on null pointers
+#define RS_NEED_ARENA(c)                              \
+    do {                                              \
+        if ((c)->max_scenes == 0) return AKZ_E_OOM;   \
+    } while (0)
 
 static RsB rs_view(const rs_ctx* c, bool with_order)
 {
@@ -1388,7 +1413,11 @@ extern "C" int32_t rs_create(int32_t device, uint32_t max_matches, uint32_t max_
         c->max_hyp = max_hyp;
         AKZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-        AKZ_TRY(rs_alloc_arena(c, 1));
+        {
+            RsArena A;
+            AKZ_TRY(rs_alloc_arena(c, 1, &A));
+            static_cast<RsArena&>(*c) = A;
+        }
         {
             // the SPRT's logarithms come from the host's libm, tabulated once: the retirement decisions then do not
             // depend on the device's log() (oracle/arrsac_oracle.c builds the same table)
@@ -1408,7 +1437,7 @@ extern "C" int32_t rs_destroy(rs_ctx* c)
         if (!c) return AKZ_OK;
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
-        rs_free_arena(c);
+        rs_free_arena(static_cast<RsArena*>(c));
         hipFree(c->d_logtab);
         if (c->ev) hipEventDestroy(c->ev);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -1425,15 +1454,24 @@ extern "C" int32_t rs_batch_reserve(rs_ctx* c, uint32_t max_scenes)
         if (max_scenes <= c->max_scenes) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         AKZ_HIP(hipStreamSynchronize(c->stream));
-        rs_free_arena(c);
-        c->max_scenes = 0;
-        int32_t st = rs_alloc_arena(c, max_scenes);
+        // the larger arena first, beside the old one: a failure leaves the context exactly as it was
+        RsArena fresh;
+        int32_t st = rs_alloc_arena(c, max_scenes, &fresh);
         if (st != AKZ_OK) {
-            rs_free_arena(c);
-            c->max_scenes = 0;
-            if (rs_alloc_arena(c, 1) != AKZ_OK) c->max_scenes = 0;
+            // not beside it: give the old one back first, and rebuild it if the larger one still does not fit
+            const uint32_t old_scenes = c->max_scenes;
+            rs_free_arena(static_cast<RsArena*>(c));
+            st = rs_alloc_arena(c, max_scenes, &fresh);
+            if (st != AKZ_OK) {
+                RsArena back;
+                if (old_scenes && rs_alloc_arena(c, old_scenes, &back) == AKZ_OK) static_cast<RsArena&>(*c) = back;
+                return st;        // (if even that failed the arena is empty and every entry point answers AKZ_E_OOM)
+            }
+        } else {
+            rs_free_arena(static_cast<RsArena*>(c));
         }
-        return st;
+        static_cast<RsArena&>(*c) = fresh;
+        return AKZ_OK;
     });
 }
 
@@ -1493,6 +1531,7 @@ static int32_t exhaustive_run(rs_ctx* c, const double* in_a, const double* in_b,
 {
     constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;
     if (!c || !in_a || !in_b || !sample_idx || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    RS_NEED_ARENA(c);
     if (n < K || n_hyp == 0) return AKZ_E_INVALID;  // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
     if (n > c->max_matches || n_hyp > c->max_hyp) return AKZ_E_TOO_LARGE;
     for (size_t i = 0; i < (size_t)n_hyp * K; ++i)
@@ -1709,6 +1748,7 @@ static int32_t arrsac_run(rs_ctx* c, const double* in_a, const double* in_b, uin
 {
     constexpr uint32_t K = P3P ? 3u : 8u, BW = P3P ? 4u : 3u;   // sample size; doubles per element of the second input
     if (!c || !in_a || !in_b || !prm || !best_pose || !best_id || !n_inliers || (cap && !inlier_idx)) return AKZ_E_INVALID;
+    RS_NEED_ARENA(c);
     if (n < K) return AKZ_E_INVALID;   // MIN_SAMPLES (eight-point/src/lib.rs:73, lambda-twist/src/lib.rs:333)
     uint32_t blocks_max = 0;
     AKZ_TRY(rs_check_params(c, prm, n, &blocks_max));
@@ -1785,6 +1825,7 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
             return AKZ_E_INVALID;
         if (cap_per_img == 0 || (flags & ~(uint32_t)RS_BATCH_SHUFFLE) || cam_a->reserved != 0 || cam_b->reserved != 0) return AKZ_E_INVALID;
         if (n_scenes == 0) return AKZ_OK;
+        RS_NEED_ARENA(c);
         if (n_scenes > c->max_scenes) return AKZ_E_TOO_LARGE;
         const uint32_t n_max = cap_per_img < c->max_matches ? cap_per_img : c->max_matches;
         if (n_max < 8) return AKZ_E_INVALID;
@@ -1814,7 +1855,7 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
         hipLaunchKernelGGL(k_rsb_prepare<false>, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps_a,
                            d_kps_b, cap_per_img, (const uint32_t*)c->d_frames,
                            (const uint32_t*)(c->d_frames + c->max_scenes), (const uint32_t*)d_pairs, (const uint32_t*)d_npairs, cam(cam_a),
-                           cam(cam_b), c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u, (unsigned long long)prm->seed);
+                           cam(cam_b), c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u, (unsigned long long)prm->seed, cap_per_img);
         AKZ_LAUNCH_CHECK();
         RsOut O;
         O.best_id = (uint32_t*)d_best_id;
@@ -1833,18 +1874,20 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
 
 // The registration path's consensus for a whole micro-batch (cv-sfm/src/lib.rs:1571-1622 for every new frame): scene s =
 // a list of (feature of keypoint block ik[s], world point) index pairs; bearing = calibrate(keypoint), point = d_world[idx]
-// (homogeneous, [n_world][4] f64: the control plane's triangulated landmarks); Lambda Twist hypotheses from 3-match
+// (homogeneous, [n_world][4] f64: the control plane's triangulated landmarks; a scene that names a point >= n_world is refused); Lambda Twist hypotheses from 3-match
 // samples, WorldToCamera::residual, the same ARRSAC-shaped loop over all scenes at once.
 extern "C" int32_t rs_p3p_arrsac_batch_device(rs_ctx* c, const void* d_kps, uint32_t cap_per_img, const uint32_t* ik, const void* d_pairs,
-                                              const void* d_npairs, uint32_t n_scenes, const void* d_world, const rs_camera* cam,
-                                              const rs_arrsac_params* prm, uint32_t flags, void* d_pose, void* d_best_id,
-                                              void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait)
+                                              const void* d_npairs, uint32_t n_scenes, const void* d_world, uint32_t n_world,
+                                              const rs_camera* cam, const rs_arrsac_params* prm, uint32_t flags, void* d_pose,
+                                              void* d_best_id, void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait)
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !d_kps || !ik || !d_pairs || !d_npairs || !d_world || !cam || !prm || !d_pose || !d_best_id || !d_inliers || !d_n_inliers)
             return AKZ_E_INVALID;
+        if (n_world == 0) return AKZ_E_INVALID;
         if (cap_per_img == 0 || (flags & ~(uint32_t)RS_BATCH_SHUFFLE) || cam->reserved != 0) return AKZ_E_INVALID;
         if (n_scenes == 0) return AKZ_OK;
+        RS_NEED_ARENA(c);
         if (n_scenes > c->max_scenes) return AKZ_E_TOO_LARGE;
         const uint32_t n_max = cap_per_img < c->max_matches ? cap_per_img : c->max_matches;
         if (n_max < 3) return AKZ_E_INVALID;
@@ -1870,7 +1913,7 @@ extern "C" int32_t rs_p3p_arrsac_batch_device(rs_ctx* c, const void* d_kps, uint
         hipLaunchKernelGGL(k_rsb_prepare<true>, dim3(n_scenes), dim3(1024), shuffle ? kRadixSortLdsBytes : 0, s, B, (const akz_keypoint*)d_kps,
                            d_world, cap_per_img, (const uint32_t*)c->d_frames, (const uint32_t*)c->d_frames, (const uint32_t*)d_pairs,
                            (const uint32_t*)d_npairs, k, k, c->d_n, c->d_a, c->d_b, c->d_order, shuffle ? 1u : 0u,
-                           (unsigned long long)prm->seed);
+                           (unsigned long long)prm->seed, n_world);
         AKZ_LAUNCH_CHECK();
         RsOut O;
         O.best_id = (uint32_t*)d_best_id;
@@ -1941,6 +1984,7 @@ extern "C" int32_t rs_debug_counts(rs_ctx* c, uint32_t* counts, uint32_t cap)
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !counts) return AKZ_E_INVALID;
+        RS_NEED_ARENA(c);
         if (cap < c->last_hyp * 4) return AKZ_E_CAPACITY;
         AKZ_HIP(hipSetDevice(c->device));
         AKZ_HIP(hipMemcpy(counts, c->d_counts, sizeof(uint32_t) * 4 * (size_t)c->last_hyp, hipMemcpyDeviceToHost));
@@ -1953,6 +1997,7 @@ extern "C" int32_t rs_debug_poses(rs_ctx* c, double* poses, uint32_t* ok, uint32
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !poses || !ok) return AKZ_E_INVALID;
+        RS_NEED_ARENA(c);
         if (n_hyp > c->last_hyp) return AKZ_E_INVALID;
         AKZ_HIP(hipSetDevice(c->device));
         AKZ_HIP(hipStreamSynchronize(c->stream));
@@ -1968,6 +2013,7 @@ extern "C" int32_t rs_debug_residuals(rs_ctx* c, const double* poses, uint32_t n
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !poses || !bearings_a || !bearings_b || !out || n_pose == 0 || n == 0 || n_pose > 65535u) return AKZ_E_INVALID;
+        RS_NEED_ARENA(c);
         AKZ_HIP(hipSetDevice(c->device));
         double *d_p = nullptr, *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
         const size_t no = (size_t)n_pose * n * (paired ? 2 : 1);
@@ -1995,6 +2041,7 @@ extern "C" int32_t rs_debug_far(rs_ctx* c, const double* poses, uint32_t n_pose,
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !poses || !bearings_a || !bearings_b || !out || n_pose == 0 || n == 0 || n_pose > 65535u) return AKZ_E_INVALID;
+        RS_NEED_ARENA(c);
         AKZ_HIP(hipSetDevice(c->device));
         double *d_p = nullptr, *d_a = nullptr, *d_b = nullptr;
         unsigned char* d_o = nullptr;

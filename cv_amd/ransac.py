@@ -166,14 +166,14 @@ class EssentialConsensus:
             _lib.RS_BATCH_SHUFFLE if shuffle else 0, d_pose, d_best_id, d_inliers, d_n_inliers, d_stats, stream_to_wait),
             "rs_essential_arrsac_batch_device")
 
-    def p3p_model_inliers_batch_device(self, d_kps, cap_per_img, ik, d_pairs, d_npairs, d_world, cam, params, d_pose, d_best_id,
-                                       d_inliers, d_n_inliers, d_stats=None, shuffle=True, stream_to_wait=None):
+    def p3p_model_inliers_batch_device(self, d_kps, cap_per_img, ik, d_pairs, d_npairs, d_world, n_world, cam, params, d_pose,
+                                       d_best_id, d_inliers, d_n_inliers, d_stats=None, shuffle=True, stream_to_wait=None):
         """rs_p3p_arrsac_batch_device: scene s = (feature of keypoint block ik[s], world point index) pairs; d_world
-        [..][4] f64.  Enqueues and returns; sync() waits."""
+        [n_world][4] f64 (a scene naming a point >= n_world is refused: no model).  Enqueues and returns; sync() waits."""
         n = len(ik)
         k = (C.c_uint32 * n)(*ik)
         check(_lib.lib().rs_p3p_arrsac_batch_device(
-            self._h, d_kps, cap_per_img, k, d_pairs, d_npairs, n, d_world, C.byref(cam), C.byref(params),
+            self._h, d_kps, cap_per_img, k, d_pairs, d_npairs, n, d_world, n_world, C.byref(cam), C.byref(params),
             _lib.RS_BATCH_SHUFFLE if shuffle else 0, d_pose, d_best_id, d_inliers, d_n_inliers, d_stats, stream_to_wait),
             "rs_p3p_arrsac_batch_device")
 

@@ -410,16 +410,20 @@ public:
     {
         std::memset(&p_, 0, sizeof(p_));
         p_.struct_size = sizeof(p_);
+        // the defaults of arrsac 0.10's Arrsac::new as the crate documents them (un-vendored: not verifiable here) —
+        // max_candidate_hypotheses 50, block_size 100, likelihood_ratio_threshold 1e3, initialization_hypotheses 256,
+        // initialization_blocks 4, estimations_per_block 64 — so a caller ported with the bare constructor
+        // (akaze/tests/estimate_pose.rs:63) runs the shape it ran before, inlier-guided re-sampling included
         p_.n_hypotheses = 256;
-        p_.block_size = 64;
-        p_.init_blocks = 1;
-        p_.max_candidates = 64;
+        p_.block_size = 100;
+        p_.init_blocks = 4;
+        p_.max_candidates = 50;
         p_.flags = RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE;
         p_.threshold = inlier_threshold;
         p_.sprt_delta = 0.05;
         p_.sprt_ratio = 1e3;
         p_.seed = seed;
-        p_.estimations_per_block = 0;
+        p_.estimations_per_block = 64;
     }
     ~Arrsac()
     {

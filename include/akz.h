@@ -480,13 +480,15 @@ int32_t rs_essential_arrsac_batch_device(rs_ctx* ctx, const void* d_kps_a, const
 /* The registration path's consensus for a micro-batch of new frames (cv-sfm/src/lib.rs:1571-1622: FeatureWorldMatch(bearing,
  * point) list -> single_view_consensus.model_inliers(&LambdaTwist, ..)).  Scene s: pair list s of d_pairs ([cap_per_img][2]
  * u32, count d_npairs[s]) whose entries are {feature index into keypoint block ik[s] of d_kps, index into d_world};
- * d_world [..][4] f64 homogeneous world points (the caller's triangulated landmarks).  bearing = calibrate(keypoint); each
+ * d_world [n_world][4] f64 homogeneous world points (the caller's triangulated landmarks).  A scene whose pair list names a
+ * feature >= cap_per_img or a world point >= n_world is refused as a whole (no model; nothing is read out of bounds); the
+ * two-view entry point above treats a pair that points outside its keypoint blocks the same way.   bearing = calibrate(keypoint); each
  * scene runs rs_p3p_arrsac's procedure with the scene seed as above.  Outputs as above (pose = WorldToCamera [R | t];
  * no model: fewer than 3 matches or no sample produced a pose).  Specified by oracle/arrsac_oracle.c (orc_p3p_arrsac_pairs). */
 int32_t rs_p3p_arrsac_batch_device(rs_ctx* ctx, const void* d_kps, uint32_t cap_per_img, const uint32_t* ik, const void* d_pairs,
-                                   const void* d_npairs, uint32_t n_scenes, const void* d_world, const rs_camera* cam,
-                                   const rs_arrsac_params* params, uint32_t flags, void* d_pose, void* d_best_id,
-                                   void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait);
+                                   const void* d_npairs, uint32_t n_scenes, const void* d_world, uint32_t n_world,
+                                   const rs_camera* cam, const rs_arrsac_params* params, uint32_t flags, void* d_pose,
+                                   void* d_best_id, void* d_inliers, void* d_n_inliers, void* d_stats, void* stream_to_wait);
 int32_t rs_sync(rs_ctx* ctx);
 void* rs_stream(rs_ctx* ctx);
 /* parity tap: match count, calibrated bearings [n][3] (a, b) and scoring order [n] of scene `scene` of the last batched

@@ -379,3 +379,13 @@ int orc_p3p_arrsac_pairs(const akz_keypoint* kps, const uint32_t* pairs, uint32_
     free(order);
     return rc;
 }
+
+/* The refusal rule of the batched device entry points (k_rsb_prepare): a scene whose pair list names a feature outside its
+ * keypoint block (>= limit_a) or a second index outside the other block / the world table (>= limit_b) ends with "no model";
+ * returns 1 when every entry of the list is in range (the scene is then one of the two functions above). */
+int orc_pairs_in_range(const uint32_t* pairs, uint32_t n, uint32_t limit_a, uint32_t limit_b)
+{
+    for (uint32_t j = 0; j < n; ++j)
+        if (pairs[2 * j] >= limit_a || pairs[2 * j + 1] >= limit_b) return 0;
+    return 1;
+}

@@ -116,6 +116,7 @@ def lib():
         L.orc_p3p_arrsac_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.orc_pairs_in_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_shuffle_order.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
         L.orc_scene_seed.restype = C.c_uint64
         L.orc_scene_seed.argtypes = [C.c_uint64, C.c_uint32]
@@ -589,6 +590,13 @@ def p3p_arrsac_pairs(kps, pairs, world, cam, threshold, n_hypotheses, scene=0, s
              "poses": int(st[4]) * 4}
     return {"pose": pose, "inliers": inl[:ninl.value].copy(), "best_id": best.value, "stats": stats,
             "bearings": ba[:n], "world": wo[:n], "order": order[:n]}
+
+
+def pairs_in_range(pairs, limit_a, limit_b):
+    """oracle/arrsac_oracle.c: orc_pairs_in_range — the refusal rule of the batched device entry points: False when the
+    pair list names an index outside its keypoint block / the world table (the scene then ends with "no model")."""
+    pr = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    return bool(lib().orc_pairs_in_range(pr.ctypes.data, len(pr), int(limit_a), int(limit_b)))
 
 
 # ---- the CPU baseline build (bench.py's cpu_baseline legs only) ----------------------------------------------------

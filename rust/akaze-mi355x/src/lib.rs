@@ -510,16 +510,19 @@ impl Arrsac {
         Self {
             params: RsArrsacParams {
                 struct_size: std::mem::size_of::<RsArrsacParams>() as u32,
+                // arrsac 0.10's documented defaults (the crate is not vendored in rust-cv/cv: unverified here):
+                // initialization_hypotheses 256, block_size 100, initialization_blocks 4, max_candidate_hypotheses 50,
+                // estimations_per_block 64, likelihood_ratio_threshold 1e3
                 n_hypotheses: 256,
-                block_size: 64,
-                init_blocks: 1,
-                max_candidates: 64,
+                block_size: 100,
+                init_blocks: 4,
+                max_candidates: 50,
                 flags: 1 | 2 | 4, // RS_PRUNE_BOUND | RS_PRUNE_SPRT | RS_PRUNE_HALVE
                 threshold: inlier_threshold,
                 sprt_delta: 0.05,
                 sprt_ratio: 1e3,
                 seed,
-                estimations_per_block: 0,
+                estimations_per_block: 64,
                 reserved: 0,
             },
             ctx: None,

@@ -6,6 +6,8 @@
 // Also checked here, because only a native caller can: the per-thread context cache (a second extract of the same size
 // re-uses the pyramid) and the growth of the device lists (a first capacity far too small still gives 399 descriptors).
 // usage: estimate_pose frame0.raw frame14.raw width height
+#include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -88,6 +90,42 @@ int main(int argc, char** argv)
         // fewer matches than a minimal sample: None
         std::vector<cv_core::FeatureMatch> few(fm.begin(), fm.begin() + 7);
         if (consensus.model_inliers(eight_point::EightPoint{}, few)) return 1;
+        // the bare constructor on a scene long enough for its inlier-guided re-sampling to run (defaults: 100-match blocks,
+        // 4 initialisation blocks, 64 estimations per block): 900 matches of a known motion, a third of them wrong
+        {
+            const double ang = 0.07, ca = std::cos(ang), sa = std::sin(ang);
+            const double R[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca}, t[3] = {0.5, 0.05, 0.1};
+            std::vector<cv_core::FeatureMatch> big;
+            uint64_t st = 0x9E3779B97F4A7C15ull;
+            auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+            auto unit = [](double x, double y, double z) {
+                const double n = std::sqrt(x * x + y * y + z * z);
+                return std::array<double, 3>{x / n, y / n, z / n};
+            };
+            size_t good = 0;
+            for (int i = 0; i < 900; ++i) {
+                const double X = 4 * rnd() - 2, Y = 2.4 * rnd() - 1.2, Z = 3 + 6 * rnd();
+                cv_core::FeatureMatch f;
+                f.a = unit(X, Y, Z);
+                if (i % 3 == 2) f.b = unit(4 * rnd() - 2, 2.4 * rnd() - 1.2, 3 + 6 * rnd());   // an outlier
+                else {
+                    f.b = unit(R[0] * X + R[1] * Y + R[2] * Z + t[0], R[3] * X + R[4] * Y + R[5] * Z + t[1], R[6] * X + R[7] * Y + R[8] * Z + t[2]);
+                    ++good;
+                }
+                big.push_back(f);
+            }
+            arrsac::Arrsac bare(1e-7, 3);
+            auto rb = bare.model_inliers(eight_point::EightPoint{}, big);
+            if (!rb) return 1;
+            printf("resampled consensus inliers %zu of %zu true\n", rb->second.size(), good);
+            if (rb->second.size() < good * 9 / 10 || rb->second.size() > good + 20) return 1;
+            for (size_t i : rb->second)
+                if (i >= big.size()) return 1;
+            // the recovered rotation is the scene's (to the precision exact synthetic bearings allow)
+            const auto& q = rb->first.rt;
+            const double err = std::fabs(q[0] - R[0]) + std::fabs(q[2] - R[2]) + std::fabs(q[5] - R[4]) + std::fabs(q[8] - R[6]) + std::fabs(q[10] - R[8]);
+            if (err > 1e-6) return 1;
+        }
         // growth: a first capacity of 64 keypoints per frame still ends with the reference's 399
         akaze::Akaze tiny = akaze::Akaze::sparse();
         tiny.initial_keypoint_capacity = 64;

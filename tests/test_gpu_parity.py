@@ -759,6 +759,7 @@ def test_cpp_host_mirror_estimate_pose(gpu, kitti, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "descriptors 399 343" in r.stdout and "matches 11" in r.stdout
     assert "inliers 11" in r.stdout and "grown 399" in r.stdout and "colour 399" in r.stdout and "estimate_pose ok" in r.stdout
+    assert "resampled consensus inliers" in r.stdout     # the bare Arrsac constructor with the crate's defaults (re-sampling on)
 
 
 def test_native_host_drives_the_device_pipeline(gpu, kitti, tmp_path):
@@ -1489,6 +1490,82 @@ def test_batched_two_view_verification_equals_its_specification(gpu, oracle, nam
     assert some_model >= 8
 
 
+@pytest.mark.gpu
+def test_pair_lists_that_point_out_of_bounds_refuse_their_scene(gpu, oracle):
+    """k_rsb_prepare reads keypoints / world points through the indices of a caller-provided device pair list.  A list
+    with an entry outside its keypoint block (>= cap_per_img) or outside the world table (>= n_world) makes THAT scene
+    end with "no model" (oracle.pairs_in_range: the specification's rule) — nothing is read out of bounds, and the
+    scenes beside it are what they are without it."""
+    import torch
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_arrsac import _registration_scene
+    rng = np.random.default_rng(0xB0D)
+    cap, n_hyp = 256, 96
+    cam = (984.2439, 980.8141, 690.0, 233.1966, 0.0, None)
+    kw = dict(block_size=32, init_blocks=1, max_candidates=32, sprt=True)
+    dev = torch.device("cuda", 0)
+    S = 4
+    scenes = [_pixel_scene(rng, cap, cap, 120, 0.3, cam) for _ in range(S)]
+    pairs = np.zeros((S, cap, 2), np.uint32)
+    for s in range(S):
+        pairs[s, :120] = scenes[s][2]
+    pairs[1, 37, 0] = cap                 # first index one past the block
+    pairs[2, 5, 1] = 0xFFFFFFF0           # second index far outside
+    kps_a = np.stack([sc[0] for sc in scenes]); kps_b = np.stack([sc[1] for sc in scenes])
+    npairs = np.full(S, 120, np.uint32)
+    d_ka = torch.from_numpy(kps_a.view(np.uint8).reshape(S, cap, 28)).to(dev)
+    d_kb = torch.from_numpy(kps_b.view(np.uint8).reshape(S, cap, 28)).to(dev)
+    d_pairs = torch.from_numpy(pairs.view(np.int32)).to(dev)
+    d_np = torch.from_numpy(npairs.view(np.int32)).to(dev)
+    d_pose = torch.zeros((S, 12), dtype=torch.float64, device=dev)
+    d_best = torch.zeros((S,), dtype=torch.int32, device=dev)
+    d_inl = torch.zeros((S, cap), dtype=torch.int32, device=dev)
+    d_ninl = torch.full((S,), 7, dtype=torch.int32, device=dev)
+    cons = EssentialConsensus(cap, n_hyp)
+    cons.reserve(S)
+    prm = cons.make_params(2e-7, n_hypotheses=n_hyp, seed=5, **kw)
+    c = cons.camera(cam)
+    ia = list(range(S))
+    cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ia, d_pairs.data_ptr(), d_np.data_ptr(), c, c, prm,
+                                    d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(), None, shuffle=True)
+    cons.sync()
+    best = d_best.cpu().numpy().view(np.uint32); ninl = d_ninl.cpu().numpy().view(np.uint32)
+    for s in range(S):
+        ok = oracle.pairs_in_range(pairs[s, :120], cap, cap)
+        assert ok == (s in (0, 3))
+        if not ok:
+            assert best[s] == 0xFFFFFFFF and ninl[s] == 0, (s, best[s], ninl[s])
+            continue
+        want = oracle.arrsac_pairs(scenes[s][0], scenes[s][1], pairs[s, :120], cam, cam, 2e-7, n_hyp, scene=s, shuffle=True, seed=5, **kw)
+        assert best[s] == want["best_id"] and ninl[s] == len(want["inliers"])
+        _eq(d_pose.cpu().numpy()[s].reshape(3, 4), want["pose"], f"scene {s} pose")
+    # the registration consensus: a world-point index >= n_world
+    n_world = 300
+    cam_r = (950.0, 955.0, 640.0, 250.0, 0.5, -0.05)
+    reg = [_registration_scene(rng, cap, n_world, 90, 0.3, cam_r) for _ in range(2)]
+    rp = np.zeros((2, cap, 2), np.uint32)
+    for s in range(2):
+        rp[s, :90] = reg[s][2]
+        rp[s, :90, 1] += s * n_world
+    rp[0, 11, 1] = 2 * n_world            # one past the table
+    world_all = np.concatenate([reg[0][1], reg[1][1]])
+    d_k = torch.from_numpy(np.stack([reg[0][0], reg[1][0]]).view(np.uint8).reshape(2, cap, 28)).to(dev)
+    d_rp = torch.from_numpy(rp.view(np.int32)).to(dev)
+    d_rn = torch.from_numpy(np.full(2, 90, np.int32)).to(dev)
+    d_world = torch.from_numpy(world_all).to(dev)
+    prm_r = cons.make_params(1e-6, n_hypotheses=n_hyp, seed=9, **kw)
+    cons.p3p_model_inliers_batch_device(d_k.data_ptr(), cap, [0, 1], d_rp.data_ptr(), d_rn.data_ptr(), d_world.data_ptr(),
+                                        2 * n_world, cons.camera(cam_r), prm_r, d_pose.data_ptr(), d_best.data_ptr(),
+                                        d_inl.data_ptr(), d_ninl.data_ptr(), None, shuffle=False)
+    cons.sync()
+    best = d_best.cpu().numpy().view(np.uint32); ninl = d_ninl.cpu().numpy().view(np.uint32)
+    assert not oracle.pairs_in_range(rp[0, :90], cap, 2 * n_world) and oracle.pairs_in_range(rp[1, :90], cap, 2 * n_world)
+    assert best[0] == 0xFFFFFFFF and ninl[0] == 0
+    want = oracle.p3p_arrsac_pairs(reg[1][0], rp[1, :90], world_all, cam_r, 1e-6, n_hyp, scene=1, shuffle=False, seed=9, **kw)
+    assert best[1] == want["best_id"] and ninl[1] == len(want["inliers"]) and want["best_id"] != 0xFFFFFFFF
+    _eq(d_pose.cpu().numpy()[1].reshape(3, 4), want["pose"], "registration scene 1 pose")
+
+
 REG_RULES = [
     ("halving, 16-match blocks, shuffled", dict(block_size=16, init_blocks=1, max_candidates=64, halve=True), True),
     ("cap + sprt, 64-match blocks", dict(block_size=64, init_blocks=2, max_candidates=96, sprt=True), False),
@@ -1544,7 +1621,7 @@ def test_batched_registration_consensus_equals_its_specification(gpu, oracle, na
     prm = cons.make_params(thr, n_hypotheses=n_hyp, seed=41, **kw)
     for rep in range(2):
         cons.p3p_model_inliers_batch_device(d_k.data_ptr(), cap, ik, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(),
-                                            cons.camera(cam), prm, d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(),
+                                            d_world.shape[0], cons.camera(cam), prm, d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(),
                                             d_ninl.data_ptr(), d_stats.data_ptr(), shuffle=shuffle)
     cons.sync()
     pose = d_pose.cpu().numpy(); best = d_best.cpu().numpy().view(np.uint32); inl = d_inl.cpu().numpy().view(np.uint32)
@@ -2083,7 +2160,7 @@ def test_new_entry_points_refuse_what_they_cannot_do(gpu):
     def reg(n_scenes, flags=0, cap=512, p=prm, camera=cam, w=world):
         ik = (C.c_uint32 * max(1, n_scenes))(*range(n_scenes))
         return L.rs_p3p_arrsac_batch_device(cons._h, kp.data_ptr(), cap, ik, pairs.data_ptr(), npairs.data_ptr(), n_scenes,
-                                            w.data_ptr() if w is not None else None, C.byref(camera), C.byref(p), flags,
+                                            w.data_ptr() if w is not None else None, 8, C.byref(camera), C.byref(p), flags,
                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), None, None)
     assert reg(2) == 0 and reg(0) == 0
     cons.sync()

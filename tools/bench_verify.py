@@ -112,7 +112,7 @@ def main():
 
     def run():
         if args.registration:
-            cons.p3p_model_inliers_batch_device(d_ka.data_ptr(), cap, ia, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(), c, prm,
+            cons.p3p_model_inliers_batch_device(d_ka.data_ptr(), cap, ia, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(), d_world.shape[0], c, prm,
                                                 d_pose.data_ptr(), d_best.data_ptr(), d_inl.data_ptr(), d_ninl.data_ptr(),
                                                 d_stats.data_ptr(), shuffle=True)
             return

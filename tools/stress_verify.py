@@ -130,7 +130,7 @@ def main():
         if reg is not None:
             d_world = torch.from_numpy(reg["world"]).to(dev)
             cons.p3p_model_inliers_batch_device(d_ka.data_ptr(), cap, ia, d_pairs.data_ptr(), d_np.data_ptr(), d_world.data_ptr(),
-                                                cons.camera(R["cam_b"]), prm, d_pose.data_ptr(), d_best.data_ptr(),
+                                                d_world.shape[0], cons.camera(R["cam_b"]), prm, d_pose.data_ptr(), d_best.data_ptr(),
                                                 d_inl.data_ptr(), d_ninl.data_ptr(), d_stats.data_ptr(), shuffle=R["shuffle"])
         else:
             cons.model_inliers_batch_device(d_ka.data_ptr(), d_kb.data_ptr(), cap, ia, ia, d_pairs.data_ptr(), d_np.data_ptr(),
