@@ -571,6 +571,7 @@ def main():
                 rc = 1
             if args.cpu_procs > 0:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(frames, args.cpu_procs)
+                out["cpu_baseline_intra_frame"] = cpu_baseline_intra_frame(frames, oracle_out, args.cpu_procs)
         if world == 1 and not args.no_extras:
             out["configs_extra"] = {"configs[2]": extra_match(torch, dev, L, _lib, args.extra_frames),
                                     "configs[3]": extra_ransac(args.extra_hyp)}
@@ -1104,6 +1105,30 @@ def cpu_baseline_all_cores(frames, threads):
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} frames, OpenMP over frames on {threads} threads (extract + symmetric match vs previous frame), {dt:.1f} s; "
                       f"host reports {os.cpu_count()} logical CPUs"}
+
+
+def cpu_baseline_intra_frame(frames, checker_results, threads):
+    """The reference as its own driver runs it (SURVEY 8d): vslam-sandbox feeds VSlam::add_frame ONE frame at a time, and a
+    frame's extraction is parallel only where the akaze crate's `rayon` feature makes it so — lib.rs:241-247 (the two simple
+    Scharr filters), detector_response.rs:21,54,71-83 (the evolutions, and the five multiscale filters of one), scale_space_
+    extrema.rs:352 and descriptors.rs:35 (the keypoints).  The separable filters, the 166 FED steps and the extrema search
+    are serial in the reference too, so this is what all the host's cores buy a single frame.  Same -O3 -march=native build
+    (ORC_OPT_INTRA); outputs asserted bit-identical to the checker's before they count."""
+    from oracle import oracle as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads if threads > 0 else avail, avail, 32))     # (16 evolutions x nested joins: more threads only spin)
+    n = min(len(checker_results), frames.shape[0])
+    host = frames[:n].cpu().numpy()
+    O.extract_many_intra(host[:1], threads=threads)         # the thread team, the pyramid
+    t0 = time.perf_counter()
+    got = O.extract_many_intra(host, threads=threads)
+    dt = time.perf_counter() - t0
+    same = all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) for a, b in zip(checker_results, got))
+    if not same:
+        raise SystemExit("bench.py: the intra-frame parallel oracle differs from the -O2 checker")
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"the same {n} frames, one after the other, each parallel at the akaze crate's four rayon sites only "
+                      f"(OpenMP, {threads} threads; extraction only, no matching), {dt:.1f} s; bit-identical to the checker"}
 
 
 if __name__ == "__main__":

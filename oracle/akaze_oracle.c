@@ -30,6 +30,13 @@
  *   ORC_OPT_TRIG     atan2f/cosf/sinf                0: include/akz_portable_math.h [default, what
  *                                                       the HIP path implements]  1: host libm (what
  *                                                       a Rust build on this host would call)
+ * and one switch that changes the schedule, never a result:
+ *   ORC_OPT_INTRA    the akaze crate's `rayon` feature     0: serial [default]  1: the reference's four intra-frame
+ *                    parallel points (lib.rs:241-247 join of the two simple Scharr filters; detector_response.rs:21,54
+ *                    par_iter over the evolutions with the joins of :71-83 nested; scale_space_extrema.rs:352 and
+ *                    descriptors.rs:35 par_iter over the keypoints, collected in order) as OpenMP regions — only in a
+ *                    build with -fopenmp (oracle/Makefile `fast`: bench.py's cpu_baseline_intra_frame leg); the
+ *                    separable filters, the FED steps and the extrema search are serial in the reference as well.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).  No FMA contraction, no
  * reassociation: rustc never does either.
@@ -39,12 +46,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/akz.h"
 #include "../include/akz_portable_math.h"
 
-enum { ORC_OPT_REDUCE = 0, ORC_OPT_FMA = 1, ORC_OPT_HALFSUM = 2, ORC_OPT_TRIG = 3, ORC_NOPT = 4 };
-static int g_opt[ORC_NOPT] = {0, 0, 0, 0};
+enum { ORC_OPT_REDUCE = 0, ORC_OPT_FMA = 1, ORC_OPT_HALFSUM = 2, ORC_OPT_TRIG = 3, ORC_OPT_INTRA = 4, ORC_NOPT = 5 };
+static int g_opt[ORC_NOPT] = {0, 0, 0, 0, 0};
 
 void orc_set_option(int which, int value)
 {
@@ -631,8 +641,18 @@ static void create_nonlinear_scale_space(orc_ctx* c, const img_t* image)
             ev[i].Lt = img_clone(&ev[i - 1].Lt);
         }
         ev[i].Lsmooth = gaussian_blur(&ev[i].Lt, 1.0f);
-        ev[i].Lx = simple_scharr_horizontal(&ev[i].Lsmooth);
-        ev[i].Ly = simple_scharr_vertical(&ev[i].Lsmooth);
+        if (g_opt[ORC_OPT_INTRA]) {                     /* lib.rs:241-247: rayon::join of the two filters */
+#pragma omp parallel sections num_threads(2)
+            {
+#pragma omp section
+                ev[i].Lx = simple_scharr_horizontal(&ev[i].Lsmooth);
+#pragma omp section
+                ev[i].Ly = simple_scharr_vertical(&ev[i].Lsmooth);
+            }
+        } else {
+            ev[i].Lx = simple_scharr_horizontal(&ev[i].Lsmooth);
+            ev[i].Ly = simple_scharr_vertical(&ev[i].Lsmooth);
+        }
         ev[i].Lflow = img_new(ev[i].Lt.w, ev[i].Lt.h);
         orc_pm_g2(ev[i].Lx.d, ev[i].Ly.d, (size_t)ev[i].Lt.w * ev[i].Lt.h, contrast, ev[i].Lflow.d);
         for (int j = 0; j < ev[i].ntau; ++j)
@@ -643,17 +663,42 @@ static void create_nonlinear_scale_space(orc_ctx* c, const img_t* image)
 /* detector_response.rs:8-85 */
 static void detector_response(orc_ctx* c)
 {
+    const int intra = g_opt[ORC_OPT_INTRA];
+#ifdef _OPENMP
+    if (intra) omp_set_max_active_levels(2);            /* the joins of :71-83 nest inside the par_iter of :21 */
+#endif
+#pragma omp parallel for schedule(dynamic, 1) if (intra)
     for (int i = 0; i < c->nlev; ++i) {
         evo_t* e = &c->ev[i];
         uint32_t sigma = deriv_sigma(c, e);
         img_free(&e->Lx);
         img_free(&e->Ly);
-        e->Lx = scharr_horizontal(&e->Lsmooth, sigma);
-        e->Ly = scharr_vertical(&e->Lsmooth, sigma);
-        e->Lxx = scharr_horizontal(&e->Lx, sigma);
-        e->Lyy = scharr_vertical(&e->Ly, sigma);
-        e->Lxy = scharr_vertical(&e->Lx, sigma);
+        if (intra) {
+#pragma omp parallel sections num_threads(2)
+            {
+#pragma omp section
+                e->Lx = scharr_horizontal(&e->Lsmooth, sigma);
+#pragma omp section
+                e->Ly = scharr_vertical(&e->Lsmooth, sigma);
+            }
+#pragma omp parallel sections num_threads(3)
+            {
+#pragma omp section
+                e->Lxx = scharr_horizontal(&e->Lx, sigma);
+#pragma omp section
+                e->Lyy = scharr_vertical(&e->Ly, sigma);
+#pragma omp section
+                e->Lxy = scharr_vertical(&e->Lx, sigma);
+            }
+        } else {
+            e->Lx = scharr_horizontal(&e->Lsmooth, sigma);
+            e->Ly = scharr_vertical(&e->Lsmooth, sigma);
+            e->Lxx = scharr_horizontal(&e->Lx, sigma);
+            e->Lyy = scharr_vertical(&e->Ly, sigma);
+            e->Lxy = scharr_vertical(&e->Lx, sigma);
+        }
     }
+#pragma omp parallel for schedule(dynamic, 1) if (intra)
     for (int i = 0; i < c->nlev; ++i) {
         evo_t* e = &c->ev[i];
         double ratio = pow(2.0, (double)(int)e->octave);
@@ -842,10 +887,10 @@ static int compute_main_orientation(const orc_ctx* c, akz_keypoint* kp)
 }
 
 /* do_subpixel_refinement — :297-362. */
-static void do_subpixel_refinement(const orc_ctx* c, const kpvec* in, kpvec* out)
+/* the closure `process_keypoint` of scale_space_extrema.rs:297-344: 1 and *res when the keypoint survives */
+static int refine_one(const orc_ctx* c, const akz_keypoint* kp, akz_keypoint* res)
 {
-    for (uint32_t n = 0; n < in->n; ++n) {
-        const akz_keypoint* kp = &in->v[n];
+    {
         const evo_t* ev = &c->ev[kp->class_id];
         float ratio = ldexpf(1.0f, (int)kp->octave);
         size_t x = sat_usize_f32(roundf(kp->x / ratio));
@@ -883,10 +928,30 @@ static void do_subpixel_refinement(const orc_ctx* c, const kpvec* in, kpvec* out
             k2.size *= 2.0f;
             if (compute_main_orientation(c, &k2) != 0) {
                 fprintf(stderr, "orc: orientation sample out of bounds (reference would panic)\n");
-                continue;
+                return 0;
             }
-            kpvec_push(out, k2);
+            *res = k2;
+            return 1;
         }
+    }
+    return 0;
+}
+static void do_subpixel_refinement(const orc_ctx* c, const kpvec* in, kpvec* out)
+{
+    if (g_opt[ORC_OPT_INTRA] && in->n) {            /* :345-352: par_iter().filter_map().collect() keeps the order */
+        akz_keypoint* tmp = (akz_keypoint*)malloc(sizeof(akz_keypoint) * in->n);
+        unsigned char* keep = (unsigned char*)malloc(in->n);
+#pragma omp parallel for schedule(static)
+        for (long n = 0; n < (long)in->n; ++n) keep[n] = (unsigned char)refine_one(c, &in->v[n], &tmp[n]);
+        for (uint32_t n = 0; n < in->n; ++n)
+            if (keep[n]) kpvec_push(out, tmp[n]);
+        free(tmp);
+        free(keep);
+        return;
+    }
+    for (uint32_t n = 0; n < in->n; ++n) {
+        akz_keypoint k2;
+        if (refine_one(c, &in->v[n], &k2)) kpvec_push(out, k2);
     }
 }
 
@@ -1025,12 +1090,27 @@ int orc_extract_f32(orc_ctx* c, const float* image)
     c->kp_final = (akz_keypoint*)malloc(sizeof(akz_keypoint) * (ns ? ns : 1));
     c->desc_final = (akz_descriptor*)malloc(sizeof(akz_descriptor) * (ns ? ns : 1));
     uint32_t nf = 0;
-    for (uint32_t i = 0; i < ns; ++i) {
-        akz_descriptor d;
-        if (get_mldb_descriptor(c, &c->kp_sorted[i], &d) == 0) {
-            c->kp_final[nf] = c->kp_sorted[i];
-            c->desc_final[nf] = d;
-            nf++;
+    if (g_opt[ORC_OPT_INTRA] && ns) {               /* descriptors.rs:31-42: par_iter().filter_map().unzip(), in order */
+        akz_descriptor* tmp = (akz_descriptor*)malloc(sizeof(akz_descriptor) * ns);
+        unsigned char* keep = (unsigned char*)malloc(ns);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)ns; ++i) keep[i] = (unsigned char)(get_mldb_descriptor(c, &c->kp_sorted[i], &tmp[i]) == 0);
+        for (uint32_t i = 0; i < ns; ++i)
+            if (keep[i]) {
+                c->kp_final[nf] = c->kp_sorted[i];
+                c->desc_final[nf] = tmp[i];
+                nf++;
+            }
+        free(tmp);
+        free(keep);
+    } else {
+        for (uint32_t i = 0; i < ns; ++i) {
+            akz_descriptor d;
+            if (get_mldb_descriptor(c, &c->kp_sorted[i], &d) == 0) {
+                c->kp_final[nf] = c->kp_sorted[i];
+                c->desc_final[nf] = d;
+                nf++;
+            }
         }
     }
     c->n_final = nf;

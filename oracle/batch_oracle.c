@@ -27,6 +27,8 @@ const akz_descriptor* orc_descriptors(const orc_ctx* c);
 int orc_match(const akz_descriptor* a, uint32_t na, const akz_descriptor* b, uint32_t nb, int rule, uint32_t pu, float pf,
               int symmetric, uint32_t* pairs, uint32_t cap);
 
+void orc_set_option(int which, int value);
+
 int orc_threads_available(void)
 {
 #ifdef _OPENMP
@@ -75,5 +77,35 @@ int orc_extract_match_many_u8(const akz_config* cfg, int w, int h, const uint8_t
         }
         if (n > 0) npairs[0] = 0;
     }
+    return bad ? -1 : 0;
+}
+
+/* The reference as its own driver runs it: vslam-sandbox hands frames to VSlam::add_frame ONE AT A TIME
+ * (vslam-sandbox/src/main.rs:124-160), and a frame's extraction is parallel only at the akaze crate's `rayon` points
+ * (ORC_OPT_INTRA, akaze_oracle.c header).  n frames in sequence, each on `threads` threads; outputs as above (no matching).
+ * Returns 0, or -1 when a frame has more than cap keypoints. */
+int orc_extract_many_intra_u8(const akz_config* cfg, int w, int h, const uint8_t* imgs, int n, int threads, uint32_t cap,
+                              akz_keypoint* kps, akz_descriptor* descs, uint32_t* counts)
+{
+    int bad = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    orc_set_option(4 /* ORC_OPT_INTRA */, 1);
+    orc_ctx* c = orc_create(cfg, w, h);
+    for (int i = 0; i < n; ++i) {
+        orc_extract_u8(c, imgs + (size_t)i * w * h, w);
+        const akz_keypoint* k = NULL;
+        uint32_t m = orc_keypoints(c, 3, &k);
+        if (m > cap) {
+            bad = 1;
+            m = cap;
+        }
+        counts[i] = m;
+        memcpy(kps + (size_t)i * cap, k, sizeof(akz_keypoint) * m);
+        memcpy(descs + (size_t)i * cap, orc_descriptors(c), sizeof(akz_descriptor) * m);
+    }
+    orc_destroy(c);
+    orc_set_option(4, 0);
     return bad ? -1 : 0;
 }

@@ -659,6 +659,23 @@ def extract_match_many(frames, threads=1, cap=8192, match=True, param_u=24, cfg=
             for i in range(n)]
 
 
+def extract_many_intra(frames, threads=0, cap=8192, cfg=None):
+    """oracle/batch_oracle.c: orc_extract_many_intra_u8 — the frames one after the other, each parallel at the akaze
+    crate's own `rayon` points only (ORC_OPT_INTRA), on `threads` OpenMP threads of the fast build.  Returns a list of
+    (keypoints, descriptors) per frame."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    L = fast_lib()
+    L.orc_extract_many_intra_u8.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+    cfg = cfg if cfg is not None else default_config()
+    kps = np.zeros((n, cap), KP_DTYPE); descs = np.zeros((n, cap, 64), np.uint8); counts = np.zeros(n, np.uint32)
+    r = L.orc_extract_many_intra_u8(C.byref(cfg), w, h, frames.ctypes.data, n, int(threads), cap, kps.ctypes.data,
+                                    descs.ctypes.data, counts.ctypes.data)
+    assert r == 0, "a frame has more keypoints than cap"
+    return [(kps[i, :counts[i]].copy(), descs[i, :counts[i]].copy()) for i in range(n)]
+
+
 def threads_available():
     return int(fast_lib().orc_threads_available())
 
