@@ -156,6 +156,10 @@ def main():
                     "two-view ARRSAC of every frame pair, device-resident); 0 = skip")
     ap.add_argument("--verify-block", type=int, default=16, help="pipeline+verify: matches per scoring block")
     ap.add_argument("--verify-check", type=int, default=16, help="pipeline+verify: scenes compared with oracle/arrsac_oracle.c")
+    ap.add_argument("--register-steps", type=int, default=3, help="timed steps of the pipeline+register leg (extract + hash_bag + "
+                    "knn(., 3) against the recent views + best-of-views + Lambda Twist ARRSAC of every frame, device-resident); 0 = skip")
+    ap.add_argument("--register-views", type=int, default=32, help="pipeline+register: recent views per frame (cv-sfm tracking_recent_frames)")
+    ap.add_argument("--register-check", type=int, default=4, help="pipeline+register: frames compared with the oracle")
     ap.add_argument("--extra-frames", type=int, default=1000, help="frames of the configs[2] matcher workload")
     ap.add_argument("--extra-hyp", type=int, default=10000, help="hypotheses of the configs[3] scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
@@ -578,6 +582,8 @@ def main():
             if args.verify_steps > 0:
                 out["configs_extra"]["pipeline+verify"] = extra_pipeline_verify(
                     torch, dev, L, _lib, args, step, step_no, barrier, verify, match_done, hm_stream, kps2, pairs2, npairs2, NF, MB)
+            if args.register_steps > 0 and K == 1 and not sharded:
+                out["configs_extra"]["pipeline+register"] = extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB)
             for v in out["configs_extra"].values():
                 if v.get("parity", {}).get("mismatches"):
                     rc = 1
@@ -907,6 +913,146 @@ def extra_pipeline_verify(torch, dev, L, _lib, args, step, step_no, barrier, ver
                               "the last step's micro-batches vs oracle/arrsac_oracle.c (orc_arrsac_pairs) on the GPU's own "
                               "keypoints and pair lists"}}
     cons.close()
+    return out
+
+
+def extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB):
+    """The loop vslam-sandbox runs on every frame once a reconstruction exists (cv-sfm/src/lib.rs:672, 1452-1542, 1549-1604,
+    1619-1622), for whole micro-batches, nothing leaving the device: extract -> hasher.hash_bag -> knn(., 3) of every feature
+    against each of the frame's recent views (tracking_recent_frames = 32) -> landmark dedup / three best / unique-match decision
+    -> duplicate-landmark filter + FeatureWorldMatch list -> Arrsac + LambdaTwist (vslam-sandbox/src/main.rs:105-111: 16 384
+    hypotheses, 1 024 candidates, 256 estimations per block).  cv_amd/registration.py chains the five device-resident entry
+    points; the reference's control plane is played by torch on the device: the landmark a stored feature observes is the
+    world-canvas cell (4 px, per evolution level) its keypoint falls into, the landmark table the cell centres on the plane the
+    panning camera looks at.  value = registered frames per second of the whole chain; sampled frames are held to the oracle
+    stage by stage (pair lists, winner, pose bits, inlier lists) and every pose to the motion the frames were rendered with."""
+    from cv_amd.registration import Registration
+    from oracle import oracle as O
+    V = max(1, min(args.register_views, NF - 1))
+    CELL, F_CAM, Z0 = 4, 1000.0, 5.0
+    cam = (F_CAM, F_CAM, W / 2.0, H / 2.0, 0.0, None)
+    wc, hc = (W + 4 * NF) // CELL + 2, (H + 2 * NF) // CELL + 2
+    n_world = wc * hc * 16
+    keys = torch.arange(n_world, device=dev, dtype=torch.int64)
+    cell = keys // 16
+    xw = ((cell % wc).to(torch.float64) + 0.5) * CELL
+    yw = ((cell // wc).to(torch.float64) + 0.5) * CELL
+    P = torch.stack([(xw - W / 2.0) * Z0 / F_CAM, (yw - H / 2.0) * Z0 / F_CAM, torch.full_like(xw, Z0), torch.ones_like(xw)], 1)
+    d_world = (P / torch.linalg.norm(P[:, :3], dim=1, keepdim=True)).contiguous()
+    del keys, cell, xw, yw, P
+    rng = np.random.default_rng(0xC0DE)
+    codewords = rng.integers(0, 256, (4096, 64), dtype=np.uint8)        # cv-sfm ships 4096 words (cv-sfm/src/codewords.rs)
+    thr, n_hyp, kw = 1e-5, 16384, dict(block_size=64, max_candidates=1024, estimations_per_block=256)
+    reg = Registration(torch, CAP, NF, V, codewords, cam, device=dev.index, threshold=thr, n_hypotheses=n_hyp, seed=0, **kw)
+    rs_s = torch.cuda.ExternalStream(reg.rs_stream(), device=dev)
+    akz_s = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
+    z2 = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=dev) for _ in range(2)]
+    kps2, descs2, counts2, lm2 = z2((NF, CAP, 28), torch.uint8), z2((NF, CAP, 64), torch.uint8), z2((NF,), torch.int32), z2((NF, CAP), torch.int32)
+    gidx = torch.arange(NF, device=dev, dtype=torch.float32).view(NF, 1)
+    frame_blocks = list(range(NF))
+    view_blocks = [[(j - 1 - v) % NF for v in range(V)] for j in range(NF)]
+    glue = torch.cuda.Stream(device=dev)
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    n = [0]
+
+    def step():
+        p = n[0] & 1
+        cur = torch.cuda.current_stream()
+        if n[0] >= 2:
+            cur.wait_event(done[p])                       # set p's keypoints / descriptors were last read two steps ago
+        for m0 in range(0, NF, MB):
+            _lib.check(L.akz_extract_batch_device(ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps2[p][m0:m0 + MB].data_ptr(),
+                                                  descs2[p][m0:m0 + MB].data_ptr(), CAP, counts2[p][m0:m0 + MB].data_ptr(),
+                                                  cur.cuda_stream), "extract")
+        # the caller's bookkeeping: which landmark every feature of every stored view observes
+        glue.wait_stream(akz_s)
+        with torch.cuda.stream(glue):
+            k = kps2[p].view(torch.float32).view(NF, CAP, 7)
+            cx = torch.clamp(torch.floor((k[..., 0] + 4.0 * gidx) / CELL), 0, wc - 1).to(torch.int32)
+            cy = torch.clamp(torch.floor((k[..., 1] + 2.0 * gidx) / CELL), 0, hc - 1).to(torch.int32)
+            cls = kps2[p].view(torch.int32).view(NF, CAP, 7)[..., 6] & 15
+            lm2[p].copy_((cy * wc + cx) * 16 + cls)
+        reg.enqueue(kps2[p], descs2[p], counts2[p], frame_blocks, view_blocks, lm2[p], d_world, n_world, stream_to_wait=glue.cuda_stream)
+        done[p].record(rs_s)
+        n[0] += 1
+
+    step(); step()
+    reg.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.register_steps):
+        step()
+    reg.sync(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.register_steps
+    last = (n[0] - 1) & 1
+    kps = kps2[last].cpu().numpy().view(_lib.KP_DTYPE).reshape(NF, CAP)
+    counts = counts2[last].cpu().numpy()
+    lms = lm2[last].cpu().numpy().view(np.uint32)
+    h_np = reg.npairs.cpu().numpy().view(np.uint32); h_id = reg.best_id.cpu().numpy().view(np.uint32)
+    h_ninl = reg.n_inliers.cpu().numpy().view(np.uint32); h_pose = reg.pose.cpu().numpy().reshape(NF, 3, 4)
+    h_dec = reg.decision.cpu().numpy().view(np.uint32)
+    # every pose against the motion the frames were rendered with: identity rotation, camera at (4 g, 2 g) px on the canvas
+    have = h_id != 0xFFFFFFFF
+    g = np.arange(NF)
+    expect_t = -np.stack([4.0 * g * Z0 / F_CAM, 2.0 * g * Z0 / F_CAM, np.zeros(NF)], 1)
+    rot_err = np.abs(h_pose[:, :, :3] - np.eye(3)).max((1, 2))
+    t_err = np.abs(h_pose[:, :, 3] - expect_t).max(1)
+    pose_ok = have & (rot_err < 0.03) & (t_err < 0.15)
+    # sampled frames stage by stage against the oracle, on the GPU's own intermediate data
+    world = None
+    bad, detail, checked = 0, [], 0
+    t0 = time.perf_counter()
+    if args.register_check:
+        world = d_world.cpu().numpy()
+        descs = descs2[last].cpu().numpy()
+        for f in sorted({0, NF - 1} | {(i * NF // args.register_check) | 1 for i in range(args.register_check)})[:args.register_check]:
+            nq = int(counts[f])
+            gk = reg.knn[f].cpu().numpy()
+            gnb = np.zeros((V, CAP, 3), _lib.NB_DTYPE)
+            gnb["index"] = gk[..., 0]; gnb["distance"] = gk[..., 1]
+            v = (f * 7) % V
+            tb = view_blocks[f][v]
+            wk = O.knn(descs[f, :200], descs[tb, :counts[tb]], 3)
+            ok = np.array_equal(gnb["index"][v, :200], wk["index"]) and np.array_equal(gnb["distance"][v, :200], wk["distance"])
+            wbest, wdec = O.best_of_views(gnb, nq, lms, np.array(view_blocks[f], np.uint32), counts.astype(np.uint32), 24)
+            ok = ok and np.array_equal(reg.best[f, :nq].cpu().numpy().view(np.uint32), wbest) and np.array_equal(h_dec[f, :nq], wdec)
+            wpairs = O.landmark_pairs(wbest, wdec, world)
+            gp = reg.pairs[f, :h_np[f]].cpu().numpy().view(np.uint32)
+            ok = ok and len(wpairs) == h_np[f] and np.array_equal(gp, wpairs)
+            want = O.p3p_arrsac_pairs(kps[f], wpairs, world, cam, thr, n_hyp, scene=f, shuffle=True, seed=0, init_blocks=1, halve=True,
+                                      sprt=True, **kw)
+            g_inl = reg.inliers[f, :h_ninl[f]].cpu().numpy().view(np.uint32)
+            ok = ok and h_id[f] == want["best_id"] and np.array_equal(g_inl, want["inliers"]) and \
+                (want["best_id"] == 0xFFFFFFFF or h_pose[f].tobytes() == want["pose"].tobytes())
+            checked += 1
+            if not ok:
+                bad += 1
+                detail.append(f"frame {f}: pairs {int(h_np[f])} vs {len(wpairs)}, id {int(h_id[f])} vs {want['best_id']}, inliers {int(h_ninl[f])} vs {len(want['inliers'])}")
+    cpu_s = time.perf_counter() - t0
+    nq_mean = float(counts.mean())
+    dist = float(sum(int(counts[j]) * int(counts[view_blocks[j]].sum()) for j in range(NF)))
+    out = {"workload": f"configs[1] batch ({NF} frames of 1920x1080 per step) -> extract -> hash_bag (4096 codewords) -> knn(., 3) of every "
+                       f"feature against each of {V} recent views ({NF * V} problems of ~{int(nq_mean)}^2) -> best-of-views (better_by 24) -> "
+                       f"(feature, landmark) pair lists -> Lambda Twist ARRSAC per frame ({n_hyp} hypotheses, candidates 1024 halving, 256 "
+                       f"estimations per block, threshold {thr:g}, seeded shuffle); landmarks = 4-px world-canvas cells per level (synthetic "
+                       f"control plane, torch on the device)",
+           "registered_frames_per_s": round(NF / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.register_steps,
+           "knn_distances_per_s": round(dist / dt, 1),
+           "mean_features_per_frame": round(nq_mean, 1), "mean_unique_matches_per_frame": round(float((h_dec == 1).sum()) / NF, 1),
+           "mean_world_matches_per_frame": round(float(h_np.mean()), 1), "mean_inliers_per_frame": round(float(h_ninl.mean()), 1),
+           "frames_with_a_model": int(have.sum()),
+           "frames_whose_pose_is_the_rendered_motion": int(pose_ok.sum()),
+           "pose_error": {"rotation_max_abs": round(float(rot_err[have].max()) if have.any() else -1.0, 6),
+                          "translation_max_abs": round(float(t_err[have].max()) if have.any() else -1.0, 6),
+                          "bounds": "rotation entries within 0.03 of the identity, translation within 0.15 of the rendered camera position "
+                                    "(cell centres stand in for triangulated landmarks: +-2 px at f = 1000 on a plane 5 units away)"},
+           "parity": {"frames_checked": checked, "mismatches": bad, "detail": detail[:4], "cpu_s_per_frame": round(cpu_s / max(1, checked), 2),
+                      "what": "knn(., 3) of 200 features against one view, best-of-views + decisions of all features, the (feature, "
+                              "landmark) pair list, and the consensus (winner id, pose bits, inlier list) of sampled frames vs "
+                              "oracle/match_oracle.c + oracle/arrsac_oracle.c (orc_p3p_arrsac_pairs) on the GPU's own intermediate data"}}
+    if pose_ok.sum() < 0.9 * NF:
+        out["parity"]["mismatches"] += 1
+        out["parity"]["detail"].append(f"only {int(pose_ok.sum())} of {NF} poses are the rendered motion")
+    reg.close()
     return out
 
 

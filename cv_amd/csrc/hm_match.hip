@@ -1065,6 +1065,122 @@ extern "C" int32_t hm_best_of_views_batch_device(hm_ctx* c, const void* d_knn, c
     });
 }
 
+// ---- from the landmark decisions to the consensus' input (cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604) ----
+// register_frame_subset, between the best-of-views decision and single_view_consensus.model_inliers: a feature whose best
+// landmark is uniquely good (decision 1) becomes the match (landmark, feature) (:1516-1520); matches whose landmark was
+// claimed by two features of the frame are dropped, both of them (:1549-1563: "always 100 % incorrect"); what is left
+// becomes FeatureWorldMatch(bearing(feature), triangulated landmark) unless the landmark has no robust triangulation
+// (:1583-1604, filter_map).  Here: one workgroup per frame; the frame's decision-1 features are sorted by landmark key
+// (stable LSD radix sort of feature ids in LDS), a landmark that occupies more than one sorted position invalidates its
+// features, and the survivors go out in ascending feature order as {feature, landmark} — exactly the pair-list form
+// rs_p3p_arrsac_batch_device takes (the landmark key indexes the caller's table of world points; an entry with w < 0,
+// impossible for a Projective point, says "no robust triangulation").  The merge candidates (decision 2) need the
+// landmark graph (are_landmarks_sharing_view) and the reference's stable sort by observation count only fixes the order
+// the consensus sees, which the seeded shuffle replaces: both stay with the caller.
+__global__ __launch_bounds__(1024) void k_landmark_pairs(const uint2* __restrict__ best, const uint32_t* __restrict__ decision,
+                                                         const uint32_t* __restrict__ nq, const uint32_t* __restrict__ iq,
+                                                         uint32_t cap, const double* __restrict__ world, uint32_t n_world,
+                                                         uint2* __restrict__ pairs, uint32_t* __restrict__ npairs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* rk = reinterpret_cast<uint32_t*>(smem);          // [cap] landmark of feature j (0xFFFFFFFF: not a candidate)
+    uint32_t* ia = rk + kRadixSortMax;
+    uint32_t* ib = ia + kRadixSortMax;
+    uint32_t* wh = ib + kRadixSortMax;
+    __shared__ uint32_t tot[256];
+    __shared__ uint32_t s_wave[16], s_base;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t n = nq[iq[f]];
+    n = n < cap ? n : cap;
+    const uint2* bf = best + (size_t)f * cap * 3;
+    const uint32_t* df = decision + (size_t)f * cap;
+    // 1. the candidates, in feature order
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < n; j0 += 1024) {
+        const uint32_t j = j0 + tid;
+        const bool on = j < n && df[j] == 1u;
+        if (j < n) rk[j] = on ? bf[(size_t)j * 3].x : 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (uint32_t q = 0; q < wv; ++q) off += s_wave[q];
+        if (on) ia[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int q = 0; q < 16; ++q) t += s_wave[q];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    const uint32_t nsel = s_base;
+    __syncthreads();
+    // 2. feature ids sorted by landmark key; 3. a key that fills more than one position invalidates its features
+    const uint32_t* sorted = lds_radix_sort_ids(rk, ia, ib, wh, tot, nsel, 4);
+    uint32_t* flag = sorted == ia ? ib : ia;
+    for (uint32_t p = tid; p < nsel; p += 1024) {
+        const uint32_t kk = rk[sorted[p]];
+        flag[p] = ((p > 0 && rk[sorted[p - 1]] == kk) || (p + 1 < nsel && rk[sorted[p + 1]] == kk)) ? 1u : 0u;
+    }
+    __syncthreads();
+    // (a second pass, so that no rk[] is overwritten while a neighbour still compares it)
+    for (uint32_t p = tid; p < nsel; p += 1024)
+        if (flag[p]) rk[sorted[p]] = 0xFFFFFFFFu;
+    __syncthreads();
+    // 4. the survivors in feature order, with a robust world point
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    uint2* out = pairs + (size_t)f * cap;
+    for (uint32_t j0 = 0; j0 < n; j0 += 1024) {
+        const uint32_t j = j0 + tid;
+        uint32_t lm = 0xFFFFFFFFu;
+        if (j < n) lm = rk[j];
+        bool on = lm != 0xFFFFFFFFu && lm < n_world;
+        if (on) on = world[(size_t)4 * lm + 3] >= 0.0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (uint32_t q = 0; q < wv; ++q) off += s_wave[q];
+        if (on) out[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(j, lm);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int q = 0; q < 16; ++q) t += s_wave[q];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) npairs[f] = s_base;
+}
+
+extern "C" int32_t hm_landmark_pairs_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
+                                                  uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
+                                                  void* d_pairs, void* d_npairs, void* stream_to_wait)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !d_best || !d_decision || !d_nq || !iq || !d_world || !d_pairs || !d_npairs) return AKZ_E_INVALID;
+        if (cap_per_img == 0 || n_world == 0 || n_frames > 65535u) return AKZ_E_INVALID;
+        if (cap_per_img > kRadixSortMax) return AKZ_E_TOO_LARGE;          // a frame's candidates are sorted in LDS
+        if (n_frames == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        if (stream_to_wait) {
+            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+        }
+        AKZ_TRY(hm_ensure_probs(c, sizeof(uint32_t) * n_frames + 64));
+        AKZ_TRY(hm_push_probs(c, 0, iq, sizeof(uint32_t) * n_frames));
+        AKZ_HIP(hipFuncSetAttribute((const void*)k_landmark_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
+        hipLaunchKernelGGL(k_landmark_pairs, dim3(n_frames), dim3(1024), kRadixSortLdsBytes, c->stream, (const uint2*)d_best,
+                           (const uint32_t*)d_decision, (const uint32_t*)d_nq, (const uint32_t*)c->d_probs, cap_per_img,
+                           (const double*)d_world, n_world, (uint2*)d_pairs, (uint32_t*)d_npairs);
+        AKZ_LAUNCH_CHECK();
+        return AKZ_OK;
+    });
+}
+
 // Timing of the k-NN kernel launches (HIP events on hm_stream()): enable, run, then read the accumulated
 // milliseconds and launch count.  hm_timing_get synchronises the pending events.
 extern "C" int32_t hm_timing_enable(hm_ctx* c, int32_t on)

@@ -57,28 +57,30 @@ __host__ __device__ __forceinline__ void rs_calibrate_one(const double* intr /* 
 
 // `WorldToCamera::residual(pose, match) < thresh` (cv-core/src/pose.rs:194-201) — the boolean only.  The exact statement
 // (akz_w2c_residual) spends most of its instructions on three f64 divisions and a square root; almost every (pose, match)
-// pair is far from the threshold, so the test is first made on  1 - (a . q) rsqrt(q . q)  (reciprocal square root by the
-// hardware estimate + two Newton steps: relative error < 1e-12 whatever the estimate's accuracy above 2^-10) and the exact
-// statement decides only inside a band 1000 times wider than that error around the threshold, or when q . q is not an
-// ordinary number.  The result is the exact statement's for every input.
+// pair is far from the threshold, so the test is first made without either:
+//     1 - (a . q) / |q| < thresh   <=>   a . q > 0  and  (a . q)^2 > (1 - thresh)^2 (q . q)        (0 < thresh < 1/2)
+// on q = [R | t] w evaluated with fused multiply-adds — 24 instructions instead of the 55 of a reciprocal square root with
+// two Newton steps (round 3), which was the registration consensus' whole cost (k_rsb_score_p3p: 58 % of a pipeline+register
+// step).  The pre-test's value differs from the exact statement's by parts in 1e15; it decides only outside a band of
+// +-2e-9 around the threshold (the two constants below), the exact statement inside it, and whenever q . q is not an
+// ordinary number or the threshold is outside (0, 1/2).  The result is the exact statement's for every input
+// (tests/test_gpu_parity.py::test_p3p_inlier_test_is_exact_at_the_threshold).
 __device__ __forceinline__ bool rs_w2c_inlier(const double* __restrict__ pose, const double* __restrict__ a,
                                               const double* __restrict__ w, double thresh)
 {
     double q[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) q[r] = ((pose[r * 4 + 0] * w[0] + pose[r * 4 + 1] * w[1]) + pose[r * 4 + 2] * w[2]) + pose[r * 4 + 3] * w[3];
-    const double sgn = __builtin_signbit(w[3]) ? -1.0 : 1.0;
-    const double s2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    const double c = sgn * ((a[0] * q[0] + a[1] * q[1]) + a[2] * q[2]);
-    if (s2 > 1e-200 && s2 < 1e200 && fabs(c) < 1e200) {
-        double y = __builtin_amdgcn_rsq(s2);
-        y = y * (1.5 - (0.5 * s2) * (y * y));
-        y = y * (1.5 - (0.5 * s2) * (y * y));
-        const double cy = c * y;
-        const double r = 1.0 - cy;
-        const double band = 1e-9 * (1.0 + fabs(cy));
-        if (r < thresh - band) return true;
-        if (r > thresh + band) return false;
+    for (int r = 0; r < 3; ++r)
+        q[r] = __builtin_fma(pose[r * 4 + 3], w[3], __builtin_fma(pose[r * 4 + 2], w[2], __builtin_fma(pose[r * 4 + 1], w[1], pose[r * 4 + 0] * w[0])));
+    const double s2 = __builtin_fma(q[2], q[2], __builtin_fma(q[1], q[1], q[0] * q[0]));
+    double c = __builtin_fma(a[2], q[2], __builtin_fma(a[1], q[1], a[0] * q[0]));
+    if (__builtin_signbit(w[3])) c = -c;
+    const double u = 1.0 - thresh, u2 = u * u;                       // (loop-invariant in every caller)
+    const double k_in = u2 * (1.0 + 4e-9), k_out = u2 * (1.0 - 4e-9);
+    if (thresh > 0.0 && thresh < 0.5 && s2 > 1e-280 && s2 < 1e280) {
+        const double c2 = c * c;
+        if (c > 0.0 && c2 > k_in * s2) return true;
+        if (c <= 0.0 || c2 < k_out * s2) return false;               // (a NaN fails every comparison: the exact statement decides)
     }
     return akz_w2c_residual(pose, a, w) < thresh;
 }

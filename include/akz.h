@@ -292,6 +292,18 @@ int32_t hm_best_of_views_batch_device(hm_ctx* ctx, const void* d_knn, const void
                                       const uint32_t* view_idx, uint32_t n_frames, uint32_t n_views, uint32_t k,
                                       const void* d_landmarks, const void* d_nviews, uint32_t better_by, void* d_best,
                                       void* d_decision, void* stream_to_wait);
+/* What follows the decision in register_frame_subset (cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604), for every frame of
+ * a micro-batch: a feature with decision 1 becomes the match (best[0].landmark, feature); matches whose landmark was claimed
+ * by more than one feature of the frame are dropped, all of them (:1549-1563); a match whose landmark has no robust
+ * triangulation is dropped (:1583-1604, filter_map) — d_world [n_world][4] f64 is the caller's table of homogeneous world
+ * points indexed by landmark key, an entry with w < 0 (impossible for a Projective point) or a key >= n_world says "none".
+ * d_best / d_decision / d_nq / iq as hm_best_of_views_batch_device wrote / took them; d_pairs [n_frames][cap][2] u32
+ * {feature, landmark} in ascending feature order, d_npairs [n_frames] — the pair lists rs_p3p_arrsac_batch_device takes.
+ * cap_per_img <= 8192.  (The merge candidates, decision 2, need the landmark graph and stay with the caller; so does the
+ * reference's stable sort by observation count, which only fixes the order the consensus sees.) */
+int32_t hm_landmark_pairs_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
+                                       uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
+                                       void* d_pairs, void* d_npairs, void* stream_to_wait);
 /* matching()/symmetric_matching() of tutorial ch5 main.rs:154-200 and cv-sfm/src/lib.rs:3097-3133,
  * and match_descriptors() of akaze/tests/estimate_pose.rs:78-97.
  *   rule 0: accept iff d0 + param_u <  d1   (tutorial, param_u = 24)

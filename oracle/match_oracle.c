@@ -185,3 +185,27 @@ void orc_best_of_views(const akz_neighbor* knn, uint32_t nq, uint32_t cap, uint3
         decision[i] = dec;
     }
 }
+
+/* The FeatureWorldMatch list of one frame, cv-sfm/src/lib.rs:1516-1520 (decision 1 -> (best[0].landmark, feature)),
+ * :1549-1563 (a landmark matched by two features of the frame takes all its matches with it) and :1583-1604 (no robust
+ * triangulation -> dropped; here: landmark key >= n_world or a world point with w < 0).  best [nq][3][2] {landmark, distance},
+ * decision [nq]; pairs [..][2] {feature, landmark} in ascending feature order; returns their number. */
+uint32_t orc_landmark_pairs(const uint32_t* best, const uint32_t* decision, uint32_t nq, const double* world, uint32_t n_world,
+                            uint32_t* pairs)
+{
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (decision[i] != 1u) continue;
+        const uint32_t lm = best[(size_t)i * 6];
+        if (lm == 0xFFFFFFFFu) continue;
+        uint32_t claims = 0;
+        for (uint32_t j = 0; j < nq; ++j)
+            if (decision[j] == 1u && best[(size_t)j * 6] == lm) claims++;
+        if (claims != 1) continue;
+        if (lm >= n_world || !(world[(size_t)4 * lm + 3] >= 0.0)) continue;
+        pairs[2 * n] = i;
+        pairs[2 * n + 1] = lm;
+        n++;
+    }
+    return n;
+}

@@ -477,6 +477,20 @@ def best_of_views(knn_out, nq, landmarks, view_idx, nviews, better_by=24):
     return best, dec
 
 
+def landmark_pairs(best, decision, world):
+    """cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604 (oracle/match_oracle.c: orc_landmark_pairs): the (feature, landmark)
+    pair list of one frame from the best-of-views output; world [n_world, 4] f64 (w < 0: no robust triangulation)."""
+    best = np.ascontiguousarray(best, np.uint32).reshape(-1, 3, 2)
+    dec = np.ascontiguousarray(decision, np.uint32)
+    W = np.ascontiguousarray(world, np.float64).reshape(-1, 4)
+    out = np.zeros((max(len(dec), 1), 2), np.uint32)
+    L = lib()
+    L.orc_landmark_pairs.restype = C.c_uint32
+    L.orc_landmark_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    n = L.orc_landmark_pairs(best.ctypes.data, dec.ctypes.data, len(dec), W.ctypes.data, len(W), out.ctypes.data)
+    return out[:n].copy()
+
+
 class ArrsacParams(C.Structure):
     """rs_arrsac_params (include/akz.h), restated here so that tests/ can drive the oracle without the product's
     Python package."""

@@ -172,15 +172,23 @@ def test_lambda_twist_on_the_reference_degenerate_scene(gpu):
     assert got is not None                                     # the reference's assertion: a model comes out
     pose, inl, best = got
     P, ok = cons.poses(len(samples))
+    # The scene repeats two bearings for different points, so most triples contradict themselves and have no exact pose:
+    # Lambda Twist then returns what its algebra gives (the reference does not validate either; the consensus weeds it
+    # out).  What can be held: every returned pose is a rigid motion, and where the independent solver finds an exact
+    # solution of a triple the device has it too.
     checked = 0
     for h, tri in enumerate(samples):
         for p in range(4):
-            if not ok[h, p]:
+            if ok[h, p]:
+                R = P[h, p, :, :3]
+                assert abs(np.linalg.det(R) - 1.0) < 1e-8 and np.abs(R @ R.T - np.eye(3)).max() < 1e-8, (h, p)
+        if len({tuple(fb[i]) for i in tri}) < 3:
+            continue
+        for Ri, ti in p3p_conics(fb[tri], pts[tri]):
+            if _w2c_residual(Ri, ti, fb[tri], world[tri]).max() > 1e-12:
                 continue
-            R, t = P[h, p, :, :3], P[h, p, :, 3]
-            assert abs(np.linalg.det(R) - 1.0) < 1e-8
-            res = _w2c_residual(R, t, fb[tri], world[tri])
-            assert res.max() < 1e-9, (h, p, res)              # identical bearings for distinct points: still exact on its sample
+            dev = [(P[h, p, :, :3], P[h, p, :, 3]) for p in range(4) if ok[h, p]]
+            assert dev and min(_pose_gap(Ri, ti, Rd, td) for Rd, td in dev) < 1e-6, (h, tri)
             checked += 1
     assert checked > 0
     res = _w2c_residual(pose[:, :3], pose[:, 3], fb, world)
@@ -247,7 +255,12 @@ def test_eight_point_poses_and_inlier_sets_against_lapack(gpu):
     sa, sb = a[samples], b[samples]                                      # [H,8,3]
     A = np.einsum("hni,hnj->hnij", sa / sa[:, :, 2:3], sb / sa[:, :, 2:3]).reshape(H, 8, 9)   # kron(a / a.z, b / a.z): eight-point/src/lib.rs:11-24
     U, S, Vt = np.linalg.svd(A)
-    E_ref = Vt[:, -1, :].reshape(H, 3, 3).transpose(0, 2, 1)            # Matrix3::from_iterator is column-major
+    E_raw = Vt[:, -1, :].reshape(H, 3, 3).transpose(0, 2, 1)            # Matrix3::from_iterator is column-major
+    # possible_unscaled_poses reads only U and V of E's SVD (cv-pinhole/src/essential.rs:114-231): the poses describe the
+    # essential matrix U diag(1, 1, 0) V^T nearest to the (noisy) null vector, not the null vector itself
+    Ue, Se, Vte = np.linalg.svd(E_raw)
+    E_ref = Ue @ np.diag([1.0, 1.0, 0.0]) @ Vte
+    E_ref = E_ref / np.linalg.norm(E_ref.reshape(H, 9), axis=1)[:, None, None]
     tv = P[:, :, :, 3]
     Rm = P[:, :, :, :3]
     tx = np.zeros((H, 4, 3, 3))
@@ -258,7 +271,7 @@ def test_eight_point_poses_and_inlier_sets_against_lapack(gpu):
     E = E / np.linalg.norm(E.reshape(H, 4, 9), axis=2)[..., None, None]
     align = np.abs((E * E_ref[:, None]).sum((2, 3)))
     # (an 8 x 9 system whose two smallest singular values are close has no well-defined null vector: compare where it has)
-    well = S[:, 7] > 1e-6 * S[:, 0]
+    well = (S[:, 7] > 1e-6 * S[:, 0]) & (Se[:, 1] > 1e-3 * Se[:, 0])     # ... and E has a well-defined rank-2 part
     assert well.sum() > 0.9 * H
     assert np.abs(align[well] - 1.0).max() < 1e-8, np.abs(align[well] - 1.0).max()
     # R2: four proper poses: R in SO(3), |t| = 1, (t, R1), (t, R2), (-t, R1), (-t, R2)
