@@ -44,6 +44,7 @@ FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PROFILE_TAG = "r03"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
+PROFILE_TAG_RANSAC = "r04"   # profiles/<tag>_pmc_ransac.json (tools/pmc_ransac.sh)
 FED_BYTES_PER_PIXEL_STEP = 12.0
 CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage
 FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
@@ -431,20 +432,38 @@ def main():
         elapsed = max(per_rank)
     ctx.timing_enable(False)
 
-    # Isolated pass: the same scale-space launches with nothing else on the GPU (in the timed region above they
-    # share the chip with the keypoint and matcher streams of neighbouring micro-batches).
-    fam_iso, iso_fps = None, None
+    # Isolated pass: the library's launches with nothing else on the GPU (in the timed region above three streams share the
+    # chip).  One whole extraction per repetition — scale space, then the keypoint stage of the same call — with a device
+    # synchronisation in between, into the output set the parity checks do NOT read; then the matcher alone on that set.
+    fam_iso, iso_fps, iso_match = None, None, None
+    ISO_REPS = 3
     if rank == 0 and not args.no_isolated and not args.pmc_run:
         torch.cuda.synchronize()
+        spare = 1 - last
         ctx.timing_enable(1)
         ctx.timing_reset()
-        for _ in range(3):
-            _lib.check(L.akz_scale_space_device(ctx.handle, frames[:MB].data_ptr(), 0, MB, W, H, None), "scale_space")
-            _lib.check(L.akz_sync(ctx.handle), "akz_sync")
+        for _ in range(ISO_REPS):
+            for m0 in range(0, NF, MB):
+                _lib.check(L.akz_extract_batch_device(ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps2[spare][m0:m0 + MB].data_ptr(),
+                                                      descs2[spare][m0:m0 + MB].data_ptr(), CAP, counts2[spare][m0:m0 + MB].data_ptr(), None), "extract")
+                _lib.check(L.akz_sync(ctx.handle), "akz_sync")
         fam_iso = read_families(ctx)
         s_ms, _, _ = ctx.timing_get(1)
         ctx.timing_enable(False)
-        iso_fps = 3 * MB / (s_ms * 1e-3) if s_ms > 0 else None
+        iso_fps = ISO_REPS * NF / (s_ms * 1e-3) if s_ms > 0 else None
+        if K == 1 and not sharded:
+            js_all = list(range(NF))
+            _lib.check(L.hm_timing_get(matcher.handle, None, None, 1), "hm_timing_get")
+            _lib.check(L.hm_timing_enable(matcher.handle, 1), "hm_timing_enable")
+            for _ in range(ISO_REPS):
+                _lib.check(L.hm_match_batch_device(matcher.handle, descs2[spare].data_ptr(), counts2[spare].data_ptr(), descs2[spare].data_ptr(),
+                                                   counts2[spare].data_ptr(), CAP, idx(js_all), idx([(j - 1) % NF for j in js_all]), NF, RULE_STRICT,
+                                                   24, 0.0, 1, pairs2[spare].data_ptr(), npairs2[spare].data_ptr(), None), "match")
+                _lib.check(L.hm_sync(matcher.handle), "hm_sync")
+            im, il_ = C.c_double(), C.c_uint64()
+            _lib.check(L.hm_timing_get(matcher.handle, C.byref(im), C.byref(il_), 1), "hm_timing_get")
+            _lib.check(L.hm_timing_enable(matcher.handle, 0), "hm_timing_enable")
+            iso_match = (im.value, int(il_.value))
     if world > 1:
         dist.barrier()
 
@@ -493,7 +512,34 @@ def main():
     if rank == 0:
         total_frames = NF * world * args.steps
         fps = total_frames / elapsed
-        tops = roofline_entries(fam_pipe, fam_iso, MB, args.steps)
+        gather = None
+        try:
+            gs = sorted({0, NF // 3, NF // 2, NF - 1})
+            hk = [kps[j].cpu().numpy().view(_lib.KP_DTYPE).reshape(-1) for j in gs]
+            gather = gather_model(ctx, hk, [int(counts[j].item()) for j in gs])
+        except Exception as e:                 # the model is reporting only: never fail the run for it
+            print(f"bench.py: gather model skipped ({e})", file=sys.stderr)
+        tops = roofline_entries(fam_pipe, fam_iso, MB, args.steps, gather, ISO_REPS)
+        if knn_ms.value > 0:
+            # the matcher as a family of its own: 2 directions x nq x nt x 512-bit contractions per frame pair as MACs (2 ops each)
+            ops_pair = 2.0 * 2.0 * (n_kp ** 2) * 512.0
+            tops_m = ops_pair * NF * args.steps / (knn_ms.value * 1e-3) / 1e12
+            em = {"bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands: exact 2-NN of every descriptor, both directions)",
+                  "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4),
+                  "frac_is": "2 x 512 MACs per (query, target) pair / kernel time / the 10 PF dense FP4 MFMA peak",
+                  "traffic": None, "launches": int(knn_launches.value), "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
+                  "gpu_ms": round(knn_ms.value, 2), "gpu_ms_per_step": round(knn_ms.value / args.steps, 3),
+                  "timed": "the k-NN launches' own start/stop events over the timed steps; the matcher's stream has the lowest priority, so "
+                           "inside the pipeline its kernels are the ones time-sliced (3-4x their isolated duration)"}
+            em["rank_ms_per_step"] = em["gpu_ms_per_step"]
+            if iso_match and iso_match[0] > 0:
+                it_ = ops_pair * NF * ISO_REPS / (iso_match[0] * 1e-3) / 1e12
+                em["isolated"] = {"achieved": round(it_, 1), "frac": round(it_ / MFMA_FP4_PEAK_TOPS, 4),
+                                  "avg_launch_us": round(iso_match[0] * 1e3 / max(1, iso_match[1]), 2),
+                                  "gpu_ms_per_step": round(iso_match[0] / ISO_REPS, 3)}
+                em["rank_ms_per_step"] = em["isolated"]["gpu_ms_per_step"]
+            tops.append(em)
+        tops.sort(key=lambda e: -e["rank_ms_per_step"])
         traffic = pipeline_traffic(MB, NF)
         out = {
             "metric": "frames/sec AKAZE detect+describe+BF-Hamming-match, 1080p",
@@ -507,7 +553,11 @@ def main():
                        "mean_matches_per_pair": round(n_match, 1),
                        "library_options": okw or "defaults"},
             "roofline": tops[0] if tops else None,
-            "roofline_top": tops[:4],
+            "roofline_top": tops[:5],
+            "roofline_rule": "roofline = the kernel family with the largest time per step when the GPU is its alone (isolated pass: "
+                             "rank_ms_per_step); roofline_top = the five largest, the matcher among them.  frac is always the family's own "
+                             "roofline fraction inside the timed pipeline (bytes / 8 TB/s, or MFMA ops / 10 PF for the matcher), "
+                             "isolated.frac the same with nothing else running; valu_frac (VALU issue) and bound beside it",
         }
         if INSTR_STEPS:
             out["phase_ms_per_step"] = {"fed": round(fed_ms / INSTR_STEPS, 2), "scale_space": round(ss_ms / INSTR_STEPS, 2),
@@ -520,7 +570,8 @@ def main():
             out["scale_space_isolated"] = {
                 "frames_per_s": round(iso_fps, 1),
                 "algorithmic_gbs": round(iso_fps * CONTRACT_BYTES_PER_FRAME / 1e9, 1),
-                "note": "configs[1] 'scale-space kernels only' (A1-A11, nothing else on the GPU); algorithmic_gbs = "
+                "note": "configs[1] 'scale-space kernels only' (A1-A11: the scale-space phase of whole extractions run one at a time, "
+                        "nothing else on the GPU); algorithmic_gbs = "
                         "frames/s x SURVEY 8d's 1.0535 GB contract figure, which counts every pyramid buffer once per "
                         "consuming stage: fused kernels and temporal blocking move less, so it is NOT a roofline "
                         "fraction (see roofline / roofline_top for those)"}
@@ -543,7 +594,9 @@ def main():
                 "per_rank_frames_per_s": [round(NF * args.steps / t_, 1) for t_ in per_rank],
                 "recent_views": K, "exchange": "all-gather of fixed-capacity descriptor blocks" if use_allgather else "ring shift",
                 "comm": "akz_comm_* (libakz -> librccl.so.1)" if comm_kind == "akz" else f"torch.distributed ({args.backend})",
-                "block_bytes_per_rank_per_step": NF * (CAP * 64 + 4)}
+                "block_bytes_per_rank_per_step": NF * (CAP * 64 + 4),
+                # did RCCL see N ranks?  akz_comm_world() of the library's own communicator (None on the torch.distributed route)
+                "rccl_ranks_seen": exchange.ranks_seen() if hasattr(exchange, "ranks_seen") else None}
             if comm_note:
                 out["multi_gpu"]["comm_note"] = comm_note
             if exch:
@@ -582,6 +635,7 @@ def main():
             if args.verify_steps > 0:
                 out["configs_extra"]["pipeline+verify"] = extra_pipeline_verify(
                     torch, dev, L, _lib, args, step, step_no, barrier, verify, match_done, hm_stream, kps2, pairs2, npairs2, NF, MB)
+            out["configs_extra"]["criterion"] = extra_criterion(_lib)
             if args.register_steps > 0 and K == 1 and not sharded:
                 out["configs_extra"]["pipeline+register"] = extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB)
             for v in out["configs_extra"].values():
@@ -620,31 +674,97 @@ VALU_ISSUE_PEAK_T = 39.3     # T wave-lane instructions / s: 256 CUs x 4 SIMDs x
                              # lane and cycle; = the 78.6 T lane-op/s non-FMA packed-f32 peak of MI355X_MICROARCH.md / 2)
 
 
-def roofline_entries(fam_pipe, fam_iso, mb, steps):
-    """Roofline objects of the timed kernel families, most expensive (inside the timed region) first.  Per family:
-    hbm_frac = algorithmic bytes / kernel time / 8 TB/s; valu_frac = VALU instructions x 64 lanes / kernel time / the VALU
-    issue peak (counters: profiles/, taken at this micro-batch); `bound` names the larger one and `frac` is its value."""
+def gather_model(ctx, kps_frames, counts):
+    """What k_orient_describe MUST fetch, from the kernel's own sampling geometry on the GPU's own keypoints: the orientation
+    stage reads {Lx, Ly} (8 B) at the 109 lattice points (x + i s, y + j s), i^2 + j^2 < 36 (scale_space_extrema.rs:230-260),
+    the descriptor Lt (4 B) and {Lx, Ly} at the 21 x 21 rotated lattice (descriptors.rs:102-177); every sample pulls the
+    32-byte sector it lies in.  Per keypoint the DISTINCT sectors of the {Lx, Ly} plane and of the Lt plane are counted (a
+    keypoint's samples are gathered once into LDS, so re-use inside a keypoint is the kernel's to have; re-use between
+    keypoints is the cache's).  Returns bytes per FRAME at three granularities: 32-byte sectors per keypoint (the algorithmic
+    numerator), the 128-byte lines per keypoint (the memory side fetches whole lines: profiles/r04_fetch_calibration.txt)
+    and the distinct sectors of the whole frame (the floor a perfect cache would reach)."""
+    nl = ctx.num_levels(W, H)
+    lw = np.array([ctx.level(W, H, i).width for i in range(nl)], np.int64)
+    loct = np.array([ctx.level(W, H, i).octave for i in range(nl)], np.int64)
+    ii, jj = np.meshgrid(np.arange(-6, 7), np.arange(-6, 7))
+    m = (ii * ii + jj * jj) < 36
+    oi, oj = ii[m].astype(np.float32), jj[m].astype(np.float32)
+    kk, ll = np.meshgrid(np.arange(-10, 11), np.arange(-10, 11), indexing="ij")
+    kk, ll = kk.reshape(-1).astype(np.float32), ll.reshape(-1).astype(np.float32)
+    s32 = l128 = fr32 = 0.0
+    nkp = 0
+
+    def distinct(a):
+        a = np.sort(a, axis=1)
+        return 1 + (np.diff(a, axis=1) != 0).sum(1)
+    for f, kp in enumerate(kps_frames):
+        kp = kp[:int(counts[f])]
+        if len(kp) == 0:
+            continue
+        cls = kp["class_id"].astype(np.int64)
+        ratio = (1 << loct[cls]).astype(np.float32)
+        sc = np.round(np.float32(0.5) * kp["size"] / ratio)
+        xf, yf = kp["x"] / ratio, kp["y"] / ratio
+        w = lw[cls][:, None]
+        ox = np.round(xf[:, None] + oi[None, :] * sc[:, None]).astype(np.int64)
+        oy = np.round(yf[:, None] + oj[None, :] * sc[:, None]).astype(np.int64)
+        co, si = np.cos(kp["angle"]), np.sin(kp["angle"])
+        dx = np.round(xf[:, None] + (-ll[None, :] * si[:, None] * sc[:, None] + kk[None, :] * co[:, None] * sc[:, None])).astype(np.int64)
+        dy = np.round(yf[:, None] + (ll[None, :] * co[:, None] * sc[:, None] + kk[None, :] * si[:, None] * sc[:, None])).astype(np.int64)
+        pix_xy = np.concatenate([oy * w + ox, dy * w + dx], 1)          # {Lx, Ly} plane: orientation + descriptor samples
+        pix_lt = dy * w + dx                                            # Lt plane: descriptor samples
+        s32 += 32.0 * float(distinct(pix_xy // 4).sum() + distinct(pix_lt // 8).sum())
+        l128 += 128.0 * float(distinct(pix_xy // 16).sum() + distinct(pix_lt // 32).sum())
+        lvl = cls[:, None] * (1 << 40)
+        fr32 += 32.0 * float(len(np.unique((pix_xy // 4 + lvl).reshape(-1))) + len(np.unique((pix_lt // 8 + lvl).reshape(-1))))
+        nkp += len(kp)
+    nf = max(1, len(kps_frames))
+    return {"sector_bytes_per_frame": s32 / nf, "line_bytes_per_frame": l128 / nf, "frame_distinct_sector_bytes": fr32 / nf,
+            "keypoints_per_frame": nkp / nf, "frames_sampled": len(kps_frames),
+            "what": "32-byte sectors of the {Lx,Ly} (8 B/px) and Lt (4 B/px) planes touched by the 109 orientation samples and the "
+                    "21 x 21 descriptor lattice, distinct per keypoint, from this run's own keypoints; line_bytes = the same at the "
+                    "128-byte granularity the memory side fetches (profiles/r04_fetch_calibration.txt: every read request is 128 B); "
+                    "frame_distinct = distinct sectors of the whole frame (perfect re-use between keypoints)"}
+
+
+def roofline_entries(fam_pipe, fam_iso, mb, steps, gather=None, iso_steps=3):
+    """Roofline objects of the timed kernel families.  Per family: frac = hbm_frac = algorithmic bytes / kernel time / 8 TB/s
+    (always the BYTES fraction); valu_frac = VALU instructions x 64 lanes / kernel time / the VALU issue peak (counters:
+    profiles/, taken at this micro-batch); `bound` names whichever of the two is larger.  Ordered by a family's time per step
+    with the GPU to itself (isolated pass) — inside the pipeline three streams time-slice the chip and a kernel's duration
+    says how the chip was shared, not what the kernel costs."""
     iso = {f[0]: f for f in (fam_iso or [])}
     pmc = pmc_traffic(mb)
     sq = sq_counters()
     out = []
-    for name, ms, launches, units, bpu in sorted(fam_pipe, key=lambda f: -f[1]):
+    for name, ms, launches, units, bpu in fam_pipe:
         if ms <= 0:
             continue
         key = name.split(" ")[0]
-        if bpu is None:        # no byte model: the counted bytes of the committed pass are the numerator
-            if not (pmc and key in pmc["kernels"]):
+        model = None
+        if bpu is None:        # the gather kernel: units = frames, bytes from its sampling geometry (gather_model)
+            if not gather:
                 continue
-            bpu = pmc["kernels"][key]["hbm_bytes_per_launch"] * launches / max(1, units)
+            # compulsory bytes = every sector the frame's keypoints touch, once (what a perfect cache would fetch); the
+            # per-keypoint figures (what the L2 is asked for) go beside it as sector_frac / line_frac
+            bpu, model = gather["frame_distinct_sector_bytes"], gather
         gbs = units * bpu / (ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(launches),
-             "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2),
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_is": "algorithmic bytes / kernel time / 8 TB/s",
+             "traffic": None, "launches": int(launches),
+             "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2), "gpu_ms_per_step": round(ms / steps, 3),
              "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_unit": round(bpu, 3),
              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
              "timed": f"the launches' own start/stop events (hipExtLaunchKernel: the dispatch's begin -> end, rocprofv3's "
                       f"kernel duration) over the {steps} timed steps; the keypoint and matcher streams of neighbouring "
                       f"micro-batches share the GPU"}
+        if model:
+            e["byte_model"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in model.items()}
+            e["sector_demand_frac"] = round(units * model["sector_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            e["line_demand_frac"] = round(units * model["line_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            e["frac_is"] = ("distinct 32-byte sectors the frame's keypoints touch (each once) / kernel time / 8 TB/s; sector_demand_frac / "
+                            "line_demand_frac = the same with every keypoint's sectors / 128-byte lines counted on their own (what the "
+                            "caches are asked for, not what HBM must deliver: they can exceed 1)")
         if pmc and key in pmc["kernels"]:
             k = pmc["kernels"][key]
             e["traffic"] = round(k["hbm_bytes_per_launch"])
@@ -658,13 +778,17 @@ def roofline_entries(fam_pipe, fam_iso, mb, steps):
                                      "run's kernel time; the frame-pair kernels issue packed f32 (2 lane-ops per "
                                      "instruction), so this is also their fraction of the 78.6 T lane-op/s non-FMA peak"}
                 if e["valu_frac"] > e["hbm_frac"]:
-                    e["bound"] = "valu"
-                    e["frac"] = e["valu_frac"]
+                    e["bound"] = "valu"          # (frac stays the bytes fraction; valu_frac is beside it)
+        rank_ms = ms / steps
         if name in iso:
             _, ims, il, iu, _ = iso[name]
             igbs = iu * bpu / (ims * 1e-3) / 1e9
             e["isolated"] = {"achieved": round(igbs, 1), "frac": round(igbs / HBM_PEAK_GBS, 4),
-                             "avg_launch_us": round(ims * 1e3 / il, 2)}
+                             "avg_launch_us": round(ims * 1e3 / il, 2), "gpu_ms_per_step": round(ims / iso_steps, 3)}
+            if pmc and key in pmc["kernels"] and pmc["kernels"][key].get("valu_insts_per_launch"):
+                e["isolated"]["valu_frac"] = round(pmc["kernels"][key]["valu_insts_per_launch"] * 64.0 / (ims * 1e-3 / il) / 1e12 / VALU_ISSUE_PEAK_T, 4)
+            rank_ms = ims / iso_steps
+        e["rank_ms_per_step"] = round(rank_ms, 3)
         if name.startswith("k_front_fed"):
             # what the same work cost as two kernels (k_level_front2 16 B + k_fed_pair 12 B per pixel): the fused kernel's
             # time expressed against THOSE bytes, for comparison with round 1's front-end / FED fractions only
@@ -1128,13 +1252,7 @@ def extra_ransac(n_hyp):
                        "host buffers in and out",
            "hypotheses_per_s": round(n_hyp / dt, 1), "residuals_per_s": round(n_hyp * 4 * n / dt, 1),
            "ms_per_scene": round(dt * 1e3, 3), "inliers": int(len(inl)), "best_id": int(best),
-           "roofline": {"bound": "fp64-valu", "kernel": "k_rsb_score_first over all matches (CameraToCamera::residual < threshold per (pose, match): a "
-                                                        "lower bound first, the 4x4 Jacobi where it does not decide)",
-                        "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                        "exhaustive_equivalent_tflops": round(2400.0 * n_hyp * 4 * n / dt / 1e12, 2),
-                        "note": "exhaustive_equivalent = what evaluating ~2.4 kflop for EVERY pair at this rate would take; it "
-                                "exceeds what the chip can do because most pairs are decided by the ~100-flop bound (exact: "
-                                "the inlier sets are the oracle's); includes the host<->device copies"},
+           "roofline": ransac_roofline(n_hyp, n, dt),
            "arrsac": arr,
            "cpu_oracle": {"hypotheses_per_s": round(sub / cpu_s, 1), "cores": 1,
                           "sample": f"first {sub} hypotheses, {cpu_s:.1f} s"},
@@ -1143,6 +1261,97 @@ def extra_ransac(n_hyp):
                               "pose index and inlier set, vs oracle/ransac_oracle.c"}}
     cons.close()
     return out
+
+
+def extra_criterion(_lib):
+    """The reference's own benchmark harness (akaze/benches/criterion.rs:8-52 — the one workload anybody with cargo can
+    reproduce): `extract` = Akaze::sparse().extract_from_gray_float_image on res/0000000000.png (1241 x 376, the first KITTI
+    fixture), and horizontal_filter / vertical_filter of that image with gaussian_kernel(1.0, 7) and gaussian_kernel(10.0, 71).
+    GPU through the C ABI with HOST buffers in and out, as a criterion iteration has them (akz_extract_gray_f32,
+    akz_horizontal_filter / akz_vertical_filter); beside it the -O3 -march=native build of the oracle, one thread, on the same
+    arrays; outputs compared bit for bit."""
+    from cv_amd import akaze as A
+    from oracle import oracle as O
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kitti_pair.npz"))
+    img8 = z["frame0"]
+    img = O.u8_to_f32(img8)
+    h, w = img.shape
+    ak = A.Akaze.sparse()
+    ctx = ak.context(w, h, 1)
+    fast = O.fast_lib()
+    for fn in ("orc_horizontal_filter", "orc_vertical_filter"):
+        getattr(fast, fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+
+    def best_of(f, reps):
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = f()
+            t.append(time.perf_counter() - t0)
+        return r, float(np.median(t))
+    out = {"image": f"res/0000000000.png ({w} x {h}), tests/golden/kitti_pair.npz", "rows": {}, "mismatches": 0,
+           "how": "median wall time per call; GPU = the C ABI with host buffers in and out (one frame per call: launch latency, "
+                  "not throughput, is what is measured); CPU = oracle/ at -O3 -march=native, one thread; outputs bit-identical"}
+    ak.extract_from_gray_float_image(img)                       # context, tables
+    (gk, gd), g_s = best_of(lambda: ak.extract_arrays(img), 20)
+    cfg = O.default_config(threshold=0.01)
+    O.extract_match_many(img8[None], threads=1, match=False, cfg=cfg)
+    cres, c_s = best_of(lambda: O.extract_match_many(img8[None], threads=1, match=False, cfg=cfg), 3)
+    same = gk.tobytes() == cres[0][0].tobytes() and np.array_equal(gd, cres[0][1])
+    out["rows"]["extract"] = {"gpu_ms": round(g_s * 1e3, 3), "cpu_ms": round(c_s * 1e3, 2), "descriptors": int(len(gd)), "bit_identical": bool(same),
+                              "reference": "Akaze::sparse().extract_from_gray_float_image (criterion.rs:8-15); 399 descriptors (estimate_pose.rs:41)"}
+    out["mismatches"] += int(not same) + int(len(gd) != 399)
+    for kname, (r, n) in (("small_kernel", (1.0, 7)), ("large_kernel", (10.0, 71))):
+        k = O.gaussian_kernel(r, n)
+        for direction, gfn, cfn in (("horizontal", A.horizontal_filter, fast.orc_horizontal_filter),
+                                    ("vertical", A.vertical_filter, fast.orc_vertical_filter)):
+            gfn(img, k, ctx)
+            g, g_s = best_of(lambda: gfn(img, k, ctx), 20)
+            co = np.empty_like(img)
+            _, c_s = best_of(lambda: cfn(img.ctypes.data, w, h, k.ctypes.data, len(k), co.ctypes.data), 5)
+            same = g.tobytes() == co.tobytes()
+            out["rows"][f"{direction}_filter_{kname}"] = {"gpu_ms": round(g_s * 1e3, 3), "cpu_ms": round(c_s * 1e3, 3), "taps": n,
+                                                          "bit_identical": bool(same), "reference": f"criterion.rs: gaussian_kernel({r}, {n})"}
+            out["mismatches"] += int(not same)
+    out["parity"] = {"mismatches": out["mismatches"]}
+    return out
+
+
+def ransac_roofline(n_hyp, n, dt):
+    """configs[3] against the FP64 vector roofline (SURVEY 8d names it as the bound of R1-R4).  Every VALU instruction of
+    k_rsb_hypotheses / k_rsb_score_first is f64 arithmetic or its control overhead; SQ_INSTS_VALU per call comes from the
+    committed counter pass of exactly this workload (tools/pmc_ransac.sh -> profiles/<tag>_pmc_ransac.json), the time from
+    this run.  frac = wave-instructions x 64 lanes / time / the 39.3 T lane-instructions/s the chip can issue (one f64
+    instruction per lane and cycle = the 78.6 TFLOP/s FP64 vector peak counted at 2 flops per FMA; the reference's
+    arithmetic is unfused, so a lane-instruction is ONE flop here and flops_frac is half of frac)."""
+    note = ("exhaustive_equivalent = what evaluating ~2.4 kflop for EVERY pair at this rate would take; it exceeds what the chip "
+            "can do because most pairs are decided by the ~100-flop bound (exact: the inlier sets are the oracle's)")
+    base = {"bound": "fp64-valu", "kernel": "k_rsb_score_first + k_rsb_hypotheses (CameraToCamera::residual < threshold per (pose, match): a lower "
+                                            "bound first, the 4x4 Jacobi where it does not decide; 9x9 Jacobi + SVD per hypothesis)",
+            "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T f64 lane-instr/s", "frac": None, "traffic": None,
+            "exhaustive_equivalent_tflops": round(2400.0 * n_hyp * 4 * n / dt / 1e12, 2), "note": note}
+    try:
+        name = PROFILE_TAG_RANSAC + "_pmc_ransac.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        if "10 000" not in d["workload"] or n_hyp != 10000 or n != 1000:
+            return base                      # counters of another workload: nothing is rescaled
+        insts = float(d["valu_insts_per_call"])
+        whole = insts * 64.0 / dt / 1e12
+        base.update({"achieved": round(whole, 2), "frac": round(whole / VALU_ISSUE_PEAK_T, 4),
+                     "flops_frac": round(whole / FP64_VALU_PEAK_TFLOPS, 4),
+                     "frac_is": "SQ_INSTS_VALU of one call x 64 lanes / this run's wall time per call (host buffers in and out, launches "
+                                "included) / 39.3 T lane-instr/s; flops_frac = the same lane-instructions as flops (unfused: one each) / 78.6 TFLOP/s",
+                     "valu_insts_per_call": round(insts), "counters": "profiles/" + name, "kernels": {}})
+        for k, v in d["kernels"].items():
+            if v["kernel_us_per_call"] > 0 and v["valu_insts_per_call"] > 1e6:
+                r = v["valu_insts_per_call"] * 64.0 / (v["kernel_us_per_call"] * 1e-6) / 1e12
+                base["kernels"][k] = {"valu_insts_per_call": round(v["valu_insts_per_call"]), "kernel_us_per_call": round(v["kernel_us_per_call"], 1),
+                                      "frac": round(r / VALU_ISSUE_PEAK_T, 4), "waves_per_call": round(v["waves_per_call"]),
+                                      "timed": "rocprofv3 --kernel-trace of the committed pass (the kernel's own duration)"}
+    except Exception:
+        pass
+    return base
 
 
 def device_probe(torch, dev):

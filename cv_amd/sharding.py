@@ -180,6 +180,10 @@ class AkzExchange:
         self.stream = torch.cuda.ExternalStream(L.akz_comm_stream(self._h), device=torch.device("cuda", device))
         _lib.check(L.akz_comm_timing(self._h, 1, None, None, None, 1), "akz_comm_timing")
 
+    def ranks_seen(self):
+        """akz_comm_world(): the world size the library's communicator was created with — what RCCL saw."""
+        return int(self._lib.lib().akz_comm_world(self._h))
+
     def _after(self):
         self._torch.cuda.current_stream().wait_stream(self.stream)    # what follows on the caller's stream sees the rows
 
