@@ -44,6 +44,8 @@ struct AkzSet {
     uint32_t* d_lvl_slot = nullptr;        // [B][kAkzMaxLevels + 1] first cache slot pushed at every level (+ the total)
     uint32_t* d_sup = nullptr;             // [B][sup_cap * (2 * 24 + 6)] scratch of the parallel suppression (k_sup_*)
     uint32_t* d_sup_flag = nullptr;        // [B] 1 = this frame takes the serial k_suppress
+    uint32_t* d_big_flag = nullptr;        // [B] 1 = the serial pass's LDS list overflowed: the frame takes k_suppress_big
+    void* d_big_act = nullptr;             // [B][max_kp] 16-byte active-list entries of k_suppress_big (contexts with max_kp > 8192 only)
     DevKp* d_kp_a = nullptr;               // [B][max_kp]  stage-0 list (find_scale_space_extrema output)
     uint32_t* d_n_a = nullptr;
     DevKp* d_kp_b = nullptr;               // [B][max_kp]  stage-1 list (refined + orientation), pre-compaction slots
