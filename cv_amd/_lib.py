@@ -44,7 +44,7 @@ class Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32), ("fed_block", C.c_uint32),
         ("sup_capacity", C.c_uint32), ("max_candidates", C.c_uint32), ("desc_tile_shift", C.c_uint32),
-        ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("reserved", C.c_uint32 * 8),
+        ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("arith", C.c_uint32), ("reserved", C.c_uint32 * 7),
     ]
 
 
@@ -52,6 +52,7 @@ OPT_KEEP_ALL, OPT_NO_FRAME_PAIRS, OPT_SERIAL_SUPPRESSION, OPT_NO_PIPELINE = 1, 2
 OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED, OPT_EQUAL_PRIORITY = 16, 32, 64, 128, 256, 512, 1024
 HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY = 1, 2, 4
 FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
+ARITH_REDUCE_PAIRWISE, ARITH_FMA, ARITH_HALF_SEQUENTIAL = 1, 2, 4
 
 
 BOOL_OPTIONS = ("keep_all", "frame_pairs", "parallel_suppression", "pipeline", "stream_priority", "stream_kernels",
@@ -60,8 +61,9 @@ BOOL_OPTIONS = ("keep_all", "frame_pairs", "parallel_suppression", "pipeline", "
 
 def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=True,
                  contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0, stream_kernels=True,
-                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True):
-    """Options with readable names.  contrast: "fine" (default), "exact", "force_odd"."""
+                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True, arith=0):
+    """Options with readable names.  contrast: "fine" (default), "exact", "force_odd".  arith: AKZ_ARITH_* bits (1: pairwise
+    reduce_add, 2: fused mul_add, 4: sequential 2 x 2 sum) — the one option that changes results (include/akz.h)."""
     o = Options()
     o.struct_size = C.sizeof(Options)
     o.flags = ((OPT_KEEP_ALL if keep_all else 0) | (0 if frame_pairs else OPT_NO_FRAME_PAIRS)
@@ -71,6 +73,7 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
                | {"fine": 0, "exact": OPT_CONTRAST_EXACT, "force_odd": OPT_CONTRAST_FORCE_ODD}[contrast])
     o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift
     o.stream_waves, o.stream_min_waves = stream_waves, stream_min_waves
+    o.arith = arith
     return o
 
 

@@ -11,7 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libakz.so")
-SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_color.hip", "akz_comm.hip", "akz_plan.cpp"]
+SOURCES = ["akz_api.hip", "akz_scale_space.hip", "akz_arith.hip", "akz_keypoints.hip", "hm_match.hip", "rs_ransac.hip", "akz_color.hip",
+           "akz_comm.hip", "akz_plan.cpp"]
+# akz_scale_space.hip is compiled once per combination of the reference's three un-vendored arithmetic orders
+# (-DAKZ_ARITH=k, include/akz.h AKZ_ARITH_*); akz_arith.hip routes a context to its copy
+ARITH_VARIANTS = {"akz_scale_space.hip": range(8)}
 HEADERS = ["akz_common.h", "akz_ctx.h", "../../include/akz.h", "../../include/akz_portable_math.h", "../../include/akz_ransac_math.h", "../../include/akz_p3p_math.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -37,15 +41,35 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     objs = []
-    procs = []
+    jobs = []
     for s in SOURCES:
-        o = os.path.join(HERE, "lib", s.replace(".", "_") + ".o")
-        extra = os.environ.get("AKZ_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DKNN_ABLATE=1)
-        cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(o)
+        for k in ARITH_VARIANTS.get(s, [None]):
+            tag = "" if k is None else f"_a{k}"
+            o = os.path.join(HERE, "lib", s.replace(".", "_") + tag + ".o")
+            extra = os.environ.get("AKZ_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DKNN_ABLATE=1)
+            extra += [] if k is None else [f"-DAKZ_ARITH={k}"]
+            cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+            jobs.append((s + tag, cmd))
+            objs.append(o)
+    # (at most as many compilers at once as the host has cores: the eight copies of the largest file would otherwise all
+    # start together on a small box)
+    failed = False
+    limit = max(2, os.cpu_count() or 2)
+    for j0 in range(0, len(jobs), limit):
+        procs = []
+        for name, cmd in jobs[j0:j0 + limit]:
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        failed = _wait(procs, verbose) or failed
+    if failed:
+        raise RuntimeError("libakz build failed")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def _wait(procs, verbose):
     failed = False
     for s, p in procs:
         out, _ = p.communicate()
@@ -54,11 +78,7 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"hipcc failed on {s}\n")
-    if failed:
-        raise RuntimeError("libakz build failed")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
-    subprocess.check_call(cmd)
-    return LIB
+    return failed
 
 
 if __name__ == "__main__":

@@ -165,6 +165,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
                 if (r) return AKZ_E_INVALID;
             if (o.flags & ~((AKZ_OPT_EQUAL_PRIORITY << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
+            if (o.arith > 7u) return AKZ_E_INVALID;
             // sizes that would only surface as an opaque allocation failure (or wrap in an int) otherwise
             if (o.sup_capacity > (1u << 24) || o.max_candidates > kAkzMaxKeypoints || o.stream_waves > (1u << 24) ||
                 o.stream_min_waves > (1u << 24))
@@ -207,6 +208,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
         c->det_side_stream = !(o.flags & AKZ_OPT_SERIAL_DET);
         c->fuse_front_fed = !(o.flags & AKZ_OPT_SPLIT_FRONT_FED);
+        c->arith = (int)o.arith;
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
         if (o.stream_min_waves) c->stream_min_waves = (size_t)o.stream_min_waves;
         c->contrast_fine = !(o.flags & AKZ_OPT_CONTRAST_EXACT);
@@ -868,7 +870,7 @@ static int32_t filter_host(akz_ctx* c, const float* img, int w, int h, const flo
     if (st == AKZ_OK) {
         hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
         hipMemcpyAsync(d_k, kernel, ksize * 4, hipMemcpyHostToDevice, c->stream);
-        st = akz_dev_filter1d(c->stream, d_in, d_out, w, h, d_k, (int)ksize, vertical);
+        st = akz_dev_filter1d(c->arith, c->stream, d_in, d_out, w, h, d_k, (int)ksize, vertical);
         if (st == AKZ_OK && hipMemcpyAsync(out, d_out, px * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
         if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
     }
@@ -902,7 +904,7 @@ extern "C" int32_t akz_half_size(akz_ctx* c, const float* img, int32_t w, int32_
         if (hipMalloc(&d_in, px * 4) != hipSuccess || hipMalloc(&d_out, opx * 4) != hipSuccess) st = AKZ_E_OOM;
         if (st == AKZ_OK) {
             hipMemcpyAsync(d_in, img, px * 4, hipMemcpyHostToDevice, c->stream);
-            st = akz_dev_half_size(c->stream, d_in, d_out, w, h, 1, px, opx);
+            st = akz_dev_half_size(c->arith, c->stream, d_in, d_out, w, h, 1, px, opx);
             if (st == AKZ_OK && hipMemcpyAsync(out, d_out, opx * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = AKZ_E_HIP;
             if (hipStreamSynchronize(c->stream) != hipSuccess) st = AKZ_E_HIP;
         }

@@ -69,6 +69,7 @@ struct akz_ctx {
     akz_config cfg;
     int device = 0;
     int n_cu = 256;           // compute units of the device (sizes the grids of the tile-walking kernels)
+    int arith = 0;            // AKZ_ARITH_* bits (akz_options.arith): which copy of the scale-space kernels the context runs
     hipStream_t stream = nullptr;
     int max_w = 0, max_h = 0, max_batch = 0;
     uint32_t max_kp = 0;      // capacity of every per-frame keypoint list
@@ -138,16 +139,18 @@ struct akz_ctx {
 int32_t akz_ctx_prepare(akz_ctx* c, int w, int h);
 
 // Stage launchers (enqueue on c->stream).
+// akz_scale_space.hip exists once per combination of the three un-vendored arithmetic orders (AKZ_ARITH_* of include/akz.h;
+// -DAKZ_ARITH=0..7): akz_arith.hip routes these four calls to the copy c->arith / `arith` names.
 int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n);
 // h_err_copy (optional, host-visible): receives the sticky overflow flag together with the outputs
 int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_descs, uint32_t cap_per_img,
                           uint32_t* d_n_out, uint32_t* h_err_copy = nullptr);
 
 // stand-alone image ops on device buffers (used by akz_horizontal_filter & co)
-int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel,
+int32_t akz_dev_filter1d(int arith, hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel,
                          int ksize, int vertical);
 int32_t akz_dev_deinterleave(hipStream_t s, const float2* in, float* out, size_t n, int component);
-int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
+int32_t akz_dev_half_size(int arith, hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
                           size_t out_fs);
 
 int32_t akz_upload_tables(akz_ctx* c);

@@ -25,7 +25,26 @@
 // edge-replicated scratch rows/columns produce stage by stage.
 #include "akz_ctx.h"
 
+// ---- the three arithmetic orders that live in un-vendored crates of the reference ([3P-unverified]) ----
+// This translation unit is compiled once per combination (-DAKZ_ARITH=0..7, cv_amd/build.py); akz_options.arith selects
+// the copy a context runs (akz_arith.hip).  AKZ_ARITH = 0 is what the crate sources imply for a default x86-64 build and
+// what every measured number is quoted on; in that copy every `if constexpr` below folds to the code of rounds 1-3.
+//   bit 0  AKZ_ARITH_REDUCE_PAIRWISE   wide::f32x4::reduce_add = (a0 + a1) + (a2 + a3)   [0: ((a0 + a1) + a2) + a3]
+//   bit 1  AKZ_ARITH_FMA               wide::f32x4::mul_add is one fused operation        [0: multiply, then add]
+//   bit 2  AKZ_ARITH_HALF_SEQUENTIAL   ndarray sum() of the 2 x 2 window = ((a + b) + c) + d   [0: (a + b) + (c + d)]
+// (akaze/src/image.rs:242-247, :320-325 and :160-195; the oracle has the same switches: oracle/akaze_oracle.c ORC_OPT_*.)
+#ifndef AKZ_ARITH
+#define AKZ_ARITH 0
+#endif
+#define AKZ_SS_CAT2(a, b) a##b
+#define AKZ_SS_CAT(a, b) AKZ_SS_CAT2(a, b)
+#define AKZ_SS(name) AKZ_SS_CAT(name##_arith, AKZ_ARITH)
+
 namespace {
+
+constexpr bool kArithPairwise = (AKZ_ARITH & 1) != 0;
+constexpr bool kArithFma = (AKZ_ARITH & 2) != 0;
+constexpr bool kArithHalfSeq = (AKZ_ARITH & 4) != 0;
 
 constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
 constexpr int kTH = 32;  // output tile height
@@ -85,31 +104,73 @@ __device__ __forceinline__ float load_px(const uint16_t* p, size_t i) { return p
 // The fold starts every lane from +0.  Only lane 0's start is observable: x + (+0) differs from x for x = -0 alone,
 // a0 = ... + (p0 + 0) can therefore never be -0, and a sum whose left operand is not -0 does not depend on the sign of
 // a zero on its right — so lanes 1..3 start from their first product (three adds fewer per filter tap group, same bits).
+// (AKZ_ARITH: a fused mul_add changes every accumulation after a lane's first product — fma(s, k, +0) is s * k up to the
+// sign of a zero, which the argument above makes unobservable; a pairwise reduce_add changes the last two additions, and
+// a0 + a1 is not -0 either, so the argument covers it as well.)
+__device__ __forceinline__ float arith_mad(float s, float k, float acc)
+{
+    if constexpr (kArithFma) return __builtin_fmaf(s, k, acc);
+    else return s * k + acc;
+}
+__device__ __forceinline__ float arith_reduce(float a0, float a1, float a2, float a3)
+{
+    if constexpr (kArithPairwise) return (a0 + a1) + (a2 + a3);
+    else return ((a0 + a1) + a2) + a3;
+}
 template <int N>
 __device__ __forceinline__ float lane4_dot(const float* s, int stride, const float* k)
 {
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        float p = s[i * stride] * k[i];
-        if ((i & 3) == 0) a0 = p + a0;
-        else if ((i & 3) == 1) a1 = i == 1 ? p : p + a1;
-        else if ((i & 3) == 2) a2 = i == 2 ? p : p + a2;
-        else a3 = i == 3 ? p : p + a3;
+        const float v = s[i * stride];
+        if ((i & 3) == 0) a0 = arith_mad(v, k[i], a0);
+        else if ((i & 3) == 1) a1 = i == 1 ? v * k[i] : arith_mad(v, k[i], a1);
+        else if ((i & 3) == 2) a2 = i == 2 ? v * k[i] : arith_mad(v, k[i], a2);
+        else a3 = i == 3 ? v * k[i] : arith_mad(v, k[i], a3);
     }
-    return ((a0 + a1) + a2) + a3;
+    return arith_reduce(a0, a1, a2, a3);
 }
 
+// The multiscale Scharr "off" kernel [n, 0 .. 0, m, 0 .. 0, n] (taps 0, sigma, 2 sigma of 2 sigma + 1) through the
+// four-lane accumulation: tap i goes to lane i & 3, so with a = v(-s), b = v(0), c = v(+s) and pa = a n (+0: lane 0's
+// start), pb = b m, pc = c n the result is one of
+//   mode 0  (pa + pc) + pb      a and c share lane 0 (sigma % 4 == 2), or lanes 0, 3, 2 summed in lane order (sigma % 4 == 3)
+//   mode 1  (pa + pb) + pc      all three in lane 0 (sigma % 4 == 0), or lanes 0, 1, 2 (sigma % 4 == 1; the simple Scharr [3, 10, 3])
+//   mode 2  pa + (pc + pb)      lanes 0, 3, 2 under a pairwise reduce_add: (l0 + l1) + (l2 + l3)                [AKZ_ARITH bit 0]
+//   mode 3  fma(c, n, pa) + pb            a and c share lane 0, fused mul_add                                      [AKZ_ARITH bit 1]
+//   mode 4  fma(c, n, fma(b, m, pa))      all three in lane 0, fused mul_add                                       [AKZ_ARITH bit 1]
+// (a lane that holds a single product is the same fused or not; every other lane is +0.)
 struct OffK {
     float n, m;
-    int mode;  // 0: (a*n + c*n) + b*m   1: (a*n + b*m) + c*n    (a = v(-s), b = v(0), c = v(+s))
+    int mode;
 };
+constexpr int offk_mode(uint32_t sigma)
+{
+    if (sigma == 1) return 1;
+    const int lb = (int)(sigma & 3u), lc = (int)((2u * sigma) & 3u);
+    if (lc == 0 && lb != 0) return kArithFma ? 3 : 0;
+    if (lb == 0) return kArithFma ? 4 : 1;
+    if (lb < lc) return 1;
+    return kArithPairwise ? 2 : 0;
+}
 __device__ __forceinline__ float off_combine(const OffK k, float a, float b, float c)
 {
     // the first tap of lane 0 is accumulated onto the +0 the reference's fold starts from (a product that
     // underflows to -0 becomes +0); after that no partial sum can be -0, so no other tap needs it
-    float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
-    return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+    const float pa = a * k.n + 0.0f;
+    if constexpr (!kArithFma && !kArithPairwise) {
+        const float pb = b * k.m, pc = c * k.n;
+        return k.mode == 0 ? (pa + pc) + pb : (pa + pb) + pc;
+    } else {
+        switch (k.mode) {
+        case 0: return (pa + c * k.n) + b * k.m;
+        case 1: return (pa + b * k.m) + c * k.n;
+        case 2: return pa + (c * k.n + b * k.m);
+        case 3: return __builtin_fmaf(c, k.n, pa) + b * k.m;
+        default: return __builtin_fmaf(c, k.n, __builtin_fmaf(b, k.m, pa));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,28 +269,38 @@ __device__ __forceinline__ void lds_write4(v2f* __restrict__ row, int c, v2f a, 
 }
 
 // lane4_dot on register operands (see lane4_dot): taps v[0..N-1]
+__device__ __forceinline__ v2f arith_mad_v(v2f s, float k, v2f acc)
+{
+    if constexpr (kArithFma) return __builtin_elementwise_fma(s, splat(k), acc);
+    else return s * splat(k) + acc;
+}
 template <int N>
 __device__ __forceinline__ v2f lane4_dot_v(const v2f* v, const float* k)
 {
     v2f a0 = splat(0.0f), a1 = splat(0.0f), a2 = splat(0.0f), a3 = splat(0.0f);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        v2f p = v[i] * splat(k[i]);
-        if ((i & 3) == 0) a0 = p + a0;
-        else if ((i & 3) == 1) a1 = i == 1 ? p : p + a1;      // (lanes 1..3 start from their first product: see lane4_dot)
-        else if ((i & 3) == 2) a2 = i == 2 ? p : p + a2;
-        else a3 = i == 3 ? p : p + a3;
+        if ((i & 3) == 0) a0 = arith_mad_v(v[i], k[i], a0);
+        else if ((i & 3) == 1) a1 = i == 1 ? v[i] * splat(k[i]) : arith_mad_v(v[i], k[i], a1);   // (lanes 1..3 start from their first product: see lane4_dot)
+        else if ((i & 3) == 2) a2 = i == 2 ? v[i] * splat(k[i]) : arith_mad_v(v[i], k[i], a2);
+        else a3 = i == 3 ? v[i] * splat(k[i]) : arith_mad_v(v[i], k[i], a3);
     }
-    return ((a0 + a1) + a2) + a3;
+    if constexpr (kArithPairwise) return (a0 + a1) + (a2 + a3);
+    else return ((a0 + a1) + a2) + a3;
 }
 
-// off_combine with the accumulation order fixed at compile time: make_offk(sigma).mode is 1 for sigma 4 (all
-// three taps in f32x4 lane 0) and 0 for sigma 2 and 3, the only derivative scales the two-frame kernels serve.
+// off_combine with the accumulation order fixed at compile time (offk_mode(SG)): the derivative scales the two-frame
+// kernels serve are 2, 3 and 4.
 template <int SG>
 __device__ __forceinline__ v2f off_combine_sg(const OffK k, v2f a, v2f b, v2f c)
 {
-    v2f pa = a * splat(k.n) + splat(0.0f), pb = b * splat(k.m), pc = c * splat(k.n);
-    return SG == 4 ? (pa + pb) + pc : (pa + pc) + pb;
+    constexpr int mode = offk_mode(SG);
+    const v2f pa = a * splat(k.n) + splat(0.0f);
+    if constexpr (mode == 0) return (pa + c * splat(k.n)) + b * splat(k.m);
+    else if constexpr (mode == 1) return (pa + b * splat(k.m)) + c * splat(k.n);
+    else if constexpr (mode == 2) return pa + (c * splat(k.n) + b * splat(k.m));
+    else if constexpr (mode == 3) return __builtin_elementwise_fma(c, splat(k.n), pa) + b * splat(k.m);
+    else return __builtin_elementwise_fma(c, splat(k.n), __builtin_elementwise_fma(b, splat(k.m), pa));
 }
 
 __device__ __forceinline__ float4 load4_px(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
@@ -1040,7 +1111,8 @@ __global__ __launch_bounds__(256) void k_half_size(const float* __restrict__ in,
         v = (src[(size_t)(h - 1) * w + 2 * x] + src[(size_t)(h - 1) * w + 2 * x + 1]) * 0.5f;
     } else {
         const float* p = src + (size_t)(2 * y) * w + 2 * x;
-        v = ((p[0] + p[1]) + (p[w] + p[w + 1])) * 0.25f;
+        if constexpr (kArithHalfSeq) v = (((p[0] + p[1]) + p[w]) + p[w + 1]) * 0.25f;   // ndarray's fold over the window in memory order
+        else v = ((p[0] + p[1]) + (p[w] + p[w + 1])) * 0.25f;
     }
     out[(size_t)blockIdx.z * out_fs + (size_t)y * ow + x] = v;
 }
@@ -1348,6 +1420,9 @@ __device__ __forceinline__ int ff_elem(int row, int col) { return 2 * ff_chunk<R
 
 // Experiment builds only (-DAKZ_FF_PROF, tools/build_variant.sh; never in the product library): thread 0 of every
 // 8th block of k_front_fed records the shader clock at its phase boundaries, tools/ff_prof.py reads them back.
+#if defined(AKZ_FF_PROF) && AKZ_ARITH != 0
+#undef AKZ_FF_PROF   // (the profiler lives in the default copy only)
+#endif
 #ifdef AKZ_FF_PROF
 constexpr int kFFProfStamps = 12, kFFProfCap = 1 << 16;
 __device__ unsigned long long g_ff_prof[(size_t)kFFProfCap * kFFProfStamps];
@@ -2107,8 +2182,13 @@ __global__ __launch_bounds__(NT) void k_deriv_second_cand2(const float2* __restr
 template <int SG>
 __device__ __forceinline__ float off_combine_s(const OffK k, float a, float b, float c)
 {
-    const float pa = a * k.n + 0.0f, pb = b * k.m, pc = c * k.n;
-    return SG == 4 ? (pa + pb) + pc : (pa + pc) + pb;
+    constexpr int mode = offk_mode(SG);
+    const float pa = a * k.n + 0.0f;
+    if constexpr (mode == 0) return (pa + c * k.n) + b * k.m;
+    else if constexpr (mode == 1) return (pa + b * k.m) + c * k.n;
+    else if constexpr (mode == 2) return pa + (c * k.n + b * k.m);
+    else if constexpr (mode == 3) return __builtin_fmaf(c, k.n, pa) + b * k.m;
+    else return __builtin_fmaf(c, k.n, __builtin_fmaf(b, k.m, pa));
 }
 
 constexpr int det_stream_halo(int SG) { return (SG + 2) & ~1; }                    // columns each side: even, >= SG + 1
@@ -2446,15 +2526,14 @@ __global__ __launch_bounds__(256) void k_filter1d(const float* __restrict__ in, 
     for (int i = 0; i < ksize; ++i) {
         float s = vertical ? in[(size_t)clampi(y + i - half, 0, h - 1) * w + x]
                            : in[(size_t)y * w + clampi(x + i - half, 0, w - 1)];
-        float p = s * kern[i];
         int l = i & 3;
         // (branch-free lane select keeps a[] in registers)
-        a[0] = l == 0 ? p + a[0] : a[0];
-        a[1] = l == 1 ? p + a[1] : a[1];
-        a[2] = l == 2 ? p + a[2] : a[2];
-        a[3] = l == 3 ? p + a[3] : a[3];
+        a[0] = l == 0 ? arith_mad(s, kern[i], a[0]) : a[0];
+        a[1] = l == 1 ? arith_mad(s, kern[i], a[1]) : a[1];
+        a[2] = l == 2 ? arith_mad(s, kern[i], a[2]) : a[2];
+        a[3] = l == 3 ? arith_mad(s, kern[i], a[3]) : a[3];
     }
-    out[(size_t)y * w + x] = ((a[0] + a[1]) + a[2]) + a[3];
+    out[(size_t)y * w + x] = arith_reduce(a[0], a[1], a[2], a[3]);
 }
 
 OffK make_offk(uint32_t sigma)
@@ -2464,21 +2543,11 @@ OffK make_offk(uint32_t sigma)
     if (sigma == 1) {  // simple_scharr: [3,10,3], taps in lanes 0,1,2 -> (a*3 + b*10) + c*3
         k.n = 3.0f;
         k.m = 10.0f;
-        k.mode = 1;
     } else {
         k.n = sw.norm;
         k.m = sw.middle;
-        // tap indices 0, sigma, 2*sigma -> lanes 0, sigma&3, (2*sigma)&3, chunks idx>>2.
-        int lb = sigma & 3, lc = (2 * sigma) & 3;
-        if (lc == 0 && lb != 0) {
-            k.mode = 0;  // a and c share lane 0: lane0 = c*n + a*n; then + lane(lb) = b*m
-        } else if (lb == 0) {
-            k.mode = 1;  // all three in lane 0, chunk order a, b, c: (a*n + b*m) + c*n
-        } else {
-            // three distinct lanes 0, lb, lc summed in lane order 0,1,2,3
-            k.mode = (lb < lc) ? 1 : 0;
-        }
     }
+    k.mode = offk_mode(sigma);
     return k;
 }
 
@@ -2487,23 +2556,25 @@ inline dim3 grid_px(int w, int h, int n) { return dim3(akz_div_up(w, 64), akz_di
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-int32_t akz_dev_filter1d(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel, int ksize,
-                         int vertical)
+int32_t AKZ_SS(akz_dev_filter1d)(hipStream_t s, const float* in, float* out, int w, int h, const float* d_kernel, int ksize,
+                                int vertical)
 {
     AKZ_LAUNCH(k_filter1d, grid_px(w, h, 1), dim3(256), 0, s, in, out, w, h, d_kernel, ksize, vertical);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
 
+#if AKZ_ARITH == 0   // (no arithmetic in it: one copy serves every context)
 int32_t akz_dev_deinterleave(hipStream_t s, const float2* in, float* out, size_t n, int component)
 {
     AKZ_LAUNCH(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, component);
     AKZ_LAUNCH_CHECK();
     return AKZ_OK;
 }
+#endif
 
-int32_t akz_dev_half_size(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
-                          size_t out_fs)
+int32_t AKZ_SS(akz_dev_half_size)(hipStream_t s, const float* in, float* out, int w, int h, int n, size_t in_fs,
+                                 size_t out_fs)
 {
     if (w / 2 <= 0 || h / 2 <= 0) return AKZ_E_INVALID;
     AKZ_LAUNCH(k_half_size, grid_px(w / 2, h / 2, n), dim3(256), 0, s, in, out, w, h, in_fs, out_fs);
@@ -2665,7 +2736,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 // first one writes Lt[i], so the half-sized image goes to the scratch plane, and vice versa
                 float* half_dst = (nwrites % 2 == 0) ? bufA : bufB;
                 if (nwrites == 0) half_dst = bufA;
-                AKZ_TRY(akz_dev_half_size(s, S.Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
+                AKZ_TRY(AKZ_SS(akz_dev_half_size)(s, S.Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
                 init = half_dst;
             } else {
                 init = S.Lt[i - 1];  // lib.rs:230 clone(): read in place, never modified again
@@ -2888,7 +2959,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     return AKZ_OK;
 }
 
-int32_t akz_run_scale_space(akz_ctx* c, const void* d_imgs, int fmt, int n)
+int32_t AKZ_SS(akz_run_scale_space)(akz_ctx* c, const void* d_imgs, int fmt, int n)
 {
     AkzTimerScope timer_scope(c);
     if (fmt == AKZ_FMT_U8) return scale_space_impl<uint8_t>(c, (const uint8_t*)d_imgs, n);

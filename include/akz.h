@@ -91,7 +91,7 @@ int32_t akz_destroy(akz_ctx* ctx);
 /* Behaviour switches of ONE context.  The library reads no environment variable: two contexts in one
  * process can differ, and nothing outside the caller's code changes what a context does.  The defaults
  * (all zero) are the measured-best paths; the other values select the fall-back / reference kernels that
- * the parity tests and A/B runs exercise.  Results are bit-identical under every combination. */
+ * the parity tests and A/B runs exercise.  Results are bit-identical under every combination (of everything but `arith`, below). */
 enum {
     AKZ_OPT_KEEP_ALL = 1u << 0,           /* keep per-level Lsmooth / Lflow and write the Ldet planes (parity taps) */
     AKZ_OPT_NO_FRAME_PAIRS = 1u << 1,     /* one-frame kernels even for widths divisible by 4 */
@@ -117,8 +117,19 @@ typedef struct akz_options {
     uint32_t desc_tile_shift; /* log2 tile edge of the descriptor visiting order, 2..9; 0 = default (5) */
     uint32_t stream_waves;    /* waves a row-streaming launch aims for (sets its row-segment length); 0 = default (8192) */
     uint32_t stream_min_waves; /* launches that cannot field this many streaming waves take the tile kernel; 0 = default (2048) */
-    uint32_t reserved[8];     /* must be zero */
+    uint32_t arith;           /* AKZ_ARITH_* bits: which of the reference's un-vendored arithmetic orders the filters use; 0 = default */
+    uint32_t reserved[7];     /* must be zero */
 } akz_options;
+/* akz_options.arith — the only option that CHANGES RESULTS.  Three pieces of the reference's arithmetic live in crates that
+ * are not vendored in rust-cv/cv, and its known answers (399 / 343 descriptors, 11 matches) come out the same under all
+ * eight combinations, so none can be ruled out from here:
+ *   wide::f32x4::reduce_add of the four filter lanes (akaze/src/image.rs:246-247, :324-325):  ((a0 + a1) + a2) + a3  [default]
+ *                                                                                     or  (a0 + a1) + (a2 + a3)   [REDUCE_PAIRWISE]
+ *   wide::f32x4::mul_add in the filters' accumulation (image.rs:246, :324):  multiply, then add  [default]  or one fused operation [FMA]
+ *   ndarray's sum() over a 2 x 2 window in half_size (image.rs:160-166):     (a + b) + (c + d)   [default]  or  ((a + b) + c) + d  [HALF_SEQUENTIAL]
+ * The default is what the crate sources imply for a default x86-64 build.  Every combination is a complete copy of the
+ * scale-space kernels (no cost in the default one) and is held bit for bit to the oracle under the same ORC_OPT_* switches. */
+enum { AKZ_ARITH_REDUCE_PAIRWISE = 1u << 0, AKZ_ARITH_FMA = 1u << 1, AKZ_ARITH_HALF_SEQUENTIAL = 1u << 2 };
 /* akz_create with explicit options (NULL = defaults = akz_create). */
 int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h,
                       int32_t max_batch, uint32_t max_keypoints, const akz_options* opts, akz_ctx** out);

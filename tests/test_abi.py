@@ -78,6 +78,8 @@ def test_options_struct_and_early_validation(lib):
     assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
     o = _lib.make_options(fed_block=9)
     assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
+    o = _lib.make_options(arith=8)                              # three switches: 0..7
+    assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
     o = _lib.make_options()
     o.struct_size = 4
     assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
