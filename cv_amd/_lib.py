@@ -131,7 +131,7 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "rs_debug_scene_world", "rs_debug_far",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "hm_set_targets", "hm_knn_targets", "rs_debug_scene_world", "rs_debug_far",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
     "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
@@ -199,6 +199,8 @@ def lib():
     L.hm_knn_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, u32, vp, vp]
     L.hm_best_of_views_batch_device.argtypes = [vp, vp, vp, vp, u32, vp, u32, u32, u32, vp, vp, u32, vp, vp, vp]
     L.hm_best_of_views_device.argtypes = [vp, vp, vp, u32, vp, u32, u32, vp, vp, u32, vp, vp, vp]
+    L.hm_set_targets.argtypes = [vp, vp, u32]
+    L.hm_knn_targets.argtypes = [vp, vp, u32, u32, vp]
     L.hm_landmark_pairs_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]

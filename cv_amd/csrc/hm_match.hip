@@ -581,6 +581,8 @@ struct hm_ctx {
     uint4* d_a = nullptr;
     uint4* d_b = nullptr;
     uint32_t* d_na = nullptr;  // [2]: na, nb
+    uint32_t resident_nt = 0;  // hm_set_targets: d_b holds this many target descriptors (0: nothing resident)
+    bool resident = false;
     akz_neighbor* d_fwd = nullptr;
     akz_neighbor* d_rev = nullptr;
     uint32_t* d_pairs = nullptr;
@@ -856,6 +858,7 @@ extern "C" int32_t hm_knn2(hm_ctx* c, const akz_descriptor* q, uint32_t nq, cons
         uint32_t cnt[2] = {nq, nt};
         AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
         AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+        c->resident = false;   // (the staging buffer of the targets is overwritten)
         AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
         HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt, c->d_fwd};
         AKZ_TRY(launch_knn2(c, &p, 1, nq, 0));
@@ -888,7 +891,57 @@ extern "C" int32_t hm_knn(hm_ctx* c, const akz_descriptor* q, uint32_t nq, const
         uint32_t cnt[2] = {nq, nt};
         AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
         AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
+        c->resident = false;   // (the staging buffer of the targets is overwritten)
         if (nt) AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+        HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt ? nt : 1u, c->d_bfwd};
+        AKZ_TRY(launch_knn2(c, &p, 1, nq, 0, (int)k));
+        AKZ_HIP(hipMemcpyAsync(out, c->d_bfwd, sizeof(akz_neighbor) * k * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));
+        return AKZ_OK;
+    });
+}
+
+// space::LinearKnn keeps its target set (`iter`) and is asked once per query descriptor (akaze/tests/estimate_pose.rs:82-88:
+// `.map(|d1| knn.knn(d1, 2))`).  A literal port of that loop through hm_knn uploads the whole target set for every query;
+// hm_set_targets uploads it ONCE and hm_knn_targets answers any number of queries (one, or a batch) against the resident
+// copy.  Any other host-buffer call on the context (hm_knn, hm_knn2, hm_match, hm_hash_bag) reuses the staging buffer and
+// ends the residency: hm_knn_targets then answers AKZ_E_INVALID instead of searching stale data.
+extern "C" int32_t hm_set_targets(hm_ctx* c, const akz_descriptor* t, uint32_t nt)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || (nt && !t)) return AKZ_E_INVALID;
+        if (nt > c->max_t) return AKZ_E_TOO_LARGE;
+        AKZ_HIP(hipSetDevice(c->device));
+        c->resident = false;
+        if (nt) AKZ_HIP(hipMemcpyAsync(c->d_b, t, (size_t)nt * 64, hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipStreamSynchronize(c->stream));   // the caller's array may go away
+        c->resident_nt = nt;
+        c->resident = true;
+        return AKZ_OK;
+    });
+}
+extern "C" int32_t hm_knn_targets(hm_ctx* c, const akz_descriptor* q, uint32_t nq, uint32_t k, akz_neighbor* out)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !q || !out || k < 1 || k > 3 || !c->resident) return AKZ_E_INVALID;
+        if (nq > c->max_q) return AKZ_E_TOO_LARGE;
+        if (nq == 0) return AKZ_OK;
+        AKZ_HIP(hipSetDevice(c->device));
+        AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(1)));
+        const size_t need = (size_t)nq * 3;
+        if (need > c->bscratch_elems) {
+            AKZ_HIP(hipStreamSynchronize(c->stream));
+            if (c->d_bfwd) AKZ_HIP(hipFree(c->d_bfwd));
+            if (c->d_brev) AKZ_HIP(hipFree(c->d_brev));
+            c->d_bfwd = c->d_brev = nullptr;
+            AKZ_HIP(hipMalloc(&c->d_bfwd, sizeof(akz_neighbor) * need));
+            AKZ_HIP(hipMalloc(&c->d_brev, sizeof(akz_neighbor) * need));
+            c->bscratch_elems = need;
+        }
+        const uint32_t nt = c->resident_nt;
+        uint32_t cnt[2] = {nq, nt};
+        AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+        AKZ_HIP(hipMemcpyAsync(c->d_a, q, (size_t)nq * 64, hipMemcpyHostToDevice, c->stream));
         HmProb p = {c->d_a, c->d_na, nq, c->d_b, c->d_na + 1, nt ? nt : 1u, c->d_bfwd};
         AKZ_TRY(launch_knn2(c, &p, 1, nq, 0, (int)k));
         AKZ_HIP(hipMemcpyAsync(out, c->d_bfwd, sizeof(akz_neighbor) * k * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
@@ -1233,6 +1286,7 @@ extern "C" int32_t hm_match(hm_ctx* c, const akz_descriptor* a, uint32_t na, con
         uint32_t cnt[2] = {na, nb};
         AKZ_HIP(hipMemcpyAsync(c->d_na, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
         AKZ_HIP(hipMemcpyAsync(c->d_a, a, (size_t)na * 64, hipMemcpyHostToDevice, c->stream));
+        c->resident = false;   // (the staging buffer of the targets is overwritten)
         AKZ_HIP(hipMemcpyAsync(c->d_b, b, (size_t)nb * 64, hipMemcpyHostToDevice, c->stream));
         HmProb p[2] = {{c->d_a, c->d_na, na, c->d_b, c->d_na + 1, nb, c->d_fwd},
                        {c->d_b, c->d_na + 1, nb, c->d_a, c->d_na, na, c->d_rev}};
@@ -1396,6 +1450,7 @@ extern "C" int32_t hm_hash_bag(hm_ctx* c, const akz_descriptor* feats, uint32_t 
         uint32_t* d_hash = reinterpret_cast<uint32_t*>((char*)c->d_lsh + hash_off);
         AKZ_HIP(hipMemcpyAsync(c->d_na, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         if (n) AKZ_HIP(hipMemcpyAsync(c->d_a, feats, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+        c->resident = false;   // (the staging buffer of the targets is overwritten)
         AKZ_HIP(hipMemcpyAsync(c->d_b, codewords, (size_t)n_codewords * 64, hipMemcpyHostToDevice, c->stream));
         AKZ_TRY(hash_bag_launch(c, c->d_a, c->d_na, cap, 1, c->d_b, n_codewords, d_hash, d_words));
         AKZ_HIP(hipMemcpyAsync(hash, d_hash, n_codewords / 8, hipMemcpyDeviceToHost, c->stream));

@@ -70,6 +70,18 @@ class Matcher:
         check(_lib.lib().hm_knn(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), k, out.ctypes.data), "hm_knn")
         return out
 
+    def set_targets(self, t):
+        """hm_set_targets: the target set stays on the device for the knn_targets() calls that follow."""
+        t = _desc(t)
+        check(_lib.lib().hm_set_targets(self._h, t.ctypes.data, len(t)), "hm_set_targets")
+
+    def knn_targets(self, q, k):
+        """hm_knn_targets: LinearKnn.knn(q, k) of every row of q against the resident targets."""
+        q = _desc(q)
+        out = np.zeros((len(q), k), NB_DTYPE)
+        check(_lib.lib().hm_knn_targets(self._h, q.ctypes.data, len(q), k, out.ctypes.data), "hm_knn_targets")
+        return out
+
     def match(self, a, b, rule=RULE_STRICT, param_u=24, param_f=0.5, symmetric=True):
         a = _desc(a); b = _desc(b)
         cap = max(len(a), 1)
@@ -106,18 +118,32 @@ class LinearKnn:
         self.iter = _desc(iter if iter is not None else np.zeros((0, 64), np.uint8))
         self.device = device
 
+    def _resident(self):
+        m = default_matcher(max(len(self.iter), 1), self.device)
+        if getattr(m, "_resident_of", None) is not self:
+            m.set_targets(self.iter)
+            m._resident_of = self
+        return m
+
     def knn(self, query, num):
         """Knn::knn(&self, query, num) -> Vec<Neighbor>, sorted by (distance, index), min(num, len) long.
         The device path implements num <= 3 (the reference asks for 2 when matching frame pairs and 3 when
-        registering a frame against recent views, cv-sfm/src/lib.rs:1474)."""
+        registering a frame against recent views, cv-sfm/src/lib.rs:1474).  `iter` is uploaded once and stays on the
+        device between calls (hm_set_targets / hm_knn_targets); a call still costs one launch per query — match whole
+        frames with knn_batch() or matching() where the caller's loop allows it."""
         if not 1 <= num <= 3:
             raise NotImplementedError("the MI355X matcher implements knn(query, k) for k <= 3")
-        nn = default_matcher(max(len(self.iter), 1), self.device).knn(_desc(query)[:1], self.iter, num)
+        try:
+            nn = self._resident().knn_targets(_desc(query)[:1], num)
+        except _lib.AkzError:
+            default_matcher(max(len(self.iter), 1), self.device)._resident_of = None    # another call took the staging buffer
+            nn = self._resident().knn_targets(_desc(query)[:1], num)
         return [Neighbor(int(nn[0, i]["index"]), int(nn[0, i]["distance"])) for i in range(min(num, len(self.iter)))]
 
     def knn_batch(self, queries, num=2):
         """knn(q, num) for every row of `queries` in one launch: [nq,num] structured (index, distance)."""
         m = default_matcher(max(len(self.iter), len(queries), 1), self.device)
+        m._resident_of = None
         return m.knn2(queries, self.iter) if num == 2 else m.knn(queries, self.iter, num)
 
 

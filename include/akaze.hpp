@@ -282,6 +282,10 @@ private:
 };
 
 // space::LinearKnn { metric: Hamming, iter }: exact k-NN by scanning `iter` (the target descriptors).
+// The reference's callers ask once per query descriptor (akaze/tests/estimate_pose.rs:82-88).  `iter` goes to the device
+// once (hm_set_targets, on the first question) and stays there; every knn() is then one launch over the resident targets
+// — still launch-bound (ask for whole frames with knn_batch() or match_descriptors() where the loop is yours), but no
+// longer an upload of the whole target set per query.
 class LinearKnn {
 public:
     LinearKnn(Hamming, const std::vector<akaze::BitArray64>& iter, Matcher& m) : iter_(iter), m_(m) {}
@@ -290,9 +294,7 @@ public:
     {
         if (num != 2) throw std::invalid_argument("the MI355X matcher implements knn(query, 2)");
         akz_neighbor out[2];
-        akaze::check(hm_knn2(m_.handle(), reinterpret_cast<const akz_descriptor*>(query.data()), 1,
-                             reinterpret_cast<const akz_descriptor*>(iter_.data()), (uint32_t)iter_.size(), out),
-                     "hm_knn2");
+        ask(&query, 1, 2, out);
         return {Neighbor{out[0].index, out[0].distance}, Neighbor{out[1].index, out[1].distance}};
     }
 
@@ -302,18 +304,40 @@ public:
     {
         if (num < 1 || num > 3) throw std::invalid_argument("the MI355X matcher implements knn(query, k) for k <= 3");
         akz_neighbor out[3];
-        akaze::check(hm_knn(m_.handle(), reinterpret_cast<const akz_descriptor*>(query.data()), 1,
-                            reinterpret_cast<const akz_descriptor*>(iter_.data()), (uint32_t)iter_.size(),
-                            (uint32_t)num, out),
-                     "hm_knn");
+        ask(&query, 1, (uint32_t)num, out);
         std::vector<Neighbor> r;
         for (std::size_t i = 0; i < num && i < iter_.size(); ++i) r.push_back(Neighbor{out[i].index, out[i].distance});
         return r;
     }
+    // the same for every query in one launch: out[i * num + j] = j-th neighbour of queries[i]
+    std::vector<Neighbor> knn_batch(const std::vector<akaze::BitArray64>& queries, std::size_t num) const
+    {
+        if (num < 1 || num > 3) throw std::invalid_argument("the MI355X matcher implements knn(query, k) for k <= 3");
+        std::vector<akz_neighbor> out(queries.size() * num);
+        if (!queries.empty()) ask(queries.data(), (uint32_t)queries.size(), (uint32_t)num, out.data());
+        std::vector<Neighbor> r(out.size());
+        for (std::size_t i = 0; i < out.size(); ++i) r[i] = Neighbor{out[i].index, out[i].distance};
+        return r;
+    }
 
 private:
+    void ask(const akaze::BitArray64* q, uint32_t nq, uint32_t k, akz_neighbor* out) const
+    {
+        const akz_descriptor* t = reinterpret_cast<const akz_descriptor*>(iter_.data());
+        if (!resident_) {
+            akaze::check(hm_set_targets(m_.handle(), t, (uint32_t)iter_.size()), "hm_set_targets");
+            resident_ = true;
+        }
+        int32_t st = hm_knn_targets(m_.handle(), reinterpret_cast<const akz_descriptor*>(q), nq, k, out);
+        if (st == AKZ_E_INVALID) {          // another host-buffer call on this matcher took the staging buffer: upload again
+            akaze::check(hm_set_targets(m_.handle(), t, (uint32_t)iter_.size()), "hm_set_targets");
+            st = hm_knn_targets(m_.handle(), reinterpret_cast<const akz_descriptor*>(q), nq, k, out);
+        }
+        akaze::check(st, "hm_knn_targets");
+    }
     const std::vector<akaze::BitArray64>& iter_;
     Matcher& m_;
+    mutable bool resident_ = false;
 };
 
 inline std::vector<std::array<std::size_t, 2>> run_match(Matcher& m, const std::vector<akaze::BitArray64>& a,

@@ -269,6 +269,12 @@ int32_t hm_knn2(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_des
  * neighbours, here the slots past nt hold {index 2^22 - 1, distance 1023}. */
 int32_t hm_knn(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_descriptor* t, uint32_t nt,
                uint32_t k, akz_neighbor* out);
+/* LinearKnn keeps its targets (`iter`) and is asked once per query (akaze/tests/estimate_pose.rs:82-88).  hm_set_targets
+ * uploads the target set once; hm_knn_targets answers queries — one, or a batch — against the resident copy, results as
+ * hm_knn's.  Any other host-buffer call on the context (hm_knn, hm_knn2, hm_match, hm_hash_bag) reuses the staging buffer
+ * and ends the residency: hm_knn_targets then returns AKZ_E_INVALID rather than search stale data. */
+int32_t hm_set_targets(hm_ctx* ctx, const akz_descriptor* t, uint32_t nt);
+int32_t hm_knn_targets(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, uint32_t k, akz_neighbor* out);
 /* Device-resident multi-view form of the same call (cv-sfm/src/lib.rs:1468-1486: every feature of the new
  * frame against each of up to 32 recent views): d_q [cap][64] + count d_nq, d_views [..][cap][64] + counts
  * d_nviews, view v of this call = block view_idx[v]; d_out [n_views][cap][k].  Stream-ordered after

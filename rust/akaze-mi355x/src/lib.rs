@@ -83,6 +83,8 @@ extern "C" {
     fn hm_knn2(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, out: *mut AkzNeighbor) -> i32;
     fn hm_knn(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, k: u32,
               out: *mut AkzNeighbor) -> i32;
+    fn hm_set_targets(ctx: *mut c_void, t: *const [u8; 64], nt: u32) -> i32;
+    fn hm_knn_targets(ctx: *mut c_void, q: *const [u8; 64], nq: u32, k: u32, out: *mut AkzNeighbor) -> i32;
     fn hm_hash_bag(ctx: *mut c_void, feats: *const [u8; 64], n: u32, codewords: *const [u8; 64], n_codewords: u32,
                    hash: *mut u8, words: *mut AkzNeighbor) -> i32;
     fn hm_hash_knn(ctx: *mut c_void, query: *const u8, hashes: *const u8, n: u32, hash_bytes: u32, k: u32,
@@ -343,9 +345,62 @@ impl Akaze {
     }
 }
 
+thread_local! {
+    /// Which target set the thread's matcher holds on the device: (address, length, first and last descriptor) of the
+    /// slice `hm_set_targets` was last called with, and the matcher it was uploaded to.
+    static RESIDENT: RefCell<Option<(usize, usize, [u8; 64], [u8; 64], *mut c_void)>> = RefCell::new(None);
+}
+
 /// A `space::Knn` implementor with `LinearKnn { metric: Hamming, iter }` semantics for `BitArray<64>`.
+///
+/// The reference's callers build the `LinearKnn` once per frame pair and call `knn` once per query descriptor
+/// (akaze/tests/estimate_pose.rs:82-88, cv-sfm/src/lib.rs:3103).  Ported literally that is one kernel launch per query:
+/// the target set is uploaded ONCE (`hm_set_targets`: it stays on the device for as long as this thread keeps asking
+/// about the same slice) and each `knn` sends 64 bytes up and `num` neighbours back — correct, and far better than
+/// re-uploading 320 KB per query, but still launch-bound (about 20 us per query against 0.2 us per query for a whole
+/// frame at once).  Callers that own their loop should ask for all queries together: [`Mi355xLinearKnn::knn_batch`], or
+/// [`match_descriptors`] / `symmetric_matching`, which also keep the pair lists on the device side of the matcher.
 pub struct Mi355xLinearKnn<'a> {
     pub targets: &'a [BitArray<64>],
+}
+impl<'a> Mi355xLinearKnn<'a> {
+    fn key(&self) -> (usize, usize, [u8; 64], [u8; 64]) {
+        let z = [0u8; 64];
+        (self.targets.as_ptr() as usize, self.targets.len(),
+         self.targets.first().map_or(z, |d| *d.bytes()), self.targets.last().map_or(z, |d| *d.bytes()))
+    }
+    /// Upload the targets unless this thread's matcher already holds exactly this slice.
+    fn resident(&self, ctx: *mut c_void) {
+        let k = self.key();
+        let hit = RESIDENT.with(|r| r.borrow().map_or(false, |(p, n, a, b, c)| (p, n, a, b) == k && c == ctx));
+        if !hit {
+            let st = unsafe { hm_set_targets(ctx, self.targets.as_ptr() as *const [u8; 64], self.targets.len() as u32) };
+            assert_eq!(st, 0, "hm_set_targets failed with status {st}");
+            RESIDENT.with(|r| *r.borrow_mut() = Some((k.0, k.1, k.2, k.3, ctx)));
+        }
+    }
+    /// `knn(q, num)` for every query in ONE launch: `out[i]` are the `min(num, targets.len())` nearest targets of
+    /// `queries[i]`, ascending (distance, index) — what `queries.iter().map(|q| self.knn(q, num))` returns.
+    pub fn knn_batch(&self, queries: &[BitArray<64>], num: usize) -> Vec<Vec<space::Neighbor<u32, usize>>> {
+        assert!((1..=3).contains(&num), "the MI355X matcher implements knn(query, k) for k <= 3");
+        let (nq, nt) = (queries.len() as u32, self.targets.len() as u32);
+        let mut out = vec![AkzNeighbor { index: 0, distance: 0 }; queries.len() * num];
+        let st = with_matcher(nq.max(nt), |ctx| {
+            self.resident(ctx);
+            let mut st = unsafe { hm_knn_targets(ctx, queries.as_ptr() as *const [u8; 64], nq, num as u32, out.as_mut_ptr()) };
+            if st == -1 {
+                // another host-buffer call of this thread took the staging buffer in between: upload again
+                RESIDENT.with(|r| *r.borrow_mut() = None);
+                self.resident(ctx);
+                st = unsafe { hm_knn_targets(ctx, queries.as_ptr() as *const [u8; 64], nq, num as u32, out.as_mut_ptr()) };
+            }
+            st
+        });
+        assert_eq!(st, 0);
+        let keep = num.min(self.targets.len());
+        out.chunks(num).map(|c| c.iter().take(keep)
+            .map(|o| space::Neighbor { index: o.index as usize, distance: o.distance }).collect()).collect()
+    }
 }
 impl<'a> space::Knn for Mi355xLinearKnn<'a> {
     type Ix = usize;
@@ -354,17 +409,7 @@ impl<'a> space::Knn for Mi355xLinearKnn<'a> {
     type KnnIter = Vec<space::Neighbor<u32, usize>>;
     fn knn(&self, query: &BitArray<64>, num: usize) -> Self::KnnIter {
         // cv-sfm asks for 2 when matching frame pairs (lib.rs:3103) and 3 when registering a frame (lib.rs:1474)
-        assert!((1..=3).contains(&num), "the MI355X matcher implements knn(query, k) for k <= 3");
-        let n = self.targets.len() as u32;
-        let mut out = [AkzNeighbor { index: 0, distance: 0 }; 3];
-        let st = with_matcher(n, |ctx| unsafe {
-            hm_knn(ctx, query.bytes() as *const [u8; 64], 1, self.targets.as_ptr() as *const [u8; 64], n, num as u32,
-                   out.as_mut_ptr())
-        });
-        assert_eq!(st, 0);
-        // LinearKnn returns min(num, len) neighbours
-        out.iter().take(num.min(self.targets.len()))
-            .map(|o| space::Neighbor { index: o.index as usize, distance: o.distance }).collect()
+        self.knn_batch(std::slice::from_ref(query), num).pop().unwrap()
     }
     fn nn(&self, query: &BitArray<64>) -> Option<space::Neighbor<u32, usize>> {
         self.knn(query, 2).into_iter().next()

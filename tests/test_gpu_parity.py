@@ -2192,6 +2192,38 @@ def test_the_three_unvendored_arithmetic_orders(gpu, oracle, kitti):
     assert seen[0][2] != seen[4][2] and seen[0][1] == seen[4][1]
 
 
+def test_linear_knn_keeps_its_targets_on_the_device(gpu, oracle):
+    """space::LinearKnn is built once per frame pair and asked once per query (akaze/tests/estimate_pose.rs:82-88).
+    hm_set_targets / hm_knn_targets keep `iter` resident between the questions: per-query answers == the oracle, k = 1..3, a
+    batch of questions in one call == the per-query answers, and a call that overwrites the matcher's staging buffer in between
+    is noticed (AKZ_E_INVALID from the C ABI, a silent re-upload in the host mirror) instead of searching stale data."""
+    _, knn = gpu
+    from cv_amd import _lib
+    rng = np.random.default_rng(0x71)
+    t = _rand_desc(rng, 700); q = _rand_desc(rng, 40)
+    t[10] = t[500] = q[3]                                     # ties: the lowest index wins
+    lk = knn.LinearKnn(knn.Hamming, t)
+    for k in (1, 2, 3):
+        want = oracle.knn(q, t, k)
+        for i in range(len(q)):
+            got = lk.knn(q[i], k)
+            assert [(n.index, n.distance) for n in got] == [(int(want[i, j]["index"]), int(want[i, j]["distance"])) for j in range(k)], (k, i)
+    m = knn.default_matcher(len(t))
+    m.set_targets(t)
+    gb = m.knn_targets(q, 3)
+    wb = oracle.knn(q, t, 3)
+    _eq(gb["index"], wb["index"], "resident batch idx"); _eq(gb["distance"], wb["distance"], "resident batch dist")
+    other = _rand_desc(rng, 300)
+    m.match(q, other)                                         # takes the staging buffer
+    out = np.zeros((1, 2), _lib.NB_DTYPE)
+    assert _lib.lib().hm_knn_targets(m.handle, q.ctypes.data, 1, 2, out.ctypes.data) == -1
+    got = lk.knn(q[0], 2)                                     # the mirror uploads again
+    assert [(n.index, n.distance) for n in got] == [(int(wb[0, j]["index"]), int(wb[0, j]["distance"])) for j in range(2)]
+    # fewer targets than neighbours asked for: min(k, len) come back
+    small = knn.LinearKnn(knn.Hamming, t[:2])
+    assert len(small.knn(q[0], 3)) == 2
+
+
 def test_new_entry_points_refuse_what_they_cannot_do(gpu):
     """Round-3 entry points answer with a status, never with a wrong result: the batched consensus (scenes beyond the
     reservation, unknown flags, a shuffle that would not fit its LDS sort, a stale parameter struct), the colour arm

@@ -6,7 +6,9 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 N=$1; SRC=$2; shift 2
 mkdir -p $R/gpurun_variants/$N
-O=$R/gpurun_variants/$N/$(basename $SRC | tr . _).o
+# (akz_scale_space.hip exists once per arithmetic combination, cv_amd/build.py: the experiment replaces the default copy)
+TAG=""; [ "$SRC" == "akz_scale_space.hip" ] && TAG="_a0"
+O=$R/gpurun_variants/$N/$(basename $SRC | tr . _)$TAG.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt "$@" -x hip -c $R/cv_amd/csrc/$SRC -o $O
 OBJS=""
 for f in $R/cv_amd/lib/*.o; do
