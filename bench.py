@@ -43,7 +43,7 @@ W, H = 1920, 1080
 FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r03"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
+PROFILE_TAG = "r04"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
 PROFILE_TAG_RANSAC = "r04"   # profiles/<tag>_pmc_ransac.json (tools/pmc_ransac.sh)
 FED_BYTES_PER_PIXEL_STEP = 12.0
 CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage

@@ -1994,7 +1994,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     // contexts created for more than kActCap keypoints per frame: a frame whose active list outgrows the LDS starts over in
     // k_suppress_big (its list: d_big_act, max_kp entries per frame)
     const bool big_pass = c->max_kp > (uint32_t)kActCap;
-    if (big_pass) AKZ_HIP(hipMemsetAsync(S.d_big_flag, 0, sizeof(uint32_t) * (size_t)n, s));
+    if (big_pass && !c->sup_parallel) AKZ_HIP(hipMemsetAsync(S.d_big_flag, 0, sizeof(uint32_t) * (size_t)n, s));   // (else: cleared with the flags above)
     hipLaunchKernelGGL(k_suppress, dim3(n), dim3(64), sizeof(ActEntry) * kActCap, s, T, S.d_ncand,
                        S.d_cand, c->max_cand, S.d_cache, c->max_kp, S.d_ncache, c->d_err,
                        c->sup_parallel ? (const uint32_t*)S.d_sup_flag : (const uint32_t*)nullptr, S.d_lvl_slot,

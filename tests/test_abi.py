@@ -121,13 +121,13 @@ def test_gaussian_kernel_host_entry(lib):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r02_bench.json is the JSON line bench.py printed on the MI355X: the driver's keys, the roofline object
-    of the run's dominant kernel family (a fraction of the HBM peak, so <= 1), the same for the top four, the parity
+    """profiles/r04_bench.json is the JSON line bench.py printed on the MI355X: the driver's keys, the roofline object
+    of the run's dominant kernel family (its own roofline fraction, so <= 1), the same for the top five, the parity
     check against the oracle, the extra BASELINE configs and the bounded CPU baseline must all be there."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r02_bench.json")) as f:
+    with open(os.path.join(root, "profiles", "r04_bench.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_top", "cpu_baseline", "parity_checked",
@@ -136,17 +136,32 @@ def test_committed_bench_line_follows_the_contract():
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     for r in [d["roofline"]] + d["roofline_top"]:
-        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_is", "rank_ms_per_step"):
             assert k in r, k
-        assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
+        # frac is ALWAYS the family's own roofline fraction (bytes / 8 TB/s; MFMA ops / 10 PF for the matcher) — the VALU
+        # issue fraction sits beside it as valu_frac and `bound` names the larger of the two
+        assert r["bound"] in ("hbm", "valu", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
+        assert (r["unit"], r["peak"]) in (("GB/s", 8000.0), ("TOP/s", 10000.0))
+        if r["unit"] == "GB/s":
+            assert r["frac"] == r["hbm_frac"]
+            if r["bound"] == "valu":
+                assert r["valu_frac"] > r["hbm_frac"]
         if r["traffic"] is not None:       # counters were taken at this micro-batch; the kernel moves >= its algorithmic bytes
             assert r["traffic_source"]["micro_batch"] == d["config"]["micro_batch"]
             assert r["traffic"] >= 0.98 * r["algorithmic_bytes_per_launch"]
     assert d["roofline"]["kernel"] == d["roofline_top"][0]["kernel"]
-    assert d["roofline_top"][0]["gpu_ms"] >= d["roofline_top"][1]["gpu_ms"]
+    ranks = [r["rank_ms_per_step"] for r in d["roofline_top"]]
+    assert ranks == sorted(ranks, reverse=True)                 # ordered by time per step with the GPU to itself
+    assert any(r["bound"] == "mfma" for r in d["roofline_top"])  # the matcher is one of the families
     assert d["parity_checked"]["mismatches"] == 0 and d["parity_checked"]["frames"] >= 2
     for cfg in ("configs[2]", "configs[3]"):
         assert d["configs_extra"][cfg]["parity"]["mismatches"] == 0 and "roofline" in d["configs_extra"][cfg]
+    assert 0 < d["configs_extra"]["configs[3]"]["roofline"]["frac"] <= 1.0            # FP64 issue fraction from committed counters
+    reg = d["configs_extra"]["pipeline+register"]
+    assert reg["parity"]["mismatches"] == 0 and reg["registered_frames_per_s"] > 500 and reg["frames_with_a_model"] == d["config"]["frames_per_gpu_per_step"]
+    crit = d["configs_extra"]["criterion"]
+    assert crit["mismatches"] == 0 and set(crit["rows"]) >= {"extract", "horizontal_filter_small_kernel", "vertical_filter_large_kernel"}
+    assert d["cpu_baseline_intra_frame"]["value"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 2000.0          # BASELINE.json's target for one MI355X
