@@ -46,8 +46,12 @@ def make_case(i, seed, arms=False):
 
 
 def oracle_case(args):
-    i, seed, arms = args
+    i, seed, arms, arith = args
     from oracle import oracle as O
+    # the three un-vendored arithmetic orders (include/akz.h AKZ_ARITH_*): the oracle's switches follow akz_options.arith
+    O.set_option(O.OPT_REDUCE, arith & 1)
+    O.set_option(O.OPT_FMA, (arith >> 1) & 1)
+    O.set_option(O.OPT_HALFSUM, (arith >> 2) & 1)
     w, h, thr, img = make_case(i, seed, arms)
     if img.ndim == 3:
         img = O.luma(img)                       # DynamicImage::grayscale(), then the gray arm of its type
@@ -68,7 +72,7 @@ def main():
     O.build()
     ctx = mp.get_context("spawn")
     with ctx.Pool(a.procs) as pool:
-        want = {r[0]: r[1:] for r in pool.map(oracle_case, [(i, a.seed, a.arms) for i in range(a.n)], chunksize=1)}
+        want = {r[0]: r[1:] for r in pool.map(oracle_case, [(i, a.seed, a.arms, kw.get("arith", 0)) for i in range(a.n)], chunksize=1)}
     from cv_amd import build
     build.build()
     from cv_amd import _lib, akaze
