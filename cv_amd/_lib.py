@@ -125,7 +125,7 @@ ABI_SYMBOLS = [
     "akz_extract_gray_f32", "akz_extract_color",
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_last_overflow", "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
-    "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
+    "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_debug_orientation_masks", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_knn_batch_device", "hm_best_of_views_device", "hm_best_of_views_batch_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
@@ -185,6 +185,7 @@ def lib():
     L.akz_debug_get_contrast.argtypes = [vp, i32, C.POINTER(C.c_double)]
     L.akz_debug_get_keypoints.argtypes = [vp, i32, i32, vp, u32, C.POINTER(u32)]
     L.akz_debug_portable_math.argtypes = [vp, i32, vp, vp, u32, vp]
+    L.akz_debug_orientation_masks.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.akz_gaussian_kernel.argtypes = [C.c_float, u32, vp]
     L.akz_horizontal_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]
     L.akz_vertical_filter.argtypes = [vp, vp, i32, i32, vp, u32, vp]

@@ -1646,10 +1646,115 @@ __global__ __launch_bounds__(256) void k_refine_pos(LevelTable T, const DevKp* _
     flag[(size_t)frame * stride + ki] = keep ? 1u : 0u;
 }
 
+// ---- helpers of k_orient_describe -------------------------------------------------------------------------------
+// roundf(v) for the sample coordinates without roundf's compare-and-select sequence: for every f32 v >= 0,
+// floor(v + 0.49999997f) == roundf(v) (0.49999997f = 0x3EFFFFFF, the largest f32 below 0.5: adding 0.5 itself would
+// round 0.49999997 up to 1; tests/test_oracle_math.py walks every f32 of [2^-4, 2^25) against the definition), and for
+// v < 0 the sum is negative exactly when v <= -0.5, i.e. when roundf(v) <= -1.
+// `f32 as usize` of the rounded value (negatives and NaN -> 0): v_cvt_u32_f32 truncates toward zero and saturates.
+__device__ __forceinline__ unsigned round_sat_u32(float v)
+{
+    unsigned r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v + 0.49999997f));
+    return r;
+}
+// `f32 as isize` of the rounded value where only "inside [0, n)" matters: any v <= -0.5 gives a negative result (not
+// necessarily roundf's), NaN gives 0 as Rust's cast does, the infinities saturate.
+__device__ __forceinline__ int round_flr_i32(float v)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v + 0.49999997f));
+    return r;
+}
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_max_i32(int v)   // max(v, the DPP-selected lane's v); lanes without a source keep v
+{
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+
+// Number of window end points below `ang` (OriTables::bnd, 128 sorted entries padded with +inf): 0..127.
+__device__ __forceinline__ int ori_rank(const float* s_bnd, float ang)
+{
+    int r = 0;
+#pragma unroll
+    for (int step = 64; step > 0; step >>= 1) r += s_bnd[r + step - 1] < ang ? step : 0;
+    return r;
+}
+
+// The angle of compute_main_orientation (scale_space_extrema.rs:242) is only ever COMPARED with the windows' end points,
+// and evaluating it exactly (akz_pm_atan2f: f64, two divisions) for 109 samples per keypoint was a quarter of the
+// kernel's instructions.  So: an f32 estimate (one v_rcp_f32, a degree-15 odd polynomial; within 7.2e-7 of the exact
+// value over 4 M random and adversarial inputs, tools/fit_atan.py) places the sample among the end points, and whenever
+// the estimate lies within kOriEps = 8e-6 (11 x that error) of an end point — or the operands are outside the range the
+// estimate is good for, or anything is NaN — the exact expression decides instead.  Both 0 and 2 pi are end points, so the
+// wrap of rem_euclid is covered by the same band.  (0, +x): exactly 0 in the reference, and common (flat areas, vertical
+// edges): taken without the fallback.  Returns the membership bits (bit = window).
+constexpr float kOriEps = 8e-6f;
+__device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const float* s_bnd, const uint2* s_mopen, const uint2* s_meq,
+                                                  bool* fell_back)
+{
+    const float ax = fabsf(rx), ay = fabsf(ry);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float p = -0.004668773151934147f;
+    p = __builtin_fmaf(p, s, 0.02416618913412094f);
+    p = __builtin_fmaf(p, s, -0.0593671016395092f);
+    p = __builtin_fmaf(p, s, 0.09906096756458282f);
+    p = __builtin_fmaf(p, s, -0.14016585052013397f);
+    p = __builtin_fmaf(p, s, 0.19969235360622406f);
+    p = __builtin_fmaf(p, s, -0.33331960439682007f);
+    p = __builtin_fmaf(p, s, 0.9999998807907104f);
+    float a = t * p;
+    a = ay > ax ? 1.57079637050628662109f - a : a;
+    a = __builtin_signbit(rx) ? 3.14159274101257324219f - a : a;
+    a = __builtin_signbit(ry) ? 6.28318548202514648438f - a : a;
+    const bool zero_known = ry == 0.0f && __float_as_uint(rx) <= 0x7F800000u;   // x = +0 .. +inf (not -0, not NaN)
+    float ang = zero_known ? 0.0f : a;
+    int r = ori_rank(s_bnd, ang);
+    float b1 = s_bnd[r];
+    const float b0 = s_bnd[r > 0 ? r - 1 : 0];
+    // (ax < 1e30 && ay < 1e30 rather than mx < 1e30: v_max_f32 drops a NaN operand)
+    const bool sure = zero_known || (mx > 1e-30f && ax < 1e30f && ay < 1e30f && fabsf(ang - b1) > kOriEps && fabsf(ang - b0) > kOriEps);
+    if (!sure) {
+        ang = fast_atan2_equiv(ry, rx);
+        r = ori_rank(s_bnd, ang);
+        b1 = s_bnd[r];
+    }
+    if (fell_back) *fell_back = !sure;
+    return b1 == ang ? s_meq[r] : s_mopen[r];
+}
+
 // A14 + A16 + A17 for the default pattern: main orientation (as in k_refine), then the descriptor (as in
 // k_describe_fast), one wave per keypoint, four keypoints per block (the orientation tables are staged once per
-// block).  The wave's LDS segment is used twice: weighted gradients and window masks of the 109 orientation samples,
-// then the 441 lattice values of the descriptor.  The angle is written back into the keypoint list.
+// block).  The wave's LDS segment is used twice: weighted gradients of the 109 orientation samples, then the 441 lattice
+// values of the descriptor.  The angle is written back into the keypoint list.
+//
+// Round 4 (the kernel is the largest VALU consumer of the pipeline: 1 900 instructions per keypoint before):
+//   * window membership from an f32 estimate of the angle, the exact f64 expression only inside a band around the
+//     windows' end points (ori_sample_masks);
+//   * the 42 window sums run with the sample's membership bits AS the execution mask: sample k's 64-bit mask goes from
+//     its owner lane to an SGPR pair (v_readlane), `s_mov exec` and one v_pk_add_f32 add {Lx, Ly} in exactly the lanes
+//     (windows) that contain it — 3 VALU instructions per sample instead of 5 (bit test, compare, two selects, add), and
+//     a sample outside a window is skipped as the reference skips it;
+//   * the window maximum by DPP row operations;
+//   * the descriptor lattice as 7 rounds of 3 rows x 21 columns (lane 63 idle): the lane's column term and the integer
+//     division leave the loop; coordinates rounded by round_flr_i32.
+// Experiment builds only (-DAKZ_OD_PROF, tools/build_variant.sh; never in the product library): lane 0 of every sampled
+// wave stamps s_memtime at the phase boundaries below (after waiting for its outstanding memory operations).
+#ifdef AKZ_OD_PROF
+constexpr int kODProfStamps = 8, kODProfCap = 1 << 17;
+__device__ unsigned long long g_od_prof[(size_t)kODProfCap * kODProfStamps];
+__device__ unsigned int g_od_prof_n;
+#define OD_STAMP(i)                                                                                     \
+    do {                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+        if (od_slot >= 0 && lane == 0) g_od_prof[(size_t)od_slot * kODProfStamps + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define OD_STAMP(i) do { } while (0)
+#endif
 constexpr int kODWaves = 4;
 __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
                                                                    const DescTables* __restrict__ desc_p,
@@ -1659,7 +1764,8 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
                                                                    akz_descriptor* __restrict__ out,
                                                                    uint32_t* __restrict__ flag, uint32_t* __restrict__ err)
 {
-    constexpr int LAT = 21, NS = LAT * LAT, NIT = (NS + 63) / 64, SMAX = 448;
+    constexpr int LAT = 21, NS = LAT * LAT, NIT = 7, SMAX = 448;
+    typedef float v2f __attribute__((ext_vector_type(2)));
     __shared__ float s_bnd[128];
     __shared__ uint2 s_mopen[128], s_meq[128];
     __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 96];
@@ -1677,6 +1783,16 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     const uint32_t n = min(n_in[frame], stride);
     const uint32_t vi = blk.x * kODWaves + wv;
     if (vi >= n) return;  // whole wave
+#ifdef AKZ_OD_PROF
+    int od_slot = -1;
+    {
+        unsigned q = 0;
+        if (lane == 0) q = atomicAdd(&g_od_prof_n, 1u);
+        q = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+        od_slot = q < (unsigned)kODProfCap ? (int)q : -1;
+    }
+#endif
+    OD_STAMP(0);
     const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
     DevKp kp = kps[(size_t)frame * stride + ki];
     const LevelDesc& L = T.L[kp.class_id];
@@ -1684,56 +1800,68 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     const float xf = kp.x / ratio, yf = kp.y / ratio;
     const float2* LXY = L.Lxy + (size_t)frame * L.fs;
     const int W = L.w, Hh = L.h;
+    const float scale = roundf(0.5f * kp.size / ratio);     // scale_space_extrema.rs:236 and descriptors.rs:69: the same value
+    OD_STAMP(1);
     // ---- compute_main_orientation, scale_space_extrema.rs:229-288 ----
     {
-        float2* s_r = reinterpret_cast<float2*>(s_w[wv]);             // [112] weighted {Lx, Ly} of every sample
-        uint32_t* s_msk = reinterpret_cast<uint32_t*>(s_w[wv] + 224);   // [112][2] windows that contain its angle
-        const float s = roundf(0.5f * kp.size / ratio);
-        for (int idx = lane; idx < 109; idx += 64) {
-            unsigned iy = sat_u32(roundf(yf + (float)c_ori.dj[idx] * s));
-            unsigned ix = sat_u32(roundf(xf + (float)c_ori.di[idx] * s));
+        float2* s_r = reinterpret_cast<float2*>(s_w[wv]);             // [128] weighted {Lx, Ly} of every sample
+        uint2 msk[2];                                                  // membership bits of samples lane and 64 + lane
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 64 + lane;
+            const bool on = idx < 109;
+            const int ii = on ? idx : 0;
+            unsigned iy = round_sat_u32(yf + (float)c_ori.dj[ii] * scale);
+            unsigned ix = round_sat_u32(xf + (float)c_ori.di[ii] * scale);
             if (ix >= (unsigned)W || iy >= (unsigned)Hh) {  // the reference would panic here
                 atomicOr(err, 8u);
                 ix = min(ix, (unsigned)W - 1u);
                 iy = min(iy, (unsigned)Hh - 1u);
             }
-            const float g = c_ori.gw[idx];
+            const float g = c_ori.gw[ii];
             const float2 dxy = LXY[(size_t)iy * W + ix];
             const float rx = g * dxy.x;
             const float ry = g * dxy.y;
             s_r[idx] = make_float2(rx, ry);
             // window membership of this sample (:261-287) from the end-point table (see k_refine)
-            const float ang = fast_atan2_equiv(ry, rx);
-            int r = 0;
+            const uint2 mm = ori_sample_masks(ry, rx, s_bnd, s_mopen, s_meq, nullptr);
+            msk[it] = on ? mm : make_uint2(0u, 0u);
+        }
+        OD_STAMP(2);
+        // sums of the windows, lane <-> window, samples in the reference's order
+        v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
 #pragma unroll
-            for (int step = 64; step > 0; step >>= 1) r += s_bnd[r + step - 1] < ang ? step : 0;
-            const uint2 mm = (r < 128 && s_bnd[r & 127] == ang) ? s_meq[r & 127] : s_mopen[r & 127];
-            s_msk[idx * 2] = mm.x;
-            s_msk[idx * 2 + 1] = mm.y;
+        for (int k = 0; k < 109; ++k) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)msk[k >> 6].x, k & 63);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)msk[k >> 6].y, k & 63);
+            const unsigned long long m64 = ((unsigned long long)hi << 32) | lo;
+            const float2 rk = s_r[k];
+            const v2f rv = {rk.x, rk.y};
+            unsigned long long saved;
+            asm("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_pk_add_f32 %[s], %[s], %[r]\n\ts_mov_b64 exec, %[sv]"
+                : [s] "+v"(sum), [sv] "=&s"(saved)
+                : [m] "s"(m64), [r] "v"(rv));
         }
-        float val = -1.0f, sum_x = 0.0f, sum_y = 0.0f;
-        if (lane < c_ori.n_win) {
-            // branch-free: a sample outside the window adds +0.0, which leaves the sums bit-identical to skipping it
-            const int word = lane >> 5, bit = lane & 31;
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
-#pragma unroll 4
-            for (int k = 0; k < 109; ++k) {
-                const bool in = (s_msk[k * 2 + word] >> bit) & 1u;
-                const float2 r = s_r[k];
-                sum += (v2f){in ? r.x : 0.0f, in ? r.y : 0.0f};
-            }
-            sum_x = sum.x;
-            sum_y = sum.y;
-            val = sum_x * sum_x + sum_y * sum_y;
-        }
-        // the serial loop keeps the FIRST window whose val exceeds every earlier one
-        float m = val;
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        unsigned long long bal = __ballot(val == m && lane < c_ori.n_win);
-        int win = __ffsll((long long)bal) - 1;
-        float best_sx = __shfl(sum_x, win), best_sy = __shfl(sum_y, win);
-        kp.angle = (m > 0.0f) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
+        OD_STAMP(3);
+        const float sum_x = sum.x, sum_y = sum.y;
+        const float val = sum_x * sum_x + sum_y * sum_y;
+        // the serial loop keeps the FIRST window whose val exceeds every earlier one (a NaN never does).  val >= +0, so its
+        // bit pattern orders as an integer; lanes beyond the windows and NaNs enter as -1
+        const bool is_win = lane < c_ori.n_win && val == val;
+        const int vbits = is_win ? __float_as_int(val) : -1;
+        int mr = vbits;
+        mr = dpp_max_i32<0xB1>(mr);            // quad_perm [1,0,3,2]
+        mr = dpp_max_i32<0x4E>(mr);            // quad_perm [2,3,0,1]
+        mr = dpp_max_i32<0x141>(mr);           // row_half_mirror
+        mr = dpp_max_i32<0x140>(mr);           // row_mirror: every lane of a row of 16 holds the row's maximum
+        mr = dpp_max_i32<0x142, 0xa>(mr);      // row_bcast:15 into rows 1 and 3
+        mr = dpp_max_i32<0x143, 0xc>(mr);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+        const int mbits = __builtin_amdgcn_readlane(mr, 63);
+        const unsigned long long bal = __ballot(is_win && vbits == mbits);
+        const int win = bal ? __ffsll((long long)bal) - 1 : 0;
+        const float best_sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_x), win));
+        const float best_sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_y), win));
+        kp.angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
         if (lane == 0) kps[(size_t)frame * stride + ki].angle = kp.angle;
     }
     // the segment changes hands: every LDS read above has returned before the writes below are issued
@@ -1743,26 +1871,37 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     float* s_dx = s_w[wv] + SMAX;
     float* s_dy = s_w[wv] + 2 * SMAX;
     float* s_val = s_w[wv] + 3 * SMAX;
-    const float scale = roundf(0.5f * kp.size / ratio);
     const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
     const float* LT = L.Lt + (size_t)frame * L.fs;
     bool oob = false;
-    int idx[NIT], canon[NIT];
+    int idx[NIT];
+    OD_STAMP(4);
+    // Lattice sample (k, l) sits at (xf + (-l*si*scale + k*co*scale), yf + (l*co*scale + k*si*scale)), descriptors.rs:127-128.
+    // Consecutive lanes take consecutive samples along the lattice axis whose image-space step is the more HORIZONTAL one
+    // (k steps by scale * (co, si), l by scale * (-si, co)): the lanes of a quad then fall on the same row and mostly the
+    // same cache line (wave-uniform choice).  A round is 3 lines of 21 samples along that axis: the lane's position on the
+    // line (its term of both sums) is fixed, the line advances by 3 per round.
     const bool k_fast = fabsf(co) > fabsf(si);
+    const bool on = lane < 63;
+    const int line0 = lane / LAT, pos = lane - line0 * LAT;
+    const float fpos = (float)(pos - 10);
+    // k_fast: k = pos, l = line:  y = yf + ((l*co)*scale + (k*si)*scale),  x = xf + (((-l)*si)*scale + (k*co)*scale)
+    // else:   l = pos, k = line:  the same expressions with the roles swapped; a + b == b + a, (-l)*si == l*(-si)
+    const float cy = k_fast ? co : si;                    // factor of the line number in y
+    const float cx = k_fast ? -si : co;                   //                      ... in x
+    const float fix_y = k_fast ? fpos * si * scale : fpos * co * scale;
+    const float fix_x = k_fast ? fpos * co * scale : -fpos * si * scale;
+    // position in the (k outer, l inner) lattice the sums walk
+    const int canon0 = k_fast ? pos * LAT + line0 : line0 * LAT + pos;
+    const int cstep = k_fast ? 3 : 3 * LAT;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int s = it * 64 + lane;
-        const bool on = s < NS;
-        const int qa = s / LAT, qb = s - qa * LAT;
-        const int kq = k_fast ? qb : qa, lq = k_fast ? qa : qb;
-        canon[it] = kq * LAT + lq;                       // position in the (k outer, l inner) lattice the sums walk
-        const float kf = (float)(kq - 10), lf = (float)(lq - 10);
-        // descriptors.rs:127-128, exact expression order
-        float sample_y = yf + (lf * co * scale + kf * si * scale);
-        float sample_x = xf + (-lf * si * scale + kf * co * scale);
-        int y1 = sat_i32(roundf(sample_y));
-        int x1 = sat_i32(roundf(sample_x));
-        bool bad = x1 < 0 || x1 >= W || y1 < 0 || y1 >= Hh;
+        const float fl = (float)(line0 + 3 * it - 10);
+        const float sample_y = yf + (fl * cy * scale + fix_y);
+        const float sample_x = xf + (fl * cx * scale + fix_x);
+        const int y1 = round_flr_i32(sample_y);
+        const int x1 = round_flr_i32(sample_x);
+        const bool bad = (unsigned)x1 >= (unsigned)W || (unsigned)y1 >= (unsigned)Hh;
         oob |= on && bad;   // Error::SampleOutOfBounds in any grid drops the keypoint (descriptors.rs:28)
         idx[it] = (on && !bad) ? y1 * W + x1 : 0;
     }
@@ -1775,21 +1914,23 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int s = it * 64 + lane;
         float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
         float rrx = -dd[it].x * si + dd[it].y * co;
-        if (s < NS) {
-            s_ri[canon[it]] = ri[it];
-            s_dx[canon[it]] = rrx;
-            s_dy[canon[it]] = rry;
+        if (on) {
+            const int canon = canon0 + it * cstep;
+            s_ri[canon] = ri[it];
+            s_dx[canon] = rrx;
+            s_dy[canon] = rry;
         }
     }
     oob = __any(oob);
+    OD_STAMP(5);
     if (!oob) {
         desc_cells<10, 2, 0>(s_ri, s_dx, s_dy, s_val, lane);
         desc_cells<7, 3, 12>(s_ri, s_dx, s_dy, s_val, lane);
         desc_cells<5, 4, 39>(s_ri, s_dx, s_dy, s_val, lane);
     }
+    OD_STAMP(6);
     // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
     uint32_t byte = 0;
     if (!oob) {
@@ -1803,6 +1944,7 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     }
     out[(size_t)frame * stride + ki].bytes[lane] = (uint8_t)byte;
     if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
+    OD_STAMP(7);
 }
 
 void build_level_table(akz_ctx* c, LevelTable* T)
@@ -1825,6 +1967,24 @@ void build_level_table(akz_ctx* c, LevelTable* T)
 }
 
 }  // namespace
+
+#ifdef AKZ_OD_PROF
+extern "C" int32_t akz_debug_od_prof(unsigned long long* out, uint32_t cap_waves, uint32_t* n, int32_t reset)
+{
+    unsigned int cnt = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return AKZ_E_HIP;
+    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_od_prof_n), sizeof(cnt)) != hipSuccess) return AKZ_E_HIP;
+    if (cnt > (unsigned)kODProfCap) cnt = kODProfCap;
+    if (cnt > cap_waves) cnt = cap_waves;
+    if (out && cnt && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_od_prof), (size_t)cnt * kODProfStamps * 8) != hipSuccess) return AKZ_E_HIP;
+    if (n) *n = cnt;
+    if (reset) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_od_prof_n), &z, sizeof(z)) != hipSuccess) return AKZ_E_HIP;
+    }
+    return AKZ_OK;
+}
+#endif
 
 size_t akz_ori_table_bytes() { return sizeof(OriTables); }
 size_t akz_desc_table_bytes() { return sizeof(DescTables); }
@@ -2127,5 +2287,61 @@ extern "C" int32_t akz_debug_portable_math(akz_ctx* c, int32_t which, const floa
         AKZ_HIP(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
         hipFree(dx); hipFree(dy); hipFree(dout);
         return AKZ_OK;
+    });
+}
+
+// ---- parity tap: the orientation samples' window membership, both ways ----
+// fast[i]: ori_sample_masks (the kernel's path: f32 estimate, exact expression inside the band); exact[i]: the exact
+// expression alone; fell[i]: 1 where the band sent the sample to the exact expression.
+__global__ __launch_bounds__(256) void k_debug_ori_masks(const OriTables* __restrict__ ori_p, const float* __restrict__ x,
+                                                         const float* __restrict__ y, uint32_t n, uint2* __restrict__ fast,
+                                                         uint2* __restrict__ exact, uint32_t* __restrict__ fell)
+{
+    __shared__ float s_bnd[128];
+    __shared__ uint2 s_mopen[128], s_meq[128];
+    if (threadIdx.x < 128) {
+        s_bnd[threadIdx.x] = ori_p->bnd[threadIdx.x];
+        s_mopen[threadIdx.x] = ori_p->m_open[threadIdx.x];
+        s_meq[threadIdx.x] = ori_p->m_eq[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool fb = false;
+    fast[i] = ori_sample_masks(y[i], x[i], s_bnd, s_mopen, s_meq, &fb);
+    fell[i] = fb ? 1u : 0u;
+    const float ang = fast_atan2_equiv(y[i], x[i]);
+    const int r = ori_rank(s_bnd, ang);
+    exact[i] = s_bnd[r] == ang ? s_meq[r] : s_mopen[r];
+}
+
+extern "C" int32_t akz_debug_orientation_masks(akz_ctx* c, const float* x, const float* y, uint32_t n, uint64_t* fast,
+                                               uint64_t* exact, uint32_t* fell_back)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !x || !y || !fast || !exact || !fell_back || n == 0) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        float *dx = nullptr, *dy = nullptr;
+        uint2 *df = nullptr, *de = nullptr;
+        uint32_t* dfl = nullptr;
+        int32_t rc = AKZ_OK;
+        if (hipMalloc(&dx, sizeof(float) * n) != hipSuccess || hipMalloc(&dy, sizeof(float) * n) != hipSuccess ||
+            hipMalloc(&df, sizeof(uint2) * n) != hipSuccess || hipMalloc(&de, sizeof(uint2) * n) != hipSuccess ||
+            hipMalloc(&dfl, sizeof(uint32_t) * n) != hipSuccess) {
+            rc = AKZ_E_HIP;
+        } else if (hipMemcpy(dx, x, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess ||
+                   hipMemcpy(dy, y, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = AKZ_E_HIP;
+        } else {
+            hipLaunchKernelGGL(k_debug_ori_masks, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const OriTables*)c->d_ori, dx, dy, n,
+                               df, de, dfl);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+                hipMemcpy(fast, df, sizeof(uint2) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(exact, de, sizeof(uint2) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(fell_back, dfl, sizeof(uint32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = AKZ_E_HIP;
+        }
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(df); (void)hipFree(de); (void)hipFree(dfl);
+        return rc;
     });
 }

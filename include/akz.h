@@ -231,6 +231,14 @@ int32_t akz_debug_get_keypoints(akz_ctx* ctx, int32_t img, int32_t stage, akz_ke
  * (y ignored).  Host buffers.  The tests hold these to the host libm within 1 ulp. */
 int32_t akz_debug_portable_math(akz_ctx* ctx, int32_t which, const float* x, const float* y, uint32_t n, float* out);
 
+/* Window membership of orientation samples (weighted gradient (x[i], y[i]); scale_space_extrema.rs:242-287), bit w = the
+ * sample's angle lies in window w: fast[i] as the descriptor kernel decides it (an f32 estimate of the angle, the exact
+ * expression inside a band around the windows' end points), exact[i] from the exact expression alone, fell_back[i] = 1 where
+ * the band applied.  fast == exact for every input is the kernel's contract; the tests drive this with end points +- a few
+ * ulp, axes, zeros, denormals and huge operands.  Host buffers. */
+int32_t akz_debug_orientation_masks(akz_ctx* ctx, const float* x, const float* y, uint32_t n, uint64_t* fast, uint64_t* exact,
+                                    uint32_t* fell_back);
+
 /* ---- stand-alone image ops (akaze::image public API, akaze/src/image.rs:202-389) ---- */
 /* gaussian_kernel(r, kernel_size) — image.rs:360-374.  Host-only scalar math. */
 int32_t akz_gaussian_kernel(float r, uint32_t kernel_size, float* out);

@@ -1915,6 +1915,69 @@ def test_device_transcendentals_against_the_host_libm(gpu, oracle):
     _eq(si, os_, "device sinf"); _eq(co, oc_, "device cosf")
 
 
+def test_orientation_window_membership_estimate_equals_the_exact_expression(gpu, oracle):
+    """k_orient_describe places every orientation sample among the windows' end points from an f32 ESTIMATE of the angle and
+    evaluates the exact expression (akz_portable_math.h, f64) only when the estimate lies within 8e-6 of an end point
+    (ori_sample_masks).  akz_debug_orientation_masks returns both decisions.  They must agree on: 800 000 random gradients;
+    gradients whose angle is swept in 1e-7 steps through +-2e-5 around EVERY end point (42 window starts, their ends, 0 and
+    2 pi) at several magnitudes; the axes, the diagonals, signed zeros, denormal, huge, infinite and NaN operands.  The
+    exact decision itself is re-derived here from the oracle's atan2 and the reference's window predicate
+    (scale_space_extrema.rs:242-287), and the band must be rare on random input (it is what the kernel saves)."""
+    akaze, _ = gpu
+    from cv_amd import _lib
+    f32 = np.float32
+    ctx = akaze.Akaze.default().context(64, 64, 1)
+    rng = np.random.default_rng(0x0A1)
+    n_rand = 400000
+    mag = 10.0 ** rng.uniform(-8, 3, n_rand)                 # directions uniform on the circle, any magnitude ...
+    y = (rng.standard_normal(n_rand) * mag).astype(f32)
+    x = (rng.standard_normal(n_rand) * mag).astype(f32)
+    wy = (rng.standard_normal(n_rand) * 10.0 ** rng.uniform(-8, 3, n_rand)).astype(f32)   # ... and components decades apart
+    wx = (rng.standard_normal(n_rand) * 10.0 ** rng.uniform(-8, 3, n_rand)).astype(f32)   # (angles hugging the axes)
+    # the windows of the reference: starts by f32 accumulation of 0.15 below 2 pi, width pi / 3, wrapping
+    PI = f32(3.14159274101257324219)
+    starts = []
+    a1 = f32(0.0)
+    while a1 < f32(2.0) * PI:
+        starts.append(a1)
+        a1 = f32(a1 + f32(0.15))
+    assert len(starts) == 42
+    ends = [f32(s - f32(f32(5.0) * PI) / f32(3.0)) if f32(s + PI / f32(3.0)) > f32(2.0) * PI else f32(s + PI / f32(3.0)) for s in starts]
+    pts = np.array(starts + ends + [0.0, float(f32(2.0) * PI)], np.float64)
+    sweep = (pts[:, None] + np.linspace(-2e-5, 2e-5, 401)[None, :]).reshape(-1)
+    xs, ys = [x, wx], [y, wy]
+    for mag in (1.0, 3.7e-4, 251.0):
+        xs.append((np.cos(sweep) * mag).astype(f32)); ys.append((np.sin(sweep) * mag).astype(f32))
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-40, -1e-40, 1e-30, 3e38, -3e38, np.inf, -np.inf, np.nan, 1e-20, 2.5e-7], f32)
+    gx, gy = np.meshgrid(special, special)
+    xs.append(gx.reshape(-1)); ys.append(gy.reshape(-1))
+    d = (rng.standard_normal(20000) * 10.0 ** rng.uniform(-6, 2, 20000)).astype(f32)
+    for sx, sy in ((1, 1), (-1, 1), (1, -1), (-1, -1)):                       # the diagonals, and a hair off them
+        xs.append(sx * d); ys.append(sy * d)
+        xs.append(sx * d); ys.append((sy * d * f32(1.0000001)).astype(f32))
+    x = np.ascontiguousarray(np.concatenate(xs), f32); y = np.ascontiguousarray(np.concatenate(ys), f32)
+    n = len(x)
+    fast = np.zeros(n, np.uint64); exact = np.zeros(n, np.uint64); fell = np.zeros(n, np.uint32)
+    _lib.check(_lib.lib().akz_debug_orientation_masks(ctx.handle, x.ctypes.data, y.ctypes.data, n, fast.ctypes.data, exact.ctypes.data,
+                                                      fell.ctypes.data), "akz_debug_orientation_masks")
+    bad = np.nonzero(fast != exact)[0]
+    assert len(bad) == 0, [(float(x[i]), float(y[i]), hex(int(fast[i])), hex(int(exact[i])), int(fell[i])) for i in bad[:5]]
+    assert fell[:n_rand].mean() < 1e-3, fell[:n_rand].mean()                 # the band is rare on directions at random ...
+    assert fell[2 * n_rand:2 * n_rand + 3 * len(sweep)].mean() > 0.3          # ... and is what the sweeps exercise
+    # the exact decision, independently: (atan2 + 2 pi) mod 2 pi in f32, then the reference's predicate per window
+    fin = np.isfinite(x) & np.isfinite(y)
+    xa, ya = x[fin], y[fin]
+    two_pi = f32(2.0) * PI
+    a = (oracle.pm_atan2f(ya, xa) + two_pi).astype(f32)
+    ang = np.where(a >= two_pi, (a - two_pi).astype(f32), a)
+    want = np.zeros(len(xa), np.uint64)
+    for wd, (s, e) in enumerate(zip(starts, ends)):
+        inside = ((s < e) & (s < ang) & (ang < e)) | ((e < s) & (((ang > 0) & (ang < e)) | ((ang > s) & (ang < two_pi))))
+        want |= inside.astype(np.uint64) << np.uint64(wd)
+    assert (want == exact[fin]).all()
+    ctx.close()
+
+
 def test_comm_c_abi_on_one_rank(gpu):
     """akz_comm_* (include/akz.h: the exchange step through the library itself, RCCL loaded with dlopen): a communicator of
     ONE rank on the GPU — the ring shift is a send to oneself, the all-gather a copy — so the RCCL branch of the N > 1

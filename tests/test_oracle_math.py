@@ -108,3 +108,23 @@ def test_bicubic_colour_sampling_matches_float32_restatement(oracle):
         assert tuple(got[i]) == tuple(want), (i, got[i], want)
     for i in range(10):
         assert tuple(got[i]) == tuple(rgb[int(kps["y"][i]), int(kps["x"][i])])
+
+
+def test_round_half_away_by_one_add_and_floor():
+    """k_orient_describe rounds its sample coordinates as floor(v + 0.49999997f) (one add, one convert) instead of roundf's
+    compare-and-select sequence (cv_amd/csrc/akz_keypoints.hip: round_flr_i32 / round_sat_u32).  The identity
+    floor(v (+) c) == roundf(v), c = 0x3EFFFFFF, holds for every f32 v >= 0: walked here over every f32 of the binades where
+    the fraction matters most ([0.25, 16) and [2^22, 2^25)) and a stride of the ones between; below 0.25 the sum stays under
+    1, above 2^24 every f32 is an integer and the sum rounds back to it.  For v < 0 the kernel only needs the sign: the sum
+    is negative exactly when v <= -0.5."""
+    c = np.float32(0.49999997)
+    assert c.view(np.uint32) == 0x3EFFFFFF
+    for e in range(-4, 26):
+        dense = -2 <= e <= 3 or e >= 22
+        m = np.arange(0, 1 << 23, 1 if dense else 61, dtype=np.uint32)
+        v = (np.uint32((e + 127) << 23) | m).view(np.float32)
+        got = np.floor(v + c).astype(np.float64)                       # f32 add (round to nearest even), floor
+        want = np.floor(v.astype(np.float64) + 0.5)                    # roundf for v >= 0: the f64 sum is exact
+        assert (got == want).all(), e
+    neg = -np.concatenate([np.linspace(0, 1, 100001), [0.5, 0.49999997, 0.50000006, 0.25]]).astype(np.float32)
+    assert (((neg + c) < 0) == (neg <= np.float32(-0.5))).all()
