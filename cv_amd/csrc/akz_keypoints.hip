@@ -1498,6 +1498,25 @@ __device__ __forceinline__ void desc_cells(const float* s_ri, const float* s_dx,
     s_val[VBASE + cell * 3 + ch] = acc / (float)(ST * ST);
 }
 
+// The same, returning the mean instead of storing it (k_orient_describe keeps the three grids' means in registers until
+// the lattice planes are dead and stores them over the planes).
+template <int ST, int SIDE>
+__device__ __forceinline__ float desc_cell_mean(const float* s_ri, const float* s_dx, const float* s_dy, int lane)
+{
+    constexpr int LAT = 21;
+    float acc = 0.0f;
+    if (lane < SIDE * SIDE * 3) {
+        const int cell = lane / 3, ch = lane - cell * 3;
+        const int ci = cell / SIDE, cj = cell - ci * SIDE;          // i outer (k), j inner (l): descriptors.rs:117-118
+        const float* src = (ch == 0 ? s_ri : (ch == 1 ? s_dx : s_dy)) + (ci * ST) * LAT + cj * ST;
+#pragma unroll
+        for (int kk = 0; kk < ST; ++kk)
+#pragma unroll
+            for (int ll = 0; ll < ST; ++ll) acc += src[kk * LAT + ll];
+    }
+    return acc / (float)(ST * ST);
+}
+
 // The three grids sample the SAME lattice: sample (k, l) of any grid sits at
 // (xf + (-l*si*scale + k*co*scale), yf + (l*co*scale + k*si*scale)) with integer k, l in [-10, 10] (the 3x3 grid
 // of step 7 reaches +10, the other two stop at +9), so the 21 x 21 = 441 lattice values are gathered ONCE
@@ -1691,7 +1710,7 @@ __device__ __forceinline__ int ori_rank(const float* s_bnd, float ang)
 // wrap of rem_euclid is covered by the same band.  (0, +x): exactly 0 in the reference, and common (flat areas, vertical
 // edges): taken without the fallback.  Returns the membership bits (bit = window).
 constexpr float kOriEps = 8e-6f;
-__device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const float* s_bnd, const uint2* s_mopen, const uint2* s_meq,
+__device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const float* s_bnd, const uint2* s_mopen, const uint2* meq,
                                                   bool* fell_back)
 {
     const float ax = fabsf(rx), ay = fabsf(ry);
@@ -1723,7 +1742,9 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
         b1 = s_bnd[r];
     }
     if (fell_back) *fell_back = !sure;
-    return b1 == ang ? s_meq[r] : s_mopen[r];
+    uint2 mm = s_mopen[r];
+    if (b1 == ang) mm = meq[r];          // the angle IS an end point (rare: this table stays in global memory)
+    return mm;
 }
 
 // A14 + A16 + A17 for the default pattern: main orientation (as in k_refine), then the descriptor (as in
@@ -1731,7 +1752,9 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
 // block).  The wave's LDS segment is used twice: weighted gradients of the 109 orientation samples, then the 441 lattice
 // values of the descriptor.  The angle is written back into the keypoint list.
 //
-// Round 4 (the kernel is the largest VALU consumer of the pipeline: 1 900 instructions per keypoint before):
+// Round 4 (the kernel is the largest VALU consumer of the pipeline — 1 900 instructions per keypoint before — and, behind
+// that, a chain of dependent memory round trips: count -> permutation -> keypoint record -> sample offsets -> orientation
+// samples -> ... -> lattice samples -> comparison tables -> store, with six waves per SIMD to hide it):
 //   * window membership from an f32 estimate of the angle, the exact f64 expression only inside a band around the
 //     windows' end points (ori_sample_masks);
 //   * the 42 window sums run with the sample's membership bits AS the execution mask: sample k's 64-bit mask goes from
@@ -1740,23 +1763,30 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
 //     a sample outside a window is skipped as the reference skips it;
 //   * the window maximum by DPP row operations;
 //   * the descriptor lattice as 7 rounds of 3 rows x 21 columns (lane 63 idle): the lane's column term and the integer
-//     division leave the loop; coordinates rounded by round_flr_i32.
-// Experiment builds only (-DAKZ_OD_PROF, tools/build_variant.sh; never in the product library): lane 0 of every sampled
-// wave stamps s_memtime at the phase boundaries below (after waiting for its outstanding memory operations).
-#ifdef AKZ_OD_PROF
-constexpr int kODProfStamps = 8, kODProfCap = 1 << 17;
-__device__ unsigned long long g_od_prof[(size_t)kODProfCap * kODProfStamps];
-__device__ unsigned int g_od_prof_n;
-#define OD_STAMP(i)                                                                                     \
-    do {                                                                                                \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
-        if (od_slot >= 0 && lane == 0) g_od_prof[(size_t)od_slot * kODProfStamps + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define OD_STAMP(i) do { } while (0)
+//     division leave the loop; coordinates rounded by round_flr_i32;
+//   * the per-lane tables (sample offsets, weights, comparison pairs) are requested before the wave's first wait, so no
+//     round trip precedes the comparisons; the cell means overwrite the dead lattice planes and the table for angles that
+//     ARE an end point stays in global memory: 22.7 KB of LDS per block, seven waves per SIMD instead of six (which
+//     measures the same, 5.51 against 5.42 ms per 256 frames: the kernel is no longer waiting on round trips — VALU issue
+//     ~50 %, LDS and the texture path ~30 % each, no unit saturated).
+//   (Built and dropped: a wave walking 4 / 8 / 16 consecutive keypoints with the next keypoint's samples requested behind
+//   the current lattice gather — 7.9 / 9.6 / 10.8 ms per 256 frames against 5.9: the registers the walk carries leave the
+//   scheduler two LDS reads in flight; the keypoint records copied into visiting order and fetched by scalar loads together
+//   with the count, before the barrier — 5.61 / 5.52 ms against 5.45 with the plain count -> permutation -> record chain:
+//   with seven waves per SIMD those round trips are hidden already.  A per-wave LDS segment that is not 8-byte aligned
+//   doubles the kernel's time: the +1 below.)
+#ifndef AKZ_OD_OCC
+#define AKZ_OD_OCC 7
 #endif
 constexpr int kODWaves = 4;
-__global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
+struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
+    float xf, yf, scale;
+    const float* LT;
+    const float2* LXY;
+    int W, Hh;
+    uint32_t ki;         // the keypoint's slot in the response-sorted list (where angle, descriptor and flag go)
+};
+__global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
                                                                    const DescTables* __restrict__ desc_p,
                                                                    DevKp* __restrict__ kps,
                                                                    const uint32_t* __restrict__ n_in, uint32_t stride,
@@ -1764,76 +1794,92 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
                                                                    akz_descriptor* __restrict__ out,
                                                                    uint32_t* __restrict__ flag, uint32_t* __restrict__ err)
 {
-    constexpr int LAT = 21, NS = LAT * LAT, NIT = 7, SMAX = 448;
+    constexpr int LAT = 21, NIT = 7, SMAX = LAT * LAT;
     typedef float v2f __attribute__((ext_vector_type(2)));
+    // LDS: 1.5 KB of tables + 4 x 5 296 B of lattice planes = 22 720 B, seven blocks (seven waves per SIMD) per CU.  The cell
+    // means overwrite the planes once the last sum has read them; the table for angles that ARE an end point stays in global
+    // memory (ori_sample_masks).
     __shared__ float s_bnd[128];
-    __shared__ uint2 s_mopen[128], s_meq[128];
-    __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 96];
+    __shared__ uint2 s_mopen[128];
+    __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 1];     // (+ 1: every wave's segment 16-byte aligned)
     const OriTables& c_ori = *ori_p;
     const DescTables& c_desc = *desc_p;
     if (threadIdx.x < 128) {
         s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
         s_mopen[threadIdx.x] = c_ori.m_open[threadIdx.x];
-        s_meq[threadIdx.x] = c_ori.m_eq[threadIdx.x];
     }
-    __syncthreads();          // the only block-level barrier: waves are independent from here on
+    const uint2* meq = c_ori.m_eq;
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t vi = blk.x * kODWaves + (uint32_t)wv;
+    const size_t fbase = (size_t)frame * stride;
+    __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
     const uint32_t n = min(n_in[frame], stride);
-    const uint32_t vi = blk.x * kODWaves + wv;
     if (vi >= n) return;  // whole wave
-#ifdef AKZ_OD_PROF
-    int od_slot = -1;
-    {
-        unsigned q = 0;
-        if (lane == 0) q = atomicAdd(&g_od_prof_n, 1u);
-        q = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
-        od_slot = q < (unsigned)kODProfCap ? (int)q : -1;
-    }
-#endif
-    OD_STAMP(0);
-    const uint32_t ki = perm[(size_t)frame * stride + vi];  // spatially coherent visiting order
-    DevKp kp = kps[(size_t)frame * stride + ki];
-    const LevelDesc& L = T.L[kp.class_id];
-    const float ratio = (float)(1u << kp.octave);
-    const float xf = kp.x / ratio, yf = kp.y / ratio;
-    const float2* LXY = L.Lxy + (size_t)frame * L.fs;
-    const int W = L.w, Hh = L.h;
-    const float scale = roundf(0.5f * kp.size / ratio);     // scale_space_extrema.rs:236 and descriptors.rs:69: the same value
-    OD_STAMP(1);
+    const uint32_t ki = perm[fbase + vi];  // spatially coherent visiting order
+    const DevKp kp = kps[fbase + ki];
+    const bool on1 = lane + 64 < 109;
+    const int i1 = on1 ? lane + 64 : 0;
+    const float dj0 = (float)c_ori.dj[lane], di0 = (float)c_ori.di[lane], gw0 = c_ori.gw[lane];
+    const float dj1 = (float)c_ori.dj[i1], di1 = (float)c_ori.di[i1], gw1 = c_ori.gw[i1];
+    uint2 cmpa, cmpb;        // value indices compared for the lane's output byte (bits 8 lane .. 8 lane + 7)
+    __builtin_memcpy(&cmpa, &c_desc.cmp_a[lane * 8], 8);
+    __builtin_memcpy(&cmpb, &c_desc.cmp_b[lane * 8], 8);
+    const int n_bits = c_desc.n_bits, n_win = c_ori.n_win;
+    const bool on = lane < 63;
+    const int line0 = lane / LAT, pos = lane - line0 * LAT;
+    const float fpos = (float)(pos - 10);
+    float2* s_r = reinterpret_cast<float2*>(s_w[wv]);             // [128] weighted {Lx, Ly} of every orientation sample
+    float* s_ri = s_w[wv];
+    float* s_dx = s_w[wv] + SMAX;
+    float* s_dy = s_w[wv] + 2 * SMAX;
+    float* s_val = s_w[wv];                                        // [87] the cell means, over the dead planes
+
+    auto load_head = [&]() {
+        ODHead h;
+        h.ki = ki;
+        const LevelDesc& L = T.L[kp.class_id];
+        const float ratio = (float)(1u << kp.octave);
+        h.xf = kp.x / ratio;
+        h.yf = kp.y / ratio;
+        h.scale = roundf(0.5f * kp.size / ratio);   // scale_space_extrema.rs:236 and descriptors.rs:69: the same value
+        h.LT = L.Lt + (size_t)frame * L.fs;
+        h.LXY = L.Lxy + (size_t)frame * L.fs;
+        h.W = L.w;
+        h.Hh = L.h;
+        return h;
+    };
+    const ODHead cur = load_head();
+    // the two orientation samples of this lane (scale_space_extrema.rs:236-241)
+    unsigned iy0 = round_sat_u32(cur.yf + dj0 * cur.scale), ix0 = round_sat_u32(cur.xf + di0 * cur.scale);
+    unsigned iy1 = round_sat_u32(cur.yf + dj1 * cur.scale), ix1 = round_sat_u32(cur.xf + di1 * cur.scale);
+    const bool outside = ix0 >= (unsigned)cur.W || iy0 >= (unsigned)cur.Hh || ix1 >= (unsigned)cur.W || iy1 >= (unsigned)cur.Hh;
+    ix0 = min(ix0, (unsigned)cur.W - 1u); iy0 = min(iy0, (unsigned)cur.Hh - 1u);
+    ix1 = min(ix1, (unsigned)cur.W - 1u); iy1 = min(iy1, (unsigned)cur.Hh - 1u);
+    const size_t o0 = (size_t)iy0 * cur.W + ix0, o1 = (size_t)iy1 * cur.W + ix1;
+    if (outside) atomicOr(err, 8u);        // the reference would panic here
+    const float2 smp0 = cur.LXY[o0], smp1 = cur.LXY[o1];
     // ---- compute_main_orientation, scale_space_extrema.rs:229-288 ----
+    uint2 msk0, msk1;                                              // membership bits of samples lane and 64 + lane
     {
-        float2* s_r = reinterpret_cast<float2*>(s_w[wv]);             // [128] weighted {Lx, Ly} of every sample
-        uint2 msk[2];                                                  // membership bits of samples lane and 64 + lane
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 64 + lane;
-            const bool on = idx < 109;
-            const int ii = on ? idx : 0;
-            unsigned iy = round_sat_u32(yf + (float)c_ori.dj[ii] * scale);
-            unsigned ix = round_sat_u32(xf + (float)c_ori.di[ii] * scale);
-            if (ix >= (unsigned)W || iy >= (unsigned)Hh) {  // the reference would panic here
-                atomicOr(err, 8u);
-                ix = min(ix, (unsigned)W - 1u);
-                iy = min(iy, (unsigned)Hh - 1u);
-            }
-            const float g = c_ori.gw[ii];
-            const float2 dxy = LXY[(size_t)iy * W + ix];
-            const float rx = g * dxy.x;
-            const float ry = g * dxy.y;
-            s_r[idx] = make_float2(rx, ry);
-            // window membership of this sample (:261-287) from the end-point table (see k_refine)
-            const uint2 mm = ori_sample_masks(ry, rx, s_bnd, s_mopen, s_meq, nullptr);
-            msk[it] = on ? mm : make_uint2(0u, 0u);
-        }
-        OD_STAMP(2);
+        const float rx0 = gw0 * smp0.x, ry0 = gw0 * smp0.y;
+        const float rx1 = gw1 * smp1.x, ry1 = gw1 * smp1.y;
+        s_r[lane] = make_float2(rx0, ry0);
+        s_r[lane + 64] = make_float2(rx1, ry1);
+        // window membership of the samples (:261-287) from the end-point table (see k_refine)
+        msk0 = ori_sample_masks(ry0, rx0, s_bnd, s_mopen, meq, nullptr);
+        msk1 = ori_sample_masks(ry1, rx1, s_bnd, s_mopen, meq, nullptr);
+        if (!on1) msk1 = make_uint2(0u, 0u);
+    }
+    float angle;
+    {
         // sums of the windows, lane <-> window, samples in the reference's order
         v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
 #pragma unroll
         for (int k = 0; k < 109; ++k) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)msk[k >> 6].x, k & 63);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)msk[k >> 6].y, k & 63);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.x : msk1.x), k & 63);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.y : msk1.y), k & 63);
             const unsigned long long m64 = ((unsigned long long)hi << 32) | lo;
             const float2 rk = s_r[k];
             const v2f rv = {rk.x, rk.y};
@@ -1842,12 +1888,11 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
                 : [s] "+v"(sum), [sv] "=&s"(saved)
                 : [m] "s"(m64), [r] "v"(rv));
         }
-        OD_STAMP(3);
         const float sum_x = sum.x, sum_y = sum.y;
         const float val = sum_x * sum_x + sum_y * sum_y;
-        // the serial loop keeps the FIRST window whose val exceeds every earlier one (a NaN never does).  val >= +0, so its
-        // bit pattern orders as an integer; lanes beyond the windows and NaNs enter as -1
-        const bool is_win = lane < c_ori.n_win && val == val;
+        // the serial loop keeps the FIRST window whose val exceeds every earlier one (a NaN never does).  val >= +0, so
+        // its bit pattern orders as an integer; lanes beyond the windows and NaNs enter as -1
+        const bool is_win = lane < n_win && val == val;
         const int vbits = is_win ? __float_as_int(val) : -1;
         int mr = vbits;
         mr = dpp_max_i32<0xB1>(mr);            // quad_perm [1,0,3,2]
@@ -1861,30 +1906,23 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
         const int win = bal ? __ffsll((long long)bal) - 1 : 0;
         const float best_sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_x), win));
         const float best_sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_y), win));
-        kp.angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
-        if (lane == 0) kps[(size_t)frame * stride + ki].angle = kp.angle;
+        angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
+        if (lane == 0) kps[fbase + cur.ki].angle = angle;
     }
     // the segment changes hands: every LDS read above has returned before the writes below are issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- get_mldb_descriptor, descriptors.rs:66-72 (as k_describe_fast) ----
-    float* s_ri = s_w[wv];
-    float* s_dx = s_w[wv] + SMAX;
-    float* s_dy = s_w[wv] + 2 * SMAX;
-    float* s_val = s_w[wv] + 3 * SMAX;
-    const float co = akz_pm_cosf(kp.angle), si = akz_pm_sinf(kp.angle);
-    const float* LT = L.Lt + (size_t)frame * L.fs;
+    const float co = akz_pm_cosf(angle), si = akz_pm_sinf(angle);
+    const float scale = cur.scale, xf = cur.xf, yf = cur.yf;
+    const int W = cur.W, Hh = cur.Hh;
     bool oob = false;
     int idx[NIT];
-    OD_STAMP(4);
     // Lattice sample (k, l) sits at (xf + (-l*si*scale + k*co*scale), yf + (l*co*scale + k*si*scale)), descriptors.rs:127-128.
-    // Consecutive lanes take consecutive samples along the lattice axis whose image-space step is the more HORIZONTAL one
-    // (k steps by scale * (co, si), l by scale * (-si, co)): the lanes of a quad then fall on the same row and mostly the
-    // same cache line (wave-uniform choice).  A round is 3 lines of 21 samples along that axis: the lane's position on the
-    // line (its term of both sums) is fixed, the line advances by 3 per round.
+    // Consecutive lanes take consecutive samples along the lattice axis whose image-space step is the more HORIZONTAL
+    // one (k steps by scale * (co, si), l by scale * (-si, co)): the lanes of a quad then fall on the same row and mostly
+    // the same cache line (wave-uniform choice).  A round is 3 lines of 21 samples along that axis: the lane's position
+    // on the line (its term of both sums) is fixed, the line advances by 3 per round.
     const bool k_fast = fabsf(co) > fabsf(si);
-    const bool on = lane < 63;
-    const int line0 = lane / LAT, pos = lane - line0 * LAT;
-    const float fpos = (float)(pos - 10);
     // k_fast: k = pos, l = line:  y = yf + ((l*co)*scale + (k*si)*scale),  x = xf + (((-l)*si)*scale + (k*co)*scale)
     // else:   l = pos, k = line:  the same expressions with the roles swapped; a + b == b + a, (-l)*si == l*(-si)
     const float cy = k_fast ? co : si;                    // factor of the line number in y
@@ -1892,7 +1930,7 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     const float fix_y = k_fast ? fpos * si * scale : fpos * co * scale;
     const float fix_x = k_fast ? fpos * co * scale : -fpos * si * scale;
     // position in the (k outer, l inner) lattice the sums walk
-    const int canon0 = k_fast ? pos * LAT + line0 : line0 * LAT + pos;
+    const int canon0 = k_fast ? pos * LAT + line0 : lane;          // line0 * LAT + pos == lane
     const int cstep = k_fast ? 3 : 3 * LAT;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1909,8 +1947,8 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
     float2 dd[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        ri[it] = LT[idx[it]];
-        dd[it] = LXY[idx[it]];
+        ri[it] = cur.LT[idx[it]];
+        dd[it] = cur.LXY[idx[it]];
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1924,27 +1962,28 @@ __global__ __launch_bounds__(64 * kODWaves) void k_orient_describe(LevelTable T,
         }
     }
     oob = __any(oob);
-    OD_STAMP(5);
     if (!oob) {
-        desc_cells<10, 2, 0>(s_ri, s_dx, s_dy, s_val, lane);
-        desc_cells<7, 3, 12>(s_ri, s_dx, s_dy, s_val, lane);
-        desc_cells<5, 4, 39>(s_ri, s_dx, s_dy, s_val, lane);
+        const float m2 = desc_cell_mean<10, 2>(s_ri, s_dx, s_dy, lane);
+        const float m3 = desc_cell_mean<7, 3>(s_ri, s_dx, s_dy, lane);
+        const float m4 = desc_cell_mean<5, 4>(s_ri, s_dx, s_dy, lane);
+        // (a wave's LDS accesses execute in order: the sums above have read the planes before these stores land on them)
+        if (lane < 12) s_val[lane] = m2;
+        if (lane < 27) s_val[12 + lane] = m3;
+        if (lane < 48) s_val[39 + lane] = m4;
     }
-    OD_STAMP(6);
     // mldb_binary_comparisons, descriptors.rs:181-202: bit b -> byte b>>3, position b&7 (LSB first)
     uint32_t byte = 0;
     if (!oob) {
+#pragma unroll
         for (int t = 0; t < 8; ++t) {
-            int b = lane * 8 + t;
-            if (b < c_desc.n_bits) {
-                float va = s_val[c_desc.cmp_a[b]], vb = s_val[c_desc.cmp_b[b]];
-                byte |= (va > vb ? 1u : 0u) << t;
-            }
+            const uint32_t ia = ((t < 4 ? cmpa.x : cmpa.y) >> (8 * (t & 3))) & 0xFFu;
+            const uint32_t ib = ((t < 4 ? cmpb.x : cmpb.y) >> (8 * (t & 3))) & 0xFFu;
+            const float va = s_val[ia], vb = s_val[ib];
+            byte |= (lane * 8 + t < n_bits && va > vb ? 1u : 0u) << t;
         }
     }
-    out[(size_t)frame * stride + ki].bytes[lane] = (uint8_t)byte;
-    if (lane == 0) flag[(size_t)frame * stride + ki] = oob ? 0u : 1u;
-    OD_STAMP(7);
+    out[fbase + cur.ki].bytes[lane] = (uint8_t)byte;
+    if (lane == 0) flag[fbase + cur.ki] = oob ? 0u : 1u;
 }
 
 void build_level_table(akz_ctx* c, LevelTable* T)
@@ -1967,24 +2006,6 @@ void build_level_table(akz_ctx* c, LevelTable* T)
 }
 
 }  // namespace
-
-#ifdef AKZ_OD_PROF
-extern "C" int32_t akz_debug_od_prof(unsigned long long* out, uint32_t cap_waves, uint32_t* n, int32_t reset)
-{
-    unsigned int cnt = 0;
-    if (hipDeviceSynchronize() != hipSuccess) return AKZ_E_HIP;
-    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_od_prof_n), sizeof(cnt)) != hipSuccess) return AKZ_E_HIP;
-    if (cnt > (unsigned)kODProfCap) cnt = kODProfCap;
-    if (cnt > cap_waves) cnt = cap_waves;
-    if (out && cnt && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_od_prof), (size_t)cnt * kODProfStamps * 8) != hipSuccess) return AKZ_E_HIP;
-    if (n) *n = cnt;
-    if (reset) {
-        const unsigned int z = 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_od_prof_n), &z, sizeof(z)) != hipSuccess) return AKZ_E_HIP;
-    }
-    return AKZ_OK;
-}
-#endif
 
 size_t akz_ori_table_bytes() { return sizeof(OriTables); }
 size_t akz_desc_table_bytes() { return sizeof(DescTables); }
@@ -2240,8 +2261,8 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         if (orient_in_desc) {
             akz_timer_begin(c, AKZ_T_ORIENT_DESCRIBE_K, s);
             AKZ_LAUNCH(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
-                       (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp, S.d_perm,
-                       S.d_desc_tmp, S.d_flag_d, c->d_err);
+                       (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp,
+                       S.d_perm, S.d_desc_tmp, S.d_flag_d, c->d_err);
             akz_timer_end(c, AKZ_T_ORIENT_DESCRIBE_K, s, 1, (uint64_t)n);
         } else
             hipLaunchKernelGGL(k_describe_fast, dim3((uint32_t)akz_div_up((int)c->max_kp, kDescWaves), n), dim3(64 * kDescWaves), 0, s, T,
@@ -2308,7 +2329,7 @@ __global__ __launch_bounds__(256) void k_debug_ori_masks(const OriTables* __rest
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     bool fb = false;
-    fast[i] = ori_sample_masks(y[i], x[i], s_bnd, s_mopen, s_meq, &fb);
+    fast[i] = ori_sample_masks(y[i], x[i], s_bnd, s_mopen, ori_p->m_eq, &fb);
     fell[i] = fb ? 1u : 0u;
     const float ang = fast_atan2_equiv(y[i], x[i]);
     const int r = ori_rank(s_bnd, ang);
