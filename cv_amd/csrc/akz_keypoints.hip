@@ -1876,17 +1876,37 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     {
         // sums of the windows, lane <-> window, samples in the reference's order
         v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
-#pragma unroll
-        for (int k = 0; k < 109; ++k) {
+        // four samples per step: their masks travel to SGPRs together, the execution mask is restored once
+        auto m64 = [&](int k) {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.x : msk1.x), k & 63);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.y : msk1.y), k & 63);
-            const unsigned long long m64 = ((unsigned long long)hi << 32) | lo;
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        auto rv = [&](int k) {
             const float2 rk = s_r[k];
-            const v2f rv = {rk.x, rk.y};
+            return (v2f){rk.x, rk.y};
+        };
+#pragma unroll
+        for (int k = 0; k + 4 <= 108; k += 4) {
+            const unsigned long long m0 = m64(k), m1 = m64(k + 1), m2 = m64(k + 2), m3 = m64(k + 3);
+            const v2f r0 = rv(k), r1 = rv(k + 1), r2 = rv(k + 2), r3 = rv(k + 3);
             unsigned long long saved;
-            asm("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_pk_add_f32 %[s], %[s], %[r]\n\ts_mov_b64 exec, %[sv]"
+            asm("s_mov_b64 %[sv], exec\n\t"
+                "s_mov_b64 exec, %[m0]\n\tv_pk_add_f32 %[s], %[s], %[r0]\n\t"
+                "s_mov_b64 exec, %[m1]\n\tv_pk_add_f32 %[s], %[s], %[r1]\n\t"
+                "s_mov_b64 exec, %[m2]\n\tv_pk_add_f32 %[s], %[s], %[r2]\n\t"
+                "s_mov_b64 exec, %[m3]\n\tv_pk_add_f32 %[s], %[s], %[r3]\n\t"
+                "s_mov_b64 exec, %[sv]"
                 : [s] "+v"(sum), [sv] "=&s"(saved)
-                : [m] "s"(m64), [r] "v"(rv));
+                : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3));
+        }
+        {
+            const unsigned long long m0 = m64(108);
+            const v2f r0 = rv(108);
+            unsigned long long saved;
+            asm("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m0]\n\tv_pk_add_f32 %[s], %[s], %[r0]\n\ts_mov_b64 exec, %[sv]"
+                : [s] "+v"(sum), [sv] "=&s"(saved)
+                : [m0] "s"(m0), [r0] "v"(r0));
         }
         const float sum_x = sum.x, sum_y = sum.y;
         const float val = sum_x * sum_x + sum_y * sum_y;
@@ -1925,20 +1945,22 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     const bool k_fast = fabsf(co) > fabsf(si);
     // k_fast: k = pos, l = line:  y = yf + ((l*co)*scale + (k*si)*scale),  x = xf + (((-l)*si)*scale + (k*co)*scale)
     // else:   l = pos, k = line:  the same expressions with the roles swapped; a + b == b + a, (-l)*si == l*(-si)
-    const float cy = k_fast ? co : si;                    // factor of the line number in y
-    const float cx = k_fast ? -si : co;                   //                      ... in x
-    const float fix_y = k_fast ? fpos * si * scale : fpos * co * scale;
-    const float fix_x = k_fast ? fpos * co * scale : -fpos * si * scale;
+    // both coordinates of a sample in one packed operation each ({x, y}: v_pk_mul_f32 / v_pk_add_f32 round each half as the
+    // scalar instruction would)
+    const v2f cxy = {k_fast ? -si : co, k_fast ? co : si};         // factors of the line number in {x, y}
+    const v2f fix = {k_fast ? fpos * co * scale : -fpos * si * scale, k_fast ? fpos * si * scale : fpos * co * scale};
+    const v2f base = {xf, yf}, scale2 = {scale, scale}, half_ulp = {0.49999997f, 0.49999997f};
     // position in the (k outer, l inner) lattice the sums walk
     const int canon0 = k_fast ? pos * LAT + line0 : lane;          // line0 * LAT + pos == lane
     const int cstep = k_fast ? 3 : 3 * LAT;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const float fl = (float)(line0 + 3 * it - 10);
-        const float sample_y = yf + (fl * cy * scale + fix_y);
-        const float sample_x = xf + (fl * cx * scale + fix_x);
-        const int y1 = round_flr_i32(sample_y);
-        const int x1 = round_flr_i32(sample_x);
+        const v2f fl2 = {fl, fl};
+        const v2f smp = (base + (fl2 * cxy * scale2 + fix)) + half_ulp;     // round_flr_i32's add
+        int x1, y1;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(x1) : "v"(smp.x));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y1) : "v"(smp.y));
         const bool bad = (unsigned)x1 >= (unsigned)W || (unsigned)y1 >= (unsigned)Hh;
         oob |= on && bad;   // Error::SampleOutOfBounds in any grid drops the keypoint (descriptors.rs:28)
         idx[it] = (on && !bad) ? y1 * W + x1 : 0;
@@ -1950,15 +1972,17 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         ri[it] = cur.LT[idx[it]];
         dd[it] = cur.LXY[idx[it]];
     }
+    const v2f rot_x = {co, -si}, rot_y = {si, co};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        float rry = dd[it].x * co + dd[it].y * si;     // descriptors.rs:151-152
-        float rrx = -dd[it].x * si + dd[it].y * co;
+        // descriptors.rs:151-152: rry = dx*co + dy*si, rrx = -dx*si + dy*co ((-dx)*si == dx*(-si))
+        const v2f dx2 = {dd[it].x, dd[it].x}, dy2 = {dd[it].y, dd[it].y};
+        const v2f rr = dx2 * rot_x + dy2 * rot_y;                          // {rry, rrx}
         if (on) {
             const int canon = canon0 + it * cstep;
             s_ri[canon] = ri[it];
-            s_dx[canon] = rrx;
-            s_dy[canon] = rry;
+            s_dx[canon] = rr.y;
+            s_dy[canon] = rr.x;
         }
     }
     oob = __any(oob);
