@@ -50,7 +50,7 @@ class Options(C.Structure):
 
 OPT_KEEP_ALL, OPT_NO_FRAME_PAIRS, OPT_SERIAL_SUPPRESSION, OPT_NO_PIPELINE = 1, 2, 4, 8
 OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED, OPT_EQUAL_PRIORITY = 16, 32, 64, 128, 256, 512, 1024
-HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY = 1, 2, 4
+HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY, HM_OPT_NO_LDS_DMA = 1, 2, 4, 8
 FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
 ARITH_REDUCE_PAIRWISE, ARITH_FMA, ARITH_HALF_SEQUENTIAL = 1, 2, 4
 

@@ -374,19 +374,19 @@ __global__ __launch_bounds__(256) void k_expand4(const HmExpandJob* __restrict__
 // The 8 chained MFMAs of tile `tp` into `out`, interleaved with the key epilogue of the PREVIOUS tile's accumulators
 // (`prev`, always a full tile): a dependent MFMA issues every ~32 cycles, the seven or so VALU instructions of the
 // epilogue that fit in between are independent of it, so the matrix pipe and the VALU of one wave overlap.
-template <int KNN, bool EPI>
+template <int KNN, bool EPI, int STRIDE = 2>    // STRIDE: uint4 between a lane's consecutive fragments in the LDS image
 __device__ __forceinline__ void knn_chain4(const uint4* __restrict__ tp, const v4i32 (&qb)[8], const v16f32& bias,
                                            v16f32& out, const v16f32& prev, uint32_t tprev, uint32_t half, int (&k)[KNN])
 {
     uint4 f[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = tp[2 * i];
+    for (int i = 0; i < 4; ++i) f[i] = tp[STRIDE * i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint4 av = f[i & 3];
         const v8i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
         const v8i32 b = {qb[i][0], qb[i][1], qb[i][2], qb[i][3], 0, 0, 0, 0};
-        if (i + 4 < 8) f[i & 3] = tp[2 * (i + 4)];
+        if (i + 4 < 8) f[i & 3] = tp[STRIDE * (i + 4)];
         // the chain starts from the resident bias block (D != C): no per-tile accumulator initialisation
         // block scales: targets 2^5 (E8M0 0x84), queries 1 (0x7F): the accumulators are tile-local keys, see
         // knn_keys_tagged
@@ -507,6 +507,225 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma4(const HmProbX* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The wide FP4 kernel: 64 resident queries per wave and the target tiles brought in by LDS-DMA.
+//
+// k_knn_mfma4 keeps the matrix pipe busy 61 % of the time (SQ_VALU_MFMA_BUSY_CYCLES against SQ_WAVE_CYCLES,
+// profiles/r04_pmc_matcher.txt) and no pipelining of its staging changes that (an LDS-DMA ring with four tiles of
+// prefetch and half the barriers measured the same 3.05 ms per 256 frame pairs): its limit is LDS READ BANDWIDTH.  A
+// wave multiplies a 32-target x 64-nibble fragment (1 KB from LDS) by 32 resident queries per MFMA; sixteen waves per
+// CU fetch 8 KB per tile each, 128 KB per 1 024 MFMA cycles = the LDS's 128 B per clock, all of it.  Here a wave keeps
+// 64 queries (two column blocks) in registers and every fragment feeds two MFMAs — half the LDS bytes per MAC — at two
+// waves per SIMD (256 registers): the two column blocks' dependent MFMA chains interleave, so one wave alone keeps
+// the pipe issuing, and the key epilogue of the previous tile rides between them as before.
+//
+// The target tiles come by global_load_lds_dwordx4 (gfx950): no staging registers, no ds_write, three STAGES of two
+// tiles in a ring, the DMA of stage s + 2 issued when stage s starts, one barrier per stage, a counted vmcnt for the
+// stage about to be read.  The DMA writes lane-linearly (M0 base + 16 lane), so the image cannot be padded per row;
+// bank conflicts are avoided by WHAT each lane fetches: a 1 KB group holds four rows, lane l the chunk (l >> 2) of
+// row (l & 3) — the slot of (row, chunk) is 4 chunk + (row & 3) — and the groups are 64 B apart.  A fragment read
+// (lane <-> row, all lanes the same chunk) then touches, per eight lanes, eight different 16-byte columns of the
+// 128-byte LDS row, and a lane's eight fragments are 128 B apart: immediate offsets.
+constexpr int kGSeg = 1024 + 64;               // bytes of a 4-row group
+constexpr int kGTile = 8 * kGSeg;              // 8 704 B per 32-target tile
+#ifndef AKZ_G_STAGES
+#define AKZ_G_STAGES 3
+#endif
+#ifndef AKZ_G_TPS
+#define AKZ_G_TPS 2
+#endif
+constexpr int kGStages = AKZ_G_STAGES;         // ring of stages (kGStages - 1 of them requested ahead) ...
+constexpr int kGTps = AKZ_G_TPS;               // ... of this many tiles each (even): 3 x 2: 52 224 B per block, two blocks per CU
+constexpr int kWideBlock = 256;                // 4 waves x 64 queries
+
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
+{
+    // (M0 is the compiler's: saved and restored; the statement is opaque to its wait-count bookkeeping, the waits are ours)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// one tile for both column blocks: 8 fragments, 16 MFMAs (two interleaved dependent chains), and the key epilogue of
+// the PREVIOUS tile's two accumulator blocks between them.  The order is written out and pinned (sched_barrier): two
+// insertions of the previous tile's keys behind every MFMA — four to five VALU instructions in the ~32 cycles before the
+// next MFMA of the other chain can issue.  (sched_group_barrier patterns, which k_knn_mfma4 uses, collapse here: the
+// scheduler put the sixteen MFMAs back to back, one chain after the other, and the epilogue behind them.)
+template <int KNN, bool EPI>
+__device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const v4i32 (&qb)[2][8], const v16f32& bias,
+                                            v16f32& o0, v16f32& o1, const v16f32& p0, const v16f32& p1, uint32_t tprev,
+                                            uint32_t half, int (&k0)[KNN], int (&k1)[KNN])
+{
+    constexpr int FS = 128 / 16;           // a lane's fragments are 128 B apart
+    const v16i32 r0 = __builtin_bit_cast(v16i32, p0), r1 = __builtin_bit_cast(v16i32, p1);
+    int l0[KNN], l1[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) l0[i] = l1[i] = 0x7FFFFFFF;
+    uint4 f[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = tp[FS * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 av = f[i & 3];
+        const v8i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+        const v8i32 b0 = {qb[0][i][0], qb[0][i][1], qb[0][i][2], qb[0][i][3], 0, 0, 0, 0};
+        const v8i32 b1 = {qb[1][i][0], qb[1][i][1], qb[1][i][2], qb[1][i][3], 0, 0, 0, 0};
+        // block scales: targets 2^5 (E8M0 0x84), queries 1 (0x7F): the accumulators are tile-local keys (knn_keys_tagged)
+        if (i == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+        else o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, o0, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+        if (EPI) {
+            topk_insert<KNN>(l0, r0[2 * i]);
+            topk_insert<KNN>(l0, r0[2 * i + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+        else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, o1, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
+        if (i + 4 < 8) f[i & 3] = tp[FS * (i + 4)];        // four fragments (eight MFMAs) ahead
+        if (EPI) {
+            topk_insert<KNN>(l1, r1[2 * i]);
+            topk_insert<KNN>(l1, r1[2 * i + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EPI) {
+        // the tile's KNN smallest become global keys (knn_keys_tagged's second half)
+        const int row0 = (int)(tprev + 4u * half);
+#pragma unroll
+        for (int i = 0; i < KNN; ++i) {
+            topk_insert<KNN>(k0, (int)(((uint32_t)l0[i] << 16) & 0xFFE00000u) | ((l0[i] & 31) | row0));
+            topk_insert<KNN>(k1, (int)(((uint32_t)l1[i] << 16) & 0xFFE00000u) | ((l1[i] & 31) | row0));
+        }
+    }
+}
+
+template <int KNN>
+__global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
+{
+    static_assert(kGStages >= 3 && kGTps % 2 == 0 && kGTps <= 4, "ring shape");
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[kGStages * kGTps * kGTile];
+    uint32_t bx, by;
+    {
+        const uint32_t nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const uint32_t xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+        by = t / gridDim.x;
+        bx = t - by * gridDim.x;
+    }
+    const HmProbX P = probs[by];
+    const uint32_t nq = min(*P.nq, P.q_cap), nt = min(*P.nt, P.t_cap);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t qblk = bx * 256u;
+    if (qblk >= nq) return;                              // whole block
+    const uint32_t q0 = qblk + wv * 64u;                 // 64 queries (two column blocks) per wave
+    const bool wave_on = q0 < nq;                        // idle waves still carry their share of the tiles and hit the barriers
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    int k0[KNN], k1[KNN];
+#pragma unroll
+    for (int i = 0; i < KNN; ++i) k0[i] = k1[i] = 0x7FFFFFFF;
+    if (nt > 0) {
+        // B fragments: queries (q0 + col) and (q0 + 32 + col), nibbles [64 j + 32 half, +32) of their 512, resident, negated
+        v4i32 qb[2][8];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const uint32_t qi = min(q0 + 32u * cb + col, nq - 1u);
+            const v4i32* qp = reinterpret_cast<const v4i32*>(P.q + (size_t)qi * 64) + half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qb[cb][i] = qp[2 * i] ^ (int)0x88888888;
+        }
+        const unsigned char* tg = reinterpret_cast<const unsigned char*>(P.t);   // 256 B per descriptor
+        const uint32_t lds0 = (uint32_t)(uintptr_t)s_t;                          // LDS byte address of the ring
+        const uint32_t drow = 8u * wv + (lane & 3u), dchunk = lane >> 2;          // this lane's share: rows drow and drow + 4
+        // request the tiles of stage `st` (rows past the end repeat the last descriptor: the counts stay uniform)
+        auto issue = [&](uint32_t st) {
+            const uint32_t slot = lds0 + (st % kGStages) * (uint32_t)(kGTps * kGTile) + 2u * wv * kGSeg;
+#pragma unroll
+            for (uint32_t h = 0; h < (uint32_t)kGTps; ++h)
+#pragma unroll
+                for (uint32_t g = 0; g < 2; ++g) {
+                    const uint32_t row = min((st * kGTps + h) * 32u + drow + 4u * g, nt - 1u);
+                    glds16(tg + (size_t)row * 256 + dchunk * 16, slot + h * kGTile + g * kGSeg);
+                }
+        };
+        // the wave's query fragments must have arrived before the first DMA: the compiler's own vmcnt bookkeeping does not
+        // see the DMAs, so none of its loads may be outstanding when they start
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t st = 0; st + 1 < (uint32_t)kGStages; ++st) issue(st);
+        v16f32 bias;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias[i] = 12582912.0f + (float)((i & 3) + 8 * (i >> 2));   // + off(r): the row tag
+        asm volatile("" : "+v"(bias));
+        v16f32 a00 = bias, a01 = bias, a10 = bias, a11 = bias;      // [ping-pong][column block]
+        const uint4* tlane = reinterpret_cast<const uint4*>(s_t + (col >> 2) * kGSeg + (col & 3u) * 16 + half * 64);
+        uint32_t t0 = 0;
+#define HM_LAST(x0, x1)                                                                                          \
+        if (wave_on) {                                                                                           \
+            const v16i32 n0 = __builtin_bit_cast(v16i32, x0), n1 = __builtin_bit_cast(v16i32, x1);               \
+            if (t0 + 32u <= nt) {                                                                                \
+                knn_keys_tagged<false, KNN>(n0, t0, half, nt, k0);                                               \
+                knn_keys_tagged<false, KNN>(n1, t0, half, nt, k1);                                               \
+            } else {                                                                                             \
+                knn_keys_tagged<true, KNN>(n0, t0, half, nt, k0);                                                \
+                knn_keys_tagged<true, KNN>(n1, t0, half, nt, k1);                                                \
+            }                                                                                                    \
+        }
+        for (uint32_t st = 0;; ++st) {
+            // stage st has landed (its requests are the oldest; those of the kGStages - 2 stages behind it may stay in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kGStages - 2) * kGTps * 2) : "memory");
+            // ... for every wave of the block, and everybody is done reading stage st - 1, whose slot the next request takes
+            asm volatile("s_barrier" ::: "memory");
+            issue(st + (uint32_t)kGStages - 1u);
+            const uint4* ta = tlane + (size_t)((st % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
+            bool done = false;
+#pragma unroll
+            for (int h = 0; h < kGTps; h += 2) {
+                if (wave_on) {
+                    if (st == 0 && h == 0) knn_chain4w<KNN, false>(ta + h * (kGTile / 16), qb, bias, a00, a01, a10, a11, 0u, half, k0, k1);
+                    else knn_chain4w<KNN, true>(ta + h * (kGTile / 16), qb, bias, a00, a01, a10, a11, t0 - 32u, half, k0, k1);
+                }
+                if (t0 + 32u >= nt) {
+                    HM_LAST(a00, a01)
+                    done = true;
+                    break;
+                }
+                t0 += 32u;
+                if (wave_on) knn_chain4w<KNN, true>(ta + (h + 1) * (kGTile / 16), qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1);
+                if (t0 + 32u >= nt) {
+                    HM_LAST(a10, a11)
+                    done = true;
+                    break;
+                }
+                t0 += 32u;
+            }
+            if (done) break;
+        }
+#undef HM_LAST
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the requests past the end
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        int (&k)[KNN] = cb ? k1 : k0;
+        int o[KNN];
+#pragma unroll
+        for (int i = 0; i < KNN; ++i) o[i] = __shfl_xor(k[i], 32);
+#pragma unroll
+        for (int i = 0; i < KNN; ++i) topk_insert<KNN>(k, o[i]);
+        const uint32_t qi = q0 + 32u * cb + col;
+        if (half == 0 && qi < nq) {
+#pragma unroll
+            for (int i = 0; i < KNN; ++i) {
+                const uint32_t m = k[i] == 0x7FFFFFFF ? 0xFFFFFFFFu : (uint32_t)k[i] + (512u << 21);
+                akz_neighbor nb = {m & ((1u << kIdxBits) - 1u), m >> kIdxBits};
+                P.out[(size_t)qi * KNN + i] = nb;
+            }
+        }
+    }
+}
+
 struct HmPairProb {
     const akz_neighbor* fwd;  // [na][2]  a -> b
     const akz_neighbor* rev;  // [nb][2]  b -> a (symmetric only)
@@ -610,6 +829,7 @@ struct hm_ctx {
     size_t exp_words = 0;
     bool use_mfma = true;
     bool use_fp4 = true;           // E2M1 recoding + v_mfma_scale_f32_32x32x64_f8f6f4 (AKZ_MATCH_FP4=0: int8 MFMA)
+    bool use_glds = true;          // the wide FP4 kernel, tiles by LDS-DMA (HM_OPT_NO_LDS_DMA: k_knn_mfma4, register-staged)
     // optional timing of the k-NN launches (HIP events on the matcher stream), for bench.py's MFMA roofline
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pending;
@@ -665,7 +885,7 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
     return akz_guard([&]() -> int32_t {
         // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
         if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-        if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY)) return AKZ_E_INVALID;   // unknown switches
+        if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY | HM_OPT_NO_LDS_DMA)) return AKZ_E_INVALID;   // unknown switches
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
         AKZ_HIP(hipSetDevice(device));
@@ -684,6 +904,7 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
         AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
         c->use_mfma = !(flags & HM_OPT_NO_MFMA);
         c->use_fp4 = !(flags & HM_OPT_NO_FP4);
+        c->use_glds = !(flags & HM_OPT_NO_LDS_DMA);
         AKZ_HIP(hipMalloc(&c->d_a, (size_t)m * 64));
         AKZ_HIP(hipMalloc(&c->d_b, (size_t)m * 64));
         AKZ_HIP(hipMalloc(&c->d_na, sizeof(uint32_t) * 4));
@@ -817,7 +1038,13 @@ static int32_t launch_knn2(hm_ctx* c, const HmProb* h_probs, uint32_t n_probs, u
     {
         dim3 grid((max_nq + 255) / 256, n_probs);
         const HmProbX* dp = reinterpret_cast<const HmProbX*>((char*)c->d_probs + probs_off);
-        if (c->use_fp4) {
+        if (c->use_fp4 && c->use_glds) {
+            switch (knn) {
+            case 1: hipExtLaunchKernelGGL(k_knn_mfma4w<1>, grid, dim3(kWideBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            case 3: hipExtLaunchKernelGGL(k_knn_mfma4w<3>, grid, dim3(kWideBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            default: hipExtLaunchKernelGGL(k_knn_mfma4w<2>, grid, dim3(kWideBlock), 0, c->stream, ev0, ev1, 0, dp); break;
+            }
+        } else if (c->use_fp4) {
             switch (knn) {
             case 1: hipExtLaunchKernelGGL(k_knn_mfma4<1>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;
             case 3: hipExtLaunchKernelGGL(k_knn_mfma4<3>, grid, dim3(kMfmaBlock), 0, c->stream, ev0, ev1, 0, dp); break;

@@ -263,7 +263,7 @@ typedef struct hm_ctx hm_ctx;
 int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out);
 /* hm_create with kernel-selection flags (0 = defaults): the k-NN kernel is the FP4 MFMA one unless a flag
  * selects the int8 MFMA or the xor/popcount VALU kernel (k = 2 only); all three are bit-identical. */
-enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2 };
+enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2, HM_OPT_NO_LDS_DMA = 1u << 3 };
 int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t max_targets, uint32_t flags, hm_ctx** out);
 int32_t hm_destroy(hm_ctx* ctx);
 /* LinearKnn::knn(q, 2) for every query (akaze/tests/estimate_pose.rs:82-88): out[2*i+0/1] are the

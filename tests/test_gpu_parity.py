@@ -665,11 +665,11 @@ def test_matcher_properties_at_full_size(gpu):
     assert len(ab) > 100 and sorted((x, y) for x, y in ab) == sorted((y, x) for x, y in ba)
 
 
-@pytest.mark.parametrize("switch", ["valu", "int8"])
+@pytest.mark.parametrize("switch", ["valu", "int8", "fp4_regs"])
 def test_alternative_matcher_kernels(gpu, oracle, switch):
     """HM_OPT_NO_MFMA: the xor/popcount kernel (the reference implementation of the MFMA ones, k = 2);
-    HM_OPT_NO_FP4: the int8 MFMA kernel (k = 1..3).  The default is the FP4 MFMA kernel, which every other
-    matcher test exercises."""
+    HM_OPT_NO_FP4: the int8 MFMA kernel (k = 1..3); HM_OPT_NO_LDS_DMA: the FP4 kernel with its register stage (k = 1..3).
+    The default is the FP4 MFMA kernel fed by LDS-DMA, which every other matcher test exercises."""
     _, knn = gpu
     rng = np.random.default_rng(5)
     m = knn.Matcher(4096, kernel=switch)
@@ -679,11 +679,11 @@ def test_alternative_matcher_kernels(gpu, oracle, switch):
     _eq(got["index"], want["index"], switch + " knn idx")
     _eq(got["distance"], want["distance"], switch + " knn dist")
     assert m.match(q, t).tolist() == oracle.match(q, t).tolist()
-    if switch == "int8":
+    if switch in ("int8", "fp4_regs"):
         for k in (1, 3):
             got, want = m.knn(q, t[:1001], k), oracle.knn(q, t[:1001], k)
-            _eq(got["index"], want["index"], f"int8 knn{k} idx")
-            _eq(got["distance"], want["distance"], f"int8 knn{k} dist")
+            _eq(got["index"], want["index"], f"{switch} knn{k} idx")
+            _eq(got["distance"], want["distance"], f"{switch} knn{k} dist")
     m.close()
 
 

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
 ap.add_argument("--kp", type=int, default=5070)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--kernel", default="fp4", help="fp4 (LDS-DMA staging), fp4_regs, int8, valu")
 a = ap.parse_args()
 L = _lib.lib()
 dev = torch.device("cuda", 0)
@@ -33,7 +34,7 @@ descs[:, :, 61:] = 0
 counts = torch.randint(a.kp - 200, a.kp + 200, (n,), generator=g, device=dev, dtype=torch.int32)
 pairs = torch.zeros((n, cap, 2), dtype=torch.int32, device=dev)
 npairs = torch.zeros((n,), dtype=torch.int32, device=dev)
-m = Matcher(cap)
+m = Matcher(cap, kernel=a.kernel)
 ia = (C.c_uint32 * n)(*range(n))
 ib = (C.c_uint32 * n)(*[(j - 1) % n for j in range(n)])
 
@@ -55,5 +56,5 @@ _lib.check(L.hm_timing_get(m.handle, C.byref(ms), C.byref(launches), 1), "timing
 kp = counts.float().mean().item()
 per = ms.value / launches.value
 ops = 2.0 * 2.0 * n * kp * kp * 512.0
-print(json.dumps({"pairs": n, "mean_kp": round(kp, 1), "knn_ms_per_launch": round(per, 4),
+print(json.dumps({"kernel": a.kernel, "pairs": n, "mean_kp": round(kp, 1), "knn_ms_per_launch": round(per, 4),
                   "tops": round(ops / (per * 1e-3) / 1e12, 1), "checksum": int(npairs.sum().item())}))
