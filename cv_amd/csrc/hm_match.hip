@@ -175,6 +175,40 @@ __device__ __forceinline__ void topk_insert(int (&l)[K], int v)
     }
 }
 
+// Two values at once into the ascending pair l[0] <= l[1] in three instructions instead of four: the new smallest is
+// min3(l0, a, b); the new second is min(l1, median(l0, a, b)) — if l1 is below the median of {l0, a, b} then l0 is that
+// triple's smallest (l0 <= l1) and l1 the second of all four, otherwise the median is.  On this part an integer VALU
+// instruction behind an FP4 MFMA costs the SIMD ~5.6 cycles of matrix time (they do not overlap at two waves per SIMD,
+// tools/ubench/mfma_fp4_rate.hip), so the key epilogue is priced per instruction.
+template <int K>
+__device__ __forceinline__ void topk_insert2(int (&l)[K], int a, int b)
+{
+    if constexpr (K == 2) {
+        int m, lo;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(l[0]), "v"(a), "v"(b));
+        asm("v_min3_i32 %0, %1, %2, %3" : "=v"(lo) : "v"(l[0]), "v"(a), "v"(b));
+        l[0] = lo;
+        l[1] = min(l[1], m);
+    } else {
+        topk_insert<K>(l, a);
+        topk_insert<K>(l, b);
+    }
+}
+// an ascending pair g0 <= g1 into the ascending pair l: as above, one instruction less (min3 = min: g0 <= g1)
+template <int K>
+__device__ __forceinline__ void topk_merge2(int (&l)[K], const int (&g)[K])
+{
+    if constexpr (K == 2) {
+        int m;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(l[0]), "v"(g[0]), "v"(g[1]));
+        l[0] = min(l[0], g[0]);
+        l[1] = min(l[1], m);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) topk_insert<K>(l, g[i]);
+    }
+}
+
 // One 32-target x 32-query tile: 16 chained MFMAs (K = 512 = 16 x 32) with the LDS fragment reads kept
 // four deep in flight, then the (distance, row) keys and the tile's KNN smallest, merged into k[].
 // D layout: column = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (target).
@@ -207,6 +241,13 @@ __device__ __forceinline__ void knn_keys(const v16i32& nacc, uint32_t t0, uint32
 // tile's KNN smallest become global keys (nacc << 21) | (row0 + off): `<< 16` moves 32 nacc to bit 21 and drops
 // the constant (its lowest set bit is bit 22), the low five bits are off, and off never uses bit 2, so
 // `| row0` (row0 = t0 + 4 half) adds it.  Three instructions per survivor instead of one per register.
+// tile-local key -> global key: three instructions (clear the row tag, shift the rest to bit 21 and OR the row in)
+__device__ __forceinline__ int knn_global_key(int l, int row0)
+{
+    const int low = (l & 31) | row0;                                  // v_and_or_b32
+    return (int)((uint32_t)(l & ~31) << 16) | low;                    // v_and_b32, v_lshl_or_b32: bits 16..20 stay clear
+}
+
 template <bool TAIL, int KNN>
 __device__ __forceinline__ void knn_keys_tagged(const v16i32& raw, uint32_t t0, uint32_t half, uint32_t nt, int (&k)[KNN])
 {
@@ -214,20 +255,22 @@ __device__ __forceinline__ void knn_keys_tagged(const v16i32& raw, uint32_t t0, 
     int l[KNN];
 #pragma unroll
     for (int i = 0; i < KNN; ++i) l[i] = 0x7FFFFFFF;
+    int key[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int off = (r & 3) + 8 * (r >> 2);
-        int key = raw[r];
-        if (TAIL) key = (uint32_t)(row0 + off) < nt ? key : 0x7FFFFFFF;
-        topk_insert<KNN>(l, key);
+        key[r] = raw[r];
+        if (TAIL) key[r] = (uint32_t)(row0 + off) < nt ? key[r] : 0x7FFFFFFF;
     }
 #pragma unroll
+    for (int r = 0; r < 16; r += 2) topk_insert2<KNN>(l, key[r], key[r + 1]);
+    int g[KNN];
+#pragma unroll
     for (int i = 0; i < KNN; ++i) {
-        const int low = (l[i] & 31) | row0;
-        int g = (int)(((uint32_t)l[i] << 16) & 0xFFE00000u) | low;
-        if (TAIL) g = l[i] == 0x7FFFFFFF ? 0x7FFFFFFF : g;
-        topk_insert<KNN>(k, g);
+        g[i] = knn_global_key(l[i], row0);
+        if (TAIL) g[i] = l[i] == 0x7FFFFFFF ? 0x7FFFFFFF : g[i];
     }
+    topk_merge2<KNN>(k, g);          // (g ascending: the rekeying is monotone, and INT_MAX stays last)
 }
 
 template <int KNN>
@@ -542,6 +585,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
 {
     // (M0 is the compiler's: saved and restored; the statement is opaque to its wait-count bookkeeping, the waits are ours)
     uint32_t keep;
+    lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);    // wave-uniform by construction; an SGPR for the compiler too
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
@@ -553,21 +597,35 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
 // insertions of the previous tile's keys behind every MFMA — four to five VALU instructions in the ~32 cycles before the
 // next MFMA of the other chain can issue.  (sched_group_barrier patterns, which k_knn_mfma4 uses, collapse here: the
 // scheduler put the sixteen MFMAs back to back, one chain after the other, and the epilogue behind them.)
-template <int KNN, bool EPI>
-__device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const v4i32 (&qb)[2][8], const v16f32& bias,
-                                            v16f32& o0, v16f32& o1, const v16f32& p0, const v16f32& p1, uint32_t tprev,
-                                            uint32_t half, int (&k0)[KNN], int (&k1)[KNN])
+#ifndef HM_ABLATE
+#define HM_ABLATE 0      // experiment builds only (tools/build_variant.sh): 1 no key epilogue, 2 fragments read once, 4 no DMA / barrier
+#endif
+// one tile for both column blocks: 8 fragments, 16 MFMAs (two interleaved dependent chains), and the key epilogue of
+// the PREVIOUS tile's two accumulator blocks between them.  The order is written out and pinned (sched_barrier): two
+// insertions of the previous tile's keys behind every MFMA — four to five VALU instructions in the ~32 cycles before the
+// next MFMA of the other chain can issue.  (sched_group_barrier patterns, which k_knn_mfma4 uses, collapse here: the
+// scheduler put the sixteen MFMAs back to back, one chain after the other, and the epilogue behind them.)
+// The fragment stream does not stop at the tile's end: f[] arrives holding this tile's fragments 0..3 and leaves
+// holding the NEXT tile's (tn, read behind steps 4..7), so no tile starts by waiting for LDS.  When the next tile
+// belongs to the next stage, `hook` — the wait for that stage, the block's barrier and the next DMA — runs between
+// steps 3 and 4, when this wave's last read of the current stage has been issued.
+template <int KNN, bool EPI_, typename Hook>
+__device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const uint4* __restrict__ tn, uint4 (&f)[4], const v4i32 (&qb)[2][8], const v16f32& bias, v16f32& o0, v16f32& o1,
+                                            const v16f32& p0, const v16f32& p1, uint32_t tprev, uint32_t half, int (&k0)[KNN],
+                                            int (&k1)[KNN], Hook hook)
 {
     constexpr int FS = 128 / 16;           // a lane's fragments are 128 B apart
+    constexpr bool EPI = EPI_ && !(HM_ABLATE & 1);
     const v16i32 r0 = __builtin_bit_cast(v16i32, p0), r1 = __builtin_bit_cast(v16i32, p1);
     int l0[KNN], l1[KNN];
 #pragma unroll
     for (int i = 0; i < KNN; ++i) l0[i] = l1[i] = 0x7FFFFFFF;
-    uint4 f[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = tp[FS * i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        if (i == 4) {
+            hook();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const uint4 av = f[i & 3];
         const v8i32 a = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
         const v8i32 b0 = {qb[0][i][0], qb[0][i][1], qb[0][i][2], qb[0][i][3], 0, 0, 0, 0};
@@ -575,35 +633,38 @@ __device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const 
         // block scales: targets 2^5 (E8M0 0x84), queries 1 (0x7F): the accumulators are tile-local keys (knn_keys_tagged)
         if (i == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
         else o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, o0, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
-        if (EPI) {
-            topk_insert<KNN>(l0, r0[2 * i]);
-            topk_insert<KNN>(l0, r0[2 * i + 1]);
-        }
+        if (EPI) topk_insert2<KNN>(l0, r0[2 * i], r0[2 * i + 1]);
         __builtin_amdgcn_sched_barrier(0);
         if (i == 0) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
         else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, o1, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
-        if (i + 4 < 8) f[i & 3] = tp[FS * (i + 4)];        // four fragments (eight MFMAs) ahead
-        if (EPI) {
-            topk_insert<KNN>(l1, r1[2 * i]);
-            topk_insert<KNN>(l1, r1[2 * i + 1]);
+        // four fragments (eight MFMAs) ahead: this tile's 4..7, then the next tile's 0..3
+        if (!(HM_ABLATE & 2)) {
+            // (no branch in here: with control flow inside the chain the MFMAs sink below it and the pinned order is gone —
+            // the last tile re-reads itself)
+            if (i < 4) f[i & 3] = tp[FS * (i + 4)];
+            else f[i & 3] = tn[FS * (i - 4)];
         }
+        if (EPI) topk_insert2<KNN>(l1, r1[2 * i], r1[2 * i + 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (EPI) {
         // the tile's KNN smallest become global keys (knn_keys_tagged's second half)
         const int row0 = (int)(tprev + 4u * half);
+        int g0[KNN], g1[KNN];
 #pragma unroll
         for (int i = 0; i < KNN; ++i) {
-            topk_insert<KNN>(k0, (int)(((uint32_t)l0[i] << 16) & 0xFFE00000u) | ((l0[i] & 31) | row0));
-            topk_insert<KNN>(k1, (int)(((uint32_t)l1[i] << 16) & 0xFFE00000u) | ((l1[i] & 31) | row0));
+            g0[i] = knn_global_key(l0[i], row0);
+            g1[i] = knn_global_key(l1[i], row0);
         }
+        topk_merge2<KNN>(k0, g0);
+        topk_merge2<KNN>(k1, g1);
     }
 }
 
 template <int KNN>
 __global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
 {
-    static_assert(kGStages >= 3 && kGTps % 2 == 0 && kGTps <= 4, "ring shape");
+    static_assert(kGStages >= 3 && kGTps == 2, "ring shape");
     __shared__ __attribute__((aligned(16))) unsigned char s_t[kGStages * kGTps * kGTile];
     uint32_t bx, by;
     {
@@ -672,35 +733,49 @@ __global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __r
                 knn_keys_tagged<true, KNN>(n1, t0, half, nt, k1);                                                \
             }                                                                                                    \
         }
-        for (uint32_t st = 0;; ++st) {
-            // stage st has landed (its requests are the oldest; those of the kGStages - 2 stages behind it may stay in flight) ...
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kGStages - 2) * kGTps * 2) : "memory");
-            // ... for every wave of the block, and everybody is done reading stage st - 1, whose slot the next request takes
+        // The stage boundary, run by every wave between steps 3 and 4 of a stage's last tile: this wave's reads of the stage
+        // have returned; the next stage has landed (its requests are the oldest; those of the kGStages - 2 stages behind it
+        // may stay in flight) — for every wave of the block once the barrier is passed, and by then everybody is done reading
+        // the current stage, whose slot the next request takes.
+        uint32_t st = 0;
+        auto boundary = [&]() {
+#if !(HM_ABLATE & 4)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kGStages - 2) * kGTps * 2) : "memory");
             asm volatile("s_barrier" ::: "memory");
-            issue(st + (uint32_t)kGStages - 1u);
-            const uint4* ta = tlane + (size_t)((st % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
-            bool done = false;
+            issue(st + (uint32_t)kGStages);
+#endif
+        };
+        auto nothing = [&]() {};
+        // stage 0 has landed; the last slot of the ring takes its first request
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kGStages - 2) * kGTps * 2) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue((uint32_t)kGStages - 1u);
+        uint4 f[4];
 #pragma unroll
-            for (int h = 0; h < kGTps; h += 2) {
-                if (wave_on) {
-                    if (st == 0 && h == 0) knn_chain4w<KNN, false>(ta + h * (kGTile / 16), qb, bias, a00, a01, a10, a11, 0u, half, k0, k1);
-                    else knn_chain4w<KNN, true>(ta + h * (kGTile / 16), qb, bias, a00, a01, a10, a11, t0 - 32u, half, k0, k1);
-                }
-                if (t0 + 32u >= nt) {
-                    HM_LAST(a00, a01)
-                    done = true;
-                    break;
-                }
-                t0 += 32u;
-                if (wave_on) knn_chain4w<KNN, true>(ta + (h + 1) * (kGTile / 16), qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1);
-                if (t0 + 32u >= nt) {
-                    HM_LAST(a10, a11)
-                    done = true;
-                    break;
-                }
-                t0 += 32u;
+        for (int i = 0; i < 4; ++i) f[i] = tlane[(128 / 16) * i];
+        for (;; ++st) {
+            const uint4* ta = tlane + (size_t)((st % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
+            const uint4* tb = ta + kGTile / 16;
+            const uint4* tn = tlane + (size_t)(((st + 1u) % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
+            const bool last_a = t0 + 32u >= nt, last_b = t0 + 64u >= nt;
+            // (idle waves skip the arithmetic, not the boundary)
+            if (wave_on) {
+                if (st == 0) knn_chain4w<KNN, false>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, 0u, half, k0, k1, nothing);
+                else knn_chain4w<KNN, true>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, t0 - 32u, half, k0, k1, nothing);
             }
-            if (done) break;
+            if (last_a) {
+                HM_LAST(a00, a01)
+                break;
+            }
+            t0 += 32u;
+            if (last_b) {
+                if (wave_on) knn_chain4w<KNN, true>(tb, tb, f, qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1, nothing);
+                HM_LAST(a10, a11)
+                break;
+            }
+            if (wave_on) knn_chain4w<KNN, true>(tb, tn, f, qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1, boundary);
+            else boundary();
+            t0 += 32u;
         }
 #undef HM_LAST
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the requests past the end
