@@ -524,9 +524,13 @@ def main():
             # the matcher as a family of its own: 2 directions x nq x nt x 512-bit contractions per frame pair as MACs (2 ops each)
             ops_pair = 2.0 * 2.0 * (n_kp ** 2) * 512.0
             tops_m = ops_pair * NF * args.steps / (knn_ms.value * 1e-3) / 1e12
-            em = {"bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands: exact 2-NN of every descriptor, both directions)",
+            em = {"bound": "mfma", "kernel": "k_knn_mfma4w<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands, 64 resident queries per wave, target tiles by LDS-DMA: exact 2-NN of every descriptor, both directions)",
                   "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4),
                   "frac_is": "2 x 512 MACs per (query, target) pair / kernel time / the 10 PF dense FP4 MFMA peak",
+                  "peak_check": "the instruction alone sustains 9 870 TOP/s on this part (tools/ubench/mfma_fp4_rate.hip, "
+                                "profiles/r04_mfma_fp4_rate.txt); with 4 / 8 integer VALU instructions behind every MFMA — the key "
+                                "epilogue's share is ~4 — the same loop gives 5 880 / 4 140: FP4 MFMA and VALU do not overlap at two "
+                                "waves per SIMD, so the kernel's ceiling is MFMA time + epilogue time, ~0.58 of the peak",
                   "traffic": None, "launches": int(knn_launches.value), "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
                   "gpu_ms": round(knn_ms.value, 2), "gpu_ms_per_step": round(knn_ms.value / args.steps, 3),
                   "timed": "the k-NN launches' own start/stop events over the timed steps; the matcher's stream has the lowest priority, so "
@@ -582,7 +586,7 @@ def main():
             macs = 2.0 * pairs_total * (n_kp ** 2) * 512.0
             tops_m = 2.0 * macs / (knn_ms.value * 1e-3) / 1e12
             out["roofline_matcher"] = {
-                "bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
+                "bound": "mfma", "kernel": "k_knn_mfma4w<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
                 "achieved": round(tops_m, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(tops_m / MFMA_FP4_PEAK_TOPS, 4), "traffic": None, "launches": int(knn_launches.value),
                 "avg_launch_us": round(knn_ms.value * 1e3 / max(1, knn_launches.value), 2),
@@ -936,7 +940,7 @@ def extra_match(torch, dev, L, _lib, n_frames):
                        f"bit flips), {npr} consecutive pairs, symmetric d0 + 24 < d1, device-resident",
            "pairs_per_s": round(npr / dt, 1), "distances_per_s": round(dist_per_pair * npr / dt, 1),
            "ms_per_call": round(dt * 1e3, 3), "mean_matches_per_pair": round(npairs.float().mean().item(), 1),
-           "roofline": {"bound": "mfma", "kernel": "k_knn_mfma4<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
+           "roofline": {"bound": "mfma", "kernel": "k_knn_mfma4w<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
                         "achieved": round(tops, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
                         "frac": round(tops / MFMA_FP4_PEAK_TOPS, 4), "traffic": None,
                         "launches": int(launches.value),

@@ -6,6 +6,7 @@ cp gpurun_out/refresh/${T}_bench.json profiles/${T}_bench.json
 cp gpurun_out/refresh/${T}_bench_profiled.json profiles/${T}_bench_profiled.json
 cp gpurun_out/refresh/${T}_bench_kernel_stats.txt gpurun_out/refresh/${T}_pmc_traffic.json gpurun_out/refresh/${T}_pmc_fetch_size.txt gpurun_out/refresh/${T}_pmc_write_size.txt profiles/
 cp gpurun_out/pmc_sq_summary.txt profiles/${T}_pmc_sq_summary.txt
+(echo "# SQ counters of the k-NN launches of tools/bench_match.py (128 frame pairs, one repetition): the wide LDS-DMA kernel, then the register-staged one"; cat gpurun_out/pmc_matcher_fp4.txt gpurun_out/pmc_matcher_fp4_regs.txt) > profiles/${T}_pmc_matcher.txt
 cp gpurun_out/kstat_final.txt profiles/${T}_kstat_serial_64frames.txt
 (grep -i "single\|alone" gpurun_out/lat_plain.txt; cat gpurun_out/lat_trace.txt) > profiles/${T}_single_frame_timeline.txt
 ls -la profiles | grep ${T}_

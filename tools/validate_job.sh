@@ -4,9 +4,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -6
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-bash tools/refresh_profiles.sh r03 256 > gpurun_out/refresh.log 2>&1
+T=${1:-r04}
+bash tools/refresh_profiles.sh $T 256 > gpurun_out/refresh.log 2>&1
 tail -c 600 gpurun_out/refresh/bench.log
 KSTAT_LINES=60 bash tools/kstat.sh final > /dev/null 2>&1
 bash tools/pmc_sq.sh > /dev/null 2>&1
+bash tools/pmc_match.sh fp4 > /dev/null 2>&1
+bash tools/pmc_match.sh fp4_regs > /dev/null 2>&1
 bash tools/lat_job.sh > /dev/null 2>&1
 grep single gpurun_out/lat_plain.txt
