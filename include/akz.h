@@ -261,8 +261,9 @@ int32_t akz_sample_colors_rgb8(akz_ctx* ctx, const uint8_t* rgb, int32_t w, int3
 
 typedef struct hm_ctx hm_ctx;
 int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm_ctx** out);
-/* hm_create with kernel-selection flags (0 = defaults): the k-NN kernel is the FP4 MFMA one unless a flag
- * selects the int8 MFMA or the xor/popcount VALU kernel (k = 2 only); all three are bit-identical. */
+/* hm_create with kernel-selection flags (0 = defaults): the k-NN kernel is the FP4 MFMA one (64 resident queries per
+ * wave, target tiles by LDS-DMA) unless a flag selects its register-staged predecessor (HM_OPT_NO_LDS_DMA), the int8
+ * MFMA or the xor/popcount VALU kernel (k = 2 only); all four are bit-identical. */
 enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2, HM_OPT_NO_LDS_DMA = 1u << 3 };
 int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t max_targets, uint32_t flags, hm_ctx** out);
 int32_t hm_destroy(hm_ctx* ctx);

@@ -128,3 +128,18 @@ def test_round_half_away_by_one_add_and_floor():
         assert (got == want).all(), e
     neg = -np.concatenate([np.linspace(0, 1, 100001), [0.5, 0.49999997, 0.50000006, 0.25]]).astype(np.float32)
     assert (((neg + c) < 0) == (neg <= np.float32(-0.5))).all()
+
+
+def test_top2_insertion_of_a_pair_in_three_operations():
+    """The matcher keeps the two smallest keys per query (cv_amd/csrc/hm_match.hip: topk_insert2 / topk_merge2).  Two new
+    keys a, b go into the ascending pair (l0, l1) as  l0' = min3(l0, a, b),  l1' = min(l1, med3(l0, a, b))  — three
+    instructions instead of two insertions of two.  Exhaustive over small values with every tie pattern."""
+    v = np.arange(6)
+    l0, l1, a, b = np.meshgrid(v, v, v, v, indexing="ij")
+    keep = l0 <= l1
+    l0, l1, a, b = l0[keep], l1[keep], a[keep], b[keep]
+    want = np.sort(np.stack([l0, l1, a, b], 1), axis=1)[:, :2]
+    med3 = np.sort(np.stack([l0, a, b], 1), axis=1)[:, 1]
+    got0 = np.minimum(np.minimum(l0, a), b)
+    got1 = np.minimum(l1, med3)
+    assert (got0 == want[:, 0]).all() and (got1 == want[:, 1]).all()

@@ -81,9 +81,18 @@ def main():
     for i in range(a.n):
         w, h, thr, img = make_case(i, a.seed, a.arms)
         if img.dtype == np.uint8 and img.ndim == 2:
-            c = akaze.Context(akaze.Akaze.new(thr), w, h, 1, _lib.make_options(**kw) if kw else None)
-            (kp, d), = c.extract_batch([img])
-            c.close()
+            ak = akaze.Akaze.new(thr)
+            while True:                    # a dense noise frame can pass 16 384 keypoints: more room, as the host mirrors do
+                c = akaze.Context(ak, w, h, 1, _lib.make_options(**kw) if kw else None)
+                try:
+                    (kp, d), = c.extract_batch([img])
+                    break
+                except _lib.AkzError as e:
+                    if e.status != -7 or ak.max_keypoints >= akaze.MAX_KEYPOINTS:
+                        raise
+                    ak.max_keypoints = min(akaze.MAX_KEYPOINTS, 2 * int(ak.max_keypoints))
+                finally:
+                    c.close()
         else:
             kp, d = akaze.Akaze.new(thr).extract_arrays(img)       # the host mirror's dispatch on dtype / channels
         okp, od, n = want[i]
