@@ -373,6 +373,31 @@ def test_knn_k_bit_exact(gpu, oracle, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_knn_at_the_tile_stage_and_block_boundaries(gpu, oracle, k):
+    """The wide FP4 kernel streams targets in 32-row tiles, two tiles per LDS-DMA stage, three stages in a ring, with the stage
+    boundary inside the second tile's MFMA chain; a wave holds 64 queries, a block 256.  Every target count around a tile, a
+    stage and a ring revolution against every query count around a wave and a block, ties included, k = 1..3 — and the same
+    through the register-staged kernel."""
+    _, knn = gpu
+    rng = np.random.default_rng(900 + k)
+    nts = [k, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 385]
+    nqs = [1, 31, 33, 63, 64, 65, 191, 255, 256, 257]
+    pool_q = _rand_desc(rng, max(nqs)); pool_t = _rand_desc(rng, max(nts))
+    pool_t[rng.integers(0, len(pool_t), 150)] = pool_t[rng.integers(0, len(pool_t), 150)]      # duplicates: ties across tiles
+    pool_q[:40] = pool_t[rng.integers(0, len(pool_t), 40)]                                        # distance 0
+    for kernel in ("fp4", "fp4_regs"):
+        m = knn.Matcher(1024, kernel=kernel)
+        for nt in nts:
+            want_all = oracle.knn(pool_q, pool_t[:nt], k)
+            for nq in nqs:
+                got = m.knn(pool_q[:nq], pool_t[:nt], k)
+                _eq(got["index"], want_all["index"][:nq], f"{kernel} knn{k} idx {nq}x{nt}")
+                _eq(got["distance"], want_all["distance"][:nq], f"{kernel} knn{k} dist {nq}x{nt}")
+        m.close()
+
+
+@pytest.mark.gpu
 def test_knn_views_device(gpu, oracle):
     """hm_knn_views_device: one query frame against several stored views, k = 3, device-resident."""
     import ctypes as C
