@@ -1778,6 +1778,12 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
 #ifndef AKZ_OD_OCC
 #define AKZ_OD_OCC 7
 #endif
+#ifndef AKZ_OD_ABLATE
+#define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather
+#endif
+#ifndef AKZ_OD_WIN
+#define AKZ_OD_WIN 0      // experiment builds: 1 = window sums by bit test and selects instead of the execution mask
+#endif
 constexpr int kODWaves = 4;
 struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
     float xf, yf, scale;
@@ -1868,8 +1874,13 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         s_r[lane] = make_float2(rx0, ry0);
         s_r[lane + 64] = make_float2(rx1, ry1);
         // window membership of the samples (:261-287) from the end-point table (see k_refine)
+#if AKZ_OD_ABLATE & 8
+        msk0 = make_uint2(__float_as_uint(rx0) | 1u, __float_as_uint(ry0) & 0x3FFu);
+        msk1 = make_uint2(__float_as_uint(rx1) | 1u, __float_as_uint(ry1) & 0x3FFu);
+#else
         msk0 = ori_sample_masks(ry0, rx0, s_bnd, s_mopen, meq, nullptr);
         msk1 = ori_sample_masks(ry1, rx1, s_bnd, s_mopen, meq, nullptr);
+#endif
         if (!on1) msk1 = make_uint2(0u, 0u);
     }
     float angle;
@@ -1886,6 +1897,22 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
             const float2 rk = s_r[k];
             return (v2f){rk.x, rk.y};
         };
+#if AKZ_OD_ABLATE & 1
+        sum = (v2f){(float)msk0.x + s_r[lane & 63].x, (float)msk1.y + 1.0f};
+#elif AKZ_OD_WIN == 1
+        // (experiment: membership by per-lane bit test and selects — five VALU instructions per sample, no exec writes)
+        {
+            const int word = lane >> 5, bit = lane & 31;
+#pragma unroll
+            for (int k = 0; k < 109; ++k) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.x : msk1.x), k & 63);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.y : msk1.y), k & 63);
+                const bool in = ((word ? hi : lo) >> bit) & 1u;
+                const v2f r = rv(k);
+                sum += (v2f){in ? r.x : 0.0f, in ? r.y : 0.0f};
+            }
+        }
+#else
 #pragma unroll
         for (int k = 0; k + 4 <= 108; k += 4) {
             const unsigned long long m0 = m64(k), m1 = m64(k + 1), m2 = m64(k + 2), m3 = m64(k + 3);
@@ -1908,6 +1935,7 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
                 : [s] "+v"(sum), [sv] "=&s"(saved)
                 : [m0] "s"(m0), [r0] "v"(r0));
         }
+#endif
         const float sum_x = sum.x, sum_y = sum.y;
         const float val = sum_x * sum_x + sum_y * sum_y;
         // the serial loop keeps the FIRST window whose val exceeds every earlier one (a NaN never does).  val >= +0, so
@@ -1926,13 +1954,21 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         const int win = bal ? __ffsll((long long)bal) - 1 : 0;
         const float best_sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_x), win));
         const float best_sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_y), win));
+#if AKZ_OD_ABLATE & 4
+        angle = (mbits > 0) ? best_sy * 0.001f + best_sx * 0.002f : 0.0f;
+#else
         angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
+#endif
         if (lane == 0) kps[fbase + cur.ki].angle = angle;
     }
     // the segment changes hands: every LDS read above has returned before the writes below are issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- get_mldb_descriptor, descriptors.rs:66-72 (as k_describe_fast) ----
+#if AKZ_OD_ABLATE & 4
+    const float co = 1.0f - 0.5f * angle * angle, si = angle;
+#else
     const float co = akz_pm_cosf(angle), si = akz_pm_sinf(angle);
+#endif
     const float scale = cur.scale, xf = cur.xf, yf = cur.yf;
     const int W = cur.W, Hh = cur.Hh;
     bool oob = false;
@@ -1969,8 +2005,13 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     float2 dd[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+#if AKZ_OD_ABLATE & 16
+        ri[it] = (float)idx[it];
+        dd[it] = make_float2((float)idx[it] * 0.5f, 1.0f);
+#else
         ri[it] = cur.LT[idx[it]];
         dd[it] = cur.LXY[idx[it]];
+#endif
     }
     const v2f rot_x = {co, -si}, rot_y = {si, co};
 #pragma unroll
@@ -1987,9 +2028,13 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     }
     oob = __any(oob);
     if (!oob) {
+#if AKZ_OD_ABLATE & 2
+        const float m2 = s_ri[lane], m3 = s_dx[lane], m4 = s_dy[lane];
+#else
         const float m2 = desc_cell_mean<10, 2>(s_ri, s_dx, s_dy, lane);
         const float m3 = desc_cell_mean<7, 3>(s_ri, s_dx, s_dy, lane);
         const float m4 = desc_cell_mean<5, 4>(s_ri, s_dx, s_dy, lane);
+#endif
         // (a wave's LDS accesses execute in order: the sums above have read the planes before these stores land on them)
         if (lane < 12) s_val[lane] = m2;
         if (lane < 27) s_val[12 + lane] = m3;
