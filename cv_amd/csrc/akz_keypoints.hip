@@ -578,6 +578,9 @@ struct OriTables {
     // the host with ori_window_contains, the predicate the summation used to evaluate per (window, sample).
     float bnd[128];
     uint2 m_open[128], m_eq[128];
+    // the same two tables interleaved for a lookup by scalar load: m_tab[2 r] = m_open[r], m_tab[2 r + 1] = m_eq[r], and
+    // m_tab[256] = no window (the lanes of k_orient_describe that carry no sample)
+    uint2 m_tab[257];
 };
 
 // scale_space_extrema.rs:261-287: is `ang` inside the window that starts at ang1 (width pi/3, wrapping at 2 pi)
@@ -1710,8 +1713,8 @@ __device__ __forceinline__ int ori_rank(const float* s_bnd, float ang)
 // wrap of rem_euclid is covered by the same band.  (0, +x): exactly 0 in the reference, and common (flat areas, vertical
 // edges): taken without the fallback.  Returns the membership bits (bit = window).
 constexpr float kOriEps = 8e-6f;
-__device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const float* s_bnd, const uint2* s_mopen, const uint2* meq,
-                                                  bool* fell_back)
+// Returns the sample's entry of OriTables::m_tab: 2 rank + (the angle IS end point `rank`).
+__device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float* s_bnd, bool* fell_back)
 {
     const float ax = fabsf(rx), ay = fabsf(ry);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
@@ -1742,9 +1745,7 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
         b1 = s_bnd[r];
     }
     if (fell_back) *fell_back = !sure;
-    uint2 mm = s_mopen[r];
-    if (b1 == ang) mm = meq[r];          // the angle IS an end point (rare: this table stays in global memory)
-    return mm;
+    return 2 * r + (b1 == ang ? 1 : 0);
 }
 
 // A14 + A16 + A17 for the default pattern: main orientation (as in k_refine), then the descriptor (as in
@@ -1756,7 +1757,7 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
 // that, a chain of dependent memory round trips: count -> permutation -> keypoint record -> sample offsets -> orientation
 // samples -> ... -> lattice samples -> comparison tables -> store, with six waves per SIMD to hide it):
 //   * window membership from an f32 estimate of the angle, the exact f64 expression only inside a band around the
-//     windows' end points (ori_sample_masks);
+//     windows' end points (ori_sample_entry);
 //   * the 42 window sums run with the sample's membership bits AS the execution mask: sample k's 64-bit mask goes from
 //     its owner lane to an SGPR pair (v_readlane), `s_mov exec` and one v_pk_add_f32 add {Lx, Ly} in exactly the lanes
 //     (windows) that contain it — 3 VALU instructions per sample instead of 5 (bit test, compare, two selects, add), and
@@ -1781,9 +1782,6 @@ __device__ __forceinline__ uint2 ori_sample_masks(float ry, float rx, const floa
 #ifndef AKZ_OD_ABLATE
 #define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather
 #endif
-#ifndef AKZ_OD_WIN
-#define AKZ_OD_WIN 0      // experiment builds: 1 = window sums by bit test and selects instead of the execution mask
-#endif
 constexpr int kODWaves = 4;
 struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
     float xf, yf, scale;
@@ -1802,19 +1800,14 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
 {
     constexpr int LAT = 21, NIT = 7, SMAX = LAT * LAT;
     typedef float v2f __attribute__((ext_vector_type(2)));
-    // LDS: 1.5 KB of tables + 4 x 5 296 B of lattice planes = 22 720 B, seven blocks (seven waves per SIMD) per CU.  The cell
-    // means overwrite the planes once the last sum has read them; the table for angles that ARE an end point stays in global
-    // memory (ori_sample_masks).
+    // LDS: the end points (512 B) + 4 x 5 296 B of lattice planes = 21 696 B, seven blocks (seven waves per SIMD) per CU.  The
+    // cell means overwrite the planes once the last sum has read them; the membership table is read by scalar loads (below).
     __shared__ float s_bnd[128];
-    __shared__ uint2 s_mopen[128];
     __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 1];     // (+ 1: every wave's segment 16-byte aligned)
     const OriTables& c_ori = *ori_p;
     const DescTables& c_desc = *desc_p;
-    if (threadIdx.x < 128) {
-        s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
-        s_mopen[threadIdx.x] = c_ori.m_open[threadIdx.x];
-    }
-    const uint2* meq = c_ori.m_eq;
+    if (threadIdx.x < 128) s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
+    const uint2* __restrict__ m_tab = c_ori.m_tab;
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1867,7 +1860,7 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     if (outside) atomicOr(err, 8u);        // the reference would panic here
     const float2 smp0 = cur.LXY[o0], smp1 = cur.LXY[o1];
     // ---- compute_main_orientation, scale_space_extrema.rs:229-288 ----
-    uint2 msk0, msk1;                                              // membership bits of samples lane and 64 + lane
+    int ent0, ent1;                                                // m_tab entries of samples lane and 64 + lane
     {
         const float rx0 = gw0 * smp0.x, ry0 = gw0 * smp0.y;
         const float rx1 = gw1 * smp1.x, ry1 = gw1 * smp1.y;
@@ -1875,43 +1868,32 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         s_r[lane + 64] = make_float2(rx1, ry1);
         // window membership of the samples (:261-287) from the end-point table (see k_refine)
 #if AKZ_OD_ABLATE & 8
-        msk0 = make_uint2(__float_as_uint(rx0) | 1u, __float_as_uint(ry0) & 0x3FFu);
-        msk1 = make_uint2(__float_as_uint(rx1) | 1u, __float_as_uint(ry1) & 0x3FFu);
+        ent0 = (int)(__float_as_uint(rx0) & 127u) * 8;
+        ent1 = (int)(__float_as_uint(ry1) & 127u) * 8;
 #else
-        msk0 = ori_sample_masks(ry0, rx0, s_bnd, s_mopen, meq, nullptr);
-        msk1 = ori_sample_masks(ry1, rx1, s_bnd, s_mopen, meq, nullptr);
+        ent0 = 8 * ori_sample_entry(ry0, rx0, s_bnd, nullptr);       // (as byte offsets into the table)
+        ent1 = 8 * ori_sample_entry(ry1, rx1, s_bnd, nullptr);
 #endif
-        if (!on1) msk1 = make_uint2(0u, 0u);
+        if (!on1) ent1 = 8 * 256;
     }
     float angle;
     {
         // sums of the windows, lane <-> window, samples in the reference's order
         v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
-        // four samples per step: their masks travel to SGPRs together, the execution mask is restored once
+        // Four samples per step.  A sample's 42 membership bits reach an SGPR pair without crossing the vector ALU twice: its
+        // table ENTRY travels (one v_readlane), the bits follow by scalar load from the 2 KB table (resident in the scalar
+        // cache): tools/ubench/window_sum.hip prices a v_readlane at ~4.3 of the step's 18 SIMD cycles.
         auto m64 = [&](int k) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.x : msk1.x), k & 63);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.y : msk1.y), k & 63);
-            return ((unsigned long long)hi << 32) | lo;
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane(k < 64 ? ent0 : ent1, k & 63);      // byte offset of the entry
+            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(m_tab) + e);
+            return ((unsigned long long)mk.y << 32) | mk.x;
         };
         auto rv = [&](int k) {
             const float2 rk = s_r[k];
             return (v2f){rk.x, rk.y};
         };
 #if AKZ_OD_ABLATE & 1
-        sum = (v2f){(float)msk0.x + s_r[lane & 63].x, (float)msk1.y + 1.0f};
-#elif AKZ_OD_WIN == 1
-        // (experiment: membership by per-lane bit test and selects — five VALU instructions per sample, no exec writes)
-        {
-            const int word = lane >> 5, bit = lane & 31;
-#pragma unroll
-            for (int k = 0; k < 109; ++k) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.x : msk1.x), k & 63);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64 ? msk0.y : msk1.y), k & 63);
-                const bool in = ((word ? hi : lo) >> bit) & 1u;
-                const v2f r = rv(k);
-                sum += (v2f){in ? r.x : 0.0f, in ? r.y : 0.0f};
-            }
-        }
+        sum = (v2f){(float)ent0 + s_r[lane & 63].x, (float)ent1 + 1.0f};
 #else
 #pragma unroll
         for (int k = 0; k + 4 <= 108; k += 4) {
@@ -2141,7 +2123,10 @@ int32_t akz_upload_tables(akz_ctx* c)
             // or one below b[0]; above the last end point (>= 2 pi) nothing is a member
             float probe = r == 0 ? -1.0f : (r <= nb ? nextafterf(b[r - 1], INFINITY) : INFINITY);
             ot.m_open[r] = (r <= nb && !(r < nb && probe >= b[r])) ? mask_of(probe) : make_uint2(0u, 0u);
+            ot.m_tab[2 * r] = ot.m_open[r];
+            ot.m_tab[2 * r + 1] = ot.m_eq[r];
         }
+        ot.m_tab[256] = make_uint2(0u, 0u);
         // self-check of the table against the predicate at every end point and the floats next to it
         auto lookup = [&](float ang) {
             int r = 0;
@@ -2381,28 +2366,23 @@ extern "C" int32_t akz_debug_portable_math(akz_ctx* c, int32_t which, const floa
 }
 
 // ---- parity tap: the orientation samples' window membership, both ways ----
-// fast[i]: ori_sample_masks (the kernel's path: f32 estimate, exact expression inside the band); exact[i]: the exact
+// fast[i]: ori_sample_entry + the table (the kernel's path: f32 estimate, exact expression inside the band); exact[i]: the exact
 // expression alone; fell[i]: 1 where the band sent the sample to the exact expression.
 __global__ __launch_bounds__(256) void k_debug_ori_masks(const OriTables* __restrict__ ori_p, const float* __restrict__ x,
                                                          const float* __restrict__ y, uint32_t n, uint2* __restrict__ fast,
                                                          uint2* __restrict__ exact, uint32_t* __restrict__ fell)
 {
     __shared__ float s_bnd[128];
-    __shared__ uint2 s_mopen[128], s_meq[128];
-    if (threadIdx.x < 128) {
-        s_bnd[threadIdx.x] = ori_p->bnd[threadIdx.x];
-        s_mopen[threadIdx.x] = ori_p->m_open[threadIdx.x];
-        s_meq[threadIdx.x] = ori_p->m_eq[threadIdx.x];
-    }
+    if (threadIdx.x < 128) s_bnd[threadIdx.x] = ori_p->bnd[threadIdx.x];
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     bool fb = false;
-    fast[i] = ori_sample_masks(y[i], x[i], s_bnd, s_mopen, ori_p->m_eq, &fb);
+    fast[i] = ori_p->m_tab[ori_sample_entry(y[i], x[i], s_bnd, &fb)];
     fell[i] = fb ? 1u : 0u;
     const float ang = fast_atan2_equiv(y[i], x[i]);
     const int r = ori_rank(s_bnd, ang);
-    exact[i] = s_bnd[r] == ang ? s_meq[r] : s_mopen[r];
+    exact[i] = s_bnd[r] == ang ? ori_p->m_eq[r] : ori_p->m_open[r];
 }
 
 extern "C" int32_t akz_debug_orientation_masks(akz_ctx* c, const float* x, const float* y, uint32_t n, uint64_t* fast,
