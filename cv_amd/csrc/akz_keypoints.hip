@@ -1758,16 +1758,16 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 // samples -> ... -> lattice samples -> comparison tables -> store, with six waves per SIMD to hide it):
 //   * window membership from an f32 estimate of the angle, the exact f64 expression only inside a band around the
 //     windows' end points (ori_sample_entry);
-//   * the 42 window sums run with the sample's membership bits AS the execution mask: sample k's 64-bit mask goes from
-//     its owner lane to an SGPR pair (v_readlane), `s_mov exec` and one v_pk_add_f32 add {Lx, Ly} in exactly the lanes
-//     (windows) that contain it — 3 VALU instructions per sample instead of 5 (bit test, compare, two selects, add), and
-//     a sample outside a window is skipped as the reference skips it;
+//   * the 42 window sums run with the sample's membership bits AS the execution mask: sample k's table entry goes from
+//     its owner lane to an SGPR (v_readlane), its 64-bit mask follows by scalar load from the 2 KB table, `s_mov exec` and
+//     one v_pk_add_f32 add {Lx, Ly} in exactly the lanes (windows) that contain it — 2 VALU instructions per sample
+//     instead of 5 (bit test, compare, two selects, add), and a sample outside a window is skipped as the reference skips it;
 //   * the window maximum by DPP row operations;
 //   * the descriptor lattice as 7 rounds of 3 rows x 21 columns (lane 63 idle): the lane's column term and the integer
 //     division leave the loop; coordinates rounded by round_flr_i32;
 //   * the per-lane tables (sample offsets, weights, comparison pairs) are requested before the wave's first wait, so no
-//     round trip precedes the comparisons; the cell means overwrite the dead lattice planes and the table for angles that
-//     ARE an end point stays in global memory: 22.7 KB of LDS per block, seven waves per SIMD instead of six (which
+//     round trip precedes the comparisons; the cell means overwrite the dead lattice planes and the membership table
+//     is read by scalar loads: 21.7 KB of LDS per block, seven waves per SIMD instead of six (which
 //     measures the same, 5.51 against 5.42 ms per 256 frames: the kernel is no longer waiting on round trips — VALU issue
 //     ~50 %, LDS and the texture path ~30 % each, no unit saturated).
 //   (Built and dropped: a wave walking 4 / 8 / 16 consecutive keypoints with the next keypoint's samples requested behind
