@@ -143,3 +143,17 @@ def test_top2_insertion_of_a_pair_in_three_operations():
     got0 = np.minimum(np.minimum(l0, a), b)
     got1 = np.minimum(l1, med3)
     assert (got0 == want[:, 0]).all() and (got1 == want[:, 1]).all()
+
+
+def test_top3_insertion_in_three_operations():
+    """k = 3 (cv-sfm's registration path): a new key v goes into the ascending triple (l0, l1, l2) as
+    l0' = min(l0, v), l1' = med3(l0, l1, v), l2' = med3(l1, l2, v) (cv_amd/csrc/hm_match.hip: topk_insert<3>).
+    Exhaustive over small values with every tie pattern."""
+    v = np.arange(6)
+    l0, l1, l2, x = np.meshgrid(v, v, v, v, indexing="ij")
+    keep = (l0 <= l1) & (l1 <= l2)
+    l0, l1, l2, x = l0[keep], l1[keep], l2[keep], x[keep]
+    want = np.sort(np.stack([l0, l1, l2, x], 1), axis=1)[:, :3]
+    med = lambda a, b, c: np.sort(np.stack([a, b, c], 1), axis=1)[:, 1]
+    got = np.stack([np.minimum(l0, x), med(l0, l1, x), med(l1, l2, x)], 1)
+    assert (got == want).all()
