@@ -1880,6 +1880,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     {
         // sums of the windows, lane <-> window, samples in the reference's order
         v2f sum = {0.0f, 0.0f};                       // {sum_x, sum_y}: one packed add per sample
+        // (EXEC is rewritten inside the statements below and restored by them; every lane of the wave is live here — the only
+        // exit above is taken by whole waves — so no lane the compiler holds inactive can be switched on.)
         // Four samples per step.  A sample's 42 membership bits reach an SGPR pair without crossing the vector ALU twice: its
         // table ENTRY travels (one v_readlane), the bits follow by scalar load from the 2 KB table (resident in the scalar
         // cache): tools/ubench/window_sum.hip prices a v_readlane at ~4.3 of the step's 18 SIMD cycles.

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __r
             for (int i = 0; i < 8; ++i) qb[cb][i] = qp[2 * i] ^ (int)0x88888888;
         }
         const unsigned char* tg = reinterpret_cast<const unsigned char*>(P.t);   // 256 B per descriptor
-        const uint32_t lds0 = (uint32_t)(uintptr_t)s_t;                          // LDS byte address of the ring
+        const uint32_t lds0 = (uint32_t)(uintptr_t)s_t;                          // LDS byte address of the ring (the low half of its flat address)
         const uint32_t drow = 8u * wv + (lane & 3u), dchunk = lane >> 2;          // this lane's share: rows drow and drow + 4
         // request the tiles of stage `st` (rows past the end repeat the last descriptor: the counts stay uniform)
         auto issue = [&](uint32_t st) {
