@@ -670,8 +670,12 @@ __device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const 
     }
 }
 
+#ifndef AKZ_G_PP
+#define AKZ_G_PP 1       // 1: two accumulator sets, the previous tile's keys taken inside the next tile's chain (two waves per
+#endif                   //    SIMD); 0 (experiment): one set, the keys taken right behind the chain, three waves per SIMD
+                         //    (168 registers): 3.32 against 2.82 ms per 256 frame pairs
 template <int KNN>
-__global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
+__global__ __launch_bounds__(kWideBlock, AKZ_G_PP ? 2 : 3) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
 {
     static_assert(kGStages >= 3 && kGTps == 2, "ring shape");
     __shared__ __attribute__((aligned(16))) unsigned char s_t[kGStages * kGTps * kGTile];
@@ -768,6 +772,7 @@ __global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __r
             const uint4* tn = tlane + (size_t)(((st + 1u) % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
             const bool last_a = t0 + 32u >= nt, last_b = t0 + 64u >= nt;
             // (idle waves skip the arithmetic, not the boundary)
+#if AKZ_G_PP
             if (wave_on) {
                 if (st == 0) knn_chain4w<KNN, false>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, 0u, half, k0, k1, nothing);
                 else knn_chain4w<KNN, true>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, t0 - 32u, half, k0, k1, nothing);
@@ -785,6 +790,21 @@ __global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __r
             if (wave_on) knn_chain4w<KNN, true>(tb, tn, f, qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1, boundary);
             else boundary();
             t0 += 32u;
+#else
+            if (wave_on) knn_chain4w<KNN, false>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, nothing);
+            HM_LAST(a00, a01)
+            if (last_a) break;
+            t0 += 32u;
+            if (last_b) {
+                if (wave_on) knn_chain4w<KNN, false>(tb, tb, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, nothing);
+                HM_LAST(a00, a01)
+                break;
+            }
+            if (wave_on) knn_chain4w<KNN, false>(tb, tn, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, boundary);
+            else boundary();
+            HM_LAST(a00, a01)
+            t0 += 32u;
+#endif
         }
 #undef HM_LAST
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the requests past the end
