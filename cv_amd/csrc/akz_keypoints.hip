@@ -1780,7 +1780,7 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 #define AKZ_OD_OCC 7
 #endif
 #ifndef AKZ_OD_ABLATE
-#define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather
+#define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather, 32 f32 / hardware trigonometry (same angles to ~1e-6)
 #endif
 constexpr int kODWaves = 4;
 struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
@@ -1940,6 +1940,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         const float best_sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_y), win));
 #if AKZ_OD_ABLATE & 4
         angle = (mbits > 0) ? best_sy * 0.001f + best_sx * 0.002f : 0.0f;
+#elif AKZ_OD_ABLATE & 32
+        angle = (mbits > 0) ? atan2f(best_sy, best_sx) + (best_sy < 0.0f ? 6.2831855f : 0.0f) : 0.0f;   // (nearly the same angle, f32)
 #else
         angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
 #endif
@@ -1950,6 +1952,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     // ---- get_mldb_descriptor, descriptors.rs:66-72 (as k_describe_fast) ----
 #if AKZ_OD_ABLATE & 4
     const float co = 1.0f - 0.5f * angle * angle, si = angle;
+#elif AKZ_OD_ABLATE & 32
+    const float co = __cosf(angle), si = __sinf(angle);                  // (nearly the same values, hardware approximations)
 #else
     const float co = akz_pm_cosf(angle), si = akz_pm_sinf(angle);
 #endif
