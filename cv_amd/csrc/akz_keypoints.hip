@@ -1782,7 +1782,10 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 #ifndef AKZ_OD_ABLATE
 #define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather, 32 f32 / hardware trigonometry (same angles to ~1e-6)
 #endif
-constexpr int kODWaves = 4;
+#ifndef AKZ_OD_WAVES
+#define AKZ_OD_WAVES 4     // keypoints (waves) per block: 2 / 4 / 8 / 16 measure 1 332 / 1 288 / 1 372 / 1 633 us per 64 frames
+#endif
+constexpr int kODWaves = AKZ_OD_WAVES;
 struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
     float xf, yf, scale;
     const float* LT;
