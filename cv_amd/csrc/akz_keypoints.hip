@@ -1782,6 +1782,9 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 #ifndef AKZ_OD_ABLATE
 #define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather, 32 f32 / hardware trigonometry (same angles to ~1e-6)
 #endif
+#ifndef AKZ_OD_MAP
+#define AKZ_OD_MAP 0       // 0: an XCD takes whole frames; 1 (experiment): the eight XCDs share every frame (1 535 against 1 284 us per 64 frames)
+#endif
 #ifndef AKZ_OD_WAVES
 #define AKZ_OD_WAVES 4     // keypoints (waves) per block: 2 / 4 / 8 / 16 measure 1 332 / 1 288 / 1 372 / 1 633 us per 64 frames
 #endif
@@ -1811,6 +1814,21 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     const DescTables& c_desc = *desc_p;
     if (threadIdx.x < 128) s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
     const uint2* __restrict__ m_tab = c_ori.m_tab;
+#if AKZ_OD_MAP == 1
+    // Every XCD works on the SAME frame, each on its own eighth of the frame's keypoints in visiting order (level, tile row,
+    // tile column): workgroup id -> XCD id % 8 (observed), so id = 8 (frame * per + j) + xcd takes block xcd * chunk + j.
+    const uint32_t orig = blockIdx.x + gridDim.x * blockIdx.y, xcd = orig & 7u, m = orig >> 3, per = gridDim.x >> 3;
+    const int frame = (int)(m / per);
+    const uint32_t jb = m - (uint32_t)frame * per;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const size_t fbase = (size_t)frame * stride;
+    __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
+    const uint32_t n = min(n_in[frame], stride);
+    const uint32_t chunk = ((n + kODWaves - 1) / kODWaves + 7u) >> 3;
+    if (jb >= chunk) return;  // whole block
+    const uint32_t vi = (xcd * chunk + jb) * kODWaves + (uint32_t)wv;
+    if (vi >= n) return;  // whole wave
+#else
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1819,6 +1837,7 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
     const uint32_t n = min(n_in[frame], stride);
     if (vi >= n) return;  // whole wave
+#endif
     const uint32_t ki = perm[fbase + vi];  // spatially coherent visiting order
     const DevKp kp = kps[fbase + ki];
     const bool on1 = lane + 64 < 109;
@@ -2323,7 +2342,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         AKZ_LAUNCH_CHECK();
         if (orient_in_desc) {
             akz_timer_begin(c, AKZ_T_ORIENT_DESCRIBE_K, s);
-            AKZ_LAUNCH(k_orient_describe, dim3((uint32_t)akz_div_up((int)c->max_kp, kODWaves), n), dim3(64 * kODWaves), 0, s, T,
+            AKZ_LAUNCH(k_orient_describe, dim3(((uint32_t)akz_div_up((int)c->max_kp, kODWaves) + 7u) & ~7u, n), dim3(64 * kODWaves), 0, s, T,
                        (const OriTables*)c->d_ori, (const DescTables*)c->d_desc, S.d_kp_d, S.d_n_d, c->max_kp,
                        S.d_perm, S.d_desc_tmp, S.d_flag_d, c->d_err);
             akz_timer_end(c, AKZ_T_ORIENT_DESCRIBE_K, s, 1, (uint64_t)n);
