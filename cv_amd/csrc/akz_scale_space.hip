@@ -1349,9 +1349,50 @@ __device__ __forceinline__ void fed_store_patch(const v2f (&L)[4][4], float* __r
     }
 }
 
+// half_size (image.rs:154-199, as k_half_size) of the level an octave ends with, from the patch the level's LAST FED launch
+// holds in registers: the next octave's first image without reading the level back (w % 4 == 0, patches 4-aligned, so
+// every 2 x 2 window lies inside one patch).  An odd height keeps the reference's rule: the last output row is the 1 x 2
+// mean of the LAST input row alone.
+__device__ __forceinline__ void fed_store_half(const v2f (&L)[4][4], float* __restrict__ half, int fa, int fb, bool has_b,
+                                               size_t hfs, int w, int h, int x0, int y0)
+{
+    const int ow = w >> 1, oh = h >> 1;
+    const bool odd_h = (h & 1) != 0;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = y0 + 2 * rr;
+        if (y >= h) break;
+        const int oy = y >> 1;
+        v2f v0, v1;
+        bool put = false;
+        int orow = oy;
+        if (oy < oh && !(odd_h && oy == oh - 1)) {
+            if constexpr (kArithHalfSeq) {   // ndarray's fold over the window in memory order
+                v0 = (((L[2 * rr][0] + L[2 * rr][1]) + L[2 * rr + 1][0]) + L[2 * rr + 1][1]) * splat(0.25f);
+                v1 = (((L[2 * rr][2] + L[2 * rr][3]) + L[2 * rr + 1][2]) + L[2 * rr + 1][3]) * splat(0.25f);
+            } else {
+                v0 = ((L[2 * rr][0] + L[2 * rr][1]) + (L[2 * rr + 1][0] + L[2 * rr + 1][1])) * splat(0.25f);
+                v1 = ((L[2 * rr][2] + L[2 * rr][3]) + (L[2 * rr + 1][2] + L[2 * rr + 1][3])) * splat(0.25f);
+            }
+            put = true;
+        } else if (odd_h && y == h - 1) {
+            v0 = (L[2 * rr][0] + L[2 * rr][1]) * splat(0.5f);
+            v1 = (L[2 * rr][2] + L[2 * rr][3]) * splat(0.5f);
+            orow = oh - 1;
+            put = oh > 0;
+        }
+        if (put) {
+            const size_t o = (size_t)orow * ow + (x0 >> 1);
+            *reinterpret_cast<float2*>(half + (size_t)fa * hfs + o) = make_float2(v0.x, v1.x);
+            if (has_b) *reinterpret_cast<float2*>(half + (size_t)fb * hfs + o) = make_float2(v0.y, v1.y);
+        }
+    }
+}
+
 template <int T>
 __global__ __launch_bounds__(256, 4) void k_fed_pair(const float* __restrict__ src, const float* __restrict__ cnd,
-                                                  float* __restrict__ dst, int w, int h, size_t fs, int n, FedTaus taus)
+                                                  float* __restrict__ dst, int w, int h, size_t fs, int n, FedTaus taus,
+                                                  float* __restrict__ half_out, size_t half_fs)
 {
     __shared__ __attribute__((aligned(16))) float4 s_top[256 * 2];   // [patch][4 px x 2 frames]: top image rows
     __shared__ __attribute__((aligned(16))) float4 s_vd[256 * 2];    // bottom-edge flows
@@ -1382,7 +1423,10 @@ __global__ __launch_bounds__(256, 4) void k_fed_pair(const float* __restrict__ s
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
     const bool useful = pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in;
     fed_steps(L, C, s_top, s_ct, s_vd, taus, T, tid, up, dn, x0, y0, w, h);
-    if (useful) fed_store_patch(L, dst, fa, fb, has_b, fs, w, h, x0, y0);
+    if (useful) {
+        fed_store_patch(L, dst, fa, fb, has_b, fs, w, h, x0, y0);
+        if (half_out) fed_store_half(L, half_out, fa, fb, has_b, half_fs, w, h, x0, y0);
+    }
 }
 
 
@@ -1471,6 +1515,9 @@ __device__ __forceinline__ void front_fed_fetch(float4 (&ra)[ITEMS], float4 (&rb
 #ifndef AKZ_FF_WAVES
 #define AKZ_FF_WAVES 3
 #endif
+#ifndef AKZ_FUSE_HALF
+#define AKZ_FUSE_HALF 1      // the half-sized start image of an octave from the previous level's last FED launch (0: k_half_size)
+#endif
 #ifndef AKZ_FF_SUMS
 #define AKZ_FF_SUMS 1
 #endif
@@ -1479,7 +1526,7 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
                                                       GaussTaps taps, OffK k, FedTaus taus, int nsteps,
                                                       float* __restrict__ out_lt, float* __restrict__ out_flow,
                                                       float2* __restrict__ out_xy, const float* __restrict__ invk,
-                                                      int invk_off)
+                                                      int invk_off, float* __restrict__ half_out, size_t half_fs)
 {
     // one block of LDS, three lives: input window [kFFIn][kFFInC], blurred window [kFFW + 2][kFFGS] (one apron row
     // above and below), FED exchange buffers
@@ -1832,7 +1879,10 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
     fed_steps(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
 #endif
     FF_STAMP(8);
-    if (useful) fed_store_patch(L, out_lt, fa, fb, has_b, fs, w, h, x0, y0);
+    if (useful) {
+        fed_store_patch(L, out_lt, fa, fb, has_b, fs, w, h, x0, y0);
+        if (half_out) fed_store_half(L, half_out, fa, fb, has_b, half_fs, w, h, x0, y0);
+    }
     FF_STAMP(9);
 }
 
@@ -2708,6 +2758,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     // the side stream shortens the dependency chain of a few-frame call; a batch fills the chip either way (measured:
     // 6342 vs 6310 frames/s) and its kernels are easier to read in a profile when they do not overlap each other
     const bool det_side = c->det_side_stream && c->stream_det != nullptr && n <= kLatencyFrames;
+    int half_ready = -1;        // the level whose half-sized start image its predecessor's last FED launch has written
     for (int i = 0; i < nlev; ++i) {
         const AkzLevel& L = P.levels[i];
         const size_t fs = L.pixels();
@@ -2729,8 +2780,22 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // which a batch would lose on (see above) and a single frame wins on
             if (n <= kLatencyFrames && L.octave > 0 && c->fed_block == 8) fed_block = kFedMaxBlock;
             const int nwrites = blocked ? (nsteps + fed_block - 1) / fed_block : nsteps;  // FED launches
+            // The level an octave ends with hands the next octave its half-sized start image straight from the registers of
+            // its last FED launch (fed_store_half) instead of being read back by k_half_size.  The image goes to the plane of
+            // the level AFTER the next one, which nobody touches until that level's own diffusion.
+            float* half_next = nullptr;
+            size_t half_next_fs = 0;
+#if AKZ_FUSE_HALF
+            if (blocked && nsteps > 0 && i + 2 < nlev && P.levels[i + 1].new_octave && P.levels[i + 1].w == (L.w >> 1) &&
+                P.levels[i + 1].h == (L.h >> 1) && !P.levels[i + 2].new_octave) {
+                half_next = S.Lt[i + 2];
+                half_next_fs = P.levels[i + 1].pixels();
+            }
+#endif
             const float* init;
-            if (L.new_octave) {
+            if (L.new_octave && half_ready == i) {
+                init = S.Lt[i + 1];      // written by the previous level's last FED launch (fed_store_half)
+            } else if (L.new_octave) {
                 const AkzLevel& Lp = P.levels[i - 1];
                 // the first FED launch must not write where it reads: with an odd number of launches the
                 // first one writes Lt[i], so the half-sized image goes to the scratch plane, and vice versa
@@ -2770,7 +2835,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     AKZ_LAUNCH((k_front_fed<SGV, HPV, RGV, WFV>),                                                             \
                        dim3(akz_div_up(L.w, front_fed_tile(HPV)), akz_div_up(L.h, front_fed_tile(HPV)), (n + 1) / 2), \
                        dim3(256), 0, s, init, L.w, L.h, fs, n, t1, kk, ft, groups[0], dst0, S.Lflow[i], S.Lxy[i],      \
-                       (const float*)S.d_invk, (int)L.octave)
+                       (const float*)S.d_invk, (int)L.octave, ng == 1 ? half_next : (float*)nullptr, half_next_fs)
 #define AKZ_FF2(SGV, HPV, RGV) if (ng > 1) { AKZ_FF3(SGV, HPV, RGV, true); } else { AKZ_FF3(SGV, HPV, RGV, false); }
 #define AKZ_FF(SGV)                                                                                                  \
     if (groups[0] <= 3) { AKZ_FF2(SGV, 1, false) } else { AKZ_FF2(SGV, 1, true) }
@@ -2833,7 +2898,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
 #define AKZ_FED_CASE(TT)                                                                                              \
     case TT: {                                                                                                        \
         dim3 gridp(akz_div_up(L.w, fed_tile_edge(TT)), akz_div_up(L.h, fed_tile_edge(TT)), (n + 1) / 2);              \
-        AKZ_LAUNCH((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft);     \
+        AKZ_LAUNCH((k_fed_pair<TT>), gridp, dim3(256), 0, s, src, S.Lflow[i], dstb, L.w, L.h, fs, n, ft,      \
+                   gi == ng - 1 ? half_next : (float*)nullptr, half_next_fs);                                        \
     } break;
                     const int t_fed = AKZ_T_FED_T1 + (groups[gi] <= 8 ? groups[gi] : 8) - 1;   // (9..16 steps: single-frame calls only)
                     akz_timer_begin(c, t_fed, s);
@@ -2859,6 +2925,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 src = dst;
             }
             akz_timer_end(c, AKZ_T_FED, s, (uint64_t)nwrites, (uint64_t)nsteps * fs * n, (uint64_t)nwrites * fs * n);
+            if (half_next) half_ready = i + 1;
             fed_launches += nsteps;
             fed_units += (uint64_t)nsteps * fs * n;
             if (nsteps == 0 && init != bufA)
