@@ -1682,10 +1682,11 @@ __device__ __forceinline__ unsigned round_sat_u32(float v)
 }
 // `f32 as isize` of the rounded value where only "inside [0, n)" matters: any v <= -0.5 gives a negative result (not
 // necessarily roundf's), NaN gives 0 as Rust's cast does, the infinities saturate.
-__device__ __forceinline__ int round_flr_i32(float v)
+// (the caller has already added 0.49999997f: k_orient_describe does it for both coordinates in one packed add)
+__device__ __forceinline__ int round_flr_i32_biased(float v_plus_bias)
 {
     int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v + 0.49999997f));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v_plus_bias));
     return r;
 }
 
@@ -1764,7 +1765,7 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 //     instead of 5 (bit test, compare, two selects, add), and a sample outside a window is skipped as the reference skips it;
 //   * the window maximum by DPP row operations;
 //   * the descriptor lattice as 7 rounds of 3 rows x 21 columns (lane 63 idle): the lane's column term and the integer
-//     division leave the loop; coordinates rounded by round_flr_i32;
+//     division leave the loop; coordinates rounded by one add and v_cvt_flr_i32_f32 (round_flr_i32_biased);
 //   * the per-lane tables (sample offsets, weights, comparison pairs) are requested before the wave's first wait, so no
 //     round trip precedes the comparisons; the cell means overwrite the dead lattice planes and the membership table
 //     is read by scalar loads: 21.7 KB of LDS per block, seven waves per SIMD instead of six (which
@@ -2003,10 +2004,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     for (int it = 0; it < NIT; ++it) {
         const float fl = (float)(line0 + 3 * it - 10);
         const v2f fl2 = {fl, fl};
-        const v2f smp = (base + (fl2 * cxy * scale2 + fix)) + half_ulp;     // round_flr_i32's add
-        int x1, y1;
-        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(x1) : "v"(smp.x));
-        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y1) : "v"(smp.y));
+        const v2f smp = (base + (fl2 * cxy * scale2 + fix)) + half_ulp;
+        const int x1 = round_flr_i32_biased(smp.x), y1 = round_flr_i32_biased(smp.y);
         const bool bad = (unsigned)x1 >= (unsigned)W || (unsigned)y1 >= (unsigned)Hh;
         oob |= on && bad;   // Error::SampleOutOfBounds in any grid drops the keypoint (descriptors.rs:28)
         idx[it] = (on && !bad) ? y1 * W + x1 : 0;
