@@ -183,6 +183,21 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
+// Element `byte_off` bytes behind a frame's base pointer.  With the base uniform (a frame index from blockIdx) and the
+// offset 32 bits wide the access compiles to `global_load/store v, v_off, s[base]` — without it every access builds its own
+// 64-bit address (a shift and two 64-bit adds: three to four VALU instructions per access, 4-5 % of the diffusion kernels).
+// A frame is far below 4 GB (kAkzMaxDim^2 * 8 bytes).
+template <typename T>
+__device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ const T* at_bytes(const T* base, uint32_t byte_off)
+{
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // 1.0f / d for both halves, correctly rounded, for d that is finite and >= 1 (pm_g2's denominator 1 + k (lx^2 + ly^2),
 // nonlinear_diffusion.rs:80): the compiler's IEEE f32 division is v_div_scale x2, v_rcp, a chain of six FMAs,
 // v_div_fmas and v_div_fixup per lane half — 22 scalar instructions for a {frame a, frame b} pair.  In that range
@@ -1338,14 +1353,15 @@ __device__ __forceinline__ void fed_steps_sums(v2f (&L)[4][4], const v2f (&C)[4]
 __device__ __forceinline__ void fed_store_patch(const v2f (&L)[4][4], float* __restrict__ dst, int fa, int fb, bool has_b,
                                                 size_t fs, int w, int h, int x0, int y0)
 {
+    float* da = dst + (size_t)fa * fs;
+    float* db = dst + (size_t)fb * fs;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int y = y0 + r;
         if (y >= h) break;
-        const size_t o = (size_t)y * w + x0;
-        *reinterpret_cast<float4*>(dst + (size_t)fa * fs + o) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
-        if (has_b)
-            *reinterpret_cast<float4*>(dst + (size_t)fb * fs + o) = make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
+        const uint32_t o = (uint32_t)(y * w + x0) << 2;
+        *reinterpret_cast<float4*>(at_bytes(da, o)) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
+        if (has_b) *reinterpret_cast<float4*>(at_bytes(db, o)) = make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
     }
 }
 
@@ -1382,9 +1398,9 @@ __device__ __forceinline__ void fed_store_half(const v2f (&L)[4][4], float* __re
             put = oh > 0;
         }
         if (put) {
-            const size_t o = (size_t)orow * ow + (x0 >> 1);
-            *reinterpret_cast<float2*>(half + (size_t)fa * hfs + o) = make_float2(v0.x, v1.x);
-            if (has_b) *reinterpret_cast<float2*>(half + (size_t)fb * hfs + o) = make_float2(v0.y, v1.y);
+            const uint32_t o = (uint32_t)(orow * ow + (x0 >> 1)) << 2;
+            *reinterpret_cast<float2*>(at_bytes(half + (size_t)fa * hfs, o)) = make_float2(v0.x, v1.x);
+            if (has_b) *reinterpret_cast<float2*>(at_bytes(half + (size_t)fb * hfs, o)) = make_float2(v0.y, v1.y);
         }
     }
 }
@@ -1411,11 +1427,11 @@ __global__ __launch_bounds__(256, 4) void k_fed_pair(const float* __restrict__ s
         const int y = y0 + r;
         float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la, ca = la, cb = la;
         if (col_in && y >= 0 && y < h) {
-            const size_t o = (size_t)y * w + x0;
-            la = *reinterpret_cast<const float4*>(src + (size_t)fa * fs + o);
-            lb = *reinterpret_cast<const float4*>(src + (size_t)fb * fs + o);
-            ca = *reinterpret_cast<const float4*>(cnd + (size_t)fa * fs + o);
-            cb = *reinterpret_cast<const float4*>(cnd + (size_t)fb * fs + o);
+            const uint32_t o = (uint32_t)(y * w + x0) << 2;
+            la = *reinterpret_cast<const float4*>(at_bytes(src + (size_t)fa * fs, o));
+            lb = *reinterpret_cast<const float4*>(at_bytes(src + (size_t)fb * fs, o));
+            ca = *reinterpret_cast<const float4*>(at_bytes(cnd + (size_t)fa * fs, o));
+            cb = *reinterpret_cast<const float4*>(at_bytes(cnd + (size_t)fb * fs, o));
         }
         L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
         C[r][0] = (v2f){ca.x, cb.x}; C[r][1] = (v2f){ca.y, cb.y}; C[r][2] = (v2f){ca.z, cb.z}; C[r][3] = (v2f){ca.w, cb.w};
@@ -1505,9 +1521,11 @@ __device__ __forceinline__ void front_fed_fetch(float4 (&ra)[ITEMS], float4 (&rb
         const int idx = tid + 256 * i;
         if (idx < NCH) {
             const int iy = idx / (kFFInC / 4), c4 = idx - iy * (kFFInC / 4);
-            const size_t o = (size_t)(wy0 - 3 + iy) * w + (wx0 - 4 + 4 * c4);
-            ra[i] = *reinterpret_cast<const float4*>(srca + o);
-            rb[i] = *reinterpret_cast<const float4*>(srcb + o);
+            // (the window lies inside the image here: a 32-bit element offset from the frame's uniform base — an SGPR base and
+            // a VGPR offset in the load, instead of a 64-bit address built per item)
+            const uint32_t o = (uint32_t)((wy0 - 3 + iy) * w + (wx0 - 4 + 4 * c4)) << 2;      // bytes (a frame is far below 4 GB)
+            ra[i] = *reinterpret_cast<const float4*>(at_bytes(srca, o));
+            rb[i] = *reinterpret_cast<const float4*>(at_bytes(srcb, o));
         }
     }
 }
@@ -1805,10 +1823,10 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
         for (int j = 0; j < 4; ++j) {
             const int y = y0 + j;
             if (y >= h) break;
-            const size_t o = (size_t)y * w + x0;
-            *reinterpret_cast<float4*>(out_flow + (size_t)fa * fs + o) = make_float4(C[j][0].x, C[j][1].x, C[j][2].x, C[j][3].x);
+            const uint32_t o = (uint32_t)(y * w + x0) << 2;
+            *reinterpret_cast<float4*>(at_bytes(out_flow + (size_t)fa * fs, o)) = make_float4(C[j][0].x, C[j][1].x, C[j][2].x, C[j][3].x);
             if (has_b)
-                *reinterpret_cast<float4*>(out_flow + (size_t)fb * fs + o) = make_float4(C[j][0].y, C[j][1].y, C[j][2].y, C[j][3].y);
+                *reinterpret_cast<float4*>(at_bytes(out_flow + (size_t)fb * fs, o)) = make_float4(C[j][0].y, C[j][1].y, C[j][2].y, C[j][3].y);
         }
     }
     // ---- 2b. multiscale Scharr first derivatives of the useful patches (derivatives.rs:23-49), taps at -SG, 0, +SG ----
@@ -1839,14 +1857,14 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
                 rx[o] = off_combine_sg<SG>(k, mp - mm, zp - zm, pp - pm);
                 ry[o] = off_combine_sg<SG>(k, pm, p0, pp) - off_combine_sg<SG>(k, mm, m0, mp);
             }
-            const size_t o = (size_t)y * w + x0;
+            const uint32_t o = (uint32_t)(y * w + x0) << 3;
             {
-                float4* xy = reinterpret_cast<float4*>(out_xy + (size_t)fa * fs + o);
+                float4* xy = reinterpret_cast<float4*>(at_bytes(out_xy + (size_t)fa * fs, o));
                 xy[0] = make_float4(rx[0].x, ry[0].x, rx[1].x, ry[1].x);
                 xy[1] = make_float4(rx[2].x, ry[2].x, rx[3].x, ry[3].x);
             }
             if (has_b) {
-                float4* xy = reinterpret_cast<float4*>(out_xy + (size_t)fb * fs + o);
+                float4* xy = reinterpret_cast<float4*>(at_bytes(out_xy + (size_t)fb * fs, o));
                 xy[0] = make_float4(rx[0].y, ry[0].y, rx[1].y, ry[1].y);
                 xy[1] = make_float4(rx[2].y, ry[2].y, rx[3].y, ry[3].y);
             }
