@@ -185,3 +185,35 @@ def test_pixel_normalisation_shortcut_is_exact():
         got = np.array([fma(fma(-d, q0[i], v[i]), r, q0[i]) for i in range(n)], np.float32)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert not np.array_equal(q0.view(np.uint32), want.view(np.uint32))      # the multiply alone is NOT enough
+
+
+def test_profiled_line_agrees_with_the_committed_rocprof_statistics():
+    """profiles/r04_bench_profiled.json is the line `bench.py --steps 30 ...` printed UNDER rocprofv3 --kernel-trace, and
+    profiles/r04_bench_kernel_stats.txt the per-kernel statistics of that very trace (tools/refresh_profiles.sh).  A family's
+    `avg_launch_us` in the line (the launches' own start / stop events over the 30 timed steps) and the trace's average
+    duration of the same kernel (all 34 launches of the process: warm-up and the instrumented pass included) are the same
+    measurement taken twice: they must agree to within a few per cent, family by family."""
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04_bench_profiled.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    stats = {}
+    with open(os.path.join(root, "profiles", "r04_bench_kernel_stats.txt")) as f:
+        for line in f.read().splitlines()[1:]:
+            m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if m:
+                stats[m.group(1).strip()] = (int(m.group(2)), float(m.group(4)))
+    trace_name = {"k_orient_describe": "k_orient_describe", "k_front_fed<3": "k_front_fed<3, 1, false, false>",
+                  "k_front_fed<4": "k_front_fed<4, 1, true, false>", "k_det_stream<3": "k_det_stream<3, false>",
+                  "k_knn_mfma4w<2>": "k_knn_mfma4w<2>"}
+    seen = 0
+    for r in d["roofline_top"]:
+        key = next((k for k in trace_name if r["kernel"].startswith(k)), None)
+        assert key is not None, r["kernel"]
+        calls, avg_us = stats[trace_name[key]]
+        assert calls >= r["launches"]
+        assert abs(r["avg_launch_us"] - avg_us) <= 0.08 * avg_us, (r["kernel"], r["avg_launch_us"], avg_us)
+        seen += 1
+    assert seen == 5
