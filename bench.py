@@ -9,13 +9,16 @@ frame g -> rank g mod N; the only exchange is a ring shift of t
 blocks (RCCL send/recv to rank + 1) so that the owner of frame g holds frame g-1's descriptors.  Weak scaling: every rank
 processes its own 256 frames per step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline        — the kernel family that took the most GPU time IN THIS RUN (HIP events recorded by the library
-                    around its launches, on the stream they run on): achieved = the kernel's own algorithmic bytes
-                    (what it must read and write once, given what it fuses: DESIGN.md §5) / its event time, against
-                    the 8 TB/s HBM3E peak, so frac <= 1 by construction; `traffic` = PMC HBM bytes per launch from
-                    the committed rocprofv3 counter passes when they were taken at this micro-batch, else null.
-  roofline_top    — the same triple for the four most expensive kernel families of the run.
+Rank 0 writes the full report (every object named below, ~20 KB) to gpurun_out/bench_detail.json and prints, as the LAST
+and only JSON line of stdout, a compact headline (< 4 KB: `headline()` below) that carries the contract fields plus one
+`roofline` object, one `cpu_baseline` object, the parity counts and one scalar per extra leg.  The report's objects:
+  roofline        — the kernel family with the largest time per step when the GPU is its alone (isolated pass), timed
+                    in the run by the launches' own start/stop events: achieved = the kernel's algorithmic bytes
+                    (what it must read and write once, given what it fuses: DESIGN.md §5; for the gather kernel the
+                    distinct 32-byte sectors its keypoints touch) / its event time, against the 8 TB/s HBM3E peak, so
+                    frac <= 1 by construction; `traffic` = PMC HBM bytes per launch from the committed rocprofv3
+                    counter passes when they were taken at this micro-batch, else null.
+  roofline_top    — the same for the five most expensive kernel families, the matcher (MFMA ops / 10 PF) among them.
   algorithmic_gbs — SURVEY §8d's contract figure (1.0535 GB per 1080p frame) x the isolated scale-space rate: it
                     counts every named pyramid buffer once per consuming stage and therefore exceeds what the fused
                     kernels move; kept for continuity, never used as a roofline fraction.
@@ -23,9 +26,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                     oracle just computed for them (the run FAILS, rc 1, on any mismatch).
   configs_extra   — BASELINE configs[2] (1 000 x 5 000 Bernoulli descriptors, 999 consecutive pairs) and configs[3]
                     (10 000 eight-point hypotheses on a 1 000-match scene), each oracle-checked on a sample, each with
-                    its own roofline triple.
+                    its own roofline triple; the pipeline+verify and pipeline+register legs; the criterion rows.
   cpu_baseline    — the CPU oracle (a restatement of the reference, kind "port") timed on this box's host
                     cores on a bounded sample of the same workload (rank 0, N=1 only).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(torch.distributed.run on 127.0.0.1); under torch.distributed.run it is one of them.
 """
 import argparse
 import ctypes as C
@@ -75,8 +80,8 @@ KERNEL_FAMILIES = [
     ("k_fed_pair<8> (calculate_step, 8 steps per launch)", 21, 12.0),
     ("k_contrast_pair (contrast factor passes)", 10, 1.0),
 ]
-# the keypoint-stage kernel with the most GPU time: gathers, no per-pixel byte model — its roofline entry takes the PMC
-# bytes themselves as the numerator (what it really moved per launch)
+# the keypoint-stage kernel with the most GPU time: gathers, no per-pixel byte model — its roofline numerator is the
+# distinct 32-byte sectors the frame's keypoints touch, each once (gather_model); the PMC bytes go beside it as `traffic`
 ORIENT_DESCRIBE = ("k_orient_describe (main orientation + M-LDB descriptor, one wave per keypoint)", 25)
 MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
 MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4/FP6 MFMA (MI355X_MICROARCH.md; AMD's 20 PF headline is 2:1 sparse)
@@ -175,10 +180,14 @@ def main():
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange code path even with one rank (a rank "
                     "then sends to itself): the single-GPU test of the N > 1 path's collectives")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (smoke test of N>1 on one GPU)")
+    ap.add_argument("--detail-stdout", action="store_true", help="also print the full report (one {\"bench_detail\": ...} line) before "
+                    "the headline; by default it only goes to gpurun_out/bench_detail.json")
     ap.add_argument("--dump-matches", default=None, help="write per-global-frame keypoint/match counts to this .npy")
     args = ap.parse_args()
     if args.pmc_run:
         args.no_cpu_baseline = args.no_extras = args.no_isolated = True
+    if args.share_device and args.gpus > 1 and args.backend == "nccl":
+        args.backend = "gloo"         # RCCL refuses two ranks on one device; the smoke test of N > 1 on one GPU runs over gloo
 
     import torch
     import torch.distributed as dist
@@ -186,8 +195,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])          # (does not return: exec of torch.distributed.run with the same arguments)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU fallback)"
     if args.share_device:
         local_rank = 0
@@ -550,9 +561,11 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch of 256 synthetic 1920x1080 frames per GPU, "
-                                   "Akaze::default() detect+describe, + symmetric better-by-24 BF Hamming match "
-                                   "of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
+            "config": {"workload": "BASELINE configs[1]: batch of 256 synthetic 1920x1080 frames per GPU (ONE panning "
+                                   "camera over a single seeded world canvas, 4 px right / 2 px down per frame, +-2 sensor "
+                                   "noise per frame — not SURVEY 8d's per-frame seeds: consecutive frames must overlap for "
+                                   "the match to mean something), Akaze::default() detect+describe, + symmetric "
+                                   "better-by-24 BF Hamming match of consecutive frames", "frames_per_gpu_per_step": NF, "micro_batch": MB,
                        "parallelism": f"frame-sharded x{world}", "mean_keypoints_per_frame": round(n_kp, 1),
                        "mean_matches_per_pair": round(n_match, 1),
                        "library_options": okw or "defaults"},
@@ -646,12 +659,133 @@ def main():
                 if v.get("parity", {}).get("mismatches"):
                     rc = 1
         flush_c_stdio()                     # (RCCL writes a version banner through C stdio: it must not follow the line)
-        print(json.dumps(out), flush=True)
+        detail = write_detail(out)
+        if args.detail_stdout:
+            print(json.dumps({"bench_detail": out}), flush=True)
+        print(headline(out, detail), flush=True)        # the LAST line of stdout, < 4 KB
         if rc:
             print("bench.py: GPU output differs from the oracle (see parity_checked / configs_extra)", file=sys.stderr)
             sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
+
+
+HEADLINE_LIMIT = 4096      # bytes: the driver keeps a bounded tail of stdout; a 22 KB line (round 4) was not parseable from it
+
+
+def _short_roofline(e):
+    """One flat roofline object for the headline: the contract's keys + the kernel's own launch statistics."""
+    if not e:
+        return None
+    r = {k: e.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us")}
+    r["kernel"] = str(e.get("kernel", "")).split(" ")[0]
+    for k in ("valu_frac", "gpu_ms_per_step"):
+        if e.get(k) is not None:
+            r[k] = e[k]
+    iso = e.get("isolated") or {}
+    if iso.get("frac") is not None:
+        r["isolated_frac"] = iso["frac"]
+        r["isolated_avg_launch_us"] = iso.get("avg_launch_us")
+    return r
+
+
+def headline(out, detail_path=None):
+    """The compact last line (< HEADLINE_LIMIT bytes): the contract fields of the task statement, ONE roofline object,
+    ONE cpu_baseline object, parity counts and one scalar per extra leg.  Everything else stays in the detail file."""
+    cfg = out.get("config", {})
+    h = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    h["config"] = {k: cfg[k] for k in ("workload", "frames_per_gpu_per_step", "micro_batch", "parallelism", "mean_keypoints_per_frame",
+                                       "mean_matches_per_pair", "recent_views") if k in cfg}
+    h["roofline"] = _short_roofline(out.get("roofline"))
+    tops = out.get("roofline_top") or []
+    if tops:      # [kernel, frac in the pipeline, frac alone, ms per step alone]
+        h["roofline_top"] = [[str(e.get("kernel", "")).split(" ")[0], e.get("frac"), (e.get("isolated") or {}).get("frac"),
+                              e.get("rank_ms_per_step")] for e in tops[:5]]
+    for k in ("end_to_end_hbm_frac", "end_to_end_valu_frac"):
+        if k in out:
+            h[k] = out[k]
+    iso = out.get("scale_space_isolated")
+    if iso:
+        h["scale_space_isolated_frames_per_s"] = iso.get("frames_per_s")
+    cb = out.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        h["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        ac = out.get("cpu_baseline_all_cores")
+        if ac:
+            h["cpu_baseline"]["all_cores"] = {"value": ac.get("value"), "cores": ac.get("cores")}
+    pc, ps = out.get("parity_checked"), out.get("parity_checked_spread")
+    if pc:
+        h["parity"] = {"frames": pc.get("frames", 0) + (ps or {}).get("frames", 0), "pairs": pc.get("pairs", 0) + (ps or {}).get("pairs", 0),
+                       "mismatches": pc.get("mismatches", 0) + (ps or {}).get("mismatches", 0), "vs": "oracle/ (bit patterns)"}
+    ex = out.get("configs_extra") or {}
+    legs = {}
+    pick = (("configs[2]", "pairs_per_s"), ("configs[3]", "hypotheses_per_s"), ("pipeline+verify", "verified_pairs_per_s"),
+            ("pipeline+register", "registered_frames_per_s"))
+    for leg, key in pick:
+        if leg in ex:
+            e = {key: ex[leg].get(key), "mismatches": (ex[leg].get("parity") or {}).get("mismatches")}
+            rf = (ex[leg].get("roofline") or {}).get("frac")
+            if rf is not None:
+                e["roofline_frac"] = rf
+            if "ms_per_step" in ex[leg]:
+                e["ms_per_step"] = ex[leg]["ms_per_step"]
+            legs[leg] = e
+    if "criterion" in ex:
+        legs["criterion"] = {"extract_gpu_ms": ex["criterion"].get("rows", {}).get("extract", {}).get("gpu_ms"),
+                             "mismatches": ex["criterion"].get("mismatches")}
+    if legs:
+        h["extras"] = legs
+    mg = out.get("multi_gpu")
+    if mg:
+        h["multi_gpu"] = {k: mg[k] for k in ("exchange", "comm", "rccl_ranks_seen", "exchange_ms_per_step", "recent_views") if k in mg}
+        prf = mg.get("per_rank_frames_per_s")
+        if prf:
+            h["multi_gpu"]["per_rank_frames_per_s_min_max"] = [min(prf), max(prf)]
+    if detail_path:
+        h["detail"] = detail_path
+    line = json.dumps(h, separators=(",", ":"))
+    for drop in ("roofline_top", "multi_gpu", "extras"):      # never exceed the limit: shed the optional objects first
+        if len(line) < HEADLINE_LIMIT:
+            break
+        h.pop(drop, None)
+        line = json.dumps(h, separators=(",", ":"))
+    if len(line) >= HEADLINE_LIMIT:
+        h["config"]["workload"] = h["config"].get("workload", "")[:200]
+        line = json.dumps(h, separators=(",", ":"))
+    assert len(line) < HEADLINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(out):
+    """The full report as a side file (gpurun_out/ merges back from the GPU box); returns the path relative to the repo."""
+    rel = os.path.join("gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(out, f)
+            f.write("\n")
+        return rel
+    except OSError as e:
+        print(f"bench.py: detail file not written ({e})", file=sys.stderr)
+        return None
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher of N ranks of this same command
+    on this node (127.0.0.1 rendezvous, a free port), one rank per GPU — or all on cuda:0 with --share-device."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def flush_c_stdio():

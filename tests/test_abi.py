@@ -167,6 +167,66 @@ def test_committed_bench_line_follows_the_contract():
     assert d["value"] > 2000.0          # BASELINE.json's target for one MI355X
 
 
+def test_headline_is_compact_and_parseable():
+    """The driver keeps a bounded tail of stdout (the 22 KB line of round 4 left BENCH_r04.parsed null): bench.py's LAST
+    stdout line is the headline built by bench.headline() — under 4 KB, with the contract keys, one flat roofline object,
+    one cpu_baseline object, the parity counts and one scalar per extra leg; the full report goes to a side file."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "profiles", "r04_bench.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])
+    line = bench.headline(full, "gpurun_out/bench_detail.json")
+    assert len(line) < 4096 and "\n" not in line
+    h = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "extras"):
+        assert k in h, k
+    assert h["value"] == full["value"] and h["ms_per_step"] == full["ms_per_step"]
+    r = h["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches"):
+        assert k in r, k
+    assert all(not isinstance(v, (dict, list)) for v in r.values())          # one flat object, no nested models
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1
+    assert h["cpu_baseline"]["value"] > 0 and h["cpu_baseline"]["kind"] in ("port", "reference") and h["cpu_baseline"]["cores"] >= 1
+    assert h["parity"]["mismatches"] == 0 and h["parity"]["frames"] >= 2
+    assert set(h["extras"]) >= {"configs[2]", "configs[3]", "pipeline+verify", "pipeline+register"}
+    # a report stuffed far beyond anything real still yields a line under the limit (optional objects are shed first)
+    fat = dict(full)
+    fat["config"] = dict(full["config"], workload="x" * 6000)
+    assert len(bench.headline(fat, None)) < 4096
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the driver's N = 1 command shape with another
+    N) must become the launcher of its own ranks: exec of torch.distributed.run on 127.0.0.1 with the same arguments."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_execve(exe, argv, env):
+        seen["exe"], seen["argv"], seen["env"] = exe, list(argv), dict(env)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execve", fake_execve)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in a and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert a[-6:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"] and a[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
 def test_pixel_normalisation_shortcut_is_exact():
     """cv_amd/csrc/akz_scale_space.hip: px_over_255 / px_over_65535 replace the reference's per-pixel IEEE division
     (image.rs:54, :57-66) by q0 = v * r, q = fma(fma(-d, q0, v), r, q0).  Exhaustive check over every u8 and u16 value

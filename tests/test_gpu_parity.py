@@ -2104,6 +2104,25 @@ def test_window_of_recent_views_two_ranks_equals_single_rank(gpu, tmp_path):
     assert not np.array_equal(single["g10"][0], single["g10"][3])
 
 
+def test_bench_gpus_2_launches_its_own_ranks(gpu):
+    """The driver's command shape with another N — `python3 bench.py --gpus 2 --steps K --warmup W`, no launcher around it —
+    must start its own two ranks (here both on cuda:0) and rank 0 must print the one parseable headline as the LAST line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--steps", "1", "--warmup", "1",
+                        "--frames", "16", "--micro-batch", "8", "--no-extras", "--no-cpu-baseline", "--no-isolated"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+    assert len(line) < 4096
+    h = json.loads(line)
+    assert h["n_gpus"] == 2 and h["value"] > 0 and h["steps"] == 1 and h["config"]["frames_per_gpu_per_step"] == 16
+    assert h["multi_gpu"]["exchange"] == "ring shift" and "roofline" in h
+
+
 @pytest.mark.parametrize("dtype,channels", [(np.uint8, 3), (np.uint8, 4), (np.uint16, 3), (np.float32, 3), (np.float32, 4)])
 def test_colour_input_arms(gpu, oracle, dtype, channels):
     """The colour arms of GrayFloatImage::from_dynamic (akaze/src/image.rs:45-46, 87-106) on the C ABI (akz_extract_color):
