@@ -119,6 +119,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "
 NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
 assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 
+ABI_VERSION = 5          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
+
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "akz_config_default", "akz_create", "akz_create_ex", "akz_destroy", "akz_extract_gray_u8", "akz_extract_gray_u16",
@@ -131,8 +133,8 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "hm_set_targets", "hm_knn_targets", "rs_debug_scene_world", "rs_debug_far",
-    "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "hm_landmark_matches_batch_device", "hm_set_targets", "hm_targets_generation", "hm_knn_targets", "rs_debug_scene_world", "rs_debug_far",
+    "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version", "akz_abi_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
     "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
     "akz_comm_stream", "akz_comm_rank", "akz_comm_world", "akz_comm_timing", "akz_comm_last_error_string",
@@ -163,6 +165,12 @@ def lib():
     L.akz_strerror.argtypes = [i32]
     L.akz_last_hip_error_string.restype = C.c_char_p
     L.akz_version.restype = C.c_char_p
+    L.akz_abi_version.restype = C.c_uint32
+    L.hm_targets_generation.restype = C.c_uint64
+    L.hm_targets_generation.argtypes = [C.c_void_p]
+    if L.akz_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} exports ABI {L.akz_abi_version()}, this binding was written against {ABI_VERSION} "
+                           "(include/akz.h AKZ_ABI_VERSION): rebuild with `python -m cv_amd.build`")
     L.akz_config_default.argtypes = [C.POINTER(Config)]
     L.akz_create.argtypes = [C.POINTER(Config), i32, i32, i32, i32, u32, C.POINTER(vp)]
     L.akz_create_ex.argtypes = [C.POINTER(Config), i32, i32, i32, i32, u32, C.POINTER(Options), C.POINTER(vp)]
@@ -203,6 +211,7 @@ def lib():
     L.hm_set_targets.argtypes = [vp, vp, u32]
     L.hm_knn_targets.argtypes = [vp, vp, u32, u32, vp]
     L.hm_landmark_pairs_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
+    L.hm_landmark_matches_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]
     L.hm_sync.argtypes = [vp]

@@ -36,6 +36,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object_is_current(obj, cmd):
+    """An object is reused when it is newer than every file its compiler listed as a dependency (the -MD file beside it) and
+    was produced by the same command line."""
+    dep, tag = obj + ".d", obj + ".cmd"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(tag)):
+        return False
+    with open(tag) as f:
+        if f.read() != " ".join(cmd):
+            return False
+    t = os.path.getmtime(obj)
+    with open(dep) as f:
+        text = f.read().replace("\\\n", " ")
+    files = [w for part in text.split(":", 1)[1:] for w in part.split() if not w.endswith(":")]
+    return bool(files) and all(os.path.exists(w) and os.path.getmtime(w) <= t for w in files)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -48,20 +64,28 @@ def build(force=False, verbose=False):
             o = os.path.join(HERE, "lib", s.replace(".", "_") + tag + ".o")
             extra = os.environ.get("AKZ_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DKNN_ABLATE=1)
             extra += [] if k is None else [f"-DAKZ_ARITH={k}"]
-            cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
-            jobs.append((s + tag, cmd))
+            cmd = [hipcc()] + FLAGS + extra + (["-x", "hip"] if s.endswith(".hip") else []) + ["-MD", "-MF", o + ".d", "-c", os.path.join(CSRC, s), "-o", o]
             objs.append(o)
+            if not force and _object_is_current(o, cmd):
+                continue
+            if os.path.exists(o + ".cmd"):
+                os.remove(o + ".cmd")
+            jobs.append((s + tag, cmd, o))
     # (at most as many compilers at once as the host has cores: the eight copies of the largest file would otherwise all
     # start together on a small box)
     failed = False
     limit = max(2, os.cpu_count() or 2)
     for j0 in range(0, len(jobs), limit):
         procs = []
-        for name, cmd in jobs[j0:j0 + limit]:
+        for name, cmd, _ in jobs[j0:j0 + limit]:
             if verbose:
                 print(" ".join(cmd))
             procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         failed = _wait(procs, verbose) or failed
+    if not failed:
+        for _, cmd, o in jobs:
+            with open(o + ".cmd", "w") as f:
+                f.write(" ".join(cmd))
     if failed:
         raise RuntimeError("libakz build failed")
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]

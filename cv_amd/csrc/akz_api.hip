@@ -10,7 +10,8 @@
 
 thread_local int g_akz_last_hip = 0;
 
-extern "C" const char* akz_version(void) { return "cv_amd-akz 0.1 (gfx950)"; }
+extern "C" const char* akz_version(void) { return "cv_amd-akz 0.5 (gfx950)"; }
+extern "C" uint32_t akz_abi_version(void) { return AKZ_ABI_VERSION; }
 
 extern "C" const char* akz_strerror(int32_t s)
 {
@@ -150,6 +151,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
 {
     return akz_guard([&]() -> int32_t {
         if (!cfg || !out || max_w < 3 || max_h < 3 || max_batch < 1 || max_w > 65535 || max_h > 65535) return AKZ_E_INVALID;
+        if ((size_t)max_w * (size_t)max_h > kAkzMaxPixels) return AKZ_E_TOO_LARGE;     // 32-bit byte offsets inside a frame (akz_common.h)
         AKZ_TRY(validate_config(cfg));
         akz_options o;
         memset(&o, 0, sizeof(o));

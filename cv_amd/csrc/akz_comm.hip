@@ -102,6 +102,19 @@ thread_local int g_last_rccl = 0;
         }                                          \
     } while (0)
 
+// ncclGroupStart / ncclGroupEnd themselves (same scope): no group is open after either fails, but the timing events taken by
+// comm_begin still go back to the pool.
+#define AKZ_RCCL_GROUP_EDGE(call)                  \
+    do {                                           \
+        int r_ = (call);                           \
+        if (r_ != 0) {                             \
+            g_last_rccl = r_;                      \
+            if (e0) c->pool.push_back(e0);         \
+            if (e1) c->pool.push_back(e1);         \
+            return AKZ_E_COMM;                     \
+        }                                          \
+    } while (0)
+
 // most event pairs kept un-resolved when timing is on and akz_comm_timing() is never called: beyond it the oldest are
 // resolved (their transfers are long finished) before another pair is added
 constexpr size_t kCommMaxPending = 256;
@@ -261,12 +274,12 @@ extern "C" int32_t akz_comm_shift_blocks(akz_comm* c, const void* d_descs, const
         AKZ_TRY(comm_begin(c, stream_to_wait, &e0, &e1));
         const size_t db = (size_t)n_frames * cap_per_img * 64, cb = (size_t)n_frames;
         const int nxt = (c->rank + 1) % c->world, prv = (c->rank + c->world - 1) % c->world;
-        AKZ_RCCL(R->GroupStart());
+        AKZ_RCCL_GROUP_EDGE(R->GroupStart());
         AKZ_RCCL_IN_GROUP(R, R->Send(d_descs, db, kRcclUint8, nxt, c->comm, c->stream));
         AKZ_RCCL_IN_GROUP(R, R->Send(d_counts, cb, kRcclUint32, nxt, c->comm, c->stream));
         AKZ_RCCL_IN_GROUP(R, R->Recv(d_recv_descs, db, kRcclUint8, prv, c->comm, c->stream));
         AKZ_RCCL_IN_GROUP(R, R->Recv(d_recv_counts, cb, kRcclUint32, prv, c->comm, c->stream));
-        AKZ_RCCL(R->GroupEnd());
+        AKZ_RCCL_GROUP_EDGE(R->GroupEnd());
         return comm_end(c, e0, e1, db + 4 * cb);
     });
 }
@@ -285,10 +298,10 @@ extern "C" int32_t akz_comm_allgather_blocks(akz_comm* c, const void* d_descs, c
         hipEvent_t e0, e1;
         AKZ_TRY(comm_begin(c, stream_to_wait, &e0, &e1));
         const size_t db = (size_t)n_frames * cap_per_img * 64, cb = (size_t)n_frames;
-        AKZ_RCCL(R->GroupStart());
+        AKZ_RCCL_GROUP_EDGE(R->GroupStart());
         AKZ_RCCL_IN_GROUP(R, R->AllGather(d_descs, d_all_descs, db, kRcclUint8, c->comm, c->stream));
         AKZ_RCCL_IN_GROUP(R, R->AllGather(d_counts, d_all_counts, cb, kRcclUint32, c->comm, c->stream));
-        AKZ_RCCL(R->GroupEnd());
+        AKZ_RCCL_GROUP_EDGE(R->GroupEnd());
         return comm_end(c, e0, e1, (db + 4 * cb) * (size_t)c->world);
     });
 }

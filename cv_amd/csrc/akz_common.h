@@ -31,6 +31,11 @@ extern thread_local int g_akz_last_hip;
 // Slots per frame in every per-(frame, level) table (candidate counts and lists, the keypoint kernels' level
 // table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
 constexpr int kAkzMaxLevels = 32;
+// Largest frame a context accepts, in pixels: the diffusion / determinant kernels address a frame's planes with 32-bit BYTE
+// offsets (at_bytes in akz_scale_space.hip), the widest being the 8-byte {Lx, Ly} plane: pixels * 8 must stay below 2^32.
+// 2^28 pixels (16384 x 16384) leaves a factor of two; akz_create_ex refuses more with AKZ_E_TOO_LARGE.
+constexpr size_t kAkzMaxPixels = (size_t)1 << 28;
+static_assert(kAkzMaxPixels * 8 <= ((size_t)1 << 32) / 2, "32-bit byte offsets into the {Lx, Ly} plane");
 // Largest per-frame keypoint list / per-(frame, level) candidate list a context can be created for.
 constexpr uint32_t kAkzMaxKeypoints = 262144u;   // (Akaze::dense() on 1080p noise: 82 000 keypoints in one frame)
 // Keys a per-frame / per-level sort keeps in LDS (128 KB of the CU's 160 KB); longer lists sort through global memory.

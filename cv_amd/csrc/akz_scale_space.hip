@@ -186,7 +186,7 @@ __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 // Element `byte_off` bytes behind a frame's base pointer.  With the base uniform (a frame index from blockIdx) and the
 // offset 32 bits wide the access compiles to `global_load/store v, v_off, s[base]` — without it every access builds its own
 // 64-bit address (a shift and two 64-bit adds: three to four VALU instructions per access, 4-5 % of the diffusion kernels).
-// A frame is far below 4 GB (kAkzMaxDim^2 * 8 bytes).
+// A context never holds a frame above kAkzMaxPixels (akz_common.h; akz_create_ex refuses it): pixels * 8 bytes < 2^31.
 template <typename T>
 __device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off)
 {

@@ -906,6 +906,7 @@ struct hm_ctx {
     uint32_t* d_na = nullptr;  // [2]: na, nb
     uint32_t resident_nt = 0;  // hm_set_targets: d_b holds this many target descriptors (0: nothing resident)
     bool resident = false;
+    uint64_t generation = 0;   // of the resident set: hm_set_targets hands out a new one per upload (hm_targets_generation)
     akz_neighbor* d_fwd = nullptr;
     akz_neighbor* d_rev = nullptr;
     uint32_t* d_pairs = nullptr;
@@ -1248,8 +1249,17 @@ extern "C" int32_t hm_set_targets(hm_ctx* c, const akz_descriptor* t, uint32_t n
         AKZ_HIP(hipStreamSynchronize(c->stream));   // the caller's array may go away
         c->resident_nt = nt;
         c->resident = true;
+        c->generation += 1;
         return AKZ_OK;
     });
+}
+// Which upload the context holds: the number of the hm_set_targets call whose targets are resident, 0 when none is (never
+// uploaded, or another host-buffer call took the staging buffer since).  A binding remembers the value its own upload got
+// and asks again before every hm_knn_targets: two target sets alternating on one context, a set dropped and another
+// allocated at the same address — every case a pointer comparison misses — shows up as a different number.
+extern "C" uint64_t hm_targets_generation(hm_ctx* c)
+{
+    return (c && c->resident) ? c->generation : 0;
 }
 extern "C" int32_t hm_knn_targets(hm_ctx* c, const akz_descriptor* q, uint32_t nq, uint32_t k, akz_neighbor* out)
 {
@@ -1449,86 +1459,104 @@ extern "C" int32_t hm_best_of_views_batch_device(hm_ctx* c, const void* d_knn, c
     });
 }
 
-// ---- from the landmark decisions to the consensus' input (cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604) ----
-// register_frame_subset, between the best-of-views decision and single_view_consensus.model_inliers: a feature whose best
-// landmark is uniquely good (decision 1) becomes the match (landmark, feature) (:1516-1520); matches whose landmark was
-// claimed by two features of the frame are dropped, both of them (:1549-1563: "always 100 % incorrect"); what is left
-// becomes FeatureWorldMatch(bearing(feature), triangulated landmark) unless the landmark has no robust triangulation
-// (:1583-1604, filter_map).  Here: one workgroup per frame; the frame's decision-1 features are sorted by landmark key
-// (stable LSD radix sort of feature ids in LDS), a landmark that occupies more than one sorted position invalidates its
-// features, and the survivors go out in ascending feature order as {feature, landmark} — exactly the pair-list form
-// rs_p3p_arrsac_batch_device takes (the landmark key indexes the caller's table of world points; an entry with w < 0,
-// impossible for a Projective point, says "no robust triangulation").  The merge candidates (decision 2) need the
-// landmark graph (are_landmarks_sharing_view) and the reference's stable sort by observation count only fixes the order
-// the consensus sees, which the seeded shuffle replaces: both stay with the caller.
+// ---- from the landmark decisions to the consensus' input (cv-sfm/src/lib.rs:1516-1532, 1549-1563, 1583-1604) ----
+// register_frame_subset, between the best-of-views decision and single_view_consensus.model_inliers.  original_matches holds
+// ([best0], feature) for a uniquely good best landmark (decision 1, :1516-1520) and ([best0, best1], feature) for a merge
+// candidate (decision 2) whose two landmarks share no view (:1521-1531 — are_landmarks_sharing_view is the caller's graph
+// test: its verdict arrives as the per-feature mask merge_ok).  landmark_counts then counts EVERY landmark of EVERY
+// original match, both landmarks of a merge included (:1549-1552), and a match survives only if all of its landmarks were
+// counted once (:1555-1559: "two separate features match to the landmark, that is always 100 % incorrect").  What is left
+// becomes FeatureWorldMatch(bearing(feature), triangulate_landmark_robust(landmark)) or, for a merge,
+// triangulate_merged_landmark_robust([a, b]) — dropped when the triangulation is None (:1583-1604, filter_map).
+// Here: one workgroup per frame.  The landmarks of all original matches go into an open-addressing hash set in LDS (32 768
+// slots for at most 2 x 8 192 keys; a key met a second time sets its slot's bit in a duplicate bitmap — set semantics, so
+// the outcome does not depend on the order the lanes arrive in); the survivors leave in ascending feature order as
+// {feature, row of the world table} — exactly the pair-list form rs_p3p_arrsac_batch_device takes.  The world table is the
+// caller's: rows [0, n_world) by landmark key and, when a merge mask is given, rows n_world + f * cap + j = the merged
+// triangulation for feature j of frame f; a row with w < 0 (impossible for a Projective point) says "None".  The
+// reference's stable sort by observation count (:1561-1574) only fixes the order the consensus sees, which the seeded
+// shuffle replaces: it stays with the caller.
+constexpr uint32_t kLmSlots = 32768u;
+constexpr size_t kLmLdsBytes = sizeof(uint32_t) * (kLmSlots + kLmSlots / 32);
+__device__ __forceinline__ uint32_t lm_slot(uint32_t key) { return (key * 2654435761u) >> 17; }
+__device__ __forceinline__ void lm_insert(uint32_t* tab, uint32_t* dup, uint32_t key)
+{
+    uint32_t s = lm_slot(key);
+    for (;;) {
+        const uint32_t prev = atomicCAS(&tab[s], 0xFFFFFFFFu, key);
+        if (prev == 0xFFFFFFFFu) return;
+        if (prev == key) { atomicOr(&dup[s >> 5], 1u << (s & 31u)); return; }
+        s = (s + 1u) & (kLmSlots - 1u);
+    }
+}
+__device__ __forceinline__ bool lm_claimed_once(const uint32_t* tab, const uint32_t* dup, uint32_t key)
+{
+    uint32_t s = lm_slot(key);
+    while (tab[s] != key) s = (s + 1u) & (kLmSlots - 1u);
+    return ((dup[s >> 5] >> (s & 31u)) & 1u) == 0u;
+}
 __global__ __launch_bounds__(1024) void k_landmark_pairs(const uint2* __restrict__ best, const uint32_t* __restrict__ decision,
+                                                         const uint8_t* __restrict__ merge_ok,
                                                          const uint32_t* __restrict__ nq, const uint32_t* __restrict__ iq,
                                                          uint32_t cap, const double* __restrict__ world, uint32_t n_world,
                                                          uint2* __restrict__ pairs, uint32_t* __restrict__ npairs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* rk = reinterpret_cast<uint32_t*>(smem);          // [cap] landmark of feature j (0xFFFFFFFF: not a candidate)
-    uint32_t* ia = rk + kRadixSortMax;
-    uint32_t* ib = ia + kRadixSortMax;
-    uint32_t* wh = ib + kRadixSortMax;
-    __shared__ uint32_t tot[256];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);         // [kLmSlots] landmark keys (0xFFFFFFFF: empty)
+    uint32_t* dup = tab + kLmSlots;                            // [kLmSlots / 32] bit s: slot s' key was inserted more than once
     __shared__ uint32_t s_wave[16], s_base;
     const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint32_t n = nq[iq[f]];
     n = n < cap ? n : cap;
     const uint2* bf = best + (size_t)f * cap * 3;
     const uint32_t* df = decision + (size_t)f * cap;
-    // 1. the candidates, in feature order
+    const uint8_t* mf = merge_ok ? merge_ok + (size_t)f * cap : nullptr;
+    for (uint32_t s = tid; s < kLmSlots; s += 1024) tab[s] = 0xFFFFFFFFu;
+    for (uint32_t s = tid; s < kLmSlots / 32; s += 1024) dup[s] = 0u;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (uint32_t j0 = 0; j0 < n; j0 += 1024) {
-        const uint32_t j = j0 + tid;
-        const bool on = j < n && df[j] == 1u;
-        if (j < n) rk[j] = on ? bf[(size_t)j * 3].x : 0xFFFFFFFFu;
-        const unsigned long long bal = __ballot(on);
-        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t off = s_base;
-        for (uint32_t q = 0; q < wv; ++q) off += s_wave[q];
-        if (on) ia[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int q = 0; q < 16; ++q) t += s_wave[q];
-            s_base += t;
-        }
-        __syncthreads();
-    }
-    const uint32_t nsel = s_base;
-    __syncthreads();
-    // 2. feature ids sorted by landmark key; 3. a key that fills more than one position invalidates its features
-    const uint32_t* sorted = lds_radix_sort_ids(rk, ia, ib, wh, tot, nsel, 4);
-    uint32_t* flag = sorted == ia ? ib : ia;
-    for (uint32_t p = tid; p < nsel; p += 1024) {
-        const uint32_t kk = rk[sorted[p]];
-        flag[p] = ((p > 0 && rk[sorted[p - 1]] == kk) || (p + 1 < nsel && rk[sorted[p + 1]] == kk)) ? 1u : 0u;
+    // kind of feature j's original match: 0 none, 1 ([best0], j), 2 ([best0, best1], j)
+    auto kind_of = [&](uint32_t j, uint32_t& l0, uint32_t& l1) -> uint32_t {
+        const uint32_t d = df[j];
+        l0 = bf[(size_t)j * 3].x;
+        l1 = bf[(size_t)j * 3 + 1].x;
+        if (l0 == 0xFFFFFFFFu) return 0u;
+        if (d == 1u) return 1u;
+        if (d == 2u && mf && mf[j] && l1 != 0xFFFFFFFFu) return 2u;
+        return 0u;
+    };
+    // 1. landmark_counts: every landmark of every original match
+    for (uint32_t j = tid; j < n; j += 1024) {
+        uint32_t l0, l1;
+        const uint32_t kind = kind_of(j, l0, l1);
+        if (kind >= 1u) lm_insert(tab, dup, l0);
+        if (kind == 2u) lm_insert(tab, dup, l1);
     }
     __syncthreads();
-    // (a second pass, so that no rk[] is overwritten while a neighbour still compares it)
-    for (uint32_t p = tid; p < nsel; p += 1024)
-        if (flag[p]) rk[sorted[p]] = 0xFFFFFFFFu;
-    __syncthreads();
-    // 4. the survivors in feature order, with a robust world point
-    if (tid == 0) s_base = 0;
-    __syncthreads();
+    // 2. the survivors in feature order, with a robust world point
     uint2* out = pairs + (size_t)f * cap;
     for (uint32_t j0 = 0; j0 < n; j0 += 1024) {
         const uint32_t j = j0 + tid;
-        uint32_t lm = 0xFFFFFFFFu;
-        if (j < n) lm = rk[j];
-        bool on = lm != 0xFFFFFFFFu && lm < n_world;
-        if (on) on = world[(size_t)4 * lm + 3] >= 0.0;
+        bool on = false;
+        uint32_t row = 0;
+        if (j < n) {
+            uint32_t l0, l1;
+            const uint32_t kind = kind_of(j, l0, l1);
+            if (kind == 1u) {
+                on = lm_claimed_once(tab, dup, l0) && l0 < n_world;
+                row = l0;
+            } else if (kind == 2u) {
+                on = lm_claimed_once(tab, dup, l0) && lm_claimed_once(tab, dup, l1);
+                row = n_world + f * cap + j;
+            }
+            if (on) on = world[(size_t)4 * row + 3] >= 0.0;
+        }
         const unsigned long long bal = __ballot(on);
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t off = s_base;
         for (uint32_t q = 0; q < wv; ++q) off += s_wave[q];
-        if (on) out[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(j, lm);
+        if (on) out[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(j, row);
         __syncthreads();
         if (tid == 0) {
             uint32_t t = 0;
@@ -1540,14 +1568,16 @@ __global__ __launch_bounds__(1024) void k_landmark_pairs(const uint2* __restrict
     if (tid == 0) npairs[f] = s_base;
 }
 
-extern "C" int32_t hm_landmark_pairs_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
-                                                  uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
-                                                  void* d_pairs, void* d_npairs, void* stream_to_wait)
+extern "C" int32_t hm_landmark_matches_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_merge_ok,
+                                                    const void* d_nq, const uint32_t* iq, uint32_t cap_per_img, uint32_t n_frames,
+                                                    const void* d_world, uint32_t n_world, void* d_pairs, void* d_npairs,
+                                                    void* stream_to_wait)
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !d_best || !d_decision || !d_nq || !iq || !d_world || !d_pairs || !d_npairs) return AKZ_E_INVALID;
         if (cap_per_img == 0 || n_world == 0 || n_frames > 65535u) return AKZ_E_INVALID;
-        if (cap_per_img > kRadixSortMax) return AKZ_E_TOO_LARGE;          // a frame's candidates are sorted in LDS
+        if (cap_per_img > kLmSlots / 4) return AKZ_E_TOO_LARGE;           // 2 keys per feature at a load factor <= 1/2
+        if (d_merge_ok && (uint64_t)n_world + (uint64_t)n_frames * cap_per_img > 0xFFFFFFFFull) return AKZ_E_TOO_LARGE;
         if (n_frames == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
@@ -1556,13 +1586,22 @@ extern "C" int32_t hm_landmark_pairs_batch_device(hm_ctx* c, const void* d_best,
         }
         AKZ_TRY(hm_ensure_probs(c, sizeof(uint32_t) * n_frames + 64));
         AKZ_TRY(hm_push_probs(c, 0, iq, sizeof(uint32_t) * n_frames));
-        AKZ_HIP(hipFuncSetAttribute((const void*)k_landmark_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRadixSortLdsBytes));
-        hipLaunchKernelGGL(k_landmark_pairs, dim3(n_frames), dim3(1024), kRadixSortLdsBytes, c->stream, (const uint2*)d_best,
-                           (const uint32_t*)d_decision, (const uint32_t*)d_nq, (const uint32_t*)c->d_probs, cap_per_img,
-                           (const double*)d_world, n_world, (uint2*)d_pairs, (uint32_t*)d_npairs);
+        AKZ_HIP(hipFuncSetAttribute((const void*)k_landmark_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLdsBytes));
+        hipLaunchKernelGGL(k_landmark_pairs, dim3(n_frames), dim3(1024), kLmLdsBytes, c->stream, (const uint2*)d_best,
+                           (const uint32_t*)d_decision, (const uint8_t*)d_merge_ok, (const uint32_t*)d_nq, (const uint32_t*)c->d_probs,
+                           cap_per_img, (const double*)d_world, n_world, (uint2*)d_pairs, (uint32_t*)d_npairs);
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     });
+}
+
+// hm_landmark_matches_batch_device with no merge mask: no decision-2 match passes the caller's graph test.
+extern "C" int32_t hm_landmark_pairs_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
+                                                  uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
+                                                  void* d_pairs, void* d_npairs, void* stream_to_wait)
+{
+    return hm_landmark_matches_batch_device(c, d_best, d_decision, nullptr, d_nq, iq, cap_per_img, n_frames, d_world, n_world, d_pairs,
+                                            d_npairs, stream_to_wait);
 }
 
 // Timing of the k-NN kernel launches (HIP events on hm_stream()): enable, run, then read the accumulated

@@ -71,7 +71,10 @@ __device__ __forceinline__ bool rs_w2c_inlier(const double* __restrict__ pose, c
     double q[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-        q[r] = __builtin_fma(pose[r * 4 + 3], w[3], __builtin_fma(pose[r * 4 + 2], w[2], __builtin_fma(pose[r * 4 + 1], w[1], pose[r * 4 + 0] * w[0])));
+        // q = [R | t] w in the exact statement's own unfused order ((a + b) + c) + d (akz_w2c_residual): when R w + t cancels —
+        // a world point near the hypothesis' camera centre — a fused q would differ from the exact one by far more than
+        // the band below; s2 and c have no cancellation in the band (|c| ~ |q| there) and keep their FMAs
+        q[r] = ((pose[r * 4 + 0] * w[0] + pose[r * 4 + 1] * w[1]) + pose[r * 4 + 2] * w[2]) + pose[r * 4 + 3] * w[3];
     const double s2 = __builtin_fma(q[2], q[2], __builtin_fma(q[1], q[1], q[0] * q[0]));
     double c = __builtin_fma(a[2], q[2], __builtin_fma(a[1], q[1], a[0] * q[0]));
     if (__builtin_signbit(w[3])) c = -c;

@@ -72,9 +72,14 @@ class Matcher:
         return out
 
     def set_targets(self, t):
-        """hm_set_targets: the target set stays on the device for the knn_targets() calls that follow."""
+        """hm_set_targets: the target set stays on the device for the knn_targets() calls that follow.  Returns the upload's
+        generation number (targets_generation() answers it for as long as this set is the resident one)."""
         t = _desc(t)
         check(_lib.lib().hm_set_targets(self._h, t.ctypes.data, len(t)), "hm_set_targets")
+        return self.targets_generation()
+
+    def targets_generation(self):
+        return int(_lib.lib().hm_targets_generation(self._h))
 
     def knn_targets(self, q, k):
         """hm_knn_targets: LinearKnn.knn(q, k) of every row of q against the resident targets."""
@@ -116,36 +121,44 @@ class LinearKnn:
 
     def __init__(self, metric=Hamming, iter=None, device=0):
         self.metric = metric
-        self.iter = _desc(iter if iter is not None else np.zeros((0, 64), np.uint8))
         self.device = device
+        self.iter = iter if iter is not None else np.zeros((0, 64), np.uint8)
+
+    @property
+    def iter(self):
+        return self._iter
+
+    @iter.setter
+    def iter(self, value):
+        # a private, read-only copy: what is resident on the device cannot drift from what this object scans (a caller
+        # mutating its own array in place does not reach it), and assigning a new set forgets the upload
+        self._iter = np.array(_desc(value), np.uint8, copy=True)
+        self._iter.setflags(write=False)
+        self._upload = None              # (matcher, generation) of this object's upload
 
     def _resident(self):
-        m = default_matcher(max(len(self.iter), 1), self.device)
-        if getattr(m, "_resident_of", None) is not self:
-            m.set_targets(self.iter)
-            m._resident_of = self
+        m = default_matcher(max(len(self._iter), 1), self.device)
+        if self._upload is None or self._upload[0] is not m or m.targets_generation() != self._upload[1]:
+            self._upload = (m, m.set_targets(self._iter))
         return m
 
     def knn(self, query, num):
         """Knn::knn(&self, query, num) -> Vec<Neighbor>, sorted by (distance, index), min(num, len) long.
         The device path implements num <= 3 (the reference asks for 2 when matching frame pairs and 3 when
         registering a frame against recent views, cv-sfm/src/lib.rs:1474).  `iter` is uploaded once and stays on the
-        device between calls (hm_set_targets / hm_knn_targets); a call still costs one launch per query — match whole
-        frames with knn_batch() or matching() where the caller's loop allows it."""
+        device between calls (hm_set_targets / hm_knn_targets; the upload's generation number is compared before every
+        call, so another LinearKnn or a matching() call on the same matcher in between triggers a fresh upload); a call
+        still costs one launch per query — match whole frames with knn_batch() or matching() where the caller's loop
+        allows it."""
         if not 1 <= num <= 3:
             raise NotImplementedError("the MI355X matcher implements knn(query, k) for k <= 3")
-        try:
-            nn = self._resident().knn_targets(_desc(query)[:1], num)
-        except _lib.AkzError:
-            default_matcher(max(len(self.iter), 1), self.device)._resident_of = None    # another call took the staging buffer
-            nn = self._resident().knn_targets(_desc(query)[:1], num)
-        return [Neighbor(int(nn[0, i]["index"]), int(nn[0, i]["distance"])) for i in range(min(num, len(self.iter)))]
+        nn = self._resident().knn_targets(_desc(query)[:1], num)
+        return [Neighbor(int(nn[0, i]["index"]), int(nn[0, i]["distance"])) for i in range(min(num, len(self._iter)))]
 
     def knn_batch(self, queries, num=2):
         """knn(q, num) for every row of `queries` in one launch: [nq,num] structured (index, distance)."""
-        m = default_matcher(max(len(self.iter), len(queries), 1), self.device)
-        m._resident_of = None
-        return m.knn2(queries, self.iter) if num == 2 else m.knn(queries, self.iter, num)
+        m = default_matcher(max(len(self._iter), len(queries), 1), self.device)
+        return m.knn2(queries, self._iter) if num == 2 else m.knn(queries, self._iter, num)
 
 
 def matching(a_descriptors, b_descriptors, better_by=24, strict=True, device=0):

@@ -11,10 +11,11 @@
 
 The reference walks this per feature on the CPU; here one call enqueues, for ALL frames of a micro-batch,
 hm_hash_bag_device -> hm_knn_batch_device (k = 3, frames x views problems) -> hm_best_of_views_batch_device ->
-hm_landmark_pairs_batch_device -> rs_p3p_arrsac_batch_device on the blocks where akz_extract_batch_device left them; nothing
+hm_landmark_matches_batch_device -> rs_p3p_arrsac_batch_device on the blocks where akz_extract_batch_device left them; nothing
 returns to the host in between.  What stays with the caller is the reference's control plane: which views a frame is matched
-against, which landmark each stored feature observes, the table of triangulated landmarks (and the graph test for merge
-candidates, decision 2).  There is no CPU fallback.
+against, which landmark each stored feature observes, the table of triangulated landmarks, and for the merge candidates
+(decision 2) the graph test are_landmarks_sharing_view plus the merged triangulation — handed in as a mask and extra world
+rows between match_views() and consensus().  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -83,18 +84,23 @@ class Registration:
         return self.cons.stream()
 
     def enqueue(self, d_kps, d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, d_world, n_world, stream_to_wait=None,
-                shuffle=True):
+                shuffle=True, d_merge_ok=None):
+        """match_views() followed by consensus(): the whole chain in one go (see the two for the arguments)."""
+        self.match_views(d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, stream_to_wait=stream_to_wait)
+        self.consensus(d_kps, d_counts, d_world, n_world, shuffle=shuffle, d_merge_ok=d_merge_ok)
+
+    def match_views(self, d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, stream_to_wait=None):
         """frame_blocks [F]: block index (into d_descs / d_counts / d_kps, [..][cap] each) of every new frame;
         view_blocks [F][V]: the blocks of the views each frame is matched against; d_landmarks [blocks][cap] int32: the
-        landmark key observed by every feature of every stored block; d_world [n_world][4] f64 indexed by landmark key.
-        All d_* are torch tensors on the device.  Enqueues on the matcher's and the consensus' streams and returns;
-        sync() waits.  Outputs: self.hash, self.best / decision, self.pairs / npairs, self.pose / best_id / inliers /
-        n_inliers / stats (slot = position in frame_blocks) — of THIS call until the next enqueue() (two output sets
-        alternate)."""
+        landmark key observed by every feature of every stored block.  All d_* are torch tensors on the device.  Enqueues
+        hash_bag, the k = 3 searches and the best-of-views decision on the matcher's stream and returns.  Outputs:
+        self.hash, self.best / decision (slot = position in frame_blocks) — of THIS call until the next match_views() (two
+        output sets alternate)."""
         L = _lib.lib()
         cur = self._sets[self._calls & 1]
         self._select(self._calls & 1)
         self._calls += 1
+        self._cur = cur
         if cur["used"]:
             self._hm_s.wait_event(cur["done"])           # the consensus of two calls ago has read this set's pair lists
         F = len(frame_blocks)
@@ -103,6 +109,7 @@ class Registration:
         fb, fb_p = _u32(frame_blocks)
         iq, iq_p = _u32(np.repeat(fb, V))
         it, it_p = _u32(view_blocks)
+        self._fb = fb
         h = self.matcher.handle
         # hash_bag runs over the frames' blocks where they lie: block b of d_descs -> row b of the hash table of THIS call
         # (the new frames are contiguous in every caller so far: hash the span)
@@ -117,11 +124,28 @@ class Registration:
         check(L.hm_best_of_views_batch_device(h, self.knn.data_ptr(), d_counts.data_ptr(), fb_p, self.cap, it_p, F, V, self.k,
                                               d_landmarks.data_ptr(), d_counts.data_ptr(), self.better_by, self.best.data_ptr(),
                                               self.decision.data_ptr(), None), "hm_best_of_views_batch_device")
-        check(L.hm_landmark_pairs_batch_device(h, self.best.data_ptr(), self.decision.data_ptr(), d_counts.data_ptr(), fb_p,
-                                               self.cap, F, d_world.data_ptr(), n_world, self.pairs.data_ptr(),
-                                               self.npairs.data_ptr(), None), "hm_landmark_pairs_batch_device")
+
+    def consensus(self, d_kps, d_counts, d_world, n_world, shuffle=True, d_merge_ok=None, stream_to_wait=None):
+        """The duplicate-landmark filter, the FeatureWorldMatch lists and single_view_consensus.model_inliers for the frames of
+        the last match_views().  d_world [rows][4] f64: rows [0, n_world) indexed by landmark key.  d_merge_ok [F][cap] uint8
+        (optional): the caller's are_landmarks_sharing_view verdicts for the merge candidates (decision 2,
+        cv-sfm/src/lib.rs:1521-1531, read from self.decision after match_views()) — non-zero admits ([best0, best1], feature)
+        as a match, whose world point is row n_world + f * cap + feature of d_world (triangulate_merged_landmark_robust; d_world
+        then has n_world + F * cap rows); stream_to_wait = the stream the mask and those rows were written on.  Without a mask no
+        merge candidate becomes a match — equal to the reference exactly when none passes its graph test.  Outputs:
+        self.pairs / npairs, self.pose / best_id / inliers / n_inliers / stats."""
+        L = _lib.lib()
+        cur, fb = self._cur, self._fb
+        F = len(fb)
+        _, fb_p = _u32(fb)
+        rows = n_world if d_merge_ok is None else n_world + F * self.cap
+        assert d_world.shape[0] >= rows
+        check(L.hm_landmark_matches_batch_device(self.matcher.handle, self.best.data_ptr(), self.decision.data_ptr(),
+                                                 None if d_merge_ok is None else d_merge_ok.data_ptr(), d_counts.data_ptr(), fb_p,
+                                                 self.cap, F, d_world.data_ptr(), n_world, self.pairs.data_ptr(),
+                                                 self.npairs.data_ptr(), stream_to_wait), "hm_landmark_matches_batch_device")
         self.cons.p3p_model_inliers_batch_device(d_kps.data_ptr(), self.cap, [int(b) for b in fb], self.pairs.data_ptr(),
-                                                 self.npairs.data_ptr(), d_world.data_ptr(), n_world, self.cam, self.prm,
+                                                 self.npairs.data_ptr(), d_world.data_ptr(), rows, self.cam, self.prm,
                                                  self.pose.data_ptr(), self.best_id.data_ptr(), self.inliers.data_ptr(),
                                                  self.n_inliers.data_ptr(), self.stats.data_ptr(), shuffle=shuffle,
                                                  stream_to_wait=self.hm_stream())

@@ -39,6 +39,13 @@ inline void check(int32_t s, const char* what)
 {
     if (s != AKZ_OK) throw Error(s, what);
 }
+// The library this translation unit is linked to must export the ABI this header was written against (AKZ_ABI_VERSION).
+inline void require_abi()
+{
+    static const bool ok = akz_abi_version() == AKZ_ABI_VERSION;
+    if (!ok) throw std::runtime_error("libakz exports ABI " + std::to_string(akz_abi_version()) + ", akaze.hpp was written against " +
+                                      std::to_string(AKZ_ABI_VERSION));
+}
 
 // akaze::KeyPoint (lib.rs:69-93)
 struct KeyPoint {
@@ -120,6 +127,7 @@ struct CtxCache {
         }
         if (victim->ctx) akz_destroy(victim->ctx);
         victim->ctx = nullptr;
+        require_abi();
         check(akz_create(&k.cfg, k.device, k.w, k.h, 1, k.max_keypoints, &victim->ctx), "akz_create");
         victim->key = k;
         victim->used = ++tick;
@@ -267,6 +275,7 @@ class Matcher {
 public:
     explicit Matcher(uint32_t max_descriptors = 16384, int device = 0)
     {
+        akaze::require_abi();
         akaze::check(hm_create(device, max_descriptors, max_descriptors, &ctx_), "hm_create");
     }
     ~Matcher()
@@ -324,20 +333,17 @@ private:
     void ask(const akaze::BitArray64* q, uint32_t nq, uint32_t k, akz_neighbor* out) const
     {
         const akz_descriptor* t = reinterpret_cast<const akz_descriptor*>(iter_.data());
-        if (!resident_) {
+        // upload unless the matcher still holds THIS object's upload (its generation number: another LinearKnn on the same
+        // matcher, or any host-buffer call that took the staging buffer, changes it)
+        if (generation_ == 0 || hm_targets_generation(m_.handle()) != generation_) {
             akaze::check(hm_set_targets(m_.handle(), t, (uint32_t)iter_.size()), "hm_set_targets");
-            resident_ = true;
+            generation_ = hm_targets_generation(m_.handle());
         }
-        int32_t st = hm_knn_targets(m_.handle(), reinterpret_cast<const akz_descriptor*>(q), nq, k, out);
-        if (st == AKZ_E_INVALID) {          // another host-buffer call on this matcher took the staging buffer: upload again
-            akaze::check(hm_set_targets(m_.handle(), t, (uint32_t)iter_.size()), "hm_set_targets");
-            st = hm_knn_targets(m_.handle(), reinterpret_cast<const akz_descriptor*>(q), nq, k, out);
-        }
-        akaze::check(st, "hm_knn_targets");
+        akaze::check(hm_knn_targets(m_.handle(), reinterpret_cast<const akz_descriptor*>(q), nq, k, out), "hm_knn_targets");
     }
     const std::vector<akaze::BitArray64>& iter_;
     Matcher& m_;
-    mutable bool resident_ = false;
+    mutable uint64_t generation_ = 0;
 };
 
 inline std::vector<std::array<std::size_t, 2>> run_match(Matcher& m, const std::vector<akaze::BitArray64>& a,
@@ -513,6 +519,7 @@ private:
             ctx_ = nullptr;
             cap_m_ = n < 64 ? 64 : n;
             cap_h_ = need_h;
+            akaze::require_abi();
             akaze::check(rs_create(device_, cap_m_, cap_h_, &ctx_), "rs_create");
         }
         std::vector<uint32_t> idx(n);

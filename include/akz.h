@@ -83,7 +83,8 @@ void akz_config_default(akz_config* cfg);
 /* Context = the pre-allocated per-device pyramid for up to max_batch frames of up to
  * max_w x max_h pixels (what Akaze::allocate_evolutions, akaze/src/evolution.rs:80-126, allocates
  * per call in the reference).  max_keypoints bounds the per-frame candidate/keypoint lists
- * (0 = default 16384). */
+ * (0 = default 16384).  max_w, max_h in [3, 65535] and max_w * max_h <= 2^28 pixels (the kernels address a
+ * frame's planes with 32-bit byte offsets): a larger frame is refused with AKZ_E_TOO_LARGE. */
 int32_t akz_create(const akz_config* cfg, int32_t device, int32_t max_w, int32_t max_h,
                    int32_t max_batch, uint32_t max_keypoints, akz_ctx** out);
 int32_t akz_destroy(akz_ctx* ctx);
@@ -283,6 +284,10 @@ int32_t hm_knn(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, const akz_desc
  * hm_knn's.  Any other host-buffer call on the context (hm_knn, hm_knn2, hm_match, hm_hash_bag) reuses the staging buffer
  * and ends the residency: hm_knn_targets then returns AKZ_E_INVALID rather than search stale data. */
 int32_t hm_set_targets(hm_ctx* ctx, const akz_descriptor* t, uint32_t nt);
+/* The number of the hm_set_targets call whose targets the context holds, 0 when nothing is resident.  A LinearKnn mirror keeps
+ * the value its own upload produced and compares before every hm_knn_targets: any other upload or residency-ending call on the
+ * context in between changes it (a pointer / length comparison of the host array would not notice a re-used allocation). */
+uint64_t hm_targets_generation(hm_ctx* ctx);
 int32_t hm_knn_targets(hm_ctx* ctx, const akz_descriptor* q, uint32_t nq, uint32_t k, akz_neighbor* out);
 /* Device-resident multi-view form of the same call (cv-sfm/src/lib.rs:1468-1486: every feature of the new
  * frame against each of up to 32 recent views): d_q [cap][64] + count d_nq, d_views [..][cap][64] + counts
@@ -318,15 +323,24 @@ int32_t hm_best_of_views_batch_device(hm_ctx* ctx, const void* d_knn, const void
                                       const uint32_t* view_idx, uint32_t n_frames, uint32_t n_views, uint32_t k,
                                       const void* d_landmarks, const void* d_nviews, uint32_t better_by, void* d_best,
                                       void* d_decision, void* stream_to_wait);
-/* What follows the decision in register_frame_subset (cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604), for every frame of
- * a micro-batch: a feature with decision 1 becomes the match (best[0].landmark, feature); matches whose landmark was claimed
- * by more than one feature of the frame are dropped, all of them (:1549-1563); a match whose landmark has no robust
- * triangulation is dropped (:1583-1604, filter_map) — d_world [n_world][4] f64 is the caller's table of homogeneous world
- * points indexed by landmark key, an entry with w < 0 (impossible for a Projective point) or a key >= n_world says "none".
- * d_best / d_decision / d_nq / iq as hm_best_of_views_batch_device wrote / took them; d_pairs [n_frames][cap][2] u32
- * {feature, landmark} in ascending feature order, d_npairs [n_frames] — the pair lists rs_p3p_arrsac_batch_device takes.
- * cap_per_img <= 8192.  (The merge candidates, decision 2, need the landmark graph and stay with the caller; so does the
- * reference's stable sort by observation count, which only fixes the order the consensus sees.) */
+/* What follows the decision in register_frame_subset (cv-sfm/src/lib.rs:1516-1532, 1549-1563, 1583-1604), for every frame of
+ * a micro-batch.  original_matches: a feature with decision 1 is the match ([best0], feature); a feature with decision 2
+ * whose two landmarks share no view — are_landmarks_sharing_view (:1528) is the caller's graph test, its verdict is
+ * d_merge_ok [n_frames][cap] u8 (non-zero: the merge may be attempted), NULL when no merge candidate passes — is the match
+ * ([best0, best1], feature).  landmark_counts covers every landmark of every original match, both landmarks of a merge
+ * included, and a match survives only if each of its landmarks was counted once (:1549-1563).  A survivor whose
+ * triangulation is None is dropped (:1583-1604, filter_map): d_world is the caller's table of homogeneous world points,
+ * rows [0, n_world) indexed by landmark key (triangulate_landmark_robust) and — only with a merge mask — rows
+ * n_world + f * cap + j = triangulate_merged_landmark_robust of frame f's feature j; a row with w < 0 (impossible for a
+ * Projective point) or a landmark key >= n_world says "None".  d_best / d_decision / d_nq / iq as
+ * hm_best_of_views_batch_device wrote / took them; d_pairs [n_frames][cap][2] u32 {feature, world row} in ascending feature
+ * order, d_npairs [n_frames] — the pair lists rs_p3p_arrsac_batch_device takes (with n_world + n_frames * cap rows when a
+ * merge mask is given).  cap_per_img <= 8192.  (The reference's stable sort by observation count, :1561-1574, only fixes
+ * the order the consensus sees and stays with the caller.) */
+int32_t hm_landmark_matches_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_merge_ok,
+                                         const void* d_nq, const uint32_t* iq, uint32_t cap_per_img, uint32_t n_frames,
+                                         const void* d_world, uint32_t n_world, void* d_pairs, void* d_npairs, void* stream_to_wait);
+/* hm_landmark_matches_batch_device without a merge mask (equals the reference when no decision-2 match passes the graph test). */
 int32_t hm_landmark_pairs_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
                                        uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
                                        void* d_pairs, void* d_npairs, void* stream_to_wait);
@@ -573,6 +587,11 @@ const char* akz_strerror(int32_t status);
 int32_t akz_last_hip_error(void);
 const char* akz_last_hip_error_string(void);
 const char* akz_version(void);
+/* The ABI number: raised whenever a declared signature, struct layout or enum value of this header changes (additions
+ * included).  A binding compares akz_abi_version() of the library it loaded with the AKZ_ABI_VERSION it was written against
+ * and refuses to run on a mismatch (cv_amd/_lib.py, rust/akaze-mi355x/src/lib.rs, include/akaze.hpp do). */
+#define AKZ_ABI_VERSION 5u
+uint32_t akz_abi_version(void);
 
 /* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Kernel families (every id but the
  * phase ids below): each launch carries its own start / stop events (hipExtLaunchKernel — the dispatch's begin and end

@@ -186,26 +186,51 @@ void orc_best_of_views(const akz_neighbor* knn, uint32_t nq, uint32_t cap, uint3
     }
 }
 
-/* The FeatureWorldMatch list of one frame, cv-sfm/src/lib.rs:1516-1520 (decision 1 -> (best[0].landmark, feature)),
- * :1549-1563 (a landmark matched by two features of the frame takes all its matches with it) and :1583-1604 (no robust
- * triangulation -> dropped; here: landmark key >= n_world or a world point with w < 0).  best [nq][3][2] {landmark, distance},
- * decision [nq]; pairs [..][2] {feature, landmark} in ascending feature order; returns their number. */
-uint32_t orc_landmark_pairs(const uint32_t* best, const uint32_t* decision, uint32_t nq, const double* world, uint32_t n_world,
-                            uint32_t* pairs)
+/* The FeatureWorldMatch list of one frame, cv-sfm/src/lib.rs:1516-1532 (decision 1 -> ([best0], feature); decision 2 with
+ * the caller's are_landmarks_sharing_view verdict merge_ok[i] != 0 -> ([best0, best1], feature)), :1549-1563 (landmark_counts
+ * over every landmark of every original match; a match survives iff each of its landmarks was counted once) and :1583-1604
+ * (triangulation None -> dropped; here: landmark key >= n_world, or a world row with w < 0; the merged triangulation of
+ * feature i is row merged_base + i).  best [nq][3][2] {landmark, distance}, decision [nq], merge_ok [nq] or NULL;
+ * pairs [..][2] {feature, world row} in ascending feature order; returns their number. */
+static uint32_t orc_lm_kind(const uint32_t* best, const uint32_t* decision, const uint8_t* merge_ok, uint32_t i)
+{
+    if (best[(size_t)i * 6] == 0xFFFFFFFFu) return 0;
+    if (decision[i] == 1u) return 1;
+    if (decision[i] == 2u && merge_ok && merge_ok[i] && best[(size_t)i * 6 + 2] != 0xFFFFFFFFu) return 2;
+    return 0;
+}
+static uint32_t orc_lm_claims(const uint32_t* best, const uint32_t* decision, const uint8_t* merge_ok, uint32_t nq, uint32_t lm)
+{
+    uint32_t claims = 0;
+    for (uint32_t j = 0; j < nq; ++j) {
+        const uint32_t k = orc_lm_kind(best, decision, merge_ok, j);
+        if (k >= 1 && best[(size_t)j * 6] == lm) claims++;
+        if (k == 2 && best[(size_t)j * 6 + 2] == lm) claims++;
+    }
+    return claims;
+}
+uint32_t orc_landmark_matches(const uint32_t* best, const uint32_t* decision, const uint8_t* merge_ok, uint32_t nq,
+                              const double* world, uint32_t n_world, uint32_t merged_base, uint32_t* pairs)
 {
     uint32_t n = 0;
     for (uint32_t i = 0; i < nq; ++i) {
-        if (decision[i] != 1u) continue;
-        const uint32_t lm = best[(size_t)i * 6];
-        if (lm == 0xFFFFFFFFu) continue;
-        uint32_t claims = 0;
-        for (uint32_t j = 0; j < nq; ++j)
-            if (decision[j] == 1u && best[(size_t)j * 6] == lm) claims++;
-        if (claims != 1) continue;
-        if (lm >= n_world || !(world[(size_t)4 * lm + 3] >= 0.0)) continue;
+        const uint32_t k = orc_lm_kind(best, decision, merge_ok, i);
+        if (k == 0) continue;
+        if (orc_lm_claims(best, decision, merge_ok, nq, best[(size_t)i * 6]) != 1) continue;
+        uint32_t row = best[(size_t)i * 6];
+        if (k == 2) {
+            if (orc_lm_claims(best, decision, merge_ok, nq, best[(size_t)i * 6 + 2]) != 1) continue;
+            row = merged_base + i;
+        } else if (row >= n_world) continue;
+        if (!(world[(size_t)4 * row + 3] >= 0.0)) continue;
         pairs[2 * n] = i;
-        pairs[2 * n + 1] = lm;
+        pairs[2 * n + 1] = row;
         n++;
     }
     return n;
+}
+uint32_t orc_landmark_pairs(const uint32_t* best, const uint32_t* decision, uint32_t nq, const double* world, uint32_t n_world,
+                            uint32_t* pairs)
+{
+    return orc_landmark_matches(best, decision, NULL, nq, world, n_world, 0, pairs);
 }

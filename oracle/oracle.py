@@ -477,17 +477,21 @@ def best_of_views(knn_out, nq, landmarks, view_idx, nviews, better_by=24):
     return best, dec
 
 
-def landmark_pairs(best, decision, world):
-    """cv-sfm/src/lib.rs:1516-1520, 1549-1563, 1583-1604 (oracle/match_oracle.c: orc_landmark_pairs): the (feature, landmark)
-    pair list of one frame from the best-of-views output; world [n_world, 4] f64 (w < 0: no robust triangulation)."""
+def landmark_pairs(best, decision, world, merge_ok=None, n_world=None, merged_base=0):
+    """cv-sfm/src/lib.rs:1516-1532, 1549-1563, 1583-1604 (oracle/match_oracle.c: orc_landmark_matches): the (feature, world
+    row) list of one frame from the best-of-views output; world [rows, 4] f64 (w < 0: no robust triangulation).  merge_ok
+    [nq] (the caller's are_landmarks_sharing_view verdicts) admits decision-2 features as merged matches; their world point is
+    row merged_base + feature; n_world = rows addressed by landmark key (default: all of them)."""
     best = np.ascontiguousarray(best, np.uint32).reshape(-1, 3, 2)
     dec = np.ascontiguousarray(decision, np.uint32)
     W = np.ascontiguousarray(world, np.float64).reshape(-1, 4)
     out = np.zeros((max(len(dec), 1), 2), np.uint32)
+    mk = None if merge_ok is None else np.ascontiguousarray(merge_ok, np.uint8)
     L = lib()
-    L.orc_landmark_pairs.restype = C.c_uint32
-    L.orc_landmark_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
-    n = L.orc_landmark_pairs(best.ctypes.data, dec.ctypes.data, len(dec), W.ctypes.data, len(W), out.ctypes.data)
+    L.orc_landmark_matches.restype = C.c_uint32
+    L.orc_landmark_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    n = L.orc_landmark_matches(best.ctypes.data, dec.ctypes.data, None if mk is None else mk.ctypes.data, len(dec), W.ctypes.data,
+                               len(W) if n_world is None else n_world, merged_base, out.ctypes.data)
     return out[:n].copy()
 
 

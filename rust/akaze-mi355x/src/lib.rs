@@ -14,7 +14,7 @@ use cv_core::{
     CameraToCamera, FeatureMatch, FeatureWorldMatch, ImagePoint, Projective, WorldToCamera,
 };
 use ::image::{DynamicImage, ImageResult};
-use std::{cell::RefCell, os::raw::c_void, path::Path, ptr};
+use std::{cell::{Cell, RefCell}, os::raw::c_void, path::Path, ptr};
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -84,6 +84,8 @@ extern "C" {
     fn hm_knn(ctx: *mut c_void, q: *const [u8; 64], nq: u32, t: *const [u8; 64], nt: u32, k: u32,
               out: *mut AkzNeighbor) -> i32;
     fn hm_set_targets(ctx: *mut c_void, t: *const [u8; 64], nt: u32) -> i32;
+    fn hm_targets_generation(ctx: *mut c_void) -> u64;
+    fn akz_abi_version() -> u32;
     fn hm_knn_targets(ctx: *mut c_void, q: *const [u8; 64], nq: u32, k: u32, out: *mut AkzNeighbor) -> i32;
     fn hm_hash_bag(ctx: *mut c_void, feats: *const [u8; 64], n: u32, codewords: *const [u8; 64], n_codewords: u32,
                    hash: *mut u8, words: *mut AkzNeighbor) -> i32;
@@ -197,6 +199,13 @@ fn same_cfg(a: &AkzConfig, b: &AkzConfig) -> bool {
         && a.descriptor_pattern_size == b.descriptor_pattern_size
 }
 /// The thread's matcher context, grown to hold `n` descriptors a side.
+/// include/akz.h AKZ_ABI_VERSION these bindings were written against; the loaded library must export the same number.
+const AKZ_ABI_VERSION: u32 = 5;
+fn require_abi() {
+    let got = unsafe { akz_abi_version() };
+    assert_eq!(got, AKZ_ABI_VERSION, "libakz exports ABI {got}, akaze-mi355x was written against {AKZ_ABI_VERSION}");
+}
+
 fn with_matcher<R>(n: u32, f: impl FnOnce(*mut c_void) -> R) -> R {
     MATCHER.with(|m| {
         let mut m = m.borrow_mut();
@@ -204,6 +213,7 @@ fn with_matcher<R>(n: u32, f: impl FnOnce(*mut c_void) -> R) -> R {
             if let Some((_, old)) = m.take() {
                 unsafe { hm_destroy(old) };
             }
+            require_abi();
             let cap = n.max(4096).next_power_of_two();
             let mut ctx: *mut c_void = ptr::null_mut();
             let st = unsafe { hm_create(0, cap, cap, &mut ctx) };
@@ -345,12 +355,6 @@ impl Akaze {
     }
 }
 
-thread_local! {
-    /// Which target set the thread's matcher holds on the device: (address, length, first and last descriptor) of the
-    /// slice `hm_set_targets` was last called with, and the matcher it was uploaded to.
-    static RESIDENT: RefCell<Option<(usize, usize, [u8; 64], [u8; 64], *mut c_void)>> = RefCell::new(None);
-}
-
 /// A `space::Knn` implementor with `LinearKnn { metric: Hamming, iter }` semantics for `BitArray<64>`.
 ///
 /// The reference's callers build the `LinearKnn` once per frame pair and call `knn` once per query descriptor
@@ -362,21 +366,24 @@ thread_local! {
 /// [`match_descriptors`] / `symmetric_matching`, which also keep the pair lists on the device side of the matcher.
 pub struct Mi355xLinearKnn<'a> {
     pub targets: &'a [BitArray<64>],
+    /// (matcher, generation) of THIS value's upload (`hm_targets_generation` right after its `hm_set_targets`).  The
+    /// borrow keeps `targets` immutable for as long as the value lives, and the token lives in the value: a set dropped
+    /// and another allocated at the same address is a different value with no token, so it uploads.
+    upload: Cell<Option<(*mut c_void, u64)>>,
 }
 impl<'a> Mi355xLinearKnn<'a> {
-    fn key(&self) -> (usize, usize, [u8; 64], [u8; 64]) {
-        let z = [0u8; 64];
-        (self.targets.as_ptr() as usize, self.targets.len(),
-         self.targets.first().map_or(z, |d| *d.bytes()), self.targets.last().map_or(z, |d| *d.bytes()))
+    /// `LinearKnn { metric: Hamming, iter: targets }`.
+    pub fn new(targets: &'a [BitArray<64>]) -> Self {
+        Self { targets, upload: Cell::new(None) }
     }
-    /// Upload the targets unless this thread's matcher already holds exactly this slice.
+    /// Upload the targets unless the matcher still holds exactly this value's upload: any other upload, or any
+    /// host-buffer call that took the staging buffer, changes the matcher's generation number.
     fn resident(&self, ctx: *mut c_void) {
-        let k = self.key();
-        let hit = RESIDENT.with(|r| r.borrow().map_or(false, |(p, n, a, b, c)| (p, n, a, b) == k && c == ctx));
-        if !hit {
+        let current = unsafe { hm_targets_generation(ctx) };
+        if self.upload.get().map_or(true, |(c, g)| c != ctx || g != current || current == 0) {
             let st = unsafe { hm_set_targets(ctx, self.targets.as_ptr() as *const [u8; 64], self.targets.len() as u32) };
             assert_eq!(st, 0, "hm_set_targets failed with status {st}");
-            RESIDENT.with(|r| *r.borrow_mut() = Some((k.0, k.1, k.2, k.3, ctx)));
+            self.upload.set(Some((ctx, unsafe { hm_targets_generation(ctx) })));
         }
     }
     /// `knn(q, num)` for every query in ONE launch: `out[i]` are the `min(num, targets.len())` nearest targets of
@@ -387,14 +394,7 @@ impl<'a> Mi355xLinearKnn<'a> {
         let mut out = vec![AkzNeighbor { index: 0, distance: 0 }; queries.len() * num];
         let st = with_matcher(nq.max(nt), |ctx| {
             self.resident(ctx);
-            let mut st = unsafe { hm_knn_targets(ctx, queries.as_ptr() as *const [u8; 64], nq, num as u32, out.as_mut_ptr()) };
-            if st == -1 {
-                // another host-buffer call of this thread took the staging buffer in between: upload again
-                RESIDENT.with(|r| *r.borrow_mut() = None);
-                self.resident(ctx);
-                st = unsafe { hm_knn_targets(ctx, queries.as_ptr() as *const [u8; 64], nq, num as u32, out.as_mut_ptr()) };
-            }
-            st
+            unsafe { hm_knn_targets(ctx, queries.as_ptr() as *const [u8; 64], nq, num as u32, out.as_mut_ptr()) }
         });
         assert_eq!(st, 0);
         let keep = num.min(self.targets.len());

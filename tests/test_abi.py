@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"libakz.so does not export {name}"
 
 
+def test_abi_number_is_the_headers(lib):
+    """akz_abi_version() of the built library == AKZ_ABI_VERSION of include/akz.h == what every binding was written against
+    (cv_amd/_lib.py refuses to load anything else; include/akaze.hpp and rust/akaze-mi355x check the same number)."""
+    from cv_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "akz.h")).read()
+    n = int(re.search(r"#define\s+AKZ_ABI_VERSION\s+(\d+)u", hdr).group(1))
+    assert lib.akz_abi_version() == n == _lib.ABI_VERSION
+    rs = open(os.path.join(ROOT, "rust", "akaze-mi355x", "src", "lib.rs")).read()
+    assert int(re.search(r"const AKZ_ABI_VERSION: u32 = (\d+);", rs).group(1)) == n
+    assert "require_abi()" in open(os.path.join(ROOT, "include", "akaze.hpp")).read()
+    assert lib.hm_targets_generation(None) == 0
+
+
 def test_pod_layouts_match_the_reference_types(lib):
     from cv_amd import _lib
     assert C.sizeof(_lib.Config) == 80
@@ -83,6 +96,11 @@ def test_options_struct_and_early_validation(lib):
     o = _lib.make_options()
     o.struct_size = 4
     assert lib.akz_create_ex(C.byref(cfg), 0, 640, 480, 1, 0, C.byref(o), C.byref(h)) == -1
+    # a frame the 32-bit byte offsets of the diffusion / determinant kernels cannot address (akz_common.h kAkzMaxPixels)
+    lib.akz_config_default(C.byref(cfg))
+    assert lib.akz_create_ex(C.byref(cfg), 0, 32768, 16384, 1, 0, None, C.byref(h)) == -6        # AKZ_E_TOO_LARGE
+    assert lib.akz_create_ex(C.byref(cfg), 0, 16385, 16384, 1, 0, None, C.byref(h)) == -6
+    assert lib.akz_create(C.byref(cfg), 0, 65535, 65535, 1, 0, C.byref(h)) == -6
     # a valid call gets as far as the device probe
     import torch
     if not torch.cuda.is_available():

@@ -2329,6 +2329,26 @@ def test_linear_knn_keeps_its_targets_on_the_device(gpu, oracle):
     # fewer targets than neighbours asked for: min(k, len) come back
     small = knn.LinearKnn(knn.Hamming, t[:2])
     assert len(small.knn(q[0], 3)) == 2
+    # two LinearKnn objects asked in turn on the SAME matcher (same length, even: a pointer / length comparison cannot tell
+    # them apart): each question is answered from its own set — the upload's generation number decides, not a heuristic
+    t2 = _rand_desc(rng, 700)
+    la, lb = knn.LinearKnn(knn.Hamming, t), knn.LinearKnn(knn.Hamming, t2)
+    wa, wb2 = oracle.knn(q, t, 2), oracle.knn(q, t2, 2)
+    for i in range(6):
+        for lk_, w in ((la, wa), (lb, wb2), (la, wa)):
+            got = lk_.knn(q[i], 2)
+            assert [(n.index, n.distance) for n in got] == [(int(w[i, j]["index"]), int(w[i, j]["distance"])) for j in range(2)], i
+    g0 = m.targets_generation()
+    la.knn(q[0], 2); la.knn(q[1], 2)                          # (la asked last: no further upload)
+    assert m.targets_generation() == g0 != 0
+    # the caller mutating ITS array afterwards does not reach the object (private copy), assigning `iter` forgets the upload
+    src = t.copy()
+    lc = knn.LinearKnn(knn.Hamming, src)
+    first = lc.knn(q[5], 2)
+    src[:] = t2
+    assert [(n.index, n.distance) for n in lc.knn(q[5], 2)] == [(n.index, n.distance) for n in first]
+    lc.iter = t2
+    assert [(n.index, n.distance) for n in lc.knn(q[5], 2)] == [(int(wb2[5, j]["index"]), int(wb2[5, j]["distance"])) for j in range(2)]
 
 
 def test_new_entry_points_refuse_what_they_cannot_do(gpu):

@@ -193,3 +193,62 @@ def test_landmark_pairs_rules(gpu, oracle):
                                             cap, F, d_world.data_ptr(), n_world, d_pairs.data_ptr(), d_np.data_ptr(), None) == -1
     assert L.hm_landmark_pairs_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p),
                                             cap, F, d_world.data_ptr(), 0, d_pairs.data_ptr(), d_np.data_ptr(), None) == -1
+
+
+def test_landmark_matches_with_merge_candidates(gpu, oracle):
+    """hm_landmark_matches_batch_device with the caller's merge verdicts (cv-sfm/src/lib.rs:1521-1531): an accepted decision-2
+    feature is the match ([best0, best1], feature); landmark_counts covers BOTH of its landmarks (:1549-1552), so a decision-1
+    match whose landmark a merge also claims is dropped and so is the merge, and a surviving merge leaves with its merged
+    world row n_world + f * cap + feature — every frame equal to the oracle, and the mask-less call equal to a zero mask."""
+    import ctypes as C
+    torch = gpu
+    from cv_amd import _lib
+    from cv_amd.knn import Matcher
+    rng = np.random.default_rng(0x3E46E)
+    cap, F, n_world = 2048, 5, 6000
+    nq = np.array([2048, 1500, 0, 2048, 300], np.int32)
+    best = np.zeros((F, cap, 3, 2), np.uint32)
+    # mostly distinct landmarks per feature (as after the per-feature dedup), with collisions between features
+    for f in range(F):
+        for j in range(cap):
+            best[f, j, :, 0] = rng.choice(n_world + 40, 3, replace=False)
+    best[..., 1] = rng.integers(0, 300, (F, cap, 3))
+    best[0, :, 0, 0] = rng.permutation(n_world)[:cap]                  # frame 0: first landmarks all distinct ...
+    best[0, :, 1, 0] = (best[0, :, 0, 0] + 1 + rng.integers(0, 3, cap)) % n_world   # ... seconds collide with other firsts
+    best[3, 7, 1, 0] = 0xFFFFFFFF
+    dec = rng.integers(0, 3, (F, cap)).astype(np.uint32)
+    merge_ok = (rng.random((F, cap)) < 0.6).astype(np.uint8)
+    world = rng.standard_normal((n_world + F * cap, 4))
+    world[:, 3] = np.abs(world[:, 3])
+    world[rng.random(len(world)) < 0.2, 3] = -1.0
+    dev = torch.device("cuda", 0)
+    d_best = torch.from_numpy(best.view(np.int32)).to(dev); d_dec = torch.from_numpy(dec.view(np.int32)).to(dev)
+    d_ok = torch.from_numpy(merge_ok).to(dev)
+    d_nq = torch.from_numpy(nq).to(dev); d_world = torch.from_numpy(world).to(dev)
+    m = Matcher(cap)
+    iq = np.arange(F, dtype=np.uint32)
+    L = _lib.lib()
+
+    def run(mask):
+        d_pairs = torch.full((F, cap, 2), -1, dtype=torch.int32, device=dev); d_np = torch.full((F,), 77, dtype=torch.int32, device=dev)
+        _lib.check(L.hm_landmark_matches_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), None if mask is None else mask.data_ptr(),
+                                                      d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p), cap, F, d_world.data_ptr(), n_world,
+                                                      d_pairs.data_ptr(), d_np.data_ptr(), torch.cuda.current_stream().cuda_stream), "landmark_matches")
+        _lib.check(L.hm_sync(m.handle), "hm_sync")
+        return d_pairs.cpu().numpy().view(np.uint32), d_np.cpu().numpy()
+    gp, gn = run(d_ok)
+    merged = dropped_by_merge = 0
+    for f in range(F):
+        n = int(nq[f])
+        want = oracle.landmark_pairs(best[f, :n], dec[f, :n], world, merge_ok=merge_ok[f, :n], n_world=n_world, merged_base=n_world + f * cap)
+        plain = oracle.landmark_pairs(best[f, :n], dec[f, :n], world[:n_world])
+        assert gn[f] == len(want), (f, gn[f], len(want))
+        assert np.array_equal(gp[f, :gn[f]], want), f
+        assert (gp[f, gn[f]:] == 0xFFFFFFFF).all()
+        merged += int((want[:, 1] >= n_world).sum())
+        dropped_by_merge += len(set(map(int, plain[:, 0])) - set(map(int, want[:, 0])))
+    assert merged > 100 and dropped_by_merge > 50          # both effects of the merges are really exercised
+    g0, n0 = run(torch.zeros_like(d_ok))
+    g1, n1 = run(None)
+    assert np.array_equal(n0, n1) and np.array_equal(g0, g1)
+    m.close()
