@@ -1777,19 +1777,8 @@ __device__ __forceinline__ int ori_sample_entry(float ry, float rx, const float*
 //   with the count, before the barrier — 5.61 / 5.52 ms against 5.45 with the plain count -> permutation -> record chain:
 //   with seven waves per SIMD those round trips are hidden already.  A per-wave LDS segment that is not 8-byte aligned
 //   doubles the kernel's time: the +1 below.)
-#ifndef AKZ_OD_OCC
-#define AKZ_OD_OCC 7
-#endif
-#ifndef AKZ_OD_ABLATE
-#define AKZ_OD_ABLATE 0   // experiment builds (timing only, results wrong): 1 no window sums, 2 no cell sums, 4 no f64 trigonometry, 8 no window membership, 16 no lattice gather, 32 f32 / hardware trigonometry (same angles to ~1e-6)
-#endif
-#ifndef AKZ_OD_MAP
-#define AKZ_OD_MAP 0       // 0: an XCD takes whole frames; 1 (experiment): the eight XCDs share every frame (1 535 against 1 284 us per 64 frames)
-#endif
-#ifndef AKZ_OD_WAVES
-#define AKZ_OD_WAVES 4     // keypoints (waves) per block: 2 / 4 / 8 / 16 measure 1 332 / 1 288 / 1 372 / 1 633 us per 64 frames
-#endif
-constexpr int kODWaves = AKZ_OD_WAVES;
+constexpr int kODWaves = 4;     // keypoints (waves) per block: 2 / 4 / 8 / 16 measure 1 332 / 1 288 / 1 372 / 1 633 us per 64 frames
+constexpr int kODOcc = 7;       // waves per SIMD the register budget is held to
 struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
     float xf, yf, scale;
     const float* LT;
@@ -1797,7 +1786,7 @@ struct ODHead {          // what the kernel needs of one keypoint (wave-uniform)
     int W, Hh;
     uint32_t ki;         // the keypoint's slot in the response-sorted list (where angle, descriptor and flag go)
 };
-__global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
+__global__ __launch_bounds__(64 * kODWaves, kODOcc) void k_orient_describe(LevelTable T, const OriTables* __restrict__ ori_p,
                                                                    const DescTables* __restrict__ desc_p,
                                                                    DevKp* __restrict__ kps,
                                                                    const uint32_t* __restrict__ n_in, uint32_t stride,
@@ -1815,21 +1804,6 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     const DescTables& c_desc = *desc_p;
     if (threadIdx.x < 128) s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
     const uint2* __restrict__ m_tab = c_ori.m_tab;
-#if AKZ_OD_MAP == 1
-    // Every XCD works on the SAME frame, each on its own eighth of the frame's keypoints in visiting order (level, tile row,
-    // tile column): workgroup id -> XCD id % 8 (observed), so id = 8 (frame * per + j) + xcd takes block xcd * chunk + j.
-    const uint32_t orig = blockIdx.x + gridDim.x * blockIdx.y, xcd = orig & 7u, m = orig >> 3, per = gridDim.x >> 3;
-    const int frame = (int)(m / per);
-    const uint32_t jb = m - (uint32_t)frame * per;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const size_t fbase = (size_t)frame * stride;
-    __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
-    const uint32_t n = min(n_in[frame], stride);
-    const uint32_t chunk = ((n + kODWaves - 1) / kODWaves + 7u) >> 3;
-    if (jb >= chunk) return;  // whole block
-    const uint32_t vi = (xcd * chunk + jb) * kODWaves + (uint32_t)wv;
-    if (vi >= n) return;  // whole wave
-#else
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1838,7 +1812,6 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
     const uint32_t n = min(n_in[frame], stride);
     if (vi >= n) return;  // whole wave
-#endif
     const uint32_t ki = perm[fbase + vi];  // spatially coherent visiting order
     const DevKp kp = kps[fbase + ki];
     const bool on1 = lane + 64 < 109;
@@ -1890,13 +1863,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         s_r[lane] = make_float2(rx0, ry0);
         s_r[lane + 64] = make_float2(rx1, ry1);
         // window membership of the samples (:261-287) from the end-point table (see k_refine)
-#if AKZ_OD_ABLATE & 8
-        ent0 = (int)(__float_as_uint(rx0) & 127u) * 8;
-        ent1 = (int)(__float_as_uint(ry1) & 127u) * 8;
-#else
         ent0 = 8 * ori_sample_entry(ry0, rx0, s_bnd, nullptr);       // (as byte offsets into the table)
         ent1 = 8 * ori_sample_entry(ry1, rx1, s_bnd, nullptr);
-#endif
         if (!on1) ent1 = 8 * 256;
     }
     float angle;
@@ -1917,9 +1885,6 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
             const float2 rk = s_r[k];
             return (v2f){rk.x, rk.y};
         };
-#if AKZ_OD_ABLATE & 1
-        sum = (v2f){(float)ent0 + s_r[lane & 63].x, (float)ent1 + 1.0f};
-#else
 #pragma unroll
         for (int k = 0; k + 4 <= 108; k += 4) {
             const unsigned long long m0 = m64(k), m1 = m64(k + 1), m2 = m64(k + 2), m3 = m64(k + 3);
@@ -1942,7 +1907,6 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
                 : [s] "+v"(sum), [sv] "=&s"(saved)
                 : [m0] "s"(m0), [r0] "v"(r0));
         }
-#endif
         const float sum_x = sum.x, sum_y = sum.y;
         const float val = sum_x * sum_x + sum_y * sum_y;
         // the serial loop keeps the FIRST window whose val exceeds every earlier one (a NaN never does).  val >= +0, so
@@ -1961,25 +1925,13 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
         const int win = bal ? __ffsll((long long)bal) - 1 : 0;
         const float best_sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_x), win));
         const float best_sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum_y), win));
-#if AKZ_OD_ABLATE & 4
-        angle = (mbits > 0) ? best_sy * 0.001f + best_sx * 0.002f : 0.0f;
-#elif AKZ_OD_ABLATE & 32
-        angle = (mbits > 0) ? atan2f(best_sy, best_sx) + (best_sy < 0.0f ? 6.2831855f : 0.0f) : 0.0f;   // (nearly the same angle, f32)
-#else
         angle = (mbits > 0) ? fast_atan2_equiv(best_sy, best_sx) : 0.0f;
-#endif
         if (lane == 0) kps[fbase + cur.ki].angle = angle;
     }
     // the segment changes hands: every LDS read above has returned before the writes below are issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- get_mldb_descriptor, descriptors.rs:66-72 (as k_describe_fast) ----
-#if AKZ_OD_ABLATE & 4
-    const float co = 1.0f - 0.5f * angle * angle, si = angle;
-#elif AKZ_OD_ABLATE & 32
-    const float co = __cosf(angle), si = __sinf(angle);                  // (nearly the same values, hardware approximations)
-#else
     const float co = akz_pm_cosf(angle), si = akz_pm_sinf(angle);
-#endif
     const float scale = cur.scale, xf = cur.xf, yf = cur.yf;
     const int W = cur.W, Hh = cur.Hh;
     bool oob = false;
@@ -2014,13 +1966,8 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     float2 dd[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-#if AKZ_OD_ABLATE & 16
-        ri[it] = (float)idx[it];
-        dd[it] = make_float2((float)idx[it] * 0.5f, 1.0f);
-#else
         ri[it] = cur.LT[idx[it]];
         dd[it] = cur.LXY[idx[it]];
-#endif
     }
     const v2f rot_x = {co, -si}, rot_y = {si, co};
 #pragma unroll
@@ -2037,13 +1984,9 @@ __global__ __launch_bounds__(64 * kODWaves, AKZ_OD_OCC) void k_orient_describe(L
     }
     oob = __any(oob);
     if (!oob) {
-#if AKZ_OD_ABLATE & 2
-        const float m2 = s_ri[lane], m3 = s_dx[lane], m4 = s_dy[lane];
-#else
         const float m2 = desc_cell_mean<10, 2>(s_ri, s_dx, s_dy, lane);
         const float m3 = desc_cell_mean<7, 3>(s_ri, s_dx, s_dy, lane);
         const float m4 = desc_cell_mean<5, 4>(s_ri, s_dx, s_dy, lane);
-#endif
         // (a wave's LDS accesses execute in order: the sums above have read the planes before these stores land on them)
         if (lane < 12) s_val[lane] = m2;
         if (lane < 27) s_val[12 + lane] = m3;

@@ -1464,6 +1464,7 @@ __global__ __launch_bounds__(256, 4) void k_fed_pair(const float* __restrict__ s
 // pixels inside the window, as in k_fed_pair: HP halo patches serve T <= 4 HP steps — without the ring (cheaper by
 // 6 %) the conductivity is right on window pixels 1..62 only and HP patches serve T <= 4 HP - 1.
 // Every value is computed by the same expression, in the same order, as in k_level_front2 / k_fed_pair.
+constexpr int kFFWaves = 3;                    // k_front_fed: waves per SIMD the register budget is held to
 constexpr int kFFW = 64;                       // window edge
 constexpr int kFFIn = kFFW + 6;                // input rows: the window, its one-pixel ring, the blur radius 2
 constexpr int kFFInC = kFFW + 8;               // input columns held (4 either side: whole 16-byte chunks)
@@ -1477,37 +1478,6 @@ template <int RS>
 __device__ __forceinline__ int ff_chunk(int row, int ci) { return row * RS + ((ci & 1) ? RS / 2 : 0) + (ci >> 1); }
 template <int RS>
 __device__ __forceinline__ int ff_elem(int row, int col) { return 2 * ff_chunk<RS>(row, col >> 1) + (col & 1); }
-
-// Experiment builds only (-DAKZ_FF_PROF, tools/build_variant.sh; never in the product library): thread 0 of every
-// 8th block of k_front_fed records the shader clock at its phase boundaries, tools/ff_prof.py reads them back.
-#if defined(AKZ_FF_PROF) && AKZ_ARITH != 0
-#undef AKZ_FF_PROF   // (the profiler lives in the default copy only)
-#endif
-#ifdef AKZ_FF_PROF
-constexpr int kFFProfStamps = 12, kFFProfCap = 1 << 16;
-__device__ unsigned long long g_ff_prof[(size_t)kFFProfCap * kFFProfStamps];
-__device__ unsigned int g_ff_prof_n;
-#define FF_STAMP(i)                                                                              \
-    do {                                                                                         \
-        if (ff_slot >= 0 && threadIdx.x == 0) g_ff_prof[(size_t)ff_slot * kFFProfStamps + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-extern "C" int32_t akz_debug_ff_prof(unsigned long long* out, uint32_t cap_blocks, uint32_t* n, int32_t reset)
-{
-    unsigned int cnt = 0;
-    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_ff_prof_n), sizeof(cnt)) != hipSuccess) return AKZ_E_HIP;
-    if (cnt > (unsigned)kFFProfCap) cnt = kFFProfCap;
-    if (cnt > cap_blocks) cnt = cap_blocks;
-    if (out && cnt && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_prof), (size_t)cnt * kFFProfStamps * 8) != hipSuccess) return AKZ_E_HIP;
-    if (n) *n = cnt;
-    if (reset) {
-        unsigned int z = 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ff_prof_n), &z, sizeof(z)) != hipSuccess) return AKZ_E_HIP;
-    }
-    return AKZ_OK;
-}
-#else
-#define FF_STAMP(i) do { } while (0)
-#endif
 
 // the interior input window of k_front_fed (rows wy0 - 3 .., columns wx0 - 4 .., all inside the image) as ITEMS float4 per
 // thread and frame; every load is issued before any is consumed
@@ -1530,17 +1500,8 @@ __device__ __forceinline__ void front_fed_fetch(float4 (&ra)[ITEMS], float4 (&rb
     }
 }
 
-#ifndef AKZ_FF_WAVES
-#define AKZ_FF_WAVES 3
-#endif
-#ifndef AKZ_FUSE_HALF
-#define AKZ_FUSE_HALF 1      // the half-sized start image of an octave from the previous level's last FED launch (0: k_half_size)
-#endif
-#ifndef AKZ_FF_SUMS
-#define AKZ_FF_SUMS 1
-#endif
 template <int SG, int HP, bool RING, bool WRITE_FLOW>
-__global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
+__global__ __launch_bounds__(256, kFFWaves) void k_front_fed(const float* __restrict__ in, int w, int h, size_t fs, int n,
                                                       GaussTaps taps, OffK k, FedTaus taus, int nsteps,
                                                       float* __restrict__ out_lt, float* __restrict__ out_flow,
                                                       float2* __restrict__ out_xy, const float* __restrict__ invk,
@@ -1548,11 +1509,7 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
 {
     // one block of LDS, three lives: input window [kFFIn][kFFInC], blurred window [kFFW + 2][kFFGS] (one apron row
     // above and below), FED exchange buffers
-#ifdef AKZ_FF_PAD_LDS
-    __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC + AKZ_FF_PAD_LDS / 8];   // occupancy experiment
-#else
     __shared__ __attribute__((aligned(16))) v2f s_buf[kFFIn * kFFInC];
-#endif
     static_assert((kFFW + 2) * kFFGS <= kFFIn * kFFInC, "blurred window fits in the input window's space");
     static_assert(3 * 256 * 2 * 2 <= kFFIn * kFFInC, "FED exchange buffers fit");
     constexpr int U = front_fed_tile(HP);
@@ -1564,26 +1521,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
     const int wx0 = (int)tile.x * U - 4 * HP, wy0 = (int)tile.y * U - 4 * HP;   // window origin in the image
     const float* srca = in + (size_t)fa * fs;
     const float* srcb = in + (size_t)fb * fs;
-#ifdef AKZ_FF_PROF
-    __shared__ int ff_slot_s;
-    if (threadIdx.x == 0) {
-        int sl = -1;
-        if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u) == 0) {
-            const unsigned q = atomicAdd(&g_ff_prof_n, 1u);
-            if (q < (unsigned)kFFProfCap) sl = (int)q;
-        }
-        ff_slot_s = sl;
-        if (sl >= 0) {
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            g_ff_prof[(size_t)sl * kFFProfStamps + 11] = ((unsigned long long)xcc << 32) | hwid;
-        }
-    }
-    __syncthreads();
-    const int ff_slot = ff_slot_s;
-#endif
-    FF_STAMP(0);
     // ---- 1a. input window: rows wy0 - 3 .., columns wx0 - 4 .., clamped coordinates outside the image ----
     {
         const bool inside = wx0 >= 4 && wx0 + kFFW + 4 <= w && wy0 >= 3 && wy0 + kFFW + 3 <= h;
@@ -1633,7 +1570,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
         }
     }
     __syncthreads();
-    FF_STAMP(1);
     // ---- 1b. Gaussian blur (sigma 1.0, 5 taps) of the thread's own patch ----
     // Horizontal pass: every window row once — a thread takes the four rows of its own patch, and the four rows the
     // vertical pass needs above and below the window (rows -2, -1, 64, 65) are dealt one pixel per thread; the rows go
@@ -1694,7 +1630,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
         }
     }
     __syncthreads();   // every thread has read its input: the horizontally blurred rows take the space
-    FF_STAMP(2);
     {
         // row Y of the window (-2 .. 65) is row Y + 2 of s_h, 64 columns = 32 chunks in the two-plane layout
         constexpr int HR = kFFW / 2;
@@ -1730,7 +1665,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
             }
     }
     __syncthreads();   // every thread has read its rows: the blurred window takes the space
-    FF_STAMP(3);
     // blurred window: pixel (X, Y) of the window is element (row Y + 1, column X + 2) of s_g
     v2f* s_g = s_buf;
     float4* g4 = reinterpret_cast<float4*>(s_buf);
@@ -1769,7 +1703,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
             }
         __syncthreads();
     }
-    FF_STAMP(4);
     const int x0 = wx0 + 4 * pc, y0 = wy0 + 4 * pr;
     const bool col_in = x0 >= 0 && x0 < w;   // w % 4 == 0: a patch column is entirely inside or outside
     const bool useful = pc >= HP && pc <= 15 - HP && pr >= HP && pr <= 15 - HP && col_in;
@@ -1817,7 +1750,6 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
             }
         }
     }
-    FF_STAMP(5);
     if (WRITE_FLOW && useful) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1884,24 +1816,16 @@ __global__ __launch_bounds__(256, AKZ_FF_WAVES) void k_front_fed(const float* __
             }
         }
     }
-    FF_STAMP(6);
     __syncthreads();   // the blurred window is dead: the exchange buffers take the space
-    FF_STAMP(7);
     float4* s_top = reinterpret_cast<float4*>(s_buf);            // [256 * 2]  [patch][4 px x 2 frames]: top image rows
     float4* s_vd = s_top + 256 * 2;                              // bottom-edge flows
     float4* s_ct = s_vd + 256 * 2;                               // top rows of C
     const int up = pr > 0 ? tid - 16 : tid, dn = pr < 15 ? tid + 16 : tid;   // block-edge patches are halo
-#if AKZ_FF_SUMS
     fed_steps_sums(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
-#else
-    fed_steps(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, x0, y0, w, h);
-#endif
-    FF_STAMP(8);
     if (useful) {
         fed_store_patch(L, out_lt, fa, fb, has_b, fs, w, h, x0, y0);
         if (half_out) fed_store_half(L, half_out, fa, fb, has_b, half_fs, w, h, x0, y0);
     }
-    FF_STAMP(9);
 }
 
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
@@ -2803,13 +2727,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // the level AFTER the next one, which nobody touches until that level's own diffusion.
             float* half_next = nullptr;
             size_t half_next_fs = 0;
-#if AKZ_FUSE_HALF
             if (blocked && nsteps > 0 && i + 2 < nlev && P.levels[i + 1].new_octave && P.levels[i + 1].w == (L.w >> 1) &&
                 P.levels[i + 1].h == (L.h >> 1) && !P.levels[i + 2].new_octave) {
                 half_next = S.Lt[i + 2];
                 half_next_fs = P.levels[i + 1].pixels();
             }
-#endif
             const float* init;
             if (L.new_octave && half_ready == i) {
                 init = S.Lt[i + 1];      // written by the previous level's last FED launch (fed_store_half)

@@ -580,14 +580,8 @@ __global__ __launch_bounds__(kMfmaBlock, 4) void k_knn_mfma4(const HmProbX* __re
 // 128-byte LDS row, and a lane's eight fragments are 128 B apart: immediate offsets.
 constexpr int kGSeg = 1024 + 64;               // bytes of a 4-row group
 constexpr int kGTile = 8 * kGSeg;              // 8 704 B per 32-target tile
-#ifndef AKZ_G_STAGES
-#define AKZ_G_STAGES 3
-#endif
-#ifndef AKZ_G_TPS
-#define AKZ_G_TPS 2
-#endif
-constexpr int kGStages = AKZ_G_STAGES;         // ring of stages (kGStages - 1 of them requested ahead) ...
-constexpr int kGTps = AKZ_G_TPS;               // ... of this many tiles each (even): 3 x 2: 52 224 B per block, two blocks per CU
+constexpr int kGStages = 3;                    // ring of stages (kGStages - 1 of them requested ahead) ...
+constexpr int kGTps = 2;                       // ... of this many tiles each (even): 3 x 2: 52 224 B per block, two blocks per CU
 constexpr int kWideBlock = 256;                // 4 waves x 64 queries
 
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
@@ -606,14 +600,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst)
 // insertions of the previous tile's keys behind every MFMA — four to five VALU instructions in the ~32 cycles before the
 // next MFMA of the other chain can issue.  (sched_group_barrier patterns, which k_knn_mfma4 uses, collapse here: the
 // scheduler put the sixteen MFMAs back to back, one chain after the other, and the epilogue behind them.)
-#ifndef HM_ABLATE
-#define HM_ABLATE 0      // experiment builds only (tools/build_variant.sh): 1 no key epilogue, 2 fragments read once, 4 no DMA / barrier
-#endif
-// one tile for both column blocks: 8 fragments, 16 MFMAs (two interleaved dependent chains), and the key epilogue of
-// the PREVIOUS tile's two accumulator blocks between them.  The order is written out and pinned (sched_barrier): two
-// insertions of the previous tile's keys behind every MFMA — four to five VALU instructions in the ~32 cycles before the
-// next MFMA of the other chain can issue.  (sched_group_barrier patterns, which k_knn_mfma4 uses, collapse here: the
-// scheduler put the sixteen MFMAs back to back, one chain after the other, and the epilogue behind them.)
 // The fragment stream does not stop at the tile's end: f[] arrives holding this tile's fragments 0..3 and leaves
 // holding the NEXT tile's (tn, read behind steps 4..7), so no tile starts by waiting for LDS.  When the next tile
 // belongs to the next stage, `hook` — the wait for that stage, the block's barrier and the next DMA — runs between
@@ -624,7 +610,7 @@ __device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const 
                                             int (&k1)[KNN], Hook hook)
 {
     constexpr int FS = 128 / 16;           // a lane's fragments are 128 B apart
-    constexpr bool EPI = EPI_ && !(HM_ABLATE & 1);
+    constexpr bool EPI = EPI_;
     const v16i32 r0 = __builtin_bit_cast(v16i32, p0), r1 = __builtin_bit_cast(v16i32, p1);
     int l0[KNN], l1[KNN];
 #pragma unroll
@@ -647,12 +633,10 @@ __device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const 
         if (i == 0) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, bias, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
         else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, o1, 4, 4, 0, 0x84848484, 0, 0x7F7F7F7F);
         // four fragments (eight MFMAs) ahead: this tile's 4..7, then the next tile's 0..3
-        if (!(HM_ABLATE & 2)) {
-            // (no branch in here: with control flow inside the chain the MFMAs sink below it and the pinned order is gone —
-            // the last tile re-reads itself)
-            if (i < 4) f[i & 3] = tp[FS * (i + 4)];
-            else f[i & 3] = tn[FS * (i - 4)];
-        }
+        // (no run-time branch in here: with control flow inside the chain the MFMAs sink below it and the pinned order is
+        // gone — the last tile re-reads itself)
+        if (i < 4) f[i & 3] = tp[FS * (i + 4)];
+        else f[i & 3] = tn[FS * (i - 4)];
         if (EPI) topk_insert2<KNN>(l1, r1[2 * i], r1[2 * i + 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -670,12 +654,10 @@ __device__ __forceinline__ void knn_chain4w(const uint4* __restrict__ tp, const 
     }
 }
 
-#ifndef AKZ_G_PP
-#define AKZ_G_PP 1       // 1: two accumulator sets, the previous tile's keys taken inside the next tile's chain (two waves per
-#endif                   //    SIMD); 0 (experiment): one set, the keys taken right behind the chain, three waves per SIMD
-                         //    (168 registers): 3.32 against 2.82 ms per 256 frame pairs
+// Two accumulator sets: the previous tile's keys are taken inside the next tile's chain (two waves per SIMD).  (One set with the
+// keys taken right behind the chain, three waves per SIMD at 168 registers, measured 3.32 against 2.82 ms per 256 frame pairs.)
 template <int KNN>
-__global__ __launch_bounds__(kWideBlock, AKZ_G_PP ? 2 : 3) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
+__global__ __launch_bounds__(kWideBlock, 2) void k_knn_mfma4w(const HmProbX* __restrict__ probs)
 {
     static_assert(kGStages >= 3 && kGTps == 2, "ring shape");
     __shared__ __attribute__((aligned(16))) unsigned char s_t[kGStages * kGTps * kGTile];
@@ -752,11 +734,9 @@ __global__ __launch_bounds__(kWideBlock, AKZ_G_PP ? 2 : 3) void k_knn_mfma4w(con
         // the current stage, whose slot the next request takes.
         uint32_t st = 0;
         auto boundary = [&]() {
-#if !(HM_ABLATE & 4)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kGStages - 2) * kGTps * 2) : "memory");
             asm volatile("s_barrier" ::: "memory");
             issue(st + (uint32_t)kGStages);
-#endif
         };
         auto nothing = [&]() {};
         // stage 0 has landed; the last slot of the ring takes its first request
@@ -772,7 +752,6 @@ __global__ __launch_bounds__(kWideBlock, AKZ_G_PP ? 2 : 3) void k_knn_mfma4w(con
             const uint4* tn = tlane + (size_t)(((st + 1u) % kGStages) * (uint32_t)(kGTps * kGTile)) / 16;
             const bool last_a = t0 + 32u >= nt, last_b = t0 + 64u >= nt;
             // (idle waves skip the arithmetic, not the boundary)
-#if AKZ_G_PP
             if (wave_on) {
                 if (st == 0) knn_chain4w<KNN, false>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, 0u, half, k0, k1, nothing);
                 else knn_chain4w<KNN, true>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a10, a11, t0 - 32u, half, k0, k1, nothing);
@@ -790,21 +769,6 @@ __global__ __launch_bounds__(kWideBlock, AKZ_G_PP ? 2 : 3) void k_knn_mfma4w(con
             if (wave_on) knn_chain4w<KNN, true>(tb, tn, f, qb, bias, a10, a11, a00, a01, t0 - 32u, half, k0, k1, boundary);
             else boundary();
             t0 += 32u;
-#else
-            if (wave_on) knn_chain4w<KNN, false>(ta, last_a ? ta : tb, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, nothing);
-            HM_LAST(a00, a01)
-            if (last_a) break;
-            t0 += 32u;
-            if (last_b) {
-                if (wave_on) knn_chain4w<KNN, false>(tb, tb, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, nothing);
-                HM_LAST(a00, a01)
-                break;
-            }
-            if (wave_on) knn_chain4w<KNN, false>(tb, tn, f, qb, bias, a00, a01, a00, a01, 0u, half, k0, k1, boundary);
-            else boundary();
-            HM_LAST(a00, a01)
-            t0 += 32u;
-#endif
         }
 #undef HM_LAST
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the requests past the end

@@ -2067,7 +2067,7 @@ def test_exchange_code_paths_on_one_rank(gpu, tmp_path, comm, exchange):
                         "--exchange", exchange] + common, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
-    assert "multi_gpu" in line and line["multi_gpu"]["per_rank_frames_per_s"][0] > 0
+    assert "multi_gpu" in line and line["multi_gpu"]["per_rank_frames_per_s_min_max"][0] > 0
     assert np.array_equal(np.load(m1), np.load(m2))
     a, b = np.load(str(m1) + ".r0.npz"), np.load(str(m2) + ".r0.npz")
     for g in range(16):

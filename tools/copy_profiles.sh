@@ -3,6 +3,7 @@
 T=${1:-r03}
 cd "$(dirname "$0")/.."
 cp gpurun_out/refresh/${T}_bench.json profiles/${T}_bench.json
+cp gpurun_out/refresh/${T}_bench_headline.json profiles/${T}_bench_headline.json
 cp gpurun_out/refresh/${T}_bench_profiled.json profiles/${T}_bench_profiled.json
 cp gpurun_out/refresh/${T}_bench_kernel_stats.txt gpurun_out/refresh/${T}_pmc_traffic.json gpurun_out/refresh/${T}_pmc_fetch_size.txt gpurun_out/refresh/${T}_pmc_write_size.txt profiles/
 cp gpurun_out/pmc_sq_summary.txt profiles/${T}_pmc_sq_summary.txt

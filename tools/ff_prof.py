@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of k_front_fed from an experiment build (-DAKZ_FF_PROF, tools/build_variant.sh): where a block's
+"""Phase timeline of k_front_fed from an experiment build (tools/variants/experiment_knobs.patch applied, -DAKZ_FF_PROF, tools/build_variant.sh): where a block's
 lifetime goes, and how many blocks of a CU are in the same phase at the same time.
 usage (GPU box): cp gpurun_variants/prof/libakz.so cv_amd/lib/libakz.so; python tools/ff_prof.py [frames]"""
 import ctypes as C

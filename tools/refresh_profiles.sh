@@ -23,12 +23,13 @@ python tools/pmc_traffic.py $O/pmc_fetch/${T}_results.db $O/pmc_write/${T}_resul
 cp $O/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json   # bench.py reads it for roofline.traffic / valu_frac
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/trace -o $T -- python $R/bench.py --steps 30 --warmup 2 --no-isolated --no-extras --no-cpu-baseline > $O/trace.log 2> $O/trace.err
-grep '^{' $O/trace.log | tail -1 > $O/${T}_bench_profiled.json
+cp $R/gpurun_out/bench_detail.json $O/${T}_bench_profiled.json       # the full report of that run (stdout carries the < 4 KB headline only)
 cd $R
 python tools/rocpd_pmc.py $O/pmc_fetch/${T}_results.db $O/${T}_pmc_fetch_size.txt > /dev/null
 python tools/rocpd_pmc.py $O/pmc_write/${T}_results.db $O/${T}_pmc_write_size.txt > /dev/null
 python tools/rocpd_stats.py $O/trace/${T}_results.db $O/${T}_bench_kernel_stats.txt > /dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.log 2> $O/bench.err   # the command the driver runs
-grep '^{' $O/bench.log | tail -1 > $O/${T}_bench.json
+cp $R/gpurun_out/bench_detail.json $O/${T}_bench.json                # the full report ...
+grep '^{' $O/bench.log | tail -1 > $O/${T}_bench_headline.json    # ... and the line the driver parses
 tail -c 1500 $O/bench.log
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/trace   # raw databases are large: only the summaries travel back
