@@ -157,6 +157,7 @@ def main():
                     "the defaults are what the headline is quoted on)")
     ap.add_argument("--max-features", type=int, default=0, help="A/B: Akaze.maximum_features (0 = the reference's default, unlimited)")
     ap.add_argument("--matcher-low-priority", action="store_true", help="A/B: matcher stream at the lowest priority")
+    ap.add_argument("--matcher-cus", type=int, default=0, help="A/B: matcher stream on the last N compute units of every XCD (0 = all)")
     ap.add_argument("--no-extras", action="store_true", help="skip configs_extra (BASELINE configs[2] and [3], pipeline+verify)")
     ap.add_argument("--verify-steps", type=int, default=4, help="timed steps of the pipeline+verify leg (extract + match + "
                     "two-view ARRSAC of every frame pair, device-resident); 0 = skip")
@@ -245,7 +246,7 @@ def main():
     if args.no_pipeline:
         okw["pipeline"] = False
     ctx = ak.context(W, H, MB, options=_lib.make_options(**okw) if okw else None)
-    matcher = Matcher(CAP, device=local_rank, low_priority=args.matcher_low_priority)
+    matcher = Matcher(CAP, device=local_rank, low_priority=args.matcher_low_priority, cus=args.matcher_cus)
     akz_stream = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
     hm_stream = torch.cuda.ExternalStream(L.hm_stream(matcher.handle), device=dev)
 

@@ -44,7 +44,8 @@ class Options(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32), ("fed_block", C.c_uint32),
         ("sup_capacity", C.c_uint32), ("max_candidates", C.c_uint32), ("desc_tile_shift", C.c_uint32),
-        ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("arith", C.c_uint32), ("reserved", C.c_uint32 * 7),
+        ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("arith", C.c_uint32), ("cu_ss", C.c_uint32),
+        ("cu_kp", C.c_uint32), ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -61,7 +62,7 @@ BOOL_OPTIONS = ("keep_all", "frame_pairs", "parallel_suppression", "pipeline", "
 
 def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=True,
                  contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0, stream_kernels=True,
-                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True, arith=0):
+                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True, arith=0, cu_ss=0, cu_kp=0):
     """Options with readable names.  contrast: "fine" (default), "exact", "force_odd".  arith: AKZ_ARITH_* bits (1: pairwise
     reduce_add, 2: fused mul_add, 4: sequential 2 x 2 sum) — the one option that changes results (include/akz.h)."""
     o = Options()
@@ -74,6 +75,7 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
     o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift
     o.stream_waves, o.stream_min_waves = stream_waves, stream_min_waves
     o.arith = arith
+    o.cu_ss, o.cu_kp = cu_ss, cu_kp
     return o
 
 

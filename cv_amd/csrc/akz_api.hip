@@ -163,6 +163,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             // (zero) — anything else would be dropped silently
             for (uint32_t i = (uint32_t)sizeof(o); i < opts->struct_size; ++i)
                 if (reinterpret_cast<const unsigned char*>(opts)[i]) return AKZ_E_INVALID;
+            if (o.cu_ss > 32 || o.cu_kp > 32) return AKZ_E_INVALID;
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
             if (o.flags & ~((AKZ_OPT_EQUAL_PRIORITY << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
@@ -225,10 +226,17 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         int prio_lo = 0, prio_hi = 0;
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // lo = numerically greatest = least urgent
         const bool use_prio = !(o.flags & AKZ_OPT_EQUAL_PRIORITY);
-        if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
-        if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
-            st = AKZ_E_HIP;
-        if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_det, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess)
+        if (o.cu_ss) {
+            if (akz_stream_on_cus(&c->stream, 0, (int)o.cu_ss) != hipSuccess) st = AKZ_E_HIP;
+            if (st == AKZ_OK && akz_stream_on_cus(&c->stream_det, 0, (int)o.cu_ss) != hipSuccess) st = AKZ_E_HIP;
+        } else {
+            if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess) st = AKZ_E_HIP;
+            if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_det, hipStreamNonBlocking, use_prio ? prio_hi : 0) != hipSuccess)
+                st = AKZ_E_HIP;
+        }
+        if (st == AKZ_OK && o.cu_kp) {
+            if (akz_stream_on_cus(&c->stream_kp, 32 - (int)o.cu_kp, (int)o.cu_kp) != hipSuccess) st = AKZ_E_HIP;
+        } else if (st == AKZ_OK && hipStreamCreateWithPriority(&c->stream_kp, hipStreamNonBlocking, use_prio ? prio_lo : 0) != hipSuccess)
             st = AKZ_E_HIP;
         if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_input, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;
         if (st == AKZ_OK && hipEventCreateWithFlags(&c->ev_det_done, hipEventDisableTiming) != hipSuccess) st = AKZ_E_HIP;

@@ -31,6 +31,16 @@ extern thread_local int g_akz_last_hip;
 // Slots per frame in every per-(frame, level) table (candidate counts and lists, the keypoint kernels' level
 // table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
 constexpr int kAkzMaxLevels = 32;
+// A stream restricted to compute units [first, first + count) of EVERY XCD (MI355X: 8 XCDs x 32 CUs; bit n of the mask is
+// CU n / 8 of XCD n % 8 — the driver deals the mask's bits round-robin over the XCDs, so workgroup b still lands on XCD b % 8).
+// hipExtStreamCreateWithCUMask takes neither flags nor a priority.
+inline hipError_t akz_stream_on_cus(hipStream_t* s, int first, int count)
+{
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = first; c < first + count && c < 32; ++c)
+        for (int x = 0; x < 8; ++x) mask[(c * 8 + x) >> 5] |= 1u << ((c * 8 + x) & 31);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
 // Largest frame a context accepts, in pixels: the diffusion / determinant kernels address a frame's planes with 32-bit BYTE
 // offsets (at_bytes in akz_scale_space.hip), the widest being the 8-byte {Lx, Ly} plane: pixels * 8 must stay below 2^32.
 // 2^28 pixels (16384 x 16384) leaves a factor of two; akz_create_ex refuses more with AKZ_E_TOO_LARGE.

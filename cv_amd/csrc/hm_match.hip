@@ -954,7 +954,7 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
     return akz_guard([&]() -> int32_t {
         // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
         if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
-        if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY | HM_OPT_NO_LDS_DMA)) return AKZ_E_INVALID;   // unknown switches
+        if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY | HM_OPT_NO_LDS_DMA | HM_OPT_CU_MASK)) return AKZ_E_INVALID;   // unknown switches
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
         AKZ_HIP(hipSetDevice(device));
@@ -968,7 +968,10 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
             int prio_lo = 0, prio_hi = 0;
             hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             // HM_OPT_STREAM_PRIORITY: the matcher as least-urgent filler work that yields to the scale-space stream
-            AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (flags & HM_OPT_STREAM_PRIORITY) ? prio_lo : 0));
+            const int cus = (int)((flags & HM_OPT_CU_MASK) >> HM_OPT_CU_SHIFT);
+            if (cus > 32) return AKZ_E_INVALID;
+            if (cus) AKZ_HIP(akz_stream_on_cus(&c->stream, 32 - cus, cus));
+            else AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (flags & HM_OPT_STREAM_PRIORITY) ? prio_lo : 0));
         }
         AKZ_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
         c->use_mfma = !(flags & HM_OPT_NO_MFMA);

@@ -32,14 +32,16 @@ class Neighbor:
 class Matcher:
     """Owns one hm_ctx."""
 
-    def __init__(self, max_descriptors=16384, device=0, kernel="fp4", low_priority=False):
+    def __init__(self, max_descriptors=16384, device=0, kernel="fp4", low_priority=False, cus=0):
         """kernel: "fp4" (default, FP4 MFMA, target tiles by LDS-DMA), "fp4_regs" (the same with a register stage), "int8"
         (int8 MFMA) or "valu" (xor/popcount, k = 2 only).
-        low_priority: the matcher's stream as least-urgent filler work (HM_OPT_STREAM_PRIORITY)."""
+        low_priority: the matcher's stream as least-urgent filler work (HM_OPT_STREAM_PRIORITY).
+        cus: the matcher's stream on the last `cus` compute units of every XCD (0 = the whole chip)."""
         self._h = C.c_void_p()
         self.cap = max_descriptors
         flags = {"fp4": 0, "fp4_regs": _lib.HM_OPT_NO_LDS_DMA, "int8": _lib.HM_OPT_NO_FP4, "valu": _lib.HM_OPT_NO_MFMA}[kernel]
         flags |= _lib.HM_OPT_STREAM_PRIORITY if low_priority else 0
+        flags |= (int(cus) & 0x3F) << 16
         check(_lib.lib().hm_create_ex(device, max_descriptors, max_descriptors, flags, C.byref(self._h)), "hm_create_ex")
 
     def close(self):

@@ -119,7 +119,9 @@ typedef struct akz_options {
     uint32_t stream_waves;    /* waves a row-streaming launch aims for (sets its row-segment length); 0 = default (8192) */
     uint32_t stream_min_waves; /* launches that cannot field this many streaming waves take the tile kernel; 0 = default (2048) */
     uint32_t arith;           /* AKZ_ARITH_* bits: which of the reference's un-vendored arithmetic orders the filters use; 0 = default */
-    uint32_t reserved[7];     /* must be zero */
+    uint32_t cu_ss;           /* CU partitioning (hipExtStreamCreateWithCUMask), 0 = none: the scale-space and determinant streams run on the */
+    uint32_t cu_kp;           /* FIRST cu_ss compute units of every XCD, the keypoint stream on the LAST cu_kp (1..32 each; measured: DESIGN.md 5) */
+    uint32_t reserved[5];     /* must be zero */
 } akz_options;
 /* akz_options.arith — the only option that CHANGES RESULTS.  Three pieces of the reference's arithmetic live in crates that
  * are not vendored in rust-cv/cv, and its known answers (399 / 343 descriptors, 11 matches) come out the same under all
@@ -265,7 +267,8 @@ int32_t hm_create(int32_t device, uint32_t max_queries, uint32_t max_targets, hm
 /* hm_create with kernel-selection flags (0 = defaults): the k-NN kernel is the FP4 MFMA one (64 resident queries per
  * wave, target tiles by LDS-DMA) unless a flag selects its register-staged predecessor (HM_OPT_NO_LDS_DMA), the int8
  * MFMA or the xor/popcount VALU kernel (k = 2 only); all four are bit-identical. */
-enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2, HM_OPT_NO_LDS_DMA = 1u << 3 };
+enum { HM_OPT_NO_FP4 = 1u << 0, HM_OPT_NO_MFMA = 1u << 1, HM_OPT_STREAM_PRIORITY = 1u << 2, HM_OPT_NO_LDS_DMA = 1u << 3,
+       HM_OPT_CU_SHIFT = 16, HM_OPT_CU_MASK = 0x3Fu << 16 /* bits 16..21: the matcher's stream on the LAST n compute units of every XCD (0 = all) */ };
 int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t max_targets, uint32_t flags, hm_ctx** out);
 int32_t hm_destroy(hm_ctx* ctx);
 /* LinearKnn::knn(q, 2) for every query (akaze/tests/estimate_pose.rs:82-88): out[2*i+0/1] are the
