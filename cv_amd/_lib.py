@@ -121,7 +121,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "
 NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
 assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 
-ABI_VERSION = 5          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
+ABI_VERSION = 6          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
 
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -129,7 +129,7 @@ ABI_SYMBOLS = [
     "akz_extract_gray_f32", "akz_extract_color",
     "akz_extract_batch", "akz_extract_batch_device", "akz_sync", "akz_stream", "akz_scale_space_device",
     "akz_last_overflow", "akz_num_levels", "akz_level", "akz_fed_tau", "akz_debug_get_level", "akz_debug_get_contrast",
-    "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_debug_orientation_masks", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
+    "akz_debug_get_keypoints", "akz_debug_portable_math", "akz_debug_orientation_masks", "akz_debug_rcp_error", "akz_gaussian_kernel", "akz_horizontal_filter", "akz_vertical_filter",
     "akz_half_size", "akz_sample_colors_rgb8", "hm_create", "hm_create_ex", "hm_destroy", "hm_knn2", "hm_knn", "hm_knn_views_device", "hm_knn_batch_device", "hm_best_of_views_device", "hm_best_of_views_batch_device", "hm_match",
     "hm_match_batch_device", "hm_sync", "hm_hash_bag", "hm_hash_bag_device", "hm_hash_knn", "hm_timing_enable",
     "hm_timing_get",
@@ -168,6 +168,7 @@ def lib():
     L.akz_last_hip_error_string.restype = C.c_char_p
     L.akz_version.restype = C.c_char_p
     L.akz_abi_version.restype = C.c_uint32
+    L.akz_debug_rcp_error.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.hm_targets_generation.restype = C.c_uint64
     L.hm_targets_generation.argtypes = [C.c_void_p]
     if L.akz_abi_version() != ABI_VERSION:

@@ -1707,10 +1707,14 @@ __device__ __forceinline__ int ori_rank(const float* s_bnd, float ang)
 
 // The angle of compute_main_orientation (scale_space_extrema.rs:242) is only ever COMPARED with the windows' end points,
 // and evaluating it exactly (akz_pm_atan2f: f64, two divisions) for 109 samples per keypoint was a quarter of the
-// kernel's instructions.  So: an f32 estimate (one v_rcp_f32, a degree-15 odd polynomial; within 7.2e-7 of the exact
-// value over 4 M random and adversarial inputs, tools/fit_atan.py) places the sample among the end points, and whenever
-// the estimate lies within kOriEps = 8e-6 (11 x that error) of an end point — or the operands are outside the range the
-// estimate is good for, or anything is NaN — the exact expression decides instead.  Both 0 and 2 pi are end points, so the
+// kernel's instructions.  So: an f32 estimate (one v_rcp_f32, a degree-15 odd polynomial, tools/fit_atan.py) places the
+// sample among the end points, and whenever the estimate lies within kOriEps = 8e-6 of an end point — or the operands are
+// outside the range the estimate is good for, or anything is NaN — the exact expression decides instead.  The band is
+// PROVEN wide enough, not sampled: |estimate - exact expression| <= 1.84e-6 for every admitted input
+// (tools/ubench/atan_bound.c: the polynomial against atan over every f32 argument by exhaustion, 1.63e-7; v_rcp_f32's 1 ulp
+// and the product's rounding, 1.8e-7; the three reflections' constants and roundings, 7.2e-7; the f32 roundings of the
+// exact expression itself, 7.7e-7; tests/test_oracle_math.py runs it on the coefficients of THIS file, and the -m gpu
+// suite checks the reciprocal's ulp on the device for every operand the path admits).  Both 0 and 2 pi are end points, so the
 // wrap of rem_euclid is covered by the same band.  (0, +x): exactly 0 in the reference, and common (flat areas, vertical
 // edges): taken without the fallback.  Returns the membership bits (bit = window).
 constexpr float kOriEps = 8e-6f;
@@ -2332,6 +2336,49 @@ extern "C" int32_t akz_debug_portable_math(akz_ctx* c, int32_t which, const floa
         AKZ_HIP(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
         hipFree(dx); hipFree(dy); hipFree(dout);
         return AKZ_OK;
+    });
+}
+
+// ---- the specification the angle estimate's error bound leans on, checked on the part itself ----
+// v_rcp_f32 is specified to 1 ulp; tools/ubench/atan_bound.c (the bound behind kOriEps) uses exactly that.  This walks every
+// f32 of [lo_bits, hi_bits] (bit patterns of positive floats), compares the instruction with 1 / x in f64 and returns the
+// largest error in ulps of the correctly rounded quotient.
+__global__ __launch_bounds__(256) void k_debug_rcp_error(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* __restrict__ worst)
+{
+    double w = 0.0;
+    const unsigned long long total = (unsigned long long)hi_bits - lo_bits + 1ull, stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < total; i += stride) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        const double exact = 1.0 / (double)x;
+        const float r = __builtin_amdgcn_rcpf(x);
+        int e;
+        (void)frexp(exact, &e);                                   // exact = m 2^e, m in [0.5, 1): ulp of its f32 = 2^(e - 24)
+        const double err = fabs((double)r - exact) * ldexp(1.0, 24 - e);
+        w = err > w ? err : w;
+    }
+    // non-negative doubles order like their bit patterns
+    atomicMax(worst, (unsigned long long)__double_as_longlong(w));
+}
+
+extern "C" int32_t akz_debug_rcp_error(akz_ctx* c, uint32_t lo_bits, uint32_t hi_bits, double* max_ulps)
+{
+    return akz_guard([&]() -> int32_t {
+        if (!c || !max_ulps || lo_bits > hi_bits || hi_bits >= 0x7F800000u || lo_bits < 0x00800000u) return AKZ_E_INVALID;
+        AKZ_HIP(hipSetDevice(c->device));
+        unsigned long long* d = nullptr;
+        AKZ_HIP(hipMalloc(&d, sizeof(*d)));
+        int32_t rc = AKZ_OK;
+        unsigned long long bits = 0;
+        if (hipMemsetAsync(d, 0, sizeof(*d), c->stream) != hipSuccess) rc = AKZ_E_HIP;
+        if (rc == AKZ_OK) {
+            hipLaunchKernelGGL(k_debug_rcp_error, dim3(4096), dim3(256), 0, c->stream, lo_bits, hi_bits, d);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+                hipMemcpy(&bits, d, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = AKZ_E_HIP;
+        }
+        (void)hipFree(d);
+        if (rc == AKZ_OK) memcpy(max_ulps, &bits, sizeof(bits));
+        return rc;
     });
 }
 

@@ -241,6 +241,11 @@ int32_t akz_debug_portable_math(akz_ctx* ctx, int32_t which, const float* x, con
  * ulp, axes, zeros, denormals and huge operands.  Host buffers. */
 int32_t akz_debug_orientation_masks(akz_ctx* ctx, const float* x, const float* y, uint32_t n, uint64_t* fast, uint64_t* exact,
                                     uint32_t* fell_back);
+/* The error BOUND of that estimate (tools/ubench/atan_bound.c, tests/test_oracle_math.py: 1.84e-6 in total against the band
+ * of 8e-6) takes one thing from the instruction set's specification: v_rcp_f32 is accurate to 1 ulp.  This checks it on the
+ * device in use: the instruction against 1 / x in f64 for EVERY f32 whose bit pattern lies in [lo_bits, hi_bits] (positive
+ * normal numbers); *max_ulps = the largest error in ulps of the correctly rounded quotient. */
+int32_t akz_debug_rcp_error(akz_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, double* max_ulps);
 
 /* ---- stand-alone image ops (akaze::image public API, akaze/src/image.rs:202-389) ---- */
 /* gaussian_kernel(r, kernel_size) — image.rs:360-374.  Host-only scalar math. */
@@ -593,7 +598,7 @@ const char* akz_version(void);
 /* The ABI number: raised whenever a declared signature, struct layout or enum value of this header changes (additions
  * included).  A binding compares akz_abi_version() of the library it loaded with the AKZ_ABI_VERSION it was written against
  * and refuses to run on a mismatch (cv_amd/_lib.py, rust/akaze-mi355x/src/lib.rs, include/akaze.hpp do). */
-#define AKZ_ABI_VERSION 5u
+#define AKZ_ABI_VERSION 6u
 uint32_t akz_abi_version(void);
 
 /* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Kernel families (every id but the

@@ -1940,6 +1940,22 @@ def test_device_transcendentals_against_the_host_libm(gpu, oracle):
     _eq(si, os_, "device sinf"); _eq(co, oc_, "device cosf")
 
 
+def test_v_rcp_f32_meets_its_specification_on_this_device(gpu):
+    """The error bound of the orientation kernel's angle estimate (tests/test_oracle_math.py, tools/ubench/atan_bound.c) takes
+    v_rcp_f32's accuracy — 1 ulp — from the instruction set's specification.  Checked here on the device itself, against 1 / x
+    in f64, for EVERY f32 of [1e-30, 1e30] (the operand range ori_sample_entry admits to the estimate path): 1.67 G values."""
+    import ctypes as C
+    akaze, _ = gpu
+    from cv_amd import _lib
+    ctx = akaze.Akaze.default().context(64, 64, 1)
+    lo = int(np.float32(1e-30).view(np.uint32)) - 1
+    hi = int(np.float32(1e30).view(np.uint32)) + 1
+    worst = C.c_double(-1.0)
+    _lib.check(_lib.lib().akz_debug_rcp_error(ctx.handle, lo, hi, C.byref(worst)), "akz_debug_rcp_error")
+    assert 0.0 < worst.value <= 1.0, worst.value
+    assert _lib.lib().akz_debug_rcp_error(ctx.handle, 0, hi, C.byref(worst)) == -1          # denormals are not part of the claim
+
+
 def test_orientation_window_membership_estimate_equals_the_exact_expression(gpu, oracle):
     """k_orient_describe places every orientation sample among the windows' end points from an f32 ESTIMATE of the angle and
     evaluates the exact expression (akz_portable_math.h, f64) only when the estimate lies within 8e-6 of an end point

@@ -157,3 +157,31 @@ def test_top3_insertion_in_three_operations():
     med = lambda a, b, c: np.sort(np.stack([a, b, c], 1), axis=1)[:, 1]
     got = np.stack([np.minimum(l0, x), med(l0, l1, x), med(l1, l2, x)], 1)
     assert (got == want).all()
+
+
+def test_orientation_angle_estimate_error_bound(tmp_path):
+    """The window membership of k_orient_describe comes from an f32 ESTIMATE of the angle wherever the estimate is further
+    than kOriEps from every end point (cv_amd/csrc/akz_keypoints.hip: ori_sample_entry).  That is safe iff
+    |estimate - exact expression| < kOriEps for EVERY input the estimate path accepts.  tools/ubench/atan_bound.c proves it:
+    the polynomial against atan over every f32 argument of [2^-13, 1] with correctly rounded f32 operations (the rest bounded
+    analytically), v_rcp_f32's specified 1 ulp, the three reflections' constants and roundings, and the f32 roundings of the
+    exact expression it is compared with.  The coefficients and the band are read from the kernel source, so the proof is
+    of the code that ships; the total must stay below a quarter of the band."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "cv_amd", "csrc", "akz_keypoints.hip")).read()
+    body = src[src.index("__device__ __forceinline__ int ori_sample_entry("):]
+    body = body[:body.index("float a = t * p;")]
+    first = re.search(r"float p = (-?[0-9.e-]+)f;", body).group(1)
+    rest = re.findall(r"p = __builtin_fmaf\(p, s, (-?[0-9.e-]+)f\);", body)
+    assert len(rest) == 7
+    eps = re.search(r"constexpr float kOriEps = ([0-9.e-]+)f;", src).group(1)
+    exe = str(tmp_path / "atan_bound")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", os.path.join(root, "tools", "ubench", "atan_bound.c"),
+                           "-o", exe, "-lm"])
+    r = subprocess.run([exe, first] + rest + [eps], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"TOTAL ([0-9.e+-]+)\s+kOriEps ([0-9.e+-]+)\s+ratio ([0-9.]+)", r.stdout)
+    assert m and float(m.group(1)) < 2.0e-6 and float(m.group(3)) >= 4.0, r.stdout
