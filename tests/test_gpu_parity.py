@@ -1789,7 +1789,8 @@ def test_unknown_option_bits_are_refused(gpu):
     o.flags = 1 << 20
     h = C.c_void_p()
     assert _lib.lib().akz_create_ex(C.byref(cfg), 0, 64, 64, 1, 0, C.byref(o), C.byref(h)) == -1
-    assert _lib.lib().hm_create_ex(0, 64, 64, 1 << 20, C.byref(h)) == -1
+    assert _lib.lib().hm_create_ex(0, 64, 64, 1 << 24, C.byref(h)) == -1
+    assert _lib.lib().hm_create_ex(0, 64, 64, 33 << 16, C.byref(h)) == -1      # (bits 16..21: CUs per XCD for the stream, at most 32)
 
 
 def test_mirrored_pose_pairs_share_one_eigen_decomposition(gpu, oracle):
