@@ -48,7 +48,7 @@ W, H = 1920, 1080
 FRAMES_PER_STEP = 256
 CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r04"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
+PROFILE_TAG = "r05"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
 PROFILE_TAG_RANSAC = "r04"   # profiles/<tag>_pmc_ransac.json (tools/pmc_ransac.sh)
 FED_BYTES_PER_PIXEL_STEP = 12.0
 CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage
@@ -830,8 +830,9 @@ def gather_model(ctx, kps_frames, counts):
     oi, oj = ii[m].astype(np.float32), jj[m].astype(np.float32)
     kk, ll = np.meshgrid(np.arange(-10, 11), np.arange(-10, 11), indexing="ij")
     kk, ll = kk.reshape(-1).astype(np.float32), ll.reshape(-1).astype(np.float32)
-    s32 = l128 = fr32 = 0.0
+    s32 = l128 = fr32 = fr128 = 0.0
     nkp = 0
+    tile_hist = np.zeros(6, np.int64)      # 32-px tiles of a level holding 1, 2, 3-4, 5-8, 9-16, > 16 keypoints
 
     def distinct(a):
         a = np.sort(a, axis=1)
@@ -856,14 +857,25 @@ def gather_model(ctx, kps_frames, counts):
         l128 += 128.0 * float(distinct(pix_xy // 16).sum() + distinct(pix_lt // 32).sum())
         lvl = cls[:, None] * (1 << 40)
         fr32 += 32.0 * float(len(np.unique((pix_xy // 4 + lvl).reshape(-1))) + len(np.unique((pix_lt // 8 + lvl).reshape(-1))))
+        fr128 += 128.0 * float(len(np.unique((pix_xy // 16 + lvl).reshape(-1))) + len(np.unique((pix_lt // 32 + lvl).reshape(-1))))
+        # how many keypoints share a 32-px tile of their level (what staging a tile's patch in LDS could amortise over)
+        tkey = cls * (1 << 40) + (np.round(yf).astype(np.int64) >> 5) * 4096 + (np.round(xf).astype(np.int64) >> 5)
+        _, per_tile = np.unique(tkey, return_counts=True)
+        tile_hist += np.bincount(np.searchsorted([1, 2, 4, 8, 16], per_tile, side="left"), minlength=6)[:6]
         nkp += len(kp)
     nf = max(1, len(kps_frames))
     return {"sector_bytes_per_frame": s32 / nf, "line_bytes_per_frame": l128 / nf, "frame_distinct_sector_bytes": fr32 / nf,
+            "frame_distinct_line_bytes": fr128 / nf,
+            "keypoints_per_32px_tile_histogram": {"1": int(tile_hist[0]), "2": int(tile_hist[1]), "3-4": int(tile_hist[2]), "5-8": int(tile_hist[3]),
+                                                  "9-16": int(tile_hist[4]), ">16": int(tile_hist[5]), "frames": len(kps_frames)},
             "keypoints_per_frame": nkp / nf, "frames_sampled": len(kps_frames),
             "what": "32-byte sectors of the {Lx,Ly} (8 B/px) and Lt (4 B/px) planes touched by the 109 orientation samples and the "
                     "21 x 21 descriptor lattice, distinct per keypoint, from this run's own keypoints; line_bytes = the same at the "
                     "128-byte granularity the memory side fetches (profiles/r04_fetch_calibration.txt: every read request is 128 B); "
-                    "frame_distinct = distinct sectors of the whole frame (perfect re-use between keypoints)"}
+                    "frame_distinct = distinct sectors of the whole frame (perfect re-use between keypoints); "
+                    "frame_distinct_line_bytes = the same in 128-byte lines: what HBM must deliver at the granularity the memory "
+                    "side fetches (the PMC traffic is to be read against THIS: the gap to the sector figure is line granularity, not "
+                    "re-fetching)"}
 
 
 def roofline_entries(fam_pipe, fam_iso, mb, steps, gather=None, iso_steps=3):
@@ -901,12 +913,15 @@ def roofline_entries(fam_pipe, fam_iso, mb, steps, gather=None, iso_steps=3):
             e["byte_model"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in model.items()}
             e["sector_demand_frac"] = round(units * model["sector_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             e["line_demand_frac"] = round(units * model["line_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            e["distinct_line_bytes_per_launch"] = round(units * model["frame_distinct_line_bytes"] / launches)
             e["frac_is"] = ("distinct 32-byte sectors the frame's keypoints touch (each once) / kernel time / 8 TB/s; sector_demand_frac / "
                             "line_demand_frac = the same with every keypoint's sectors / 128-byte lines counted on their own (what the "
                             "caches are asked for, not what HBM must deliver: they can exceed 1)")
         if pmc and key in pmc["kernels"]:
             k = pmc["kernels"][key]
             e["traffic"] = round(k["hbm_bytes_per_launch"])
+            if model:
+                e["traffic_over_distinct_lines"] = round(e["traffic"] / max(1, e["distinct_line_bytes_per_launch"]), 3)
             e["traffic_source"] = {"file": pmc["file"], "micro_batch": pmc["micro_batch"], "launches_counted": k["launches"]}
             if k.get("valu_insts_per_launch"):
                 lane_ops = k["valu_insts_per_launch"] * 64.0 / (ms * 1e-3 / launches) / 1e12

@@ -139,13 +139,13 @@ def test_gaussian_kernel_host_entry(lib):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r04_bench.json is the JSON line bench.py printed on the MI355X: the driver's keys, the roofline object
+    """profiles/r05_bench.json is the JSON line bench.py printed on the MI355X: the driver's keys, the roofline object
     of the run's dominant kernel family (its own roofline fraction, so <= 1), the same for the top five, the parity
     check against the oracle, the extra BASELINE configs and the bounded CPU baseline must all be there."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r04_bench.json")) as f:
+    with open(os.path.join(root, "profiles", "r05_bench.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_top", "cpu_baseline", "parity_checked",
@@ -195,7 +195,7 @@ def test_headline_is_compact_and_parseable():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    with open(os.path.join(root, "profiles", "r04_bench.json")) as f:
+    with open(os.path.join(root, "profiles", "r05_bench.json")) as f:
         full = json.loads(f.read().strip().splitlines()[-1])
     line = bench.headline(full, "gpurun_out/bench_detail.json")
     assert len(line) < 4096 and "\n" not in line
@@ -212,6 +212,10 @@ def test_headline_is_compact_and_parseable():
     assert h["cpu_baseline"]["value"] > 0 and h["cpu_baseline"]["kind"] in ("port", "reference") and h["cpu_baseline"]["cores"] >= 1
     assert h["parity"]["mismatches"] == 0 and h["parity"]["frames"] >= 2
     assert set(h["extras"]) >= {"configs[2]", "configs[3]", "pipeline+verify", "pipeline+register"}
+    # the line the run itself printed (what the driver parses) is the same construction
+    with open(os.path.join(root, "profiles", "r05_bench_headline.json")) as f:
+        printed = f.read().strip()
+    assert len(printed) < 4096 and json.loads(printed)["value"] == full["value"] and json.loads(printed)["roofline"]["frac"] == r["frac"]
     # a report stuffed far beyond anything real still yields a line under the limit (optional objects are shed first)
     fat = dict(full)
     fat["config"] = dict(full["config"], workload="x" * 6000)
@@ -266,8 +270,8 @@ def test_pixel_normalisation_shortcut_is_exact():
 
 
 def test_profiled_line_agrees_with_the_committed_rocprof_statistics():
-    """profiles/r04_bench_profiled.json is the line `bench.py --steps 30 ...` printed UNDER rocprofv3 --kernel-trace, and
-    profiles/r04_bench_kernel_stats.txt the per-kernel statistics of that very trace (tools/refresh_profiles.sh).  A family's
+    """profiles/r05_bench_profiled.json is the line `bench.py --steps 30 ...` printed UNDER rocprofv3 --kernel-trace, and
+    profiles/r05_bench_kernel_stats.txt the per-kernel statistics of that very trace (tools/refresh_profiles.sh).  A family's
     `avg_launch_us` in the line (the launches' own start / stop events over the 30 timed steps) and the trace's average
     duration of the same kernel (all 34 launches of the process: warm-up and the instrumented pass included) are the same
     measurement taken twice: they must agree to within a few per cent, family by family."""
@@ -275,10 +279,10 @@ def test_profiled_line_agrees_with_the_committed_rocprof_statistics():
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r04_bench_profiled.json")) as f:
+    with open(os.path.join(root, "profiles", "r05_bench_profiled.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     stats = {}
-    with open(os.path.join(root, "profiles", "r04_bench_kernel_stats.txt")) as f:
+    with open(os.path.join(root, "profiles", "r05_bench_kernel_stats.txt")) as f:
         for line in f.read().splitlines()[1:]:
             m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
             if m:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies the summaries a tools/validate_job.sh run merged into gpurun_out/ to profiles/ (tracked)
-T=${1:-r03}
+T=${1:-r05}
 cd "$(dirname "$0")/.."
 cp gpurun_out/refresh/${T}_bench.json profiles/${T}_bench.json
 cp gpurun_out/refresh/${T}_bench_headline.json profiles/${T}_bench_headline.json
