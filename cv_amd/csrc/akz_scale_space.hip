@@ -2759,10 +2759,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                     left -= g;
                 }
             // k_front_fed: front end + the first of those launches in one kernel (Lflow stays on chip unless a later
-            // launch of the level needs it).  First octave only: there a level is one or two launches, below it the
-            // 5 to 8 steps of a launch would need a three-patch halo.
+            // launch of the level needs it).  The first octave, where a level is one or two launches of at most 4 steps, and
+            // any deeper level whose WHOLE diffusion is one launch of at most 4 steps (level 4 of the default pyramid: no
+            // Lflow at all then).  The other deeper levels run 5 to 8 steps per launch, which would need a two-patch halo
+            // around the blur's (octaves 1-3 fused that way measured 9636 vs 9781 frames/s).
             const bool front_fed = c->fuse_front_fed && blocked && fused_front && !c->keep_all && !groups.empty() &&
-                                   groups[0] <= 4 && L.octave == 0;   // (first-octave launches hold at most 4 steps; octaves 1-3 measured: 9636 vs 9781 frames/s)
+                                   ((groups[0] <= 4 && (L.octave == 0 || groups.size() == 1)) || (groups[0] <= 8 && L.octave > 0));
             if (front_fed) {
                 const int ng = (int)groups.size();
                 float* dst0 = ((ng - 1) % 2 == 0) ? bufA : bufB;
@@ -2778,7 +2780,8 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                        (const float*)S.d_invk, (int)L.octave, ng == 1 ? half_next : (float*)nullptr, half_next_fs)
 #define AKZ_FF2(SGV, HPV, RGV) if (ng > 1) { AKZ_FF3(SGV, HPV, RGV, true); } else { AKZ_FF3(SGV, HPV, RGV, false); }
 #define AKZ_FF(SGV)                                                                                                  \
-    if (groups[0] <= 3) { AKZ_FF2(SGV, 1, false) } else { AKZ_FF2(SGV, 1, true) }
+    if (groups[0] <= 3) { AKZ_FF2(SGV, 1, false) } else if (groups[0] == 4) { AKZ_FF2(SGV, 1, true) }               \
+    else if (groups[0] <= 7) { AKZ_FF2(SGV, 2, false) } else { AKZ_FF2(SGV, 2, true) }
                 switch (L.deriv_sigma) {
                 case 2: AKZ_FF(2) break;
                 case 3: AKZ_FF(3) break;

@@ -1714,6 +1714,8 @@ OPTION_SETS = [
     ("one-frame kernels", dict(frame_pairs=False)),
     ("one FED step per launch", dict(fed_block=1)),
     ("three FED steps per launch", dict(fed_block=3)),
+    ("five FED steps per launch (two-patch halo, fused first launch writes Lflow)", dict(fed_block=5)),
+    ("seven FED steps per launch", dict(fed_block=7)),
     ("serial suppression, no pipeline", dict(parallel_suppression=False, pipeline=False)),
     ("exact contrast, equal stream priorities", dict(contrast="exact", stream_priority=False)),
     ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
