@@ -58,7 +58,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
 # (DESIGN.md §5): front-end f32 levels 4 in + 4 Lflow + 8 {Lx,Ly} out; level 0: 1 (u8) in + 4 Lt + 8 {Lx,Ly};
 # determinant: 8 in ({Lx,Ly}), candidates only out; FED: 4 L + 4 c in, 4 L out per LAUNCH (T steps share the pass);
 # contrast: 1 (u8) in per pass; fused front end + first FED launch (k_front_fed): 4 in (Lt), 4 (Lt') + 8 {Lx,Ly} out —
-# Lflow stays on chip (the kernel is VALU-bound, its HBM fraction is what is left of the 28 B the split pair moves).
+# Lflow stays on chip (the kernel is VALU-bound, its HBM fraction is what is left of the 28 B the split pair moves); the same
+# kernel below the first octave (timer ids 26..28) is counted at 16 B as well — 20 B when a later FED launch of the level
+# needs Lflow written, so its fraction is understated there, never overstated.
 KERNEL_FAMILIES = [
     ("k_level_front2<4,2,..,u8> (level 0: u8->f32, blur 1.6, Lt, {Lx,Ly})", 3, 13.0),
     ("k_level_front2<2,2,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 2)", 4, 16.0),
@@ -67,6 +69,9 @@ KERNEL_FAMILIES = [
     ("k_front_fed<2,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 2)", 22, 16.0),
     ("k_front_fed<3,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 3)", 23, 16.0),
     ("k_front_fed<4,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 4)", 24, 16.0),
+    ("k_front_fed<2,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 2)", 26, 16.0),
+    ("k_front_fed<3,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 3)", 27, 16.0),
+    ("k_front_fed<4,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 4)", 28, 16.0),
     ("k_det_stream<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
     ("k_det_stream<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
     ("k_det_stream<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),

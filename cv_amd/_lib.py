@@ -121,7 +121,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "
 NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
 assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 
-ABI_VERSION = 6          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
+ABI_VERSION = 7          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
 
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [

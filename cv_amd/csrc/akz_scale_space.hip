@@ -2771,7 +2771,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 FedTaus ft;
                 for (int q = 0; q < kFedMaxBlock; ++q) ft.half_tau[q] = q < groups[0] ? 0.5f * (float)L.tau[q] : 0.0f;
                 OffK kk = make_offk(L.deriv_sigma);
-                const int t_ff = AKZ_T_FRONT_FED_SG2 + (int)L.deriv_sigma - 2;
+                const int t_ff = (L.octave == 0 ? AKZ_T_FRONT_FED_SG2 : AKZ_T_FRONT_FED_DEEP_SG2) + (int)L.deriv_sigma - 2;
                 akz_timer_begin(c, t_ff, s);
 #define AKZ_FF3(SGV, HPV, RGV, WFV)                                                                                  \
     AKZ_LAUNCH((k_front_fed<SGV, HPV, RGV, WFV>),                                                             \

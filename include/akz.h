@@ -598,7 +598,7 @@ const char* akz_version(void);
 /* The ABI number: raised whenever a declared signature, struct layout or enum value of this header changes (additions
  * included).  A binding compares akz_abi_version() of the library it loaded with the AKZ_ABI_VERSION it was written against
  * and refuses to run on a mismatch (cv_amd/_lib.py, rust/akaze-mi355x/src/lib.rs, include/akaze.hpp do). */
-#define AKZ_ABI_VERSION 6u
+#define AKZ_ABI_VERSION 7u
 uint32_t akz_abi_version(void);
 
 /* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Kernel families (every id but the
@@ -632,7 +632,10 @@ enum {
     AKZ_T_FRONT_FED_SG3 = 23,
     AKZ_T_FRONT_FED_SG4 = 24,
     AKZ_T_ORIENT_DESCRIBE_K = 25, /* the k_orient_describe launch itself (kernel timer inside the AKZ_T_DESCRIBE phase), units: frames */
-    AKZ_T_COUNT = 26
+    AKZ_T_FRONT_FED_DEEP_SG2 = 26, /* k_front_fed on levels BELOW the first octave (two-patch halo for launches of 5..8 steps; Lflow is */
+    AKZ_T_FRONT_FED_DEEP_SG3 = 27, /* written when a later launch of the level reads it), sigma 2..4: ids 26..28, units: pixel-frames */
+    AKZ_T_FRONT_FED_DEEP_SG4 = 28,
+    AKZ_T_COUNT = 29
 };
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);

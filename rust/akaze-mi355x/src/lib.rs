@@ -200,7 +200,7 @@ fn same_cfg(a: &AkzConfig, b: &AkzConfig) -> bool {
 }
 /// The thread's matcher context, grown to hold `n` descriptors a side.
 /// include/akz.h AKZ_ABI_VERSION these bindings were written against; the loaded library must export the same number.
-const AKZ_ABI_VERSION: u32 = 6;
+const AKZ_ABI_VERSION: u32 = 7;
 fn require_abi() {
     let got = unsafe { akz_abi_version() };
     assert_eq!(got, AKZ_ABI_VERSION, "libakz exports ABI {got}, akaze-mi355x was written against {AKZ_ABI_VERSION}");

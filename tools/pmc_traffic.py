@@ -21,9 +21,12 @@ def family_key(name):
     if m:
         src = {"unsigned char": ",u8", "unsigned short": ",u16"}.get(m.group(3), "") if m.group(1) == "4" else ""
         return f"k_level_front2<{m.group(1)},{m.group(2)},..{src}>"
-    m = re.match(r"k_front_fed<(\d+),", n)
+    m = re.match(r"k_front_fed<(\d+), (\d+),", n)
     if m:
-        return f"k_front_fed<{m.group(1)},..>"
+        # <sigma, halo patches, ..>: the first octave runs one-patch halos at sigma 3 / 4; everything with a two-patch halo, and
+        # sigma 2 (the first sublevel of every deeper octave), is the "below the first octave" family of bench.py
+        deep = m.group(2) != "1" or m.group(1) == "2"
+        return f"k_front_fed<{m.group(1)},2,..>" if deep else f"k_front_fed<{m.group(1)},..>"
     m = re.match(r"k_det_stream<(\d+),", n)
     if m:
         return f"k_det_stream<{m.group(1)},..>"
