@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--procs", type=int, default=32)
     ap.add_argument("--arms", action="store_true", help="also draw the input arm: Luma16, f32, RGB8, RGBA16, RGB32F")
     ap.add_argument("--opt", action="append", default=[], help="akz_options field, key=value (make_options keywords)")
+    ap.add_argument("--copies", type=int, default=1, help="frames per call: the case's frame K times in ONE batch call (call size selects "
+                    "kernels: above 4 frames the batch paths run — FED launches of up to 8 steps with the fused first launch, one "
+                    "workgroup per frame in the keypoint stage); every copy is compared")
     a = ap.parse_args()
     kw = {k: int(v) for k, v in (kv.split("=") for kv in a.opt)}
     from oracle import oracle as O
@@ -83,9 +86,13 @@ def main():
         if img.dtype == np.uint8 and img.ndim == 2:
             ak = akaze.Akaze.new(thr)
             while True:                    # a dense noise frame can pass 16 384 keypoints: more room, as the host mirrors do
-                c = akaze.Context(ak, w, h, 1, _lib.make_options(**kw) if kw else None)
+                c = akaze.Context(ak, w, h, a.copies, _lib.make_options(**kw) if kw else None)
                 try:
-                    (kp, d), = c.extract_batch([img])
+                    res = c.extract_batch([img] * a.copies)
+                    kp, d = res[0]
+                    for q in range(1, a.copies):      # every copy of the call must carry the same bytes
+                        if res[q][0].tobytes() != kp.tobytes() or res[q][1].tobytes() != d.tobytes():
+                            kp = res[q][0][:0]        # (forces the mismatch report below)
                     break
                 except _lib.AkzError as e:
                     if e.status != -7 or ak.max_keypoints >= akaze.MAX_KEYPOINTS:
