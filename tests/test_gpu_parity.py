@@ -1782,6 +1782,69 @@ def test_host_calls_with_and_without_pinned_staging(gpu, oracle):
         ctx.close()
 
 
+def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
+    """Maximum size.  akz_create accepts frames of up to 2^28 pixels because the diffusion / determinant kernels address a frame's
+    planes with 32-bit byte offsets (8 B per pixel for {Lx, Ly}: 2^31 at the cap).  A 4096 x 65528 frame (268.4 M pixels) carries
+    its content in the LAST 2048 rows — the highest addresses of every plane — under a constant field, the first rows of the
+    content being the same constant, so that clamping (the cropped image the oracle gets) and the constant above (the big
+    frame) are the same neighbourhood.  Pixel VALUES do not depend on where a pixel lies: Lt, Lx and Ly of the last level of
+    every octave must equal the oracle's planes of the cropped image bit for bit below the rows the different upper boundary
+    can have reached (FED steps and filter supports, octave by octave), and the keypoints of the first octaves found there must
+    be the oracle's (level, x, response, size; y up to the f32 spacing at 65 000)."""
+    akaze, _ = gpu
+    W, H, h = 4096, 65528, 2048
+    y0 = H - h
+    assert y0 % 8 == 0 and W * H <= 1 << 28 and W * H > (1 << 28) - (1 << 20)
+    small = synth_frame(W, h, seed=0xB16, n_rect=700, n_disc=700)
+    small[:16] = 96
+    big = np.full((H, W), 96, np.uint8)
+    big[y0:] = small
+    ak = akaze.Akaze.default()
+    ak.max_keypoints = 65536
+    ctx = akaze.Context(ak, W, H, 1)
+    (kp, _desc), = ctx.extract_batch([big])
+    orc = oracle.Akaze(W, h, oracle.default_config())
+    okp, _od = orc.extract(small)
+    assert ctx.num_levels(W, H) == orc.num_levels == 16
+    # rows (in the octave's own pixels) the upper boundary can have influenced: the previous octave's, halved, + this octave's FED
+    # steps + a generous 40 for the blur, Scharr and multiscale-derivative supports of its four levels
+    reach, steps = [], [10, 22, 44, 90]
+    for o in range(4):
+        reach.append((reach[-1] + 1) // 2 + steps[o] + 40 if reach else steps[0] + 40)
+    checked = 0
+    for lvl in (3, 7, 11, 15):
+        o = lvl // 4
+        m, yl = reach[o] + 8, y0 >> o
+        for name in ("Lt", "Lx", "Ly"):
+            g = ctx.level_buffer(0, lvl, name, W, H)
+            want = orc.buffer(lvl, name)
+            assert g.shape == (H >> o, W >> o) and want.shape == (h >> o, W >> o)
+            _eq(g[yl + m:], want[m:], f"{name}[{lvl}] rows below the boundary's reach")
+            assert np.all(g[:yl - m].view(np.uint32) == g[0, 0].view(np.uint32)), f"{name}[{lvl}]: the constant field is not constant"
+            checked += want[m:].size
+    assert checked > 5_000_000
+    # keypoints of levels 0..6 (they depend on levels <= 7 only: a candidate is matched against entries of its own and the
+    # previous level, and the second pass looks one level up) well below the boundary
+    sel_g = kp[(kp["class_id"] <= 6) & (kp["y"] > y0 + 400)]
+    sel_o = okp[(okp["class_id"] <= 6) & (okp["y"] > 400)]
+    assert len(sel_o) > 3000 and len(sel_g) == len(sel_o), (len(sel_g), len(sel_o))
+    for f in ("class_id", "octave"):
+        assert np.array_equal(sel_g[f], sel_o[f]), f
+    for f in ("x", "response", "size"):
+        _eq(sel_g[f], sel_o[f], f"large frame keypoint {f}")
+    assert np.abs((sel_g["y"].astype(np.float64) - y0) - sel_o["y"]).max() < 0.05
+    ctx.close()
+    # a little wider is over the cap: refused (AKZ_E_TOO_LARGE), not wrapped
+    with pytest.raises(_lib_error()) as e:
+        akaze.Context(ak, W + 8, H, 1)
+    assert e.value.status == -6
+
+
+def _lib_error():
+    from cv_amd import _lib
+    return _lib.AkzError
+
+
 def test_unknown_option_bits_are_refused(gpu):
     import ctypes as C
     from cv_amd import _lib
