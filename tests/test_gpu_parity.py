@@ -1782,7 +1782,8 @@ def test_host_calls_with_and_without_pinned_staging(gpu, oracle):
         ctx.close()
 
 
-def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
+@pytest.mark.parametrize("W,H,h,levels", [(4096, 65528, 2048, (3, 7, 11, 15)), (65528, 4096, 640, (3, 7, 11))], ids=["tall", "wide"])
+def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle, W, H, h, levels):
     """Maximum size.  akz_create accepts frames of up to 2^28 pixels because the diffusion / determinant kernels address a frame's
     planes with 32-bit byte offsets (8 B per pixel for {Lx, Ly}: 2^31 at the cap).  A 4096 x 65528 frame (268.4 M pixels) carries
     its content in the LAST 2048 rows — the highest addresses of every plane — under a constant field, the first rows of the
@@ -1790,9 +1791,9 @@ def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
     frame) are the same neighbourhood.  Pixel VALUES do not depend on where a pixel lies: Lt, Lx and Ly of the last level of
     every octave must equal the oracle's planes of the cropped image bit for bit below the rows the different upper boundary
     can have reached (FED steps and filter supports, octave by octave), and the keypoints of the first octaves found there must
-    be the oracle's (level, x, response, size; y up to the f32 spacing at 65 000)."""
+    be the oracle's (level, x, response, size; y up to the f32 spacing at 65 000).  "wide" is the same with 65 528-pixel rows
+    (512 determinant bands per row, 1 170 diffusion windows per row) and a lower content, checked up to octave 2."""
     akaze, _ = gpu
-    W, H, h = 4096, 65528, 2048
     y0 = H - h
     assert y0 % 8 == 0 and W * H <= 1 << 28 and W * H > (1 << 28) - (1 << 20)
     small = synth_frame(W, h, seed=0xB16, n_rect=700, n_disc=700)
@@ -1812,7 +1813,7 @@ def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
     for o in range(4):
         reach.append((reach[-1] + 1) // 2 + steps[o] + 40 if reach else steps[0] + 40)
     checked = 0
-    for lvl in (3, 7, 11, 15):
+    for lvl in levels:
         o = lvl // 4
         m, yl = reach[o] + 8, y0 >> o
         for name in ("Lt", "Lx", "Ly"):
@@ -1822,12 +1823,12 @@ def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
             _eq(g[yl + m:], want[m:], f"{name}[{lvl}] rows below the boundary's reach")
             assert np.all(g[:yl - m].view(np.uint32) == g[0, 0].view(np.uint32)), f"{name}[{lvl}]: the constant field is not constant"
             checked += want[m:].size
-    assert checked > 5_000_000
+    assert checked > 4_000_000
     # keypoints of levels 0..6 (they depend on levels <= 7 only: a candidate is matched against entries of its own and the
     # previous level, and the second pass looks one level up) well below the boundary
     sel_g = kp[(kp["class_id"] <= 6) & (kp["y"] > y0 + 400)]
     sel_o = okp[(okp["class_id"] <= 6) & (okp["y"] > 400)]
-    assert len(sel_o) > 3000 and len(sel_g) == len(sel_o), (len(sel_g), len(sel_o))
+    assert len(sel_o) > 2000 and len(sel_g) == len(sel_o), (len(sel_g), len(sel_o))
     for f in ("class_id", "octave"):
         assert np.array_equal(sel_g[f], sel_o[f]), f
     for f in ("x", "response", "size"):
@@ -1836,7 +1837,7 @@ def test_frame_at_the_pixel_cap_is_addressed_correctly(gpu, oracle):
     ctx.close()
     # a little wider is over the cap: refused (AKZ_E_TOO_LARGE), not wrapped
     with pytest.raises(_lib_error()) as e:
-        akaze.Context(ak, W + 8, H, 1)
+        akaze.Context(ak, *((W + 8, H) if W < H else (W, H + 8)), 1)
     assert e.value.status == -6
 
 
