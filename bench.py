@@ -784,6 +784,12 @@ def self_launch(args, argv):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher of N ranks of this same command
     on this node (127.0.0.1 rendezvous, a free port), one rank per GPU — or all on cuda:0 with --share-device."""
     import socket
+    if not args.share_device:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s) (--share-device puts all ranks on cuda:0 "
+                             "for a smoke test)")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]

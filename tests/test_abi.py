@@ -235,9 +235,18 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     def fake_execve(exe, argv, env):
         seen["exe"], seen["argv"], seen["env"] = exe, list(argv), dict(env)
         raise SystemExit(0)
+    import torch
     monkeypatch.setattr(os, "execve", fake_execve)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"])
+    # a node with fewer GPUs than ranks: a clear refusal instead of N ranks failing one by one
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    try:
+        bench.main()
+        assert False, "expected a refusal"
+    except SystemExit as e:
+        assert "--gpus 2" in str(e.code) and "seen" not in seen
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     try:
         bench.main()
     except SystemExit as e:
