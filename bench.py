@@ -822,8 +822,14 @@ def read_families(ctx):
     return fam
 
 
-VALU_ISSUE_PEAK_T = 39.3     # T wave-lane instructions / s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (one VALU instruction per
-                             # lane and cycle; = the 78.6 T lane-op/s non-FMA packed-f32 peak of MI355X_MICROARCH.md / 2)
+VALU_ISSUE_PEAK_T = 39.3     # T lane-instructions / s at FOUR cycles per wave64 instruction (256 CUs x 4 SIMDs x 64 lanes / 4 x
+                             # 2.4 GHz): the rate of the instructions the big kernels are made of — packed f32 (v_pk_add/mul_f32: two
+                             # lane-ops each, i.e. the 78.6 T lane-op/s non-FMA peak) and f64.  MI355X_MICROARCH.md gives a PLAIN
+                             # 32-bit VALU instruction two cycles (SIMD-32: 157.3 TFLOP/s of v_fma_f32), so valu_frac computed with
+                             # this constant is the fraction of issue time IF every instruction were packed or f64: exact for the
+                             # consensus kernels (f64), close for the diffusion kernels (mostly packed), an UPPER bound for kernels
+                             # of scalar 32-bit work (k_orient_describe, the sorts).  The cycle-based counters beside it
+                             # (issue_counters.valu_busy_pct: SQ_ACTIVE_INST_VALU over busy cycles) do not depend on it.
 
 
 def gather_model(ctx, kps_frames, counts):
