@@ -616,6 +616,7 @@ def main():
                         "of MI355X_MICROARCH.md (~10 PF)"}
         if sharded:
             out["multi_gpu"] = {
+                "ranks": world,
                 "per_rank_frames_per_s": [round(NF * args.steps / t_, 1) for t_ in per_rank],
                 "recent_views": K, "exchange": "all-gather of fixed-capacity descriptor blocks" if use_allgather else "ring shift",
                 "comm": "akz_comm_* (libakz -> librccl.so.1)" if comm_kind == "akz" else f"torch.distributed ({args.backend})",
@@ -747,10 +748,8 @@ def headline(out, detail_path=None):
         h["extras"] = legs
     mg = out.get("multi_gpu")
     if mg:
-        h["multi_gpu"] = {k: mg[k] for k in ("exchange", "comm", "rccl_ranks_seen", "exchange_ms_per_step", "recent_views") if k in mg}
-        prf = mg.get("per_rank_frames_per_s")
-        if prf:
-            h["multi_gpu"]["per_rank_frames_per_s_min_max"] = [min(prf), max(prf)]
+        h["multi_gpu"] = {k: mg[k] for k in ("ranks", "exchange", "comm", "rccl_ranks_seen", "exchange_ms_per_step", "recent_views",
+                                             "per_rank_frames_per_s") if k in mg}
     if detail_path:
         h["detail"] = detail_path
     line = json.dumps(h, separators=(",", ":"))

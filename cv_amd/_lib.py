@@ -167,6 +167,9 @@ def lib():
     L.akz_strerror.argtypes = [i32]
     L.akz_last_hip_error_string.restype = C.c_char_p
     L.akz_version.restype = C.c_char_p
+    if not hasattr(L, "akz_abi_version"):   # a library from before the ABI carried a version: the same remedy
+        raise RuntimeError(f"{LIB_PATH} exports no akz_abi_version (a build older than ABI 6), this binding was written "
+                           f"against {ABI_VERSION} (include/akz.h AKZ_ABI_VERSION): rebuild with `python -m cv_amd.build`")
     L.akz_abi_version.restype = C.c_uint32
     L.akz_debug_rcp_error.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.hm_targets_generation.restype = C.c_uint64

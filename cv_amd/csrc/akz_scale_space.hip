@@ -2759,12 +2759,12 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                     left -= g;
                 }
             // k_front_fed: front end + the first of those launches in one kernel (Lflow stays on chip unless a later
-            // launch of the level needs it).  The first octave, where a level is one or two launches of at most 4 steps, and
-            // any deeper level whose WHOLE diffusion is one launch of at most 4 steps (level 4 of the default pyramid: no
-            // Lflow at all then).  The other deeper levels run 5 to 8 steps per launch, which would need a two-patch halo
-            // around the blur's (octaves 1-3 fused that way measured 9636 vs 9781 frames/s).
+            // launch of the level needs it: WRITE_FLOW).  The first octave's levels are one or two launches of at most 4
+            // steps (one halo patch, HP = 1); below it the first launch runs up to 8 steps behind a two-patch halo (HP = 2:
+            // rejected in rounds 2-3 at 9636 vs 9781 frames/s, adopted in round 5 at -4.9 % of the scale-space kernel time
+            // once the kernel had lost 17 % of its instructions).  A few-frame call's 9..16-step launches keep the split path.
             const bool front_fed = c->fuse_front_fed && blocked && fused_front && !c->keep_all && !groups.empty() &&
-                                   ((groups[0] <= 4 && (L.octave == 0 || groups.size() == 1)) || (groups[0] <= 8 && L.octave > 0));
+                                   groups[0] <= (L.octave == 0 ? 4 : 8);
             if (front_fed) {
                 const int ng = (int)groups.size();
                 float* dst0 = ((ng - 1) % 2 == 0) ? bufA : bufB;

@@ -16,6 +16,7 @@
 // v_min_u32 / v_med3_u32: smaller key == smaller (distance, index), which is exactly LinearKnn's
 // "lowest index wins ties" order (space 0.17: partition_point(d <= new) insertion).
 #include <algorithm>
+#include <atomic>
 
 #include <hip/hip_ext.h>
 
@@ -955,6 +956,8 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
         // the MFMA kernel carries (2 * hamming) << 21 | row: rows need 21 bits
         if (!out || max_queries == 0 || max_targets == 0 || max_targets >= (1u << (kIdxBits - 1))) return AKZ_E_INVALID;
         if (flags & ~(HM_OPT_NO_FP4 | HM_OPT_NO_MFMA | HM_OPT_STREAM_PRIORITY | HM_OPT_NO_LDS_DMA | HM_OPT_CU_MASK)) return AKZ_E_INVALID;   // unknown switches
+        const int cus = (int)((flags & HM_OPT_CU_MASK) >> HM_OPT_CU_SHIFT);
+        if (cus > 32) return AKZ_E_INVALID;            // (before anything is allocated)
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AKZ_E_NO_DEVICE;
         AKZ_HIP(hipSetDevice(device));
@@ -968,8 +971,6 @@ extern "C" int32_t hm_create_ex(int32_t device, uint32_t max_queries, uint32_t m
             int prio_lo = 0, prio_hi = 0;
             hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             // HM_OPT_STREAM_PRIORITY: the matcher as least-urgent filler work that yields to the scale-space stream
-            const int cus = (int)((flags & HM_OPT_CU_MASK) >> HM_OPT_CU_SHIFT);
-            if (cus > 32) return AKZ_E_INVALID;
             if (cus) AKZ_HIP(akz_stream_on_cus(&c->stream, 32 - cus, cus));
             else AKZ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (flags & HM_OPT_STREAM_PRIORITY) ? prio_lo : 0));
         }
@@ -1216,7 +1217,10 @@ extern "C" int32_t hm_set_targets(hm_ctx* c, const akz_descriptor* t, uint32_t n
         AKZ_HIP(hipStreamSynchronize(c->stream));   // the caller's array may go away
         c->resident_nt = nt;
         c->resident = true;
-        c->generation += 1;
+        // process-wide, never reused: a context destroyed and re-created at the same address (a binding that grows its
+        // matcher) must not hand out a number an older upload already carries
+        static std::atomic<uint64_t> g_generation{0};
+        c->generation = ++g_generation;
         return AKZ_OK;
     });
 }

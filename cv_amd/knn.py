@@ -41,7 +41,9 @@ class Matcher:
         self.cap = max_descriptors
         flags = {"fp4": 0, "fp4_regs": _lib.HM_OPT_NO_LDS_DMA, "int8": _lib.HM_OPT_NO_FP4, "valu": _lib.HM_OPT_NO_MFMA}[kernel]
         flags |= _lib.HM_OPT_STREAM_PRIORITY if low_priority else 0
-        flags |= (int(cus) & 0x3F) << 16
+        if not 0 <= int(cus) <= 32:
+            raise ValueError(f"cus = {cus}: the matcher's stream takes 0 (the whole chip) to 32 compute units per XCD")
+        flags |= int(cus) << 16
         check(_lib.lib().hm_create_ex(device, max_descriptors, max_descriptors, flags, C.byref(self._h)), "hm_create_ex")
 
     def close(self):

@@ -87,9 +87,10 @@ struct CtxKey {
     akz_config cfg;
     int device, w, h;
     uint32_t max_keypoints;
+    uint32_t arith = 0;   // akz_options.arith (tools/pin_arith.py names the value a given Rust build computes)
     bool same(const CtxKey& o) const
     {
-        return cfg.maximum_features == o.cfg.maximum_features && cfg.num_sublevels == o.cfg.num_sublevels &&
+        return arith == o.arith && cfg.maximum_features == o.cfg.maximum_features && cfg.num_sublevels == o.cfg.num_sublevels &&
                cfg.max_octave_evolution == o.cfg.max_octave_evolution && cfg.base_scale_offset == o.cfg.base_scale_offset &&
                cfg.initial_contrast == o.cfg.initial_contrast && cfg.contrast_percentile == o.cfg.contrast_percentile &&
                cfg.contrast_factor_num_bins == o.cfg.contrast_factor_num_bins && cfg.derivative_factor == o.cfg.derivative_factor &&
@@ -128,7 +129,10 @@ struct CtxCache {
         if (victim->ctx) akz_destroy(victim->ctx);
         victim->ctx = nullptr;
         require_abi();
-        check(akz_create(&k.cfg, k.device, k.w, k.h, 1, k.max_keypoints, &victim->ctx), "akz_create");
+        akz_options opt = {};
+        opt.struct_size = (uint32_t)sizeof(opt);
+        opt.arith = k.arith;
+        check(akz_create_ex(&k.cfg, k.device, k.w, k.h, 1, k.max_keypoints, k.arith ? &opt : nullptr, &victim->ctx), "akz_create_ex");
         victim->key = k;
         victim->used = ++tick;
         return victim->ctx;
@@ -168,6 +172,10 @@ public:
     // first capacity of the device's per-frame lists.  The reference's Vecs are unbounded; a call that overflows the
     // capacity is repeated with twice as much (up to the library's 262 144 per frame), so this is a starting point only.
     uint32_t initial_keypoint_capacity = 16384;
+    // which of the reference's three un-vendored arithmetic orders the filters and half_size use (akz_options.arith,
+    // AKZ_ARITH_* bits; 0 = what the crate sources imply).  `python3 tools/pin_arith.py <rust>_kps.csv <rust>_descs.txt image`
+    // names the value that reproduces a given cargo build byte for byte.
+    uint32_t arith = 0;
 
     static Akaze new_(double threshold)  // Akaze::new (lib.rs:147-152); `new` is reserved in C++
     {
@@ -229,7 +237,7 @@ private:
         uint32_t cap = initial_keypoint_capacity < 64 ? 64 : (initial_keypoint_capacity > kLibraryMax ? kLibraryMax : initial_keypoint_capacity);
         if ((uint64_t)maximum_features < cap) cap = (uint32_t)(maximum_features < 64 ? 64 : maximum_features);
         for (;;) {
-            detail::CtxKey key{config(), device, w, h, cap};
+            detail::CtxKey key{config(), device, w, h, cap, arith};
             akz_ctx* c = detail::ctx_cache().get(key);
             std::vector<akz_keypoint> k(cap);
             std::vector<akz_descriptor> d(cap);

@@ -120,7 +120,11 @@ typedef struct akz_options {
     uint32_t stream_min_waves; /* launches that cannot field this many streaming waves take the tile kernel; 0 = default (2048) */
     uint32_t arith;           /* AKZ_ARITH_* bits: which of the reference's un-vendored arithmetic orders the filters use; 0 = default */
     uint32_t cu_ss;           /* CU partitioning (hipExtStreamCreateWithCUMask), 0 = none: the scale-space and determinant streams run on the */
-    uint32_t cu_kp;           /* FIRST cu_ss compute units of every XCD, the keypoint stream on the LAST cu_kp (1..32 each; measured: DESIGN.md 5) */
+    uint32_t cu_kp;           /* FIRST cu_ss compute units of every XCD, the keypoint stream on the LAST cu_kp (1..32 each; measured: DESIGN.md 5).
+                               * Experiment-only: a masked stream is created by an API that takes neither a priority nor
+                               * hipStreamNonBlocking, so it OVERRIDES AKZ_OPT_EQUAL_PRIORITY (no priorities at all) and is a
+                               * blocking stream — it synchronises implicitly with the NULL stream of the process.  The same
+                               * holds for HM_OPT_CU_MASK against HM_OPT_STREAM_PRIORITY. */
     uint32_t reserved[5];     /* must be zero */
 } akz_options;
 /* akz_options.arith — the only option that CHANGES RESULTS.  Three pieces of the reference's arithmetic live in crates that

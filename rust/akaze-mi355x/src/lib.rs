@@ -49,9 +49,29 @@ pub struct AkzNeighbor {
     pub distance: u32,
 }
 
+/// `akz_options` (include/akz.h): sixteen 32-bit words; everything zero = the library's defaults.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct AkzOptions {
+    struct_size: u32,
+    flags: u32,
+    fed_block: u32,
+    sup_capacity: u32,
+    max_candidates: u32,
+    desc_tile_shift: u32,
+    stream_waves: u32,
+    stream_min_waves: u32,
+    arith: u32,
+    cu_ss: u32,
+    cu_kp: u32,
+    reserved: [u32; 5],
+}
+
 extern "C" {
     fn akz_create(cfg: *const AkzConfig, device: i32, max_w: i32, max_h: i32, max_batch: i32, max_kp: u32,
                   out: *mut *mut c_void) -> i32;
+    fn akz_create_ex(cfg: *const AkzConfig, device: i32, max_w: i32, max_h: i32, max_batch: i32, max_kp: u32,
+                     opts: *const AkzOptions, out: *mut *mut c_void) -> i32;
     fn akz_destroy(ctx: *mut c_void) -> i32;
     fn akz_extract_gray_u16(ctx: *mut c_void, img: *const u16, w: i32, h: i32, stride: i32, kps: *mut AkzKeypoint,
                             descs: *mut [u8; 64], cap: u32, n_out: *mut u32) -> i32;
@@ -179,6 +199,7 @@ struct CachedCtx {
     w: u32,
     h: u32,
     cap: u32,
+    arith: u32,
     ctx: *mut c_void,
 }
 impl Drop for CachedCtx {
@@ -198,6 +219,17 @@ fn same_cfg(a: &AkzConfig, b: &AkzConfig) -> bool {
         && a.detector_threshold == b.detector_threshold && a.descriptor_channels == b.descriptor_channels
         && a.descriptor_pattern_size == b.descriptor_pattern_size
 }
+/// Which of the reference's three un-vendored arithmetic orders the filters and `half_size` use (`akz_options.arith`,
+/// `AKZ_ARITH_*` bits of include/akz.h; 0 = what the crate sources imply for a default x86-64 build).  The `Akaze` struct
+/// stays the reference's eleven fields, so this is process-wide: call it once, before the first `extract`, with the value
+/// `python3 tools/pin_arith.py <rust>_kps.csv <rust>_descs.txt image.png` names for the cargo build this crate replaces
+/// (INTEGRATION.md 6).  Contexts created under another value are dropped at the next call.
+pub fn set_arith(arith: u32) {
+    assert!(arith < 8, "akz_options.arith takes AKZ_ARITH_* bits 0..7");
+    ARITH.store(arith, std::sync::atomic::Ordering::Relaxed);
+}
+static ARITH: std::sync::atomic::AtomicU32 = std::sync::atomic::AtomicU32::new(0);
+
 /// The thread's matcher context, grown to hold `n` descriptors a side.
 /// include/akz.h AKZ_ABI_VERSION these bindings were written against; the loaded library must export the same number.
 const AKZ_ABI_VERSION: u32 = 7;
@@ -262,13 +294,15 @@ impl Akaze {
         loop {
             let (st, kps, descs, n) = CTX.with(|slot| {
                 let mut slot = slot.borrow_mut();
-                let fits = slot.as_ref().map_or(false, |c| same_cfg(&c.cfg, &cfg) && c.cap == cap && w <= c.w && h <= c.h);
+                let arith = ARITH.load(std::sync::atomic::Ordering::Relaxed);
+                let fits = slot.as_ref().map_or(false, |c| same_cfg(&c.cfg, &cfg) && c.cap == cap && c.arith == arith && w <= c.w && h <= c.h);
                 if !fits {
                     *slot = None; // drops (and destroys) the previous context first
                     let mut ctx: *mut c_void = ptr::null_mut();
-                    let st = unsafe { akz_create(&cfg, 0, w as i32, h as i32, 1, cap, &mut ctx) };
-                    assert_eq!(st, 0, "akz_create failed with status {st} (there is no CPU fallback)");
-                    *slot = Some(CachedCtx { cfg, w, h, cap, ctx });
+                    let opts = AkzOptions { struct_size: std::mem::size_of::<AkzOptions>() as u32, arith, ..Default::default() };
+                    let st = unsafe { akz_create_ex(&cfg, 0, w as i32, h as i32, 1, cap, if arith != 0 { &opts } else { ptr::null() }, &mut ctx) };
+                    assert_eq!(st, 0, "akz_create_ex failed with status {st} (there is no CPU fallback)");
+                    *slot = Some(CachedCtx { cfg, w, h, cap, arith, ctx });
                 }
                 let ctx = slot.as_ref().unwrap().ctx;
                 let mut kps = vec![AkzKeypoint::default(); cap as usize];

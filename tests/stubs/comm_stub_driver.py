@@ -62,7 +62,7 @@ def read_log():
 
 NF, CAP = 3, 8
 res = {}
-for world in (1, 2, 3):
+for world in (1, 2, 3, 4, 8):      # 8 = BASELINE configs[4]: eight communicators in one process
     stub.rccl_stub_reset()
     assert L.akz_comm_unique_id(idb) == 0
     comms = []

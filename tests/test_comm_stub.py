@@ -2,8 +2,8 @@
 
 No N > 1 RCCL transfer has ever run on hardware the builder could reach, so the send / receive argument layout of the ring
 shift and the all-gather is held here: tests/stubs/rccl_stub.cpp implements the nine symbols the library resolves, logs
-every call and moves the data between the communicators of ONE process, which then plays every rank of a world of 2 and
-3 on one GPU.  The CPU half (no device) checks that the dlopen / dlsym path reaches a librccl.so.1 at all."""
+every call and moves the data between the communicators of ONE process, which then plays every rank of a world of 1, 2,
+3, 4 and 8 (BASELINE configs[4]: eight communicators, eight streams) on one GPU.  The CPU half (no device) checks that the dlopen / dlsym path reaches a librccl.so.1 at all."""
 import json
 import os
 import subprocess
@@ -51,10 +51,11 @@ def _data_calls(log):
 
 
 @pytest.mark.gpu
-def test_ring_shift_and_all_gather_for_world_2_and_3():
+def test_ring_shift_and_all_gather_for_world_1_to_8():
     out = run_driver("gpu")
     NF, CAP = 3, 8
-    for world in (1, 2, 3):
+    assert sorted(int(k) for k in out["worlds"]) == [1, 2, 3, 4, 8]
+    for world in (1, 2, 3, 4, 8):
         w = out["worlds"][str(world)]
         assert w["shift_ok"] and w["allgather_ok"], world          # the bytes arrived where the matcher reads them
         assert w["unfinished_after_shift"] == 0 and w["unfinished_after_allgather"] == 0

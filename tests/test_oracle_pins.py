@@ -1,5 +1,7 @@
 """Pins the CPU oracle against every known-answer test the reference holds for the hot path
 (SURVEY.md §8c).  CPU only.  All file:line citations are relative to the rust-cv/cv checkout."""
+import os
+
 import numpy as np
 import pytest
 
@@ -225,3 +227,43 @@ def test_cpu_baseline_build_is_the_checker_bit_for_bit(oracle):
     kp, d = single.extract(frames[2])
     assert kp.tobytes() == want[2][0].tobytes() and np.array_equal(d, want[2][1])
     assert len(kp) > 100
+
+
+def test_pin_arith_names_the_combination_a_dump_was_made_with(kitti, tmp_path):
+    """tools/pin_arith.py — the one-command route from "parity vs oracle/" to "parity vs rust-cv" (INTEGRATION.md): given the
+    two files `cargo run --example akaze` writes (akaze/examples/akaze.rs:11-33) and the image, it names the combination
+    of the three un-vendored arithmetic orders that reproduces them byte for byte.  Fed the oracle's own dump at arith 5
+    (tools/akaze_dump.py --oracle --arith 5) it must answer 5 and nothing else; a dump whose angles carry another libm's
+    last bits is still pinned in its arithmetic."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = kitti[0][:256, :640]                      # four octaves, odd sizes on the way down: every switch matters
+    np.save(tmp_path / "crop.npy", img)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "akaze_dump.py"), "--oracle", "--arith", "5", "--out-dir", str(tmp_path),
+                        str(tmp_path / "crop.npy")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_arith.py"), str(tmp_path / "crop_kps.csv"),
+                        str(tmp_path / "crop_descs.txt"), str(tmp_path / "crop.npy")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 17 and sum(ln.startswith("MATCH") for ln in lines) == 1
+    assert [ln for ln in lines if ln.startswith("MATCH")][0].startswith("MATCH     arith 5 ") and "trig portable" in lines[5]
+    assert lines[-1].startswith("VERDICT: the Rust build computes arith = 5 ")
+    # `--arith all` writes the eight variants; variant 5 is the file above, the others differ from it
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "akaze_dump.py"), "--oracle", "--arith", "all", "--out-dir", str(tmp_path / "all"),
+                        str(tmp_path / "crop.npy")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    texts = [open(tmp_path / "all" / f"crop_a{k}_kps.csv").read() + open(tmp_path / "all" / f"crop_a{k}_descs.txt").read() for k in range(8)]
+    assert texts[5] == open(tmp_path / "crop_kps.csv").read() + open(tmp_path / "crop_descs.txt").read()
+    assert len(set(texts)) == 8
+    # another libm: nudge one angle by an ulp -> no byte match, the arithmetic is still pinned to 5
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import akaze_dump as D
+    import pin_arith as P
+    kps, descs = D.oracle_extract(img, 5, "portable")
+    kps = kps.copy()
+    kps["angle"][3] = np.nextafter(kps["angle"][3], np.float32(10.0))
+    out = []
+    matches, _ = P.pin(D.kps_text(kps), D.descs_text(descs), img, out=out.append)
+    assert matches == [] and "arith = 5 reproduces every keypoint" in out[-1]

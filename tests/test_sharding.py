@@ -1,4 +1,4 @@
-"""The N>1 path's exchange step on CPU: world_size 2 and 3 over gloo.  Descriptor blocks are
+"""The N>1 path's exchange step on CPU: world_size 2, 3, 4 and 8 over gloo (8 = BASELINE configs[4]).  Descriptor blocks are
 fake but tagged with their global frame index, so the test checks that after the ring shift every local
 frame holds exactly its predecessor's block, that the rows a rank does not own are never written, and that every
 frame becomes matchable exactly once."""
@@ -54,7 +54,7 @@ def _worker(rank, world, port, nf, mb, cap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nf,mb,world", [(8, 4, 2), (6, 2, 2), (4, 4, 2), (3, 1, 2), (6, 3, 3)])
+@pytest.mark.parametrize("nf,mb,world", [(8, 4, 2), (6, 2, 2), (4, 4, 2), (3, 1, 2), (6, 3, 3), (4, 2, 4), (4, 2, 8), (2, 1, 8)])
 def test_predecessor_exchange(nf, mb, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -74,6 +74,60 @@ def test_owner_mapping():
         for g in range(64):
             r, j = owner(g, world)
             assert global_index(r, j, world) == g
+
+
+@pytest.mark.parametrize("world,nf,mb,k", [(8, 32, 8, 32), (8, 16, 4, 32), (8, 8, 8, 63), (4, 16, 8, 32), (8, 4, 4, 31)])
+def test_world_8_index_arithmetic(world, nf, mb, k):
+    """BASELINE configs[4] without the wire: the index arithmetic of an eight-rank job, checked rank by rank in one process.
+    gathered_block is a bijection of the step's global frames onto the [nf // mb][world][mb] slab array and agrees with the
+    rank-major layout an all-gather of micro-batch m produces; a window of K = 32 views (more than the world: several of
+    them live on the SAME rank, and the first frames' windows wrap to the step's end) names exactly g-1 .. g-K; the ring
+    shift's receive rows (pred_row) put the predecessor of every local frame of every rank where the matcher reads it."""
+    from cv_amd.sharding import exchange_predecessors, gathered_block, global_index, owner, pred_row, window_views
+    total = nf * world
+    slab = {}
+    for m in range(nf // mb):                        # what rank-major all-gathers of every micro-batch leave behind
+        for r in range(world):
+            for i in range(mb):
+                slab[(m * world + r) * mb + i] = global_index(r, m * mb + i, world)
+    assert sorted(slab) == list(range(total))
+    for g in range(total):
+        assert slab[gathered_block(g, world, nf, mb)] == g
+    for r in range(world):
+        for j in range(nf):
+            g = global_index(r, j, world)
+            views = window_views(r, j, world, nf, k)
+            assert views == [(g - d) % total for d in range(1, k + 1)] and len(set(views)) == min(k, len(views))
+            owners = [owner(v, world)[0] for v in views]
+            if k >= world:
+                assert set(owners) == set(range(world))            # every rank holds one of the frame's views
+            assert owners.count(r) == k // world                   # ... and g-world, g-2*world, .. are the frame's own rank's
+    # the ring shift, played by all ranks in one process: rank r's block of micro-batch m lands in rank r + 1's rows
+    class FakeExchange:
+        def __init__(self, r):
+            self.r = r
+
+        def shift(self, descs, counts, recv_descs, recv_counts):
+            sent[self.r] = (descs, counts)
+            recv[self.r] = (recv_descs, recv_counts)
+
+    import torch
+    blocks = [torch.tensor([global_index(r, j, world) for j in range(nf)], dtype=torch.int32) for r in range(world)]
+    prev = [torch.full((nf + 1,), -1, dtype=torch.int32) for _ in range(world)]
+    ready_all = [[] for _ in range(world)]
+    for m0 in range(0, nf, mb):
+        sent, recv, ready = {}, {}, {}
+        for r in range(world):
+            ready[r] = exchange_predecessors(None, r, world, m0, mb, nf, blocks[r][m0:m0 + mb], blocks[r][m0:m0 + mb],
+                                             prev[r], prev[r], FakeExchange(r))
+        for r in range(world):                       # the wire: what rank r - 1 sent is what rank r receives
+            recv[r][1].copy_(sent[(r - 1) % world][1])
+        for r in range(world):
+            for j in ready[r]:
+                assert int(prev[r][pred_row(r, j, nf)]) == (global_index(r, j, world) - 1) % total, (r, j)
+            ready_all[r] += ready[r]
+    for r in range(world):
+        assert sorted(ready_all[r]) == list(range(nf))
 
 
 def _window_worker(rank, world, port, nf, mb, cap, k, q):
@@ -111,7 +165,8 @@ def _window_worker(rank, world, port, nf, mb, cap, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nf,mb,world,k", [(8, 4, 2, 4), (6, 2, 3, 4), (4, 4, 2, 1), (6, 3, 3, 7)])
+@pytest.mark.parametrize("nf,mb,world,k", [(8, 4, 2, 4), (6, 2, 3, 4), (4, 4, 2, 1), (6, 3, 3, 7), (4, 2, 4, 6),
+                                          (8, 4, 8, 32), (4, 2, 8, 31), (2, 2, 8, 15)])
 def test_window_allgather(nf, mb, world, k):
     """All-gather route (SURVEY §8e, K recent views): after the per-micro-batch all-gathers every rank addresses the block
     of ANY global frame through gathered_block, and a frame's window is its K predecessors modulo the step."""
