@@ -72,6 +72,7 @@ KERNEL_FAMILIES = [
     ("k_front_fed<2,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 2)", 26, 16.0),
     ("k_front_fed<3,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 3)", 27, 16.0),
     ("k_front_fed<4,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 4)", 28, 16.0),
+    ("k_level_resident<..> (a level that fits one compute unit: front end + every FED step in one launch, one workgroup per frame)", 29, 16.0),
     ("k_det_stream<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
     ("k_det_stream<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
     ("k_det_stream<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),

@@ -45,24 +45,25 @@ class Options(C.Structure):
         ("struct_size", C.c_uint32), ("flags", C.c_uint32), ("fed_block", C.c_uint32),
         ("sup_capacity", C.c_uint32), ("max_candidates", C.c_uint32), ("desc_tile_shift", C.c_uint32),
         ("stream_waves", C.c_uint32), ("stream_min_waves", C.c_uint32), ("arith", C.c_uint32), ("cu_ss", C.c_uint32),
-        ("cu_kp", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("cu_kp", C.c_uint32), ("resident_min_frames", C.c_uint32), ("reserved", C.c_uint32 * 4),
     ]
 
 
 OPT_KEEP_ALL, OPT_NO_FRAME_PAIRS, OPT_SERIAL_SUPPRESSION, OPT_NO_PIPELINE = 1, 2, 4, 8
-OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED, OPT_EQUAL_PRIORITY = 16, 32, 64, 128, 256, 512, 1024
+OPT_STREAM_PRIORITY, OPT_CONTRAST_EXACT, OPT_CONTRAST_FORCE_ODD, OPT_TILE_KERNELS, OPT_SERIAL_DET, OPT_SPLIT_FRONT_FED, OPT_EQUAL_PRIORITY, OPT_NO_RESIDENT_LEVELS = 16, 32, 64, 128, 256, 512, 1024, 2048
 HM_OPT_NO_FP4, HM_OPT_NO_MFMA, HM_OPT_STREAM_PRIORITY, HM_OPT_NO_LDS_DMA = 1, 2, 4, 8
 FMT_U8, FMT_F32, FMT_U16 = 0, 1, 2
 ARITH_REDUCE_PAIRWISE, ARITH_FMA, ARITH_HALF_SEQUENTIAL = 1, 2, 4
 
 
 BOOL_OPTIONS = ("keep_all", "frame_pairs", "parallel_suppression", "pipeline", "stream_priority", "stream_kernels",
-                "det_side_stream", "fuse_front_fed")
+                "det_side_stream", "fuse_front_fed", "resident_levels")
 
 
 def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pipeline=True, stream_priority=True,
                  contrast="fine", fed_block=0, sup_capacity=0, max_candidates=0, desc_tile_shift=0, stream_kernels=True,
-                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True, arith=0, cu_ss=0, cu_kp=0):
+                 stream_waves=0, stream_min_waves=0, det_side_stream=True, fuse_front_fed=True, arith=0, cu_ss=0, cu_kp=0,
+                 resident_levels=True, resident_min_frames=0):
     """Options with readable names.  contrast: "fine" (default), "exact", "force_odd".  arith: AKZ_ARITH_* bits (1: pairwise
     reduce_add, 2: fused mul_add, 4: sequential 2 x 2 sum) — the one option that changes results (include/akz.h)."""
     o = Options()
@@ -71,11 +72,13 @@ def make_options(keep_all=False, frame_pairs=True, parallel_suppression=True, pi
                | (0 if parallel_suppression else OPT_SERIAL_SUPPRESSION) | (0 if pipeline else OPT_NO_PIPELINE)
                | (0 if stream_priority else OPT_EQUAL_PRIORITY) | (0 if stream_kernels else OPT_TILE_KERNELS)
                | (0 if det_side_stream else OPT_SERIAL_DET) | (0 if fuse_front_fed else OPT_SPLIT_FRONT_FED)
+               | (0 if resident_levels else OPT_NO_RESIDENT_LEVELS)
                | {"fine": 0, "exact": OPT_CONTRAST_EXACT, "force_odd": OPT_CONTRAST_FORCE_ODD}[contrast])
     o.fed_block, o.sup_capacity, o.max_candidates, o.desc_tile_shift = fed_block, sup_capacity, max_candidates, desc_tile_shift
     o.stream_waves, o.stream_min_waves = stream_waves, stream_min_waves
     o.arith = arith
     o.cu_ss, o.cu_kp = cu_ss, cu_kp
+    o.resident_min_frames = resident_min_frames
     return o
 
 
@@ -121,7 +124,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("size", "
 NB_DTYPE = np.dtype([("index", "<u4"), ("distance", "<u4")])
 assert KP_DTYPE.itemsize == 28 and NB_DTYPE.itemsize == 8
 
-ABI_VERSION = 7          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
+ABI_VERSION = 8          # include/akz.h AKZ_ABI_VERSION this file's argtypes were written against
 
 # every symbol include/akz.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -135,7 +138,7 @@ ABI_SYMBOLS = [
     "hm_timing_get",
     "hm_stream", "rs_create", "rs_destroy", "rs_calibrate", "rs_essential_batch", "rs_essential_arrsac", "rs_p3p_arrsac", "rs_arrsac_samples",
     "rs_p3p_batch", "rs_debug_counts", "rs_debug_poses", "rs_batch_reserve", "rs_essential_arrsac_batch_device", "rs_sync",
-    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "hm_landmark_matches_batch_device", "hm_set_targets", "hm_targets_generation", "hm_knn_targets", "rs_debug_scene_world", "rs_debug_far",
+    "rs_stream", "rs_debug_scene", "rs_debug_residuals", "rs_p3p_arrsac_batch_device", "hm_landmark_pairs_batch_device", "hm_landmark_matches_batch_device", "hm_landmark_matches_ordered_batch_device", "hm_set_targets", "hm_targets_generation", "hm_knn_targets", "rs_debug_scene_world", "rs_debug_far",
     "akz_strerror", "akz_last_hip_error", "akz_last_hip_error_string", "akz_version", "akz_abi_version",
     "akz_timing_enable", "akz_timing_reset", "akz_timing_get",
     "akz_comm_unique_id", "akz_comm_create", "akz_comm_destroy", "akz_comm_shift_blocks", "akz_comm_allgather_blocks", "akz_comm_sync",
@@ -218,6 +221,7 @@ def lib():
     L.hm_knn_targets.argtypes = [vp, vp, u32, u32, vp]
     L.hm_landmark_pairs_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
     L.hm_landmark_matches_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
+    L.hm_landmark_matches_ordered_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp]
     L.hm_match.argtypes = [vp, vp, u32, vp, u32, i32, u32, C.c_float, i32, vp, u32, C.POINTER(u32)]
     L.hm_match_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, i32, u32, C.c_float, i32, vp, vp, vp]
     L.hm_sync.argtypes = [vp]

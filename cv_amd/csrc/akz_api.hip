@@ -166,7 +166,7 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
             if (o.cu_ss > 32 || o.cu_kp > 32) return AKZ_E_INVALID;
             for (uint32_t r : o.reserved)
                 if (r) return AKZ_E_INVALID;
-            if (o.flags & ~((AKZ_OPT_EQUAL_PRIORITY << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
+            if (o.flags & ~((AKZ_OPT_NO_RESIDENT_LEVELS << 1) - 1u)) return AKZ_E_INVALID;   // unknown switches
             if (o.fed_block > 8 || (o.desc_tile_shift != 0 && (o.desc_tile_shift < 2 || o.desc_tile_shift > 9))) return AKZ_E_INVALID;
             if (o.arith > 7u) return AKZ_E_INVALID;
             // sizes that would only surface as an opaque allocation failure (or wrap in an int) otherwise
@@ -211,6 +211,8 @@ extern "C" int32_t akz_create_ex(const akz_config* cfg, int32_t device, int32_t 
         c->stream_kernels = !(o.flags & AKZ_OPT_TILE_KERNELS);
         c->det_side_stream = !(o.flags & AKZ_OPT_SERIAL_DET);
         c->fuse_front_fed = !(o.flags & AKZ_OPT_SPLIT_FRONT_FED);
+        c->resident_levels = !(o.flags & AKZ_OPT_NO_RESIDENT_LEVELS);
+        c->resident_min_frames = (int)o.resident_min_frames;
         c->arith = (int)o.arith;
         if (o.stream_waves) c->det_stream_waves = (int)o.stream_waves;
         if (o.stream_min_waves) c->stream_min_waves = (size_t)o.stream_min_waves;

@@ -103,6 +103,8 @@ struct akz_ctx {
     hipStream_t stream_det = nullptr;
     bool det_side_stream = true;        // AKZ_OPT_SERIAL_DET clears it
     bool fuse_front_fed = true;         // k_front_fed where it applies (AKZ_OPT_SPLIT_FRONT_FED clears it)
+    bool resident_levels = true;        // k_level_resident where a level fits one compute unit (AKZ_OPT_NO_RESIDENT_LEVELS clears it)
+    int resident_min_frames = 0;        // ... for calls of at least this many frames (0: 3/8 of the compute units)
     hipEvent_t ev_level[kAkzMaxLevels] = {};   // {Lx, Ly} of level l written (recorded on `stream`)
     hipEvent_t ev_det_done = nullptr;          // every determinant kernel of the call finished (recorded on `stream_det`)
     bool sup_parallel = true;           // AKZ_SUP_PARALLEL=0: serial suppression only

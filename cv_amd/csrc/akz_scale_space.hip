@@ -1828,6 +1828,357 @@ __global__ __launch_bounds__(256, kFFWaves) void k_front_fed(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A whole level of a SMALL octave on ONE compute unit: front end + EVERY FED step of the level in one launch, the image in
+// registers for the whole diffusion, no halo, no Lflow, one pass over HBM (4 B in, 4 B Lt + 8 B {Lx, Ly} out per pixel).
+// lib.rs:230-256 for level i:  Lsmooth = blur(Lt, 1.0);  Lflow = pm_g2(simple Scharr(Lsmooth));  {Lx, Ly} = multiscale
+// Scharr(Lsmooth);  then every tau of the level's FED cycle (nonlinear_diffusion.rs:14-58).
+//
+// The tile kernels above spend the deeper octaves on halos and launches: octave 3 of a 1080p pyramid (240 x 135, 17-29 steps
+// per level) takes 13 launches of 64 x 64 windows of which 48 x 48 are useful, re-fetched and re-stored every 8 steps.  Here
+// one workgroup holds one frame: a wave is a row of 4-column patches (lane = patch column, 256 pixels a wave), the waves
+// stack vertically, and the frame is cut into an UPPER half (image rows [0, S)) and a LOWER half (rows [S, h)), S = waves x R:
+// a thread owns an R x 4 patch at the same position of both halves and holds them as {upper, lower} pairs — the packed
+// arithmetic of the two-frame kernels (v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar instruction), with the
+// two "frames" being the two halves of one image.  Every expression is the two-frame kernels' (k_front_fed's phases, k_fed_pair's
+// step); what is new is the seam and the borders:
+//   * the halves meet at rows S - 1 | S: the last wave's patch continues in the first wave's LOWER patch.  In the FED steps that
+//     is two re-addressed exchange reads (the last wave takes the first wave's top row's LOWER half as the row below its
+//     UPPER half; the first wave takes the last wave's UPPER bottom-edge flow as the flow above its LOWER half) — every other
+//     edge of the two halves is an image border (a zero step size, as in fed_steps);
+//   * the stencil phases (vertical blur pass, simple Scharr, multiscale Scharr) read a plane of {upper, lower} pairs in LDS
+//     whose apron (4 rows / columns around the S x w body) and out-of-image body rows are filled by ONE rule, res_fill_apron:
+//     every position holds the value at its CLAMPED IMAGE coordinate — across the seam that is the other half's data,
+//     beyond the image the reference's edge replication (image.rs:230-236, :287-300);
+//   * the horizontal blur pass takes its neighbours' columns from the adjacent lanes (DPP wave shifts), clamped at lanes 0 and
+//     w / 4 - 1.
+// LDS: the plane ((w + 8) x (S + 8) pairs: 151 KB at 240 x 135) and, once it is dead, the FED exchange buffers in its place.
+// Used for levels below the first octave with w % 4 == 0, w <= 256, h <= 2 * 16 * R and a plane that fits (akz_resident_fits).
+constexpr int kResMaxSteps = 64;                 // FED steps of one level (level 15 of the default pyramid: 29)
+struct FedTausN {
+    float half_tau[kResMaxSteps];
+};
+constexpr int kResLdsBytes = 160 * 1024 - 2048;   // the kernel's static LDS block (a CU has 160 KB)
+#ifndef AKZ_RES_R
+#define AKZ_RES_R 6        // 12 waves x 6 rows x 2 halves: 144 rows (168 registers a thread at three waves per SIMD)
+#define AKZ_RES_WAVES 12
+#endif
+
+// plane element (row, col), both apron-inclusive (image row j of a half is row j + 4, column c is col c + 4): 16-byte chunks of
+// two columns, even chunks first (ff_chunk's order: the lanes of a wave, which read chunks two apart, touch consecutive words)
+__device__ __forceinline__ int res_chunk(int rs, int row, int ci) { return row * rs + ((ci & 1) ? (rs >> 1) : 0) + (ci >> 1); }
+__device__ __forceinline__ int res_elem(int rs, int row, int col) { return 2 * res_chunk(rs, row, col >> 1) + (col & 1); }
+
+// Every plane position that is not an in-image body position takes the image's value at its clamped coordinate.
+// Upper half (.x) position (j, c) is image pixel (j, c), lower half (.y) position (j, c) is image pixel (S + j, c); an image
+// pixel (y, x), clamped to the image, lives in the body at (y, x).x for y < S and at (y - S, x).y otherwise.  Reads touch
+// in-image components only, writes out-of-image components only (the caller's barriers sit around the call).
+__device__ __forceinline__ void res_fill_apron(v2f* __restrict__ plane, int rs, int w, int h, int S, int tid, int nthreads)
+{
+    const int PW = w + 8, hb = h - S;
+    auto src = [&](int y_img, int c) -> float {
+        y_img = clampi(y_img, 0, h - 1);
+        const int cc = clampi(c, 0, w - 1);
+        const bool lower = y_img >= S;
+        const v2f e = plane[res_elem(rs, (lower ? y_img - S : y_img) + 4, cc + 4)];
+        return lower ? e.y : e.x;
+    };
+    // 1: the four apron rows above and below, full width; 2: the four apron columns either side of the body rows;
+    // 3: the body rows of the lower half that lie below the image (lower component only)
+    const int n1 = 8 * PW, n2 = 8 * S, n3 = (S - hb) * w;
+    for (int idx = tid; idx < n1 + n2 + n3; idx += nthreads) {
+        int j, c;
+        bool only_lower = false;
+        if (idx < n1) {
+            const int q = idx / PW;
+            c = idx - q * PW - 4;
+            j = q < 4 ? q - 4 : S + (q - 4);
+        } else if (idx < n1 + n2) {
+            const int t = idx - n1, e = t & 7;
+            j = t >> 3;
+            c = e < 4 ? e - 4 : w + (e - 4);
+        } else {
+            const int t = idx - n1 - n2, q = t / w;
+            c = t - q * w;
+            j = hb + q;
+            only_lower = true;
+        }
+        const float lo = src(S + j, c);
+        if (only_lower) reinterpret_cast<float*>(plane)[2 * res_elem(rs, j + 4, c + 4) + 1] = lo;
+        else plane[res_elem(rs, j + 4, c + 4)] = (v2f){src(j, c), lo};
+    }
+}
+
+// The FED steps of k_fed_pair / fed_steps on R x 4 patches of {upper, lower} pairs (see above).  zb[r]: row r of the LOWER
+// patch is the image's last row or lies below it (its downward flow takes a zero step); the upper half has no such row —
+// below its last row the lower half begins.  Exchange slots are per thread; `dn` / `up` name the thread below / above, for
+// the last / first wave the first / last wave's thread of the same lane (the seam).
+template <int R>
+__device__ __forceinline__ void fed_steps_halves(v2f (&L)[R][4], v2f (&C)[R][4], float4* __restrict__ s_top,
+                                                 float4* __restrict__ s_ct, float4* __restrict__ s_vd, const FedTausN& taus,
+                                                 int nsteps, int tid, int up, int dn, bool first_wave, bool last_wave,
+                                                 bool z_right, const bool (&zb)[R])
+{
+    s_ct[tid * 2] = make_float4(C[0][0].x, C[0][0].y, C[0][1].x, C[0][1].y);
+    s_ct[tid * 2 + 1] = make_float4(C[0][2].x, C[0][2].y, C[0][3].x, C[0][3].y);
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        const float htf = taus.half_tau[t];
+        const v2f ht = splat(htf);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(C[r][c]));   // (as fed_steps: no sums kept across the steps)
+        s_top[tid * 2] = make_float4(L[0][0].x, L[0][0].y, L[0][1].x, L[0][1].y);
+        s_top[tid * 2 + 1] = make_float4(L[0][2].x, L[0][2].y, L[0][3].x, L[0][3].y);
+        __syncthreads();
+        v2f vd[4];
+        {
+            const float4 a = s_top[dn * 2], b = s_top[dn * 2 + 1], c = s_ct[dn * 2], d = s_ct[dn * 2 + 1];
+            v2f Lb[4] = {(v2f){a.x, a.y}, (v2f){a.z, a.w}, (v2f){b.x, b.y}, (v2f){b.z, b.w}};
+            v2f Cb[4] = {(v2f){c.x, c.y}, (v2f){c.z, c.w}, (v2f){d.x, d.y}, (v2f){d.z, d.w}};
+            if (last_wave) {   // the row below the upper half is the lower half's first row (first wave, lower component);
+#pragma unroll                 // below the lower half there is nothing (zero step: any finite value)
+                for (int cc = 0; cc < 4; ++cc) {
+                    Lb[cc] = splat(Lb[cc].y);
+                    Cb[cc] = splat(Cb[cc].y);
+                }
+            }
+            const v2f ht3 = (v2f){htf, zb[R - 1] ? 0.0f : htf};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) vd[cc] = fed_flow2(ht3, C[R - 1][cc], Cb[cc], L[R - 1][cc], Lb[cc]);
+            s_vd[tid * 2] = make_float4(vd[0].x, vd[0].y, vd[1].x, vd[1].y);
+            s_vd[tid * 2 + 1] = make_float4(vd[2].x, vd[2].y, vd[3].x, vd[3].y);
+        }
+        const v2f htr = splat(z_right ? 0.0f : htf);
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) {
+            const v2f Lr = dpp_row<0x130>(L[r][0]), Cr = dpp_row<0x130>(C[r][0]);   // lane + 1 (wave_shl:1; 0 past lane 63)
+            v2f hf[5];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) hf[c] = fed_flow2(ht, C[r][c - 1], C[r][c], L[r][c - 1], L[r][c]);
+            hf[4] = fed_flow2(htr, C[r][3], Cr, L[r][3], Lr);
+            hf[0] = dpp_row<0x138>(hf[4]);                                            // lane - 1 (wave_shr:1; +0 into lane 0)
+            v2f vu[4];
+            if (r > 0) {
+                const v2f htu = (v2f){htf, zb[r > 0 ? r - 1 : 0] ? 0.0f : htf};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vu[c] = fed_flow2(htu, C[r - (r > 0)][c], C[r][c], L[r - (r > 0)][c], L[r][c]);
+            } else {
+                __syncthreads();
+                const float4 a = s_vd[up * 2], b = s_vd[up * 2 + 1];
+                vu[0] = (v2f){a.x, a.y}; vu[1] = (v2f){a.z, a.w}; vu[2] = (v2f){b.x, b.y}; vu[3] = (v2f){b.z, b.w};
+                if (first_wave) {   // nothing above the image's first row (+0: the skipped term); above the lower half the
+#pragma unroll                      // upper half's last row (last wave, upper component)
+                    for (int c = 0; c < 4; ++c) vu[c] = (v2f){0.0f, vu[c].x};
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                L[r][c] = (((L[r][c] + hf[c + 1]) - hf[c]) + vd[c]) - vu[c];   // nonlinear_diffusion.rs:31-52 order
+                vd[c] = vu[c];
+            }
+        }
+    }
+}
+
+template <int SG, int R, int NWMAX>
+__global__ __launch_bounds__(NWMAX * 64) void k_level_resident(const float* __restrict__ in, int w, int h, int S, size_t fs,
+                                                               GaussTaps taps, OffK k, FedTausN taus, int nsteps,
+                                                               float* __restrict__ out_lt, float2* __restrict__ out_xy,
+                                                               const float* __restrict__ invk, int invk_off)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kResLdsBytes];
+    v2f* plane = reinterpret_cast<v2f*>(s_raw);
+    float4* p4 = reinterpret_cast<float4*>(s_raw);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), NW = (int)(blockDim.x >> 6);
+    const int frame = blockIdx.x;
+    const int nl = w >> 2, rs = (w + 8) >> 1;
+    const int x0 = 4 * lane, r0 = wv * R;
+    const bool act = lane < nl, first_lane = lane == 0, last_lane = lane == nl - 1;
+    const float* src = in + (size_t)frame * fs;
+    bool vb[R];            // row r of the lower patch lies inside the image (the upper patch always does: S <= h - 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) vb[r] = S + r0 + r < h;
+    auto load_patch = [&](v2f (&L)[R][4]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;
+            if (act) {
+                la = *reinterpret_cast<const float4*>(at_bytes(src, (uint32_t)((r0 + r) * w + x0) << 2));
+                if (vb[r]) lb = *reinterpret_cast<const float4*>(at_bytes(src, (uint32_t)((S + r0 + r) * w + x0) << 2));
+            }
+            L[r][0] = (v2f){la.x, lb.x}; L[r][1] = (v2f){la.y, lb.y}; L[r][2] = (v2f){la.z, lb.z}; L[r][3] = (v2f){la.w, lb.w};
+        }
+    };
+    auto store_plane = [&](const v2f (&V)[R][4]) {   // the patch's rows into the plane body (both halves)
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                p4[res_chunk(rs, r0 + r + 4, 2 * lane + 2)] = make_float4(V[r][0].x, V[r][0].y, V[r][1].x, V[r][1].y);
+                p4[res_chunk(rs, r0 + r + 4, 2 * lane + 3)] = make_float4(V[r][2].x, V[r][2].y, V[r][3].x, V[r][3].y);
+            }
+        }
+    };
+    // ---- 1. Gaussian blur (sigma 1.0, 5 taps): horizontal pass from the neighbouring lanes' registers ----
+    v2f G[R][4];
+    {
+        v2f L[R][4];
+        load_patch(L);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v2f lm2 = dpp_row<0x138>(L[r][2]), lm1 = dpp_row<0x138>(L[r][3]);   // columns x0 - 2, x0 - 1 (lane - 1)
+            v2f rp0 = dpp_row<0x130>(L[r][0]), rp1 = dpp_row<0x130>(L[r][1]);   // columns x0 + 4, x0 + 5 (lane + 1)
+            if (first_lane) lm2 = lm1 = L[r][0];                                 // clamped columns (image.rs:230-236)
+            if (last_lane) rp0 = rp1 = L[r][3];
+            const v2f v[8] = {lm2, lm1, L[r][0], L[r][1], L[r][2], L[r][3], rp0, rp1};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) G[r][o] = lane4_dot_v<5>(v + o, taps.k);
+        }
+    }
+    store_plane(G);
+    __syncthreads();
+    res_fill_apron(plane, rs, w, h, S, tid, nthreads);
+    __syncthreads();
+    // vertical pass: rows r0 - 2 .. r0 + R + 1 of the patch's own columns
+    if (act) {
+        v2f win[5][4];
+#pragma unroll
+        for (int j = 0; j < R + 4; ++j) {
+            const f4v t0 = lds_chunk(p4 + res_chunk(rs, r0 + j + 2, 2 * lane + 2));
+            const f4v t1 = lds_chunk(p4 + res_chunk(rs, r0 + j + 2, 2 * lane + 3));
+            const int sl = j % 5;
+            win[sl][0] = (v2f){t0.x, t0.y}; win[sl][1] = (v2f){t0.z, t0.w};
+            win[sl][2] = (v2f){t1.x, t1.y}; win[sl][3] = (v2f){t1.z, t1.w};
+            if (j >= 4) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const v2f col[5] = {win[(j - 4) % 5][o], win[(j - 3) % 5][o], win[(j - 2) % 5][o], win[(j - 1) % 5][o], win[j % 5][o]};
+                    G[j - 4][o] = lane4_dot_v<5>(col, taps.k);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every thread has read its rows: the blurred image takes the plane
+    store_plane(G);
+    __syncthreads();
+    res_fill_apron(plane, rs, w, h, S, tid, nthreads);
+    __syncthreads();
+    // ---- 2a. multiscale Scharr first derivatives (derivatives.rs:23-49), taps at -SG, 0, +SG -> HBM ----
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            // plane rows Y - SG, Y, Y + SG, columns x0 - 4 .. x0 + 7
+            v2f m[12], z[12], p[12];
+            const int Y = r0 + j + 4;
+            constexpr int Q0 = (4 - SG) / 2, Q1 = (7 + SG) / 2;   // chunks that hold columns 4 - SG .. 7 + SG of the 12
+#pragma unroll
+            for (int q = Q0; q <= Q1; ++q) {
+                const f4v a = lds_chunk(p4 + res_chunk(rs, Y - SG, 2 * lane + q));
+                const f4v b = lds_chunk(p4 + res_chunk(rs, Y, 2 * lane + q));
+                const f4v c = lds_chunk(p4 + res_chunk(rs, Y + SG, 2 * lane + q));
+                m[2 * q] = (v2f){a.x, a.y}; m[2 * q + 1] = (v2f){a.z, a.w};
+                z[2 * q] = (v2f){b.x, b.y}; z[2 * q + 1] = (v2f){b.z, b.w};
+                p[2 * q] = (v2f){c.x, c.y}; p[2 * q + 1] = (v2f){c.z, c.w};
+            }
+            v2f rx[4], ry[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const v2f mm = m[4 + o - SG], m0 = m[4 + o], mp = m[4 + o + SG];
+                const v2f zm = z[4 + o - SG], zp = z[4 + o + SG];
+                const v2f pm = p[4 + o - SG], p0 = p[4 + o], pp = p[4 + o + SG];
+                rx[o] = off_combine_sg<SG>(k, mp - mm, zp - zm, pp - pm);
+                ry[o] = off_combine_sg<SG>(k, pm, p0, pp) - off_combine_sg<SG>(k, mm, m0, mp);
+            }
+            {
+                float4* xy = reinterpret_cast<float4*>(at_bytes(out_xy + (size_t)frame * fs, (uint32_t)((r0 + j) * w + x0) << 3));
+                xy[0] = make_float4(rx[0].x, ry[0].x, rx[1].x, ry[1].x);
+                xy[1] = make_float4(rx[2].x, ry[2].x, rx[3].x, ry[3].x);
+            }
+            if (vb[j]) {
+                float4* xy = reinterpret_cast<float4*>(at_bytes(out_xy + (size_t)frame * fs, (uint32_t)((S + r0 + j) * w + x0) << 3));
+                xy[0] = make_float4(rx[0].y, ry[0].y, rx[1].y, ry[1].y);
+                xy[1] = make_float4(rx[2].y, ry[2].y, rx[3].y, ry[3].y);
+            }
+        }
+    }
+    // ---- 2b. conductivity of the patch: simple Scharr (derivatives.rs:3-11) + pm_g2 (nonlinear_diffusion.rs:80) ----
+    v2f L[R][4], C[R][4];
+    load_patch(L);   // the image again (L2): the blur's copy did not stay in registers through the stencil phases
+    {
+        const v2f inverse_k = splat(invk[(size_t)frame * 8 + invk_off]);
+        v2f hx[3][4], hy[3][4];
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) {
+            // source row r0 - 1 + r, columns x0 - 2 .. x0 + 5
+            v2f v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4v t = (f4v){0.f, 0.f, 0.f, 0.f};
+                if (act) t = lds_chunk(p4 + res_chunk(rs, r0 + r + 3, 2 * lane + 1 + q));
+                v[2 * q] = (v2f){t.x, t.y};
+                v[2 * q + 1] = (v2f){t.z, t.w};
+            }
+            const int s = r % 3;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                hx[s][o] = v[o + 3] - v[o + 1];
+                hy[s][o] = (splat(3.0f) * v[o + 1] + splat(10.0f) * v[o + 2]) + splat(3.0f) * v[o + 3];
+            }
+            if (r >= 2) {
+                const int j = r - 2, sm = (r - 2) % 3, s0 = (r - 1) % 3, sp = r % 3;
+                v2f den[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const v2f lx = (splat(3.0f) * hx[sm][o] + splat(10.0f) * hx[s0][o]) + splat(3.0f) * hx[sp][o];
+                    const v2f ly = hy[sp][o] - hy[sm][o];
+                    den[o] = splat(1.0f) + inverse_k * (lx * lx + ly * ly);
+                }
+                // (as in k_level_front2: the packed reciprocal unless some denominator of the wave is not finite)
+                const v2f dsum = (den[0] + den[1]) + (den[2] + den[3]);
+                const bool odd = not_finite(dsum.x) || not_finite(dsum.y);
+                if (__any(odd)) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) C[j][o] = splat(1.0f) / den[o];
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) C[j][o] = rcp_pair_finite(den[o]);
+                }
+            }
+        }
+    }
+    // (k_fed_pair loads zeros outside the image: the lower patch's rows below the image, and the lanes right of it)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!act) C[r][c] = splat(0.0f);
+            else if (!vb[r]) C[r][c] = (v2f){C[r][c].x, 0.0f};
+        }
+    // ---- 3. every FED step of the level ----
+    __syncthreads();   // the plane is dead: the exchange buffers take its place
+    float4* s_top = p4;                           // [threads * 2]: top image rows
+    float4* s_vd = s_top + NWMAX * 64 * 2;        // bottom-edge flows
+    float4* s_ct = s_vd + NWMAX * 64 * 2;         // top rows of C
+    static_assert(3 * NWMAX * 64 * 2 * sizeof(float4) <= kResLdsBytes, "FED exchange buffers fit");
+    const bool first_wave = wv == 0, last_wave = wv == NW - 1;
+    const int up = first_wave ? (NW - 1) * 64 + lane : tid - 64, dn = last_wave ? lane : tid + 64;
+    bool zb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) zb[r] = S + r0 + r >= h - 1;
+    fed_steps_halves<R>(L, C, s_top, s_ct, s_vd, taus, nsteps, tid, up, dn, first_wave, last_wave, x0 + 4 >= w, zb);
+    if (act) {
+        float* dst = out_lt + (size_t)frame * fs;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            *reinterpret_cast<float4*>(at_bytes(dst, (uint32_t)((r0 + r) * w + x0) << 2)) = make_float4(L[r][0].x, L[r][1].x, L[r][2].x, L[r][3].x);
+            if (vb[r])
+                *reinterpret_cast<float4*>(at_bytes(dst, (uint32_t)((S + r0 + r) * w + x0) << 2)) = make_float4(L[r][0].y, L[r][1].y, L[r][2].y, L[r][3].y);
+        }
+    }
+}
+
 // Multiscale Scharr (derivatives.rs:23-79) evaluated sparsely: of the 2*sigma+1 taps only
 // {0, sigma, 2*sigma} are non-zero, and the reference's 4-lane summation puts them in lanes
 // {0, sigma&3, (2*sigma)&3}.  With the sequential lane reduce that collapses to
@@ -2545,6 +2896,22 @@ OffK make_offk(uint32_t sigma)
 
 inline dim3 grid_px(int w, int h, int n) { return dim3(akz_div_up(w, 64), akz_div_up(h, 4), n); }
 
+// k_level_resident's instantiation: rows per patch half and the most waves of a workgroup (kResWaves x 64 threads hold
+// kResWaves x kResR x 2 rows of up to 256 columns), and whether a w x h level fits: S = rows of the upper half, nw = waves.
+constexpr int kResR = AKZ_RES_R, kResWaves = AKZ_RES_WAVES;
+inline bool resident_geometry(int w, int h, int R, int nwmax, int* S_out, int* nw_out)
+{
+    if ((w & 3) != 0 || w < 8 || w > 256 || h < 4 * R) return false;
+    const int nw = akz_div_up((h + 1) / 2, R);
+    if (nw > nwmax) return false;
+    const int S = nw * R;
+    if (S > h - 1) return false;                                  // the lower half holds at least one image row
+    if ((size_t)((w + 8) / 2) * 16 * (size_t)(S + 8) > (size_t)kResLdsBytes) return false;   // the plane of pairs fits
+    *S_out = S;
+    *nw_out = nw;
+    return true;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2725,9 +3092,19 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             // The level an octave ends with hands the next octave its half-sized start image straight from the registers of
             // its last FED launch (fed_store_half) instead of being read back by k_half_size.  The image goes to the plane of
             // the level AFTER the next one, which nobody touches until that level's own diffusion.
+            // k_level_resident: the whole level (front end + every FED step) in one launch, one workgroup per frame, when
+            // the level is small enough to live on one compute unit (octave 3 of a 1080p pyramid; octaves >= 2 of smaller frames)
+            int res_S = 0, res_nw = 0;
+            // One workgroup per frame: a call of few frames leaves most compute units idle under it, and the tile kernels'
+            // many small launches win (1080p, octave 3, serial phase times: 64 frames 5.85 vs 5.78 ms of scale space, 96 frames
+            // a tie, 128 frames 10.74 vs 10.84, 256 frames 20.30 vs 20.82)
+            const int res_min = c->resident_min_frames > 0 ? c->resident_min_frames : (3 * c->n_cu + 7) / 8;
+            const bool resident = c->resident_levels && n >= res_min && blocked && L.octave > 0 && L.deriv_sigma >= 2 && L.deriv_sigma <= 4 &&
+                                  !c->keep_all && nsteps >= 1 && nsteps <= kResMaxSteps &&
+                                  resident_geometry(L.w, L.h, kResR, kResWaves, &res_S, &res_nw);
             float* half_next = nullptr;
             size_t half_next_fs = 0;
-            if (blocked && nsteps > 0 && i + 2 < nlev && P.levels[i + 1].new_octave && P.levels[i + 1].w == (L.w >> 1) &&
+            if (!resident && blocked && nsteps > 0 && i + 2 < nlev && P.levels[i + 1].new_octave && P.levels[i + 1].w == (L.w >> 1) &&
                 P.levels[i + 1].h == (L.h >> 1) && !P.levels[i + 2].new_octave) {
                 half_next = S.Lt[i + 2];
                 half_next_fs = P.levels[i + 1].pixels();
@@ -2741,6 +3118,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
                 // first one writes Lt[i], so the half-sized image goes to the scratch plane, and vice versa
                 float* half_dst = (nwrites % 2 == 0) ? bufA : bufB;
                 if (nwrites == 0) half_dst = bufA;
+                if (resident) half_dst = bufB;   // (one launch that writes Lt[i]: the start image goes to the scratch plane)
                 AKZ_TRY(AKZ_SS(akz_dev_half_size)(s, S.Lt[i - 1], half_dst, Lp.w, Lp.h, n, Lp.pixels(), fs));
                 init = half_dst;
             } else {
@@ -2748,6 +3126,25 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             }
             // lib.rs:232-248 — Lsmooth = blur(Lt, 1.0); Lx,Ly = simple Scharr; Lflow = pm_g2
             fused_front = L.deriv_sigma >= 2 && L.deriv_sigma <= 4;
+            if (resident) {
+                FedTausN ft;
+                for (int q = 0; q < kResMaxSteps; ++q) ft.half_tau[q] = q < nsteps ? 0.5f * (float)L.tau[q] : 0.0f;
+                OffK kk = make_offk(L.deriv_sigma);
+                akz_timer_begin(c, AKZ_T_LEVEL_RESIDENT, s);
+#define AKZ_RES(SGV)                                                                                                 \
+    AKZ_LAUNCH((k_level_resident<SGV, kResR, kResWaves>), dim3(n), dim3(res_nw * 64), 0, s, init, L.w, L.h, res_S, fs, t1, kk, ft,   \
+               nsteps, S.Lt[i], S.Lxy[i], (const float*)S.d_invk, (int)L.octave)
+                switch (L.deriv_sigma) {
+                case 2: AKZ_RES(2); break;
+                case 3: AKZ_RES(3); break;
+                default: AKZ_RES(4); break;
+                }
+#undef AKZ_RES
+                AKZ_LAUNCH_CHECK();
+                akz_timer_end(c, AKZ_T_LEVEL_RESIDENT, s, 1, (uint64_t)fs * n);
+                fed_launches += nsteps;
+                fed_units += (uint64_t)nsteps * fs * n;
+            } else {
             const int t_front = AKZ_T_FRONT_SG2 + (int)L.deriv_sigma - 2;
             // the FED launches of the level: groups of up to fed_block steps, balanced sizes (5 -> 3 + 2)
             std::vector<int> groups;
@@ -2873,6 +3270,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
             fed_units += (uint64_t)nsteps * fs * n;
             if (nsteps == 0 && init != bufA)
                 AKZ_HIP(hipMemcpyAsync(bufA, init, sizeof(float) * fs * n, hipMemcpyDeviceToDevice, s));
+            }   // !resident
             smooth = S.Lsm[i];
         }
         // detector_response.rs:60-67 + :33-57

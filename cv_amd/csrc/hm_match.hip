@@ -1445,8 +1445,9 @@ extern "C" int32_t hm_best_of_views_batch_device(hm_ctx* c, const void* d_knn, c
 // {feature, row of the world table} — exactly the pair-list form rs_p3p_arrsac_batch_device takes.  The world table is the
 // caller's: rows [0, n_world) by landmark key and, when a merge mask is given, rows n_world + f * cap + j = the merged
 // triangulation for feature j of frame f; a row with w < 0 (impossible for a Projective point) says "None".  The
-// reference's stable sort by observation count (:1561-1574) only fixes the order the consensus sees, which the seeded
-// shuffle replaces: it stays with the caller.
+// reference's stable sort by observation count (:1561-1574) fixes the order the consensus sees — and ARRSAC's sampling depends
+// on data order: given the per-landmark observation counts (hm_landmark_matches_ordered_batch_device) the kernel applies it,
+// a stable LSD radix sort in the same workgroup.
 constexpr uint32_t kLmSlots = 32768u;
 constexpr size_t kLmLdsBytes = sizeof(uint32_t) * (kLmSlots + kLmSlots / 32);
 __device__ __forceinline__ uint32_t lm_slot(uint32_t key) { return (key * 2654435761u) >> 17; }
@@ -1470,7 +1471,8 @@ __global__ __launch_bounds__(1024) void k_landmark_pairs(const uint2* __restrict
                                                          const uint8_t* __restrict__ merge_ok,
                                                          const uint32_t* __restrict__ nq, const uint32_t* __restrict__ iq,
                                                          uint32_t cap, const double* __restrict__ world, uint32_t n_world,
-                                                         uint2* __restrict__ pairs, uint32_t* __restrict__ npairs)
+                                                         uint2* __restrict__ pairs, uint32_t* __restrict__ npairs,
+                                                         const uint32_t* __restrict__ obs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);         // [kLmSlots] landmark keys (0xFFFFFFFF: empty)
@@ -1537,12 +1539,51 @@ __global__ __launch_bounds__(1024) void k_landmark_pairs(const uint2* __restrict
         __syncthreads();
     }
     if (tid == 0) npairs[f] = s_base;
+    if (!obs) return;
+    // 3. the order the reference's consensus sees (cv-sfm/src/lib.rs:1561-1574): a STABLE sort of the matches by the summed
+    // observation count of their landmarks, largest first — equal sums keep the feature order.  (The reference sorts before
+    // it drops the matches without a robust triangulation; a stable sort and an order-preserving filter commute.)  The hash
+    // set is dead: its LDS holds the keys and the two id buffers of the radix sort.
+    static_assert(3 * kRadixSortMax + 16 * 256 <= kLmSlots + kLmSlots / 32, "sort buffers fit in the hash set's LDS");
+    __shared__ uint32_t s_tot[256];
+    const uint32_t m = s_base;                       // (written before the last barrier of the loop above)
+    __syncthreads();                                  // every reader of the hash set is done
+    uint32_t* rk = tab;
+    uint32_t* ia = rk + kRadixSortMax;
+    uint32_t* ib = ia + kRadixSortMax;
+    uint32_t* wh = ib + kRadixSortMax;
+    for (uint32_t i = tid; i < m; i += 1024) {
+        const uint2 p = out[i];
+        const uint32_t l0 = bf[(size_t)p.x * 3].x;
+        uint32_t sum = l0 < n_world ? obs[l0] : 0u;
+        if (p.y >= n_world) {                         // a merged match: both landmarks count
+            const uint32_t l1 = bf[(size_t)p.x * 3 + 1].x;
+            const uint32_t o1 = l1 < n_world ? obs[l1] : 0u;
+            sum = sum + o1 < sum ? 0xFFFFFFFFu : sum + o1;
+        }
+        rk[i] = ~sum;                                 // ascending keys = descending sums
+        ia[i] = i;
+    }
+    __syncthreads();
+    const uint32_t* sorted = lds_radix_sort_ids(rk, ia, ib, wh, s_tot, m, 4);
+    uint2 mine[kRadixSortMax / 1024];
+#pragma unroll
+    for (uint32_t q = 0; q < kRadixSortMax / 1024; ++q) {
+        const uint32_t i = tid + 1024 * q;
+        mine[q] = i < m ? out[sorted[i]] : make_uint2(0u, 0u);
+    }
+    __syncthreads();                                  // every entry has been read before any is overwritten
+#pragma unroll
+    for (uint32_t q = 0; q < kRadixSortMax / 1024; ++q) {
+        const uint32_t i = tid + 1024 * q;
+        if (i < m) out[i] = mine[q];
+    }
 }
 
-extern "C" int32_t hm_landmark_matches_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_merge_ok,
-                                                    const void* d_nq, const uint32_t* iq, uint32_t cap_per_img, uint32_t n_frames,
-                                                    const void* d_world, uint32_t n_world, void* d_pairs, void* d_npairs,
-                                                    void* stream_to_wait)
+extern "C" int32_t hm_landmark_matches_ordered_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_merge_ok,
+                                                            const void* d_obs_counts, const void* d_nq, const uint32_t* iq,
+                                                            uint32_t cap_per_img, uint32_t n_frames, const void* d_world,
+                                                            uint32_t n_world, void* d_pairs, void* d_npairs, void* stream_to_wait)
 {
     return akz_guard([&]() -> int32_t {
         if (!c || !d_best || !d_decision || !d_nq || !iq || !d_world || !d_pairs || !d_npairs) return AKZ_E_INVALID;
@@ -1560,10 +1601,21 @@ extern "C" int32_t hm_landmark_matches_batch_device(hm_ctx* c, const void* d_bes
         AKZ_HIP(hipFuncSetAttribute((const void*)k_landmark_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLmLdsBytes));
         hipLaunchKernelGGL(k_landmark_pairs, dim3(n_frames), dim3(1024), kLmLdsBytes, c->stream, (const uint2*)d_best,
                            (const uint32_t*)d_decision, (const uint8_t*)d_merge_ok, (const uint32_t*)d_nq, (const uint32_t*)c->d_probs,
-                           cap_per_img, (const double*)d_world, n_world, (uint2*)d_pairs, (uint32_t*)d_npairs);
+                           cap_per_img, (const double*)d_world, n_world, (uint2*)d_pairs, (uint32_t*)d_npairs,
+                           (const uint32_t*)d_obs_counts);
         AKZ_LAUNCH_CHECK();
         return AKZ_OK;
     });
+}
+
+// the same in ascending feature order (no observation counts: the caller orders, or shuffles, the matches itself)
+extern "C" int32_t hm_landmark_matches_batch_device(hm_ctx* c, const void* d_best, const void* d_decision, const void* d_merge_ok,
+                                                    const void* d_nq, const uint32_t* iq, uint32_t cap_per_img, uint32_t n_frames,
+                                                    const void* d_world, uint32_t n_world, void* d_pairs, void* d_npairs,
+                                                    void* stream_to_wait)
+{
+    return hm_landmark_matches_ordered_batch_device(c, d_best, d_decision, d_merge_ok, nullptr, d_nq, iq, cap_per_img, n_frames, d_world,
+                                                    n_world, d_pairs, d_npairs, stream_to_wait);
 }
 
 // hm_landmark_matches_batch_device with no merge mask: no decision-2 match passes the caller's graph test.

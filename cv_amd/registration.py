@@ -84,10 +84,11 @@ class Registration:
         return self.cons.stream()
 
     def enqueue(self, d_kps, d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, d_world, n_world, stream_to_wait=None,
-                shuffle=True, d_merge_ok=None):
-        """match_views() followed by consensus(): the whole chain in one go (see the two for the arguments)."""
+                shuffle=None, d_merge_ok=None, d_obs_counts=None):
+        """match_views() followed by consensus(): the whole chain in one go (see the two for the arguments).  With
+        d_obs_counts the consensus sees the matches in register_frame_subset's own order (cv-sfm/src/lib.rs:1561-1574)."""
         self.match_views(d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, stream_to_wait=stream_to_wait)
-        self.consensus(d_kps, d_counts, d_world, n_world, shuffle=shuffle, d_merge_ok=d_merge_ok)
+        self.consensus(d_kps, d_counts, d_world, n_world, shuffle=shuffle, d_merge_ok=d_merge_ok, d_obs_counts=d_obs_counts)
 
     def match_views(self, d_descs, d_counts, frame_blocks, view_blocks, d_landmarks, stream_to_wait=None):
         """frame_blocks [F]: block index (into d_descs / d_counts / d_kps, [..][cap] each) of every new frame;
@@ -125,25 +126,31 @@ class Registration:
                                               d_landmarks.data_ptr(), d_counts.data_ptr(), self.better_by, self.best.data_ptr(),
                                               self.decision.data_ptr(), None), "hm_best_of_views_batch_device")
 
-    def consensus(self, d_kps, d_counts, d_world, n_world, shuffle=True, d_merge_ok=None, stream_to_wait=None):
+    def consensus(self, d_kps, d_counts, d_world, n_world, shuffle=None, d_merge_ok=None, stream_to_wait=None, d_obs_counts=None):
         """The duplicate-landmark filter, the FeatureWorldMatch lists and single_view_consensus.model_inliers for the frames of
         the last match_views().  d_world [rows][4] f64: rows [0, n_world) indexed by landmark key.  d_merge_ok [F][cap] uint8
         (optional): the caller's are_landmarks_sharing_view verdicts for the merge candidates (decision 2,
         cv-sfm/src/lib.rs:1521-1531, read from self.decision after match_views()) — non-zero admits ([best0, best1], feature)
         as a match, whose world point is row n_world + f * cap + feature of d_world (triangulate_merged_landmark_robust; d_world
         then has n_world + F * cap rows); stream_to_wait = the stream the mask and those rows were written on.  Without a mask no
-        merge candidate becomes a match — equal to the reference exactly when none passes its graph test.  Outputs:
-        self.pairs / npairs, self.pose / best_id / inliers / n_inliers / stats."""
+        merge candidate becomes a match — equal to the reference exactly when none passes its graph test.
+        d_obs_counts [n_world] uint32 (optional): observations of every landmark key — the match lists then leave in the
+        reference's order (stable sort by descending observation count, cv-sfm/src/lib.rs:1561-1574) and the consensus takes
+        them as they are (shuffle defaults to False); without it the lists are in feature order and shuffled with the seed
+        (shuffle defaults to True).  Outputs: self.pairs / npairs, self.pose / best_id / inliers / n_inliers / stats."""
+        if shuffle is None:
+            shuffle = d_obs_counts is None
         L = _lib.lib()
         cur, fb = self._cur, self._fb
         F = len(fb)
         _, fb_p = _u32(fb)
         rows = n_world if d_merge_ok is None else n_world + F * self.cap
         assert d_world.shape[0] >= rows
-        check(L.hm_landmark_matches_batch_device(self.matcher.handle, self.best.data_ptr(), self.decision.data_ptr(),
-                                                 None if d_merge_ok is None else d_merge_ok.data_ptr(), d_counts.data_ptr(), fb_p,
-                                                 self.cap, F, d_world.data_ptr(), n_world, self.pairs.data_ptr(),
-                                                 self.npairs.data_ptr(), stream_to_wait), "hm_landmark_matches_batch_device")
+        check(L.hm_landmark_matches_ordered_batch_device(self.matcher.handle, self.best.data_ptr(), self.decision.data_ptr(),
+                                                         None if d_merge_ok is None else d_merge_ok.data_ptr(),
+                                                         None if d_obs_counts is None else d_obs_counts.data_ptr(), d_counts.data_ptr(),
+                                                         fb_p, self.cap, F, d_world.data_ptr(), n_world, self.pairs.data_ptr(),
+                                                         self.npairs.data_ptr(), stream_to_wait), "hm_landmark_matches_ordered_batch_device")
         self.cons.p3p_model_inliers_batch_device(d_kps.data_ptr(), self.cap, [int(b) for b in fb], self.pairs.data_ptr(),
                                                  self.npairs.data_ptr(), d_world.data_ptr(), rows, self.cam, self.prm,
                                                  self.pose.data_ptr(), self.best_id.data_ptr(), self.inliers.data_ptr(),

@@ -107,7 +107,9 @@ enum {
                                            * the side stream that takes them off the Lt -> Lt dependency chain */
     AKZ_OPT_SPLIT_FRONT_FED = 1u << 9,    /* level front end and first FED launch as two kernels (Lflow through HBM)
                                            * instead of the fused k_front_fed */
-    AKZ_OPT_EQUAL_PRIORITY = 1u << 10     /* all streams of the context at the default priority */
+    AKZ_OPT_EQUAL_PRIORITY = 1u << 10,    /* all streams of the context at the default priority */
+    AKZ_OPT_NO_RESIDENT_LEVELS = 1u << 11 /* the tile kernels (k_front_fed + k_fed_pair launches) also for the levels small enough
+                                           * to live on one compute unit, instead of k_level_resident */
 };
 typedef struct akz_options {
     uint32_t struct_size;     /* sizeof(akz_options) of the caller (lets the struct grow) */
@@ -125,7 +127,10 @@ typedef struct akz_options {
                                * hipStreamNonBlocking, so it OVERRIDES AKZ_OPT_EQUAL_PRIORITY (no priorities at all) and is a
                                * blocking stream — it synchronises implicitly with the NULL stream of the process.  The same
                                * holds for HM_OPT_CU_MASK against HM_OPT_STREAM_PRIORITY. */
-    uint32_t reserved[5];     /* must be zero */
+    uint32_t resident_min_frames; /* fewest frames of a call for which k_level_resident (one workgroup per frame) takes the levels that
+                               * fit one compute unit; 0 = default (3/8 of the device's compute units: a call of fewer frames leaves
+                               * most of the chip idle under it and keeps the tile kernels); 1 = always (tests) */
+    uint32_t reserved[4];     /* must be zero */
 } akz_options;
 /* akz_options.arith — the only option that CHANGES RESULTS.  Three pieces of the reference's arithmetic live in crates that
  * are not vendored in rust-cv/cv, and its known answers (399 / 343 descriptors, 11 matches) come out the same under all
@@ -347,11 +352,22 @@ int32_t hm_best_of_views_batch_device(hm_ctx* ctx, const void* d_knn, const void
  * Projective point) or a landmark key >= n_world says "None".  d_best / d_decision / d_nq / iq as
  * hm_best_of_views_batch_device wrote / took them; d_pairs [n_frames][cap][2] u32 {feature, world row} in ascending feature
  * order, d_npairs [n_frames] — the pair lists rs_p3p_arrsac_batch_device takes (with n_world + n_frames * cap rows when a
- * merge mask is given).  cap_per_img <= 8192.  (The reference's stable sort by observation count, :1561-1574, only fixes
- * the order the consensus sees and stays with the caller.) */
+ * merge mask is given).  cap_per_img <= 8192.  (Ascending feature order: the order for a caller that shuffles the
+ * matches itself, RS_BATCH_SHUFFLE; the reference's own order is the next entry point's.) */
 int32_t hm_landmark_matches_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_merge_ok,
                                          const void* d_nq, const uint32_t* iq, uint32_t cap_per_img, uint32_t n_frames,
                                          const void* d_world, uint32_t n_world, void* d_pairs, void* d_npairs, void* stream_to_wait);
+/* The same lists IN THE ORDER THE REFERENCE HANDS TO THE CONSENSUS (cv-sfm/src/lib.rs:1561-1574): original_matches is stably
+ * sorted by Reverse(sum over the match's landmarks of landmark(..).observations.len()) before model_inliers (:1619-1622) sees
+ * it — matches on well-observed landmarks first, equal sums in feature order — and a consensus that samples by position
+ * (ARRSAC does) depends on it.  d_obs_counts [n_world] u32: observations of every landmark key (the caller's graph knows them;
+ * a key >= n_world counts 0); both landmarks of a merged match count.  The sort runs on the device, in the kernel that
+ * builds the list (a stable LSD radix sort in LDS); with d_obs_counts == NULL this is hm_landmark_matches_batch_device.
+ * Pass the lists to rs_p3p_arrsac_batch_device WITHOUT RS_BATCH_SHUFFLE to keep the order. */
+int32_t hm_landmark_matches_ordered_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_merge_ok,
+                                                 const void* d_obs_counts, const void* d_nq, const uint32_t* iq, uint32_t cap_per_img,
+                                                 uint32_t n_frames, const void* d_world, uint32_t n_world, void* d_pairs,
+                                                 void* d_npairs, void* stream_to_wait);
 /* hm_landmark_matches_batch_device without a merge mask (equals the reference when no decision-2 match passes the graph test). */
 int32_t hm_landmark_pairs_batch_device(hm_ctx* ctx, const void* d_best, const void* d_decision, const void* d_nq, const uint32_t* iq,
                                        uint32_t cap_per_img, uint32_t n_frames, const void* d_world, uint32_t n_world,
@@ -602,7 +618,7 @@ const char* akz_version(void);
 /* The ABI number: raised whenever a declared signature, struct layout or enum value of this header changes (additions
  * included).  A binding compares akz_abi_version() of the library it loaded with the AKZ_ABI_VERSION it was written against
  * and refuses to run on a mismatch (cv_amd/_lib.py, rust/akaze-mi355x/src/lib.rs, include/akaze.hpp do). */
-#define AKZ_ABI_VERSION 7u
+#define AKZ_ABI_VERSION 8u
 uint32_t akz_abi_version(void);
 
 /* HIP-event timing of the kernel families of a batch (bench.py's roofline objects).  Kernel families (every id but the
@@ -639,7 +655,9 @@ enum {
     AKZ_T_FRONT_FED_DEEP_SG2 = 26, /* k_front_fed on levels BELOW the first octave (two-patch halo for launches of 5..8 steps; Lflow is */
     AKZ_T_FRONT_FED_DEEP_SG3 = 27, /* written when a later launch of the level reads it), sigma 2..4: ids 26..28, units: pixel-frames */
     AKZ_T_FRONT_FED_DEEP_SG4 = 28,
-    AKZ_T_COUNT = 29
+    AKZ_T_LEVEL_RESIDENT = 29, /* k_level_resident: front end + EVERY FED step of a level that fits one compute unit (octave 3 of a 1080p
+                                * pyramid), one launch per level, one workgroup per frame; units: pixel-frames */
+    AKZ_T_COUNT = 30
 };
 int32_t akz_timing_enable(akz_ctx* ctx, int32_t on);
 int32_t akz_timing_reset(akz_ctx* ctx);

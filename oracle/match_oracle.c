@@ -229,6 +229,57 @@ uint32_t orc_landmark_matches(const uint32_t* best, const uint32_t* decision, co
     }
     return n;
 }
+/* The same list in the order the reference hands to the consensus (cv-sfm/src/lib.rs:1549-1604): original_matches in feature
+ * order (:1489-1542 walks the features in order), `retain` of the matches whose landmarks were all counted once (:1555-1559),
+ * then `sort_by_key(Reverse(sum of landmark(..).observations.len()))` (:1561-1574) — a STABLE sort: equal sums keep the
+ * feature order —, then the filter_map that drops matches without a robust triangulation (:1583-1604).  obs[l] = number of
+ * observations of landmark key l (l < n_world; a key beyond the table counts 0). */
+uint32_t orc_landmark_matches_ordered(const uint32_t* best, const uint32_t* decision, const uint8_t* merge_ok, const uint32_t* obs,
+                                      uint32_t nq, const double* world, uint32_t n_world, uint32_t merged_base, uint32_t* pairs)
+{
+    uint32_t* feat = (uint32_t*)malloc(sizeof(uint32_t) * (nq ? nq : 1));
+    uint64_t* key = (uint64_t*)malloc(sizeof(uint64_t) * (nq ? nq : 1));
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < nq; ++i) {                       /* retain */
+        const uint32_t k = orc_lm_kind(best, decision, merge_ok, i);
+        if (k == 0) continue;
+        const uint32_t l0 = best[(size_t)i * 6], l1 = best[(size_t)i * 6 + 2];
+        if (orc_lm_claims(best, decision, merge_ok, nq, l0) != 1) continue;
+        if (k == 2 && orc_lm_claims(best, decision, merge_ok, nq, l1) != 1) continue;
+        uint64_t sum = l0 < n_world ? obs[l0] : 0;
+        if (k == 2) sum += l1 < n_world ? obs[l1] : 0;
+        feat[m] = i;
+        key[m] = sum;
+        m++;
+    }
+    for (uint32_t a = 1; a < m; ++a) {                        /* stable insertion sort, descending sums */
+        const uint32_t f = feat[a];
+        const uint64_t kk = key[a];
+        uint32_t b = a;
+        while (b > 0 && key[b - 1] < kk) {
+            feat[b] = feat[b - 1];
+            key[b] = key[b - 1];
+            b--;
+        }
+        feat[b] = f;
+        key[b] = kk;
+    }
+    uint32_t n = 0;
+    for (uint32_t a = 0; a < m; ++a) {                        /* filter_map: a robust world point */
+        const uint32_t i = feat[a];
+        const uint32_t k = orc_lm_kind(best, decision, merge_ok, i);
+        uint32_t row = best[(size_t)i * 6];
+        if (k == 2) row = merged_base + i;
+        else if (row >= n_world) continue;
+        if (!(world[(size_t)4 * row + 3] >= 0.0)) continue;
+        pairs[2 * n] = i;
+        pairs[2 * n + 1] = row;
+        n++;
+    }
+    free(feat);
+    free(key);
+    return n;
+}
 uint32_t orc_landmark_pairs(const uint32_t* best, const uint32_t* decision, uint32_t nq, const double* world, uint32_t n_world,
                             uint32_t* pairs)
 {

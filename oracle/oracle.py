@@ -477,7 +477,7 @@ def best_of_views(knn_out, nq, landmarks, view_idx, nviews, better_by=24):
     return best, dec
 
 
-def landmark_pairs(best, decision, world, merge_ok=None, n_world=None, merged_base=0):
+def landmark_pairs(best, decision, world, merge_ok=None, n_world=None, merged_base=0, obs_counts=None):
     """cv-sfm/src/lib.rs:1516-1532, 1549-1563, 1583-1604 (oracle/match_oracle.c: orc_landmark_matches): the (feature, world
     row) list of one frame from the best-of-views output; world [rows, 4] f64 (w < 0: no robust triangulation).  merge_ok
     [nq] (the caller's are_landmarks_sharing_view verdicts) admits decision-2 features as merged matches; their world point is
@@ -490,6 +490,16 @@ def landmark_pairs(best, decision, world, merge_ok=None, n_world=None, merged_ba
     L = lib()
     L.orc_landmark_matches.restype = C.c_uint32
     L.orc_landmark_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    if obs_counts is not None:
+        # ... in the order the reference's consensus sees them: stable sort by descending observation count (lib.rs:1561-1574)
+        ob = np.ascontiguousarray(obs_counts, np.uint32)
+        L.orc_landmark_matches_ordered.restype = C.c_uint32
+        L.orc_landmark_matches_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                   C.c_uint32, C.c_void_p]
+        n = L.orc_landmark_matches_ordered(best.ctypes.data, dec.ctypes.data, None if mk is None else mk.ctypes.data, ob.ctypes.data,
+                                           len(dec), W.ctypes.data, len(W) if n_world is None else n_world, merged_base,
+                                           out.ctypes.data)
+        return out[:n].copy()
     n = L.orc_landmark_matches(best.ctypes.data, dec.ctypes.data, None if mk is None else mk.ctypes.data, len(dec), W.ctypes.data,
                                len(W) if n_world is None else n_world, merged_base, out.ctypes.data)
     return out[:n].copy()

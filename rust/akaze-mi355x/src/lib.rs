@@ -64,7 +64,8 @@ struct AkzOptions {
     arith: u32,
     cu_ss: u32,
     cu_kp: u32,
-    reserved: [u32; 5],
+    resident_min_frames: u32,
+    reserved: [u32; 4],
 }
 
 extern "C" {
@@ -232,7 +233,7 @@ static ARITH: std::sync::atomic::AtomicU32 = std::sync::atomic::AtomicU32::new(0
 
 /// The thread's matcher context, grown to hold `n` descriptors a side.
 /// include/akz.h AKZ_ABI_VERSION these bindings were written against; the loaded library must export the same number.
-const AKZ_ABI_VERSION: u32 = 7;
+const AKZ_ABI_VERSION: u32 = 8;
 fn require_abi() {
     let got = unsafe { akz_abi_version() };
     assert_eq!(got, AKZ_ABI_VERSION, "libakz exports ABI {got}, akaze-mi355x was written against {AKZ_ABI_VERSION}");

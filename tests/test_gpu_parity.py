@@ -109,10 +109,15 @@ def _compare_pyramid(akaze, O, img, thr, what, ak=None, ocfg=None):
     _kp_eq(kp, okp, f"{what} final keypoints")
     _eq(desc, odesc, f"{what} descriptors")
     ctx.close()
-    ctx = akaze.Context(ak, w, h, 1)
+    ctx = akaze.Context(ak, w, h, 1, _opts(resident_min_frames=1))      # (default but for k_level_resident on a one-frame call)
     (kp2, desc2), = ctx.extract_batch([img])
     _kp_eq(kp2, okp, f"{what} final keypoints (default options)")
     _eq(desc2, odesc, f"{what} descriptors (default options)")
+    # the planes that outlive a default-options call (the descriptor stage samples them): the kernels the benchmark runs
+    # — k_front_fed, k_fed_pair's fused half-size, k_level_resident — leave the oracle's Lt, Lx, Ly at every level
+    for lvl in range(orc.num_levels):
+        for name in ("Lt", "Lx", "Ly"):
+            _eq(ctx.level_buffer(0, lvl, name, w, h), orc.buffer(lvl, name), f"{what} {name}[{lvl}] (default options)")
     ctx.close()
     return kp, desc
 
@@ -1075,11 +1080,14 @@ def _oracle_one(args):
     return O.Akaze(img.shape[1], img.shape[0], cfg).extract(img)
 
 
-def test_benchmark_mode_full_hd_pipelined_vs_oracle(gpu):
+@pytest.mark.parametrize("resident", [False, True], ids=["call-size defaults", "octave 3 resident as in a 256-frame call"])
+def test_benchmark_mode_full_hd_pipelined_vs_oracle(gpu, resident):
     """The configuration bench.py measures, checked against the ORACLE (not against the library's other API):
     default options (scratch-aliased Lsmooth/Lflow, no Ldet planes, two buffer sets, two streams), 1920x1080,
     an odd micro-batch (the last frame pair is half empty), three akz_extract_batch_device calls back to back with
-    no synchronisation in between; keypoints and descriptor bytes of all nine frames equal oracle.extract's."""
+    no synchronisation in between; keypoints and descriptor bytes of all nine frames equal oracle.extract's.
+    A call of 256 frames hands octave 3 (240 x 135) to k_level_resident, a call of three does not by itself:
+    `resident` asks for it (resident_min_frames = 1) so that the benchmark's kernel selection is the one under test."""
     import torch
     akaze, _ = gpu
     from cv_amd import _lib
@@ -1091,7 +1099,7 @@ def test_benchmark_mode_full_hd_pipelined_vs_oracle(gpu):
     d_frames = torch.from_numpy(np.stack(frames)).to(dev)
     ak = akaze.Akaze.default()
     ak.max_keypoints = CAP
-    ctx = akaze.Context(ak, W, H, B)
+    ctx = akaze.Context(ak, W, H, B, _opts(resident_min_frames=1) if resident else None)
     kps = torch.zeros((NCALL, B, CAP, 28), dtype=torch.uint8, device=dev)
     descs = torch.zeros((NCALL, B, CAP, 64), dtype=torch.uint8, device=dev)
     cnt = torch.zeros((NCALL, B), dtype=torch.int32, device=dev)
@@ -1721,6 +1729,8 @@ OPTION_SETS = [
     ("small candidate lists", dict(max_candidates=4096, desc_tile_shift=3)),
     ("determinant kernels on the scale-space stream", dict(det_side_stream=False)),
     ("front end and FED as two kernels", dict(fuse_front_fed=False)),
+    ("tile kernels for the levels that fit one compute unit", dict(resident_levels=False)),
+    ("one workgroup per frame for the levels that fit one compute unit, whatever the call size", dict(resident_min_frames=1)),
 ]
 
 
@@ -1738,6 +1748,32 @@ def test_every_option_gives_the_same_bits(gpu, oracle, name, kw):
             okp, od = orc.extract(f)
             _kp_eq(got[i][0], okp, f"{name} {w}x{h} frame {i}")
             _eq(got[i][1], od, f"{name} {w}x{h} frame {i} desc")
+        ctx.close()
+
+
+@pytest.mark.parametrize("w,h,nfr", [(960, 540, 1), (960, 540, 5), (1024, 512, 2), (1024, 576, 1), (640, 360, 3), (320, 180, 1),
+                                     (512, 96, 2), (168, 1100, 1)])
+def test_levels_resident_on_one_compute_unit(gpu, oracle, w, h, nfr):
+    """k_level_resident (a whole level — front end and every FED step — in one launch, one workgroup per frame, the frame cut
+    into an upper and a lower half that share every packed instruction): Lt, Lx, Ly of EVERY level, keypoints and descriptor
+    bytes equal the oracle's.  960x540: octave 2 is the 240 x 135 plane of a 1080p pyramid's octave 3 (odd height: the lower
+    half ends one row early); 1024x512 / 1024x576: a 256-column octave uses all 64 lanes of a wave (576: its plane no longer
+    fits and the tile kernels take that octave); 640x360 / 320x180: 160x90, 80x45, 40x22 levels (few lanes, few waves);
+    512x96: an octave of 24 rows, two waves; 168x1100: a tall narrow frame — 42 x 275 is too tall, 21-column levels are not
+    divisible by 4 (tile kernels / one-frame kernels).  The same frames with AKZ_OPT_NO_RESIDENT_LEVELS give the same bytes."""
+    akaze, _ = gpu
+    frames = [synth_frame(w, h, seed=7700 + 13 * i + w, n_rect=50, n_disc=50) for i in range(nfr)]
+    orc = oracle.Akaze(w, h, oracle.default_config())
+    for kw in (dict(resident_min_frames=1), dict(resident_levels=False)):     # (by default only calls of >= 96 frames take it)
+        ctx = akaze.Context(akaze.Akaze.default(), w, h, nfr, _opts(**kw))
+        got = ctx.extract_batch(frames)
+        for i in reversed(range(nfr)):        # (the oracle's buffers after the loop are frame 0's)
+            okp, od = orc.extract(frames[i])
+            _kp_eq(got[i][0], okp, f"{w}x{h} frame {i} {kw}")
+            _eq(got[i][1], od, f"{w}x{h} frame {i} desc {kw}")
+            for lvl in range(orc.num_levels):
+                for name in ("Lt", "Lx", "Ly"):
+                    _eq(ctx.level_buffer(i, lvl, name, w, h), orc.buffer(lvl, name), f"{w}x{h} frame {i} {name}[{lvl}] {kw}")
         ctx.close()
 
 
@@ -2115,8 +2151,9 @@ def test_comm_c_abi_on_one_rank(gpu):
                                            cur.cuda_stream), "akz_comm_shift_blocks")
         ad = torch.zeros((1, n, cap, 64), dtype=torch.uint8, device=dev)
         ac = torch.zeros((1, n), dtype=torch.int32, device=dev)
-        _lib.check(L.akz_comm_allgather_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, ad.data_ptr(), ac.data_ptr(), None),
-                   "akz_comm_allgather_blocks")
+        # (the zero fills run on torch's stream, the gather on the communicator's: it waits for them)
+        _lib.check(L.akz_comm_allgather_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, ad.data_ptr(), ac.data_ptr(),
+                                               cur.cuda_stream), "akz_comm_allgather_blocks")
         _lib.check(L.akz_comm_sync(h), "akz_comm_sync")
         assert torch.equal(rd[1:n + 1], descs) and torch.equal(rc[1:n + 1], counts)
         assert bool((rd[0] == 7).all()) and bool((rd[n + 1] == 7).all()) and int(rc[0]) == -1 and int(rc[n + 1]) == -1

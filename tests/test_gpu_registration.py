@@ -251,4 +251,27 @@ def test_landmark_matches_with_merge_candidates(gpu, oracle):
     g0, n0 = run(torch.zeros_like(d_ok))
     g1, n1 = run(None)
     assert np.array_equal(n0, n1) and np.array_equal(g0, g1)
+    # the order the reference's consensus sees (cv-sfm/src/lib.rs:1561-1574): a stable sort by descending summed observation
+    # count, applied on the device (hm_landmark_matches_ordered_batch_device).  Few distinct counts: long runs of ties that
+    # must keep their feature order; a frame of zero matches; counts whose sum needs more than 16 bits.
+    for obs_kind in ("ties", "wide"):
+        obs = (rng.integers(1, 5, n_world) if obs_kind == "ties" else rng.integers(0, 1 << 20, n_world)).astype(np.uint32)
+        d_obs = torch.from_numpy(obs.view(np.int32)).to(dev)
+        d_pairs = torch.full((F, cap, 2), -1, dtype=torch.int32, device=dev); d_np = torch.full((F,), 77, dtype=torch.int32, device=dev)
+        _lib.check(L.hm_landmark_matches_ordered_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), d_ok.data_ptr(), d_obs.data_ptr(),
+                                                              d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p), cap, F, d_world.data_ptr(), n_world,
+                                                              d_pairs.data_ptr(), d_np.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "landmark_matches_ordered")
+        _lib.check(L.hm_sync(m.handle), "hm_sync")
+        op, on = d_pairs.cpu().numpy().view(np.uint32), d_np.cpu().numpy()
+        moved = 0
+        for f in range(F):
+            n = int(nq[f])
+            want = oracle.landmark_pairs(best[f, :n], dec[f, :n], world, merge_ok=merge_ok[f, :n], n_world=n_world,
+                                         merged_base=n_world + f * cap, obs_counts=obs)
+            assert on[f] == len(want) == gn[f], (obs_kind, f)
+            assert np.array_equal(op[f, :on[f]], want), (obs_kind, f)
+            assert sorted(map(tuple, want.tolist())) == sorted(map(tuple, gp[f, :gn[f]].tolist()))     # the same matches, re-ordered
+            moved += int((want[:, 0] != gp[f, :gn[f], 0]).sum())
+        assert moved > 1000
     m.close()

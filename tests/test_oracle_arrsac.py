@@ -252,3 +252,46 @@ def test_registration_scene_entry(oracle):
     camk = cam[:5] + (-0.05,)
     rk = oracle.p3p_arrsac_pairs(kps, pr, world, camk, 1e-6, 64, scene=0, **kw)
     assert rk["bearings"].tobytes() == oracle.calibrate(kps[pr[:, 0]], *cam[:5], k1=-0.05).tobytes()
+
+
+def test_landmark_matches_in_the_reference_order(oracle):
+    """orc_landmark_matches_ordered against a literal Python restatement of cv-sfm/src/lib.rs:1549-1604: landmark_counts over
+    every landmark of every original match, retain, `sort_by_key(Reverse(sum of observations))` (Python's sort is stable, as
+    Rust's sort_by_key), filter_map of the robust world points."""
+    from collections import Counter
+    rng = np.random.default_rng(0x0B5)
+    for trial in range(6):
+        nq, n_world = int(rng.integers(50, 700)), 900
+        best = np.zeros((nq, 3, 2), np.uint32)
+        for j in range(nq):
+            best[j, :, 0] = rng.choice(n_world + 20, 3, replace=False)
+        best[rng.random(nq) < 0.05, 0, 0] = 0xFFFFFFFF
+        dec = rng.integers(0, 3, nq).astype(np.uint32)
+        merge_ok = (rng.random(nq) < 0.5).astype(np.uint8)
+        world = rng.standard_normal((n_world + nq, 4))
+        world[:, 3] = np.abs(world[:, 3])
+        world[rng.random(len(world)) < 0.25, 3] = -1.0
+        obs = rng.integers(1, 4 if trial % 2 else 1 << 18, n_world).astype(np.uint32)
+        original = []                                            # (landmarks, feature) in feature order
+        for j in range(nq):
+            l0, l1 = int(best[j, 0, 0]), int(best[j, 1, 0])
+            if l0 == 0xFFFFFFFF:
+                continue
+            if dec[j] == 1:
+                original.append(([l0], j))
+            elif dec[j] == 2 and merge_ok[j] and l1 != 0xFFFFFFFF:
+                original.append(([l0, l1], j))
+        counts = Counter(l for lms, _ in original for l in lms)
+        original = [(lms, j) for lms, j in original if all(counts[l] == 1 for l in lms)]
+        original.sort(key=lambda t: -sum(int(obs[l]) if l < n_world else 0 for l in t[0]))
+        want = []
+        for lms, j in original:
+            row = lms[0] if len(lms) == 1 else n_world + j
+            if len(lms) == 1 and row >= n_world:
+                continue
+            if world[row, 3] >= 0.0:
+                want.append((j, row))
+        got = oracle.landmark_pairs(best, dec, world, merge_ok=merge_ok, n_world=n_world, merged_base=n_world, obs_counts=obs)
+        assert [tuple(map(int, r)) for r in got] == want, trial
+        plain = oracle.landmark_pairs(best, dec, world, merge_ok=merge_ok, n_world=n_world, merged_base=n_world)
+        assert sorted(map(tuple, plain.tolist())) == sorted(want)

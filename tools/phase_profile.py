@@ -35,11 +35,12 @@ def main():
     frames = bench.make_frames(torch, dev, 0, MB, 1)
     ak = Akaze.default()
     ak.max_keypoints = CAP
+    from cv_amd import _lib
     kw = {}
     for kv in a.opt:
         key, val = kv.split("=")
         kw[key] = val if key == "contrast" else int(val)
-    for key in ("keep_all", "frame_pairs", "parallel_suppression", "stream_kernels", "stream_priority", "det_side_stream"):
+    for key in _lib.BOOL_OPTIONS:
         if key in kw:
             kw[key] = bool(kw[key])
     ctx = ak.context(W, H, MB, options=_lib.make_options(pipeline=False, **kw))
