@@ -1030,6 +1030,62 @@ def test_p3p_inlier_test_is_exact_at_the_threshold(gpu, oracle):
     assert checked >= 24
 
 
+def test_block_scoring_pre_test_is_exact_at_the_threshold(gpu, oracle):
+    """k_rsb_score_p3p (the ARRSAC-shaped loop's scoring kernel) decides most residuals on a FUSED estimate of [R | t] w,
+    allowed only for certified rotations and away from deep cancellation, and hands everything else to rs_w2c_inlier.  rs_p3p_arrsac with nothing to prune scores every pose against every match in one block: the
+    per-pose inlier counts must be the exhaustive oracle's (orc_p3p_batch) with thresholds EXACTLY on residuals of the
+    winning pose, one ulp either side; negative homogeneous weights; point scales far outside the ordinary range; and world
+    points within 1e-3 .. 1e-12 of the winning pose's camera centre (R w + t cancels: the guard's arm)."""
+    import ctypes as C
+    from cv_amd import _lib
+    from cv_amd.ransac import EssentialConsensus
+    from test_oracle_ransac import _projective, _rot
+    L = _lib.lib()
+    rng = np.random.default_rng(0xF05ED)
+    n = 640
+    Rr = _rot(rng.random(3) * 0.8); tr = rng.random(3)
+    pts = rng.random((n, 3)) * 4.0 - 2.0
+    pts[:, 2] += 6.0
+    centre = -Rr.T @ tr
+    near = np.arange(5, n, 9)
+    pts[near] = centre + rng.standard_normal((len(near), 3)) * (10.0 ** -rng.integers(3, 13, len(near)))[:, None]
+    cam = pts @ Rr.T + tr
+    bb = cam / np.linalg.norm(cam, axis=1, keepdims=True)
+    bb[near] = rng.standard_normal((len(near), 3)); bb[near] /= np.linalg.norm(bb[near], axis=1, keepdims=True)
+    bb += rng.standard_normal(bb.shape) * 1e-4
+    bb /= np.linalg.norm(bb, axis=1, keepdims=True)
+    world = _projective(pts)
+    world[::3] *= -1.0
+    world[1::7] *= 1e-150
+    world[2::7] *= 1e120
+    good = np.setdiff1d(np.arange(n), near)
+    samples = np.stack([rng.choice(good, 3, replace=False) for _ in range(96)]).astype(np.uint32)
+    cons = EssentialConsensus(1024, 1024)
+    wpose, wbest, winl, _ = oracle.p3p_batch(bb, world, samples, 1e-6)
+    res = np.array([oracle.w2c_residual(wpose, bb[i], world[i]) for i in range(n)])
+    assert np.isfinite(res[good]).all()
+    picks = list(np.argsort(res)[n // 4::n // 16][:8]) + list(near[:4])
+    checked = 0
+    for k in picks:
+        if not (np.isfinite(res[k]) and 0.0 < res[k] < 0.5):
+            continue
+        for thr in (res[k], np.nextafter(res[k], np.inf), np.nextafter(res[k], -np.inf)):
+            want = oracle.p3p_batch(bb, world, samples, float(thr))
+            prm = cons.make_params(float(thr), n_hypotheses=len(samples), seed=0, block_size=64, init_blocks=1, max_candidates=0,
+                                   bound=False, sprt=False)
+            pose = np.zeros((3, 4)); best = C.c_uint32(); inl = np.zeros(n, np.uint32); ninl = C.c_uint32()
+            st = L.rs_p3p_arrsac(cons._h, bb.ctypes.data, world.ctypes.data, n, samples.ctypes.data, C.byref(prm), pose.ctypes.data,
+                                 C.byref(best), inl.ctypes.data, n, C.byref(ninl), None)
+            assert (st == 0) == (want is not None), (st, thr)
+            if want is None:
+                continue
+            _eq(cons.counts(len(samples)), want[3], f"counts at thr {thr!r}")
+            assert best.value == want[1]
+            _eq(inl[:ninl.value], want[2], f"inliers at thr {thr!r}")
+            checked += 1
+    assert checked >= 24
+
+
 def test_two_rank_path_matches_single_rank(gpu, tmp_path):
     """The N>1 path of bench.py end to end on ONE GPU: two ranks (gloo, both on cuda:0) shard 32 global frames
     g -> rank g % 2, pass their descriptor blocks one rank up the ring and match every frame against its
