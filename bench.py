@@ -43,99 +43,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-W, H = 1920, 1080
-FRAMES_PER_STEP = 256
-CAP = 8192              # descriptor block capacity per frame (cv-sfm tracking_features, settings.rs:433-434)
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r05"     # the committed counter passes bench.py reads (profiles/<tag>_pmc_traffic.json, _pmc_sq_summary.txt)
-PROFILE_TAG_RANSAC = "r04"   # profiles/<tag>_pmc_ransac.json (tools/pmc_ransac.sh)
-FED_BYTES_PER_PIXEL_STEP = 12.0
-CONTRACT_BYTES_PER_FRAME = 1053518400.0   # A1-A11 per 1080p frame, every buffer once per consuming stage
-FP64_VALU_PEAK_TFLOPS = 78.6              # MI355X_MICROARCH.md: FP64 vector
-# Kernel families the library times (include/akz.h AKZ_T_*): name, timer id, algorithmic HBM bytes per unit.  A unit
-# is one pixel of one frame covered by one launch; the bytes are what the kernel must move once given what it fuses
-# (DESIGN.md §5): front-end f32 levels 4 in + 4 Lflow + 8 {Lx,Ly} out; level 0: 1 (u8) in + 4 Lt + 8 {Lx,Ly};
-# determinant: 8 in ({Lx,Ly}), candidates only out; FED: 4 L + 4 c in, 4 L out per LAUNCH (T steps share the pass);
-# contrast: 1 (u8) in per pass; fused front end + first FED launch (k_front_fed): 4 in (Lt), 4 (Lt') + 8 {Lx,Ly} out —
-# Lflow stays on chip (the kernel is VALU-bound, its HBM fraction is what is left of the 28 B the split pair moves); the same
-# kernel below the first octave (timer ids 26..28) is counted at 16 B as well — 20 B when a later FED launch of the level
-# needs Lflow written, so its fraction is understated there, never overstated.
-KERNEL_FAMILIES = [
-    ("k_level_front2<4,2,..,u8> (level 0: u8->f32, blur 1.6, Lt, {Lx,Ly})", 3, 13.0),
-    ("k_level_front2<2,2,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 2)", 4, 16.0),
-    ("k_level_front2<2,3,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 3)", 5, 16.0),
-    ("k_level_front2<2,4,..> (blur 1.0, Scharr, pm_g2 -> Lflow, {Lx,Ly}; sigma 4)", 6, 16.0),
-    ("k_front_fed<2,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 2)", 22, 16.0),
-    ("k_front_fed<3,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 3)", 23, 16.0),
-    ("k_front_fed<4,..> (blur 1.0, Scharr, pm_g2, {Lx,Ly}, first FED launch of the level; sigma 4)", 24, 16.0),
-    ("k_front_fed<2,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 2)", 26, 16.0),
-    ("k_front_fed<3,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 3)", 27, 16.0),
-    ("k_front_fed<4,2,..> below the first octave (front end + the level's first FED launch of up to 8 steps; sigma 4)", 28, 16.0),
-    ("k_level_resident<..> (a level that fits one compute unit: front end + every FED step in one launch, one workgroup per frame)", 29, 16.0),
-    ("k_det_stream<2,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 2)", 7, 8.0),
-    ("k_det_stream<3,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 3)", 8, 8.0),
-    ("k_det_stream<4,..> (Lxx,Lyy,Lxy, Ldet, extrema candidates; sigma 4)", 9, 8.0),
-    ("k_fed_pair<1> (calculate_step, 1 step per launch)", 14, 12.0),
-    ("k_fed_pair<2> (calculate_step, 2 steps per launch)", 15, 12.0),
-    ("k_fed_pair<3> (calculate_step, 3 steps per launch)", 16, 12.0),
-    ("k_fed_pair<4> (calculate_step, 4 steps per launch)", 17, 12.0),
-    ("k_fed_pair<5> (calculate_step, 5 steps per launch)", 18, 12.0),
-    ("k_fed_pair<6> (calculate_step, 6 steps per launch)", 19, 12.0),
-    ("k_fed_pair<7> (calculate_step, 7 steps per launch)", 20, 12.0),
-    ("k_fed_pair<8> (calculate_step, 8 steps per launch)", 21, 12.0),
-    ("k_contrast_pair (contrast factor passes)", 10, 1.0),
-]
-# the keypoint-stage kernel with the most GPU time: gathers, no per-pixel byte model — its roofline numerator is the
-# distinct 32-byte sectors the frame's keypoints touch, each once (gather_model); the PMC bytes go beside it as `traffic`
-ORIENT_DESCRIBE = ("k_orient_describe (main orientation + M-LDB descriptor, one wave per keypoint)", 25)
-MFMA_I8_PEAK_TOPS = 3944.0   # dense int8 MFMA, measured ceiling in MI355X_MICROARCH.md (~2x the bf16 rate)
-MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4/FP6 MFMA (MI355X_MICROARCH.md; AMD's 20 PF headline is 2:1 sparse)
-
-
-def make_world(seed, w, h):
-    """Deterministic synthetic 'world' canvas (value noise + rectangles + discs), uint8, numpy."""
-    rng = np.random.default_rng(seed)
-    img = np.full((h, w), 96.0, np.float32)
-    for cell, amp in ((64, 48), (32, 24), (16, 12), (8, 6)):
-        gh, gw = h // cell + 2, w // cell + 2
-        g = rng.uniform(-amp, amp, (gh, gw)).astype(np.float32)
-        ys = np.arange(h, dtype=np.float32) / cell
-        xs = np.arange(w, dtype=np.float32) / cell
-        y0 = ys.astype(int); x0 = xs.astype(int)
-        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
-        img += ((1 - fy) * (1 - fx) * g[y0][:, x0] + (1 - fy) * fx * g[y0][:, x0 + 1]
-                + fy * (1 - fx) * g[y0 + 1][:, x0] + fy * fx * g[y0 + 1][:, x0 + 1])
-    density = (w * h) / (1920.0 * 1080.0)
-    n_shapes = int(200 * density)
-    for _ in range(n_shapes):
-        sw, sh = rng.integers(8, 97, 2)
-        x, y = rng.integers(0, w), rng.integers(0, h)
-        img[y:y + sh, x:x + sw] = rng.integers(0, 256)
-    yy, xx = np.mgrid[0:97, 0:97]
-    for _ in range(n_shapes):
-        r = int(rng.integers(4, 49))
-        x, y = int(rng.integers(r, w - r)), int(rng.integers(r, h - r))
-        m = (yy[:2 * r + 1, :2 * r + 1] - r) ** 2 + (xx[:2 * r + 1, :2 * r + 1] - r) ** 2 <= r * r
-        img[y - r:y + r + 1, x - r:x + r + 1][m] = rng.integers(0, 256)
-    return np.clip(img, 0, 255).astype(np.uint8)
-
-
-def make_frames(torch, device, rank, n_frames, world_size):
-    """n_frames 1080p frames for this rank: a camera panning over the world canvas (4 px right, 2 px down
-    per GLOBAL frame) plus +-2 sensor noise.  Global frame g = j*world_size + rank."""
-    total = n_frames * world_size
-    world = make_world(0xA4A2E, W + 4 * total + 64, H + 2 * total + 64)
-    wt = torch.from_numpy(world).to(device)
-    frames = torch.empty((n_frames, H, W), dtype=torch.uint8, device=device)
-    gen = torch.Generator(device=device)
-    for j in range(n_frames):
-        g = j * world_size + rank
-        gen.manual_seed(1000 + g)
-        crop = wt[2 * g:2 * g + H, 4 * g:4 * g + W].to(torch.int16)
-        noise = torch.randint(-2, 3, (H, W), generator=gen, device=device, dtype=torch.int16)
-        frames[j] = (crop + noise).clamp_(0, 255).to(torch.uint8)
-    return frames
+from tools.bench_common import W, H, FRAMES_PER_STEP, CAP, make_world, make_frames  # noqa: E402,F401
+from tools.roofline import *  # noqa: E402,F401,F403
+from tools.roofline import _short_roofline  # noqa: E402
+from tools.bench_extras import (extra_match, extra_pipeline_verify, extra_pipeline_register, extra_ransac,  # noqa: E402
+                                extra_criterion)
 
 
 def main():
@@ -683,22 +595,6 @@ def main():
 HEADLINE_LIMIT = 4096      # bytes: the driver keeps a bounded tail of stdout; a 22 KB line (round 4) was not parseable from it
 
 
-def _short_roofline(e):
-    """One flat roofline object for the headline: the contract's keys + the kernel's own launch statistics."""
-    if not e:
-        return None
-    r = {k: e.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us")}
-    r["kernel"] = str(e.get("kernel", "")).split(" ")[0]
-    for k in ("valu_frac", "gpu_ms_per_step"):
-        if e.get(k) is not None:
-            r[k] = e[k]
-    iso = e.get("isolated") or {}
-    if iso.get("frac") is not None:
-        r["isolated_frac"] = iso["frac"]
-        r["isolated_avg_launch_us"] = iso.get("avg_launch_us")
-    return r
-
-
 def headline(out, detail_path=None):
     """The compact last line (< HEADLINE_LIMIT bytes): the contract fields of the task statement, ONE roofline object,
     ONE cpu_baseline object, parity counts and one scalar per extra leg.  Everything else stays in the detail file."""
@@ -809,184 +705,6 @@ def flush_c_stdio():
         pass
 
 
-def read_families(ctx):
-    """(name, ms, launches, units, bytes_per_unit) of every timed kernel family since the last timing_reset."""
-    fam = []
-    for name, tid, bpu in KERNEL_FAMILIES:
-        ms, launches, units = ctx.timing_get(tid)
-        if launches:
-            fam.append((name, ms, launches, units, bpu))
-    ms, launches, units = ctx.timing_get(ORIENT_DESCRIBE[1])
-    if launches:
-        fam.append((ORIENT_DESCRIBE[0], ms, launches, units, None))
-    return fam
-
-
-VALU_ISSUE_PEAK_T = 39.3     # T lane-instructions / s at FOUR cycles per wave64 instruction (256 CUs x 4 SIMDs x 64 lanes / 4 x
-                             # 2.4 GHz): the rate of the instructions the big kernels are made of — packed f32 (v_pk_add/mul_f32: two
-                             # lane-ops each, i.e. the 78.6 T lane-op/s non-FMA peak) and f64.  MI355X_MICROARCH.md gives a PLAIN
-                             # 32-bit VALU instruction two cycles (SIMD-32: 157.3 TFLOP/s of v_fma_f32), so valu_frac computed with
-                             # this constant is the fraction of issue time IF every instruction were packed or f64: exact for the
-                             # consensus kernels (f64), close for the diffusion kernels (mostly packed), an UPPER bound for kernels
-                             # of scalar 32-bit work (k_orient_describe, the sorts).  The cycle-based counters beside it
-                             # (issue_counters.valu_busy_pct: SQ_ACTIVE_INST_VALU over busy cycles) do not depend on it.
-
-
-def gather_model(ctx, kps_frames, counts):
-    """What k_orient_describe MUST fetch, from the kernel's own sampling geometry on the GPU's own keypoints: the orientation
-    stage reads {Lx, Ly} (8 B) at the 109 lattice points (x + i s, y + j s), i^2 + j^2 < 36 (scale_space_extrema.rs:230-260),
-    the descriptor Lt (4 B) and {Lx, Ly} at the 21 x 21 rotated lattice (descriptors.rs:102-177); every sample pulls the
-    32-byte sector it lies in.  Per keypoint the DISTINCT sectors of the {Lx, Ly} plane and of the Lt plane are counted (a
-    keypoint's samples are gathered once into LDS, so re-use inside a keypoint is the kernel's to have; re-use between
-    keypoints is the cache's).  Returns bytes per FRAME at three granularities: 32-byte sectors per keypoint (the algorithmic
-    numerator), the 128-byte lines per keypoint (the memory side fetches whole lines: profiles/r04_fetch_calibration.txt)
-    and the distinct sectors of the whole frame (the floor a perfect cache would reach)."""
-    nl = ctx.num_levels(W, H)
-    lw = np.array([ctx.level(W, H, i).width for i in range(nl)], np.int64)
-    loct = np.array([ctx.level(W, H, i).octave for i in range(nl)], np.int64)
-    ii, jj = np.meshgrid(np.arange(-6, 7), np.arange(-6, 7))
-    m = (ii * ii + jj * jj) < 36
-    oi, oj = ii[m].astype(np.float32), jj[m].astype(np.float32)
-    kk, ll = np.meshgrid(np.arange(-10, 11), np.arange(-10, 11), indexing="ij")
-    kk, ll = kk.reshape(-1).astype(np.float32), ll.reshape(-1).astype(np.float32)
-    s32 = l128 = fr32 = fr128 = 0.0
-    nkp = 0
-    tile_hist = np.zeros(6, np.int64)      # 32-px tiles of a level holding 1, 2, 3-4, 5-8, 9-16, > 16 keypoints
-
-    def distinct(a):
-        a = np.sort(a, axis=1)
-        return 1 + (np.diff(a, axis=1) != 0).sum(1)
-    for f, kp in enumerate(kps_frames):
-        kp = kp[:int(counts[f])]
-        if len(kp) == 0:
-            continue
-        cls = kp["class_id"].astype(np.int64)
-        ratio = (1 << loct[cls]).astype(np.float32)
-        sc = np.round(np.float32(0.5) * kp["size"] / ratio)
-        xf, yf = kp["x"] / ratio, kp["y"] / ratio
-        w = lw[cls][:, None]
-        ox = np.round(xf[:, None] + oi[None, :] * sc[:, None]).astype(np.int64)
-        oy = np.round(yf[:, None] + oj[None, :] * sc[:, None]).astype(np.int64)
-        co, si = np.cos(kp["angle"]), np.sin(kp["angle"])
-        dx = np.round(xf[:, None] + (-ll[None, :] * si[:, None] * sc[:, None] + kk[None, :] * co[:, None] * sc[:, None])).astype(np.int64)
-        dy = np.round(yf[:, None] + (ll[None, :] * co[:, None] * sc[:, None] + kk[None, :] * si[:, None] * sc[:, None])).astype(np.int64)
-        pix_xy = np.concatenate([oy * w + ox, dy * w + dx], 1)          # {Lx, Ly} plane: orientation + descriptor samples
-        pix_lt = dy * w + dx                                            # Lt plane: descriptor samples
-        s32 += 32.0 * float(distinct(pix_xy // 4).sum() + distinct(pix_lt // 8).sum())
-        l128 += 128.0 * float(distinct(pix_xy // 16).sum() + distinct(pix_lt // 32).sum())
-        lvl = cls[:, None] * (1 << 40)
-        fr32 += 32.0 * float(len(np.unique((pix_xy // 4 + lvl).reshape(-1))) + len(np.unique((pix_lt // 8 + lvl).reshape(-1))))
-        fr128 += 128.0 * float(len(np.unique((pix_xy // 16 + lvl).reshape(-1))) + len(np.unique((pix_lt // 32 + lvl).reshape(-1))))
-        # how many keypoints share a 32-px tile of their level (what staging a tile's patch in LDS could amortise over)
-        tkey = cls * (1 << 40) + (np.round(yf).astype(np.int64) >> 5) * 4096 + (np.round(xf).astype(np.int64) >> 5)
-        _, per_tile = np.unique(tkey, return_counts=True)
-        tile_hist += np.bincount(np.searchsorted([1, 2, 4, 8, 16], per_tile, side="left"), minlength=6)[:6]
-        nkp += len(kp)
-    nf = max(1, len(kps_frames))
-    return {"sector_bytes_per_frame": s32 / nf, "line_bytes_per_frame": l128 / nf, "frame_distinct_sector_bytes": fr32 / nf,
-            "frame_distinct_line_bytes": fr128 / nf,
-            "keypoints_per_32px_tile_histogram": {"1": int(tile_hist[0]), "2": int(tile_hist[1]), "3-4": int(tile_hist[2]), "5-8": int(tile_hist[3]),
-                                                  "9-16": int(tile_hist[4]), ">16": int(tile_hist[5]), "frames": len(kps_frames)},
-            "keypoints_per_frame": nkp / nf, "frames_sampled": len(kps_frames),
-            "what": "32-byte sectors of the {Lx,Ly} (8 B/px) and Lt (4 B/px) planes touched by the 109 orientation samples and the "
-                    "21 x 21 descriptor lattice, distinct per keypoint, from this run's own keypoints; line_bytes = the same at the "
-                    "128-byte granularity the memory side fetches (profiles/r04_fetch_calibration.txt: every read request is 128 B); "
-                    "frame_distinct = distinct sectors of the whole frame (perfect re-use between keypoints); "
-                    "frame_distinct_line_bytes = the same in 128-byte lines: what HBM must deliver at the granularity the memory "
-                    "side fetches (the PMC traffic is to be read against THIS: the gap to the sector figure is line granularity, not "
-                    "re-fetching)"}
-
-
-def roofline_entries(fam_pipe, fam_iso, mb, steps, gather=None, iso_steps=3):
-    """Roofline objects of the timed kernel families.  Per family: frac = hbm_frac = algorithmic bytes / kernel time / 8 TB/s
-    (always the BYTES fraction); valu_frac = VALU instructions x 64 lanes / kernel time / the VALU issue peak (counters:
-    profiles/, taken at this micro-batch); `bound` names whichever of the two is larger.  Ordered by a family's time per step
-    with the GPU to itself (isolated pass) — inside the pipeline three streams time-slice the chip and a kernel's duration
-    says how the chip was shared, not what the kernel costs."""
-    iso = {f[0]: f for f in (fam_iso or [])}
-    pmc = pmc_traffic(mb)
-    sq = sq_counters()
-    out = []
-    for name, ms, launches, units, bpu in fam_pipe:
-        if ms <= 0:
-            continue
-        key = name.split(" ")[0]
-        model = None
-        if bpu is None:        # the gather kernel: units = frames, bytes from its sampling geometry (gather_model)
-            if not gather:
-                continue
-            # compulsory bytes = every sector the frame's keypoints touch, once (what a perfect cache would fetch); the
-            # per-keypoint figures (what the L2 is asked for) go beside it as sector_frac / line_frac
-            bpu, model = gather["frame_distinct_sector_bytes"], gather
-        gbs = units * bpu / (ms * 1e-3) / 1e9
-        e = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_is": "algorithmic bytes / kernel time / 8 TB/s",
-             "traffic": None, "launches": int(launches),
-             "avg_launch_us": round(ms * 1e3 / launches, 2), "gpu_ms": round(ms, 2), "gpu_ms_per_step": round(ms / steps, 3),
-             "algorithmic_bytes_per_launch": round(units * bpu / launches), "bytes_per_unit": round(bpu, 3),
-             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-             "timed": f"the launches' own start/stop events (hipExtLaunchKernel: the dispatch's begin -> end, rocprofv3's "
-                      f"kernel duration) over the {steps} timed steps; the keypoint and matcher streams of neighbouring "
-                      f"micro-batches share the GPU"}
-        if model:
-            e["byte_model"] = {k: (round(v, 1) if isinstance(v, float) else v) for k, v in model.items()}
-            e["sector_demand_frac"] = round(units * model["sector_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            e["line_demand_frac"] = round(units * model["line_bytes_per_frame"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            e["distinct_line_bytes_per_launch"] = round(units * model["frame_distinct_line_bytes"] / launches)
-            e["frac_is"] = ("distinct 32-byte sectors the frame's keypoints touch (each once) / kernel time / 8 TB/s; sector_demand_frac / "
-                            "line_demand_frac = the same with every keypoint's sectors / 128-byte lines counted on their own (what the "
-                            "caches are asked for, not what HBM must deliver: they can exceed 1)")
-        if pmc and key in pmc["kernels"]:
-            k = pmc["kernels"][key]
-            e["traffic"] = round(k["hbm_bytes_per_launch"])
-            if model:
-                e["traffic_over_distinct_lines"] = round(e["traffic"] / max(1, e["distinct_line_bytes_per_launch"]), 3)
-            e["traffic_source"] = {"file": pmc["file"], "micro_batch": pmc["micro_batch"], "launches_counted": k["launches"]}
-            if k.get("valu_insts_per_launch"):
-                lane_ops = k["valu_insts_per_launch"] * 64.0 / (ms * 1e-3 / launches) / 1e12
-                e["valu_frac"] = round(lane_ops / VALU_ISSUE_PEAK_T, 4)
-                e["valu"] = {"achieved": round(lane_ops, 2), "peak": VALU_ISSUE_PEAK_T, "unit": "T lane-instr/s",
-                             "insts_per_launch": round(k["valu_insts_per_launch"]),
-                             "note": "SQ_INSTS_VALU (rocprofv3 --pmc, committed pass at this micro-batch) x 64 lanes / this "
-                                     "run's kernel time; the frame-pair kernels issue packed f32 (2 lane-ops per "
-                                     "instruction), so this is also their fraction of the 78.6 T lane-op/s non-FMA peak"}
-                if e["valu_frac"] > e["hbm_frac"]:
-                    e["bound"] = "valu"          # (frac stays the bytes fraction; valu_frac is beside it)
-        rank_ms = ms / steps
-        if name in iso:
-            _, ims, il, iu, _ = iso[name]
-            igbs = iu * bpu / (ims * 1e-3) / 1e9
-            e["isolated"] = {"achieved": round(igbs, 1), "frac": round(igbs / HBM_PEAK_GBS, 4),
-                             "avg_launch_us": round(ims * 1e3 / il, 2), "gpu_ms_per_step": round(ims / iso_steps, 3)}
-            if pmc and key in pmc["kernels"] and pmc["kernels"][key].get("valu_insts_per_launch"):
-                e["isolated"]["valu_frac"] = round(pmc["kernels"][key]["valu_insts_per_launch"] * 64.0 / (ims * 1e-3 / il) / 1e12 / VALU_ISSUE_PEAK_T, 4)
-            rank_ms = ims / iso_steps
-        e["rank_ms_per_step"] = round(rank_ms, 3)
-        if name.startswith("k_front_fed"):
-            # what the same work cost as two kernels (k_level_front2 16 B + k_fed_pair 12 B per pixel): the fused kernel's
-            # time expressed against THOSE bytes, for comparison with round 1's front-end / FED fractions only
-            e["replaces"] = {"kernels": "k_level_front2<2,sigma,..> + k_fed_pair<T>", "bytes_per_pixel": 28.0,
-                             "equivalent_frac_of_peak": round(gbs * 28.0 / 16.0 / HBM_PEAK_GBS, 4)}
-        if key in sq:
-            e["issue_counters"] = sq[key]
-        out.append(e)
-    return out
-
-
-def pipeline_traffic(mb, nf):
-    """HBM bytes per frame of the WHOLE timed pipeline (scale space + keypoint stage + matcher; the library's kernels
-    only — frame generation and torch fills are not counted) from the committed counter passes of `bench.py --pmc-run`."""
-    pmc = pmc_traffic(mb)
-    if not pmc or not pmc.get("per_frame") or int(pmc.get("frames_per_step", 0)) != int(nf):
-        return None
-    pf = pmc["per_frame"]
-    valu = sum(k.get("valu_insts_per_launch", 0) * k["launches"] for name, k in pmc["kernels"].items() if name.startswith("k_"))
-    return {"valu_insts": round(valu / (float(pmc["frames_per_step"]) * float(pmc.get("steps", 1)))),
-            "bytes": round(pf["hbm_bytes"]), "scale_space_bytes": round(pf.get("scale_space_hbm_bytes", 0)),
-            "keypoint_stage_bytes": round(pf.get("keypoint_stage_hbm_bytes", 0)), "matcher_bytes": round(pf.get("matcher_hbm_bytes", 0)),
-            "file": pmc["file"], "source": pmc.get("source_short", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bench.py --pmc-run")}
-
-
 def parity_check(oracle_out, kps, descs, counts, pairs, npairs, mb):
     """GPU outputs of the first len(oracle_out) frames of the last timed step vs the oracle's (keypoints as raw
     bytes, descriptor bytes, symmetric better-by-24 match pairs of (frame j, frame j-1))."""
@@ -1043,490 +761,6 @@ def parity_spread(frames, kps, descs, counts, pairs, npairs, NF, MB, n_pairs):
             "what": "as parity_checked, for frame pairs at other positions of the batch"}
 
 
-def extra_match(torch, dev, L, _lib, n_frames):
-    """BASELINE configs[2] as SURVEY 8d defines it: n_frames x 5 000 descriptors; frame 0 = 486 i.i.d. Bernoulli(1/2)
-    bits (seed 0xD35C); frame f+1 = 60 % of frame f's descriptors with every bit flipped w.p. 0.05 + 40 % fresh ones,
-    shuffled; consecutive pairs matched symmetrically with d0 + 24 < d1.  Device-resident, one call."""
-    from cv_amd.knn import Matcher, RULE_STRICT
-    from oracle import oracle as O
-    ND, cap = 5000, 5000
-    g = torch.Generator(device=dev).manual_seed(0xD35C)
-    bitmask = torch.zeros(64, dtype=torch.uint8, device=dev)
-    bitmask[:60] = 0xFF
-    bitmask[60] = 0x3F                      # bits 486..511 stay zero
-    w8 = (1 << torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
-
-    def fresh(n):
-        return torch.randint(0, 256, (n, 64), generator=g, device=dev, dtype=torch.uint8) & bitmask
-
-    descs = torch.empty((n_frames, cap, 64), dtype=torch.uint8, device=dev)
-    descs[0] = fresh(ND)
-    for f in range(1, n_frames):
-        keep = torch.randperm(ND, generator=g, device=dev)[:ND * 6 // 10]
-        flips = (torch.rand((len(keep), 64, 8), generator=g, device=dev) < 0.05).to(torch.uint8)
-        flip_bytes = (flips * w8).sum(dim=2).to(torch.uint8) & bitmask
-        nxt = torch.cat([descs[f - 1][keep] ^ flip_bytes, fresh(ND - len(keep))])
-        descs[f] = nxt[torch.randperm(ND, generator=g, device=dev)]
-    counts = torch.full((n_frames,), ND, dtype=torch.int32, device=dev)
-    npr = n_frames - 1
-    pairs = torch.zeros((npr, cap, 2), dtype=torch.int32, device=dev)
-    npairs = torch.zeros((npr,), dtype=torch.int32, device=dev)
-    m = Matcher(cap)
-    ia = (C.c_uint32 * npr)(*range(1, n_frames))
-    ib = (C.c_uint32 * npr)(*range(0, n_frames - 1))
-
-    def run():
-        _lib.check(L.hm_match_batch_device(m.handle, descs.data_ptr(), counts.data_ptr(), descs.data_ptr(),
-                                           counts.data_ptr(), cap, ia, ib, npr, RULE_STRICT, 24, 0.0, 1,
-                                           pairs.data_ptr(), npairs.data_ptr(), None), "match")
-    torch.cuda.synchronize()
-    run()
-    _lib.check(L.hm_sync(m.handle), "sync")
-    _lib.check(L.hm_timing_get(m.handle, None, None, 1), "timing")
-    _lib.check(L.hm_timing_enable(m.handle, 1), "timing")
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
-    _lib.check(L.hm_sync(m.handle), "sync")
-    dt = (time.perf_counter() - t0) / reps
-    ms, launches = C.c_double(), C.c_uint64()
-    _lib.check(L.hm_timing_get(m.handle, C.byref(ms), C.byref(launches), 1), "timing")
-    _lib.check(L.hm_timing_enable(m.handle, 0), "timing")
-    # oracle on a sample of the pairs
-    sample = sorted({int(v) for v in np.linspace(0, npr - 1, min(npr, 64))})
-    bad = 0
-    hd = descs.cpu().numpy()
-    for p_ in sample:
-        want = O.match(hd[p_ + 1], hd[p_], rule=O.RULE_STRICT, param_u=24, symmetric=True).astype(np.uint32)
-        k = int(npairs[p_].item())
-        got = pairs[p_, :k].cpu().numpy().astype(np.uint32)
-        bad += int(k != len(want) or not np.array_equal(got, want))
-    dist_per_pair = 2.0 * ND * ND                      # both directions
-    ops = 2.0 * 512.0 * dist_per_pair * npr * reps     # one MAC = 2 ops per bit of the 512-deep contraction
-    tops = ops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-    out = {"workload": f"{n_frames} frames x {ND} descriptors (Bernoulli(1/2) x 486 bits, 60 % carried over with 5 % "
-                       f"bit flips), {npr} consecutive pairs, symmetric d0 + 24 < d1, device-resident",
-           "pairs_per_s": round(npr / dt, 1), "distances_per_s": round(dist_per_pair * npr / dt, 1),
-           "ms_per_call": round(dt * 1e3, 3), "mean_matches_per_pair": round(npairs.float().mean().item(), 1),
-           "roofline": {"bound": "mfma", "kernel": "k_knn_mfma4w<2> (v_mfma_scale_f32_32x32x64_f8f6f4, E2M1 operands)",
-                        "achieved": round(tops, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s",
-                        "frac": round(tops / MFMA_FP4_PEAK_TOPS, 4), "traffic": None,
-                        "launches": int(launches.value),
-                        "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2)},
-           "parity": {"pairs_checked": len(sample), "mismatches": bad,
-                      "what": "match pair lists of the sampled frame pairs vs oracle/match_oracle.c"}}
-    m.close()
-    return out
-
-
-def extra_pipeline_verify(torch, dev, L, _lib, args, step, step_no, barrier, verify, match_done, hm_stream, kps2, pairs2, npairs2,
-                          NF, MB):
-    """The headline pipeline with the stage that consumes its match lists attached: every frame pair of every
-    micro-batch goes from the matcher straight into rs_essential_arrsac_batch_device (calibrate -> seeded shuffle ->
-    8192 eight-point hypotheses -> block scoring with a halving candidate set of 1024, SPRT; vslam-sandbox/src/main.rs:
-    112-117, cv-sfm/src/lib.rs:1385-1412), nothing leaves the device.  value = verified frame pairs per second of the
-    whole pipeline; a sample of scenes from different micro-batch positions is held to oracle/arrsac_oracle.c."""
-    from cv_amd.ransac import EssentialConsensus
-    from oracle import oracle as O
-    cam = (1000.0, 1000.0, W / 2.0, H / 2.0, 0.0, None)     # a pinhole camera for the synthetic frames
-    n_hyp, thr = 8192, 1e-7                                  # initialization_hypotheses, two_view_consensus_threshold
-    kw = dict(block_size=args.verify_block, init_blocks=1, max_candidates=1024, halve=True, sprt=True)
-    cons = EssentialConsensus(CAP, n_hyp)
-    cons.reserve(MB + 1)
-    prm = cons.make_params(thr, n_hypotheses=n_hyp, seed=0, **kw)
-    c = cons.camera(cam)
-    rs_stream = torch.cuda.ExternalStream(cons.stream(), device=dev)
-    z = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=dev) for _ in range(2)]
-    pose2, best2, inl2, ninl2 = z((NF + 2, 12), torch.float64), z((NF + 2,), torch.int32), z((NF + 2, CAP), torch.int32), z((NF + 2,), torch.int32)
-    stats2 = z((NF + 2, 32), torch.uint8)
-    verify_done = [torch.cuda.Event(), torch.cuda.Event()]
-    calls = {}
-
-    def enqueue(p, m0, js, prev_js):
-        cons.model_inliers_batch_device(kps2[p].data_ptr(), kps2[p].data_ptr(), CAP, js, prev_js, pairs2[p][m0:].data_ptr(),
-                                        npairs2[p][m0:].data_ptr(), c, c, prm, pose2[p][m0:].data_ptr(), best2[p][m0:].data_ptr(),
-                                        inl2[p][m0:].data_ptr(), ninl2[p][m0:].data_ptr(), stats2[p][m0:].data_ptr(),
-                                        shuffle=True, stream_to_wait=hm_stream.cuda_stream)
-        calls[(p, m0)] = (list(js), list(prev_js))
-        if m0 + MB >= NF:
-            verify_done[p].record(rs_stream)
-            if p == 1:
-                verify["armed"] = True          # both events have been recorded once
-    barrier()
-    verify["done"] = verify_done
-    verify["on"] = enqueue
-    step(); step()                                  # warm-up: both output sets
-    cons.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.verify_steps):
-        step()
-    cons.sync()
-    barrier()
-    dt = (time.perf_counter() - t0) / args.verify_steps
-    verify["on"] = None
-    last = (step_no[0] - 1) & 1
-    kps, pairs, npairs = kps2[last], pairs2[last], npairs2[last]
-    hbest = best2[last].cpu().numpy().view(np.uint32); hninl = ninl2[last].cpu().numpy().view(np.uint32)
-    hst = stats2[last].cpu().numpy().view(np.dtype([("poses", "<u4"), ("survivors", "<u4"), ("blocks", "<u4"), ("reserved", "<u4"),
-                                                      ("evaluated", "<u8"), ("exhaustive", "<u8")])).reshape(-1)
-    hn = npairs.cpu().numpy()
-    # parity: scenes spread over the micro-batches of the last step (first, last, odd positions)
-    slots = []
-    for m0 in range(0, NF, MB):
-        js, prev_js = calls[(last, m0)]
-        per = max(1, args.verify_check // max(1, NF // MB))
-        q = sorted({0, len(js) - 1} | {min(len(js) - 1, (k * len(js) // per) | 1) for k in range(per)})
-        slots += [(m0, qq, js[qq], prev_js[qq]) for qq in q if qq < len(js)]
-    slots = slots if args.verify_check else []
-    bad, detail = 0, []
-    t0 = time.perf_counter()
-    for m0, q, ja, jb in slots:
-        n = int(hn[m0 + q])
-        ka = kps[ja].cpu().numpy().view(_lib.KP_DTYPE).reshape(-1)
-        kb = kps[jb].cpu().numpy().view(_lib.KP_DTYPE).reshape(-1)
-        pr = pairs[m0 + q, :n].cpu().numpy().astype(np.uint32)
-        w = O.arrsac_pairs(ka, kb, pr, cam, cam, thr, n_hyp, scene=q, shuffle=True, seed=0, **kw)
-        g_inl = inl2[last][m0 + q, :hninl[m0 + q]].cpu().numpy().view(np.uint32)
-        g_pose = pose2[last][m0 + q].cpu().numpy()
-        ok = (hbest[m0 + q] == w["best_id"] and np.array_equal(g_inl, w["inliers"])
-              and (w["best_id"] == 0xFFFFFFFF or g_pose.tobytes() == w["pose"].tobytes()))
-        if not ok:
-            bad += 1
-            detail.append(f"pair ({ja},{jb}): id {int(hbest[m0 + q])} vs {w['best_id']}, inliers {len(g_inl)} vs {len(w['inliers'])}")
-    cpu_s = time.perf_counter() - t0
-    valid = hn[:NF] >= 8
-    out = {"workload": f"configs[1] batch ({NF} frames of 1920x1080 per step) -> extract -> symmetric better-by-24 match of consecutive "
-                       f"frames -> two-view ARRSAC of every pair on the device ({n_hyp} eight-point hypotheses, threshold {thr:g}, "
-                       f"{kw['block_size']}-match blocks, candidates 1024 halving per block, SPRT, seeded shuffle)",
-           "verified_pairs_per_s": round(NF / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.verify_steps,
-           "mean_matches_per_pair": round(float(hn[:NF].mean()), 1),
-           "mean_inliers_per_pair": round(float(hninl[:NF].mean()), 1),
-           "pairs_with_a_model": int((hbest[:NF] != 0xFFFFFFFF).sum()),
-           "residuals_evaluated_frac": round(float(hst["evaluated"][:NF][valid].sum()) / max(1.0, float(hst["exhaustive"][:NF][valid].sum())), 5),
-           "parity": {"scenes_checked": len(slots), "mismatches": bad, "detail": detail[:4], "cpu_s_per_scene": round(cpu_s / max(1, len(slots)), 2),
-                      "what": "winner id, pose bits and inlier list of scenes taken from the first / last / odd positions of "
-                              "the last step's micro-batches vs oracle/arrsac_oracle.c (orc_arrsac_pairs) on the GPU's own "
-                              "keypoints and pair lists"}}
-    cons.close()
-    return out
-
-
-def extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB):
-    """The loop vslam-sandbox runs on every frame once a reconstruction exists (cv-sfm/src/lib.rs:672, 1452-1542, 1549-1604,
-    1619-1622), for whole micro-batches, nothing leaving the device: extract -> hasher.hash_bag -> knn(., 3) of every feature
-    against each of the frame's recent views (tracking_recent_frames = 32) -> landmark dedup / three best / unique-match decision
-    -> duplicate-landmark filter + FeatureWorldMatch list -> Arrsac + LambdaTwist (vslam-sandbox/src/main.rs:105-111: 16 384
-    hypotheses, 1 024 candidates, 256 estimations per block).  cv_amd/registration.py chains the five device-resident entry
-    points; the reference's control plane is played by torch on the device: the landmark a stored feature observes is the
-    world-canvas cell (4 px, per evolution level) its keypoint falls into, the landmark table the cell centres on the plane the
-    panning camera looks at.  value = registered frames per second of the whole chain; sampled frames are held to the oracle
-    stage by stage (pair lists, winner, pose bits, inlier lists) and every pose to the motion the frames were rendered with."""
-    from cv_amd.registration import Registration
-    from oracle import oracle as O
-    V = max(1, min(args.register_views, NF - 1))
-    CELL, F_CAM, Z0 = 4, 1000.0, 5.0
-    cam = (F_CAM, F_CAM, W / 2.0, H / 2.0, 0.0, None)
-    wc, hc = (W + 4 * NF) // CELL + 2, (H + 2 * NF) // CELL + 2
-    n_world = wc * hc * 16
-    keys = torch.arange(n_world, device=dev, dtype=torch.int64)
-    cell = keys // 16
-    xw = ((cell % wc).to(torch.float64) + 0.5) * CELL
-    yw = ((cell // wc).to(torch.float64) + 0.5) * CELL
-    P = torch.stack([(xw - W / 2.0) * Z0 / F_CAM, (yw - H / 2.0) * Z0 / F_CAM, torch.full_like(xw, Z0), torch.ones_like(xw)], 1)
-    d_world = (P / torch.linalg.norm(P[:, :3], dim=1, keepdim=True)).contiguous()
-    del keys, cell, xw, yw, P
-    rng = np.random.default_rng(0xC0DE)
-    codewords = rng.integers(0, 256, (4096, 64), dtype=np.uint8)        # cv-sfm ships 4096 words (cv-sfm/src/codewords.rs)
-    thr, n_hyp, kw = 1e-5, 16384, dict(block_size=64, max_candidates=1024, estimations_per_block=256)
-    reg = Registration(torch, CAP, NF, V, codewords, cam, device=dev.index, threshold=thr, n_hypotheses=n_hyp, seed=0, **kw)
-    rs_s = torch.cuda.ExternalStream(reg.rs_stream(), device=dev)
-    akz_s = torch.cuda.ExternalStream(L.akz_stream(ctx.handle), device=dev)
-    z2 = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=dev) for _ in range(2)]
-    kps2, descs2, counts2, lm2 = z2((NF, CAP, 28), torch.uint8), z2((NF, CAP, 64), torch.uint8), z2((NF,), torch.int32), z2((NF, CAP), torch.int32)
-    gidx = torch.arange(NF, device=dev, dtype=torch.float32).view(NF, 1)
-    frame_blocks = list(range(NF))
-    view_blocks = [[(j - 1 - v) % NF for v in range(V)] for j in range(NF)]
-    glue = torch.cuda.Stream(device=dev)
-    done = [torch.cuda.Event(), torch.cuda.Event()]
-    n = [0]
-
-    def step():
-        p = n[0] & 1
-        cur = torch.cuda.current_stream()
-        if n[0] >= 2:
-            cur.wait_event(done[p])                       # set p's keypoints / descriptors were last read two steps ago
-        for m0 in range(0, NF, MB):
-            _lib.check(L.akz_extract_batch_device(ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps2[p][m0:m0 + MB].data_ptr(),
-                                                  descs2[p][m0:m0 + MB].data_ptr(), CAP, counts2[p][m0:m0 + MB].data_ptr(),
-                                                  cur.cuda_stream), "extract")
-        # the caller's bookkeeping: which landmark every feature of every stored view observes
-        glue.wait_stream(akz_s)
-        with torch.cuda.stream(glue):
-            k = kps2[p].view(torch.float32).view(NF, CAP, 7)
-            cx = torch.clamp(torch.floor((k[..., 0] + 4.0 * gidx) / CELL), 0, wc - 1).to(torch.int32)
-            cy = torch.clamp(torch.floor((k[..., 1] + 2.0 * gidx) / CELL), 0, hc - 1).to(torch.int32)
-            cls = kps2[p].view(torch.int32).view(NF, CAP, 7)[..., 6] & 15
-            lm2[p].copy_((cy * wc + cx) * 16 + cls)
-        reg.enqueue(kps2[p], descs2[p], counts2[p], frame_blocks, view_blocks, lm2[p], d_world, n_world, stream_to_wait=glue.cuda_stream)
-        done[p].record(rs_s)
-        n[0] += 1
-
-    step(); step()
-    reg.sync(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.register_steps):
-        step()
-    reg.sync(); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.register_steps
-    last = (n[0] - 1) & 1
-    kps = kps2[last].cpu().numpy().view(_lib.KP_DTYPE).reshape(NF, CAP)
-    counts = counts2[last].cpu().numpy()
-    lms = lm2[last].cpu().numpy().view(np.uint32)
-    h_np = reg.npairs.cpu().numpy().view(np.uint32); h_id = reg.best_id.cpu().numpy().view(np.uint32)
-    h_ninl = reg.n_inliers.cpu().numpy().view(np.uint32); h_pose = reg.pose.cpu().numpy().reshape(NF, 3, 4)
-    h_dec = reg.decision.cpu().numpy().view(np.uint32)
-    # every pose against the motion the frames were rendered with: identity rotation, camera at (4 g, 2 g) px on the canvas
-    have = h_id != 0xFFFFFFFF
-    g = np.arange(NF)
-    expect_t = -np.stack([4.0 * g * Z0 / F_CAM, 2.0 * g * Z0 / F_CAM, np.zeros(NF)], 1)
-    rot_err = np.abs(h_pose[:, :, :3] - np.eye(3)).max((1, 2))
-    t_err = np.abs(h_pose[:, :, 3] - expect_t).max(1)
-    pose_ok = have & (rot_err < 0.03) & (t_err < 0.15)
-    # sampled frames stage by stage against the oracle, on the GPU's own intermediate data
-    world = None
-    bad, detail, checked = 0, [], 0
-    t0 = time.perf_counter()
-    if args.register_check:
-        world = d_world.cpu().numpy()
-        descs = descs2[last].cpu().numpy()
-        for f in sorted({0, NF - 1} | {(i * NF // args.register_check) | 1 for i in range(args.register_check)})[:args.register_check]:
-            nq = int(counts[f])
-            gk = reg.knn[f].cpu().numpy()
-            gnb = np.zeros((V, CAP, 3), _lib.NB_DTYPE)
-            gnb["index"] = gk[..., 0]; gnb["distance"] = gk[..., 1]
-            v = (f * 7) % V
-            tb = view_blocks[f][v]
-            wk = O.knn(descs[f, :200], descs[tb, :counts[tb]], 3)
-            ok = np.array_equal(gnb["index"][v, :200], wk["index"]) and np.array_equal(gnb["distance"][v, :200], wk["distance"])
-            wbest, wdec = O.best_of_views(gnb, nq, lms, np.array(view_blocks[f], np.uint32), counts.astype(np.uint32), 24)
-            ok = ok and np.array_equal(reg.best[f, :nq].cpu().numpy().view(np.uint32), wbest) and np.array_equal(h_dec[f, :nq], wdec)
-            wpairs = O.landmark_pairs(wbest, wdec, world)
-            gp = reg.pairs[f, :h_np[f]].cpu().numpy().view(np.uint32)
-            ok = ok and len(wpairs) == h_np[f] and np.array_equal(gp, wpairs)
-            want = O.p3p_arrsac_pairs(kps[f], wpairs, world, cam, thr, n_hyp, scene=f, shuffle=True, seed=0, init_blocks=1, halve=True,
-                                      sprt=True, **kw)
-            g_inl = reg.inliers[f, :h_ninl[f]].cpu().numpy().view(np.uint32)
-            ok = ok and h_id[f] == want["best_id"] and np.array_equal(g_inl, want["inliers"]) and \
-                (want["best_id"] == 0xFFFFFFFF or h_pose[f].tobytes() == want["pose"].tobytes())
-            checked += 1
-            if not ok:
-                bad += 1
-                detail.append(f"frame {f}: pairs {int(h_np[f])} vs {len(wpairs)}, id {int(h_id[f])} vs {want['best_id']}, inliers {int(h_ninl[f])} vs {len(want['inliers'])}")
-    cpu_s = time.perf_counter() - t0
-    nq_mean = float(counts.mean())
-    dist = float(sum(int(counts[j]) * int(counts[view_blocks[j]].sum()) for j in range(NF)))
-    out = {"workload": f"configs[1] batch ({NF} frames of 1920x1080 per step) -> extract -> hash_bag (4096 codewords) -> knn(., 3) of every "
-                       f"feature against each of {V} recent views ({NF * V} problems of ~{int(nq_mean)}^2) -> best-of-views (better_by 24) -> "
-                       f"(feature, landmark) pair lists -> Lambda Twist ARRSAC per frame ({n_hyp} hypotheses, candidates 1024 halving, 256 "
-                       f"estimations per block, threshold {thr:g}, seeded shuffle); landmarks = 4-px world-canvas cells per level (synthetic "
-                       f"control plane, torch on the device)",
-           "registered_frames_per_s": round(NF / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.register_steps,
-           "knn_distances_per_s": round(dist / dt, 1),
-           "mean_features_per_frame": round(nq_mean, 1), "mean_unique_matches_per_frame": round(float((h_dec == 1).sum()) / NF, 1),
-           "mean_world_matches_per_frame": round(float(h_np.mean()), 1), "mean_inliers_per_frame": round(float(h_ninl.mean()), 1),
-           "frames_with_a_model": int(have.sum()),
-           "frames_whose_pose_is_the_rendered_motion": int(pose_ok.sum()),
-           "pose_error": {"rotation_max_abs": round(float(rot_err[have].max()) if have.any() else -1.0, 6),
-                          "translation_max_abs": round(float(t_err[have].max()) if have.any() else -1.0, 6),
-                          "bounds": "rotation entries within 0.03 of the identity, translation within 0.15 of the rendered camera position "
-                                    "(cell centres stand in for triangulated landmarks: +-2 px at f = 1000 on a plane 5 units away)"},
-           "parity": {"frames_checked": checked, "mismatches": bad, "detail": detail[:4], "cpu_s_per_frame": round(cpu_s / max(1, checked), 2),
-                      "what": "knn(., 3) of 200 features against one view, best-of-views + decisions of all features, the (feature, "
-                              "landmark) pair list, and the consensus (winner id, pose bits, inlier list) of sampled frames vs "
-                              "oracle/match_oracle.c + oracle/arrsac_oracle.c (orc_p3p_arrsac_pairs) on the GPU's own intermediate data"}}
-    if pose_ok.sum() < 0.9 * NF:
-        out["parity"]["mismatches"] += 1
-        out["parity"]["detail"].append(f"only {int(pose_ok.sum())} of {NF} poses are the rendered motion")
-    reg.close()
-    return out
-
-
-def extra_ransac(n_hyp):
-    """BASELINE configs[3] as SURVEY 8d defines it: the scene of eight-point/tests/random.rs with 1 000 matches, 30 %
-    outliers, seed 0x5AC, n_hyp eight-sample hypotheses, threshold 1e-7; host buffers in and out."""
-    from cv_amd.ransac import EssentialConsensus
-    from oracle import oracle as O
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_parity import _two_view_scene
-    rng = np.random.default_rng(0x5AC)
-    n, thr = 1000, 1e-7
-    a, b = _two_view_scene(rng, n, 0.3)
-    samples = np.stack([rng.choice(n, 8, replace=False) for _ in range(n_hyp)]).astype(np.uint32)
-    resample = 64                                   # arrsac's estimations_per_block in the full-shape leg
-    cons = EssentialConsensus(n, n_hyp + resample * 16)
-    cons.model_inliers(a, b, samples, thr)          # warm-up
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pose, inl, best = cons.model_inliers(a, b, samples, thr)
-    dt = (time.perf_counter() - t0) / reps
-    counts = cons.counts(n_hyp)
-    # oracle: the first `sub` hypotheses in full (per-(hypothesis, pose) inlier counts), and the winning hypothesis
-    # on its own (pose bits and inlier set)
-    sub = min(1024, n_hyp)
-    t0 = time.perf_counter()
-    _, _, _, wcounts = O.essential_batch(a, b, samples[:sub], thr)
-    cpu_s = time.perf_counter() - t0
-    bad = int(not np.array_equal(counts[:sub], wcounts))
-    h = best // 4
-    wpose, wbest, winl, wc1 = O.essential_batch(a, b, samples[h:h + 1], thr)
-    bad += int(wbest != best % 4 or wpose.tobytes() != pose.tobytes() or not np.array_equal(winl, inl))
-    bad += int(int(counts.max()) != len(inl) or not np.array_equal(wc1[0], counts[h]))
-    # the same scene through the ARRSAC-shaped entry point: samples drawn on the device, block scoring with the exact
-    # bound, the candidate cap and the SPRT test (vslam-sandbox's parameters); and with the bound alone
-    arr = {}
-    full = dict(max_candidates=1024, bound=True, sprt=True, halve=True, estimations_per_block=resample)
-    for name, kw in (("bound_cap_sprt", dict(max_candidates=1024, bound=True, sprt=True)),
-                     ("bound_only", dict(max_candidates=0, bound=True, sprt=False)),
-                     ("halving_cap_sprt_resampling", full)):
-        cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, **kw)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            apose, ainl, abest, ast = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=n_hyp, seed=0, **kw)
-        adt = (time.perf_counter() - t0) / reps
-        arr[name] = {"hypotheses_per_s": round(n_hyp / adt, 1), "ms_per_scene": round(adt * 1e3, 3),
-                     "residuals_evaluated_frac": round(ast["residuals_evaluated"] / ast["residuals_exhaustive"], 4),
-                     "survivors": ast["survivors"], "inliers": int(len(ainl)), "best_id": int(abest)}
-    # exhaustive scoring of the device-drawn samples: the bound-only run must give the same winner
-    dsamples = cons.arrsac_samples(0, n, n_hyp)
-    epose, einl, ebest = cons.model_inliers(a, b, dsamples, thr)
-    bad += int(arr["bound_only"]["best_id"] != ebest or arr["bound_only"]["inliers"] != len(einl))
-    # the full shape against its specification (oracle/arrsac_oracle.c) at a size the CPU finishes in seconds
-    sub_h = min(2048, n_hyp)
-    got = cons.arrsac_model_inliers(a, b, thr, n_hypotheses=sub_h, seed=0, **full)
-    want = O.arrsac(a, b, thr, sub_h, seed=0, **full)
-    spec_bad = int(got[2] != want[2] or got[0].tobytes() != want[0].tobytes() or not np.array_equal(got[1], want[1])
-                   or any(got[3][k] != want[3][k] for k in ("survivors", "blocks", "poses", "residuals_evaluated")))
-    bad += spec_bad
-    arr["spec_parity"] = {"hypotheses": sub_h, "mismatches": spec_bad,
-                          "what": "winner id, pose bits, inlier list, survivors, blocks, poses made and residuals "
-                                  "evaluated of halving_cap_sprt_resampling vs oracle/arrsac_oracle.c"}
-    arr["note"] = ("rs_essential_arrsac, minimal samples drawn on the device (xoshiro256++, seed 0); bound_only is "
-                   "checked against exhaustive scoring of the same samples; exhaustive_same_samples_best_id "
-                   f"{int(ebest)}, inliers {len(einl)}; halving_cap_sprt_resampling: candidate cap 1024 halving per "
-                   f"block, SPRT, {resample} hypotheses re-sampled from the best pose's inliers after every block")
-    # The exact statement costs ~2.4 kflop of f64 per (pose, match) — 4x4 design matrix (~250 flops) + cyclic Jacobi (~6 sweeps
-    # x 6 rotations x ~60 flops) — but most pairs never reach it: rs_pair_far proves residual >= threshold from the rays'
-    # angle to each other's epipolar plane (~100 flops) and whole waves of such pairs skip the eigen-decomposition.  The
-    # rate is therefore reported as residual DECISIONS per second, not as a fraction of the f64 peak.
-    out = {"workload": f"{n_hyp} eight-point hypotheses x 4 poses x {n} matches (30 % outliers), threshold 1e-7, "
-                       "host buffers in and out",
-           "hypotheses_per_s": round(n_hyp / dt, 1), "residuals_per_s": round(n_hyp * 4 * n / dt, 1),
-           "ms_per_scene": round(dt * 1e3, 3), "inliers": int(len(inl)), "best_id": int(best),
-           "roofline": ransac_roofline(n_hyp, n, dt),
-           "arrsac": arr,
-           "cpu_oracle": {"hypotheses_per_s": round(sub / cpu_s, 1), "cores": 1,
-                          "sample": f"first {sub} hypotheses, {cpu_s:.1f} s"},
-           "parity": {"hypotheses_checked": sub + 1, "mismatches": bad,
-                      "what": "inlier counts of the first hypotheses x 4 poses, and the winning hypothesis' pose bits, "
-                              "pose index and inlier set, vs oracle/ransac_oracle.c"}}
-    cons.close()
-    return out
-
-
-def extra_criterion(_lib):
-    """The reference's own benchmark harness (akaze/benches/criterion.rs:8-52 — the one workload anybody with cargo can
-    reproduce): `extract` = Akaze::sparse().extract_from_gray_float_image on res/0000000000.png (1241 x 376, the first KITTI
-    fixture), and horizontal_filter / vertical_filter of that image with gaussian_kernel(1.0, 7) and gaussian_kernel(10.0, 71).
-    GPU through the C ABI with HOST buffers in and out, as a criterion iteration has them (akz_extract_gray_f32,
-    akz_horizontal_filter / akz_vertical_filter); beside it the -O3 -march=native build of the oracle, one thread, on the same
-    arrays; outputs compared bit for bit."""
-    from cv_amd import akaze as A
-    from oracle import oracle as O
-    z = np.load(os.path.join(ROOT, "tests", "golden", "kitti_pair.npz"))
-    img8 = z["frame0"]
-    img = O.u8_to_f32(img8)
-    h, w = img.shape
-    ak = A.Akaze.sparse()
-    ctx = ak.context(w, h, 1)
-    fast = O.fast_lib()
-    for fn in ("orc_horizontal_filter", "orc_vertical_filter"):
-        getattr(fast, fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-
-    def best_of(f, reps):
-        t = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            r = f()
-            t.append(time.perf_counter() - t0)
-        return r, float(np.median(t))
-    out = {"image": f"res/0000000000.png ({w} x {h}), tests/golden/kitti_pair.npz", "rows": {}, "mismatches": 0,
-           "how": "median wall time per call; GPU = the C ABI with host buffers in and out (one frame per call: launch latency, "
-                  "not throughput, is what is measured); CPU = oracle/ at -O3 -march=native, one thread; outputs bit-identical"}
-    ak.extract_from_gray_float_image(img)                       # context, tables
-    (gk, gd), g_s = best_of(lambda: ak.extract_arrays(img), 20)
-    cfg = O.default_config(threshold=0.01)
-    O.extract_match_many(img8[None], threads=1, match=False, cfg=cfg)
-    cres, c_s = best_of(lambda: O.extract_match_many(img8[None], threads=1, match=False, cfg=cfg), 3)
-    same = gk.tobytes() == cres[0][0].tobytes() and np.array_equal(gd, cres[0][1])
-    out["rows"]["extract"] = {"gpu_ms": round(g_s * 1e3, 3), "cpu_ms": round(c_s * 1e3, 2), "descriptors": int(len(gd)), "bit_identical": bool(same),
-                              "reference": "Akaze::sparse().extract_from_gray_float_image (criterion.rs:8-15); 399 descriptors (estimate_pose.rs:41)"}
-    out["mismatches"] += int(not same) + int(len(gd) != 399)
-    for kname, (r, n) in (("small_kernel", (1.0, 7)), ("large_kernel", (10.0, 71))):
-        k = O.gaussian_kernel(r, n)
-        for direction, gfn, cfn in (("horizontal", A.horizontal_filter, fast.orc_horizontal_filter),
-                                    ("vertical", A.vertical_filter, fast.orc_vertical_filter)):
-            gfn(img, k, ctx)
-            g, g_s = best_of(lambda: gfn(img, k, ctx), 20)
-            co = np.empty_like(img)
-            _, c_s = best_of(lambda: cfn(img.ctypes.data, w, h, k.ctypes.data, len(k), co.ctypes.data), 5)
-            same = g.tobytes() == co.tobytes()
-            out["rows"][f"{direction}_filter_{kname}"] = {"gpu_ms": round(g_s * 1e3, 3), "cpu_ms": round(c_s * 1e3, 3), "taps": n,
-                                                          "bit_identical": bool(same), "reference": f"criterion.rs: gaussian_kernel({r}, {n})"}
-            out["mismatches"] += int(not same)
-    out["parity"] = {"mismatches": out["mismatches"]}
-    return out
-
-
-def ransac_roofline(n_hyp, n, dt):
-    """configs[3] against the FP64 vector roofline (SURVEY 8d names it as the bound of R1-R4).  Every VALU instruction of
-    k_rsb_hypotheses / k_rsb_score_first is f64 arithmetic or its control overhead; SQ_INSTS_VALU per call comes from the
-    committed counter pass of exactly this workload (tools/pmc_ransac.sh -> profiles/<tag>_pmc_ransac.json), the time from
-    this run.  frac = wave-instructions x 64 lanes / time / the 39.3 T lane-instructions/s the chip can issue (one f64
-    instruction per lane and cycle = the 78.6 TFLOP/s FP64 vector peak counted at 2 flops per FMA; the reference's
-    arithmetic is unfused, so a lane-instruction is ONE flop here and flops_frac is half of frac)."""
-    note = ("exhaustive_equivalent = what evaluating ~2.4 kflop for EVERY pair at this rate would take; it exceeds what the chip "
-            "can do because most pairs are decided by the ~100-flop bound (exact: the inlier sets are the oracle's)")
-    base = {"bound": "fp64-valu", "kernel": "k_rsb_score_first + k_rsb_hypotheses (CameraToCamera::residual < threshold per (pose, match): a lower "
-                                            "bound first, the 4x4 Jacobi where it does not decide; 9x9 Jacobi + SVD per hypothesis)",
-            "achieved": None, "peak": VALU_ISSUE_PEAK_T, "unit": "T f64 lane-instr/s", "frac": None, "traffic": None,
-            "exhaustive_equivalent_tflops": round(2400.0 * n_hyp * 4 * n / dt / 1e12, 2), "note": note}
-    try:
-        name = PROFILE_TAG_RANSAC + "_pmc_ransac.json"
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            d = json.load(f)
-        if "10 000" not in d["workload"] or n_hyp != 10000 or n != 1000:
-            return base                      # counters of another workload: nothing is rescaled
-        insts = float(d["valu_insts_per_call"])
-        whole = insts * 64.0 / dt / 1e12
-        base.update({"achieved": round(whole, 2), "frac": round(whole / VALU_ISSUE_PEAK_T, 4),
-                     "flops_frac": round(whole / FP64_VALU_PEAK_TFLOPS, 4),
-                     "frac_is": "SQ_INSTS_VALU of one call x 64 lanes / this run's wall time per call (host buffers in and out, launches "
-                                "included) / 39.3 T lane-instr/s; flops_frac = the same lane-instructions as flops (unfused: one each) / 78.6 TFLOP/s",
-                     "valu_insts_per_call": round(insts), "counters": "profiles/" + name, "kernels": {}})
-        for k, v in d["kernels"].items():
-            if v["kernel_us_per_call"] > 0 and v["valu_insts_per_call"] > 1e6:
-                r = v["valu_insts_per_call"] * 64.0 / (v["kernel_us_per_call"] * 1e-6) / 1e12
-                base["kernels"][k] = {"valu_insts_per_call": round(v["valu_insts_per_call"]), "kernel_us_per_call": round(v["kernel_us_per_call"], 1),
-                                      "frac": round(r / VALU_ISSUE_PEAK_T, 4), "waves_per_call": round(v["waves_per_call"]),
-                                      "timed": "rocprofv3 --kernel-trace of the committed pass (the kernel's own duration)"}
-    except Exception:
-        pass
-    return base
-
-
 def device_probe(torch, dev):
     """What the numbers were measured on: device name, CU count, memory, and a
     device-to-device copy probe (read + write of 1 GiB, best of 5) as the practical HBM ceiling of this box."""
@@ -1546,44 +780,6 @@ def device_probe(torch, dev):
     return {"name": p.name, "gcn_arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
             "hbm_gib": round(p.total_memory / 2**30, 1), "d2d_copy_gbs": round(best, 1),
             "hbm_peak_gbs_spec": HBM_PEAK_GBS}
-
-
-def pmc_traffic(mb):
-    """HBM bytes per launch of each kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json,
-    made by tools/pmc_traffic.py: WRITE_SIZE and doubled FETCH_SIZE per MI355X_MICROARCH.md's gfx950 correction,
-    separate --pmc passes).  Only used when the counters were taken at THIS micro-batch: nothing is rescaled."""
-    try:
-        name = PROFILE_TAG + "_pmc_traffic.json"
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            d = json.load(f)
-        if int(d["micro_batch"]) != int(mb):
-            return None
-        d["file"] = "profiles/" + name
-        return d
-    except Exception:
-        return None
-
-
-def sq_counters():
-    """Issue-side counters of each kernel from the committed SQ passes (profiles/r02_pmc_sq_summary.txt, made by
-    tools/pmc_sq.sh over the serial phase profile at 64 frames per launch): what a kernel that is not HBM-bound is
-    bound by.  Keyed like the kernel families."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    try:
-        from pmc_traffic import family_key
-        out = {}
-        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq_summary.txt")) as f:
-            for line in f.read().splitlines()[1:]:
-                name, rest = line[:52].strip(), line[52:].split()
-                if len(rest) < 8:
-                    continue
-                key = family_key(name + ">") if name.count("<") > name.count(">") else family_key(name)
-                out.setdefault(key, {"file": "profiles/" + PROFILE_TAG + "_pmc_sq_summary.txt", "valu_instructions_per_wave": int(rest[1]),
-                                     "valu_busy_pct": int(rest[2]), "lds_busy_pct": int(rest[3]),
-                                     "lds_bank_conflict_pct": int(rest[4]), "waves_parked_pct": int(rest[5])})
-        return out
-    except Exception:
-        return {}
 
 
 def cpu_baseline(frames, n):
