@@ -698,17 +698,19 @@ constexpr uint32_t kP3PTile = 256;   // matches staged per pass (8 doubles each:
 // Everything else — an uncertified R, a threshold outside (0, 1/2), s2 below the guard or not an ordinary number, a value
 // inside the band — goes to rs_w2c_inlier.  The result is rs_w2c_inlier's, hence the exact statement's, for every input
 // (tests/test_gpu_parity.py::test_block_scoring_pre_test_is_exact_at_the_threshold).
-// Poses a lane scores against every match it reads from LDS.  Measured on a 256-frame registration step (16 384 hypotheses, 256
-// estimations per 64-match block, ~4 150 matches a frame; profiles/r06_register_*): the catch-up launches of the re-sampling
-// rounds — 2 x 16 workgroups a scene, up to 1 024 new poses against every match seen so far, 39 of the consensus' 52 ms — run at
-// 0.72 of the f64 issue rate with one pose a lane (1.07e9 residuals in 1 030 us at the last block); two poses a lane halve
-// the LDS reads per residual and make the first block (65 536 poses a scene) 30 % faster, but leave the second workgroup of
-// a catch-up launch half empty: 339 ms against 301 ms of scoring per six steps.  One.
-constexpr uint32_t kP3PPosesPerLane = 1, kP3PSlots = 256 * kP3PPosesPerLane;
+// One pose a lane.  Measured on a 256-frame registration step (16 384 hypotheses, 256 estimations per 64-match block, ~4 150
+// matches a frame; profiles/r06_register_*): the catch-up launches of the re-sampling rounds — up to 1 024 new poses against
+// every match seen so far, 39 of the consensus' 52 ms — run at 0.72 of the f64 issue rate (1.07e9 residuals in 1 030 us at
+// the last block).  Two poses a lane halve the LDS reads per residual and make the first block (65 536 poses a scene) 30 %
+// faster but leave the second workgroup of a catch-up launch half empty: 339 ms against 301 ms of scoring per six steps.
+// The transpose (lane = match, pose by scalar loads into SGPR operands) is bound by the scalar loads' latency: 376-407 ms.
+// (The compiler's form of this loop matters as much: the exact statement below must stay a BRANCH — flattened into
+// selects, which happened when the same source was written over an array of poses per lane, every residual pays the square
+// root and the three divisions, 1 104 ms — and the loop must be unrolled twice to keep the next match's LDS reads in
+// flight: a convergent vote or a volatile asm in the branch forbids that, 330-383 ms.  tools/check_isa.py holds both.)
 __global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uint32_t m_hi, uint32_t from_first, double thresh)
 {
     __shared__ __attribute__((aligned(16))) double s_m[kP3PTile][8];
-    constexpr int NP = (int)kP3PPosesPerLane;
     const uint32_t s = blockIdx.z;
     const uint32_t n = B.n[s];
     const uint32_t hi = m_hi < n ? m_hi : n;
@@ -717,31 +719,25 @@ __global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uin
     const uint32_t nal = B.nalive[s];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nal > first)
         atomicAdd(&B.neval[s], (unsigned long long)(nal - first) * (unsigned long long)(hi - m_lo));
-    const uint32_t slot0 = first + blockIdx.x * kP3PSlots;
+    const uint32_t slot0 = first + blockIdx.x * 256u;
     if (slot0 >= nal) return;   // whole workgroup
     const uint32_t part = (hi - m_lo + gridDim.y - 1) / gridDim.y;
     const uint32_t lo = m_lo + blockIdx.y * part;
     const uint32_t hi_p = lo + part < hi ? lo + part : hi;
     if (lo >= hi_p) return;
-    const bool thresh_ok = thresh > 0.0 && thresh < 0.5;
-    bool live[NP], fused_ok[NP];
-    uint32_t pid[NP], cnt[NP];
-    double pose[NP][12];
+    const uint32_t slot = slot0 + threadIdx.x;
+    const bool live = slot < nal;
+    const uint32_t pid = live ? B.alive[B.p4(s) + slot] : 0u;
+    double pose[12];
+    const double* pp = B.sposes(s) + (size_t)pid * 12;
 #pragma unroll
-    for (int e = 0; e < NP; ++e) {
-        const uint32_t slot = slot0 + threadIdx.x * kP3PPosesPerLane + (uint32_t)e;   // (adjacent slots: only the last live lane is half empty)
-        live[e] = slot < nal;
-        pid[e] = live[e] ? B.alive[B.p4(s) + slot] : 0u;
-        const double* pp = B.sposes(s) + (size_t)pid[e] * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) pose[e][i] = live[e] ? pp[i] : 0.0;
-        fused_ok[e] = live[e] && thresh_ok && (B.ok[B.p4(s) + pid[e]] & 2u);
-        cnt[e] = 0u;
-    }
+    for (int i = 0; i < 12; ++i) pose[i] = live ? pp[i] : 0.0;
     const double u = 1.0 - thresh, u2 = u * u, k_in6 = u2 * (1.0 + 6e-9), k_out6 = u2 * (1.0 - 6e-9);
+    const bool fused_ok = live && thresh > 0.0 && thresh < 0.5 && (B.ok[B.p4(s) + pid] & 2u);
     const double* ba = B.sa(s);
     const double* bb = B.sb(s);
     const uint32_t* order = B.order ? B.order + (size_t)s * B.n_cap : nullptr;
+    uint32_t cnt = 0;
     for (uint32_t t0 = lo; t0 < hi_p; t0 += kP3PTile) {
         const uint32_t tn = hi_p - t0 < kP3PTile ? hi_p - t0 : kP3PTile;
         __syncthreads();   // the previous tile has been read
@@ -757,7 +753,7 @@ __global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uin
             d[4] = w0; d[5] = w1; d[6] = w2; d[7] = w3;
         }
         __syncthreads();
-        if (live[0]) {
+        if (live) {
 #pragma unroll 2
             for (uint32_t i = 0; i < tn; ++i) {
                 const double2 a01 = *reinterpret_cast<const double2*>(&s_m[i][0]);
@@ -765,36 +761,31 @@ __global__ __launch_bounds__(256) void k_rsb_score_p3p(RsB B, uint32_t m_lo, uin
                 const double2 w01 = *reinterpret_cast<const double2*>(&s_m[i][4]);
                 const double2 w23 = *reinterpret_cast<const double2*>(&s_m[i][6]);
                 const double w[4] = {w01.x, w01.y, w23.x, w23.y};
+                bool inl = false, decided = false;
+                if (fused_ok) {
+                    double q[3];
 #pragma unroll
-                for (int e = 0; e < NP; ++e) {
-                    bool inl = false, decided = !live[e];
-                    if (fused_ok[e]) {
-                        double q[3];
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-                            q[r] = __builtin_fma(pose[e][r * 4 + 0], w[0], __builtin_fma(pose[e][r * 4 + 1], w[1],
-                                                 __builtin_fma(pose[e][r * 4 + 2], w[2], pose[e][r * 4 + 3] * w[3])));
-                        const double s2 = __builtin_fma(q[2], q[2], __builtin_fma(q[1], q[1], q[0] * q[0]));
-                        const double c = __builtin_fma(a2g.x, q[2], __builtin_fma(a01.y, q[1], a01.x * q[0]));
-                        const double c2 = c * c;
-                        const bool yes = c > 0.0 && c2 > k_in6 * s2;
-                        const bool no = c <= 0.0 || c2 < k_out6 * s2;               // (a NaN fails every comparison)
-                        decided = s2 >= a2g.y && s2 < 1e280 && (yes || no);
-                        inl = yes;
-                    }
-                    if (!decided) {
-                        const bool flip = __builtin_signbit(w[3]);
-                        const double a[3] = {flip ? -a01.x : a01.x, flip ? -a01.y : a01.y, flip ? -a2g.x : a2g.x};
-                        inl = rs_w2c_inlier(pose[e], a, w, thresh);
-                    }
-                    cnt[e] += inl ? 1u : 0u;
+                    for (int r = 0; r < 3; ++r)
+                        q[r] = __builtin_fma(pose[r * 4 + 0], w[0], __builtin_fma(pose[r * 4 + 1], w[1],
+                                             __builtin_fma(pose[r * 4 + 2], w[2], pose[r * 4 + 3] * w[3])));
+                    const double s2 = __builtin_fma(q[2], q[2], __builtin_fma(q[1], q[1], q[0] * q[0]));
+                    const double c = __builtin_fma(a2g.x, q[2], __builtin_fma(a01.y, q[1], a01.x * q[0]));
+                    const double c2 = c * c;
+                    const bool yes = c > 0.0 && c2 > k_in6 * s2;
+                    const bool no = c <= 0.0 || c2 < k_out6 * s2;               // (a NaN fails every comparison)
+                    decided = s2 >= a2g.y && s2 < 1e280 && (yes || no);
+                    inl = yes;
                 }
+                if (!decided) {
+                    const bool flip = __builtin_signbit(w[3]);
+                    const double a[3] = {flip ? -a01.x : a01.x, flip ? -a01.y : a01.y, flip ? -a2g.x : a2g.x};
+                    inl = rs_w2c_inlier(pose, a, w, thresh);
+                }
+                cnt += inl ? 1u : 0u;
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < NP; ++e)
-        if (live[e] && cnt[e]) atomicAdd(&B.counts[B.p4(s) + pid[e]], cnt[e]);
+    if (live && cnt) atomicAdd(&B.counts[B.p4(s) + pid], cnt);
 }
 
 // The first block of a call: nothing has been retired yet, so the live list is every valid pose and the four poses of
@@ -1714,8 +1705,7 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
         if constexpr (P3P) {
             uint32_t gy = range / 64;
             gy = gy < 1 ? 1 : (gy > 16 ? 16 : gy);
-            hipLaunchKernelGGL(k_rsb_score_p3p, dim3((slots + kP3PSlots - 1) / kP3PSlots, gy, S), dim3(256), 0, s, B, m_lo, m_hi, from_first,
-                               prm->threshold);
+            hipLaunchKernelGGL(k_rsb_score_p3p, dim3((slots + 255) / 256, gy, S), dim3(256), 0, s, B, m_lo, m_hi, from_first, prm->threshold);
         } else {
             uint32_t lg = 6;
             if (range < 64) {

@@ -314,3 +314,15 @@ def test_profiled_line_agrees_with_the_committed_rocprof_statistics():
         assert abs(r["avg_launch_us"] - avg_us) <= 0.08 * avg_us, (r["kernel"], r["avg_launch_us"], avg_us)
         seen += 1
     assert seen >= 4
+
+
+def test_compiled_form_of_the_kernels_the_compiler_can_ruin():
+    """tools/check_isa.py on the built objects: k_rsb_score_p3p keeps the exact statement of its inlier test behind a branch and
+    its match loop unrolled (the same source has compiled to forms 1.3 and 3.7 times slower)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from cv_amd import build
+    build.build()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
