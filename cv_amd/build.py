@@ -33,7 +33,12 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # an object that is missing or newer than the library (an interrupted or partial build): link again.  (On the GPU box
+    # the objects do not travel — only when SOME are present is their state a statement about the library.)
+    objs = [os.path.join(HERE, "lib", f) for f in os.listdir(os.path.join(HERE, "lib")) if f.endswith(".o")]
+    return any(os.path.getmtime(o) > t for o in objs)
 
 
 def _object_is_current(obj, cmd):
