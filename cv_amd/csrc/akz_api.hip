@@ -362,6 +362,7 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_cache = cv.take<DevKp>(B * K);
     S.d_ncache = cv.take<uint32_t>(B);
     S.d_lvl_slot = cv.take<uint32_t>((size_t)B * (kAkzMaxLevels + 1));
+    S.d_chunk_yr = cv.take<float2>(B * ((K + 63) / 64));
     S.d_sup_flag = cv.take<uint32_t>(B);   // directly before d_sup: flags and the reverse-list counters clear in one memset
     S.d_big_flag = cv.take<uint32_t>(B);   // (between the two: the same memset clears it)
     S.d_sup = cv.take<uint32_t>(sup_scratch_words(c->sup_cap, (uint32_t)B));

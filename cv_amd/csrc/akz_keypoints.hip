@@ -411,23 +411,44 @@ __global__ __launch_bounds__(64) void k_suppress_big(LevelTable T, const uint32_
 // replaced by candidates of higher levels, so an entry of class c+1 lives in a slot pushed at level <= c+1, i.e.
 // before lvl_slot[c+2] (the first-pass kernels record the first slot of every level).  Entry i therefore walks
 // (i, lvl_slot[c+2]) only.  Slots are close to raster order, so the walk is pruned by the y range of every
-// 64-slot chunk (exact: a chunk is skipped only when no entry of it can be within size_i): the block tabulates the
-// ranges of the chunks its entries can need, then every wave loads the chunks that survive the test for at least
-// one of its lanes and broadcasts their entries lane by lane.  No barrier inside the walk.
+// 64-slot chunk (exact: a chunk is skipped only when no entry of it can be within size_i).  k_chunk_yrange tabulates
+// the ranges once per frame; a block copies the part its entries can need into LDS.  A wave then lists, 64 chunks at a
+// time (lane <-> chunk), the chunks whose range meets the y window of its 64 entries, and visits them in order with the
+// NEXT listed chunk's entries already requested (the walk is a chain of L2 round trips otherwise), broadcasting the
+// entries lane by lane.  No barrier inside the walk.
+__global__ __launch_bounds__(256) void k_chunk_yrange(const DevKp* __restrict__ cache, uint32_t max_kp,
+                                                      const uint32_t* __restrict__ ncache, float2* __restrict__ yr,
+                                                      uint32_t yr_stride)
+{
+    const int frame = blockIdx.y;
+    const uint32_t n = min(ncache[frame], max_kp);
+    const uint32_t ck = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (ck * 64u >= n) return;
+    const uint32_t j = ck * 64u + lane;
+    float ylo = 3.0e38f, yhi = -3.0e38f;
+    if (j < n) ylo = yhi = cache[(size_t)frame * max_kp + j].y;
+    for (int off = 32; off > 0; off >>= 1) {
+        ylo = fminf(ylo, __shfl_xor(ylo, off));
+        yhi = fmaxf(yhi, __shfl_xor(yhi, off));
+    }
+    if (lane == 0) yr[(size_t)frame * yr_stride + ck] = make_float2(ylo, yhi);
+}
+
 __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ cache, uint32_t max_kp,
                                                       const uint32_t* __restrict__ ncache,
                                                       const uint32_t* __restrict__ lvl_slot, int nlev,
+                                                      const float2* __restrict__ yr_tab, uint32_t yr_stride,
                                                       uint32_t* __restrict__ flag)
 {
     __shared__ uint32_t s_P[kMaxLevels + 2];
-    __shared__ float2 s_yr[kAkzMaxKeypoints / 64];   // {ymin, ymax} of chunk (rb / 64 + k)
+    __shared__ float2 s_yr[kAkzMaxKeypoints / 64];   // {ymin, ymax} of chunk (cb0 + k)
     __shared__ uint32_t s_range[2];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
     const uint32_t i0 = blockIdx.x * 256;
     if (i0 >= n) return;
     const DevKp* ch = cache + (size_t)frame * max_kp;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if ((int)tid <= nlev) s_P[tid] = min(lvl_slot[(size_t)frame * (kMaxLevels + 1) + tid], n);
     if (tid == 0) {
         s_range[0] = 0xFFFFFFFFu;
@@ -460,56 +481,115 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
     bool rep = false;
     if (any_range) {
         const uint32_t cb0 = s_range[0] >> 6, cb1 = (s_range[1] + 63u) >> 6;   // chunks [cb0, cb1)
-        for (uint32_t ck = cb0 + wv; ck < cb1; ck += 4) {
-            const uint32_t j = ck * 64u + lane;
-            float ylo = 3.0e38f, yhi = -3.0e38f;
-            if (j < n) ylo = yhi = ch[j].y;
-            for (int off = 32; off > 0; off >>= 1) {
-                ylo = fminf(ylo, __shfl_xor(ylo, off));
-                yhi = fmaxf(yhi, __shfl_xor(yhi, off));
-            }
-            if (lane == 0) s_yr[ck - cb0] = make_float2(ylo, yhi);
-        }
+        const float2* yt = yr_tab + (size_t)frame * yr_stride;
+        for (uint32_t ck = cb0 + tid; ck < cb1; ck += 256) s_yr[ck - cb0] = yt[ck];
         __syncthreads();
         const float size2 = ki.size * ki.size;
         const float margin = ki.size * 1.001f + 0.01f;       // conservative: |dy| > margin  =>  dist > size^2
-        if (lo < hi) {                                        // wave-uniform: some lane of this wave has a range
-            // the wave's own window in y (its 64 entries are neighbours in cache order: a few rows): an entry outside it
-            // cannot be within `size` of any lane's keypoint and is not broadcast
-            float wy_lo = has ? ki.y - margin : 3.0e38f, wy_hi = has ? ki.y + margin : -3.0e38f;
+        // One walk per LEVEL REGION present in the wave (region e = the slots pushed at level e, in raster order).  A
+        // wave's 64 entries are neighbours in cache order — a few rows — except where a region ends inside it: the last
+        // rows of one and the first rows of the next together span the whole image, and a walk under their common window
+        // would broadcast every entry of two classes to lanes that cannot use them (such a wave took as long as the rest
+        // of its frame: 84 us of a single-frame call).  Taken region by region, each group's window is as narrow as any
+        // other wave's.
+        uint32_t reg = 0;
+        for (int e = 1; e < nlev; ++e) reg += s_P[e] <= i ? 1u : 0u;
+        unsigned long long todo = __ballot(has);
+        while (todo) {
+            const uint32_t cur = rl_u(reg, (uint32_t)__ffsll((long long)todo) - 1u);
+            const bool act = has && reg == cur;
+            todo &= ~__ballot(act);
+            uint32_t glo = act ? jb : 0xFFFFFFFFu, ghi = act ? je : 0u;   // the group's union
+            // its window in y (an entry outside it cannot be within `size` of any of the group's keypoints and is not
+            // broadcast) and the classes it wants
+            float wy_lo = act ? ki.y - margin : 3.0e38f, wy_hi = act ? ki.y + margin : -3.0e38f;
+            uint32_t wmin = act ? want : 0xFFFFFFFFu, wmax = act ? want : 0u;
             for (int off = 32; off > 0; off >>= 1) {
+                glo = min(glo, (uint32_t)__shfl_xor((int)glo, off));
+                ghi = max(ghi, (uint32_t)__shfl_xor((int)ghi, off));
                 wy_lo = fminf(wy_lo, __shfl_xor(wy_lo, off));
                 wy_hi = fmaxf(wy_hi, __shfl_xor(wy_hi, off));
+                wmin = min(wmin, (uint32_t)__shfl_xor((int)wmin, off));
+                wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
             }
-            for (uint32_t ck = lo >> 6; ck < ((hi + 63u) >> 6); ++ck) {
-                const float2 yr = s_yr[ck - cb0];
-                const uint32_t c_lo = ck * 64u, c_hi = c_lo + 64u;
-                const bool need = !rep && jb < c_hi && je > c_lo && ki.y + margin >= yr.x && ki.y - margin <= yr.y;
-                if (!__any(need)) continue;
-                const uint32_t j = c_lo + lane;
-                float ex = 0.f, ey = 0.f, er = 0.f;
-                uint32_t ec = 0xFFFFFFFFu;
-                if (j < n) {
-                    const DevKp kj = ch[j];
-                    ex = kj.x; ey = kj.y; er = kj.response; ec = kj.class_id;
+            const uint32_t cend = (ghi + 63u) >> 6;
+            for (uint32_t g0 = glo >> 6; g0 < cend; g0 += 64u) {
+                // lane <-> chunk g0 + lane: listed when its y range meets the group's window
+                const uint32_t mck = g0 + lane;
+                bool listed = false;
+                if (mck < cend) {
+                    const float2 yr = s_yr[mck - cb0];
+                    listed = wy_hi >= yr.x && wy_lo <= yr.y;
                 }
-                // entries whose class some needing lane of the wave wants
-                uint32_t wmin = need ? want : 0xFFFFFFFFu, wmax = need ? want : 0u;
-                for (int off = 32; off > 0; off >>= 1) {
-                    wmin = min(wmin, (uint32_t)__shfl_xor((int)wmin, off));
-                    wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
-                }
-                unsigned long long m = __ballot(ec >= wmin && ec <= wmax && ey >= wy_lo && ey <= wy_hi);
-                while (m) {
-                    const uint32_t t = (uint32_t)__ffsll((long long)m) - 1u;
-                    m &= m - 1ull;
-                    const float qx = rl_f(ex, t), qy = rl_f(ey, t), qr = rl_f(er, t);
-                    const uint32_t qc = rl_u(ec, t), jj = c_lo + t;
-                    if (need && jj >= jb && jj < je && qc == want) {
-                        const float dx = ki.x - qx, dy = ki.y - qy;
-                        const float dist = dx * dx + dy * dy;
-                        if (dist <= size2 && ki.response <= qr) rep = true;
+                unsigned long long cm = __ballot(listed);
+                if (!cm) continue;
+                float ex = 0.f, ey = 0.f, er = 0.f, nx = 0.f, ny = 0.f, nr = 0.f;
+                uint32_t ec = 0xFFFFFFFFu, nc = 0xFFFFFFFFu;
+                uint32_t b = (uint32_t)__ffsll((long long)cm) - 1u;
+                cm &= cm - 1ull;
+                {
+                    const uint32_t j = (g0 + b) * 64u + lane;
+                    if (j < n) {
+                        const DevKp kj = ch[j];
+                        ex = kj.x; ey = kj.y; er = kj.response; ec = kj.class_id;
                     }
+                }
+                for (;;) {
+                    const uint32_t ck = g0 + b;
+                    const bool more = cm != 0ull;
+                    if (more) {                               // the next listed chunk's entries: in flight behind this one's compares
+                        b = (uint32_t)__ffsll((long long)cm) - 1u;
+                        cm &= cm - 1ull;
+                        const uint32_t j = (g0 + b) * 64u + lane;
+                        nx = ny = nr = 0.f;
+                        nc = 0xFFFFFFFFu;
+                        if (j < n) {
+                            const DevKp kj = ch[j];
+                            nx = kj.x; ny = kj.y; nr = kj.response; nc = kj.class_id;
+                        }
+                    }
+                    const float2 yr = s_yr[ck - cb0];
+                    const uint32_t c_lo = ck * 64u, c_hi = c_lo + 64u;
+                    const bool need = act && !rep && jb < c_hi && je > c_lo && ki.y + margin >= yr.x && ki.y - margin <= yr.y;
+                    const unsigned long long nm0 = __ballot(need);
+                    if (nm0) {
+                        const bool cok = ec >= wmin && ec <= wmax && ey >= wy_lo && ey <= wy_hi;
+                        unsigned long long m = __ballot(cok);
+                        if (__popcll(m) <= __popcll(nm0)) {
+                            // the chunk's candidates one by one to every lane (the common case: a dense group of 64 neighbours)
+                            while (m) {
+                                const uint32_t t = (uint32_t)__ffsll((long long)m) - 1u;
+                                m &= m - 1ull;
+                                const float qx = rl_f(ex, t), qy = rl_f(ey, t), qr = rl_f(er, t);
+                                const uint32_t qc = rl_u(ec, t), jj = c_lo + t;
+                                if (need && jj >= jb && jj < je && qc == want) {
+                                    const float dx = ki.x - qx, dy = ki.y - qy;
+                                    const float dist = dx * dx + dy * dy;
+                                    if (dist <= size2 && ki.response <= qr) rep = true;
+                                }
+                            }
+                        } else {
+                            // the other way round — the few entries that need this chunk, one by one, against its 64 slots held by
+                            // the lanes.  A group that is sparse in y (a level that pushed few slots of its own: two dozen entries
+                            // over the whole image) lists every chunk of its range under its window, but each chunk is needed by
+                            // one or two of its entries only; broadcasting the candidates cost such a wave 1 000 steps for 66.
+                            unsigned long long nm = nm0, hitm = 0ull;
+                            const uint32_t jj = c_lo + lane;
+                            while (nm) {
+                                const uint32_t t = (uint32_t)__ffsll((long long)nm) - 1u;
+                                nm &= nm - 1ull;
+                                const float bx = rl_f(ki.x, t), by = rl_f(ki.y, t), bs2 = rl_f(size2, t), br = rl_f(ki.response, t);
+                                const uint32_t bw = rl_u(want, t), bjb = rl_u(jb, t), bje = rl_u(je, t);
+                                const float dx = bx - ex, dy = by - ey;
+                                const float dist = dx * dx + dy * dy;
+                                const bool hit = cok && jj >= bjb && jj < bje && ec == bw && dist <= bs2 && br <= er;
+                                if (__any(hit)) hitm |= 1ull << t;
+                            }
+                            if ((hitm >> lane) & 1ull) rep = true;
+                        }
+                    }
+                    if (!more) break;
+                    ex = nx; ey = ny; er = nr; ec = nc;
                 }
             }
         }
@@ -2216,8 +2296,13 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         AKZ_LAUNCH_CHECK();
     }
     const uint32_t kb = (uint32_t)akz_div_up((int)c->max_kp, 256);
+    float2* const yr_tab = reinterpret_cast<float2*>(S.d_chunk_yr);
+    const uint32_t yr_stride = (uint32_t)akz_div_up((int)c->max_kp, 64);
+    hipLaunchKernelGGL(k_chunk_yrange, dim3((uint32_t)akz_div_up((int)yr_stride, 4), n), dim3(256), 0, s, S.d_cache, c->max_kp,
+                       S.d_ncache, yr_tab, yr_stride);
+    AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache,
-                       (const uint32_t*)S.d_lvl_slot, T.n, S.d_flag_b);
+                       (const uint32_t*)S.d_lvl_slot, T.n, (const float2*)yr_tab, yr_stride, S.d_flag_b);
     AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_cache, (const akz_descriptor*)nullptr,
                        S.d_flag_b, S.d_ncache, c->max_kp, S.d_kp_a, (akz_descriptor*)nullptr, c->max_kp, S.d_n_a,
