@@ -248,7 +248,7 @@ def main():
             tA = time.perf_counter()
             _lib.check(L.akz_extract_batch_device(
                 ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps[m0:m0 + MB].data_ptr(),
-                descs[m0:m0 + MB].data_ptr(), CAP, counts[m0:m0 + MB].data_ptr(), cur.cuda_stream), "extract")
+                descs[m0:m0 + MB].data_ptr(), CAP, counts[m0:m0 + MB].data_ptr(), _lib.wait_handle(cur)), "extract")
             tB = time.perf_counter()
             js = [j for j in range(m0, m0 + MB) if j > 0]
             if m0 + MB == NF:
@@ -283,7 +283,7 @@ def main():
             # problem p writes pairs/npairs block p of the view starting at js[0]'s slot; keep them per frame
             _lib.check(L.hm_match_batch_device(
                 matcher.handle, descs.data_ptr(), counts.data_ptr(), tb.data_ptr(), nb.data_ptr(), CAP, ia, ib,
-                len(js), RULE_STRICT, 24, 0.0, 1, pairs[m0:].data_ptr(), npairs[m0:].data_ptr(), wait.cuda_stream),
+                len(js), RULE_STRICT, 24, 0.0, 1, pairs[m0:].data_ptr(), npairs[m0:].data_ptr(), _lib.wait_handle(wait)),
                 "match")
             if verify["on"] is not None:
                 verify["on"](p, m0, js, [(j - 1) % NF for j in js])
@@ -304,7 +304,7 @@ def main():
                 _lib.check(L.hm_knn_batch_device(matcher.handle, descs.data_ptr(), counts.data_ptr(), views_d.data_ptr(),
                                                  views_n.data_ptr(), CAP, idx(iq[p0:p1]), idx(it[p0:p1]), p1 - p0, 2,
                                                  knn_out2[p].view(-1, CAP, 2, 2)[p0:].data_ptr(),
-                                                 wait.cuda_stream if p0 == 0 else None), "knn_batch")
+                                                 _lib.wait_handle(wait) if p0 == 0 else None), "knn_batch")
         match_done[p].record(hm_stream)
         step_no[0] += 1
 

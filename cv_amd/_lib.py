@@ -277,3 +277,14 @@ def lib():
 def check(status, what=""):
     if status != 0:
         raise AkzError(status, what)
+
+
+STREAM_LEGACY = 1   # include/akz.h AKZ_STREAM_LEGACY (= hipStreamLegacy)
+
+
+def wait_handle(stream):
+    """The `stream_to_wait` argument for a torch stream: its handle, or AKZ_STREAM_LEGACY for the legacy default stream —
+    whose handle is 0, which the ABI reads as "nothing to wait for" (the library's streams are non-blocking: they do not
+    synchronise with the default stream by themselves)."""
+    h = stream.cuda_stream
+    return h if h else STREAM_LEGACY

@@ -363,6 +363,9 @@ static void carve_set(akz_ctx* c, AkzSet& S, Carver& cv)
     S.d_ncache = cv.take<uint32_t>(B);
     S.d_lvl_slot = cv.take<uint32_t>((size_t)B * (kAkzMaxLevels + 1));
     S.d_chunk_yr = cv.take<float2>(B * ((K + 63) / 64));
+    size_t cand_rows = 0;
+    for (const AkzLevel& L : P.levels) cand_rows += (size_t)L.h + 1;
+    S.d_cand_rows = cv.take<uint32_t>(B * cand_rows);
     S.d_sup_flag = cv.take<uint32_t>(B);   // directly before d_sup: flags and the reverse-list counters clear in one memset
     S.d_big_flag = cv.take<uint32_t>(B);   // (between the two: the same memset clears it)
     S.d_sup = cv.take<uint32_t>(sup_scratch_words(c->sup_cap, (uint32_t)B));
@@ -485,7 +488,7 @@ static int32_t sync_all(akz_ctx* c)
 static int32_t wait_for(akz_ctx* c, void* stream_to_wait)
 {
     if (!stream_to_wait) return AKZ_OK;
-    AKZ_HIP(hipEventRecord(c->ev_input, (hipStream_t)stream_to_wait));
+    AKZ_HIP(hipEventRecord(c->ev_input, akz_wait_stream(stream_to_wait)));
     AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev_input, 0));
     return AKZ_OK;
 }

@@ -231,7 +231,7 @@ static int32_t comm_begin(akz_comm* c, void* stream_to_wait, hipEvent_t* e0, hip
 {
     AKZ_HIP(hipSetDevice(c->device));
     if (stream_to_wait) {
-        AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+        AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
         AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
     }
     *e0 = *e1 = nullptr;

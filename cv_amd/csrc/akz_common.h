@@ -28,6 +28,10 @@ extern thread_local int g_akz_last_hip;
     } while (0)
 #define AKZ_LAUNCH_CHECK() AKZ_HIP(hipGetLastError())
 
+// `stream_to_wait` arguments of the ABI: NULL = nothing to wait for; AKZ_STREAM_LEGACY (include/akz.h, the value of
+// hipStreamLegacy) = the legacy default stream, whose own handle is NULL too and could not be told from "none".
+inline hipStream_t akz_wait_stream(void* h) { return h == (void*)1 ? (hipStream_t)nullptr : (hipStream_t)h; }
+
 // Slots per frame in every per-(frame, level) table (candidate counts and lists, the keypoint kernels' level
 // table).  A configuration whose pyramid has more levels is refused at akz_create (AKZ_E_INVALID).
 constexpr int kAkzMaxLevels = 32;

@@ -42,6 +42,7 @@ struct AkzSet {
     uint32_t* d_ncache = nullptr;          // [B]
     size_t zero_bytes = 0;                 // d_cmax .. end of d_fine: cleared by one memset at the start of a call
     uint32_t* d_lvl_slot = nullptr;        // [B][kAkzMaxLevels + 1] first cache slot pushed at every level (+ the total)
+    uint32_t* d_cand_rows = nullptr;       // [B][sum over levels of (h + 1)] row-start tables of the raster-sorted candidate lists (k_cand_rows)
     void* d_chunk_yr = nullptr;            // [B][ceil(max_kp / 64)] float2 {ymin, ymax} of every 64-slot chunk of the cache (k_chunk_yrange)
     uint32_t* d_sup = nullptr;             // [B][sup_cap * (2 * 24 + 6)] scratch of the parallel suppression (k_sup_*)
     uint32_t* d_sup_flag = nullptr;        // [B] 1 = this frame takes the serial k_suppress

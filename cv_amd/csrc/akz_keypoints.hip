@@ -45,11 +45,13 @@ struct LevelDesc {  // per-level constants for the keypoint kernels
     size_t fs;        // frame stride (pixels)
     uint32_t octave;
     float kp_size;    // (esigma * derivative_factor) as f32
+    uint32_t row_off; // this level's first word in a frame's row-start table (k_cand_rows): h + 1 words per level
 };
 constexpr int kMaxLevels = kAkzMaxLevels;
 struct LevelTable {
     LevelDesc L[kMaxLevels];
     int n;
+    uint32_t rows_total;   // words of a frame's row-start table
 };
 
 // A12a (candidate test + border test) is fused into the second-order derivative kernel and followed by a
@@ -747,9 +749,29 @@ __device__ __forceinline__ int sup_level(const uint32_t* base, int nlev, uint32_
     return e;
 }
 
+// Row-start table of a raster-sorted candidate list: rows[y] = the first candidate whose row is >= y, for y in [0, h]
+// (rows[h] = the list's length).  k_sup_adj bounds its scans with two look-ups instead of a twelve-step bisection of
+// the list (every step an L2 round trip).
+__global__ __launch_bounds__(1024) void k_cand_rows(LevelTable T, const uint32_t* __restrict__ ncand,
+                                                    const uint2* __restrict__ cand, uint32_t max_cand,
+                                                    uint32_t* __restrict__ rows)
+{
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const uint32_t n = min(ncand[(size_t)frame * kAkzMaxLevels + level], max_cand);
+    const uint32_t h = (uint32_t)T.L[level].h;
+    const uint2* lst = cand + ((size_t)frame * kAkzMaxLevels + level) * max_cand;
+    uint32_t* R = rows + (size_t)frame * T.rows_total + T.L[level].row_off;
+    for (uint32_t j = threadIdx.x; j <= n; j += 1024) {
+        const uint32_t r = j < n ? min(lst[j].x >> 16, h) : h;          // (the entry past the end takes the rows that are left)
+        const uint32_t first = j > 0 ? (lst[j - 1].x >> 16) + 1u : 0u;  // rows not yet covered by an earlier candidate
+        for (uint32_t y = first; y <= r; ++y) R[y] = j;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* __restrict__ ncand,
                                                  const uint2* __restrict__ cand, uint32_t max_cand, uint32_t* scratch,
-                                                 uint32_t cap, uint32_t* __restrict__ fallback)
+                                                 uint32_t cap, uint32_t* __restrict__ fallback,
+                                                 const uint32_t* __restrict__ rows)
 {
     __shared__ uint32_t s_base[kMaxLevels + 1];
     const int frame = blockIdx.y;
@@ -765,10 +787,11 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
     __syncthreads();
     const uint32_t N = s_base[T.n];
     if (N > cap) return;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= N) return;
     const SupFrame F = sup_frame(scratch, cap, frame, gridDim.y);
     const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
+    const uint32_t* RT = rows + (size_t)frame * T.rows_total;
+    // (the grid is sized for a typical frame, not for `cap`: a block takes every gridDim.x-th group of 256 candidates)
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < N; g += gridDim.x * 256) {
     uint32_t i;
     const int e = sup_level(s_base, T.n, g, &i);
     const uint2 me = cd[(size_t)e * max_cand + i];
@@ -789,15 +812,11 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
         const float lo = (fy - size - hoff) / rl - 1.0f, hi = (fy + size - hoff) / rl + 1.0f;
         const uint32_t ylo = lo > 0.0f ? (uint32_t)lo : 0u;
         const uint32_t yhi = hi > 0.0f ? (uint32_t)hi : 0u;
-        uint32_t a = 0, b = lim;                             // lower bound of row >= ylo in [0, lim)
-        while (a < b) {
-            uint32_t m = (a + b) >> 1;
-            if ((lst[m].x >> 16) < ylo) a = m + 1;
-            else b = m;
-        }
-        for (uint32_t j = a; j < lim; ++j) {
-            const uint32_t xy = lst[j].x;
-            if ((xy >> 16) > yhi) break;
+        // the candidates of rows [ylo, yhi] among the first `lim`: two look-ups in the row-start table
+        const uint32_t hL = (uint32_t)T.L[Lv].h;
+        const uint32_t* R = RT + T.L[Lv].row_off;
+        const uint32_t a = min(R[min(ylo, hL)], lim), b = min(R[min(yhi + 1u, hL)], lim);
+        auto test = [&](uint32_t xy, uint32_t j) {
             // the entry n = (Lv, j) would hold: K(n) = p * ratio + 0.5 (ratio - 1)   (:106-109)
             const float kx = (float)(xy & 0xFFFFu) * rl + hoff, ky = (float)(xy >> 16) * rl + hoff;
             const float dx = fx - kx, dy = fy - ky;
@@ -810,10 +829,20 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
                 if (r < (uint32_t)kSupDeg) F.radj[(size_t)nidx * kSupDeg + r] = g;
                 else over = true;
             }
+        };
+        // (four entries requested before the first is looked at: the scan is a chain of L2 round trips otherwise)
+        for (uint32_t j = a; j < b; j += 4) {
+            uint32_t xy[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) xy[q] = lst[min(j + q, b - 1u)].x;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q)
+                if (j + q < b) test(xy[q], j + q);
         }
     }
     F.nadj[g] = min(cnt, (uint32_t)kSupDeg);
     if (over) fallback[frame] = 1u;
+    }
 }
 
 // CHUNK_PARALLEL: one workgroup per (chunk, frame) — blockIdx.x = chunk — chained through the frame's done[] flags
@@ -2096,6 +2125,7 @@ void build_level_table(akz_ctx* c, LevelTable* T)
     const AkzPlan& P = c->plan;
     AkzSet& S = c->S();
     T->n = (int)P.levels.size();
+    uint32_t rows = 0;
     for (int i = 0; i < T->n; ++i) {
         const AkzLevel& L = P.levels[i];
         LevelDesc& d = T->L[i];
@@ -2107,7 +2137,10 @@ void build_level_table(akz_ctx* c, LevelTable* T)
         d.fs = L.pixels();
         d.octave = L.octave;
         d.kp_size = L.kp_size;
+        d.row_off = rows;
+        rows += (uint32_t)L.h + 1u;
     }
+    T->rows_total = rows;
 }
 
 }  // namespace
@@ -2268,8 +2301,11 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
         // counters and the replaced marks
         AKZ_HIP(hipMemsetAsync(S.d_sup_flag, 0, (size_t)((char*)S.d_sup - (char*)S.d_sup_flag) +
                                                     sizeof(uint32_t) * sup_zero_words(c->sup_cap, (uint32_t)n), s));
-        hipLaunchKernelGGL(k_sup_adj, dim3(akz_div_up((int)c->sup_cap, 256), n), dim3(256), 0, s, T, S.d_ncand, S.d_cand,
-                           c->max_cand, S.d_sup, c->sup_cap, S.d_sup_flag);
+        hipLaunchKernelGGL(k_cand_rows, dim3(T.n, n), dim3(1024), 0, s, T, S.d_ncand, S.d_cand, c->max_cand, S.d_cand_rows);
+        AKZ_LAUNCH_CHECK();
+        const uint32_t adj_blocks = (uint32_t)akz_div_up((int)c->sup_cap, 256);
+        hipLaunchKernelGGL(k_sup_adj, dim3(n > 16 && adj_blocks > 48u ? 48u : adj_blocks, n), dim3(256), 0, s, T, S.d_ncand, S.d_cand,
+                           c->max_cand, S.d_sup, c->sup_cap, S.d_sup_flag, (const uint32_t*)S.d_cand_rows);
         AKZ_LAUNCH_CHECK();
         if (n <= 16)
             hipLaunchKernelGGL((k_sup_resolve<true>), dim3(akz_div_up((int)c->sup_cap, 1024), n), dim3(1024), 0, s, T, S.d_ncand,

@@ -2726,9 +2726,15 @@ __global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ L
 // records into the sorted position / response list and the sorted neighbourhood list.
 constexpr uint32_t kCandRadixMax = 4096;
 constexpr size_t kCandRadixLdsBytes = sizeof(uint32_t) * (3 * (size_t)kCandRadixMax + 16 * 256);
+struct CandLevelRows {
+    uint32_t h[kAkzMaxLevels];   // rows of every level's plane
+};
+constexpr uint32_t kCandCountRows = 2048;   // the counting path's row histogram (one thread owns two rows) ...
+constexpr uint32_t kCandCountMax = 4096;    // ... and its list length (four candidates per thread)
 __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ cand_u, const uint32_t* __restrict__ ncand,
                                                     uint32_t cap, uint2* __restrict__ cand, float* __restrict__ cand_nb,
-                                                    unsigned long long* __restrict__ gkeys, uint32_t gstride, uint32_t lds_keys)
+                                                    unsigned long long* __restrict__ gkeys, uint32_t gstride, uint32_t lds_keys,
+                                                    CandLevelRows rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* lds = reinterpret_cast<unsigned long long*>(smem);
@@ -2737,6 +2743,96 @@ __global__ __launch_bounds__(1024) void k_cand_sort(const CandU* __restrict__ ca
     if (n == 0) return;
     const size_t list = ((size_t)frame * kAkzMaxLevels + level) * cap;
     const CandU* seg = cand_u + list;
+    if (n <= 256) {
+        // a short list (the last octaves): positions are unique, so a candidate's place is the number of keys below its
+        // own — one thread per candidate, the keys read back four at a time as LDS broadcasts.  (Quadratic: at 1 000
+        // candidates the block took 13 us, LDS-bound; the radix passes further down cost ~21 us whatever the length.)
+        uint32_t* rk = reinterpret_cast<uint32_t*>(smem);
+        const uint32_t tid = threadIdx.x, n4 = (n + 3u) & ~3u;
+        uint32_t mine = 0xFFFFFFFFu;
+        CandU cu;
+        if (tid < n) {
+            cu = seg[tid];
+            mine = ((cu.xy >> 16) << 16) | (cu.xy & 0xFFFFu);   // y in the high half: raster order
+        }
+        if (tid < n4) rk[tid] = mine;
+        __syncthreads();
+        if (tid < n) {
+            const uint4* r4 = reinterpret_cast<const uint4*>(rk);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n4 / 4u; ++j) {
+                const uint4 k = r4[j];
+                rank += (k.x < mine ? 1u : 0u) + (k.y < mine ? 1u : 0u) + (k.z < mine ? 1u : 0u) + (k.w < mine ? 1u : 0u);
+            }
+            cand[list + rank] = make_uint2(cu.xy, __float_as_uint(cu.v));
+            float4* nb = reinterpret_cast<float4*>(cand_nb + (list + rank) * 8);
+            nb[0] = make_float4(cu.nb[0], cu.nb[1], cu.nb[2], cu.nb[3]);
+            nb[1] = make_float4(cu.nb[4], cu.nb[5], cu.nb[6], cu.nb[7]);
+        }
+        return;
+    }
+    const uint32_t h = rows.h[level];
+    if (n <= kCandCountMax && h < kCandCountRows) {
+        // Counting sort by row, then by column inside the row.  A 1080p level holds ~1 300 candidates on 1 080 rows: a row
+        // group is one or two entries, so the place of a candidate is its row's start (a histogram of the rows and its
+        // exclusive scan) plus the number of entries of the row's group left of it — three barriers and no pass structure
+        // (~6 us a list against the ~21 us of four radix passes).
+        uint32_t* hist = reinterpret_cast<uint32_t*>(smem);                    // [h + 1] counts, then row starts
+        uint2* grp = reinterpret_cast<uint2*>(hist + kCandCountRows + 4);       // [n] {x, id} grouped by row, arrival order
+        __shared__ uint32_t s_wsum[16];
+        const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+        for (uint32_t b = tid; b <= h; b += 1024) hist[b] = 0u;
+        __syncthreads();
+        uint32_t xy[4], slot[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t i = tid + 1024u * q;
+            xy[q] = 0u;
+            slot[q] = 0u;
+            if (i < n) {
+                xy[q] = seg[i].xy;
+                slot[q] = atomicAdd(&hist[min(xy[q] >> 16, h)], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the row counts: thread t owns rows 2t and 2t + 1
+        const uint32_t c0 = 2u * tid <= h ? hist[2u * tid] : 0u, c1 = 2u * tid + 1u <= h ? hist[2u * tid + 1u] : 0u;
+        uint32_t inc = c0 + c1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63u) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wv; ++w) before += s_wsum[w];
+        const uint32_t excl = before + inc - (c0 + c1);
+        if (2u * tid <= h) hist[2u * tid] = excl;
+        if (2u * tid + 1u <= h) hist[2u * tid + 1u] = excl + c0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t i = tid + 1024u * q;
+            if (i < n) grp[hist[min(xy[q] >> 16, h)] + slot[q]] = make_uint2(xy[q] & 0xFFFFu, i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t i = tid + 1024u * q;
+            if (i < n) {
+                const uint32_t y = min(xy[q] >> 16, h), x = xy[q] & 0xFFFFu;
+                const uint32_t g0 = hist[y], g1 = y < h ? hist[y + 1u] : n;
+                uint32_t pos = g0;
+                for (uint32_t k = g0; k < g1; ++k) pos += grp[k].x < x ? 1u : 0u;
+                const CandU cu = seg[i];
+                cand[list + pos] = make_uint2(cu.xy, __float_as_uint(cu.v));
+                float4* nb = reinterpret_cast<float4*>(cand_nb + (list + pos) * 8);
+                nb[0] = make_float4(cu.nb[0], cu.nb[1], cu.nb[2], cu.nb[3]);
+                nb[1] = make_float4(cu.nb[4], cu.nb[5], cu.nb[6], cu.nb[7]);
+            }
+        }
+        return;
+    }
     if (n <= kCandRadixMax) {
         // positions inside a level are unique 32-bit keys (y << 16 | x): LSD radix sort of the ids in LDS (akz_common.h)
         // instead of the bitonic network over padded 64-bit keys; lists of up to kCandRadixMax candidates (64 KB of LDS:
@@ -3352,13 +3448,15 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         uint32_t np2 = 1;
         while (np2 < c->max_cand) np2 <<= 1;
         const uint32_t lds_keys = np2 < kAkzLdsSortKeys ? np2 : kAkzLdsSortKeys;
+        CandLevelRows cand_rows;
+        for (int i = 0; i < kAkzMaxLevels; ++i) cand_rows.h[i] = i < nlev ? (uint32_t)P.levels[i].h : 0u;
         if (n <= kLatencyFrames)
             AKZ_LAUNCH(k_cand_rank, dim3(akz_div_up((int)c->max_cand, 32), nlev, n), dim3(256), 0, s, (const CandU*)S.d_cand_u,
                                S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb);
         else
             AKZ_LAUNCH(k_cand_sort, dim3(nlev, n), dim3(1024),
                                std::max<size_t>(sizeof(unsigned long long) * lds_keys, kCandRadixLdsBytes), s, (const CandU*)S.d_cand_u,
-                               S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb, S.d_keys_cand, np2, lds_keys);
+                               S.d_ncand, c->max_cand, S.d_cand, S.d_cand_nb, S.d_keys_cand, np2, lds_keys, cand_rows);
         AKZ_LAUNCH_CHECK();
     }
     akz_timer_end(c, AKZ_T_SCALE_SPACE, s, 0, (uint64_t)n);

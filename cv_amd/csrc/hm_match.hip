@@ -1276,7 +1276,7 @@ extern "C" int32_t hm_knn_views_device(hm_ctx* c, const void* d_q, const void* d
         if (n_views == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_views)));
@@ -1303,7 +1303,7 @@ extern "C" int32_t hm_knn_batch_device(hm_ctx* c, const void* d_q, const void* d
         if (n_probs == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         AKZ_TRY(hm_ensure_probs(c, knn_stage_bytes(n_probs)));
@@ -1386,7 +1386,7 @@ extern "C" int32_t hm_best_of_views_device(hm_ctx* c, const void* d_knn, const v
         if (k < 1 || k > 3 || n_views == 0 || n_views > 64 || cap_per_img == 0) return AKZ_E_INVALID;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         AKZ_TRY(hm_ensure_probs(c, 256));
@@ -1414,7 +1414,7 @@ extern "C" int32_t hm_best_of_views_batch_device(hm_ctx* c, const void* d_knn, c
         if (n_frames == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         const size_t vi_bytes = akz_align_up(sizeof(uint32_t) * (size_t)n_frames * n_views, 64);
@@ -1593,7 +1593,7 @@ extern "C" int32_t hm_landmark_matches_ordered_batch_device(hm_ctx* c, const voi
         if (n_frames == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         AKZ_TRY(hm_ensure_probs(c, sizeof(uint32_t) * n_frames + 64));
@@ -1712,7 +1712,7 @@ extern "C" int32_t hm_match_batch_device(hm_ctx* c, const void* d_a, const void*
         if (n_pairs == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         const uint32_t ndir = symmetric ? 2u : 1u;
@@ -1807,7 +1807,7 @@ extern "C" int32_t hm_hash_bag_device(hm_ctx* c, const void* d_descs, const void
         if (n_frames == 0) return AKZ_OK;
         AKZ_HIP(hipSetDevice(c->device));
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
         }
         return hash_bag_launch(c, (const uint4*)d_descs, (const uint32_t*)d_counts, cap_per_img, n_frames,

@@ -1888,7 +1888,7 @@ extern "C" int32_t rs_essential_arrsac_batch_device(rs_ctx* c, const void* d_kps
         AKZ_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(s, c->ev, 0));
         }
         AKZ_HIP(hipMemcpyAsync(c->d_frames, ia, sizeof(uint32_t) * n_scenes, hipMemcpyHostToDevice, s));
@@ -1950,7 +1950,7 @@ extern "C" int32_t rs_p3p_arrsac_batch_device(rs_ctx* c, const void* d_kps, uint
         AKZ_HIP(hipSetDevice(c->device));
         hipStream_t s = c->stream;
         if (stream_to_wait) {
-            AKZ_HIP(hipEventRecord(c->ev, (hipStream_t)stream_to_wait));
+            AKZ_HIP(hipEventRecord(c->ev, akz_wait_stream(stream_to_wait)));
             AKZ_HIP(hipStreamWaitEvent(s, c->ev, 0));
         }
         AKZ_HIP(hipMemcpyAsync(c->d_frames, ik, sizeof(uint32_t) * n_scenes, hipMemcpyHostToDevice, s));

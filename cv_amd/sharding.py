@@ -191,14 +191,14 @@ class AkzExchange:
         cur = self._torch.cuda.current_stream()
         self._lib.check(self._lib.lib().akz_comm_shift_blocks(
             self._h, descs.data_ptr(), counts.data_ptr(), descs.shape[0], descs.shape[1], recv_descs.data_ptr(),
-            recv_counts.data_ptr(), cur.cuda_stream), "akz_comm_shift_blocks")
+            recv_counts.data_ptr(), self._lib.wait_handle(cur)), "akz_comm_shift_blocks")
         self._after()
 
     def allgather(self, descs, counts, all_descs, all_counts):
         cur = self._torch.cuda.current_stream()
         self._lib.check(self._lib.lib().akz_comm_allgather_blocks(
             self._h, descs.data_ptr(), counts.data_ptr(), descs.shape[0], descs.shape[1], all_descs.data_ptr(),
-            all_counts.data_ptr(), cur.cuda_stream), "akz_comm_allgather_blocks")
+            all_counts.data_ptr(), self._lib.wait_handle(cur)), "akz_comm_allgather_blocks")
         self._after()
 
     def exposed(self):

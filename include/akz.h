@@ -52,6 +52,13 @@ typedef struct akz_config {
     uint64_t descriptor_pattern_size; /* 10 */
 } akz_config;
 
+/* `stream_to_wait` arguments (a hipStream_t passed as void*): the stream that produced the call's device inputs; the
+ * library's stream waits for the work enqueued on it so far.  NULL = nothing to wait for.  The legacy default stream's
+ * own handle is NULL as well, so a caller that enqueues on it (torch without a stream context, plain `<<<>>>` launches)
+ * passes AKZ_STREAM_LEGACY — the value of hipStreamLegacy — instead: the library's streams are non-blocking and do NOT
+ * synchronise with the default stream on their own. */
+#define AKZ_STREAM_LEGACY ((void*)1)
+
 /* akaze::KeyPoint — akaze/src/lib.rs:69-93. point=(x,y). 28 bytes, no padding. */
 typedef struct akz_keypoint {
     float x, y;

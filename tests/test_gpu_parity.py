@@ -235,7 +235,7 @@ def test_pipelined_device_calls_match_host_api(gpu):
         for k in range(NCALL):
             _lib.check(L.akz_extract_batch_device(ctx.handle, d_frames[k * B:(k + 1) * B].data_ptr(), 0, B, W, H,
                                                   kps[k].data_ptr(), descs[k].data_ptr(), CAP, cnt[k].data_ptr(),
-                                                  cur.cuda_stream), "extract")
+                                                  _lib.wait_handle(cur)), "extract")
         _lib.check(L.akz_sync(ctx.handle), "sync")
         outs.append((kps.cpu().numpy(), descs.cpu().numpy(), cnt.cpu().numpy()))
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
@@ -430,7 +430,7 @@ def test_knn_views_device(gpu, oracle):
     idx = (C.c_uint32 * 3)(*sel)
     L = _lib.lib()
     _lib.check(L.hm_knn_views_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_views.data_ptr(), d_nv.data_ptr(), cap,
-                                     idx, 3, 3, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn_views")
+                                     idx, 3, 3, out.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())), "knn_views")
     _lib.check(L.hm_sync(m.handle), "hm_sync")
     got = out.cpu().numpy()
     for j, v in enumerate(sel):
@@ -486,7 +486,7 @@ def test_knn_batch_device(gpu, oracle):
         out = torch.full((len(iq), cap, k, 2), -1, dtype=torch.int32, device=dev)
         _lib.check(L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap,
                                          (C.c_uint32 * len(iq))(*iq), (C.c_uint32 * len(it))(*it), len(iq), k, out.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream), "knn_batch")
+                                         _lib.wait_handle(torch.cuda.current_stream())), "knn_batch")
         _lib.check(L.hm_sync(m.handle), "hm_sync")
         got = out.cpu().numpy()
         for p, (a, b) in enumerate(zip(iq, it)):
@@ -546,7 +546,7 @@ def test_registration_matching_of_a_micro_batch(gpu, oracle):
     m = knn.Matcher(cap)
     u32p = lambda a: np.ascontiguousarray(a, np.uint32).ctypes.data_as(C.c_void_p)
     _lib.check(L.hm_knn_batch_device(m.handle, d_q.data_ptr(), d_nq.data_ptr(), d_t.data_ptr(), d_nt.data_ptr(), cap, u32p(iq), u32p(it),
-                                     F * V, k, d_knn.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn_batch")
+                                     F * V, k, d_knn.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())), "knn_batch")
     fr = np.arange(F, dtype=np.uint32)
     for better_by in (24, 1):
         _lib.check(L.hm_best_of_views_batch_device(m.handle, d_knn.data_ptr(), d_nq.data_ptr(), u32p(fr), cap, u32p(views), F, V, k,
@@ -624,7 +624,7 @@ def test_place_recognition_hash_and_search(gpu, oracle, kitti_golden):
     L = _lib.lib()
     for _ in range(2):                                    # the second call reuses the staging ring
         _lib.check(L.hm_hash_bag_device(m.handle, d_blocks.data_ptr(), d_counts.data_ptr(), cap, nf, d_cw.data_ptr(), 4096,
-                                        d_hash.data_ptr(), d_words.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                        d_hash.data_ptr(), d_words.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())),
                    "hash_bag_device")
     _lib.check(L.hm_sync(m.handle), "hm_sync")
     got_h, got_w = d_hash.cpu().numpy(), d_words.cpu().numpy()
@@ -1163,7 +1163,7 @@ def test_benchmark_mode_full_hd_pipelined_vs_oracle(gpu, resident):
     for k in range(NCALL):
         _lib.check(L.akz_extract_batch_device(ctx.handle, d_frames[k * B:(k + 1) * B].data_ptr(), 0, B, W, H,
                                               kps[k].data_ptr(), descs[k].data_ptr(), CAP, cnt[k].data_ptr(),
-                                              cur.cuda_stream), "extract")
+                                              _lib.wait_handle(cur)), "extract")
     _lib.check(L.akz_sync(ctx.handle), "sync")
     kps, descs, cnt = kps.cpu().numpy(), descs.cpu().numpy(), cnt.cpu().numpy()
     for k in range(NCALL):
@@ -2204,12 +2204,12 @@ def test_comm_c_abi_on_one_rank(gpu):
         _lib.check(L.akz_comm_timing(h, 1, None, None, None, 1), "timing")
         cur = torch.cuda.current_stream()
         _lib.check(L.akz_comm_shift_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, rd[1:].data_ptr(), rc[1:].data_ptr(),
-                                           cur.cuda_stream), "akz_comm_shift_blocks")
+                                           _lib.wait_handle(cur)), "akz_comm_shift_blocks")
         ad = torch.zeros((1, n, cap, 64), dtype=torch.uint8, device=dev)
         ac = torch.zeros((1, n), dtype=torch.int32, device=dev)
         # (the zero fills run on torch's stream, the gather on the communicator's: it waits for them)
         _lib.check(L.akz_comm_allgather_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, ad.data_ptr(), ac.data_ptr(),
-                                               cur.cuda_stream), "akz_comm_allgather_blocks")
+                                               _lib.wait_handle(cur)), "akz_comm_allgather_blocks")
         _lib.check(L.akz_comm_sync(h), "akz_comm_sync")
         assert torch.equal(rd[1:n + 1], descs) and torch.equal(rc[1:n + 1], counts)
         assert bool((rd[0] == 7).all()) and bool((rd[n + 1] == 7).all()) and int(rc[0]) == -1 and int(rc[n + 1]) == -1
@@ -2217,6 +2217,19 @@ def test_comm_c_abi_on_one_rank(gpu):
         ms, calls, nbytes = C.c_double(), C.c_uint64(), C.c_uint64()
         _lib.check(L.akz_comm_timing(h, 0, C.byref(ms), C.byref(calls), C.byref(nbytes), 1), "timing")
         assert calls.value == 2 and nbytes.value == 2 * n * (cap * 64 + 4) and ms.value > 0.0
+        # the caller's stream here is the LEGACY DEFAULT stream, whose handle is 0 = "nothing to wait for" in the ABI:
+        # _lib.wait_handle() names it AKZ_STREAM_LEGACY instead.  (Passed as 0, the fills below raced the gather — one
+        # run in five of this test failed on `ac`.)  A long fill directly before every call makes the order visible.
+        assert _lib.wait_handle(cur) == _lib.STREAM_LEGACY or cur.cuda_stream != 0
+        big = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+        for rep in range(24):
+            big.fill_(rep)                                      # ~10 us of work ahead of the fills on the caller's stream
+            ad.fill_(rep & 0xFF)
+            ac.fill_(-rep - 1)
+            _lib.check(L.akz_comm_allgather_blocks(h, descs.data_ptr(), counts.data_ptr(), n, cap, ad.data_ptr(), ac.data_ptr(),
+                                                   _lib.wait_handle(cur)), "akz_comm_allgather_blocks")
+            _lib.check(L.akz_comm_sync(h), "akz_comm_sync")
+            assert torch.equal(ad[0], descs) and torch.equal(ac[0], counts), rep
         # refusals
         assert L.akz_comm_shift_blocks(h, None, counts.data_ptr(), n, cap, rd.data_ptr(), rc.data_ptr(), None) == -1
         assert L.akz_comm_create(ident, 1, 1, 0, C.byref(C.c_void_p())) == -1

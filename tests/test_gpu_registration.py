@@ -71,7 +71,7 @@ def test_registration_chain_of_a_micro_batch(gpu, oracle):
     d_descs = torch.zeros((NB, CAP, 64), dtype=torch.uint8, device=dev)
     d_counts = torch.zeros((NB,), dtype=torch.int32, device=dev)
     _lib.check(L.akz_extract_batch_device(ctx.handle, d_frames.data_ptr(), 0, NB, W, H, d_kps.data_ptr(), d_descs.data_ptr(), CAP,
-                                          d_counts.data_ptr(), torch.cuda.current_stream().cuda_stream), "extract")
+                                          d_counts.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())), "extract")
     _lib.check(L.akz_sync(ctx.handle), "akz_sync")
     counts = d_counts.cpu().numpy()
     assert counts.min() > 300, counts
@@ -98,7 +98,7 @@ def test_registration_chain_of_a_micro_batch(gpu, oracle):
     view_blocks = [[V + f - 1 - v for v in range(V)] for f in range(F)]
     for rep in range(2):        # twice: the second call runs over the first one's leftovers
         reg.enqueue(d_kps, d_descs, d_counts, frame_blocks, view_blocks, d_lm, d_world, n_world,
-                    stream_to_wait=torch.cuda.current_stream().cuda_stream)
+                    stream_to_wait=_lib.wait_handle(torch.cuda.current_stream()))
     reg.sync()
     g_hash = reg.hash.cpu().numpy(); g_knn = reg.knn.cpu().numpy(); g_best = reg.best.cpu().numpy().view(np.uint32)
     g_dec = reg.decision.cpu().numpy().view(np.uint32); g_pairs = reg.pairs.cpu().numpy().view(np.uint32)
@@ -174,7 +174,7 @@ def test_landmark_pairs_rules(gpu, oracle):
     L = _lib.lib()
     _lib.check(L.hm_landmark_pairs_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p),
                                                 cap, F, d_world.data_ptr(), n_world, d_pairs.data_ptr(), d_np.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream), "landmark_pairs")
+                                                _lib.wait_handle(torch.cuda.current_stream())), "landmark_pairs")
     _lib.check(L.hm_sync(m.handle), "hm_sync")
     gp = d_pairs.cpu().numpy().view(np.uint32); gn = d_np.cpu().numpy()
     total = 0
@@ -233,7 +233,7 @@ def test_landmark_matches_with_merge_candidates(gpu, oracle):
         d_pairs = torch.full((F, cap, 2), -1, dtype=torch.int32, device=dev); d_np = torch.full((F,), 77, dtype=torch.int32, device=dev)
         _lib.check(L.hm_landmark_matches_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), None if mask is None else mask.data_ptr(),
                                                       d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p), cap, F, d_world.data_ptr(), n_world,
-                                                      d_pairs.data_ptr(), d_np.data_ptr(), torch.cuda.current_stream().cuda_stream), "landmark_matches")
+                                                      d_pairs.data_ptr(), d_np.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())), "landmark_matches")
         _lib.check(L.hm_sync(m.handle), "hm_sync")
         return d_pairs.cpu().numpy().view(np.uint32), d_np.cpu().numpy()
     gp, gn = run(d_ok)
@@ -260,7 +260,7 @@ def test_landmark_matches_with_merge_candidates(gpu, oracle):
         d_pairs = torch.full((F, cap, 2), -1, dtype=torch.int32, device=dev); d_np = torch.full((F,), 77, dtype=torch.int32, device=dev)
         _lib.check(L.hm_landmark_matches_ordered_batch_device(m.handle, d_best.data_ptr(), d_dec.data_ptr(), d_ok.data_ptr(), d_obs.data_ptr(),
                                                               d_nq.data_ptr(), iq.ctypes.data_as(C.c_void_p), cap, F, d_world.data_ptr(), n_world,
-                                                              d_pairs.data_ptr(), d_np.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                                              d_pairs.data_ptr(), d_np.data_ptr(), _lib.wait_handle(torch.cuda.current_stream())),
                    "landmark_matches_ordered")
         _lib.check(L.hm_sync(m.handle), "hm_sync")
         op, on = d_pairs.cpu().numpy().view(np.uint32), d_np.cpu().numpy()

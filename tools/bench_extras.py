@@ -118,7 +118,7 @@ def extra_pipeline_verify(torch, dev, L, _lib, args, step, step_no, barrier, ver
         cons.model_inliers_batch_device(kps2[p].data_ptr(), kps2[p].data_ptr(), CAP, js, prev_js, pairs2[p][m0:].data_ptr(),
                                         npairs2[p][m0:].data_ptr(), c, c, prm, pose2[p][m0:].data_ptr(), best2[p][m0:].data_ptr(),
                                         inl2[p][m0:].data_ptr(), ninl2[p][m0:].data_ptr(), stats2[p][m0:].data_ptr(),
-                                        shuffle=True, stream_to_wait=hm_stream.cuda_stream)
+                                        shuffle=True, stream_to_wait=_lib.wait_handle(hm_stream))
         calls[(p, m0)] = (list(js), list(prev_js))
         if m0 + MB >= NF:
             verify_done[p].record(rs_stream)
@@ -231,7 +231,7 @@ def extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB):
         for m0 in range(0, NF, MB):
             _lib.check(L.akz_extract_batch_device(ctx.handle, frames[m0:m0 + MB].data_ptr(), 0, MB, W, H, kps2[p][m0:m0 + MB].data_ptr(),
                                                   descs2[p][m0:m0 + MB].data_ptr(), CAP, counts2[p][m0:m0 + MB].data_ptr(),
-                                                  cur.cuda_stream), "extract")
+                                                  _lib.wait_handle(cur)), "extract")
         # the caller's bookkeeping: which landmark every feature of every stored view observes
         glue.wait_stream(akz_s)
         with torch.cuda.stream(glue):
@@ -240,7 +240,7 @@ def extra_pipeline_register(torch, dev, L, _lib, args, ctx, frames, NF, MB):
             cy = torch.clamp(torch.floor((k[..., 1] + 2.0 * gidx) / CELL), 0, hc - 1).to(torch.int32)
             cls = kps2[p].view(torch.int32).view(NF, CAP, 7)[..., 6] & 15
             lm2[p].copy_((cy * wc + cx) * 16 + cls)
-        reg.enqueue(kps2[p], descs2[p], counts2[p], frame_blocks, view_blocks, lm2[p], d_world, n_world, stream_to_wait=glue.cuda_stream)
+        reg.enqueue(kps2[p], descs2[p], counts2[p], frame_blocks, view_blocks, lm2[p], d_world, n_world, stream_to_wait=_lib.wait_handle(glue))
         done[p].record(rs_s)
         n[0] += 1
 
