@@ -749,6 +749,26 @@ __device__ __forceinline__ int sup_level(const uint32_t* base, int nlev, uint32_
     return e;
 }
 
+// s_base[e] = candidates of the levels before e (s_base[nlev] = all of them), by the block's first wave: one load per
+// level in parallel and a wave scan (a single thread walking the levels paid one L2 round trip per level — ~16 us at
+// the head of every block).  Every thread of the block calls it; followed by a barrier.
+__device__ __forceinline__ void sup_level_bases(uint32_t* s_base, const uint32_t* __restrict__ ncand_frame, int nlev,
+                                                uint32_t max_cand)
+{
+    static_assert(kMaxLevels <= 64, "one wave scans the levels");
+    if (threadIdx.x >= 64) return;
+    const int lane = (int)threadIdx.x;
+    const uint32_t v = lane < nlev ? min(ncand_frame[lane], max_cand) : 0u;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane < nlev) s_base[lane] = inc - v;
+    if (lane == nlev - 1) s_base[nlev] = inc;
+    if (nlev == 0 && lane == 0) s_base[0] = 0u;
+}
+
 // Row-start table of a raster-sorted candidate list: rows[y] = the first candidate whose row is >= y, for y in [0, h]
 // (rows[h] = the list's length).  k_sup_adj bounds its scans with two look-ups instead of a twelve-step bisection of
 // the list (every step an L2 round trip).
@@ -775,17 +795,10 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
 {
     __shared__ uint32_t s_base[kMaxLevels + 1];
     const int frame = blockIdx.y;
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int e = 0; e < T.n; ++e) {
-            s_base[e] = acc;
-            acc += min(ncand[(size_t)frame * kAkzMaxLevels + e], max_cand);
-        }
-        s_base[T.n] = acc;
-        if (acc > cap && blockIdx.x == 0) fallback[frame] = 1u;
-    }
+    sup_level_bases(s_base, ncand + (size_t)frame * kAkzMaxLevels, T.n, max_cand);
     __syncthreads();
     const uint32_t N = s_base[T.n];
+    if (N > cap && blockIdx.x == 0 && threadIdx.x == 0) fallback[frame] = 1u;
     if (N > cap) return;
     const SupFrame F = sup_frame(scratch, cap, frame, gridDim.y);
     const uint2* cd = cand + (size_t)frame * kAkzMaxLevels * max_cand;
@@ -802,6 +815,12 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
     F.state[g] = make_uint2(kSupNone, kSupNone);
     uint32_t cnt = 0;
     bool over = false;
+    // the first kHits neighbours wait in registers: their reverse-list counters are then bumped by atomics that are all in
+    // flight together (one round trip instead of one per neighbour: the hits were half of the kernel's time)
+    constexpr uint32_t kHits = 6;
+    uint32_t hits[kHits];
+#pragma unroll
+    for (uint32_t q = 0; q < kHits; ++q) hits[q] = 0u;
     for (int Lv = (e > 0 ? e - 1 : 0); Lv <= e; ++Lv) {
         const float rl = ldexpf(1.0f, (int)T.L[Lv].octave);
         const float hoff = 0.5f * (rl - 1.0f);
@@ -822,6 +841,13 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
             const float dx = fx - kx, dy = fy - ky;
             if (dx * dx + dy * dy <= size2) {
                 const uint32_t nidx = s_base[Lv] + j;
+                if (cnt < kHits) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kHits; ++q)
+                        if (cnt == q) hits[q] = nidx;
+                    ++cnt;
+                    return;
+                }
                 if (cnt < (uint32_t)kSupDeg) F.adj[(size_t)g * kSupDeg + cnt] = nidx;
                 else over = true;
                 ++cnt;
@@ -830,16 +856,35 @@ __global__ __launch_bounds__(256) void k_sup_adj(LevelTable T, const uint32_t* _
                 else over = true;
             }
         };
-        // (four entries requested before the first is looked at: the scan is a chain of L2 round trips otherwise)
-        for (uint32_t j = a; j < b; j += 4) {
-            uint32_t xy[4];
+        // (the scan is a chain of memory round trips otherwise: eight entries are requested at a time, and the next eight
+        // before the first of these is looked at)
+        constexpr uint32_t kB = 8;
+        uint32_t cur[kB], nxt[kB];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) xy[q] = lst[min(j + q, b - 1u)].x;
+        for (uint32_t q = 0; q < kB; ++q) cur[q] = a + q < b ? lst[a + q].x : 0u;
+        for (uint32_t j = a; j < b; j += kB) {
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q)
-                if (j + q < b) test(xy[q], j + q);
+            for (uint32_t q = 0; q < kB; ++q) nxt[q] = j + kB + q < b ? lst[j + kB + q].x : 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < kB; ++q)
+                if (j + q < b) test(cur[q], j + q);
+#pragma unroll
+            for (uint32_t q = 0; q < kB; ++q) cur[q] = nxt[q];
         }
     }
+    static_assert(kHits <= (uint32_t)kSupDeg, "the registers hold a prefix of the list");
+    uint32_t rpos[kHits];
+#pragma unroll
+    for (uint32_t q = 0; q < kHits; ++q)
+        if (q < cnt) F.adj[(size_t)g * kSupDeg + q] = hits[q];
+#pragma unroll
+    for (uint32_t q = 0; q < kHits; ++q) rpos[q] = q < cnt ? atomicAdd(&F.nradj[hits[q]], 1u) : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < kHits; ++q)
+        if (q < cnt) {
+            if (rpos[q] < (uint32_t)kSupDeg) F.radj[(size_t)hits[q] * kSupDeg + rpos[q]] = g;
+            else over = true;
+        }
     F.nadj[g] = min(cnt, (uint32_t)kSupDeg);
     if (over) fallback[frame] = 1u;
     }
@@ -863,14 +908,7 @@ __global__ __launch_bounds__(1024) void k_sup_resolve(LevelTable T, const uint32
     const int frame = blockIdx.y;
     if (fallback[frame]) return;                 // k_suppress takes this frame
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int e = 0; e < T.n; ++e) {
-            s_base[e] = acc;
-            acc += min(ncand[(size_t)frame * kAkzMaxLevels + e], max_cand);
-        }
-        s_base[T.n] = acc;
-    }
+    sup_level_bases(s_base, ncand + (size_t)frame * kAkzMaxLevels, T.n, max_cand);
     __syncthreads();
     const uint32_t N = s_base[T.n];
     const uint32_t nchunks = (N + 1023u) / 1024u;

@@ -415,10 +415,10 @@ __global__ __launch_bounds__(256) void k_expand4(const HmExpandJob* __restrict__
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint32_t b = (bits >> (8 * g)) & 0xFFu;
-        // spread 8 bits to 8 nibbles (bit i -> bit 4 i)
-        uint32_t sp = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sp |= (b & (1u << i)) << (3 * i);
+        // spread 8 bits to 8 nibbles (bit i -> bit 4 i): halves, pairs, single bits
+        uint32_t sp = (b | (b << 12)) & 0x000F000Fu;
+        sp = (sp | (sp << 6)) & 0x03030303u;
+        sp = (sp | (sp << 3)) & 0x11111111u;
         ow[g] = 0xAAAAAAAAu ^ (sp << 3);                 // set bit -> clear the sign: 0xA -> 0x2
     }
     reinterpret_cast<uint4*>(J.dst + (size_t)d * 64)[wd] = o;
