@@ -1953,15 +1953,18 @@ __global__ __launch_bounds__(64 * kODWaves, kODOcc) void k_orient_describe(Level
     __shared__ __attribute__((aligned(16))) float s_w[kODWaves][3 * SMAX + 1];     // (+ 1: every wave's segment 16-byte aligned)
     const OriTables& c_ori = *ori_p;
     const DescTables& c_desc = *desc_p;
-    if (threadIdx.x < 128) s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
-    const uint2* __restrict__ m_tab = c_ori.m_tab;
     const uint2 blk = xcd_block2(blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
     const int frame = (int)blk.y;
+    // the grid covers the list's capacity: a block past the frame's count (two in five at 5 000 of 8 192) leaves before it
+    // stages anything
+    const uint32_t n = min(n_in[frame], stride);
+    if (blk.x * kODWaves >= n) return;   // whole block
+    if (threadIdx.x < 128) s_bnd[threadIdx.x] = c_ori.bnd[threadIdx.x];
+    const uint2* __restrict__ m_tab = c_ori.m_tab;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t vi = blk.x * kODWaves + (uint32_t)wv;
     const size_t fbase = (size_t)frame * stride;
     __syncthreads();          // the only block-level barrier (the staged tables): waves are independent from here on
-    const uint32_t n = min(n_in[frame], stride);
     if (vi >= n) return;  // whole wave
     const uint32_t ki = perm[fbase + vi];  // spatially coherent visiting order
     const DevKp kp = kps[fbase + ki];
