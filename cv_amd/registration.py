@@ -47,7 +47,8 @@ class Registration:
             raise ValueError("the codeword count must be a positive multiple of 32")
         self.n_codewords = len(cw)
         self.d_codewords = torch.from_numpy(cw).to(self.dev)
-        self.matcher = Matcher(max(cap, self.n_codewords), device=device)
+        # (bulk work: least urgent, so that the consensus' chain of small launches — most urgent, rs_create — finds compute units)
+        self.matcher = Matcher(max(cap, self.n_codewords), device=device, low_priority=True)
         n_max = max_matches or cap
         blocks = (n_max + block_size - 1) // block_size
         self.cons = EssentialConsensus(n_max, n_hypotheses + estimations_per_block * blocks, device=device)
