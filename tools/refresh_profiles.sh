@@ -9,7 +9,7 @@
 #   <tag>_bench.json              the line of `python bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r05}
+T=${1:-r06}
 MB=${2:-256}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
