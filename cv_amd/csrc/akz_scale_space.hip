@@ -48,10 +48,14 @@ constexpr bool kArithHalfSeq = (AKZ_ARITH & 4) != 0;
 
 constexpr int kTW = 64;  // output tile width  (one wave wide: a wave reads/writes one contiguous row segment)
 constexpr int kTH = 32;  // output tile height
-constexpr int kFTH = 24; // row tile of the contrast passes (24 rows x 512 threads, 9 tiles per block)
+constexpr int kFTH = 32; // row tile of the contrast passes: 32 rows x 512 threads, every thread a 4-pixel patch in the gradient phase
+                         // (24 rows — three blocks of 53 KB per CU instead of two of 62 — left a quarter of the threads idle there:
+                         // 1 543 vs 1 328 us per 256 frames once the fine histogram had joined the block's LDS)
 constexpr int kDTH = 12; // output tile height of the two-frame determinant kernel
-constexpr int kCTiles = 9; // row tiles per block of the contrast passes
-constexpr int kFNT = 512; // its block size: 3 blocks x 8 waves per CU
+constexpr int kCTiles = 17; // row tiles per block of the contrast passes in a batch (17 x 32 rows: two blocks per 1080p column;
+                           // 5 / 9 / 12 / 17 tiles: 1 452 / 1 377 / 1 340 / 1 328 us); a few-frame call takes kCTilesFew
+constexpr int kCTilesFew = 4; // ... so that one frame still fills the chip (1080p: 30 x 9 blocks)
+constexpr int kFNT = 512; // its block size: 2 blocks x 8 waves per CU
 
 enum { EPI_BLUR = 0, EPI_FLOW = 1, EPI_CMAX = 2, EPI_CHIST = 3 };
 
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
                                                         GaussTaps taps, unsigned long long* __restrict__ cmax,
                                                         const double* __restrict__ thr, uint32_t* __restrict__ hist,
                                                         uint32_t* __restrict__ npoints, int nbins,
-                                                        uint32_t* __restrict__ fine, const uint32_t* __restrict__ flag)
+                                                        uint32_t* __restrict__ fine, const uint32_t* __restrict__ flag, int ctiles)
 {
     constexpr int R = 2, SG = 1, TH = kFTH, NT = kFNT;
     constexpr int CI = kTW + 16, CG = kTW + 8;
@@ -773,16 +777,16 @@ __global__ __launch_bounds__(kFNT) void k_contrast_pair(const InT* __restrict__ 
         inv_hmax[0] = 1.0f / sqrtf((float)__longlong_as_double((long long)cmax[fa]));
         inv_hmax[1] = 1.0f / sqrtf((float)__longlong_as_double((long long)cmax[fb]));
     }
-    // kCTiles vertically adjacent tiles per block: the per-frame maximum / histogram is flushed to HBM once
+    // ctiles vertically adjacent tiles per block: the per-frame maximum / histogram is flushed to HBM once
     // per block, and with one flush per tile the device-scope atomics on the 300 bins of a frame (1350 blocks
     // each) took as long as the arithmetic (rocprof: 850 us vs 405 us for the max pass)
     PairTileRegs<R, SG, TH, NT, InT> regs;
-    if (tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)tile.y * kCTiles * TH);
-    for (int it = 0; it < kCTiles; ++it) {
-    const int ty0 = ((int)tile.y * kCTiles + it) * TH;
+    if (tx0 >= 8 && tx0 + kTW + 8 <= w) regs.fetch(in, w, h, fs, fa, fb, tx0, (int)tile.y * ctiles * TH);
+    for (int it = 0; it < ctiles; ++it) {
+    const int ty0 = ((int)tile.y * ctiles + it) * TH;
     if (ty0 >= h) break;
     if (it) __syncthreads();                     // the previous tile's readers are done with s_a
-    const int ty1 = (it + 1 < kCTiles && ty0 + TH < h) ? ty0 + TH : -1;
+    const int ty1 = (it + 1 < ctiles && ty0 + TH < h) ? ty0 + TH : -1;
     pair_blur_tile<R, SG, TH, NT, InT>(in, w, h, fs, fa, fb, tx0, ty0, ty1, taps, regs, s_a, s_h);   // ends with a barrier
     for (int idx = tid; idx < TH * (kTW / 4); idx += NT) {
         const int q = idx / (kTW / 4), c = idx - q * (kTW / 4);
@@ -3132,10 +3136,11 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
     akz_timer_begin(c, AKZ_T_CONTRAST, s);
     const bool fine = pairc && c->contrast_fine;
     if (pairc) {
-        dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), kCTiles), (n + 1) / 2);
+        const int ctiles = n <= kLatencyFrames ? kCTilesFew : kCTiles;
+        dim3 gridc(akz_div_up(w, kTW), akz_div_up(akz_div_up(h, kFTH), ctiles), (n + 1) / 2);
         AKZ_LAUNCH((k_contrast_pair<InT, EPI_CMAX>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
                            (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, fine ? S.d_fine : (uint32_t*)nullptr,
-                           (const uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, ctiles);
         AKZ_LAUNCH_CHECK();
         AKZ_LAUNCH(k_contrast_thresholds, dim3(n), dim3(512), 0, s, S.d_cmax, nbins, S.d_cthr);
         AKZ_LAUNCH_CHECK();
@@ -3147,7 +3152,7 @@ static int32_t scale_space_impl(akz_ctx* c, const InT* d_imgs, int n)
         }
         AKZ_LAUNCH((k_contrast_pair<InT, EPI_CHIST>), gridc, dim3(kFNT), 0, s, d_imgs, w, h, P0, n, t1, S.d_cmax,
                            (const double*)S.d_cthr, S.d_hist, S.d_npoints, nbins, (uint32_t*)nullptr,
-                           fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr);
+                           fine ? (const uint32_t*)S.d_cflag : (const uint32_t*)nullptr, ctiles);
         AKZ_LAUNCH_CHECK();
     } else {
         AKZ_TRY((launch_blur<2, 1, InT, EPI_CMAX>(c, d_imgs, w, h, P0, t1, nullptr, nullptr, 0, 0, n)));
