@@ -11,5 +11,6 @@ cp gpurun_out/pmc_sq_summary.txt profiles/${T}_pmc_sq_summary.txt
 cp gpurun_out/kstat_final.txt profiles/${T}_kstat_serial_64frames.txt
 (grep -i "single\|alone" gpurun_out/lat_plain.txt; cat gpurun_out/lat_trace.txt) > profiles/${T}_single_frame_timeline.txt
 [ -f gpurun_out/register_kernel_stats.txt ] && cp gpurun_out/register_kernel_stats.txt profiles/${T}_register_kernel_stats.txt
+[ -f gpurun_out/gputest_${T}.log ] && tail -12 gpurun_out/gputest_${T}.log > profiles/${T}_gputest.txt
 [ -f gpurun_out/stress_${T}.txt ] && cp gpurun_out/stress_${T}.txt profiles/${T}_stress_parity.txt
 ls -la profiles | grep ${T}_
