@@ -326,3 +326,19 @@ def test_compiled_form_of_the_kernels_the_compiler_can_ruin():
     build.build()
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_experiment_patches_still_apply():
+    """tools/variants/*.patch put experiment knobs, profilers and measured-and-rejected kernels back into the shipped sources
+    (docs/EXPERIMENTS.md cites them): each must still apply to the tree it sits in."""
+    import glob
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("git") is None:
+        pytest.skip("no git")
+    patches = sorted(glob.glob(os.path.join(root, "tools", "variants", "*.patch")))
+    assert len(patches) >= 5
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(p), r.stderr[-400:])
