@@ -443,7 +443,11 @@ __global__ __launch_bounds__(256) void k_filter_upper(const DevKp* __restrict__ 
                                                       uint32_t* __restrict__ flag)
 {
     __shared__ uint32_t s_P[kMaxLevels + 2];
-    __shared__ float2 s_yr[kAkzMaxKeypoints / 64];   // {ymin, ymax} of chunk (cb0 + k)
+    // {ymin, ymax} of chunk (cb0 + k): yr_stride entries of dynamic LDS — 1 KB at 8 192 keypoints a frame, not the 32 KB of the
+    // largest context (which held the kernel to four blocks per CU: it waits on memory, and runs 185 -> ~100 us per 256 frames
+    // with twice the waves)
+    extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
+    float2* s_yr = reinterpret_cast<float2*>(s_dyn);
     __shared__ uint32_t s_range[2];
     const int frame = blockIdx.y;
     const uint32_t n = min(ncache[frame], max_kp);
@@ -2378,7 +2382,7 @@ int32_t akz_run_keypoints(akz_ctx* c, int n, DevKp* d_kps, akz_descriptor* d_des
     hipLaunchKernelGGL(k_chunk_yrange, dim3((uint32_t)akz_div_up((int)yr_stride, 4), n), dim3(256), 0, s, S.d_cache, c->max_kp,
                        S.d_ncache, yr_tab, yr_stride);
     AKZ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), 0, s, S.d_cache, c->max_kp, S.d_ncache,
+    hipLaunchKernelGGL(k_filter_upper, dim3(kb, n), dim3(256), sizeof(float2) * (size_t)yr_stride, s, S.d_cache, c->max_kp, S.d_ncache,
                        (const uint32_t*)S.d_lvl_slot, T.n, (const float2*)yr_tab, yr_stride, S.d_flag_b);
     AKZ_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_compact<false>), dim3(n), dim3(1024), 0, s, S.d_cache, (const akz_descriptor*)nullptr,
