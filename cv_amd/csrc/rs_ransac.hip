@@ -907,7 +907,12 @@ struct RsPrune {
 // One workgroup per scene.  The cap ranks the poses by their exact distance to the best count: a 2048-bin histogram of
 // best - count (poses 2047 or more inliers behind the best share the last bin), so the best-supported poses are never
 // the ones the cap retires; ties at the threshold are admitted in ascending pose order while the budget lasts.
-__global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
+// Threads of the one-workgroup-per-scene kernels that sit in the block loop's chain of launches (prune, append, best inliers).
+// Four waves, not sixteen: while the matcher and the extraction fill the chip, a workgroup that needs sixteen free wave slots on
+// ONE compute unit waits for them at every launch of the chain (the registration leg of the bench: 122.4-122.8 ms per step at
+// 1 024 threads, 120.0-120.2 at 512, 119.9-120.0 at 256; loading more per pass at twice the registers made it 140).
+constexpr int kChainNT = 256;
+__global__ __launch_bounds__(kChainNT) void k_rsb_prune(RsB B, RsPrune P)
 {
     __shared__ uint32_t s_wave[16], s_wave_t[16];
     __shared__ uint32_t s_hist[2048];
@@ -920,10 +925,10 @@ __global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
     const uint32_t n = B.nalive[s];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_best = 0;
-    for (int i = threadIdx.x; i < 2048; i += 1024) s_hist[i] = 0;
+    for (int i = threadIdx.x; i < 2048; i += kChainNT) s_hist[i] = 0;
     __syncthreads();
     uint32_t lmax = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    for (uint32_t i = threadIdx.x; i < n; i += kChainNT) {
         const uint32_t c = counts[alive[i]];
         lmax = c > lmax ? c : lmax;
     }
@@ -932,7 +937,7 @@ __global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
     const uint32_t best = s_best, left = n_total - P.seen;
     const bool capped = P.cap && n > P.cap;
     if (capped) {
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        for (uint32_t i = threadIdx.x; i < n; i += kChainNT) {
             const uint32_t d = best - counts[alive[i]];
             atomicAdd(&s_hist[d < 2047u ? d : 2047u], 1u);
         }
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
         l_out = P.log_1m_delta - (P.log_table[P.seen - best] - P.log_table[P.seen]);     // per outlier (positive)
     }
     uint32_t base = 0, ties_before = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+    for (uint32_t i0 = 0; i0 < n; i0 += kChainNT) {
         const uint32_t i = i0 + threadIdx.x;
         bool keep = false, tie = false;
         uint32_t pid = 0;
@@ -985,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
         if (lane == 0) s_wave_t[wv] = (uint32_t)__popcll(tb);
         __syncthreads();
         uint32_t toff = 0, ttot = 0;
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < kChainNT / 64; ++q) {
             if (q < wv) toff += s_wave_t[q];
             ttot += s_wave_t[q];
         }
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(1024) void k_rsb_prune(RsB B, RsPrune P)
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t woff = 0, tot = 0;
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < kChainNT / 64; ++q) {
             if (q < wv) woff += s_wave[q];
             tot += s_wave[q];
         }
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_rsb_resample(RsB B, unsigned long long 
 
 // valid new poses join the live list in (hypothesis, pose) order — their ids exceed every id already in it — with
 // zeroed counters; first[s] receives the list length before the append
-__global__ __launch_bounds__(1024) void k_rsb_alive_append(RsB B, uint32_t base_pid, uint32_t n_new)
+__global__ __launch_bounds__(kChainNT) void k_rsb_alive_append(RsB B, uint32_t base_pid, uint32_t n_new)
 {
     __shared__ uint32_t s_wave[16];
     const uint32_t s = blockIdx.x;
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(1024) void k_rsb_alive_append(RsB B, uint32_t base_
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t old = B.nalive[s], on = B.enable[s];
     uint32_t base = old;
-    for (uint32_t i0 = 0; i0 < n_new; i0 += 1024) {
+    for (uint32_t i0 = 0; i0 < n_new; i0 += kChainNT) {
         const uint32_t i = i0 + threadIdx.x;
         const bool keep = on && i < n_new && ok[base_pid + i] != 0;
         if (i < n_new) counts[base_pid + i] = 0u;
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(1024) void k_rsb_alive_append(RsB B, uint32_t base_
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t woff = 0, tot = 0;
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < kChainNT / 64; ++q) {
             if (q < wv) woff += s_wave[q];
             tot += s_wave[q];
         }
@@ -1080,7 +1085,7 @@ struct RsOut {
 //              that order, into the arena's own list; scenes with no match left take no part (ninl = 0)
 //   final = 1  the answer: inliers over all matches in ascending match index, pose, id, stats -> O
 template <bool P3P>
-__global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit, uint32_t final_, double thresh, RsOut O)
+__global__ __launch_bounds__(kChainNT) void k_rsb_best_inliers(RsB B, uint32_t limit, uint32_t final_, double thresh, RsOut O)
 {
     __shared__ unsigned long long s_key[16];
     __shared__ uint32_t s_wave[16];
@@ -1097,7 +1102,7 @@ __global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit
     const uint32_t* alive = B.alive + B.p4(s);
     const uint32_t nal = B.nalive[s];
     unsigned long long key = 0ull;  // 0 = nothing alive
-    for (uint32_t i = threadIdx.x; i < nal; i += 1024) {
+    for (uint32_t i = threadIdx.x; i < nal; i += kChainNT) {
         const uint32_t pid = alive[i];
         const unsigned long long k = ((unsigned long long)(counts[pid] + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - pid);
         key = k > key ? k : key;
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit
     if (lane == 0) s_key[wv] = key;
     __syncthreads();
     key = s_key[0];
-    for (int i = 1; i < 16; ++i) key = s_key[i] > key ? s_key[i] : key;
+    for (int i = 1; i < kChainNT / 64; ++i) key = s_key[i] > key ? s_key[i] : key;
     const uint32_t pid = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : 0xFFFFFFFFu;
     if (threadIdx.x == 0) {
         B.best[4 * s + 0] = pid;
@@ -1149,7 +1154,7 @@ __global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit
     const double* bb = B.sb(s);
     const uint32_t* order = (!final_ && B.order) ? B.order + (size_t)s * B.n_cap : nullptr;
     uint32_t base = 0;
-    for (uint32_t m0 = 0; m0 < range; m0 += 1024) {
+    for (uint32_t m0 = 0; m0 < range; m0 += kChainNT) {
         const uint32_t pos = m0 + threadIdx.x;
         bool inl = false;
         uint32_t m = 0;
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(1024) void k_rsb_best_inliers(RsB B, uint32_t limit
         if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t woff = 0, tot = 0;
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < kChainNT / 64; ++q) {
             if (q < wv) woff += s_wave[q];
             tot += s_wave[q];
         }
@@ -1759,7 +1764,7 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
             P.log_delta = P.use_sprt ? log(prm->sprt_delta) : 0.0;
             P.log_1m_delta = P.use_sprt ? log(1.0 - prm->sprt_delta) : 0.0;
             P.log_ratio = P.use_sprt ? log(prm->sprt_ratio) : 0.0;
-            hipLaunchKernelGGL(k_rsb_prune, dim3(S), dim3(1024), 0, s, B, P);
+            hipLaunchKernelGGL(k_rsb_prune, dim3(S), dim3(kChainNT), 0, s, B, P);
             AKZ_LAUNCH_CHECK();
             if (P.cap && P.cap < live_bound) live_bound = P.cap;
             // a single survivor cannot be overtaken when nothing is re-sampled: the block loop ends (the specification's rule)
@@ -1767,7 +1772,7 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
             if (E && blocks >= prm->init_blocks) {
                 // inlier-guided re-sampling: list the inliers (matches seen so far) of the best survivor, draw E minimal
                 // samples among them, estimate, and let the valid poses join the live list after catching up on [0, seen)
-                hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(1024), 0, s, B, m_lo, 0u, prm->threshold, out_in);
+                hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(kChainNT), 0, s, B, m_lo, 0u, prm->threshold, out_in);
                 AKZ_LAUNCH_CHECK();
                 hipLaunchKernelGGL((k_rsb_resample<(int)K>), dim3((E + 255) / 256, S), dim3(256), 0, s, B, (unsigned long long)prm->seed,
                                    next_h, E);
@@ -1777,7 +1782,7 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
                 else
                     hipLaunchKernelGGL(k_rsb_hypotheses, dim3((E + 63) / 64, S), dim3(64), 0, s, B, next_h, E, (const uint32_t*)c->d_enable);
                 AKZ_LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_rsb_alive_append, dim3(S), dim3(1024), 0, s, B, next_h * 4, E * 4);
+                hipLaunchKernelGGL(k_rsb_alive_append, dim3(S), dim3(kChainNT), 0, s, B, next_h * 4, E * 4);
                 AKZ_LAUNCH_CHECK();
                 AKZ_TRY(score(0u, m_lo, 4 * E, 1u));
                 next_h += E;
@@ -1792,7 +1797,7 @@ static int32_t arrsac_engine(rs_ctx* c, uint32_t S, uint32_t n_max, const rs_arr
     O.blocks_run = blocks;
     O.block_size = prune ? prm->block_size : 0u;
     O.min_samples = K;
-    hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(1024), 0, s, B, 0u, 1u, prm->threshold, O);
+    hipLaunchKernelGGL((k_rsb_best_inliers<P3P>), dim3(S), dim3(kChainNT), 0, s, B, 0u, 1u, prm->threshold, O);
     AKZ_LAUNCH_CHECK();
     *blocks_run = blocks;
     *hyp_made = next_h;
