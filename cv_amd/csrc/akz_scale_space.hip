@@ -2589,7 +2589,10 @@ __global__ __launch_bounds__(256) void k_det_stream(const float2* __restrict__ L
     // the wave index is wave-uniform: tell the compiler, so the whole row walk (row numbers, clamps, row base
     // addresses, loop control) lives in SGPRs and on the scalar unit
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int frame = blockIdx.y;
+    // frames in DESCENDING order: the kernel runs right behind the front end that wrote this level's {Lx,Ly} frame by frame in
+    // ascending order, so the last frames written are what the 256 MB memory-side cache still holds — they are read first
+    // (the 4.2 GB of a full-size level do not fit; 9 117-9 147 vs 9 072-9 082 frames/s, three pairs on one box)
+    const int frame = (int)(gridDim.y - 1u - blockIdx.y);
     const int item = (int)blockIdx.x * 4 + wv;
     const int band = item % nbands, seg = item / nbands;
     const int ys = seg * seg_rows;
